@@ -1,0 +1,140 @@
+"""ctypes declarations for include/fdm_engine.h (libfdm_engine.so).
+
+Plumbing only: the product is the HIP library.  Loading fails loudly when the library
+has not been built — there is no Python or CPU fallback for any entry point.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfdm_engine.so")
+
+
+class FdmConfig(C.Structure):
+    """fdm_config == fastdem::Config for this path (config/fastdem.hpp:23-38)."""
+
+    _fields_ = [
+        ("z_min", C.c_float), ("z_max", C.c_float),
+        ("range_min", C.c_float), ("range_max", C.c_float),
+        ("sensor_type", C.c_int32),
+        ("lidar_range_noise", C.c_float), ("lidar_angular_noise", C.c_float),
+        ("rgbd_normal_a", C.c_float), ("rgbd_normal_b", C.c_float),
+        ("rgbd_normal_c", C.c_float), ("rgbd_lateral_factor", C.c_float),
+        ("constant_uncertainty", C.c_float),
+        ("mode", C.c_int32), ("estimation_type", C.c_int32),
+        ("kalman_min_variance", C.c_float), ("kalman_max_variance", C.c_float),
+        ("kalman_process_noise", C.c_float),
+        ("p2_dn", C.c_float * 5),
+        ("p2_elevation_marker", C.c_int32),
+        ("p2_max_sample_count", C.c_float),
+    ]
+
+
+class FdmGeometry(C.Structure):
+    _fields_ = [
+        ("length_x", C.c_double), ("length_y", C.c_double), ("resolution", C.c_double),
+        ("position_x", C.c_double), ("position_y", C.c_double),
+        ("rows", C.c_int32), ("cols", C.c_int32),
+        ("start_row", C.c_int32), ("start_col", C.c_int32),
+    ]
+
+
+class FdmTile(C.Structure):
+    _fields_ = [
+        ("row0", C.c_int32), ("col0", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
+        ("own_row0", C.c_int32), ("own_col0", C.c_int32),
+        ("own_rows", C.c_int32), ("own_cols", C.c_int32),
+    ]
+
+
+class FdmScanStats(C.Structure):
+    _fields_ = [
+        ("n_input", C.c_uint32), ("n_after_filter", C.c_uint32),
+        ("n_in_map", C.c_uint32), ("n_cells_touched", C.c_uint32),
+        ("shift_rows", C.c_int32), ("shift_cols", C.c_int32),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+SENSOR_CONSTANT, SENSOR_LIDAR, SENSOR_RGBD = 0, 1, 2
+MODE_LOCAL, MODE_GLOBAL = 0, 1
+EST_KALMAN, EST_P2 = 0, 1
+FDM_OK, FDM_SKIP_EMPTY_CLOUD, FDM_SKIP_ALL_FILTERED = 0, 1, 2
+
+_P = C.c_void_p
+_F = C.POINTER(C.c_float)
+_U = C.POINTER(C.c_uint32)
+_D = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes): every symbol include/fdm_engine.h declares
+PROTOTYPES = {
+    "fdm_default_config": (None, [C.POINTER(FdmConfig)]),
+    "fdm_last_error": (C.c_char_p, []),
+    "fdm_engine_create": (C.c_int, [C.POINTER(FdmGeometry), C.POINTER(FdmConfig),
+                                    C.POINTER(FdmTile), C.c_int, C.POINTER(_P)]),
+    "fdm_engine_destroy": (None, [_P]),
+    "fdm_engine_set_config": (C.c_int, [_P, C.POINTER(FdmConfig)]),
+    "fdm_engine_set_stream": (C.c_int, [_P, _P]),
+    "fdm_engine_integrate": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, _D, _D,
+                                       C.POINTER(FdmScanStats)]),
+    "fdm_engine_integrate_device": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, _D, _D]),
+    "fdm_engine_update": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, C.c_double,
+                                    C.c_double, C.POINTER(FdmScanStats)]),
+    "fdm_engine_update_device": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, C.c_double,
+                                           C.c_double]),
+    "fdm_engine_sync": (C.c_int, [_P]),
+    "fdm_engine_last_stats": (C.c_int, [_P, C.POINTER(FdmScanStats)]),
+    "fdm_engine_move": (C.c_int, [_P, C.c_double, C.c_double]),
+    "fdm_engine_get_geometry": (C.c_int, [_P, C.POINTER(FdmGeometry)]),
+    "fdm_engine_set_position": (C.c_int, [_P, C.c_double, C.c_double]),
+    "fdm_engine_set_start_index": (C.c_int, [_P, C.c_int32, C.c_int32]),
+    "fdm_engine_num_layers": (C.c_int, [_P]),
+    "fdm_engine_layer_name": (C.c_char_p, [_P, C.c_int]),
+    "fdm_engine_layer_exists": (C.c_int, [_P, C.c_char_p]),
+    "fdm_engine_layer_add": (C.c_int, [_P, C.c_char_p, C.c_float]),
+    "fdm_engine_layer_download": (C.c_int, [_P, C.c_char_p, _P, C.c_int32, C.c_int32]),
+    "fdm_engine_layer_upload": (C.c_int, [_P, C.c_char_p, _P, C.c_int32, C.c_int32]),
+    "fdm_engine_layer_device_ptr": (_P, [_P, C.c_char_p]),
+    "fdm_engine_clear": (C.c_int, [_P, C.c_char_p]),
+    "fdm_engine_region_pack": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.POINTER(C.c_char_p), C.c_int, _P]),
+    "fdm_engine_region_unpack": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           C.POINTER(C.c_char_p), C.c_int, _P]),
+    "fdm_engine_enable_cell_ids": (C.c_int, [_P, C.c_int]),
+    "fdm_engine_last_cell_ids": (C.c_int, [_P, _P, C.c_uint64]),
+    "fdm_engine_enable_profile": (C.c_int, [_P, C.c_int]),
+    "fdm_engine_last_kernel_ms": (C.c_int, [_P, _F]),
+    "fdm_engine_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libfdm_engine.so (after torch, so both share one HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950).  fastdem_amd has no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (loads torch's libamdhip64 first; ours resolves to the same soname)
+    except Exception:  # pragma: no cover - torch is plumbing, the library works without it
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError here == header/library drift
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def default_config():
+    cfg = FdmConfig()
+    load().fdm_default_config(C.byref(cfg))
+    return cfg

@@ -1,0 +1,380 @@
+// fdm_device.hpp — device-side arithmetic of the integrate() path (gfx950 only).
+//
+// Every function states the float/double evaluation ORDER it commits to, because
+// cell indices must be bit-exact against the reference semantics and the whole
+// translation unit is compiled with -ffp-contract=off (no FMA contraction;
+// HIP's default correctly-rounded fp32 div/sqrt and f32 denormals are kept).
+// Reference arithmetic being reproduced (file:line under /root/reference):
+//   Matrix4f * Vector4f      fastdem/lib/nanoPCL/include/nanopcl/core/transform.hpp:19-37
+//   cropRange / cropZ        fastdem/lib/nanoPCL/include/nanopcl/filters/impl/crop_impl.hpp:79-96,167-178
+//   sensor models            fastdem/include/fastdem/sensors/{sensor_model,lidar_model,rgbd_model}.hpp
+//   R*Sigma*R^T              fastdem/src/fastdem.cpp:182-187
+//   getIndex / move          nanoGrid (grid_map_core lineage), call sites elevation_mapping.cpp:55,113
+//   Kalman / P2              fastdem/include/fastdem/mapping/{kalman,quantile}_estimation.hpp
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fdm {
+
+constexpr float kFltMax = 3.402823466e+38f;
+constexpr uint64_t kEmptyKey = ~0ull;
+constexpr uint32_t kNoIdx = 0xFFFFFFFFu;
+constexpr int kShards = 64;  // sharded stat counters (same-address atomics serialise)
+
+// ---- device-resident map geometry: host never needs it between scans ----
+struct DevGeom {  // nanogrid position + circular-buffer start index
+  double px, py;
+  int sr, sc;
+  int pad0, pad1;
+};
+struct DevCand {  // geometry after the LOCAL-mode move of this scan + the index shift
+  double px, py;
+  int sr, sc;
+  int shr, shc;
+};
+struct DevFlags {
+  unsigned any_pass;    // some point survived cropRange+cropZ (fastdem.cpp:138)
+  unsigned any_inside;  // some point landed in the map (elevation_mapping.cpp:118)
+  unsigned pad0, pad1;
+};
+struct DevState {
+  DevGeom geom[4];   // ring: scan t reads geom[t&3], its update kernel writes geom[(t+1)&3]
+  DevCand cand[4];
+  DevFlags flags[4];
+  unsigned long long pass_inside[4][kShards];  // lo32 = n_after_filter, hi32 = n_in_map
+  unsigned touched[4][kShards];
+  unsigned sticky;  // bit0: intensity layer written, bit1: colour layer written
+  unsigned pad[3];
+};
+
+struct GeomConst {
+  double len_x, len_y, half_x, half_y, res;
+  int rows, cols;                      // global buffer size
+  int s_r0, s_c0, s_rows, s_cols;      // stored window (tile incl. halo)
+  int o_r0, o_c0, o_rows, o_cols;      // owned window (cells this engine updates)
+};
+
+struct ScanParams {
+  float Tbs[16], Twb[16];  // column-major, Isometry3d::matrix().cast<float>()
+  float R[9];              // column-major (T_wb*T_bs).rotation().cast<float>()
+  float min_sq, max_sq, z_min, z_max;
+  float sp[4];             // sensor-model parameters
+  double robot_x, robot_y;
+  unsigned n;
+  int slot;
+  int integrate_mode;  // 1 = FastDEM::integrate (transforms + crops), 0 = ElevationMapping::update
+  int do_move;         // LOCAL mode / explicit move
+  int gate_on_filter;  // integrate(): nothing happens when every point is filtered
+  int sensor_type;     // 0 Constant, 1 LiDAR, 2 RGBD
+  int has_intensity, has_color, has_var;
+};
+
+// ---- helpers ----
+__device__ __forceinline__ float sum3(float a0, float a1, float a2) { return a0 + (a1 + a2); }
+
+__device__ __forceinline__ void wrap_index(int& index, int size) {  // grid_map wrapIndexToRange
+  if (index < size) {
+    if (index >= 0) return;
+    if (index >= -size) { index += size; return; }
+    index = index % size;
+    index += size;
+  } else if (index < size * 2) {
+    index -= size;
+  } else {
+    index = index % size;
+  }
+}
+
+// monotone float -> uint32 (total order of finite floats; -0 < +0)
+__device__ __forceinline__ uint32_t ord(float f) {
+  const uint32_t b = __float_as_uint(f);
+  return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float unord(uint32_t u) {
+  return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
+// p <- T * p, Eigen SSE packet order: r = c0*x; r = c1*y + r; r = c2*z + r; r = c3*w + r.
+__device__ __forceinline__ void transform4(const float* __restrict__ T, float& x, float& y, float& z,
+                                           float& w) {
+  float o[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float acc = T[0 + r] * x;
+    acc = T[4 + r] * y + acc;
+    acc = T[8 + r] * z + acc;
+    acc = T[12 + r] * w + acc;
+    o[r] = acc;
+  }
+  x = o[0]; y = o[1]; z = o[2]; w = o[3];
+}
+
+// nanogrid::GridMap::move arithmetic on the position / start index (no layer access).
+__device__ __forceinline__ DevCand move_candidate(const DevGeom& g, const GeomConst& G, double x,
+                                                  double y) {
+  DevCand c;
+  const double ps[2] = {x - g.px, y - g.py};
+  int sh[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double t = ps[i] / G.res;
+    const int v = static_cast<int>(t + 0.5 * (t > 0 ? 1 : -1));
+    sh[i] = -v;
+  }
+  c.sr = g.sr + sh[0];
+  c.sc = g.sc + sh[1];
+  wrap_index(c.sr, G.rows);
+  wrap_index(c.sc, G.cols);
+  c.px = g.px + double(-sh[0]) * G.res;
+  c.py = g.py + double(-sh[1]) * G.res;
+  c.shr = sh[0];
+  c.shc = sh[1];
+  return c;
+}
+
+// nanogrid::GridMap::getIndex: fp64, truncation, circular-buffer wrap.
+__device__ __forceinline__ bool cell_of(float xf, float yf, const DevCand& g, const GeomConst& G,
+                                        int& r, int& c) {
+  const double x = double(xf), y = double(yf);
+  const double tx = -((x - g.px) - G.half_x);
+  const double ty = -((y - g.py) - G.half_y);
+  if (!(tx >= 0.0 && ty >= 0.0 && tx < G.len_x && ty < G.len_y)) return false;
+  const double vx = ((x - G.half_x) - g.px) / G.res;
+  const double vy = ((y - G.half_y) - g.py) / G.res;
+  r = static_cast<int>(-vx);
+  c = static_cast<int>(-vy);
+  if (g.sr != 0 || g.sc != 0) {
+    r += g.sr;
+    c += g.sc;
+    wrap_index(r, G.rows);
+    wrap_index(c, G.cols);
+  }
+  return r >= 0 && c >= 0 && r < G.rows && c < G.cols;
+}
+
+// is buffer index `b` on `axis` inside the strip GridMap::move vacates? (E = geometry
+// before the move, sh = index shift).  |sh| >= size -> everything.
+__device__ __forceinline__ bool in_cleared_strip(int b, int start, int sh, int size) {
+  if (sh == 0) return false;
+  const int n = sh > 0 ? sh : -sh;
+  if (n >= size) return true;
+  int index = sh > 0 ? start : start + sh;
+  wrap_index(index, size);
+  int d = b - index;
+  if (d < 0) d += size;
+  return d < n;
+}
+
+// sigma_z^2 = (R * Sigma_sensor * R^T)(2,2) for one point in the SENSOR frame.
+__device__ __forceinline__ float sigma_z2(const ScanParams& P, float x, float y, float z) {
+  float S[9];  // column-major
+  if (P.sensor_type == 1) {  // LiDAR, lidar_model.hpp:64-89
+    const float dist_sq = sum3(x * x, y * y, z * z);
+    if (dist_sq < 1e-6f) {
+      const float v = 0.01f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) S[k] = 0.0f * v;
+      S[0] = v; S[4] = v; S[8] = v;
+    } else {
+      const float distance = sqrtf(dist_sq);
+      const float dir[3] = {x / distance, y / distance, z / distance};
+      const float rn2 = P.sp[0] * P.sp[0];
+      const float var_radial = (rn2 < 1e-6f) ? 1e-6f : rn2;
+      const float da = distance * P.sp[1];
+      const float la2 = da * da;
+      const float var_lateral = (la2 < 1e-6f) ? 1e-6f : la2;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) S[k] = 0.0f * var_lateral;
+      S[0] = var_lateral; S[4] = var_lateral; S[8] = var_lateral;
+      const float s = var_radial - var_lateral;
+      const float t[3] = {s * dir[0], s * dir[1], s * dir[2]};  // (s*A)*B rewrite
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) S[c * 3 + r] = S[c * 3 + r] + dir[c] * t[r];
+    }
+  } else if (P.sensor_type == 2) {  // RGB-D, rgbd_model.hpp:82-101
+#pragma unroll
+    for (int k = 0; k < 9; ++k) S[k] = 0.0f;
+    const float depth = z;
+    if (depth <= 0.0f) {
+      const float v = 0.01f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) S[k] = 0.0f * v;
+      S[0] = v; S[4] = v; S[8] = v;
+    } else {
+      const float diff = depth - P.sp[2];
+      const float sigma_norm = P.sp[0] + P.sp[1] * diff * diff;
+      const float sigma_lat = P.sp[3] * depth;
+      S[0] = sigma_lat * sigma_lat;
+      S[4] = S[0];
+      S[8] = sigma_norm * sigma_norm;
+    }
+  } else {  // Constant, sensor_model.hpp:87-93
+    const float v = P.sp[0] * P.sp[0];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) S[k] = 0.0f * v;
+    S[0] = v; S[4] = v; S[8] = v;
+  }
+  // M = R*S (row 2 only), out(2,2) = M(2,:) . R(2,:)   — 3-term dots a0b0 + (a1b1 + a2b2)
+  const float* R = P.R;
+  float M2[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+    M2[j] = sum3(R[0 * 3 + 2] * S[j * 3 + 0], R[1 * 3 + 2] * S[j * 3 + 1], R[2 * 3 + 2] * S[j * 3 + 2]);
+  return sum3(M2[0] * R[0 * 3 + 2], M2[1] * R[1 * 3 + 2], M2[2] * R[2 * 3 + 2]);
+}
+
+// ---- estimators (one update per touched cell) ----
+__device__ __forceinline__ float clampf(float v, float lo, float hi) {
+  return (v < lo) ? lo : (hi < v) ? hi : v;
+}
+
+struct KalmanState {
+  float x, P, count, mean, var, m2, upper, lower;
+};
+// Kalman::update + computeBounds, kalman_estimation.hpp:98-153
+__device__ __forceinline__ void kalman_step(KalmanState& s, float z, float meas_var, float min_var,
+                                            float max_var, float q) {
+  const float R = (meas_var > 0.0f) ? meas_var : max_var;
+  if (isnan(s.x)) {
+    s.x = z;
+    s.P = R;
+    s.count = 1.0f;
+  } else {
+    s.P += q;
+    const float K = s.P / (s.P + R);
+    s.x = s.x + K * (z - s.x);
+    s.P = (1.0f - K) * s.P;
+    s.P = clampf(s.P, min_var, max_var);
+    s.count += 1.0f;
+  }
+  if (isnan(s.mean)) {
+    s.mean = z;
+    s.var = 0.0f;
+    s.m2 = 0.0f;
+  } else {
+    const float delta = z - s.mean;
+    const float new_mean = s.mean + (delta / s.count);
+    const float delta2 = z - new_mean;
+    s.m2 += delta * delta2;
+    s.var = (s.count > 1.0f) ? s.m2 / (s.count - 1.0f) : 0.0f;
+    s.mean = new_mean;
+  }
+  const float sigma = sqrtf((0.0f < s.var) ? s.var : 0.0f);
+  s.upper = s.x + 2.0f * sigma;
+  s.lower = s.x - 2.0f * sigma;
+}
+
+struct P2Params {
+  float dn[5];
+  int marker;
+  float max_count;
+};
+struct P2State {
+  float elevation, variance, count, upper, lower;
+  float q[5], n[5];
+};
+
+__device__ __forceinline__ float p2_parabolic(float qm, float q0, float qp, float nm, float n0,
+                                              float np, int sign) {
+  const float d_right = np - n0;
+  const float d_left = n0 - nm;
+  const float d_span = np - nm;
+  if (d_right == 0.0f || d_left == 0.0f || d_span == 0.0f) return q0;
+  const float s = static_cast<float>(sign);
+  const float t1 = (d_left + s) * (qp - q0) / d_right;
+  const float t2 = (d_right - s) * (q0 - qm) / d_left;
+  return q0 + s * (t1 + t2) / d_span;
+}
+__device__ __forceinline__ float p2_linear(float q0, float qj, float n0, float nj, int sign) {
+  const float dn = nj - n0;
+  if (dn == 0.0f) return q0;
+  return q0 + static_cast<float>(sign) * (qj - q0) / dn;
+}
+
+// P2Quantile::update + computeBounds, quantile_estimation.hpp:140-258.
+// All marker indexing is static (select chains) so q[]/n[] stay in registers.
+__device__ __forceinline__ void p2_step(P2State& s, float x, const P2Params& p) {
+  float* q = s.q;
+  float* n = s.n;
+  float count = s.count;
+  if (isnan(count) || count < 0.0f) count = 0.0f;
+  if (count < 5.0f) {
+    const int ic = static_cast<int>(count);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) q[k] = (ic == k) ? x : q[k];
+    count += 1.0f;
+    if (count >= 5.0f) {
+      // std::sort on 5 elements == stable insertion sort (libstdc++ __insertion_sort)
+#pragma unroll
+      for (int i = 1; i < 5; ++i) {
+#pragma unroll
+        for (int j = i; j > 0; --j) {
+          const float a = q[j - 1], b = q[j];
+          const bool sw = b < a;
+          q[j - 1] = sw ? b : a;
+          q[j] = sw ? a : b;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 5; ++i) n[i] = static_cast<float>(i);
+    }
+  } else {
+    int k;
+    if (x < q[0]) {
+      q[0] = x;
+      k = 0;
+    } else if (x < q[1]) {
+      k = 0;
+    } else if (x < q[2]) {
+      k = 1;
+    } else if (x < q[3]) {
+      k = 2;
+    } else if (x <= q[4]) {
+      k = 3;
+    } else {
+      q[4] = x;
+      k = 3;
+    }
+#pragma unroll
+    for (int i = 1; i < 5; ++i)
+      if (i > k) n[i] += 1.0f;
+    float n_prime[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) n_prime[i] = p.dn[i] * count;
+    count += 1.0f;
+    if (p.max_count > 0.0f && count > p.max_count) {
+      const float scale = p.max_count / count;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) n[i] *= scale;
+      count = p.max_count;
+    }
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+      const float d = n_prime[i] - n[i];
+      if ((d >= 1.0f && n[i + 1] - n[i] > 1.0f) || (d <= -1.0f && n[i - 1] - n[i] < -1.0f)) {
+        const int sign = (d >= 0.0f) ? 1 : -1;
+        const float q_new = p2_parabolic(q[i - 1], q[i], q[i + 1], n[i - 1], n[i], n[i + 1], sign);
+        const float qj = (sign > 0) ? q[i + 1] : q[i - 1];
+        const float nj = (sign > 0) ? n[i + 1] : n[i - 1];
+        q[i] = (q[i - 1] < q_new && q_new < q[i + 1]) ? q_new : p2_linear(q[i], qj, n[i], nj, sign);
+        n[i] += static_cast<float>(sign);
+      }
+    }
+  }
+  s.count = count;
+  // update() writes (count>=5 ? q[m] : x); computeBounds() then overwrites with q[m]
+  float qm = q[0];
+#pragma unroll
+  for (int k = 1; k < 5; ++k) qm = (p.marker == k) ? q[k] : qm;
+  s.elevation = qm;
+  const float sigma = (q[3] - q[1]) / 2.0f;
+  s.variance = sigma * sigma;
+  s.lower = q[0];
+  s.upper = q[4];
+}
+
+}  // namespace fdm

@@ -1,0 +1,891 @@
+// fdm_engine.hip — C ABI (include/fdm_engine.h) over the HIP kernels.  gfx950 only.
+//
+// Host responsibilities (all O(1) per scan): cast the two Isometry3d matrices to float,
+// form R = (T_wb*T_bs).rotation().cast<float>(), pick the ring slot, launch k_bin and
+// k_update on the engine's stream.  No per-point or per-cell work ever runs on the CPU and
+// there is NO CPU fallback: without a HIP device fdm_engine_create fails with
+// FDM_ERR_NO_DEVICE.
+#include "../../include/fdm_engine.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "fdm_kernels.hpp"
+
+using namespace fdm;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPCK(expr)                                                                        \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess)                                                                  \
+      return fail(FDM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));         \
+  } while (0)
+
+struct Layer {
+  std::string name;
+  float* d = nullptr;
+  bool pending = false;  // allocated, but not yet visible (lazy intensity / colour layers)
+};
+
+}  // namespace
+
+struct fdm_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  fdm_config cfg{};
+  GeomConst G{};
+  size_t ncell = 0;
+  std::vector<Layer> layers;
+  float** d_layer_ptrs = nullptr;  // device array of every layer pointer (strip clears)
+  int n_layer_ptrs = 0;
+  bool layer_ptrs_dirty = true;
+  Scratch S{};
+  DevState* d_state = nullptr;
+  DevState* h_state = nullptr;  // pinned mirror for read-backs
+  uint64_t scan_no = 0;
+  bool have_scan = false;
+  uint32_t last_n = 0;
+  int last_was_integrate = 0;
+  // staging for the host-pointer entry points
+  float* d_stage = nullptr;
+  size_t stage_cap = 0;  // in points
+  int32_t* d_cell_ids = nullptr;
+  size_t ids_cap = 0;
+  bool want_ids = false;
+  bool profile = false;
+  bool wave_merge = true;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  float last_ms[2] = {0.f, 0.f};
+};
+
+namespace {
+
+Layer* find_layer(fdm_engine* e, const char* name) {
+  for (auto& l : e->layers)
+    if (l.name == name) return &l;
+  return nullptr;
+}
+
+int fill_async(fdm_engine* e, float* p, float v, size_t n) {
+  if (n == 0) return FDM_OK;
+  const int blocks = int(std::min<size_t>((n + 255) / 256, 4096));
+  hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, e->stream, p, v, n);
+  HIPCK(hipGetLastError());
+  return FDM_OK;
+}
+
+int add_layer(fdm_engine* e, const char* name, float value, bool pending = false) {
+  if (Layer* l = find_layer(e, name)) {  // GridMap::add on an existing layer overwrites it
+    l->pending = l->pending && pending;
+    return fill_async(e, l->d, value, e->ncell);
+  }
+  Layer l;
+  l.name = name;
+  l.pending = pending;
+  HIPCK(hipMalloc(reinterpret_cast<void**>(&l.d), e->ncell * sizeof(float)));
+  e->layers.push_back(l);
+  e->layer_ptrs_dirty = true;
+  return fill_async(e, l.d, value, e->ncell);
+}
+
+int ensure_layer(fdm_engine* e, const char* name, float value) {
+  if (Layer* l = find_layer(e, name)) {
+    (void)l;
+    return FDM_OK;
+  }
+  return add_layer(e, name, value);
+}
+
+const char* kP2Q[5] = {"_p2_q0", "_p2_q1", "_p2_q2", "_p2_q3", "_p2_q4"};
+const char* kP2N[5] = {"_p2_n0", "_p2_n1", "_p2_n2", "_p2_n3", "_p2_n4"};
+
+// ElevationMapping ctor (elevation_mapping.cpp:11-39) + Kalman/P2 ensureLayers
+// (kalman_estimation.hpp:64-82, quantile_estimation.hpp:97-115): add what is missing.
+int ensure_estimator_layers(fdm_engine* e) {
+  int rc;
+  if (e->cfg.estimation_type == 1) {
+    if ((rc = ensure_layer(e, "variance", NAN))) return rc;
+    if ((rc = ensure_layer(e, "n_points", 0.0f))) return rc;
+    for (int k = 0; k < 5; ++k)
+      if ((rc = ensure_layer(e, kP2Q[k], NAN))) return rc;
+    for (int k = 0; k < 5; ++k)
+      if ((rc = ensure_layer(e, kP2N[k], float(k)))) return rc;
+    if ((rc = ensure_layer(e, "upper_bound", NAN))) return rc;
+    if ((rc = ensure_layer(e, "lower_bound", NAN))) return rc;
+  } else {
+    if ((rc = ensure_layer(e, "variance", 0.0f))) return rc;
+    if ((rc = ensure_layer(e, "n_points", 0.0f))) return rc;
+    if ((rc = ensure_layer(e, "_kalman_p", 0.0f))) return rc;
+    if ((rc = ensure_layer(e, "_sample_mean", NAN))) return rc;
+    if ((rc = ensure_layer(e, "_sample_m2", 0.0f))) return rc;
+    if ((rc = ensure_layer(e, "upper_bound", NAN))) return rc;
+    if ((rc = ensure_layer(e, "lower_bound", NAN))) return rc;
+  }
+  return ensure_layer(e, "obstacle", NAN);
+}
+
+int refresh_layer_ptrs(fdm_engine* e) {
+  if (!e->layer_ptrs_dirty) return FDM_OK;
+  std::vector<float*> ptrs;
+  for (auto& l : e->layers) ptrs.push_back(l.d);
+  // the old array may still be referenced by an in-flight kernel: drain first
+  HIPCK(hipStreamSynchronize(e->stream));
+  if (e->d_layer_ptrs) HIPCK(hipFree(e->d_layer_ptrs));
+  HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_layer_ptrs), ptrs.size() * sizeof(float*)));
+  HIPCK(hipMemcpy(e->d_layer_ptrs, ptrs.data(), ptrs.size() * sizeof(float*), hipMemcpyHostToDevice));
+  e->n_layer_ptrs = int(ptrs.size());
+  e->layer_ptrs_dirty = false;
+  return FDM_OK;
+}
+
+// Lazy layers become visible once a scan that carried the channel landed in the map
+// (updateIntensity / updateColor, elevation_mapping.cpp:154-175).
+int resolve_pending(fdm_engine* e) {
+  bool any = false;
+  for (auto& l : e->layers) any = any || l.pending;
+  if (!any) return FDM_OK;
+  HIPCK(hipStreamSynchronize(e->stream));
+  unsigned sticky = 0;
+  HIPCK(hipMemcpy(&sticky, &e->d_state->sticky, sizeof(unsigned), hipMemcpyDeviceToHost));
+  for (auto& l : e->layers) {
+    if (l.pending && l.name == "intensity" && (sticky & 1u)) l.pending = false;
+    if (l.pending && l.name == "color" && (sticky & 2u)) l.pending = false;
+  }
+  return FDM_OK;
+}
+
+// Eigen: Isometry product linear part, coeff-based 3-term dots a0b0 + (a1b1 + a2b2), then cast.
+void rotation_of_product(const double* Twb, const double* Tbs, float* R) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      const double a0 = Twb[0 * 4 + i] * Tbs[j * 4 + 0];
+      const double a1 = Twb[1 * 4 + i] * Tbs[j * 4 + 1];
+      const double a2 = Twb[2 * 4 + i] * Tbs[j * 4 + 2];
+      R[j * 3 + i] = static_cast<float>(a0 + (a1 + a2));
+    }
+}
+
+int ensure_ids(fdm_engine* e, size_t n) {
+  if (!e->want_ids) return FDM_OK;
+  if (n > e->ids_cap) {
+    HIPCK(hipStreamSynchronize(e->stream));
+    if (e->d_cell_ids) HIPCK(hipFree(e->d_cell_ids));
+    e->ids_cap = n + n / 4 + 1024;
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_cell_ids), e->ids_cap * sizeof(int32_t)));
+  }
+  return FDM_OK;
+}
+
+int ensure_scratch_channels(fdm_engine* e, bool intensity, bool color) {
+  auto alloc_u32 = [&](uint32_t** p, uint32_t init) -> int {
+    if (*p) return FDM_OK;
+    HIPCK(hipMalloc(reinterpret_cast<void**>(p), e->ncell * sizeof(uint32_t)));
+    const int blocks = int(std::min<size_t>((e->ncell + 255) / 256, 4096));
+    hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, e->stream, *p, init, e->ncell);
+    HIPCK(hipGetLastError());
+    return FDM_OK;
+  };
+  int rc;
+  if (intensity) {
+    if ((rc = alloc_u32(&e->S.imax, 0u))) return rc;
+    if ((rc = alloc_u32(&e->S.first, kNoIdx))) return rc;
+    if (!find_layer(e, "intensity") && (rc = add_layer(e, "intensity", NAN, true))) return rc;
+  }
+  if (color) {
+    if ((rc = alloc_u32(&e->S.last, 0u))) return rc;
+    if (!find_layer(e, "color") && (rc = add_layer(e, "color", NAN, true))) return rc;
+  }
+  return FDM_OK;
+}
+
+float* L(fdm_engine* e, const char* n) {
+  Layer* l = find_layer(e, n);
+  return l ? l->d : nullptr;
+}
+
+// One scan = k_bin + k_update on the stream.  All pointers are device pointers.
+int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, const float* dy,
+                 const float* dz, const float* dint, const uint32_t* drgb, const float* dvar) {
+  if (n >= 0xFFFFFFFEull) return fail(FDM_ERR_INVALID, "point count exceeds 2^32-2");
+  int rc;
+  P.n = uint32_t(n);
+  P.slot = int(e->scan_no & 3);
+  P.has_intensity = dint != nullptr;
+  P.has_color = drgb != nullptr;
+  P.has_var = dvar != nullptr;
+  P.sensor_type = e->cfg.sensor_type;
+  if (P.sensor_type == 1) {  // LiDARSensorModel ctor takes |noise| (lidar_model.hpp:58-62)
+    P.sp[0] = std::fabs(e->cfg.lidar_range_noise);
+    P.sp[1] = std::fabs(e->cfg.lidar_angular_noise);
+    P.sp[2] = P.sp[3] = 0.f;
+  } else if (P.sensor_type == 2) {
+    P.sp[0] = e->cfg.rgbd_normal_a;
+    P.sp[1] = e->cfg.rgbd_normal_b;
+    P.sp[2] = e->cfg.rgbd_normal_c;
+    P.sp[3] = e->cfg.rgbd_lateral_factor;
+  } else if (P.sensor_type == 0) {
+    P.sp[0] = e->cfg.constant_uncertainty;
+    P.sp[1] = P.sp[2] = P.sp[3] = 0.f;
+  } else {  // unknown -> LiDAR (sensor_model.cpp:34-38)
+    P.sensor_type = 1;
+    P.sp[0] = std::fabs(e->cfg.lidar_range_noise);
+    P.sp[1] = std::fabs(e->cfg.lidar_angular_noise);
+    P.sp[2] = P.sp[3] = 0.f;
+  }
+  if ((rc = ensure_scratch_channels(e, P.has_intensity, P.has_color))) return rc;
+  if ((rc = refresh_layer_ptrs(e))) return rc;
+  if ((rc = ensure_ids(e, n))) return rc;
+
+  if (e->profile) HIPCK(hipEventRecord(e->ev[0], e->stream));
+  const unsigned bin_blocks = unsigned((n + 255) / 256) > 0 ? unsigned((n + 255) / 256) : 1u;
+  int32_t* ids = e->want_ids ? e->d_cell_ids : nullptr;
+  if (e->wave_merge)
+    hipLaunchKernelGGL(k_bin<true>, dim3(bin_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state,
+                       dx, dy, dz, dint, e->S, ids);
+  else
+    hipLaunchKernelGGL(k_bin<false>, dim3(bin_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state,
+                       dx, dy, dz, dint, e->S, ids);
+  HIPCK(hipGetLastError());
+  if (e->profile) HIPCK(hipEventRecord(e->ev[1], e->stream));
+
+  const unsigned upd_blocks = unsigned((e->ncell + 255) / 256);
+  if (e->cfg.estimation_type == 1) {
+    P2Layers Lp{};
+    Lp.elevation = L(e, "elevation");
+    Lp.elevation_min = L(e, "elevation_min");
+    Lp.elevation_max = L(e, "elevation_max");
+    Lp.variance = L(e, "variance");
+    Lp.n_points = L(e, "n_points");
+    Lp.upper = L(e, "upper_bound");
+    Lp.lower = L(e, "lower_bound");
+    Lp.obstacle = L(e, "obstacle");
+    Lp.intensity = L(e, "intensity");
+    Lp.color = L(e, "color");
+    for (int k = 0; k < 5; ++k) {
+      Lp.q[k] = L(e, kP2Q[k]);
+      Lp.n[k] = L(e, kP2N[k]);
+    }
+    // P2Quantile ctor (quantile_estimation.hpp:84-95): clamp, then enforce monotone dn
+    auto clamp01 = [](float v) { return v < 0.f ? 0.f : (1.f < v ? 1.f : v); };
+    for (int k = 0; k < 5; ++k) Lp.p.dn[k] = clamp01(e->cfg.p2_dn[k]);
+    for (int k = 1; k < 5; ++k) Lp.p.dn[k] = std::max(Lp.p.dn[k], Lp.p.dn[k - 1]);
+    Lp.p.marker = std::min(std::max(e->cfg.p2_elevation_marker, 0), 4);
+    Lp.p.max_count = std::max(e->cfg.p2_max_sample_count, 0.0f);
+    hipLaunchKernelGGL(k_update_p2, dim3(upd_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state,
+                       Lp, e->d_layer_ptrs, e->n_layer_ptrs, e->S, dx, dy, dz, dint, drgb, dvar,
+                       unsigned(e->ncell));
+  } else {
+    KalmanLayers Lk{};
+    Lk.elevation = L(e, "elevation");
+    Lk.elevation_min = L(e, "elevation_min");
+    Lk.elevation_max = L(e, "elevation_max");
+    Lk.variance = L(e, "variance");
+    Lk.n_points = L(e, "n_points");
+    Lk.kalman_p = L(e, "_kalman_p");
+    Lk.sample_mean = L(e, "_sample_mean");
+    Lk.sample_m2 = L(e, "_sample_m2");
+    Lk.upper = L(e, "upper_bound");
+    Lk.lower = L(e, "lower_bound");
+    Lk.obstacle = L(e, "obstacle");
+    Lk.intensity = L(e, "intensity");
+    Lk.color = L(e, "color");
+    Lk.min_var = e->cfg.kalman_min_variance;
+    Lk.max_var = e->cfg.kalman_max_variance;
+    Lk.q = e->cfg.kalman_process_noise;
+    hipLaunchKernelGGL(k_update_kalman, dim3(upd_blocks), dim3(256), 0, e->stream, P, e->G,
+                       e->d_state, Lk, e->d_layer_ptrs, e->n_layer_ptrs, e->S, dx, dy, dz, dint, drgb,
+                       dvar, unsigned(e->ncell));
+  }
+  HIPCK(hipGetLastError());
+  if (e->profile) HIPCK(hipEventRecord(e->ev[2], e->stream));
+  e->scan_no++;
+  e->have_scan = true;
+  e->last_n = uint32_t(n);
+  e->last_was_integrate = P.integrate_mode;
+  return FDM_OK;
+}
+
+void fill_integrate_params(fdm_engine* e, ScanParams& P, const double* Tbs, const double* Twb) {
+  std::memset(&P, 0, sizeof(P));
+  for (int i = 0; i < 16; ++i) {
+    P.Tbs[i] = static_cast<float>(Tbs[i]);
+    P.Twb[i] = static_cast<float>(Twb[i]);
+  }
+  rotation_of_product(Twb, Tbs, P.R);
+  // cropRange (crop_impl.hpp:79-96): squares in fp32, FLT_MAX^2 = +inf
+  P.min_sq = e->cfg.range_min * e->cfg.range_min;
+  P.max_sq = e->cfg.range_max * e->cfg.range_max;
+  P.z_min = e->cfg.z_min;
+  P.z_max = e->cfg.z_max;
+  P.robot_x = Twb[12];  // T_world_base.translation().head<2>() (fastdem.cpp:144)
+  P.robot_y = Twb[13];
+  P.integrate_mode = 1;
+  P.do_move = e->cfg.mode == 0 ? 1 : 0;
+  P.gate_on_filter = 1;
+}
+
+void fill_update_params(fdm_engine* e, ScanParams& P, double rx, double ry, bool force_move) {
+  std::memset(&P, 0, sizeof(P));
+  P.robot_x = rx;
+  P.robot_y = ry;
+  P.integrate_mode = 0;
+  P.do_move = (force_move || e->cfg.mode == 0) ? 1 : 0;
+  P.gate_on_filter = 0;
+}
+
+int ensure_stage(fdm_engine* e, size_t n) {
+  if (n <= e->stage_cap) return FDM_OK;
+  HIPCK(hipStreamSynchronize(e->stream));
+  if (e->d_stage) HIPCK(hipFree(e->d_stage));
+  e->stage_cap = n + n / 4 + 1024;
+  HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_stage), e->stage_cap * 6 * sizeof(float)));
+  return FDM_OK;
+}
+
+// H2D of the SoA channels into the staging block; returns device pointers (nullable ones stay null)
+int stage_inputs(fdm_engine* e, uint64_t n, const float* x, const float* y, const float* z,
+                 const float* a, const uint32_t* rgb, const float* v, const float** dx,
+                 const float** dy, const float** dz, const float** da, const uint32_t** drgb,
+                 const float** dv) {
+  int rc;
+  if ((rc = ensure_stage(e, n))) return rc;
+  float* base = e->d_stage;
+  const size_t cap = e->stage_cap;
+  auto up = [&](const void* src, int k) -> int {
+    HIPCK(hipMemcpyAsync(base + cap * k, src, n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    return FDM_OK;
+  };
+  if ((rc = up(x, 0)) || (rc = up(y, 1)) || (rc = up(z, 2))) return rc;
+  *dx = base;
+  *dy = base + cap;
+  *dz = base + cap * 2;
+  *da = nullptr;
+  *drgb = nullptr;
+  *dv = nullptr;
+  if (a) {
+    if ((rc = up(a, 3))) return rc;
+    *da = base + cap * 3;
+  }
+  if (rgb) {
+    if ((rc = up(rgb, 4))) return rc;
+    *drgb = reinterpret_cast<const uint32_t*>(base + cap * 4);
+  }
+  if (v) {
+    if ((rc = up(v, 5))) return rc;
+    *dv = base + cap * 5;
+  }
+  return FDM_OK;
+}
+
+int read_stats(fdm_engine* e, fdm_scan_stats* out, int* status) {
+  HIPCK(hipStreamSynchronize(e->stream));
+  fdm_scan_stats s{};
+  *status = FDM_OK;
+  if (!e->have_scan) {
+    if (out) *out = s;
+    return FDM_OK;
+  }
+  const int slot = int((e->scan_no - 1) & 3);
+  HIPCK(hipMemcpy(e->h_state, e->d_state, sizeof(DevState), hipMemcpyDeviceToHost));
+  const DevState& st = *e->h_state;
+  uint64_t np = 0, ni = 0, nt = 0;
+  for (int k = 0; k < kShards; ++k) {
+    np += uint32_t(st.pass_inside[slot][k]);
+    ni += uint32_t(st.pass_inside[slot][k] >> 32);
+    nt += st.touched[slot][k];
+  }
+  s.n_input = e->last_n;
+  s.n_after_filter = uint32_t(np);
+  s.n_in_map = uint32_t(ni);
+  s.n_cells_touched = uint32_t(nt);
+  const bool applied = e->last_was_integrate ? (np > 0) : true;
+  if (applied) {
+    s.shift_rows = st.cand[slot].shr;
+    s.shift_cols = st.cand[slot].shc;
+  }
+  if (e->last_was_integrate) {
+    if (e->last_n == 0) *status = FDM_SKIP_EMPTY_CLOUD;
+    else if (np == 0) *status = FDM_SKIP_ALL_FILTERED;
+  }
+  if (out) *out = s;
+  if (e->profile) {
+    (void)hipEventElapsedTime(&e->last_ms[0], e->ev[0], e->ev[1]);
+    (void)hipEventElapsedTime(&e->last_ms[1], e->ev[1], e->ev[2]);
+  }
+  return FDM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void fdm_default_config(fdm_config* c) {
+  c->z_min = -std::numeric_limits<float>::max();
+  c->z_max = std::numeric_limits<float>::max();
+  c->range_min = 0.0f;
+  c->range_max = std::numeric_limits<float>::max();
+  c->sensor_type = 1;
+  c->lidar_range_noise = 0.02f;
+  c->lidar_angular_noise = 0.001f;
+  c->rgbd_normal_a = 0.001f;
+  c->rgbd_normal_b = 0.002f;
+  c->rgbd_normal_c = 0.4f;
+  c->rgbd_lateral_factor = 0.001f;
+  c->constant_uncertainty = 0.03f;
+  c->mode = 0;
+  c->estimation_type = 0;
+  c->kalman_min_variance = 0.0001f;
+  c->kalman_max_variance = 0.01f;
+  c->kalman_process_noise = 0.0f;
+  const float dn[5] = {0.01f, 0.16f, 0.50f, 0.84f, 0.99f};
+  for (int k = 0; k < 5; ++k) c->p2_dn[k] = dn[k];
+  c->p2_elevation_marker = 3;
+  c->p2_max_sample_count = 0.0f;
+}
+
+const char* fdm_last_error(void) { return g_err.c_str(); }
+
+int fdm_engine_create(const fdm_geometry* g, const fdm_config* cfg, const fdm_tile* tile, int device,
+                      fdm_engine** out) {
+  if (!g || !cfg || !out) return fail(FDM_ERR_INVALID, "null argument");
+  if (!(g->resolution > 0.0) || !(g->length_x > 0.0) || !(g->length_y > 0.0))
+    return fail(FDM_ERR_INVALID, "length and resolution must be positive");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(FDM_ERR_NO_DEVICE, "no HIP device: the engine has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(FDM_ERR_INVALID, "bad device ordinal");
+  HIPCK(hipSetDevice(device));
+
+  fdm_engine* e = new fdm_engine();
+  e->device = device;
+  e->cfg = *cfg;
+  // nanogrid::GridMap::setGeometry: size = round(length / resolution); length = size * resolution
+  GeomConst& G = e->G;
+  G.rows = int(std::round(g->length_x / g->resolution));
+  G.cols = int(std::round(g->length_y / g->resolution));
+  if (G.rows <= 0 || G.cols <= 0) {
+    delete e;
+    return fail(FDM_ERR_INVALID, "map has no cells");
+  }
+  G.res = g->resolution;
+  G.len_x = double(G.rows) * G.res;
+  G.len_y = double(G.cols) * G.res;
+  G.half_x = 0.5 * G.len_x;
+  G.half_y = 0.5 * G.len_y;
+  if (tile) {
+    if (cfg->mode != 1) {
+      delete e;
+      return fail(FDM_ERR_INVALID, "tiled engines require GLOBAL mode");
+    }
+    const bool ok = tile->rows > 0 && tile->cols > 0 && tile->row0 >= 0 && tile->col0 >= 0 &&
+                    tile->row0 + tile->rows <= G.rows && tile->col0 + tile->cols <= G.cols &&
+                    tile->own_row0 >= tile->row0 && tile->own_col0 >= tile->col0 &&
+                    tile->own_row0 + tile->own_rows <= tile->row0 + tile->rows &&
+                    tile->own_col0 + tile->own_cols <= tile->col0 + tile->cols;
+    if (!ok) {
+      delete e;
+      return fail(FDM_ERR_INVALID, "tile window outside the map or owned window outside the tile");
+    }
+    G.s_r0 = tile->row0; G.s_c0 = tile->col0; G.s_rows = tile->rows; G.s_cols = tile->cols;
+    G.o_r0 = tile->own_row0; G.o_c0 = tile->own_col0; G.o_rows = tile->own_rows; G.o_cols = tile->own_cols;
+  } else {
+    G.s_r0 = G.s_c0 = G.o_r0 = G.o_c0 = 0;
+    G.s_rows = G.o_rows = G.rows;
+    G.s_cols = G.o_cols = G.cols;
+  }
+  e->ncell = size_t(G.s_rows) * size_t(G.s_cols);
+  if (e->ncell >= 0xFFFFFFFFull) {
+    delete e;
+    return fail(FDM_ERR_INVALID, "tile exceeds 2^32 cells");
+  }
+
+#define CK(expr)                 \
+  do {                           \
+    int _rc = (expr);            \
+    if (_rc != FDM_OK) {         \
+      fdm_engine_destroy(e);     \
+      return _rc;                \
+    }                            \
+  } while (0)
+#define HCK(expr)                                                                         \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      fdm_engine_destroy(e);                                                              \
+      return fail(FDM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));        \
+    }                                                                                     \
+  } while (0)
+
+  HCK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  for (auto& ev : e->ev) HCK(hipEventCreate(&ev));
+  HCK(hipMalloc(reinterpret_cast<void**>(&e->d_state), sizeof(DevState)));
+  HCK(hipHostMalloc(reinterpret_cast<void**>(&e->h_state), sizeof(DevState)));
+  std::memset(e->h_state, 0, sizeof(DevState));
+  for (int k = 0; k < 4; ++k) {
+    e->h_state->geom[k].px = g->position_x;
+    e->h_state->geom[k].py = g->position_y;
+    e->h_state->geom[k].sr = 0;
+    e->h_state->geom[k].sc = 0;
+  }
+  HCK(hipMemcpy(e->d_state, e->h_state, sizeof(DevState), hipMemcpyHostToDevice));
+
+  HCK(hipMalloc(reinterpret_cast<void**>(&e->S.key), e->ncell * sizeof(unsigned long long)));
+  HCK(hipMalloc(reinterpret_cast<void**>(&e->S.zmax), e->ncell * sizeof(uint32_t)));
+  {
+    const int blocks = int(std::min<size_t>((e->ncell + 255) / 256, 4096));
+    hipLaunchKernelGGL(k_fill_u64, dim3(blocks), dim3(256), 0, e->stream, e->S.key, kEmptyKey, e->ncell);
+    hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, e->stream, e->S.zmax, 0u, e->ncell);
+    HCK(hipGetLastError());
+  }
+  // ElevationMap ctor: elevation, elevation_min, elevation_max = NaN (elevation_map.hpp:101-116)
+  CK(add_layer(e, "elevation", NAN));
+  CK(add_layer(e, "elevation_min", NAN));
+  CK(add_layer(e, "elevation_max", NAN));
+  CK(ensure_estimator_layers(e));
+  HCK(hipStreamSynchronize(e->stream));
+#undef CK
+#undef HCK
+  *out = e;
+  return FDM_OK;
+}
+
+void fdm_engine_destroy(fdm_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  for (auto& l : e->layers)
+    if (l.d) (void)hipFree(l.d);
+  if (e->d_layer_ptrs) (void)hipFree(e->d_layer_ptrs);
+  if (e->S.key) (void)hipFree(e->S.key);
+  if (e->S.zmax) (void)hipFree(e->S.zmax);
+  if (e->S.imax) (void)hipFree(e->S.imax);
+  if (e->S.first) (void)hipFree(e->S.first);
+  if (e->S.last) (void)hipFree(e->S.last);
+  if (e->d_state) (void)hipFree(e->d_state);
+  if (e->h_state) (void)hipHostFree(e->h_state);
+  if (e->d_stage) (void)hipFree(e->d_stage);
+  if (e->d_cell_ids) (void)hipFree(e->d_cell_ids);
+  for (auto& ev : e->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int fdm_engine_set_config(fdm_engine* e, const fdm_config* cfg) {
+  if (!e || !cfg) return fail(FDM_ERR_INVALID, "null argument");
+  if (cfg->mode != 1 && (e->G.s_rows != e->G.rows || e->G.s_cols != e->G.cols))
+    return fail(FDM_ERR_INVALID, "tiled engines require GLOBAL mode");
+  e->cfg = *cfg;
+  return ensure_estimator_layers(e);
+}
+
+int fdm_engine_set_stream(fdm_engine* e, void* hip_stream) {
+  if (!e) return fail(FDM_ERR_INVALID, "null engine");
+  HIPCK(hipStreamSynchronize(e->stream));
+  if (hip_stream) {
+    if (e->own_stream && e->stream) HIPCK(hipStreamDestroy(e->stream));
+    e->stream = static_cast<hipStream_t>(hip_stream);
+    e->own_stream = false;
+  } else if (!e->own_stream) {
+    HIPCK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->own_stream = true;
+  }
+  return FDM_OK;
+}
+
+int fdm_engine_integrate_device(fdm_engine* e, uint64_t n, const float* dx, const float* dy,
+                                const float* dz, const float* dint, const uint32_t* drgb,
+                                const float* dvar, const double Tbs[16], const double Twb[16]) {
+  if (!e || !Tbs || !Twb) return fail(FDM_ERR_INVALID, "null argument");
+  if (n && (!dx || !dy || !dz)) return fail(FDM_ERR_INVALID, "null xyz");
+  HIPCK(hipSetDevice(e->device));
+  ScanParams P;
+  fill_integrate_params(e, P, Tbs, Twb);
+  if (n == 0) {  // fastdem.cpp:125-128: nothing is touched, not even the move
+    e->have_scan = true;
+    e->last_n = 0;
+    e->last_was_integrate = 1;
+    // consume no slot; last_stats reports SKIP_EMPTY_CLOUD
+    return FDM_OK;
+  }
+  return enqueue_scan(e, P, n, dx, dy, dz, dint, drgb, dvar);
+}
+
+int fdm_engine_integrate(fdm_engine* e, uint64_t n, const float* x, const float* y, const float* z,
+                         const float* intensity, const uint32_t* rgb, const float* sigma_z2,
+                         const double Tbs[16], const double Twb[16], fdm_scan_stats* out) {
+  if (!e || !Tbs || !Twb) return fail(FDM_ERR_INVALID, "null argument");
+  if (n == 0) {
+    if (out) {
+      std::memset(out, 0, sizeof(*out));
+    }
+    return FDM_SKIP_EMPTY_CLOUD;
+  }
+  if (!x || !y || !z) return fail(FDM_ERR_INVALID, "null xyz");
+  HIPCK(hipSetDevice(e->device));
+  const float *dx, *dy, *dz, *da, *dv;
+  const uint32_t* dc;
+  int rc = stage_inputs(e, n, x, y, z, intensity, rgb, sigma_z2, &dx, &dy, &dz, &da, &dc, &dv);
+  if (rc) return rc;
+  ScanParams P;
+  fill_integrate_params(e, P, Tbs, Twb);
+  if ((rc = enqueue_scan(e, P, n, dx, dy, dz, da, dc, dv))) return rc;
+  int status = FDM_OK;
+  if ((rc = read_stats(e, out, &status))) return rc;
+  return status;
+}
+
+int fdm_engine_update_device(fdm_engine* e, uint64_t n, const float* dx, const float* dy,
+                             const float* dz, const float* dvar, const float* dint,
+                             const uint32_t* drgb, double rx, double ry) {
+  if (!e) return fail(FDM_ERR_INVALID, "null engine");
+  if (n && (!dx || !dy || !dz)) return fail(FDM_ERR_INVALID, "null xyz");
+  HIPCK(hipSetDevice(e->device));
+  ScanParams P;
+  fill_update_params(e, P, rx, ry, false);
+  return enqueue_scan(e, P, n, dx, dy, dz, dint, drgb, dvar);
+}
+
+int fdm_engine_update(fdm_engine* e, uint64_t n, const float* x, const float* y, const float* z,
+                      const float* z_var, const float* intensity, const uint32_t* rgb, double rx,
+                      double ry, fdm_scan_stats* out) {
+  if (!e) return fail(FDM_ERR_INVALID, "null engine");
+  if (n && (!x || !y || !z)) return fail(FDM_ERR_INVALID, "null xyz");
+  HIPCK(hipSetDevice(e->device));
+  const float *dx = nullptr, *dy = nullptr, *dz = nullptr, *da = nullptr, *dv = nullptr;
+  const uint32_t* dc = nullptr;
+  int rc;
+  if (n && (rc = stage_inputs(e, n, x, y, z, intensity, rgb, z_var, &dx, &dy, &dz, &da, &dc, &dv)))
+    return rc;
+  ScanParams P;
+  fill_update_params(e, P, rx, ry, false);
+  if ((rc = enqueue_scan(e, P, n, dx, dy, dz, da, dc, dv))) return rc;
+  int status = FDM_OK;
+  if ((rc = read_stats(e, out, &status))) return rc;
+  return FDM_OK;
+}
+
+int fdm_engine_sync(fdm_engine* e) {
+  if (!e) return fail(FDM_ERR_INVALID, "null engine");
+  HIPCK(hipStreamSynchronize(e->stream));
+  return FDM_OK;
+}
+
+int fdm_engine_last_stats(fdm_engine* e, fdm_scan_stats* out) {
+  if (!e) return fail(FDM_ERR_INVALID, "null engine");
+  if (e->have_scan && e->last_was_integrate && e->last_n == 0) {
+    HIPCK(hipStreamSynchronize(e->stream));
+    if (out) std::memset(out, 0, sizeof(*out));
+    return FDM_SKIP_EMPTY_CLOUD;
+  }
+  int status = FDM_OK;
+  const int rc = read_stats(e, out, &status);
+  return rc ? rc : status;
+}
+
+int fdm_engine_move(fdm_engine* e, double x, double y) {
+  if (!e) return fail(FDM_ERR_INVALID, "null engine");
+  if (e->G.s_rows != e->G.rows || e->G.s_cols != e->G.cols)
+    return fail(FDM_ERR_INVALID, "move() is not defined for tiled engines");
+  HIPCK(hipSetDevice(e->device));
+  ScanParams P;
+  fill_update_params(e, P, x, y, true);
+  return enqueue_scan(e, P, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+int fdm_engine_get_geometry(fdm_engine* e, fdm_geometry* out) {
+  if (!e || !out) return fail(FDM_ERR_INVALID, "null argument");
+  HIPCK(hipStreamSynchronize(e->stream));
+  DevGeom g;
+  HIPCK(hipMemcpy(&g, &e->d_state->geom[e->scan_no & 3], sizeof(DevGeom), hipMemcpyDeviceToHost));
+  out->length_x = e->G.len_x;
+  out->length_y = e->G.len_y;
+  out->resolution = e->G.res;
+  out->position_x = g.px;
+  out->position_y = g.py;
+  out->rows = e->G.rows;
+  out->cols = e->G.cols;
+  out->start_row = g.sr;
+  out->start_col = g.sc;
+  return FDM_OK;
+}
+
+int fdm_engine_set_position(fdm_engine* e, double x, double y) {
+  if (!e) return fail(FDM_ERR_INVALID, "null engine");
+  HIPCK(hipStreamSynchronize(e->stream));
+  const double p[2] = {x, y};
+  HIPCK(hipMemcpy(&e->d_state->geom[e->scan_no & 3].px, p, sizeof(p), hipMemcpyHostToDevice));
+  return FDM_OK;
+}
+
+int fdm_engine_set_start_index(fdm_engine* e, int32_t row, int32_t col) {
+  if (!e) return fail(FDM_ERR_INVALID, "null engine");
+  if (row < 0 || col < 0 || row >= e->G.rows || col >= e->G.cols)
+    return fail(FDM_ERR_INVALID, "start index out of range");
+  if ((row || col) && (e->G.s_rows != e->G.rows || e->G.s_cols != e->G.cols))
+    return fail(FDM_ERR_INVALID, "tiled engines need start index 0");
+  HIPCK(hipStreamSynchronize(e->stream));
+  const int s[2] = {row, col};
+  HIPCK(hipMemcpy(&e->d_state->geom[e->scan_no & 3].sr, s, sizeof(s), hipMemcpyHostToDevice));
+  return FDM_OK;
+}
+
+int fdm_engine_num_layers(fdm_engine* e) {
+  if (!e) return fail(FDM_ERR_INVALID, "null engine");
+  if (int rc = resolve_pending(e)) return rc;
+  int n = 0;
+  for (auto& l : e->layers) n += l.pending ? 0 : 1;
+  return n;
+}
+
+const char* fdm_engine_layer_name(fdm_engine* e, int i) {
+  if (!e) return nullptr;
+  if (resolve_pending(e)) return nullptr;
+  int k = 0;
+  for (auto& l : e->layers) {
+    if (l.pending) continue;
+    if (k++ == i) return l.name.c_str();
+  }
+  return nullptr;
+}
+
+int fdm_engine_layer_exists(fdm_engine* e, const char* name) {
+  if (!e || !name) return fail(FDM_ERR_INVALID, "null argument");
+  if (int rc = resolve_pending(e)) return rc;
+  Layer* l = find_layer(e, name);
+  return (l && !l->pending) ? 1 : 0;
+}
+
+int fdm_engine_layer_add(fdm_engine* e, const char* name, float value) {
+  if (!e || !name) return fail(FDM_ERR_INVALID, "null argument");
+  HIPCK(hipSetDevice(e->device));
+  return add_layer(e, name, value, false);
+}
+
+int fdm_engine_layer_download(fdm_engine* e, const char* name, float* host, int32_t rows, int32_t cols) {
+  if (!e || !name || !host) return fail(FDM_ERR_INVALID, "null argument");
+  if (rows != e->G.s_rows || cols != e->G.s_cols) return fail(FDM_ERR_INVALID, "shape mismatch");
+  if (int rc = resolve_pending(e)) return rc;
+  Layer* l = find_layer(e, name);
+  if (!l || l->pending) return fail(FDM_ERR_NO_LAYER, std::string("no layer ") + name);
+  HIPCK(hipMemcpyAsync(host, l->d, e->ncell * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIPCK(hipStreamSynchronize(e->stream));
+  return FDM_OK;
+}
+
+int fdm_engine_layer_upload(fdm_engine* e, const char* name, const float* host, int32_t rows, int32_t cols) {
+  if (!e || !name || !host) return fail(FDM_ERR_INVALID, "null argument");
+  if (rows != e->G.s_rows || cols != e->G.s_cols) return fail(FDM_ERR_INVALID, "shape mismatch");
+  HIPCK(hipSetDevice(e->device));
+  Layer* l = find_layer(e, name);
+  if (!l) {
+    if (int rc = add_layer(e, name, NAN, false)) return rc;
+    l = find_layer(e, name);
+  }
+  l->pending = false;
+  HIPCK(hipMemcpyAsync(l->d, host, e->ncell * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIPCK(hipStreamSynchronize(e->stream));
+  return FDM_OK;
+}
+
+float* fdm_engine_layer_device_ptr(fdm_engine* e, const char* name) {
+  if (!e || !name) return nullptr;
+  Layer* l = find_layer(e, name);
+  return l ? l->d : nullptr;
+}
+
+int fdm_engine_clear(fdm_engine* e, const char* name) {
+  if (!e) return fail(FDM_ERR_INVALID, "null engine");
+  HIPCK(hipSetDevice(e->device));
+  if (name) {
+    Layer* l = find_layer(e, name);
+    if (!l || l->pending) return fail(FDM_ERR_NO_LAYER, std::string("no layer ") + name);
+    return fill_async(e, l->d, NAN, e->ncell);
+  }
+  for (auto& l : e->layers)
+    if (int rc = fill_async(e, l.d, NAN, e->ncell)) return rc;
+  return FDM_OK;
+}
+
+static int region_copy(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, int32_t nc,
+                       const char* const* names, int n_layers, float* d_buf, int to_buf) {
+  if (!e || !names || !d_buf) return fail(FDM_ERR_INVALID, "null argument");
+  if (nr <= 0 || nc <= 0 || r0 < 0 || c0 < 0 || r0 + nr > e->G.s_rows || c0 + nc > e->G.s_cols)
+    return fail(FDM_ERR_INVALID, "region outside the stored window");
+  HIPCK(hipSetDevice(e->device));
+  for (int k = 0; k < n_layers; ++k) {
+    Layer* l = find_layer(e, names[k]);
+    if (!l) return fail(FDM_ERR_NO_LAYER, std::string("no layer ") + names[k]);
+    hipLaunchKernelGGL(k_region_copy, dim3((nr + 255) / 256, nc), dim3(256), 0, e->stream, l->d,
+                       d_buf + size_t(k) * nr * nc, e->G.s_rows, r0, c0, nr, nc, to_buf);
+    HIPCK(hipGetLastError());
+  }
+  return FDM_OK;
+}
+
+int fdm_engine_region_pack(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, int32_t nc,
+                           const char* const* names, int n_layers, float* d_buf) {
+  return region_copy(e, r0, c0, nr, nc, names, n_layers, d_buf, 1);
+}
+int fdm_engine_region_unpack(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, int32_t nc,
+                             const char* const* names, int n_layers, const float* d_buf) {
+  return region_copy(e, r0, c0, nr, nc, names, n_layers, const_cast<float*>(d_buf), 0);
+}
+
+int fdm_engine_enable_cell_ids(fdm_engine* e, int on) {
+  if (!e) return fail(FDM_ERR_INVALID, "null engine");
+  e->want_ids = on != 0;
+  return FDM_OK;
+}
+
+int fdm_engine_last_cell_ids(fdm_engine* e, int32_t* host_out, uint64_t n) {
+  if (!e || !host_out) return fail(FDM_ERR_INVALID, "null argument");
+  if (!e->want_ids || !e->d_cell_ids || n != e->last_n)
+    return fail(FDM_ERR_INVALID, "cell ids not recorded for the last scan");
+  HIPCK(hipMemcpyAsync(host_out, e->d_cell_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+  HIPCK(hipStreamSynchronize(e->stream));
+  return FDM_OK;
+}
+
+int fdm_engine_enable_profile(fdm_engine* e, int on) {
+  if (!e) return fail(FDM_ERR_INVALID, "null engine");
+  e->profile = on != 0;
+  return FDM_OK;
+}
+
+int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2) {
+  if (!e || !ms2) return fail(FDM_ERR_INVALID, "null argument");
+  if (!e->profile) return fail(FDM_ERR_INVALID, "profiling is off");
+  HIPCK(hipStreamSynchronize(e->stream));
+  HIPCK(hipEventElapsedTime(&ms2[0], e->ev[0], e->ev[1]));
+  HIPCK(hipEventElapsedTime(&ms2[1], e->ev[1], e->ev[2]));
+  return FDM_OK;
+}
+
+/* tuning knob used by bench.py's A/B runs (not part of the reference surface) */
+int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
+  if (!e || !key) return fail(FDM_ERR_INVALID, "null argument");
+  if (std::strcmp(key, "wave_merge") == 0) {
+    e->wave_merge = value != 0;
+    return FDM_OK;
+  }
+  return fail(FDM_ERR_INVALID, std::string("unknown option ") + key);
+}
+
+}  // extern "C"

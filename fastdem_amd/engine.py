@@ -1,0 +1,221 @@
+"""Thin Python handle over the C ABI (include/fdm_engine.h) — used by tests and bench.py.
+
+Mirrors the reference call shapes:
+  ElevationMap(width, height, resolution, frame)  -> Engine(width, height, resolution, cfg)
+  FastDEM::integrate(cloud, T_base_sensor, T_world_base) -> Engine.integrate(...)
+  ElevationMapping::update(cloud, robot_position)        -> Engine.update(...)
+Transforms are 4x4 row-major numpy arrays here and are handed to the ABI column-major
+(Eigen::Isometry3d::matrix().data()).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import FdmConfig, FdmGeometry, FdmScanStats, FdmTile
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _ck(rc):
+    if rc < 0:
+        raise EngineError(f"fdm_engine error {rc}: {capi.load().fdm_last_error().decode()}")
+    return rc
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _u32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _colmajor16(T):
+    T = np.asarray(T, dtype=np.float64).reshape(4, 4)
+    return np.ascontiguousarray(T.T).reshape(16)  # column-major flattening
+
+
+def _dptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    def __init__(self, width, height, resolution, cfg=None, position=(0.0, 0.0), tile=None,
+                 device=0):
+        self._lib = capi.load()
+        self.cfg = cfg if cfg is not None else capi.default_config()
+        g = FdmGeometry()
+        # ElevationMap::setGeometry(float,float,float) promotes float -> double
+        # (elevation_map.hpp:112-116): 0.1f becomes 0.100000001490116...
+        g.length_x = float(np.float32(width))
+        g.length_y = float(np.float32(height))
+        g.resolution = float(np.float32(resolution))
+        g.position_x, g.position_y = float(position[0]), float(position[1])
+        self._tile = None
+        tp = None
+        if tile is not None:
+            self._tile = FdmTile(*[int(v) for v in tile])
+            tp = C.byref(self._tile)
+        h = C.c_void_p()
+        _ck(self._lib.fdm_engine_create(C.byref(g), C.byref(self.cfg), tp, int(device), C.byref(h)))
+        self._h = h
+        geo = self.geometry()
+        self.rows, self.cols = geo.rows, geo.cols
+        self.s_rows = self._tile.rows if self._tile else self.rows
+        self.s_cols = self._tile.cols if self._tile else self.cols
+
+    # -- lifetime --
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fdm_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- configuration --
+    def set_config(self, cfg):
+        self.cfg = cfg
+        _ck(self._lib.fdm_engine_set_config(self._h, C.byref(cfg)))
+
+    def set_stream(self, stream_handle):
+        _ck(self._lib.fdm_engine_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def set_option(self, key, value):
+        _ck(self._lib.fdm_engine_set_option(self._h, key.encode(), int(value)))
+
+    # -- the hot path --
+    def integrate(self, x, y, z, T_base_sensor, T_world_base, intensity=None, rgb=None,
+                  sigma_z2=None):
+        """Host arrays in, synchronous.  Returns (status, stats dict); status 0 == `true`."""
+        x, y, z = _f32(x), _f32(y), _f32(z)
+        a, c, v = _f32(intensity), _u32(rgb), _f32(sigma_z2)
+        tbs, twb = _colmajor16(T_base_sensor), _colmajor16(T_world_base)
+        st = FdmScanStats()
+        rc = _ck(self._lib.fdm_engine_integrate(
+            self._h, x.size, _ptr(x), _ptr(y), _ptr(z), _ptr(a), _ptr(c), _ptr(v),
+            tbs.ctypes.data_as(C.POINTER(C.c_double)), twb.ctypes.data_as(C.POINTER(C.c_double)),
+            C.byref(st)))
+        return rc, st.as_dict()
+
+    def integrate_device(self, x, y, z, T_base_sensor, T_world_base, intensity=None, rgb=None,
+                         sigma_z2=None):
+        """torch device tensors in, enqueue only (no sync)."""
+        tbs, twb = _colmajor16(T_base_sensor), _colmajor16(T_world_base)
+        _ck(self._lib.fdm_engine_integrate_device(
+            self._h, x.numel(), _dptr(x), _dptr(y), _dptr(z), _dptr(intensity), _dptr(rgb),
+            _dptr(sigma_z2), tbs.ctypes.data_as(C.POINTER(C.c_double)),
+            twb.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def integrate_device_raw(self, n, dx, dy, dz, tbs16, twb16, dint=None, drgb=None, dvar=None):
+        """Pre-flattened column-major transforms (ctypes double arrays) + raw device pointers:
+        the minimum-overhead call used inside bench.py's timed loop."""
+        return self._lib.fdm_engine_integrate_device(self._h, n, dx, dy, dz, dint, drgb, dvar,
+                                                     tbs16, twb16)
+
+    def update(self, x, y, z, robot_xy=(0.0, 0.0), z_var=None, intensity=None, rgb=None):
+        x, y, z = _f32(x), _f32(y), _f32(z)
+        v, a, c = _f32(z_var), _f32(intensity), _u32(rgb)
+        st = FdmScanStats()
+        n = 0 if x is None else x.size
+        _ck(self._lib.fdm_engine_update(self._h, n, _ptr(x), _ptr(y), _ptr(z), _ptr(v), _ptr(a),
+                                        _ptr(c), float(robot_xy[0]), float(robot_xy[1]),
+                                        C.byref(st)))
+        return st.as_dict()
+
+    def sync(self):
+        _ck(self._lib.fdm_engine_sync(self._h))
+
+    def last_stats(self):
+        st = FdmScanStats()
+        rc = _ck(self._lib.fdm_engine_last_stats(self._h, C.byref(st)))
+        return rc, st.as_dict()
+
+    # -- grid --
+    def move(self, x, y):
+        _ck(self._lib.fdm_engine_move(self._h, float(x), float(y)))
+
+    def geometry(self):
+        g = FdmGeometry()
+        _ck(self._lib.fdm_engine_get_geometry(self._h, C.byref(g)))
+        return g
+
+    def set_position(self, x, y):
+        _ck(self._lib.fdm_engine_set_position(self._h, float(x), float(y)))
+
+    def set_start_index(self, r, c):
+        _ck(self._lib.fdm_engine_set_start_index(self._h, int(r), int(c)))
+
+    # -- layers --
+    def layers(self):
+        n = _ck(self._lib.fdm_engine_num_layers(self._h))
+        return [self._lib.fdm_engine_layer_name(self._h, i).decode() for i in range(n)]
+
+    def exists(self, name):
+        return bool(_ck(self._lib.fdm_engine_layer_exists(self._h, name.encode())))
+
+    def add(self, name, value=float("nan")):
+        _ck(self._lib.fdm_engine_layer_add(self._h, name.encode(), float(value)))
+
+    def layer(self, name):
+        """Download one layer as a (rows, cols) float32 array (Fortran order like MatrixXf)."""
+        out = np.empty((self.s_rows, self.s_cols), dtype=np.float32, order="F")
+        _ck(self._lib.fdm_engine_layer_download(self._h, name.encode(), _ptr(out), self.s_rows,
+                                                self.s_cols))
+        return out
+
+    def set_layer(self, name, arr):
+        a = np.asfortranarray(arr, dtype=np.float32)
+        assert a.shape == (self.s_rows, self.s_cols)
+        _ck(self._lib.fdm_engine_layer_upload(self._h, name.encode(), _ptr(a), self.s_rows,
+                                              self.s_cols))
+
+    def layer_device_ptr(self, name):
+        return self._lib.fdm_engine_layer_device_ptr(self._h, name.encode())
+
+    def clear(self, name=None):
+        _ck(self._lib.fdm_engine_clear(self._h, None if name is None else name.encode()))
+
+    def region_pack(self, r0, c0, nr, nc, names, dbuf_ptr):
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        _ck(self._lib.fdm_engine_region_pack(self._h, r0, c0, nr, nc, arr, len(names),
+                                             C.c_void_p(dbuf_ptr)))
+
+    def region_unpack(self, r0, c0, nr, nc, names, dbuf_ptr):
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        _ck(self._lib.fdm_engine_region_unpack(self._h, r0, c0, nr, nc, arr, len(names),
+                                               C.c_void_p(dbuf_ptr)))
+
+    # -- instrumentation --
+    def enable_cell_ids(self, on=True):
+        _ck(self._lib.fdm_engine_enable_cell_ids(self._h, int(on)))
+
+    def last_cell_ids(self, n):
+        out = np.empty(n, dtype=np.int32)
+        _ck(self._lib.fdm_engine_last_cell_ids(self._h, _ptr(out), n))
+        return out
+
+    def enable_profile(self, on=True):
+        _ck(self._lib.fdm_engine_enable_profile(self._h, int(on)))
+
+    def last_kernel_ms(self):
+        ms = (C.c_float * 2)()
+        _ck(self._lib.fdm_engine_last_kernel_ms(self._h, ms))
+        return float(ms[0]), float(ms[1])

@@ -1,0 +1,175 @@
+/* fdm_engine.h — C ABI of the MI355X elevation-map update engine (libfdm_engine.so).
+ *
+ * This is the drop-in boundary for ONE path of Ikhyeon-Cho/FastDEM:
+ *   fastdem::FastDEM::integrate(cloud, T_base_sensor, T_world_base)
+ * The reference has no FFI; its boundary is the C++ class surface
+ * (fastdem/include/fastdem/fastdem.hpp:54-158).  A maintainer swaps the body of
+ * FastDEM::integrateImpl (fastdem/src/fastdem.cpp:133-162) for the calls below —
+ * INTEGRATION.md shows the binding.  Every entry point cites what it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes; no C++/torch types; no exceptions cross the boundary
+ *   - int status: 0 ok, >0 "skipped" (the reference's `return false` cases), <0 error
+ *   - transforms are column-major double[16] == Eigen::Isometry3d::matrix().data()
+ *   - layers are float32, column-major rows x cols == Eigen::MatrixXf storage
+ *     (fastdem/include/fastdem/bridge/ros/impl.hpp:117-119)
+ *   - one engine = one device + one HIP stream; not thread-safe, caller serialises
+ *     (same contract as fastdem.hpp:48-53)
+ *   - host pointers are borrowed for the duration of the call only; device pointers
+ *     passed to the *_device entry points must stay valid until fdm_engine_sync()
+ */
+#ifndef FDM_ENGINE_H
+#define FDM_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fdm_engine fdm_engine;
+
+/* Mirrors fastdem::Config for this path, field for field
+ * (config/fastdem.hpp:23-38, config/sensor_model.hpp:10-37, config/mapping.hpp:10-48).
+ * config::Raycasting is out of scope. */
+typedef struct fdm_config {
+  float z_min, z_max, range_min, range_max;     /* config::PointFilter */
+  int32_t sensor_type;                          /* SensorType: 0 Constant, 1 LiDAR, 2 RGBD */
+  float lidar_range_noise, lidar_angular_noise;
+  float rgbd_normal_a, rgbd_normal_b, rgbd_normal_c, rgbd_lateral_factor;
+  float constant_uncertainty;
+  int32_t mode;                                 /* MappingMode: 0 LOCAL, 1 GLOBAL */
+  int32_t estimation_type;                      /* EstimationType: 0 Kalman, 1 P2Quantile */
+  float kalman_min_variance, kalman_max_variance, kalman_process_noise;
+  float p2_dn[5];
+  int32_t p2_elevation_marker;
+  float p2_max_sample_count;
+} fdm_config;
+
+/* nanogrid::GridMap geometry (length, resolution, position, circular-buffer start).
+ * rows/cols are outputs of create (size = round(length / resolution)). */
+typedef struct fdm_geometry {
+  double length_x, length_y, resolution, position_x, position_y;
+  int32_t rows, cols, start_row, start_col;
+} fdm_geometry;
+
+/* Multi-GPU spatial tiling, GLOBAL mode only.  This engine STORES the
+ * window [row0,row0+rows) x [col0,col0+cols) of the global buffer (owned cells plus a
+ * read-only halo ring) and UPDATES only the owned window [own_row0,own_row0+own_rows) x
+ * [own_col0,own_col0+own_cols); points landing elsewhere are ignored by this engine.
+ * Cell indices are always computed against the GLOBAL geometry, so they are bit-identical
+ * to the single-GPU map. */
+typedef struct fdm_tile {
+  int32_t row0, col0, rows, cols;
+  int32_t own_row0, own_col0, own_rows, own_cols;
+} fdm_tile;
+
+typedef struct fdm_scan_stats {
+  uint32_t n_input;         /* points handed in */
+  uint32_t n_after_filter;  /* survived cropRange + cropZ (fastdem.cpp:175-176) */
+  uint32_t n_in_map;        /* getIndex succeeded (elevation_mapping.cpp:55) */
+  uint32_t n_cells_touched; /* |CellObservations| */
+  int32_t shift_rows, shift_cols; /* index shift of the LOCAL-mode move applied */
+} fdm_scan_stats;
+
+enum {
+  FDM_OK = 0,
+  FDM_SKIP_EMPTY_CLOUD = 1,   /* fastdem.cpp:125-128 -> false */
+  FDM_SKIP_ALL_FILTERED = 2,  /* fastdem.cpp:138     -> false */
+  FDM_ERR_INVALID = -1,
+  FDM_ERR_HIP = -2,
+  FDM_ERR_NO_LAYER = -3,
+  FDM_ERR_NO_DEVICE = -4
+};
+
+void fdm_default_config(fdm_config* cfg);      /* Config{} defaults */
+const char* fdm_last_error(void);              /* text of the last <0 status on this thread */
+
+/* ElevationMap(width,height,resolution,frame) + FastDEM(map,cfg) construction
+ * (elevation_map.hpp:101-116, fastdem.cpp:19-22, elevation_mapping.cpp:11-39):
+ * allocates the layers in HBM with the reference's initial constants.
+ * g->length_*, resolution, position_* are read; tile may be NULL (whole map). */
+int fdm_engine_create(const fdm_geometry* g, const fdm_config* cfg, const fdm_tile* tile,
+                      int device, fdm_engine** out);
+void fdm_engine_destroy(fdm_engine* e);
+
+/* FastDEM fluent setters (fastdem.cpp:28-62): filters/sensor params take effect on
+ * the next scan; a new estimator type adds its layers, the old ones persist. */
+int fdm_engine_set_config(fdm_engine* e, const fdm_config* cfg);
+
+/* Run on the caller's HIP stream (hipStream_t as void*; NULL = engine's own stream). */
+int fdm_engine_set_stream(fdm_engine* e, void* hip_stream);
+
+/* FastDEM::integrate(const PointCloud&, T_base_sensor, T_world_base) — fastdem.cpp:122-162.
+ * SoA host arrays (x,y,z required; intensity / rgb = 0x00RRGGBB / sigma_z2 nullable).
+ * sigma_z2, when given, replaces the built-in sensor model: it is the (2,2) element of
+ * R*Sigma*R^T per point, for user SensorModel subclasses (fastdem.hpp:79-80).
+ * Synchronous: returns after the map update; status as above. */
+int fdm_engine_integrate(fdm_engine* e, uint64_t n, const float* x, const float* y,
+                         const float* z, const float* intensity, const uint32_t* rgb,
+                         const float* sigma_z2, const double T_base_sensor[16],
+                         const double T_world_base[16], fdm_scan_stats* out);
+
+/* Same, inputs already resident in HBM; enqueue-only (no host sync).  The skip
+ * decisions of fastdem.cpp:125-138 are taken on the device; read them back with
+ * fdm_engine_last_stats(). */
+int fdm_engine_integrate_device(fdm_engine* e, uint64_t n, const float* d_x, const float* d_y,
+                                const float* d_z, const float* d_intensity, const uint32_t* d_rgb,
+                                const float* d_sigma_z2, const double T_base_sensor[16],
+                                const double T_world_base[16]);
+
+/* ElevationMapping::update(cloud, robot_position) — elevation_mapping.cpp:110-125 —
+ * for a cloud already in the map frame (tests/test_dual_layer.cpp:71).  z_var NULL
+ * == cloud without covariance channel (pt_z_var = 0, elevation_mapping.cpp:57-60). */
+int fdm_engine_update(fdm_engine* e, uint64_t n, const float* x, const float* y, const float* z,
+                      const float* z_var, const float* intensity, const uint32_t* rgb,
+                      double robot_x, double robot_y, fdm_scan_stats* out);
+int fdm_engine_update_device(fdm_engine* e, uint64_t n, const float* d_x, const float* d_y,
+                             const float* d_z, const float* d_z_var, const float* d_intensity,
+                             const uint32_t* d_rgb, double robot_x, double robot_y);
+
+int fdm_engine_sync(fdm_engine* e);
+/* Waits for the stream, returns the status (0/1/2) and stats of the last enqueued scan. */
+int fdm_engine_last_stats(fdm_engine* e, fdm_scan_stats* out);
+
+/* nanogrid::GridMap::move(Position) (elevation_mapping.cpp:113): rolling-window shift. */
+int fdm_engine_move(fdm_engine* e, double x, double y);
+int fdm_engine_get_geometry(fdm_engine* e, fdm_geometry* out);       /* getPosition/getStartIndex/... */
+int fdm_engine_set_position(fdm_engine* e, double x, double y);      /* GridMap::setPosition */
+int fdm_engine_set_start_index(fdm_engine* e, int32_t row, int32_t col);
+
+/* GridMap::getLayers / exists / add / get / clear / clearAll (FastDEM::reset = clear(NULL)). */
+int fdm_engine_num_layers(fdm_engine* e);
+const char* fdm_engine_layer_name(fdm_engine* e, int i);
+int fdm_engine_layer_exists(fdm_engine* e, const char* name);
+int fdm_engine_layer_add(fdm_engine* e, const char* name, float value);
+int fdm_engine_layer_download(fdm_engine* e, const char* name, float* host, int32_t rows, int32_t cols);
+int fdm_engine_layer_upload(fdm_engine* e, const char* name, const float* host, int32_t rows, int32_t cols);
+float* fdm_engine_layer_device_ptr(fdm_engine* e, const char* name); /* NULL if absent */
+int fdm_engine_clear(fdm_engine* e, const char* name /* NULL = clearAll */);
+
+/* Halo exchange support for spatial tiling: pack the rectangle [r0,r0+nr) x [c0,c0+nc)
+ * (storage-local indices) of `n_layers` named layers into a contiguous device buffer
+ * (layer-major, each rectangle column-major), or write such a buffer back.  The RCCL
+ * send/recv between neighbouring ranks is done by the caller (fastdem_amd/tiling.py). */
+int fdm_engine_region_pack(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, int32_t nc,
+                           const char* const* names, int n_layers, float* d_buf);
+int fdm_engine_region_unpack(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, int32_t nc,
+                             const char* const* names, int n_layers, const float* d_buf);
+
+/* Parity / measurement instrumentation (not in the reference). */
+int fdm_engine_enable_cell_ids(fdm_engine* e, int on);
+/* per input point of the last scan: linear cell id (col*rows+row), -1 cropped, -2 outside map */
+int fdm_engine_last_cell_ids(fdm_engine* e, int32_t* host_out, uint64_t n);
+int fdm_engine_enable_profile(fdm_engine* e, int on);
+/* HIP-event durations of the last scan's kernels: ms[0] = bin kernel, ms[1] = update kernel */
+int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2);
+
+/* Tuning knobs for A/B measurements (bench.py); unknown keys are an error.
+ *   "wave_merge" 0/1 : merge same-cell runs inside the wavefront before the atomics */
+int fdm_engine_set_option(fdm_engine* e, const char* key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDM_ENGINE_H */

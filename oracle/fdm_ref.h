@@ -1,0 +1,104 @@
+/* fdm_ref.h — C entry points of the CPU oracle (libfdm_ref.so).
+ *
+ * *** TEST INFRASTRUCTURE — NOT PRODUCT CODE. ***
+ * Callers allowed: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.
+ * PARITY STATUS: algorithm pinned by the reference's known-answer tests
+ * (tests/test_oracle_reference_spec.py); nanoGrid index arithmetic
+ * "parity unpinned" (library absent from /root/reference — see fdm_grid.hpp).
+ *
+ * The struct layouts are deliberately identical to include/fdm_engine.h so the
+ * same ctypes definitions drive both the checker and the engine.
+ */
+#ifndef FDM_REF_H
+#define FDM_REF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fdmref_config {
+  float z_min, z_max, range_min, range_max;            /* config/fastdem.hpp:23-28 */
+  int32_t sensor_type;                                 /* 0 Constant, 1 LiDAR, 2 RGBD */
+  float lidar_range_noise, lidar_angular_noise;        /* config/sensor_model.hpp:22-25 */
+  float rgbd_normal_a, rgbd_normal_b, rgbd_normal_c, rgbd_lateral_factor;
+  float constant_uncertainty;
+  int32_t mode;                                        /* 0 LOCAL, 1 GLOBAL */
+  int32_t estimation_type;                             /* 0 Kalman, 1 P2Quantile */
+  float kalman_min_variance, kalman_max_variance, kalman_process_noise;
+  float p2_dn[5];
+  int32_t p2_elevation_marker;
+  float p2_max_sample_count;
+} fdmref_config;
+
+typedef struct fdmref_stats {
+  uint32_t n_input, n_after_filter, n_in_map, n_cells_touched;
+  int32_t shift_rows, shift_cols;
+} fdmref_stats;
+
+typedef struct fdmref_geometry {
+  double length_x, length_y, resolution, position_x, position_y;
+  int32_t rows, cols, start_row, start_col;
+} fdmref_geometry;
+
+void fdmref_default_config(fdmref_config* cfg);
+
+void* fdmref_create(float width, float height, float resolution, const fdmref_config* cfg);
+void fdmref_destroy(void* e);
+void fdmref_set_config(void* e, const fdmref_config* cfg);
+void fdmref_reset(void* e);                   /* FastDEM::reset -> clearAll */
+void fdmref_track_ids(void* e, int on);       /* record per-input-point cell ids */
+
+/* FastDEM::integrate(cloud, T_base_sensor, T_world_base); T are column-major double[16]
+ * (Eigen Isometry3d::matrix().data()).  rgb = 0x00RRGGBB.  Returns 0 ok, 1 empty cloud,
+ * 2 everything filtered (the reference's `false` cases). */
+int fdmref_integrate(void* e, uint64_t n, const float* x, const float* y, const float* z,
+                     const float* intensity, const uint32_t* rgb, const double* T_base_sensor,
+                     const double* T_world_base, fdmref_stats* out);
+
+/* ElevationMapping::update(cloud, robot_xy) on a cloud already in the map frame;
+ * z_var may be NULL (cloud without covariance channel -> 0). */
+int fdmref_update(void* e, uint64_t n, const float* x, const float* y, const float* z,
+                  const float* z_var, const float* intensity, const uint32_t* rgb, double robot_x,
+                  double robot_y, fdmref_stats* out);
+
+/* Time `iters` integrate() calls on a prebuilt AoS cloud (AoS build excluded).
+ * Poses: T_world_base[k] for k in [0, n_poses) cycled; returns seconds total.
+ * stage_seconds (nullable) receives the 5 Jetson-figure stages accumulated. */
+double fdmref_time_integrate(void* e, uint64_t n, const float* x, const float* y, const float* z,
+                             const float* intensity, const uint32_t* rgb,
+                             const double* T_base_sensor, const double* T_world_base_seq,
+                             int n_poses, int iters, double* stage_seconds);
+
+int fdmref_move(void* e, double x, double y, int32_t* shift2);
+void fdmref_get_geometry(void* e, fdmref_geometry* g);
+void fdmref_set_position(void* e, double x, double y);
+void fdmref_set_start_index(void* e, int r, int c);
+int fdmref_get_index(void* e, double x, double y, int32_t* rc2);    /* 1 inside */
+int fdmref_get_position(void* e, int r, int c, double* xy2);        /* 1 valid */
+
+int fdmref_num_layers(void* e);
+const char* fdmref_layer_name(void* e, int i);
+int fdmref_layer_exists(void* e, const char* name);
+int fdmref_layer_get(void* e, const char* name, float* out);        /* rows*cols, col-major */
+int fdmref_layer_set(void* e, const char* name, const float* in);   /* adds if missing */
+int fdmref_layer_add(void* e, const char* name, float value);
+int fdmref_clear(void* e, const char* name /* NULL = all */);
+int fdmref_last_cell_ids(void* e, int32_t* out, uint64_t n);
+
+/* unit-level entry points for the reference's known-answer tests */
+void fdmref_sensor_covariance(const fdmref_config* cfg, const float* p3, float* cov9_colmajor);
+/* state8 = {x, P, count, sample_mean, sample_var, m2, upper, lower} */
+void fdmref_kalman_update(float min_var, float max_var, float q, float* state8, float z, float var,
+                          int compute_bounds);
+/* state15 = {elevation, variance, count, upper, lower, q0..q4, n0..n4} */
+void fdmref_p2_update(const float* dn5, int marker, float max_count, float* state15, float x,
+                      int compute_bounds);
+float fdmref_sigma_z2(const fdmref_config* cfg, const float* p3, const double* T_base_sensor,
+                      const double* T_world_base);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,225 @@
+// fdm_ref_capi.cpp — extern "C" surface of the CPU oracle.
+// *** TEST INFRASTRUCTURE — NOT PRODUCT CODE. ***  (see fdm_ref.hpp header)
+#include "fdm_ref.h"
+
+#include <cstring>
+
+#include "fdm_ref.hpp"
+
+using namespace fdmref;
+
+static_assert(sizeof(fdmref_config) == sizeof(Config), "config layout must match");
+
+namespace {
+Config toConfig(const fdmref_config* c) {
+  Config out;
+  std::memcpy(static_cast<void*>(&out), c, sizeof(Config));
+  return out;
+}
+Engine* E(void* e) { return static_cast<Engine*>(e); }
+
+Cloud buildCloud(uint64_t n, const float* x, const float* y, const float* z, const float* intensity,
+                 const uint32_t* rgb) {
+  Cloud c;
+  c.has_intensity = intensity != nullptr;
+  c.has_color = rgb != nullptr;
+  c.resize(n);
+  for (uint64_t i = 0; i < n; ++i) {
+    c.pts[i] = {x[i], y[i], z[i], 1.0f};
+    if (intensity) c.intensity[i] = intensity[i];
+    if (rgb) c.color[i] = {uint8_t(rgb[i] >> 16), uint8_t(rgb[i] >> 8), uint8_t(rgb[i])};
+  }
+  return c;
+}
+void copyStats(const ScanStats& s, fdmref_stats* out) {
+  if (!out) return;
+  out->n_input = s.n_input;
+  out->n_after_filter = s.n_after_filter;
+  out->n_in_map = s.n_in_map;
+  out->n_cells_touched = s.n_cells_touched;
+  out->shift_rows = s.shift_rows;
+  out->shift_cols = s.shift_cols;
+}
+}  // namespace
+
+extern "C" {
+
+void fdmref_default_config(fdmref_config* cfg) {
+  Config d;
+  std::memcpy(cfg, &d, sizeof(Config));
+}
+
+void* fdmref_create(float width, float height, float resolution, const fdmref_config* cfg) {
+  return new Engine(width, height, resolution, toConfig(cfg));
+}
+void fdmref_destroy(void* e) { delete E(e); }
+void fdmref_set_config(void* e, const fdmref_config* cfg) { E(e)->setConfig(toConfig(cfg)); }
+void fdmref_reset(void* e) { E(e)->reset(); }
+void fdmref_track_ids(void* e, int on) { E(e)->track_ids = on != 0; }
+
+int fdmref_integrate(void* e, uint64_t n, const float* x, const float* y, const float* z,
+                     const float* intensity, const uint32_t* rgb, const double* T_bs,
+                     const double* T_wb, fdmref_stats* out) {
+  Cloud c = buildCloud(n, x, y, z, intensity, rgb);
+  ScanStats s;
+  const Status st = E(e)->integrate(c, T_bs, T_wb, &s);
+  copyStats(s, out);
+  return st;
+}
+
+int fdmref_update(void* e, uint64_t n, const float* x, const float* y, const float* z,
+                  const float* z_var, const float* intensity, const uint32_t* rgb, double robot_x,
+                  double robot_y, fdmref_stats* out) {
+  Cloud c = buildCloud(n, x, y, z, intensity, rgb);
+  if (z_var) {
+    c.has_cov = true;
+    c.cov.assign(n, Mat3f{});
+    for (uint64_t i = 0; i < n; ++i) M3(c.cov[i], 2, 2) = z_var[i];
+  }
+  Engine* en = E(e);
+  if (en->track_ids) {
+    en->last_cell_ids.assign(n, -1);
+    c.track_orig = true;
+    c.orig.resize(n);
+    for (uint64_t i = 0; i < n; ++i) c.orig[i] = uint32_t(i);
+  }
+  ScanStats s;
+  s.n_input = s.n_after_filter = uint32_t(n);
+  en->update(c, robot_x, robot_y, &s);
+  copyStats(s, out);
+  return OK;
+}
+
+double fdmref_time_integrate(void* e, uint64_t n, const float* x, const float* y, const float* z,
+                             const float* intensity, const uint32_t* rgb, const double* T_bs,
+                             const double* T_wb_seq, int n_poses, int iters, double* stage_seconds) {
+  Engine* en = E(e);
+  Cloud c = buildCloud(n, x, y, z, intensity, rgb);
+  const bool was_tracking = en->track_ids;
+  en->track_ids = false;
+  en->time_stages = stage_seconds != nullptr;
+  en->times = StageTimes{};
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int it = 0; it < iters; ++it) {
+    ScanStats s;
+    en->integrate(c, T_bs, T_wb_seq + 16 * (it % n_poses), &s);
+  }
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (stage_seconds) {
+    stage_seconds[0] = en->times.sensor_cov;
+    stage_seconds[1] = en->times.transform_filter;
+    stage_seconds[2] = en->times.cov_transform;
+    stage_seconds[3] = en->times.rasterize;
+    stage_seconds[4] = en->times.map_update;
+  }
+  en->time_stages = false;
+  en->track_ids = was_tracking;
+  return dt;
+}
+
+int fdmref_move(void* e, double x, double y, int32_t* shift2) {
+  int sh[2] = {0, 0};
+  const bool moved = E(e)->map().move(x, y, sh);
+  if (shift2) {
+    shift2[0] = sh[0];
+    shift2[1] = sh[1];
+  }
+  return moved ? 1 : 0;
+}
+
+void fdmref_get_geometry(void* e, fdmref_geometry* g) {
+  const Grid& m = E(e)->map();
+  g->length_x = m.length()[0];
+  g->length_y = m.length()[1];
+  g->resolution = m.resolution();
+  g->position_x = m.position()[0];
+  g->position_y = m.position()[1];
+  g->rows = m.rows();
+  g->cols = m.cols();
+  g->start_row = m.startIndex()[0];
+  g->start_col = m.startIndex()[1];
+}
+void fdmref_set_position(void* e, double x, double y) { E(e)->map().setPosition(x, y); }
+void fdmref_set_start_index(void* e, int r, int c) { E(e)->map().setStartIndex(r, c); }
+
+int fdmref_get_index(void* e, double x, double y, int32_t* rc2) {
+  Index2 i;
+  const bool ok = E(e)->map().getIndex(x, y, i);
+  rc2[0] = i.r;
+  rc2[1] = i.c;
+  return ok ? 1 : 0;
+}
+int fdmref_get_position(void* e, int r, int c, double* xy2) {
+  return E(e)->map().getPosition(Index2{r, c}, xy2[0], xy2[1]) ? 1 : 0;
+}
+
+int fdmref_num_layers(void* e) { return int(E(e)->map().layers().size()); }
+const char* fdmref_layer_name(void* e, int i) { return E(e)->map().layers()[size_t(i)].c_str(); }
+int fdmref_layer_exists(void* e, const char* name) { return E(e)->map().exists(name) ? 1 : 0; }
+int fdmref_layer_get(void* e, const char* name, float* out) {
+  Grid& m = E(e)->map();
+  if (!m.exists(name)) return -1;
+  const auto& v = m.get(name);
+  std::memcpy(out, v.data(), v.size() * sizeof(float));
+  return 0;
+}
+int fdmref_layer_set(void* e, const char* name, const float* in) {
+  Grid& m = E(e)->map();
+  if (!m.exists(name)) m.add(name);
+  auto& v = m.get(name);
+  std::memcpy(v.data(), in, v.size() * sizeof(float));
+  return 0;
+}
+int fdmref_layer_add(void* e, const char* name, float value) {
+  E(e)->map().add(name, value);
+  return 0;
+}
+int fdmref_clear(void* e, const char* name) {
+  Grid& m = E(e)->map();
+  if (!name) {
+    m.clearAll();
+    return 0;
+  }
+  if (!m.exists(name)) return -1;
+  m.clear(name);
+  return 0;
+}
+int fdmref_last_cell_ids(void* e, int32_t* out, uint64_t n) {
+  const auto& v = E(e)->last_cell_ids;
+  if (v.size() != n) return -1;
+  std::memcpy(out, v.data(), n * sizeof(int32_t));
+  return 0;
+}
+
+void fdmref_sensor_covariance(const fdmref_config* cfg, const float* p3, float* cov9) {
+  const Mat3f m = sensorCovariance(toConfig(cfg), p3);
+  std::memcpy(cov9, m.data(), sizeof(float) * 9);
+}
+
+void fdmref_kalman_update(float min_var, float max_var, float q, float* s, float z, float var,
+                          int compute_bounds) {
+  KalmanCell c{s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]};
+  kalmanUpdate(KalmanParams{min_var, max_var, q}, c, z, var);
+  if (compute_bounds) kalmanBounds(c);
+}
+
+void fdmref_p2_update(const float* dn5, int marker, float max_count, float* s, float x,
+                      int compute_bounds) {
+  const P2Params p = P2Params::make(dn5, marker, max_count);
+  P2Cell c{s[0], s[1], s[2], s[3], s[4], {}, {}};
+  for (int k = 0; k < 5; ++k) {
+    c.q[k] = s + 5 + k;
+    c.n[k] = s + 10 + k;
+  }
+  p2Update(p, c, x);
+  if (compute_bounds) p2Bounds(p, c);
+}
+
+float fdmref_sigma_z2(const fdmref_config* cfg, const float* p3, const double* T_bs,
+                      const double* T_wb) {
+  const Mat3f S = sensorCovariance(toConfig(cfg), p3);
+  const Mat3f R = rotationOfProduct(T_wb, T_bs);
+  return M3(rotateCovariance(R, S), 2, 2);
+}
+
+}  // extern "C"

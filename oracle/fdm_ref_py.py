@@ -1,0 +1,332 @@
+"""ctypes handle over oracle/_build/libfdm_ref.so — the CPU checker.
+
+*** TEST INFRASTRUCTURE — NOT PRODUCT CODE. ***
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The interface mirrors fastdem_amd.engine.Engine so the parity tests drive both the
+same way.  Parity status: see oracle/fdm_ref.hpp ("parity unpinned" for nanoGrid
+index arithmetic; algorithm pinned by the reference's known-answer tests).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libfdm_ref.so")
+LIB_NATIVE_PATH = os.path.join(_HERE, "_build", "libfdm_ref_native.so")
+
+
+class RefConfig(C.Structure):
+    _fields_ = [
+        ("z_min", C.c_float), ("z_max", C.c_float),
+        ("range_min", C.c_float), ("range_max", C.c_float),
+        ("sensor_type", C.c_int32),
+        ("lidar_range_noise", C.c_float), ("lidar_angular_noise", C.c_float),
+        ("rgbd_normal_a", C.c_float), ("rgbd_normal_b", C.c_float),
+        ("rgbd_normal_c", C.c_float), ("rgbd_lateral_factor", C.c_float),
+        ("constant_uncertainty", C.c_float),
+        ("mode", C.c_int32), ("estimation_type", C.c_int32),
+        ("kalman_min_variance", C.c_float), ("kalman_max_variance", C.c_float),
+        ("kalman_process_noise", C.c_float),
+        ("p2_dn", C.c_float * 5),
+        ("p2_elevation_marker", C.c_int32),
+        ("p2_max_sample_count", C.c_float),
+    ]
+
+
+class RefStats(C.Structure):
+    _fields_ = [
+        ("n_input", C.c_uint32), ("n_after_filter", C.c_uint32),
+        ("n_in_map", C.c_uint32), ("n_cells_touched", C.c_uint32),
+        ("shift_rows", C.c_int32), ("shift_cols", C.c_int32),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class RefGeometry(C.Structure):
+    _fields_ = [
+        ("length_x", C.c_double), ("length_y", C.c_double), ("resolution", C.c_double),
+        ("position_x", C.c_double), ("position_y", C.c_double),
+        ("rows", C.c_int32), ("cols", C.c_int32),
+        ("start_row", C.c_int32), ("start_col", C.c_int32),
+    ]
+
+
+_libs = {}
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def load(native=False):
+    path = LIB_NATIVE_PATH if native else LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        build()
+    lib = C.CDLL(path)
+    P, D = C.c_void_p, C.POINTER(C.c_double)
+    lib.fdmref_default_config.argtypes = [C.POINTER(RefConfig)]
+    lib.fdmref_create.restype = P
+    lib.fdmref_create.argtypes = [C.c_float, C.c_float, C.c_float, C.POINTER(RefConfig)]
+    lib.fdmref_destroy.argtypes = [P]
+    lib.fdmref_set_config.argtypes = [P, C.POINTER(RefConfig)]
+    lib.fdmref_reset.argtypes = [P]
+    lib.fdmref_track_ids.argtypes = [P, C.c_int]
+    lib.fdmref_integrate.restype = C.c_int
+    lib.fdmref_integrate.argtypes = [P, C.c_uint64, P, P, P, P, P, D, D, C.POINTER(RefStats)]
+    lib.fdmref_update.restype = C.c_int
+    lib.fdmref_update.argtypes = [P, C.c_uint64, P, P, P, P, P, P, C.c_double, C.c_double,
+                                  C.POINTER(RefStats)]
+    lib.fdmref_time_integrate.restype = C.c_double
+    lib.fdmref_time_integrate.argtypes = [P, C.c_uint64, P, P, P, P, P, D, D, C.c_int, C.c_int, D]
+    lib.fdmref_move.restype = C.c_int
+    lib.fdmref_move.argtypes = [P, C.c_double, C.c_double, C.POINTER(C.c_int32)]
+    lib.fdmref_get_geometry.argtypes = [P, C.POINTER(RefGeometry)]
+    lib.fdmref_set_position.argtypes = [P, C.c_double, C.c_double]
+    lib.fdmref_set_start_index.argtypes = [P, C.c_int, C.c_int]
+    lib.fdmref_get_index.restype = C.c_int
+    lib.fdmref_get_index.argtypes = [P, C.c_double, C.c_double, C.POINTER(C.c_int32)]
+    lib.fdmref_get_position.restype = C.c_int
+    lib.fdmref_get_position.argtypes = [P, C.c_int, C.c_int, D]
+    lib.fdmref_num_layers.restype = C.c_int
+    lib.fdmref_num_layers.argtypes = [P]
+    lib.fdmref_layer_name.restype = C.c_char_p
+    lib.fdmref_layer_name.argtypes = [P, C.c_int]
+    lib.fdmref_layer_exists.restype = C.c_int
+    lib.fdmref_layer_exists.argtypes = [P, C.c_char_p]
+    lib.fdmref_layer_get.restype = C.c_int
+    lib.fdmref_layer_get.argtypes = [P, C.c_char_p, P]
+    lib.fdmref_layer_set.restype = C.c_int
+    lib.fdmref_layer_set.argtypes = [P, C.c_char_p, P]
+    lib.fdmref_layer_add.restype = C.c_int
+    lib.fdmref_layer_add.argtypes = [P, C.c_char_p, C.c_float]
+    lib.fdmref_clear.restype = C.c_int
+    lib.fdmref_clear.argtypes = [P, C.c_char_p]
+    lib.fdmref_last_cell_ids.restype = C.c_int
+    lib.fdmref_last_cell_ids.argtypes = [P, P, C.c_uint64]
+    lib.fdmref_sensor_covariance.argtypes = [C.POINTER(RefConfig), P, P]
+    lib.fdmref_kalman_update.argtypes = [C.c_float, C.c_float, C.c_float, P, C.c_float, C.c_float,
+                                         C.c_int]
+    lib.fdmref_p2_update.argtypes = [P, C.c_int, C.c_float, P, C.c_float, C.c_int]
+    lib.fdmref_sigma_z2.restype = C.c_float
+    lib.fdmref_sigma_z2.argtypes = [C.POINTER(RefConfig), P, D, D]
+    _libs[path] = lib
+    return lib
+
+
+def default_config():
+    cfg = RefConfig()
+    load().fdmref_default_config(C.byref(cfg))
+    return cfg
+
+
+def config_from(other):
+    """Copy any ctypes struct with the same field names (e.g. fastdem_amd.capi.FdmConfig)."""
+    cfg = RefConfig()
+    for k, _ in RefConfig._fields_:
+        v = getattr(other, k)
+        if k == "p2_dn":
+            for i in range(5):
+                cfg.p2_dn[i] = v[i]
+        else:
+            setattr(cfg, k, v)
+    return cfg
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _u32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _colmajor16(T):
+    T = np.asarray(T, dtype=np.float64).reshape(4, 4)
+    return np.ascontiguousarray(T.T).reshape(16)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class RefEngine:
+    def __init__(self, width, height, resolution, cfg=None, position=(0.0, 0.0), native=False):
+        self._lib = load(native)
+        self.cfg = cfg if cfg is not None else default_config()
+        if not isinstance(self.cfg, RefConfig):
+            self.cfg = config_from(self.cfg)
+        self._h = C.c_void_p(self._lib.fdmref_create(width, height, resolution, C.byref(self.cfg)))
+        if position != (0.0, 0.0):
+            self._lib.fdmref_set_position(self._h, float(position[0]), float(position[1]))
+        g = self.geometry()
+        self.rows, self.cols = g.rows, g.cols
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fdmref_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_config(self, cfg):
+        self.cfg = cfg if isinstance(cfg, RefConfig) else config_from(cfg)
+        self._lib.fdmref_set_config(self._h, C.byref(self.cfg))
+
+    def integrate(self, x, y, z, T_base_sensor, T_world_base, intensity=None, rgb=None):
+        x, y, z = _f32(x), _f32(y), _f32(z)
+        a, c = _f32(intensity), _u32(rgb)
+        tbs, twb = _colmajor16(T_base_sensor), _colmajor16(T_world_base)
+        st = RefStats()
+        rc = self._lib.fdmref_integrate(self._h, x.size, _ptr(x), _ptr(y), _ptr(z), _ptr(a), _ptr(c),
+                                        _dp(tbs), _dp(twb), C.byref(st))
+        return rc, st.as_dict()
+
+    def update(self, x, y, z, robot_xy=(0.0, 0.0), z_var=None, intensity=None, rgb=None):
+        x, y, z = _f32(x), _f32(y), _f32(z)
+        v, a, c = _f32(z_var), _f32(intensity), _u32(rgb)
+        st = RefStats()
+        self._lib.fdmref_update(self._h, x.size, _ptr(x), _ptr(y), _ptr(z), _ptr(v), _ptr(a), _ptr(c),
+                                float(robot_xy[0]), float(robot_xy[1]), C.byref(st))
+        return st.as_dict()
+
+    def time_integrate(self, x, y, z, T_base_sensor, T_world_base_seq, iters, intensity=None,
+                       rgb=None, stages=False):
+        """Seconds for `iters` integrate() calls cycling through the pose sequence."""
+        x, y, z = _f32(x), _f32(y), _f32(z)
+        a, c = _f32(intensity), _u32(rgb)
+        tbs = _colmajor16(T_base_sensor)
+        seq = np.ascontiguousarray(np.stack([_colmajor16(T) for T in T_world_base_seq]))
+        st = np.zeros(5, dtype=np.float64) if stages else None
+        dt = self._lib.fdmref_time_integrate(self._h, x.size, _ptr(x), _ptr(y), _ptr(z), _ptr(a),
+                                             _ptr(c), _dp(tbs), _dp(seq), len(T_world_base_seq),
+                                             int(iters), None if st is None else _dp(st))
+        return (dt, st) if stages else dt
+
+    def move(self, x, y):
+        sh = (C.c_int32 * 2)()
+        self._lib.fdmref_move(self._h, float(x), float(y), sh)
+        return sh[0], sh[1]
+
+    def geometry(self):
+        g = RefGeometry()
+        self._lib.fdmref_get_geometry(self._h, C.byref(g))
+        return g
+
+    def set_position(self, x, y):
+        self._lib.fdmref_set_position(self._h, float(x), float(y))
+
+    def set_start_index(self, r, c):
+        self._lib.fdmref_set_start_index(self._h, int(r), int(c))
+
+    def get_index(self, x, y):
+        rc = (C.c_int32 * 2)()
+        ok = self._lib.fdmref_get_index(self._h, float(x), float(y), rc)
+        return bool(ok), (rc[0], rc[1])
+
+    def get_position(self, r, c):
+        xy = (C.c_double * 2)()
+        ok = self._lib.fdmref_get_position(self._h, int(r), int(c), xy)
+        return bool(ok), (xy[0], xy[1])
+
+    def layers(self):
+        n = self._lib.fdmref_num_layers(self._h)
+        return [self._lib.fdmref_layer_name(self._h, i).decode() for i in range(n)]
+
+    def exists(self, name):
+        return bool(self._lib.fdmref_layer_exists(self._h, name.encode()))
+
+    def add(self, name, value=float("nan")):
+        self._lib.fdmref_layer_add(self._h, name.encode(), float(value))
+
+    def layer(self, name):
+        out = np.empty((self.rows, self.cols), dtype=np.float32, order="F")
+        if self._lib.fdmref_layer_get(self._h, name.encode(), _ptr(out)) != 0:
+            raise KeyError(name)
+        return out
+
+    def set_layer(self, name, arr):
+        a = np.asfortranarray(arr, dtype=np.float32)
+        self._lib.fdmref_layer_set(self._h, name.encode(), _ptr(a))
+
+    def clear(self, name=None):
+        self._lib.fdmref_clear(self._h, None if name is None else name.encode())
+
+    def enable_cell_ids(self, on=True):
+        self._lib.fdmref_track_ids(self._h, int(on))
+
+    def last_cell_ids(self, n):
+        out = np.empty(n, dtype=np.int32)
+        if self._lib.fdmref_last_cell_ids(self._h, _ptr(out), n) != 0:
+            raise RuntimeError("cell ids were not tracked for the last scan")
+        return out
+
+
+# ---- unit-level helpers for the reference's known-answer tests ----
+def sensor_covariance(cfg, p):
+    p = _f32(p)
+    out = np.zeros(9, dtype=np.float32)
+    load().fdmref_sensor_covariance(C.byref(cfg), _ptr(p), _ptr(out))
+    return out.reshape(3, 3).T  # column-major -> [r][c]
+
+
+def sigma_z2(cfg, p, T_base_sensor, T_world_base):
+    p = _f32(p)
+    return float(load().fdmref_sigma_z2(C.byref(cfg), _ptr(p), _dp(_colmajor16(T_base_sensor)),
+                                        _dp(_colmajor16(T_world_base))))
+
+
+class KalmanCell:
+    """One cell driven through Kalman::update / computeBounds."""
+
+    def __init__(self, min_var=0.0001, max_var=0.01, q=0.0):
+        self.p = (min_var, max_var, q)
+        # ensureLayers constants (kalman_estimation.hpp:64-82); elevation starts NaN
+        self.s = np.array([np.nan, 0.0, 0.0, np.nan, 0.0, 0.0, np.nan, np.nan], dtype=np.float32)
+
+    def update(self, z, var, bounds=False):
+        load().fdmref_kalman_update(self.p[0], self.p[1], self.p[2], _ptr(self.s), z, var, int(bounds))
+
+    x = property(lambda s: float(s.s[0]))
+    P = property(lambda s: float(s.s[1]))
+    count = property(lambda s: float(s.s[2]))
+    sample_mean = property(lambda s: float(s.s[3]))
+    variance = property(lambda s: float(s.s[4]))
+    m2 = property(lambda s: float(s.s[5]))
+    upper = property(lambda s: float(s.s[6]))
+    lower = property(lambda s: float(s.s[7]))
+
+
+class P2Cell:
+    """One cell driven through P2Quantile::update / computeBounds."""
+
+    def __init__(self, dn=(0.01, 0.16, 0.50, 0.84, 0.99), marker=3, max_count=0.0):
+        self.dn = np.array(dn, dtype=np.float32)
+        self.marker, self.max_count = marker, max_count
+        # ensureLayers constants (quantile_estimation.hpp:97-115)
+        self.s = np.array([np.nan, np.nan, 0.0, np.nan, np.nan] + [np.nan] * 5 + [0, 1, 2, 3, 4],
+                          dtype=np.float32)
+
+    def update(self, x, bounds=False):
+        load().fdmref_p2_update(_ptr(self.dn), self.marker, self.max_count, _ptr(self.s), x, int(bounds))
+
+    elevation = property(lambda s: float(s.s[0]))
+    variance = property(lambda s: float(s.s[1]))
+    count = property(lambda s: float(s.s[2]))
+    upper = property(lambda s: float(s.s[3]))
+    lower = property(lambda s: float(s.s[4]))
+    q = property(lambda s: s.s[5:10].copy())
+    n = property(lambda s: s.s[10:15].copy())
