@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""bench.py — M points/s integrated into the ElevationMap on MI355X, with roofline + CPU baseline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5]
+
+A "step" is ONE FastDEM::integrate() of one synthetic scan whose SoA channels are already
+resident in HBM (fdm_engine_integrate_device through the C ABI; enqueue-only, no host sync
+inside the timed region).  Default workload = BASELINE.json configs[1]: VLP-16 ~30 K-pt scan into
+a 15x15 m @ 0.1 m LOCAL map, Kalman estimator.  N>1 (launched by torch.distributed.run): LOCAL
+maps do not shard so every rank runs an independent replica (weak scaling, no
+data-path collective); `--workload c5` instead tiles ONE global map across the ranks with an
+RCCL halo exchange per scan (fastdem_amd/tiling.py).
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     — dominant kernel: algorithmic bytes per launch / HIP-event duration vs 8 TB/s
+  cpu_baseline — the CPU oracle ("port" of the reference path, 1 thread) timed on this host
+  kernels      — both kernels' event-timed durations and algorithmic bytes
+  large        — the same roofline measurement on configs[3] (2 M-pt scan), where an HBM
+                 fraction is physically meaningful (a 30 K-pt scan is launch-latency bound)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--order", default="azimuth", choices=["azimuth", "ring"])
+    ap.add_argument("--profile-steps", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large", action="store_true")
+    ap.add_argument("--wave-merge", type=int, default=1)
+    return ap.parse_args()
+
+
+def colmajor16(T):
+    import numpy as np
+    a = np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(4, 4).T).reshape(16)
+    return (C.c_double * 16)(*a.tolist())
+
+
+class Resident:
+    """One workload with its scans resident in HBM and a device-side engine."""
+
+    def __init__(self, wl, device, wave_merge=1):
+        import torch
+        from fastdem_amd import Engine, capi
+        self.wl = wl
+        self.eng = Engine(wl.width, wl.height, wl.resolution, wl.apply_to(capi.default_config()),
+                          device=device)
+        self.eng.set_option("wave_merge", wave_merge)
+        self.dev = []
+        for s in wl.scans:
+            d = {k: (torch.from_numpy(v).to(f"cuda:{device}") if v is not None else None)
+                 for k, v in s.items()}
+            self.dev.append(d)
+        self.tbs = colmajor16(wl.T_base_sensor)
+        self.poses = {}
+        self.n = wl.n_points
+
+    def pose(self, k):
+        if k not in self.poses:
+            self.poses[k] = colmajor16(self.wl.pose(k))
+        return self.poses[k]
+
+    def step(self, k):
+        d = self.dev[k % len(self.dev)]
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        rc = self.eng.integrate_device_raw(d["x"].numel(), p(d["x"]), p(d["y"]), p(d["z"]),
+                                           self.tbs, self.pose(k), p(d["intensity"]), p(d["rgb"]))
+        if rc != 0:
+            raise RuntimeError(f"integrate_device failed: {rc}")
+        return d["x"].numel()
+
+    def bytes_per_point(self):
+        s = self.wl.scans[0]
+        return 12 + (4 if s["intensity"] is not None else 0) + (4 if s["rgb"] is not None else 0)
+
+    def bytes_per_cell(self):
+        s = self.wl.scans[0]
+        b = 124 if self.wl.estimation_type == 1 else 72
+        return b + (8 if s["intensity"] is not None else 0) + (4 if s["rgb"] is not None else 0)
+
+
+def measure_kernels(res, k0, steps):
+    """HIP-event durations of the two kernels (events recorded on the engine's stream around
+    each launch), averaged over `steps` scans; plus the algorithmic bytes each launch moves."""
+    eng = res.eng
+    eng.enable_profile(True)
+    t_bin = t_upd = 0.0
+    touched = 0
+    pts = 0
+    for i in range(steps):
+        pts += res.step(k0 + i)
+        b, u = eng.last_kernel_ms()
+        rc, st = eng.last_stats()
+        t_bin += b
+        t_upd += u
+        touched += st["n_cells_touched"]
+    eng.enable_profile(False)
+    ms_bin, ms_upd = t_bin / steps, t_upd / steps
+    n_per = pts / steps
+    cells_total = eng.s_rows * eng.s_cols
+    bytes_bin = n_per * res.bytes_per_point()
+    bytes_upd = (touched / steps) * res.bytes_per_cell() + cells_total * 4
+    out = {
+        "k_bin": {"ms": ms_bin, "alg_bytes": bytes_bin, "GBps": bytes_bin / (ms_bin * 1e-3) / 1e9},
+        "k_update": {"ms": ms_upd, "alg_bytes": bytes_upd, "GBps": bytes_upd / (ms_upd * 1e-3) / 1e9},
+        "touched_cells_per_scan": touched / steps, "points_per_scan": n_per,
+        "alg_bytes_per_scan": bytes_bin + bytes_upd,
+    }
+    dom = "k_bin" if ms_bin >= ms_upd else "k_update"
+    roof = {"bound": "hbm", "kernel": dom, "achieved": out[dom]["GBps"], "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": out[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+            "avg_kernel_us": out[dom]["ms"] * 1e3,
+            "alg_bytes_per_launch": out[dom]["alg_bytes"]}
+    return out, roof
+
+
+def cpu_baseline(wl, target_s=12.0):
+    """The CPU oracle (single-threaded port of the reference path, -O3 no -march: the reference's
+    Release flags) timed on this host on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import fdm_ref_py as R
+    ref = R.RefEngine(wl.width, wl.height, wl.resolution, wl.apply_to(R.default_config()))
+    s = wl.scan(0)
+    poses = [wl.pose(k) for k in range(64)]
+    kw = dict(intensity=s["intensity"], rgb=s["rgb"])
+    ref.time_integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, poses, 5, **kw)  # warm-up
+    t1 = ref.time_integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, poses, 5, **kw) / 5
+    iters = max(5, min(20000, int(target_s / max(t1, 1e-6))))
+    dt, stages = ref.time_integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, poses, iters,
+                                    stages=True, **kw)
+    n = int(s["x"].size)
+    cpu_model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    names = ["sensor_cov", "transform_filter", "cov_transform", "rasterize", "map_update"]
+    return {"value": n * iters / dt / 1e6, "unit": "Mpts/s", "cores": 1, "kind": "port",
+            "ms_per_scan": dt / iters * 1e3,
+            "sample": f"{iters} integrate() calls of the {n}-pt scan ({dt:.1f} s), "
+                      f"oracle/libfdm_ref.so -O3 no -march, 1 thread",
+            "stage_ms": {k: float(v) / iters * 1e3 for k, v in zip(names, stages)},
+            "host_cpu": cpu_model, "host_nproc": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    from fastdem_amd import synth
+
+    if args.workload == "c5":
+        from fastdem_amd import tiling
+        result = tiling.bench_global(args, rank, local_rank, world)
+    else:
+        kw = {"order": args.order} if args.workload in ("c2", "c4") else {}
+        wl = synth.make(args.workload, **kw)
+        res = Resident(wl, local_rank, args.wave_merge)
+
+        def barrier():
+            res.eng.sync()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+
+        k = 0
+        for _ in range(args.warmup):
+            res.step(k)
+            k += 1
+        barrier()
+        t0 = time.perf_counter()
+        pts = 0
+        for _ in range(args.steps):
+            pts += res.step(k)
+            k += 1
+        res.eng.sync()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+            t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        rc, st = res.eng.last_stats()
+        assert rc == 0 and st["n_in_map"] > 0, (rc, st)
+        total_pts = pts * world
+        result = {
+            "metric": "M points/s integrated into ElevationMap",
+            "value": total_pts / dt / 1e6, "unit": "Mpts/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wl.name, "points_per_scan": wl.n_points,
+                       "map_cells": res.eng.rows * res.eng.cols, "point_order": args.order,
+                       "parallelism": "replicas only (LOCAL map does not shard)" if world > 1 else "1 gpu",
+                       "inputs": "SoA float32 resident in HBM", "wave_merge": args.wave_merge},
+        }
+        if rank == 0:
+            kern, roof = measure_kernels(res, k, args.profile_steps)
+            result["roofline"] = roof
+            result["kernels"] = kern
+            # end-to-end with host staging (PCIe-inclusive) for DESIGN.md — never `value`
+            s = wl.scan(0)
+            t0 = time.perf_counter()
+            for i in range(50):
+                res.eng.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k + 1000 + i),
+                                  intensity=s["intensity"], rgb=s["rgb"])
+            result["host_buffers_ms_per_scan"] = (time.perf_counter() - t0) / 50 * 1e3
+            if world == 1 and not args.no_large and args.workload != "c4":
+                big = Resident(synth.lidar128(n_scans=2), local_rank, args.wave_merge)
+                for i in range(10):
+                    big.step(i)
+                big.eng.sync()
+                t0 = time.perf_counter()
+                for i in range(40):
+                    big.step(10 + i)
+                big.eng.sync()
+                dtb = time.perf_counter() - t0
+                kb, rb = measure_kernels(big, 50, 20)
+                result["large"] = {"workload": big.wl.name, "value": big.n * 40 / dtb / 1e6,
+                                   "unit": "Mpts/s", "ms_per_step": dtb / 40 * 1e3,
+                                   "roofline": rb, "kernels": kb}
+                del big
+            if world == 1 and not args.no_cpu_baseline:
+                result["cpu_baseline"] = cpu_baseline(wl)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

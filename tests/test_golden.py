@@ -1,0 +1,85 @@
+"""Golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py): inputs + expected
+layers after 1, 2 and 10 scans, per-point cell ids, geometry.  CPU: the oracle still reproduces
+them bit-for-bit.  GPU: the HIP engine reproduces them (ids bit-exact, layers <= 1e-5 relative)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import assert_arrays_close
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FIXTURES = ["lidar_kalman_local", "rgbd_p2_colour"]
+STAT_FIELDS = ("n_input", "n_after_filter", "n_in_map", "n_cells_touched", "shift_rows", "shift_cols")
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def fill_cfg(cfg, g):
+    for k, _ in cfg._fields_:
+        v = g["cfg_" + k]
+        if k == "p2_dn":
+            for i in range(5):
+                cfg.p2_dn[i] = float(v[i])
+        else:
+            setattr(cfg, k, v.item())
+    return cfg
+
+
+def scans_of(g):
+    out = []
+    for i in range(int(g["n_distinct"])):
+        out.append({ch: (g[f"scan{i}_{ch}"] if f"scan{i}_{ch}" in g else None)
+                    for ch in ("x", "y", "z", "intensity", "rgb")})
+    return out
+
+
+def replay(engine, g, exact):
+    scans = scans_of(g)
+    engine.enable_cell_ids()
+    for k in range(int(g["n_scans"])):
+        s = scans[k % len(scans)]
+        rc, st = engine.integrate(s["x"], s["y"], s["z"], g["T_base_sensor"], g["poses"][k],
+                                  intensity=s["intensity"], rgb=s["rgb"])
+        assert rc == int(g[f"status_{k + 1}"])
+        assert [st[f] for f in STAT_FIELDS] == list(g[f"stats_{k + 1}"])
+        if f"ids_{k + 1}" in g:
+            assert np.array_equal(engine.last_cell_ids(s["x"].size), g[f"ids_{k + 1}"])
+            geo = engine.geometry()
+            assert [geo.position_x, geo.position_y, geo.start_row, geo.start_col] == list(g[f"geom_{k + 1}"])
+            names = [n[len(f"layer_{k + 1}_"):] for n in g.files if n.startswith(f"layer_{k + 1}_")]
+            assert sorted(names) == sorted(engine.layers())
+            for n in names:
+                exp = g[f"layer_{k + 1}_{n}"]
+                if exact:
+                    assert np.array_equal(engine.layer(n).view(np.uint32), exp.view(np.uint32)), n
+                else:
+                    assert_arrays_close(engine.layer(n), exp, n)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_oracle_reproduces_golden(R, name):
+    g = load(name)
+    ref = R.RefEngine(float(g["width"]), float(g["height"]), float(g["resolution"]),
+                      fill_cfg(R.default_config(), g))
+    replay(ref, g, exact=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FIXTURES)
+def test_engine_reproduces_golden(gpu, name):
+    g = load(name)
+    eng = gpu.Engine(float(g["width"]), float(g["height"]), float(g["resolution"]),
+                     fill_cfg(gpu.capi.default_config(), g))
+    replay(eng, g, exact=False)
+
+
+def test_golden_exercises_shifts_and_edges():
+    g = load("lidar_kalman_local")
+    shifts = np.array([g[f"stats_{k}"][4:6] for k in range(1, 11)])
+    assert (shifts[:, 0] != 0).any() and (shifts[:, 1] != 0).any()
+    assert (np.abs(shifts) >= 40).any()  # a multi-metre jump (wrap-around / large strip)
+    ids = g["ids_10"]
+    assert (ids == -1).any() and (ids == -2).any() and (ids >= 0).any()

@@ -1,0 +1,395 @@
+"""Parity of the HIP engine (through the C ABI) against the CPU oracle on identical inputs.
+
+Bar (BASELINE.json north_star): cell indices bit-exact; fused height / variance within 1e-5
+relative (helpers.RTOL).  In practice the engine reproduces the oracle's float operation order,
+so most layers come out bit-identical; the tolerance is still the stated contract.
+Run on the GPU box:  python -m pytest tests -m gpu
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_arrays_close, assert_layers_equal, pair, run_both, same_geometry
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def T(x=0.0, y=0.0, z=0.0, yaw=0.0):
+    M = np.eye(4)
+    c, s = np.cos(yaw), np.sin(yaw)
+    M[:2, :2] = [[c, -s], [s, c]]
+    M[:3, 3] = (x, y, z)
+    return M
+
+
+def run_workload(gpu, R, wl, n_scans, check_every=1):
+    eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
+    worst = 0.0
+    for k in range(n_scans):
+        run_both(eng, ref, wl.scan(k), wl.T_base_sensor, wl.pose(k))
+        if (k + 1) % check_every == 0 or k == n_scans - 1:
+            worst = max(worst, assert_layers_equal(eng, ref))
+            assert same_geometry(eng.geometry(), ref.geometry())
+    return eng, ref, worst
+
+
+# ------------------------------------------------------------ BASELINE configs ----
+@pytest.mark.parametrize("order", ["azimuth", "ring"])
+def test_c2_vlp16_kalman_local(gpu, R, order):
+    """configs[1]: VLP-16 28.8K pts, 15x15 m @ 0.1 m, Kalman, LOCAL; 10 scans incl. row shifts."""
+    wl = gpu.synth.vlp16(n_scans=10, order=order)
+    eng, ref, _ = run_workload(gpu, R, wl, 10, check_every=1)
+    assert eng.geometry().start_row != 0  # the pose sequence did move the window
+    assert "intensity" in eng.layers()
+
+
+def test_c3_rgbd_p2_colour(gpu, R):
+    """configs[2]: 640x480 RGB-D (~300K pts), 10x10 m @ 0.05 m, P2 quantile, colour channel."""
+    wl = gpu.synth.rgbd(n_scans=8)
+    eng, ref, _ = run_workload(gpu, R, wl, 8, check_every=2)
+    assert "color" in eng.layers() and np.isfinite(eng.layer("elevation")).sum() > 1000
+
+
+def test_c4_lidar128_rolling_reduced(gpu, R):
+    """configs[3] at 1/8 azimuth density (262K pts): 60x60 m @ 0.05 m, 8-cell shift per scan."""
+    wl = gpu.synth.lidar128(n_scans=6, n_az=2048)
+    eng, ref, _ = run_workload(gpu, R, wl, 6, check_every=3)
+    assert eng.last_stats()[1]["shift_rows"] == -8
+
+
+def test_c4_lidar128_full_size(gpu, R):
+    """configs[3] at full size: 2 097 152 pts per scan, 1.44 M cells."""
+    wl = gpu.synth.lidar128(n_scans=2)
+    assert wl.n_points == 128 * 16384
+    run_workload(gpu, R, wl, 2, check_every=2)
+
+
+def test_c5_global_reduced_and_tiled(gpu, R):
+    """configs[4] reduced to 100x100 m: GLOBAL fixed-origin map, and the same map stored as
+    2x2 spatial tiles (owned windows only) reassembles bit-identically."""
+    wl = gpu.synth.global_map(n_scans=3, size_m=100.0, n_az=2048, radius=30.0)
+    eng, ref, _ = run_workload(gpu, R, wl, 3, check_every=3)
+    rows, cols = eng.rows, eng.cols
+    hr, hc = rows // 2, cols // 2
+    full = {n: eng.layer(n) for n in eng.layers()}
+    tiles = []
+    for tr in range(2):
+        for tc in range(2):
+            r0, c0 = tr * hr, tc * hc
+            tile = (r0, c0, hr, hc, r0, c0, hr, hc)
+            t = gpu.Engine(wl.width, wl.height, wl.resolution, wl.apply_to(gpu.capi.default_config()),
+                           tile=tile)
+            for k in range(3):
+                s = wl.scan(k)
+                t.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k),
+                            intensity=s["intensity"])
+            tiles.append((r0, c0, t))
+    for name, whole in full.items():
+        for r0, c0, t in tiles:
+            if not t.exists(name):  # a tile no point with the channel landed in
+                assert np.isnan(whole[r0:r0 + hr, c0:c0 + hc]).all()
+                continue
+            assert_arrays_close(t.layer(name), whole[r0:r0 + hr, c0:c0 + hc], name, 0.0, 0.0)
+
+
+def test_c5_full_size_properties(gpu):
+    """configs[4] at full size (8000x8000 cells) — no oracle at this size, so size-independent
+    properties: stats add up, min <= elevation <= max, n_points counts scans per cell."""
+    wl = gpu.synth.global_map(n_scans=2, n_az=4096)
+    eng = gpu.Engine(wl.width, wl.height, wl.resolution, wl.apply_to(gpu.capi.default_config()))
+    assert (eng.rows, eng.cols) == (8000, 8000)
+    touched = 0
+    for k in range(2):
+        s = wl.scan(k)
+        rc, st = eng.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k))
+        assert rc == 0 and st["n_in_map"] == st["n_after_filter"] > 0
+        touched += st["n_cells_touched"]
+    n = eng.layer("n_points")
+    assert int(n.sum()) == touched
+    el, lo, hi = eng.layer("elevation"), eng.layer("elevation_min"), eng.layer("elevation_max")
+    m = np.isfinite(el)
+    assert m.sum() == (n > 0).sum()
+    assert np.all(lo[m] <= el[m] + 1e-6) and np.all(el[m] <= hi[m] + 1e-6)
+
+
+# ------------------------------------------------- sensor x estimator matrix ----
+@pytest.mark.parametrize("sensor", [0, 1, 2])
+@pytest.mark.parametrize("est", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_sensor_estimator_mode_matrix(gpu, R, sensor, est, mode):
+    rng = np.random.default_rng(100 * sensor + 10 * est + mode)
+
+    def fill(c):
+        c.sensor_type, c.estimation_type, c.mode = sensor, est, mode
+        c.z_min, c.z_max, c.range_min, c.range_max = -2.0, 3.0, 0.3, 9.0
+
+    eng, ref = pair(gpu, R, 12.0, 9.0, 0.25, fill)  # non-square map
+    Tbs = T(0.1, -0.05, 0.7, yaw=0.3)
+    Tbs[:3, :3] = Tbs[:3, :3] @ np.array([[np.cos(0.2), 0, np.sin(0.2)], [0, 1, 0],
+                                          [-np.sin(0.2), 0, np.cos(0.2)]])
+    for k in range(7):
+        n = 5000
+        p = rng.normal(0, 3.0, size=(n, 3)).astype(F32)
+        p[:, 2] = (0.2 * np.sin(p[:, 0]) + rng.normal(0, 0.05, n)).astype(F32) + (1.0 if sensor == 2 else -0.7)
+        s = {"x": p[:, 0].copy(), "y": p[:, 1].copy(), "z": p[:, 2].copy(),
+             "intensity": rng.random(n, dtype=F32) if k % 2 == 0 else None, "rgb": None}
+        run_both(eng, ref, s, Tbs, T(0.37 * k, -0.21 * k, 0.0, yaw=0.05 * k))
+        assert_layers_equal(eng, ref)
+    assert same_geometry(eng.geometry(), ref.geometry())
+
+
+# ------------------------------------------------------------------ edge cases ----
+def test_empty_cloud_and_all_filtered(gpu, R):
+    def fill(c):
+        c.z_min, c.z_max = 5.0, 6.0
+
+    eng, ref = pair(gpu, R, 10.0, 10.0, 0.5, fill)
+    e = np.zeros(0, dtype=F32)
+    rc, _ = eng.integrate(e, e, e, T(), T(3.0, 0.0))
+    assert rc == gpu.capi.FDM_SKIP_EMPTY_CLOUD == ref.integrate(e, e, e, T(), T(3.0, 0.0))[0]
+    s = {"x": np.ones(100, F32), "y": np.ones(100, F32), "z": np.ones(100, F32)}
+    rc, st = run_both(eng, ref, s, T(), T(3.0, 0.0))  # LOCAL mode, but nothing survives cropZ
+    assert rc == gpu.capi.FDM_SKIP_ALL_FILTERED and st["n_after_filter"] == 0
+    g = eng.geometry()
+    assert (g.position_x, g.start_row) == (0.0, 0)  # fastdem.cpp:138 returns BEFORE the move
+    assert np.isnan(eng.layer("elevation")).all()
+    assert_layers_equal(eng, ref)
+
+
+def test_nothing_lands_in_map_still_true_and_obstacle_kept(gpu, R):
+    def fill(c):
+        c.mode = 1
+
+    eng, ref = pair(gpu, R, 10.0, 10.0, 0.5, fill)
+    s = {"x": np.array([0.0, 0.0], F32), "y": np.zeros(2, F32), "z": np.array([0.0, 2.0], F32)}
+    run_both(eng, ref, s, T(), T())
+    far = {"x": np.array([0.0], F32), "y": np.zeros(1, F32), "z": np.zeros(1, F32)}
+    rc, st = run_both(eng, ref, far, T(), T(500.0, 500.0))
+    assert rc == 0 and st["n_in_map"] == 0
+    # update() returns before updateObstacle when no cell was observed (elevation_mapping.cpp:118)
+    assert np.isfinite(eng.layer("obstacle")).sum() == 1
+    assert_layers_equal(eng, ref)
+
+
+def test_non_finite_points_never_integrate(gpu, R):
+    eng, ref = pair(gpu, R, 10.0, 10.0, 0.5)
+    x = np.array([0.0, np.nan, np.inf, 1.0, -np.inf, 2.0], F32)
+    y = np.array([0.0, 0.0, 0.0, np.nan, 1.0, 2.0], F32)
+    z = np.array([1.0, 1.0, 1.0, 1.0, 1.0, np.inf], F32)
+    rc, st = run_both(eng, ref, {"x": x, "y": y, "z": z}, T(z=0.2), T())
+    assert rc == 0 and st["n_in_map"] == 1
+    assert_layers_equal(eng, ref)
+
+
+def test_heavy_collisions_ties_and_signed_zero(gpu, R):
+    """All points in a handful of cells; equal-z ties must take the FIRST point's variance
+    (strict '<', elevation_mapping.cpp:65-68); -0.0 and +0.0 tie."""
+    def fill(c):
+        c.mode = 1
+        c.kalman_max_variance = 1.0
+
+    eng, ref = pair(gpu, R, 10.0, 10.0, 0.5, fill)
+    rng = np.random.default_rng(7)
+    n = 20000
+    x = rng.uniform(-0.7, 0.7, n).astype(F32)
+    y = rng.uniform(-0.7, 0.7, n).astype(F32)
+    z = rng.choice(np.array([0.25, 0.25, 0.5, -0.0, 0.0, 1.5], F32), n).astype(F32)
+    Tbs = T(0.0, 0.0, 0.0)
+    for k in range(3):
+        run_both(eng, ref, {"x": x, "y": y, "z": z}, Tbs, T())
+        assert_layers_equal(eng, ref)
+        x = x[::-1].copy()
+    # one cell, many identical points
+    one = {"x": np.zeros(4096, F32) + 2.1, "y": np.zeros(4096, F32) + 2.1, "z": np.zeros(4096, F32) + 0.3}
+    run_both(eng, ref, one, Tbs, T())
+    assert_layers_equal(eng, ref)
+
+
+def test_wave_merge_equals_plain_atomics(gpu, R):
+    wl = gpu.synth.vlp16(n_scans=3, order="ring")
+    a = gpu.Engine(wl.width, wl.height, wl.resolution, wl.apply_to(gpu.capi.default_config()))
+    b = gpu.Engine(wl.width, wl.height, wl.resolution, wl.apply_to(gpu.capi.default_config()))
+    b.set_option("wave_merge", 0)
+    for k in range(3):
+        s = wl.scan(k)
+        for e in (a, b):
+            e.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k), intensity=s["intensity"])
+    for n in a.layers():
+        assert_arrays_close(a.layer(n), b.layer(n), n, 0.0, 0.0)
+
+
+def test_update_direct_path_with_nan_z_and_variance(gpu, R):
+    """ElevationMapping::update on a map-frame cloud (tests/test_dual_layer.cpp:71): NaN z creates
+    a cell whose min_z stays FLT_MAX and max_z lowest() (SURVEY.md §8a edge semantics)."""
+    def fill(c):
+        c.mode = 1
+        c.kalman_max_variance = 1.0
+
+    eng, ref = pair(gpu, R, 10.0, 10.0, 0.5, fill)
+    x = np.array([0, 0, 1.1, 1.1, 2.2, 3.3], F32)
+    y = np.array([0, 0, 0, 0, 0, 0], F32)
+    z = np.array([0.0, 3.0, np.nan, 1.0, np.nan, np.inf], F32)
+    var = np.array([0.04, 0.01, 0.02, 0.0, 0.03, 0.05], F32)
+    for zv in (None, var):
+        se = eng.update(x, y, z, (0.0, 0.0), z_var=zv)
+        sr = ref.update(x, y, z, (0.0, 0.0), z_var=zv)
+        assert se == sr
+        assert_layers_equal(eng, ref)
+    el = eng.layer("elevation")
+    assert (el > 3e38).sum() >= 1  # the all-NaN cell fed FLT_MAX to the estimator, like the reference
+
+
+def test_update_empty_cloud_still_moves_in_local_mode(gpu, R):
+    eng, ref = pair(gpu, R, 10.0, 10.0, 0.5)
+    e = np.zeros(0, F32)
+    assert eng.update(e, e, e, (2.0, -1.0)) == ref.update(e, e, e, (2.0, -1.0))
+    assert same_geometry(eng.geometry(), ref.geometry())
+    assert eng.geometry().position_x == 2.0
+
+
+def test_intensity_nan_first_rule_and_colour_last_wins(gpu, R):
+    def fill(c):
+        c.mode = 1
+
+    eng, ref = pair(gpu, R, 10.0, 10.0, 0.5, fill)
+    x = np.array([0, 0, 0, 1.1, 1.1, 1.1, 2.2, 2.2], F32)
+    y = np.zeros(8, F32)
+    z = np.array([1, 2, 3, 1, 2, 3, 1, 2], F32) * F32(0.1)
+    inten = np.array([np.nan, 5.0, 7.0, 1.0, np.nan, 0.5, -3.0, -1.0], F32)
+    rgb = np.array([0x010203, 0x7F0000, 0x00FF00, 0x800000, 0x0000FF, 0x000001, 0xFFFFFF, 0x123456],
+                   np.uint32)
+    s = {"x": x, "y": y, "z": z, "intensity": inten, "rgb": rgb}
+    run_both(eng, ref, s, T(), T())
+    assert_layers_equal(eng, ref)
+    ok, (r, c) = ref.get_index(0.0, 0.0)
+    assert np.isnan(eng.layer("intensity")[r, c])             # first point NaN -> NaN forever
+    assert eng.layer("color").view(np.uint32)[r, c] == 0x00FF00  # last point of the cell
+    # second scan: stored intensity only replaced by larger values
+    s2 = dict(s, intensity=np.array([9, 9, 9, 0.2, 0.1, 0.3, np.nan, -2.0], F32))
+    run_both(eng, ref, s2, T(), T())
+    assert_layers_equal(eng, ref)
+
+
+def test_lazy_layers_appear_only_after_a_landed_scan(gpu, R):
+    def fill(c):
+        c.mode = 1
+
+    eng, ref = pair(gpu, R, 10.0, 10.0, 0.5, fill)
+    far = {"x": np.array([400.0], F32), "y": np.zeros(1, F32), "z": np.zeros(1, F32),
+           "intensity": np.ones(1, F32)}
+    run_both(eng, ref, far, T(), T())
+    assert not eng.exists("intensity") and not ref.exists("intensity")
+    near = dict(far, x=np.array([0.4], F32))
+    run_both(eng, ref, near, T(), T())
+    assert eng.exists("intensity") and ref.exists("intensity")
+    assert_layers_equal(eng, ref)
+
+
+def test_move_large_jump_and_wraparound(gpu, R):
+    eng, ref = pair(gpu, R, 10.0, 10.0, 0.5)
+    rng = np.random.default_rng(3)
+    poses = [(0, 0), (1.3, -0.8), (1.3, -0.8), (-3.9, 4.2), (-3.9, 9.9), (100.0, 100.0), (100.2, 99.7),
+             (95.1, 104.9)]
+    for k, (px, py) in enumerate(poses):
+        n = 3000
+        s = {"x": rng.uniform(-6, 6, n).astype(F32), "y": rng.uniform(-6, 6, n).astype(F32),
+             "z": rng.normal(0, 0.3, n).astype(F32), "intensity": rng.random(n, dtype=F32)}
+        run_both(eng, ref, s, T(z=0.5), T(px, py, yaw=0.1 * k))
+        assert_layers_equal(eng, ref)
+        assert same_geometry(eng.geometry(), ref.geometry())
+    # explicit GridMap::move
+    eng.move(90.0, 101.0)
+    ref.move(90.0, 101.0)
+    assert_layers_equal(eng, ref)
+    assert same_geometry(eng.geometry(), ref.geometry())
+
+
+def test_user_layers_are_cleared_by_move_and_reset(gpu, R):
+    eng, ref = pair(gpu, R, 10.0, 10.0, 0.5)
+    tag = np.arange(400, dtype=F32).reshape(20, 20)
+    for e in (eng, ref):
+        e.add("traversability", 0.5)
+        e.set_layer("custom", tag)
+    s = {"x": np.zeros(10, F32), "y": np.zeros(10, F32), "z": np.zeros(10, F32)}
+    run_both(eng, ref, s, T(), T(1.6, 0.0))
+    assert_layers_equal(eng, ref)
+    assert np.isnan(eng.layer("custom")).sum() == 3 * 20
+    eng.clear()   # FastDEM::reset -> clearAll
+    ref.clear()
+    assert_layers_equal(eng, ref)
+    run_both(eng, ref, s, T(), T(1.6, 0.0))  # estimators re-initialise from all-NaN state
+    assert_layers_equal(eng, ref)
+
+
+def test_switching_estimator_keeps_the_other_layers(gpu, R):
+    eng, ref = pair(gpu, R, 10.0, 10.0, 0.5)
+    rng = np.random.default_rng(5)
+
+    def scan():
+        n = 2000
+        return {"x": rng.uniform(-4, 4, n).astype(F32), "y": rng.uniform(-4, 4, n).astype(F32),
+                "z": rng.normal(0, 0.2, n).astype(F32)}
+
+    run_both(eng, ref, scan(), T(z=0.3), T())
+    for est in (1, 0, 1):
+        ce, cr = eng.cfg, ref.cfg
+        ce.estimation_type = cr.estimation_type = est
+        eng.set_config(ce)
+        ref.set_config(cr)
+        for k in range(3):
+            run_both(eng, ref, scan(), T(z=0.3), T(0.6 * k, 0.0))
+        assert_layers_equal(eng, ref)
+    assert "_kalman_p" in eng.layers() and "_p2_q0" in eng.layers()
+
+
+def test_sigma_z2_override_for_custom_sensor_models(gpu, R):
+    """A user SensorModel subclass (fastdem.hpp:79-80) is evaluated on the host and handed over
+    as per-point sigma_z^2; feeding the oracle's own values must reproduce the built-in result."""
+    wl = gpu.synth.vlp16(n_scans=1)
+    s = wl.scan(0)
+    cfg_r = wl.apply_to(R.default_config())
+    sig = np.array([R.sigma_z2(cfg_r, [s["x"][i], s["y"][i], s["z"][i]], wl.T_base_sensor, wl.pose(0))
+                    for i in range(0, wl.n_points)], dtype=F32)
+    a = gpu.Engine(wl.width, wl.height, wl.resolution, wl.apply_to(gpu.capi.default_config()))
+    b = gpu.Engine(wl.width, wl.height, wl.resolution, wl.apply_to(gpu.capi.default_config()))
+    a.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(0))
+    b.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(0), sigma_z2=sig)
+    for n in a.layers():
+        assert_arrays_close(a.layer(n), b.layer(n), n, 0.0, 0.0)
+
+
+def test_device_resident_async_stream_matches_sync(gpu, R):
+    """integrate_device (inputs in HBM, enqueue-only) over 20 scans == the synchronous path."""
+    import torch
+    wl = gpu.synth.vlp16(n_scans=4)
+    a = gpu.Engine(wl.width, wl.height, wl.resolution, wl.apply_to(gpu.capi.default_config()))
+    b = gpu.Engine(wl.width, wl.height, wl.resolution, wl.apply_to(gpu.capi.default_config()))
+    dev = [{k: (torch.from_numpy(v).cuda() if v is not None else None) for k, v in s.items()}
+           for s in wl.scans]
+    for k in range(20):
+        s, d = wl.scan(k), dev[k % 4]
+        a.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k), intensity=s["intensity"])
+        b.integrate_device(d["x"], d["y"], d["z"], wl.T_base_sensor, wl.pose(k), intensity=d["intensity"])
+    rc, st = b.last_stats()
+    assert rc == 0 and st == a.last_stats()[1]
+    for n in a.layers():
+        assert_arrays_close(a.layer(n), b.layer(n), n, 0.0, 0.0)
+    assert same_geometry(a.geometry(), b.geometry())
+
+
+def test_p2_fading_memory_and_marker_choice(gpu, R):
+    def fill(c):
+        c.estimation_type = 1
+        c.mode = 1
+        c.p2_max_sample_count = 8.0
+        c.p2_elevation_marker = 2
+
+    eng, ref = pair(gpu, R, 6.0, 6.0, 0.5, fill)
+    rng = np.random.default_rng(11)
+    for k in range(25):
+        n = 600
+        s = {"x": rng.uniform(-3, 3, n).astype(F32), "y": rng.uniform(-3, 3, n).astype(F32),
+             "z": rng.normal(0.5, 0.3, n).astype(F32)}
+        run_both(eng, ref, s, T(), T())
+    assert_layers_equal(eng, ref)
+    assert eng.layer("n_points").max() == 8.0
