@@ -33,6 +33,9 @@ def assert_arrays_close(a, b, name="", rtol=RTOL, atol=ATOL):
     fa, fb = fa[~inf], fb[~inf]
     if fa.size == 0:
         return 0.0
+    if rtol == 0.0:
+        assert np.array_equal(fa, fb), f"{name}: {(fa != fb).sum()} finite values differ (exact compare)"
+        return 0.0
     err = np.abs(fa - fb) / np.maximum(np.abs(fb), atol / rtol)
     assert err.max() <= rtol, f"{name}: max rel err {err.max():.3e} at {err.argmax()}"
     return float(err.max())
