@@ -21,7 +21,6 @@ namespace fdm {
 constexpr float kFltMax = 3.402823466e+38f;
 constexpr uint64_t kEmptyKey = ~0ull;
 constexpr uint32_t kNoIdx = 0xFFFFFFFFu;
-constexpr int kShards = 64;  // sharded stat counters (same-address atomics serialise)
 
 // ---- device-resident map geometry: host never needs it between scans ----
 struct DevGeom {  // nanogrid position + circular-buffer start index
@@ -39,18 +38,24 @@ struct DevFlags {
   unsigned any_inside;  // some point landed in the map (elevation_mapping.cpp:118)
   unsigned pad0, pad1;
 };
+struct DevObst {       // which touched-cell list bounds the cells whose obstacle may be non-NaN
+  int buf;             // list buffer (0/1) holding the cells of the last UPDATING scan
+  unsigned n;          // its length
+  unsigned scan;       // that scan's number: its scratch entries are dirty until scan+1 resets them
+  unsigned pad;
+};
 struct DevState {
-  DevGeom geom[4];   // ring: scan t reads geom[t&3], its update kernel writes geom[(t+1)&3]
+  DevGeom geom[4];   // ring: scan t reads slot t&3, its update kernel writes slot (t+1)&3
   DevCand cand[4];
   DevFlags flags[4];
-  unsigned long long pass_inside[4][kShards];  // lo32 = n_after_filter, hi32 = n_in_map
-  unsigned touched[4][kShards];
+  DevObst obst[4];
+  unsigned n_list[4];  // cells appended by scan t's bin kernel (zeroed two scans ahead)
   unsigned sticky;  // bit0: intensity layer written, bit1: colour layer written
   unsigned pad[3];
 };
 
 struct GeomConst {
-  double len_x, len_y, half_x, half_y, res;
+  double len_x, len_y, half_x, half_y, res, inv_res;
   int rows, cols;                      // global buffer size
   int s_r0, s_c0, s_rows, s_cols;      // stored window (tile incl. halo)
   int o_r0, o_c0, o_rows, o_cols;      // owned window (cells this engine updates)
@@ -63,12 +68,14 @@ struct ScanParams {
   float sp[4];             // sensor-model parameters
   double robot_x, robot_y;
   unsigned n;
+  unsigned scan_no;
   int slot;
   int integrate_mode;  // 1 = FastDEM::integrate (transforms + crops), 0 = ElevationMapping::update
   int do_move;         // LOCAL mode / explicit move
   int gate_on_filter;  // integrate(): nothing happens when every point is filtered
   int sensor_type;     // 0 Constant, 1 LiDAR, 2 RGBD
   int has_intensity, has_color, has_var;
+  int dbg_no_atomics;  // experiment switch (bench A/B only): skip the scratch atomics
 };
 
 // ---- helpers ----
@@ -134,6 +141,18 @@ __device__ __forceinline__ DevCand move_candidate(const DevGeom& g, const GeomCo
   return c;
 }
 
+// trunc(-v / res) without the fp64 divide in the common case.  t = -v * (1/res) differs from
+// the correctly rounded quotient q by a few ulp (|t - q| < 2^-49 |q|, |q| < 2^31 => < 1e-5);
+// whenever t is further than 1e-4 from an integer, trunc(t) == trunc(q) and the multiply result is
+// used; otherwise (about 2e-4 of points, those within 1e-4 of a cell edge) the exact IEEE divide decides.  Either way the
+// returned index is bit-identical to static_cast<int>(-(v / res)).
+__device__ __forceinline__ int trunc_neg_div(double v, double res, double inv_res) {
+  const double t = -v * inv_res;
+  const double f = t - floor(t);
+  if (f > 1e-4 && f < 1.0 - 1e-4) return static_cast<int>(t);
+  return static_cast<int>(-(v / res));
+}
+
 // nanogrid::GridMap::getIndex: fp64, truncation, circular-buffer wrap.
 __device__ __forceinline__ bool cell_of(float xf, float yf, const DevCand& g, const GeomConst& G,
                                         int& r, int& c) {
@@ -141,10 +160,8 @@ __device__ __forceinline__ bool cell_of(float xf, float yf, const DevCand& g, co
   const double tx = -((x - g.px) - G.half_x);
   const double ty = -((y - g.py) - G.half_y);
   if (!(tx >= 0.0 && ty >= 0.0 && tx < G.len_x && ty < G.len_y)) return false;
-  const double vx = ((x - G.half_x) - g.px) / G.res;
-  const double vy = ((y - G.half_y) - g.py) / G.res;
-  r = static_cast<int>(-vx);
-  c = static_cast<int>(-vy);
+  r = trunc_neg_div((x - G.half_x) - g.px, G.res, G.inv_res);
+  c = trunc_neg_div((y - G.half_y) - g.py, G.res, G.inv_res);
   if (g.sr != 0 || g.sc != 0) {
     r += g.sr;
     c += g.sc;

@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdint>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -70,6 +71,13 @@ struct fdm_engine {
   bool want_ids = false;
   bool profile = false;
   bool wave_merge = true;
+  bool dbg_no_atomics = false;
+  int bin_variant = 0;  // 0 = by scan size, 4 = k_bin4 (LDS-staged), 1 = k_bin (one point/thread)
+  size_t bin_part_cap = 0;   // blocks
+  unsigned last_bin_blocks = 0;
+  std::vector<unsigned long long> h_bin_part;
+  size_t list_cap = 0;       // entries per touched-cell list
+  bool obst_dense_pending = false;  // host wrote the obstacle layer: next scan clears it densely
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   float last_ms[2] = {0.f, 0.f};
 };
@@ -203,14 +211,37 @@ int ensure_scratch_channels(fdm_engine* e, bool intensity, bool color) {
   };
   int rc;
   if (intensity) {
-    if ((rc = alloc_u32(&e->S.imax, 0u))) return rc;
-    if ((rc = alloc_u32(&e->S.first, kNoIdx))) return rc;
+    for (int b = 0; b < 2; ++b) {
+      if ((rc = alloc_u32(&e->S.imax[b], 0u))) return rc;
+      if ((rc = alloc_u32(&e->S.first[b], kNoIdx))) return rc;
+    }
     if (!find_layer(e, "intensity") && (rc = add_layer(e, "intensity", NAN, true))) return rc;
   }
   if (color) {
-    if ((rc = alloc_u32(&e->S.last, 0u))) return rc;
+    for (int b = 0; b < 2; ++b)
+      if ((rc = alloc_u32(&e->S.last[b], 0u))) return rc;
     if (!find_layer(e, "color") && (rc = add_layer(e, "color", NAN, true))) return rc;
   }
+  return FDM_OK;
+}
+
+// Touched-cell lists hold at most min(points of a scan, cells) entries.  Growing keeps the
+// obstacle-dirty list's contents (it outlives the scan that wrote it).
+int ensure_lists(fdm_engine* e, size_t n) {
+  const size_t need = std::min<size_t>(std::max<size_t>(n, 1), e->ncell);
+  if (need <= e->list_cap) return FDM_OK;
+  HIPCK(hipStreamSynchronize(e->stream));
+  const size_t cap = std::min<size_t>(need + need / 4 + 1024, e->ncell);
+  for (int b = 0; b < 2; ++b) {
+    uint32_t* fresh = nullptr;
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&fresh), cap * sizeof(uint32_t)));
+    if (e->S.list[b]) {
+      HIPCK(hipMemcpy(fresh, e->S.list[b], e->list_cap * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+      HIPCK(hipFree(e->S.list[b]));
+    }
+    e->S.list[b] = fresh;
+  }
+  e->list_cap = cap;
   return FDM_OK;
 }
 
@@ -225,6 +256,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   if (n >= 0xFFFFFFFEull) return fail(FDM_ERR_INVALID, "point count exceeds 2^32-2");
   int rc;
   P.n = uint32_t(n);
+  P.scan_no = uint32_t(e->scan_no);
   P.slot = int(e->scan_no & 3);
   P.has_intensity = dint != nullptr;
   P.has_color = drgb != nullptr;
@@ -251,20 +283,56 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   if ((rc = ensure_scratch_channels(e, P.has_intensity, P.has_color))) return rc;
   if ((rc = refresh_layer_ptrs(e))) return rc;
   if ((rc = ensure_ids(e, n))) return rc;
+  if ((rc = ensure_lists(e, n))) return rc;
 
+  // k_bin4 (4 consecutive points per thread, float4 loads) needs 16-byte aligned channels
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  // k_bin4 trades latency for fewer memory-side atomics: worth it from ~64 K points up
+  const bool want4 = e->bin_variant == 4 || (e->bin_variant == 0 && n >= 65536);
+  const bool use_bin4 = want4 && al16(dx) && al16(dy) && al16(dz) && al16(dint);
+  const unsigned per_block = use_bin4 ? 1024u : 256u;
+  const unsigned bin_blocks = n ? unsigned((n + per_block - 1) / per_block) : 1u;
+  if (bin_blocks > e->bin_part_cap) {
+    HIPCK(hipStreamSynchronize(e->stream));
+    if (e->S.bin_part) HIPCK(hipFree(e->S.bin_part));
+    e->bin_part_cap = bin_blocks + bin_blocks / 4 + 64;
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->S.bin_part), e->bin_part_cap * sizeof(unsigned long long)));
+  }
+  e->last_bin_blocks = bin_blocks;
+  P.dbg_no_atomics = e->dbg_no_atomics ? 1 : 0;
   if (e->profile) HIPCK(hipEventRecord(e->ev[0], e->stream));
-  const unsigned bin_blocks = unsigned((n + 255) / 256) > 0 ? unsigned((n + 255) / 256) : 1u;
   int32_t* ids = e->want_ids ? e->d_cell_ids : nullptr;
-  if (e->wave_merge)
-    hipLaunchKernelGGL(k_bin<true>, dim3(bin_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state,
-                       dx, dy, dz, dint, e->S, ids);
-  else
-    hipLaunchKernelGGL(k_bin<false>, dim3(bin_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state,
-                       dx, dy, dz, dint, e->S, ids);
+  if (use_bin4) {
+    const bool hi = P.has_intensity != 0, hc = P.has_color != 0;
+    auto launch4 = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(bin_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state, dx, dy,
+                         dz, dint, e->S, ids);
+    };
+    if (hi && hc) launch4(k_bin4<true, true>);
+    else if (hi) launch4(k_bin4<true, false>);
+    else if (hc) launch4(k_bin4<false, true>);
+    else launch4(k_bin4<false, false>);
+  } else {
+    auto launch_bin = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(bin_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state, dx, dy,
+                         dz, dint, e->S, ids);
+    };
+    e->wave_merge ? launch_bin(k_bin<true>) : launch_bin(k_bin<false>);
+  }
   HIPCK(hipGetLastError());
   if (e->profile) HIPCK(hipEventRecord(e->ev[1], e->stream));
 
-  const unsigned upd_blocks = unsigned((e->ncell + 255) / 256);
+  if (e->obst_dense_pending) {
+    const int blocks = int(std::min<size_t>((e->ncell + 255) / 256, 4096));
+    hipLaunchKernelGGL(k_obstacle_dense_clear, dim3(blocks), dim3(256), 0, e->stream, P, e->d_state,
+                       L(e, "obstacle"), e->ncell);
+    HIPCK(hipGetLastError());
+    e->obst_dense_pending = false;
+  }
+  // grid-stride over (cells touched now) + (cells touched by the last updating scan) + (move
+  // strips): the counts live on the device, so size the grid for the usual case and let it stride
+  const size_t items = 2 * std::min<size_t>(std::max<size_t>(n, 1), e->ncell) + 4096;
+  const unsigned upd_blocks = unsigned(std::min<size_t>((items + 255) / 256, 2048));
   if (e->cfg.estimation_type == 1) {
     P2Layers Lp{};
     Lp.elevation = L(e, "elevation");
@@ -288,8 +356,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     Lp.p.marker = std::min(std::max(e->cfg.p2_elevation_marker, 0), 4);
     Lp.p.max_count = std::max(e->cfg.p2_max_sample_count, 0.0f);
     hipLaunchKernelGGL(k_update_p2, dim3(upd_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state,
-                       Lp, e->d_layer_ptrs, e->n_layer_ptrs, e->S, dx, dy, dz, dint, drgb, dvar,
-                       unsigned(e->ncell));
+                       Lp, e->d_layer_ptrs, e->n_layer_ptrs, e->S, dx, dy, dz, dint, drgb, dvar);
   } else {
     KalmanLayers Lk{};
     Lk.elevation = L(e, "elevation");
@@ -310,7 +377,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     Lk.q = e->cfg.kalman_process_noise;
     hipLaunchKernelGGL(k_update_kalman, dim3(upd_blocks), dim3(256), 0, e->stream, P, e->G,
                        e->d_state, Lk, e->d_layer_ptrs, e->n_layer_ptrs, e->S, dx, dy, dz, dint, drgb,
-                       dvar, unsigned(e->ncell));
+                       dvar);
   }
   HIPCK(hipGetLastError());
   if (e->profile) HIPCK(hipEventRecord(e->ev[2], e->stream));
@@ -404,12 +471,15 @@ int read_stats(fdm_engine* e, fdm_scan_stats* out, int* status) {
   const int slot = int((e->scan_no - 1) & 3);
   HIPCK(hipMemcpy(e->h_state, e->d_state, sizeof(DevState), hipMemcpyDeviceToHost));
   const DevState& st = *e->h_state;
-  uint64_t np = 0, ni = 0, nt = 0;
-  for (int k = 0; k < kShards; ++k) {
-    np += uint32_t(st.pass_inside[slot][k]);
-    ni += uint32_t(st.pass_inside[slot][k] >> 32);
-    nt += st.touched[slot][k];
+  uint64_t np = 0, ni = 0;
+  e->h_bin_part.resize(e->last_bin_blocks);
+  HIPCK(hipMemcpy(e->h_bin_part.data(), e->S.bin_part, e->last_bin_blocks * sizeof(unsigned long long),
+                  hipMemcpyDeviceToHost));
+  for (unsigned long long v : e->h_bin_part) {
+    np += uint32_t(v);
+    ni += uint32_t(v >> 32);
   }
+  const uint64_t nt = st.flags[slot].any_inside ? st.n_list[slot] : 0u;
   s.n_input = e->last_n;
   s.n_after_filter = uint32_t(np);
   s.n_in_map = uint32_t(ni);
@@ -484,6 +554,7 @@ int fdm_engine_create(const fdm_geometry* g, const fdm_config* cfg, const fdm_ti
     return fail(FDM_ERR_INVALID, "map has no cells");
   }
   G.res = g->resolution;
+  G.inv_res = 1.0 / G.res;  // fast-path only; the exact divide decides near cell edges
   G.len_x = double(G.rows) * G.res;
   G.len_y = double(G.cols) * G.res;
   G.half_x = 0.5 * G.len_x;
@@ -542,15 +613,18 @@ int fdm_engine_create(const fdm_geometry* g, const fdm_config* cfg, const fdm_ti
     e->h_state->geom[k].py = g->position_y;
     e->h_state->geom[k].sr = 0;
     e->h_state->geom[k].sc = 0;
+    e->h_state->obst[k].buf = 0;
+    e->h_state->obst[k].n = 0;
+    e->h_state->obst[k].scan = 0x7FFFFFFFu;  // "no updating scan yet"
   }
   HCK(hipMemcpy(e->d_state, e->h_state, sizeof(DevState), hipMemcpyHostToDevice));
 
-  HCK(hipMalloc(reinterpret_cast<void**>(&e->S.key), e->ncell * sizeof(unsigned long long)));
-  HCK(hipMalloc(reinterpret_cast<void**>(&e->S.zmax), e->ncell * sizeof(uint32_t)));
-  {
+  for (int b = 0; b < 2; ++b) {
+    HCK(hipMalloc(reinterpret_cast<void**>(&e->S.key[b]), e->ncell * sizeof(unsigned long long)));
+    HCK(hipMalloc(reinterpret_cast<void**>(&e->S.zmax[b]), e->ncell * sizeof(uint32_t)));
     const int blocks = int(std::min<size_t>((e->ncell + 255) / 256, 4096));
-    hipLaunchKernelGGL(k_fill_u64, dim3(blocks), dim3(256), 0, e->stream, e->S.key, kEmptyKey, e->ncell);
-    hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, e->stream, e->S.zmax, 0u, e->ncell);
+    hipLaunchKernelGGL(k_fill_u64, dim3(blocks), dim3(256), 0, e->stream, e->S.key[b], kEmptyKey, e->ncell);
+    hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, e->stream, e->S.zmax[b], 0u, e->ncell);
     HCK(hipGetLastError());
   }
   // ElevationMap ctor: elevation, elevation_min, elevation_max = NaN (elevation_map.hpp:101-116)
@@ -572,11 +646,15 @@ void fdm_engine_destroy(fdm_engine* e) {
   for (auto& l : e->layers)
     if (l.d) (void)hipFree(l.d);
   if (e->d_layer_ptrs) (void)hipFree(e->d_layer_ptrs);
-  if (e->S.key) (void)hipFree(e->S.key);
-  if (e->S.zmax) (void)hipFree(e->S.zmax);
-  if (e->S.imax) (void)hipFree(e->S.imax);
-  if (e->S.first) (void)hipFree(e->S.first);
-  if (e->S.last) (void)hipFree(e->S.last);
+  for (int b = 0; b < 2; ++b) {
+    if (e->S.key[b]) (void)hipFree(e->S.key[b]);
+    if (e->S.zmax[b]) (void)hipFree(e->S.zmax[b]);
+    if (e->S.imax[b]) (void)hipFree(e->S.imax[b]);
+    if (e->S.first[b]) (void)hipFree(e->S.first[b]);
+    if (e->S.last[b]) (void)hipFree(e->S.last[b]);
+    if (e->S.list[b]) (void)hipFree(e->S.list[b]);
+  }
+  if (e->S.bin_part) (void)hipFree(e->S.bin_part);
   if (e->d_state) (void)hipFree(e->d_state);
   if (e->h_state) (void)hipHostFree(e->h_state);
   if (e->d_stage) (void)hipFree(e->d_stage);
@@ -775,6 +853,7 @@ int fdm_engine_layer_exists(fdm_engine* e, const char* name) {
 int fdm_engine_layer_add(fdm_engine* e, const char* name, float value) {
   if (!e || !name) return fail(FDM_ERR_INVALID, "null argument");
   HIPCK(hipSetDevice(e->device));
+  if (std::strcmp(name, "obstacle") == 0) e->obst_dense_pending = true;
   return add_layer(e, name, value, false);
 }
 
@@ -799,6 +878,7 @@ int fdm_engine_layer_upload(fdm_engine* e, const char* name, const float* host, 
     l = find_layer(e, name);
   }
   l->pending = false;
+  if (std::strcmp(name, "obstacle") == 0) e->obst_dense_pending = true;
   HIPCK(hipMemcpyAsync(l->d, host, e->ncell * sizeof(float), hipMemcpyHostToDevice, e->stream));
   HIPCK(hipStreamSynchronize(e->stream));
   return FDM_OK;
@@ -883,6 +963,15 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
   if (!e || !key) return fail(FDM_ERR_INVALID, "null argument");
   if (std::strcmp(key, "wave_merge") == 0) {
     e->wave_merge = value != 0;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "bin_variant") == 0) {
+    if (value != 0 && value != 1 && value != 4) return fail(FDM_ERR_INVALID, "bin_variant must be 0, 1 or 4");
+    e->bin_variant = value;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "dbg_no_atomics") == 0) {  // measurement only: results are wrong when set
+    e->dbg_no_atomics = value != 0;
     return FDM_OK;
   }
   return fail(FDM_ERR_INVALID, std::string("unknown option ") + key);

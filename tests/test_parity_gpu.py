@@ -205,17 +205,39 @@ def test_heavy_collisions_ties_and_signed_zero(gpu, R):
     assert_layers_equal(eng, ref)
 
 
-def test_wave_merge_equals_plain_atomics(gpu, R):
-    wl = gpu.synth.vlp16(n_scans=3, order="ring")
-    a = gpu.Engine(wl.width, wl.height, wl.resolution, wl.apply_to(gpu.capi.default_config()))
-    b = gpu.Engine(wl.width, wl.height, wl.resolution, wl.apply_to(gpu.capi.default_config()))
-    b.set_option("wave_merge", 0)
+@pytest.mark.parametrize("order", ["ring", "azimuth"])
+def test_bin_kernel_variants_agree(gpu, R, order):
+    """k_bin4 (LDS-staged, default) == k_bin with wave merge == k_bin with plain atomics."""
+    wl = gpu.synth.vlp16(n_scans=3, order=order)
+    engs = [gpu.Engine(wl.width, wl.height, wl.resolution, wl.apply_to(gpu.capi.default_config()))
+            for _ in range(3)]
+    engs[1].set_option("bin_variant", 1)
+    engs[2].set_option("bin_variant", 1)
+    engs[2].set_option("wave_merge", 0)
     for k in range(3):
         s = wl.scan(k)
-        for e in (a, b):
+        for e in engs:
             e.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k), intensity=s["intensity"])
-    for n in a.layers():
-        assert_arrays_close(a.layer(n), b.layer(n), n, 0.0, 0.0)
+    for n in engs[0].layers():
+        for e in engs[1:]:
+            assert_arrays_close(engs[0].layer(n), e.layer(n), n, 0.0, 0.0)
+
+
+def test_unaligned_device_pointers_fall_back_to_scalar_kernel(gpu, R):
+    import torch
+    wl = gpu.synth.vlp16(n_scans=1)
+    s = wl.scan(0)
+    a = gpu.Engine(wl.width, wl.height, wl.resolution, wl.apply_to(gpu.capi.default_config()))
+    b = gpu.Engine(wl.width, wl.height, wl.resolution, wl.apply_to(gpu.capi.default_config()))
+    n = wl.n_points - 3  # odd length + 4-byte offset views: not 16-byte aligned
+    d = {k: torch.from_numpy(s[k]).cuda() for k in ("x", "y", "z", "intensity")}
+    a.integrate(s["x"][1:1 + n], s["y"][1:1 + n], s["z"][1:1 + n], wl.T_base_sensor, wl.pose(0),
+                intensity=s["intensity"][1:1 + n])
+    b.integrate_device(d["x"][1:1 + n], d["y"][1:1 + n], d["z"][1:1 + n], wl.T_base_sensor, wl.pose(0),
+                       intensity=d["intensity"][1:1 + n])
+    b.sync()
+    for name in a.layers():
+        assert_arrays_close(a.layer(name), b.layer(name), name, 0.0, 0.0)
 
 
 def test_update_direct_path_with_nan_z_and_variance(gpu, R):
