@@ -38,18 +38,16 @@ struct DevFlags {
   unsigned any_inside;  // some point landed in the map (elevation_mapping.cpp:118)
   unsigned pad0, pad1;
 };
-struct DevObst {       // which touched-cell list bounds the cells whose obstacle may be non-NaN
-  int buf;             // list buffer (0/1) holding the cells of the last UPDATING scan
-  unsigned n;          // its length
-  unsigned scan;       // that scan's number: its scratch entries are dirty until scan+1 resets them
-  unsigned pad;
-};
+struct DevObst {       // the last scan that updated the map (observed >= 1 cell): the tiles it
+  unsigned scan;       // stamped are the only ones whose obstacle layer can hold non-NaN cells
+  unsigned pad0, pad1, pad2;  // scalars on purpose: an array member here made hipcc spill the
+};                     // struct copy to a promoted-LDS alloca addressed through the AQL dispatch
+                       // packet (host-visible memory): +10 us on every k_update launch
 struct DevState {
   DevGeom geom[4];   // ring: scan t reads slot t&3, its update kernel writes slot (t+1)&3
   DevCand cand[4];
   DevFlags flags[4];
   DevObst obst[4];
-  unsigned n_list[4];  // cells appended by scan t's bin kernel (zeroed two scans ahead)
   unsigned sticky;  // bit0: intensity layer written, bit1: colour layer written
   unsigned pad[3];
 };
@@ -76,6 +74,7 @@ struct ScanParams {
   int sensor_type;     // 0 Constant, 1 LiDAR, 2 RGBD
   int has_intensity, has_color, has_var;
   int dbg_no_atomics;  // experiment switch (bench A/B only): skip the scratch atomics
+  int dbg_upd;         // experiment switch: 1 = k_update returns after the context, 2 = after round 1
 };
 
 // ---- helpers ----
@@ -141,34 +140,37 @@ __device__ __forceinline__ DevCand move_candidate(const DevGeom& g, const GeomCo
   return c;
 }
 
-// trunc(-v / res) without the fp64 divide in the common case.  t = -v * (1/res) differs from
-// the correctly rounded quotient q by a few ulp (|t - q| < 2^-49 |q|, |q| < 2^31 => < 1e-5);
-// whenever t is further than 1e-4 from an integer, trunc(t) == trunc(q) and the multiply result is
-// used; otherwise (about 2e-4 of points, those within 1e-4 of a cell edge) the exact IEEE divide decides.  Either way the
-// returned index is bit-identical to static_cast<int>(-(v / res)).
-__device__ __forceinline__ int trunc_neg_div(double v, double res, double inv_res) {
-  const double t = -v * inv_res;
-  const double f = t - floor(t);
-  if (f > 1e-4 && f < 1.0 - 1e-4) return static_cast<int>(t);
-  return static_cast<int>(-(v / res));
-}
-
 // nanogrid::GridMap::getIndex: fp64, truncation, circular-buffer wrap.
+//   inside test : t = -((pos - center) - half);  0 <= t < length      (checkIfPositionWithinMap)
+//   index       : trunc(-(((pos - half) - center) / res)), + start, wrapped
+// The two expressions associate differently, so both are evaluated where they can disagree; for
+// an index 1..size-2 the inside test is implied (they differ by rounding, ~1e-13 of a cell) and
+// skipped.  r lies in [0, size] and start in [0, size), so the wrap is one conditional subtract
+// (identical to wrapIndexToRange on that range).
+__device__ __forceinline__ bool axis_index(double pos, double center, double half, double len,
+                                           double res, double inv_res, int start, bool any_start,
+                                           int size, int& out) {
+  const double v = (pos - half) - center;
+  const double t = -v * inv_res;  // fast estimate of -v/res
+  int k = static_cast<int>(t);
+  const double f = t - double(k);
+  const bool sure = f > 1e-4 && f < 1.0 - 1e-4 && t >= 1.0 && t < double(size - 1);
+  if (!sure) {  // near a cell edge / map border / outside: the reference arithmetic decides
+    const double tt = -((pos - center) - half);
+    if (!(tt >= 0.0 && tt < len)) return false;
+    k = static_cast<int>(-(v / res));
+  }
+  k += start;
+  if (any_start && k >= size) k -= size;  // getBufferIndexFromIndex wraps BOTH axes if either start != 0
+  out = k;
+  return k >= 0 && k < size;
+}
 __device__ __forceinline__ bool cell_of(float xf, float yf, const DevCand& g, const GeomConst& G,
                                         int& r, int& c) {
-  const double x = double(xf), y = double(yf);
-  const double tx = -((x - g.px) - G.half_x);
-  const double ty = -((y - g.py) - G.half_y);
-  if (!(tx >= 0.0 && ty >= 0.0 && tx < G.len_x && ty < G.len_y)) return false;
-  r = trunc_neg_div((x - G.half_x) - g.px, G.res, G.inv_res);
-  c = trunc_neg_div((y - G.half_y) - g.py, G.res, G.inv_res);
-  if (g.sr != 0 || g.sc != 0) {
-    r += g.sr;
-    c += g.sc;
-    wrap_index(r, G.rows);
-    wrap_index(c, G.cols);
-  }
-  return r >= 0 && c >= 0 && r < G.rows && c < G.cols;
+  const bool any_start = g.sr != 0 || g.sc != 0;
+  const bool okr = axis_index(double(xf), g.px, G.half_x, G.len_x, G.res, G.inv_res, g.sr, any_start, G.rows, r);
+  const bool okc = axis_index(double(yf), g.py, G.half_y, G.len_y, G.res, G.inv_res, g.sc, any_start, G.cols, c);
+  return okr && okc;
 }
 
 // is buffer index `b` on `axis` inside the strip GridMap::move vacates? (E = geometry

@@ -72,11 +72,13 @@ struct fdm_engine {
   bool profile = false;
   bool wave_merge = true;
   bool dbg_no_atomics = false;
+  int dbg_upd = 0;
   int bin_variant = 0;  // 0 = by scan size, 4 = k_bin4 (LDS-staged), 1 = k_bin (one point/thread)
   size_t bin_part_cap = 0;   // blocks
   unsigned last_bin_blocks = 0;
   std::vector<unsigned long long> h_bin_part;
-  size_t list_cap = 0;       // entries per touched-cell list
+  unsigned n_tiles = 0;
+  std::vector<uint32_t> h_upd_part;
   bool obst_dense_pending = false;  // host wrote the obstacle layer: next scan clears it densely
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   float last_ms[2] = {0.f, 0.f};
@@ -103,6 +105,7 @@ int add_layer(fdm_engine* e, const char* name, float value, bool pending = false
     l->pending = l->pending && pending;
     return fill_async(e, l->d, value, e->ncell);
   }
+  if (e->layers.size() >= size_t(kMaxLayers)) return fail(FDM_ERR_INVALID, "too many layers (max 64)");
   Layer l;
   l.name = name;
   l.pending = pending;
@@ -211,37 +214,14 @@ int ensure_scratch_channels(fdm_engine* e, bool intensity, bool color) {
   };
   int rc;
   if (intensity) {
-    for (int b = 0; b < 2; ++b) {
-      if ((rc = alloc_u32(&e->S.imax[b], 0u))) return rc;
-      if ((rc = alloc_u32(&e->S.first[b], kNoIdx))) return rc;
-    }
+    if ((rc = alloc_u32(&e->S.imax, 0u))) return rc;
+    if ((rc = alloc_u32(&e->S.first, kNoIdx))) return rc;
     if (!find_layer(e, "intensity") && (rc = add_layer(e, "intensity", NAN, true))) return rc;
   }
   if (color) {
-    for (int b = 0; b < 2; ++b)
-      if ((rc = alloc_u32(&e->S.last[b], 0u))) return rc;
+    if ((rc = alloc_u32(&e->S.last, 0u))) return rc;
     if (!find_layer(e, "color") && (rc = add_layer(e, "color", NAN, true))) return rc;
   }
-  return FDM_OK;
-}
-
-// Touched-cell lists hold at most min(points of a scan, cells) entries.  Growing keeps the
-// obstacle-dirty list's contents (it outlives the scan that wrote it).
-int ensure_lists(fdm_engine* e, size_t n) {
-  const size_t need = std::min<size_t>(std::max<size_t>(n, 1), e->ncell);
-  if (need <= e->list_cap) return FDM_OK;
-  HIPCK(hipStreamSynchronize(e->stream));
-  const size_t cap = std::min<size_t>(need + need / 4 + 1024, e->ncell);
-  for (int b = 0; b < 2; ++b) {
-    uint32_t* fresh = nullptr;
-    HIPCK(hipMalloc(reinterpret_cast<void**>(&fresh), cap * sizeof(uint32_t)));
-    if (e->S.list[b]) {
-      HIPCK(hipMemcpy(fresh, e->S.list[b], e->list_cap * sizeof(uint32_t), hipMemcpyDeviceToDevice));
-      HIPCK(hipFree(e->S.list[b]));
-    }
-    e->S.list[b] = fresh;
-  }
-  e->list_cap = cap;
   return FDM_OK;
 }
 
@@ -283,7 +263,6 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   if ((rc = ensure_scratch_channels(e, P.has_intensity, P.has_color))) return rc;
   if ((rc = refresh_layer_ptrs(e))) return rc;
   if ((rc = ensure_ids(e, n))) return rc;
-  if ((rc = ensure_lists(e, n))) return rc;
 
   // k_bin4 (4 consecutive points per thread, float4 loads) needs 16-byte aligned channels
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
@@ -300,6 +279,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   }
   e->last_bin_blocks = bin_blocks;
   P.dbg_no_atomics = e->dbg_no_atomics ? 1 : 0;
+  P.dbg_upd = e->dbg_upd;
   if (e->profile) HIPCK(hipEventRecord(e->ev[0], e->stream));
   int32_t* ids = e->want_ids ? e->d_cell_ids : nullptr;
   if (use_bin4) {
@@ -329,10 +309,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     HIPCK(hipGetLastError());
     e->obst_dense_pending = false;
   }
-  // grid-stride over (cells touched now) + (cells touched by the last updating scan) + (move
-  // strips): the counts live on the device, so size the grid for the usual case and let it stride
-  const size_t items = 2 * std::min<size_t>(std::max<size_t>(n, 1), e->ncell) + 4096;
-  const unsigned upd_blocks = unsigned(std::min<size_t>((items + 255) / 256, 2048));
+  const unsigned upd_blocks = e->n_tiles;  // one block per map tile
   if (e->cfg.estimation_type == 1) {
     P2Layers Lp{};
     Lp.elevation = L(e, "elevation");
@@ -355,8 +332,9 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     for (int k = 1; k < 5; ++k) Lp.p.dn[k] = std::max(Lp.p.dn[k], Lp.p.dn[k - 1]);
     Lp.p.marker = std::min(std::max(e->cfg.p2_elevation_marker, 0), 4);
     Lp.p.max_count = std::max(e->cfg.p2_max_sample_count, 0.0f);
-    hipLaunchKernelGGL(k_update_p2, dim3(upd_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state,
-                       Lp, e->d_layer_ptrs, e->n_layer_ptrs, e->S, dx, dy, dz, dint, drgb, dvar);
+    hipLaunchKernelGGL(k_update<P2Policy>, dim3(upd_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state,
+                       Lp, e->d_layer_ptrs, e->n_layer_ptrs, e->S, dx, dy, dz, dint, drgb, dvar,
+                       unsigned(e->ncell));
   } else {
     KalmanLayers Lk{};
     Lk.elevation = L(e, "elevation");
@@ -375,9 +353,9 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     Lk.min_var = e->cfg.kalman_min_variance;
     Lk.max_var = e->cfg.kalman_max_variance;
     Lk.q = e->cfg.kalman_process_noise;
-    hipLaunchKernelGGL(k_update_kalman, dim3(upd_blocks), dim3(256), 0, e->stream, P, e->G,
+    hipLaunchKernelGGL(k_update<KalmanPolicy>, dim3(upd_blocks), dim3(256), 0, e->stream, P, e->G,
                        e->d_state, Lk, e->d_layer_ptrs, e->n_layer_ptrs, e->S, dx, dy, dz, dint, drgb,
-                       dvar);
+                       dvar, unsigned(e->ncell));
   }
   HIPCK(hipGetLastError());
   if (e->profile) HIPCK(hipEventRecord(e->ev[2], e->stream));
@@ -479,7 +457,11 @@ int read_stats(fdm_engine* e, fdm_scan_stats* out, int* status) {
     np += uint32_t(v);
     ni += uint32_t(v >> 32);
   }
-  const uint64_t nt = st.flags[slot].any_inside ? st.n_list[slot] : 0u;
+  uint64_t nt = 0;
+  e->h_upd_part.resize(e->n_tiles);
+  HIPCK(hipMemcpy(e->h_upd_part.data(), e->S.upd_part, e->n_tiles * sizeof(uint32_t),
+                  hipMemcpyDeviceToHost));
+  for (uint32_t v : e->h_upd_part) nt += v;
   s.n_input = e->last_n;
   s.n_after_filter = uint32_t(np);
   s.n_in_map = uint32_t(ni);
@@ -613,18 +595,26 @@ int fdm_engine_create(const fdm_geometry* g, const fdm_config* cfg, const fdm_ti
     e->h_state->geom[k].py = g->position_y;
     e->h_state->geom[k].sr = 0;
     e->h_state->geom[k].sc = 0;
-    e->h_state->obst[k].buf = 0;
-    e->h_state->obst[k].n = 0;
-    e->h_state->obst[k].scan = 0x7FFFFFFFu;  // "no updating scan yet"
+    e->h_state->obst[k].scan = 0xFFFFFFFDu;  // "no updating scan yet"
   }
   HCK(hipMemcpy(e->d_state, e->h_state, sizeof(DevState), hipMemcpyHostToDevice));
 
-  for (int b = 0; b < 2; ++b) {
-    HCK(hipMalloc(reinterpret_cast<void**>(&e->S.key[b]), e->ncell * sizeof(unsigned long long)));
-    HCK(hipMalloc(reinterpret_cast<void**>(&e->S.zmax[b]), e->ncell * sizeof(uint32_t)));
+  // Up to 4 M cells every tile is visited each scan (keys are read unconditionally, which takes
+  // one dependent round trip out of the update kernel); larger maps gate tiles by scan stamps.
+  e->S.dense = e->ncell <= (size_t(4) << 20) ? 1 : 0;
+  e->n_tiles = unsigned((e->ncell + 255) >> 8);
+  HCK(hipMalloc(reinterpret_cast<void**>(&e->S.key), e->ncell * sizeof(unsigned long long)));
+  HCK(hipMalloc(reinterpret_cast<void**>(&e->S.zmax), e->ncell * sizeof(uint32_t)));
+  HCK(hipMalloc(reinterpret_cast<void**>(&e->S.upd_part), e->n_tiles * sizeof(uint32_t)));
+  HCK(hipMalloc(reinterpret_cast<void**>(&e->S.tile_stamp), e->n_tiles * sizeof(uint32_t)));
+  {
     const int blocks = int(std::min<size_t>((e->ncell + 255) / 256, 4096));
-    hipLaunchKernelGGL(k_fill_u64, dim3(blocks), dim3(256), 0, e->stream, e->S.key[b], kEmptyKey, e->ncell);
-    hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, e->stream, e->S.zmax[b], 0u, e->ncell);
+    hipLaunchKernelGGL(k_fill_u64, dim3(blocks), dim3(256), 0, e->stream, e->S.key, kEmptyKey, e->ncell);
+    hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, e->stream, e->S.zmax, 0u, e->ncell);
+    hipLaunchKernelGGL(k_fill_u32, dim3(64), dim3(256), 0, e->stream, e->S.tile_stamp, 0xFFFFFFFEu,
+                       size_t(e->n_tiles));
+    hipLaunchKernelGGL(k_fill_u32, dim3(64), dim3(256), 0, e->stream, e->S.upd_part, 0u,
+                       size_t(e->n_tiles));
     HCK(hipGetLastError());
   }
   // ElevationMap ctor: elevation, elevation_min, elevation_max = NaN (elevation_map.hpp:101-116)
@@ -646,15 +636,14 @@ void fdm_engine_destroy(fdm_engine* e) {
   for (auto& l : e->layers)
     if (l.d) (void)hipFree(l.d);
   if (e->d_layer_ptrs) (void)hipFree(e->d_layer_ptrs);
-  for (int b = 0; b < 2; ++b) {
-    if (e->S.key[b]) (void)hipFree(e->S.key[b]);
-    if (e->S.zmax[b]) (void)hipFree(e->S.zmax[b]);
-    if (e->S.imax[b]) (void)hipFree(e->S.imax[b]);
-    if (e->S.first[b]) (void)hipFree(e->S.first[b]);
-    if (e->S.last[b]) (void)hipFree(e->S.last[b]);
-    if (e->S.list[b]) (void)hipFree(e->S.list[b]);
-  }
+  if (e->S.key) (void)hipFree(e->S.key);
+  if (e->S.zmax) (void)hipFree(e->S.zmax);
+  if (e->S.imax) (void)hipFree(e->S.imax);
+  if (e->S.first) (void)hipFree(e->S.first);
+  if (e->S.last) (void)hipFree(e->S.last);
   if (e->S.bin_part) (void)hipFree(e->S.bin_part);
+  if (e->S.upd_part) (void)hipFree(e->S.upd_part);
+  if (e->S.tile_stamp) (void)hipFree(e->S.tile_stamp);
   if (e->d_state) (void)hipFree(e->d_state);
   if (e->h_state) (void)hipHostFree(e->h_state);
   if (e->d_stage) (void)hipFree(e->d_stage);
@@ -968,6 +957,15 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
   if (std::strcmp(key, "bin_variant") == 0) {
     if (value != 0 && value != 1 && value != 4) return fail(FDM_ERR_INVALID, "bin_variant must be 0, 1 or 4");
     e->bin_variant = value;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "dense") == 0) {  // force stamp-gated (0) or dense (1) update sweeps
+    e->S.dense = value != 0;
+    e->obst_dense_pending = true;  // stamps were not maintained while dense
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "dbg_upd") == 0) {
+    e->dbg_upd = value;
     return FDM_OK;
   }
   if (std::strcmp(key, "dbg_no_atomics") == 0) {  // measurement only: results are wrong when set

@@ -5,39 +5,49 @@
 //       per-cell reduction (elevation_mapping.cpp:41-92).  SoA channels are read with 16 B/lane
 //       coalesced loads; same-cell points are merged in registers, then in a per-block LDS table
 //       ("LDS-staged cell tile"), and only the block's UNIQUE cells go to the device-resident
-//       scratch with one atomic set each.  A returning atomicMin tells the first toucher of a cell,
-//       which appends it to the scan's touched-cell list.
-//   k_update : per TOUCHED cell (grid-stride over the list) — never a dense pass over the map.
-//       Per-cell Kalman / P2 update (elevation_mapping.cpp:94-108), min/max, obstacle, intensity,
-//       colour (elevation_mapping.cpp:127-175); obstacle clear of the cells the previous updating
-//       scan touched; GridMap::move strip clear; scratch reset; geometry commit.
+//       scratch with one atomic set each.  Every flushed cell stamps its 1024-cell map tile with
+//       the scan number.
+//   k_update : one block per 1024-cell map tile, cells visited in MEMORY ORDER (column-major, so a
+//       wave's accesses to each layer coalesce).  A tile that was not stamped by this scan, not
+//       stamped by the last updating scan (obstacle clear) and not crossed by a GridMap::move strip
+//       costs one scalar load.  Touched cells get the Kalman / P2 update
+//       (elevation_mapping.cpp:94-108), min/max, obstacle, intensity, colour
+//       (elevation_mapping.cpp:127-175); the scratch is reset; block 0 commits the geometry.
 //
 // Measured facts this design rests on (MI355X, scripts/ubench/atomics.hip, profiles/):
 //   * global atomics execute at the memory side (TCC_EA0_ATOMIC == TCC_ATOMIC): ~26 Gop/s for
 //     scattered addresses, ~1 ns per op on one address, 7-12x faster when a wave's addresses are
-//     consecutive.  Atomic COUNT, not bytes, bounds the bin kernel => merge on chip first.
-//   * same-address counters serialise => statistics are per-block partials / one add per block.
+//     consecutive; returning atomics are slower still.  Atomic COUNT, not bytes, bounds the bin
+//     kernel => merge on chip first, never ask for the old value.
+//   * same-address counters serialise => statistics are per-block partials summed on demand.
+//   * scattered 32 B accesses run at 20-80 G/s => the update walks cells in memory order instead
+//     of following a touched-cell list (tried: 1.8x slower).
 //
 // Roofline: HBM-bound work (no contraction => MFMA is irrelevant).  Algorithmic bytes
 // (SURVEY.md §8d): 12 B per input point (+4 intensity, +4 colour); per touched cell 72 B (Kalman)
 // / 124 B (P2); 4 B per map cell per scan for the reference's whole-layer obstacle clear (which
-// this engine replaces by clearing only the cells that can be non-NaN).
+// this engine narrows to the tiles that can hold non-NaN obstacle cells).
 #pragma once
 
 #include "fdm_device.hpp"
 
 namespace fdm {
 
-// Device-resident per-cell scratch, double-buffered by scan parity so that k_update(t) reads
-// buffer t&1 immutably while it resets the entries scan t-1 left in buffer (t-1)&1.
+
+constexpr int kMaxLayers = 64;  // layers per map
+constexpr int kTileShift = 8;   // k_update tile = 256 storage-linear cells
+
+// Device-resident per-cell scratch of one scan + per-tile stamps.
 struct Scratch {
   unsigned long long* bin_part;  // [bin blocks] lo32 = n_after_filter, hi32 = n_in_map
-  unsigned long long* key[2];    // (ord(z) << 32 | point index), min-reduced; kEmptyKey = untouched
-  uint32_t* zmax[2];             // ord(max z), 0 = none
-  uint32_t* imax[2];             // ord(max non-NaN intensity), 0 = none
-  uint32_t* first[2];            // lowest point index in the cell (intensity NaN-first rule)
-  uint32_t* last[2];             // highest point index in the cell (colour = last point wins)
-  uint32_t* list[2];             // touched-cell lists (one being written, one = obstacle-dirty set)
+  uint32_t* upd_part;            // [tiles] cells touched in the tile
+  uint32_t* tile_stamp;          // [tiles] number of the last scan that touched a cell of the tile
+  int dense;                     // 1: every tile is visited (small/medium maps); 0: stamp-gated
+  unsigned long long* key;       // (ord(z) << 32 | point index), min-reduced; kEmptyKey = untouched
+  uint32_t* zmax;                // ord(max z), 0 = none
+  uint32_t* imax;                // ord(max non-NaN intensity), 0 = none
+  uint32_t* first;               // lowest point index in the cell (intensity NaN-first rule)
+  uint32_t* last;                // highest point index in the cell (colour = last point wins)
 };
 
 struct KalmanLayers {
@@ -88,19 +98,19 @@ __device__ __forceinline__ uint32_t make_zmax(float z) {
   return (z > -kFltMax) ? ord(zc) : 0u;  // strict "z > max_z" starting from lowest()
 }
 
-// One cell's reduction goes to the scratch; returns true for the first toucher of the cell.
+// One cell's reduction goes to the scratch (non-returning atomics) and stamps the cell's tile.
 template <bool HAS_INT, bool HAS_COL>
-__device__ __forceinline__ bool scratch_merge(const Scratch& S, int b, uint32_t cell,
+__device__ __forceinline__ void scratch_merge(const Scratch& S, unsigned scan_no, uint32_t cell,
                                               unsigned long long key, uint32_t zmx, uint32_t imx,
                                               uint32_t fst, uint32_t lst) {
-  const unsigned long long old = atomicMin(&S.key[b][cell], key);
-  if (zmx) atomicMax(&S.zmax[b][cell], zmx);
+  atomicMin(&S.key[cell], key);
+  if (zmx) atomicMax(&S.zmax[cell], zmx);
   if (HAS_INT) {
-    if (imx) atomicMax(&S.imax[b][cell], imx);
-    atomicMin(&S.first[b][cell], fst);
+    if (imx) atomicMax(&S.imax[cell], imx);
+    atomicMin(&S.first[cell], fst);
   }
-  if (HAS_COL) atomicMax(&S.last[b][cell], lst);
-  return old == kEmptyKey;
+  if (HAS_COL) atomicMax(&S.last[cell], lst);
+  if (!S.dense) S.tile_stamp[cell >> kTileShift] = scan_no;  // benign race: all writers store the same value
 }
 
 __device__ __forceinline__ DevCand block_candidate(const ScanParams& P, const GeomConst& G,
@@ -142,18 +152,9 @@ __global__ __launch_bounds__(256) void k_bin4(const ScanParams P, const GeomCons
   __shared__ uint32_t h_last[HAS_COL ? kHashSlots : 1];
   __shared__ DevCand s_cand;
   __shared__ unsigned s_cnt[4];
-  __shared__ unsigned s_nfirst, s_base;
 
-  for (int k = threadIdx.x; k < kHashSlots; k += 256) {
-    h_key[k] = kEmptyKey;
-    h_cell[k] = kEmptyCell;
-    h_zmax[k] = 0u;
-    if (HAS_INT) { h_imax[k] = 0u; h_first[k] = kNoIdx; }
-    if (HAS_COL) h_last[k] = 0u;
-  }
-  if (threadIdx.x == 0) s_nfirst = 0u;
-  const DevCand cand = block_candidate(P, G, st, &s_cand);  // contains the __syncthreads
-
+  // the point loads go out first: they are in flight while the table is initialised and
+  // thread 0 works out the post-move geometry
   const unsigned i0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
   float xs[4], ys[4], zs[4], vs[4];
   if (i0 + 3 < P.n) {
@@ -177,6 +178,15 @@ __global__ __launch_bounds__(256) void k_bin4(const ScanParams P, const GeomCons
       if (HAS_INT) vs[j] = ok ? pint[i0 + j] : 0.f;
     }
   }
+
+  for (int k = threadIdx.x; k < kHashSlots; k += 256) {
+    h_key[k] = kEmptyKey;
+    h_cell[k] = kEmptyCell;
+    h_zmax[k] = 0u;
+    if (HAS_INT) { h_imax[k] = 0u; h_first[k] = kNoIdx; }
+    if (HAS_COL) h_last[k] = 0u;
+  }
+  const DevCand cand = block_candidate(P, G, st, &s_cand);  // contains the __syncthreads
 
   // phase 1: all four points through the arithmetic (independent chains -> ILP)
   int cells[4];
@@ -248,39 +258,23 @@ __global__ __launch_bounds__(256) void k_bin4(const ScanParams P, const GeomCons
   if (__ballot(any_glob) && (threadIdx.x & 63) == 0) st->flags[P.slot].any_inside = 1u;
   __syncthreads();  // every run of the block is in the table
 
-  // phase 3: one global atomic set per unique cell; collect the first touchers
-  const int b = P.slot & 1;
-  uint32_t mine[kHashSlots / 256];
-  unsigned n_mine = 0;
+  // phase 3: one global atomic set per unique cell of the block
+  if (!P.dbg_no_atomics) {
 #pragma unroll
-  for (int q = 0; q < kHashSlots / 256; ++q) {
-    const int k = threadIdx.x + q * 256;
-    const uint32_t cell = h_cell[k];
-    mine[q] = kEmptyCell;
-    if (cell == kEmptyCell || P.dbg_no_atomics) continue;
-    const bool first = scratch_merge<HAS_INT, HAS_COL>(S, b, cell, h_key[k], h_zmax[k],
-                                                      HAS_INT ? h_imax[k] : 0u,
-                                                      HAS_INT ? h_first[k] : 0u,
-                                                      HAS_COL ? h_last[k] : 0u);
-    if (first) { mine[q] = cell; ++n_mine; }
+    for (int q = 0; q < kHashSlots / 256; ++q) {
+      const int k = threadIdx.x + q * 256;
+      const uint32_t cell = h_cell[k];
+      if (cell == kEmptyCell) continue;
+      scratch_merge<HAS_INT, HAS_COL>(S, P.scan_no, cell, h_key[k], h_zmax[k],
+                                      HAS_INT ? h_imax[k] : 0u, HAS_INT ? h_first[k] : 0u,
+                                      HAS_COL ? h_last[k] : 0u);
+    }
   }
-  unsigned rank = 0;
-  if (n_mine) rank = atomicAdd(&s_nfirst, n_mine);
-  __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     const unsigned np = tot & 0xFFFFu, ni = tot >> 16;
     if (np) st->flags[P.slot].any_pass = 1u;
     S.bin_part[blockIdx.x] = (unsigned long long)np | ((unsigned long long)ni << 32);
-    s_base = s_nfirst ? atomicAdd(&st->n_list[P.slot], s_nfirst) : 0u;
-  }
-  __syncthreads();
-  if (n_mine) {
-    uint32_t* list = S.list[1 - st->obst[P.slot].buf];
-    unsigned o = s_base + rank;
-#pragma unroll
-    for (int q = 0; q < kHashSlots / 256; ++q)
-      if (mine[q] != kEmptyCell) list[o++] = mine[q];
   }
 }
 
@@ -350,30 +344,15 @@ __global__ __launch_bounds__(256) void k_bin(const ScanParams P, const GeomConst
     const int ncell = __shfl_down(cell, 1);
     commit = inside && (lane == 63 || ncell != cell);
   }
-  bool first = false;
   if (commit && !P.dbg_no_atomics) {
-    const int b = P.slot & 1;
     if (P.has_intensity && P.has_color)
-      first = scratch_merge<true, true>(S, b, cell, key, zmx, imx, fst, lst);
+      scratch_merge<true, true>(S, P.scan_no, cell, key, zmx, imx, fst, lst);
     else if (P.has_intensity)
-      first = scratch_merge<true, false>(S, b, cell, key, zmx, imx, fst, lst);
+      scratch_merge<true, false>(S, P.scan_no, cell, key, zmx, imx, fst, lst);
     else if (P.has_color)
-      first = scratch_merge<false, true>(S, b, cell, key, zmx, imx, fst, lst);
+      scratch_merge<false, true>(S, P.scan_no, cell, key, zmx, imx, fst, lst);
     else
-      first = scratch_merge<false, false>(S, b, cell, key, zmx, imx, fst, lst);
-  }
-  // wave-aggregated append of the first touchers
-  const unsigned long long mf = __ballot(first);
-  if (mf) {
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)mf) - 1;
-    unsigned base = 0;
-    if (lane == leader) base = atomicAdd(&st->n_list[P.slot], unsigned(__popcll(mf)));
-    base = __shfl(base, leader);
-    if (first) {
-      uint32_t* list = S.list[1 - st->obst[P.slot].buf];
-      list[base + __popcll(mf & ((1ull << lane) - 1ull))] = uint32_t(cell);
-    }
+      scratch_merge<false, false>(S, P.scan_no, cell, key, zmx, imx, fst, lst);
   }
 
   const unsigned long long mp = __ballot(pass), mi = __ballot(inside), mg = __ballot(glob);
@@ -392,69 +371,43 @@ __global__ __launch_bounds__(256) void k_bin(const ScanParams P, const GeomConst
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_update: grid-stride over work items
-//   [0, n_cur)                      cells touched by this scan         -> estimator update
-//   [n_cur, n_cur + n_obst)         cells of the last updating scan    -> obstacle clear + scratch reset
-//   [.., .. + n_strip)              cells vacated by GridMap::move     -> NaN in every layer
+// k_update: one thread per map cell, one block per 256-cell tile; consecutive threads are
+// consecutive cells of a column, so every layer access of a wave coalesces.  The kernel is a chain
+// of dependent memory round trips (context -> key -> winning point + stored state -> stores),
+// so it keeps the chain SHORT (loads that do not depend on each other are issued together) and
+// the machine FULL (about 30 VGPRs: 8 waves/SIMD):
+//   round 1: scan context (scalar loads) + the cell's key, issued together
+//            (dense mode reads the key unconditionally: an untouched cell simply holds kEmptyKey;
+//             stamp mode - very large maps - first checks the tile stamp and skips idle tiles)
+//   round 2: winning point's x/y/z, zmax/intensity/colour scratch, stored estimator state
+//   round 3: arithmetic + stores.
+
 struct UpdateCtx {
-  bool applied, do_update, reset_prev;
-  int cb;               // scratch buffer of this scan
-  unsigned n_cur, n_obst, n_strip;
-  const uint32_t* cur_list;
-  const uint32_t* obst_list;
+  bool applied, do_update;
+  bool cur;        // tile may hold touched cells
+  bool obst_tile;  // obstacle cells of this tile must be cleared (map_.clear(obstacle))
+  bool strips;     // a move happened: cells may lie in a vacated strip
   DevGeom E;
   DevCand C;
-  // strip decomposition
-  bool clear_all;
-  int row_idx, row_n, col_idx, col_n;
 };
 
-__device__ __forceinline__ void strip_range(int start, int sh, int size, int& idx, int& n) {
-  n = sh > 0 ? sh : -sh;
-  idx = sh > 0 ? start : start + sh;
-  if (n) wrap_index(idx, size);
-}
-
-__device__ __forceinline__ UpdateCtx make_ctx(const ScanParams& P, const GeomConst& G,
-                                              DevState* __restrict__ st, const Scratch& S) {
-  UpdateCtx u;
+__device__ __forceinline__ void make_ctx(const ScanParams& P, DevState* __restrict__ st,
+                                         const Scratch& S, UpdateCtx& u) {
   const int slot = P.slot;
   const bool any_pass = st->flags[slot].any_pass != 0u;
   u.do_update = st->flags[slot].any_inside != 0u;
   u.applied = P.do_move && (!P.gate_on_filter || any_pass);
-  u.cb = slot & 1;
-  const DevObst ob = st->obst[slot];
-  u.n_cur = u.do_update ? st->n_list[slot] : 0u;
-  u.n_obst = ob.n;
-  u.cur_list = S.list[1 - ob.buf];
-  u.obst_list = S.list[ob.buf];
-  u.reset_prev = ob.scan + 1u == P.scan_no;  // its scratch entries are still dirty
+  const unsigned ob_scan = st->obst[slot].scan;
   u.E = st->geom[slot];
   u.C = st->cand[slot];
-  u.clear_all = false;
-  u.row_idx = u.row_n = u.col_idx = u.col_n = 0;
-  u.n_strip = 0;
-  if (u.applied && (u.C.shr != 0 || u.C.shc != 0)) {
-    strip_range(u.E.sr, u.C.shr, G.rows, u.row_idx, u.row_n);
-    strip_range(u.E.sc, u.C.shc, G.cols, u.col_idx, u.col_n);
-    if (u.row_n >= G.rows || u.col_n >= G.cols) {
-      u.clear_all = true;
-      u.n_strip = unsigned(G.rows) * unsigned(G.cols);
-    } else {
-      u.n_strip = unsigned(u.row_n) * unsigned(G.cols) + unsigned(u.col_n) * unsigned(G.rows);
-    }
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // commit geometry + ring bookkeeping
     const int nxt = (slot + 1) & 3, nn = (slot + 2) & 3;
     DevGeom g = u.E;
     if (u.applied) { g.px = u.C.px; g.py = u.C.py; g.sr = u.C.sr; g.sc = u.C.sc; }
     st->geom[nxt] = g;
-    DevObst o2 = ob;
-    if (u.do_update) { o2.buf = 1 - ob.buf; o2.n = u.n_cur; o2.scan = P.scan_no; }
-    st->obst[nxt] = o2;
+    st->obst[nxt].scan = u.do_update ? P.scan_no : ob_scan;
     st->flags[nn].any_pass = 0u;
     st->flags[nn].any_inside = 0u;
-    st->n_list[nn] = 0u;
     if (u.do_update) {
       unsigned f = 0;
       if (P.has_intensity) f |= 1u;
@@ -462,206 +415,189 @@ __device__ __forceinline__ UpdateCtx make_ctx(const ScanParams& P, const GeomCon
       if (f) st->sticky |= f;
     }
   }
-  return u;
+  if (S.dense) {
+    u.cur = u.do_update;
+    u.obst_tile = u.do_update;
+  } else {
+    const unsigned stamp = S.tile_stamp[blockIdx.x];
+    u.cur = u.do_update && stamp == P.scan_no;
+    u.obst_tile = u.do_update && (u.cur || stamp == ob_scan);
+  }
+  u.strips = u.applied && (u.C.shr != 0 || u.C.shc != 0);
 }
 
-struct CellObs {
-  int o;
-  bool in_strip;
-  float min_z, min_z_var, max_z;
-  uint32_t first, last, imax;
+struct KalmanPolicy {
+  using Layers = KalmanLayers;
+  struct State { KalmanState s; };
+  static __device__ __forceinline__ void load(const Layers& L, unsigned o, State& t) {
+    t.s.x = L.elevation[o];
+    t.s.P = L.kalman_p[o];
+    t.s.count = L.n_points[o];
+    t.s.mean = L.sample_mean[o];
+    t.s.var = L.variance[o];
+    t.s.m2 = L.sample_m2[o];
+  }
+  static __device__ __forceinline__ void set_nan(State& t) {
+    const float nanv = __uint_as_float(0x7FC00000u);
+    t.s.x = t.s.P = t.s.count = t.s.mean = t.s.var = t.s.m2 = nanv;
+  }
+  static __device__ __forceinline__ void step_store(const Layers& L, unsigned o, State& t, float z,
+                                                    float var) {
+    kalman_step(t.s, z, var, L.min_var, L.max_var, L.q);
+    L.elevation[o] = t.s.x;
+    L.kalman_p[o] = t.s.P;
+    L.n_points[o] = t.s.count;
+    L.sample_mean[o] = t.s.mean;
+    L.variance[o] = t.s.var;
+    L.sample_m2[o] = t.s.m2;
+    L.upper[o] = t.s.upper;
+    L.lower[o] = t.s.lower;
+  }
 };
 
-// decode the scan's CellObservation of a touched cell
-__device__ __forceinline__ CellObs load_obs(const ScanParams& P, const GeomConst& G, const UpdateCtx& u,
-                                            const Scratch& S, uint32_t cell,
-                                            const float* __restrict__ px,
-                                            const float* __restrict__ py,
-                                            const float* __restrict__ pz,
-                                            const float* __restrict__ pvar) {
-  CellObs c;
-  c.o = int(cell);
-  c.in_strip = false;
-  if (u.n_strip) {
-    const int r = int(cell % unsigned(G.s_rows)) + G.s_r0;
-    const int col = int(cell / unsigned(G.s_rows)) + G.s_c0;
-    c.in_strip = in_cleared_strip(r, u.E.sr, u.C.shr, G.rows) || in_cleared_strip(col, u.E.sc, u.C.shc, G.cols);
-  }
-  const unsigned long long key = S.key[u.cb][cell];
-  const uint32_t idx = uint32_t(key);
-  c.min_z = kFltMax;
-  c.min_z_var = 0.0f;
-  if (idx != kNoIdx) {
-    float x = px[idx], y = py[idx], z = pz[idx];
-    if (P.has_var) {
-      c.min_z_var = pvar[idx];
-    } else if (P.integrate_mode) {
-      c.min_z_var = sigma_z2(P, x, y, z);
-    }
-    preprocess_point(P, x, y, z);
-    c.min_z = z;
-  }
-  const uint32_t zm = S.zmax[u.cb][cell];
-  c.max_z = zm ? unord(zm) : -kFltMax;
-  c.first = kNoIdx;
-  c.last = 0u;
-  c.imax = 0u;
-  if (P.has_intensity) {
-    c.first = S.first[u.cb][cell];
-    c.imax = S.imax[u.cb][cell];
-  }
-  if (P.has_color) c.last = S.last[u.cb][cell];
-  return c;
-}
-
-// updateMinMax / updateObstacle / updateIntensity / updateColor (elevation_mapping.cpp:127-175)
-template <typename LAYERS>
-__device__ __forceinline__ void cell_epilogue(const ScanParams& P, const LAYERS& L, const CellObs& cx,
-                                              const float* __restrict__ pint,
-                                              const uint32_t* __restrict__ prgb) {
-  const int o = cx.o;
-  const float nanv = __uint_as_float(0x7FC00000u);
-  const float smin = cx.in_strip ? nanv : L.elevation_min[o];
-  const float smax = cx.in_strip ? nanv : L.elevation_max[o];
-  if (isnan(smin) || cx.min_z < smin) L.elevation_min[o] = cx.min_z;
-  if (isnan(smax) || cx.max_z > smax) L.elevation_max[o] = cx.max_z;
-  L.obstacle[o] = (cx.max_z > cx.min_z) ? cx.max_z : nanv;
-  if (P.has_intensity) {
-    const float vf = pint[cx.first];
-    const float obs = isnan(vf) ? vf : unord(cx.imax);
-    const float stored = cx.in_strip ? nanv : L.intensity[o];
-    if (isnan(stored) || obs > stored) L.intensity[o] = obs;
-  }
-  if (P.has_color) reinterpret_cast<uint32_t*>(L.color)[o] = prgb[cx.last] & 0x00FFFFFFu;
-}
-
-// obstacle clear of a cell the previous updating scan touched + reset of its scratch entry
-template <typename LAYERS>
-__device__ __forceinline__ void obst_item(const UpdateCtx& u, const Scratch& S, const LAYERS& L,
-                                          uint32_t cell) {
-  if (u.reset_prev) {
-    const int pb = 1 - u.cb;
-    S.key[pb][cell] = kEmptyKey;
-    S.zmax[pb][cell] = 0u;
-    if (S.imax[pb]) { S.imax[pb][cell] = 0u; S.first[pb][cell] = kNoIdx; }
-    if (S.last[pb]) S.last[pb][cell] = 0u;
-  }
-  // map_.clear(obstacle) runs only when this scan observed a cell (elevation_mapping.cpp:118-121)
-  if (u.do_update && S.key[u.cb][cell] == kEmptyKey) L.obstacle[cell] = __uint_as_float(0x7FC00000u);
-}
-
-// a cell vacated by GridMap::move: NaN in EVERY layer unless this scan re-observes it
-__device__ __forceinline__ void strip_item(const GeomConst& G, const UpdateCtx& u, const Scratch& S,
-                                           float* const* __restrict__ all_layers, int n_layers,
-                                           unsigned w) {
-  int r, c;
-  if (u.clear_all) {
-    r = int(w % unsigned(G.rows));
-    c = int(w / unsigned(G.rows));
-  } else if (w < unsigned(u.row_n) * unsigned(G.cols)) {
-    c = int(w / unsigned(u.row_n));
-    r = u.row_idx + int(w % unsigned(u.row_n));
-    if (r >= G.rows) r -= G.rows;
-  } else {
-    const unsigned v = w - unsigned(u.row_n) * unsigned(G.cols);
-    c = u.col_idx + int(v / unsigned(G.rows));
-    if (c >= G.cols) c -= G.cols;
-    r = int(v % unsigned(G.rows));
-  }
-  const size_t o = size_t(c) * G.rows + r;  // moves exist only for untiled engines
-  if (u.do_update && S.key[u.cb][o] != kEmptyKey) return;  // its cur-list item rewrites it
-  const float nanv = __uint_as_float(0x7FC00000u);
-  for (int l = 0; l < n_layers; ++l) all_layers[l][o] = nanv;
-}
-
-__global__ __launch_bounds__(256) void k_update_kalman(
-    const ScanParams P, const GeomConst G, DevState* __restrict__ st, const KalmanLayers L,
-    float* const* __restrict__ all_layers, int n_layers, const Scratch S,
-    const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
-    const float* __restrict__ pint, const uint32_t* __restrict__ prgb,
-    const float* __restrict__ pvar) {
-  const UpdateCtx u = make_ctx(P, G, st, S);
-  const unsigned total = u.n_cur + u.n_obst + u.n_strip;
-  const float nanv = __uint_as_float(0x7FC00000u);
-  for (unsigned w = blockIdx.x * 256u + threadIdx.x; w < total; w += gridDim.x * 256u) {
-    if (w < u.n_cur) {
-      const CellObs cx = load_obs(P, G, u, S, u.cur_list[w], px, py, pz, pvar);
-      const int o = cx.o;
-      KalmanState s;
-      if (cx.in_strip) {
-        for (int l = 0; l < n_layers; ++l) all_layers[l][o] = nanv;
-        s.x = s.P = s.count = s.mean = s.var = s.m2 = nanv;
-      } else {
-        s.x = L.elevation[o];
-        s.P = L.kalman_p[o];
-        s.count = L.n_points[o];
-        s.mean = L.sample_mean[o];
-        s.var = L.variance[o];
-        s.m2 = L.sample_m2[o];
-      }
-      kalman_step(s, cx.min_z, cx.min_z_var, L.min_var, L.max_var, L.q);
-      L.elevation[o] = s.x;
-      L.kalman_p[o] = s.P;
-      L.n_points[o] = s.count;
-      L.sample_mean[o] = s.mean;
-      L.variance[o] = s.var;
-      L.sample_m2[o] = s.m2;
-      L.upper[o] = s.upper;
-      L.lower[o] = s.lower;
-      cell_epilogue(P, L, cx, pint, prgb);
-    } else if (w < u.n_cur + u.n_obst) {
-      obst_item(u, S, L, u.obst_list[w - u.n_cur]);
-    } else {
-      strip_item(G, u, S, all_layers, n_layers, w - u.n_cur - u.n_obst);
+struct P2Policy {
+  using Layers = P2Layers;
+  struct State { P2State s; };
+  static __device__ __forceinline__ void load(const Layers& L, unsigned o, State& t) {
+    t.s.count = L.n_points[o];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      t.s.q[k] = L.q[k][o];
+      t.s.n[k] = L.n[k][o];
     }
   }
-}
+  static __device__ __forceinline__ void set_nan(State& t) {
+    const float nanv = __uint_as_float(0x7FC00000u);
+    t.s.count = nanv;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) t.s.q[k] = t.s.n[k] = nanv;
+  }
+  static __device__ __forceinline__ void step_store(const Layers& L, unsigned o, State& t, float z,
+                                                    float /*var*/) {
+    p2_step(t.s, z, L.p);
+    L.n_points[o] = t.s.count;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      L.q[k][o] = t.s.q[k];
+      L.n[k][o] = t.s.n[k];
+    }
+    L.elevation[o] = t.s.elevation;
+    L.variance[o] = t.s.variance;
+    L.upper[o] = t.s.upper;
+    L.lower[o] = t.s.lower;
+  }
+};
 
-__global__ __launch_bounds__(256) void k_update_p2(
-    const ScanParams P, const GeomConst G, DevState* __restrict__ st, const P2Layers L,
-    float* const* __restrict__ all_layers, int n_layers, const Scratch S,
-    const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
-    const float* __restrict__ pint, const uint32_t* __restrict__ prgb,
-    const float* __restrict__ pvar) {
-  const UpdateCtx u = make_ctx(P, G, st, S);
-  const unsigned total = u.n_cur + u.n_obst + u.n_strip;
+template <typename POLICY>
+__global__ __launch_bounds__(256) void k_update(
+    const ScanParams P, const GeomConst G, DevState* __restrict__ st,
+    const typename POLICY::Layers L, float* const* __restrict__ all_layers, int n_layers,
+    const Scratch S, const float* __restrict__ px, const float* __restrict__ py,
+    const float* __restrict__ pz, const float* __restrict__ pint,
+    const uint32_t* __restrict__ prgb, const float* __restrict__ pvar, unsigned ncell) {
   const float nanv = __uint_as_float(0x7FC00000u);
-  for (unsigned w = blockIdx.x * 256u + threadIdx.x; w < total; w += gridDim.x * 256u) {
-    if (w < u.n_cur) {
-      const CellObs cx = load_obs(P, G, u, S, u.cur_list[w], px, py, pz, pvar);
-      const int o = cx.o;
-      P2State s;
-      if (cx.in_strip) {
-        for (int l = 0; l < n_layers; ++l) all_layers[l][o] = nanv;
-        s.count = nanv;
+  __shared__ unsigned s_t[4];
+  const unsigned o = blockIdx.x * 256u + threadIdx.x;
+  const bool valid = o < ncell;
+
+  // ---- round 1: the cell's key (dense mode: independent of the context) + the scan context ----
+  unsigned long long key = kEmptyKey;
+  if (S.dense && valid) key = S.key[o];
+  UpdateCtx u;
+  make_ctx(P, st, S, u);
+  bool touched = false;
+  if (valid && (u.cur || u.obst_tile || u.strips) && P.dbg_upd != 1) {
+    if (!S.dense && u.cur) key = S.key[o];
+    bool in_strip = false;
+    if (u.strips) {
+      const int r = int(o % unsigned(G.s_rows)) + G.s_r0;
+      const int col = int(o / unsigned(G.s_rows)) + G.s_c0;
+      in_strip = in_cleared_strip(r, u.E.sr, u.C.shr, G.rows) ||
+                 in_cleared_strip(col, u.E.sc, u.C.shc, G.cols);
+      if (in_strip) {
+        // NaN in EVERY layer (GridMap::move).  Pointers are fetched 8 at a time so the loop costs
+        // ceil(n/8) round trips, not one per layer.
+        for (int l0 = 0; l0 < n_layers; l0 += 8) {
+          float* p[8];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) s.q[k] = s.n[k] = nanv;
-      } else {
-        s.count = L.n_points[o];
+          for (int k = 0; k < 8; ++k) p[k] = all_layers[min(l0 + k, n_layers - 1)];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-          s.q[k] = L.q[k][o];
-          s.n[k] = L.n[k][o];
+          for (int k = 0; k < 8; ++k)
+            if (l0 + k < n_layers) p[k][o] = nanv;
         }
       }
-      p2_step(s, cx.min_z, L.p);
-      L.n_points[o] = s.count;
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        L.q[k][o] = s.q[k];
-        L.n[k][o] = s.n[k];
-      }
-      L.elevation[o] = s.elevation;
-      L.variance[o] = s.variance;
-      L.upper[o] = s.upper;
-      L.lower[o] = s.lower;
-      cell_epilogue(P, L, cx, pint, prgb);
-    } else if (w < u.n_cur + u.n_obst) {
-      obst_item(u, S, L, u.obst_list[w - u.n_cur]);
+    }
+    touched = u.cur && key != kEmptyKey && P.dbg_upd != 3;
+    if (!touched) {
+      // map_.clear(obstacle) (elevation_mapping.cpp:144-146) for the cells it can matter for
+      if (u.obst_tile && !in_strip) L.obstacle[o] = nanv;
     } else {
-      strip_item(G, u, S, all_layers, n_layers, w - u.n_cur - u.n_obst);
+      // ---- round 2: every load the update needs, issued before any is used ----
+      const uint32_t idx = uint32_t(key);
+      float gx = 0.f, gy = 0.f, gz = 0.f, gvar = 0.f;
+      if (idx != kNoIdx) {
+        gx = px[idx];
+        gy = py[idx];
+        gz = pz[idx];
+        if (P.has_var) gvar = pvar[idx];
+      }
+      const uint32_t zm = S.zmax[o];
+      uint32_t imx = 0u, fst = kNoIdx, lst = 0u;
+      if (P.has_intensity) { imx = S.imax[o]; fst = S.first[o]; }
+      if (P.has_color) lst = S.last[o];
+      float smin = nanv, smax = nanv, sint = nanv;
+      typename POLICY::State stt;
+      if (in_strip) {
+        POLICY::set_nan(stt);
+      } else {
+        POLICY::load(L, o, stt);
+        smin = L.elevation_min[o];
+        smax = L.elevation_max[o];
+        if (P.has_intensity) sint = L.intensity[o];
+      }
+      float vfirst = 0.f;
+      uint32_t rgb = 0u;
+      // ---- round 3 (only with intensity / colour channels): first point's intensity, last colour
+      if (P.has_intensity) vfirst = pint[fst];
+      if (P.has_color) rgb = prgb[lst];
+
+      if (P.dbg_upd == 4) {  // measurement only: loads without the update
+        if (gx + gy + gz + gvar + smin + smax + sint + vfirst + float(zm + imx + rgb) == 12345.f) L.obstacle[o] = 0.f;
+        return;
+      }
+      // ---- one estimator update per touched cell (elevation_mapping.cpp:94-175) ----
+      float min_z = kFltMax, min_z_var = 0.0f;  // CellObservation defaults (elevation_mapping.hpp:26-34)
+      if (idx != kNoIdx) {
+        float x = gx, y = gy, z = gz;
+        if (P.has_var) min_z_var = gvar;
+        else if (P.integrate_mode) min_z_var = sigma_z2(P, x, y, z);
+        preprocess_point(P, x, y, z);
+        min_z = z;
+      }
+      const float max_z = zm ? unord(zm) : -kFltMax;
+      POLICY::step_store(L, o, stt, min_z, min_z_var);
+      if (isnan(smin) || min_z < smin) L.elevation_min[o] = min_z;
+      if (isnan(smax) || max_z > smax) L.elevation_max[o] = max_z;
+      L.obstacle[o] = (max_z > min_z) ? max_z : nanv;
+      if (P.has_intensity) {
+        const float obs = isnan(vfirst) ? vfirst : unord(imx);
+        if (isnan(sint) || obs > sint) L.intensity[o] = obs;
+        S.imax[o] = 0u;
+        S.first[o] = kNoIdx;
+      }
+      if (P.has_color) {
+        reinterpret_cast<uint32_t*>(L.color)[o] = rgb & 0x00FFFFFFu;
+        S.last[o] = 0u;
+      }
+      S.key[o] = kEmptyKey;  // scratch is clean again for the next scan
+      S.zmax[o] = 0u;
     }
   }
+  // per-tile touched-cell count (plain store; summed by the host on demand)
+  const unsigned long long m = __ballot(touched);
+  if ((threadIdx.x & 63) == 0) s_t[threadIdx.x >> 6] = unsigned(__popcll(m));
+  __syncthreads();
+  if (threadIdx.x == 0) S.upd_part[blockIdx.x] = s_t[0] + s_t[1] + s_t[2] + s_t[3];
 }
 
 // The host wrote the obstacle layer (upload / add): the touched-cell lists no longer bound the

@@ -223,6 +223,24 @@ def test_bin_kernel_variants_agree(gpu, R, order):
             assert_arrays_close(engs[0].layer(n), e.layer(n), n, 0.0, 0.0)
 
 
+def test_stamp_gated_update_equals_dense(gpu, R):
+    """Very large maps gate update tiles by scan stamps; force that mode on a small map and check
+    it against the oracle through moves, obstacle appear/disappear and a scan that lands nowhere."""
+    eng, ref = pair(gpu, R, 12.0, 12.0, 0.1)
+    eng.set_option("dense", 0)
+    rng = np.random.default_rng(21)
+    for k in range(12):
+        n = 4000
+        cx = -3.0 + 0.5 * k
+        s = {"x": (rng.normal(cx, 0.8, n)).astype(F32), "y": rng.normal(0.3 * k, 0.8, n).astype(F32),
+             "z": rng.normal(0, 0.3, n).astype(F32), "intensity": rng.random(n, dtype=F32)}
+        if k == 6:
+            s = {kk: (v + 500.0 if kk == "x" else v) for kk, v in s.items()}  # nothing lands
+        run_both(eng, ref, s, T(z=0.4), T(0.13 * k, -0.07 * k, yaw=0.02 * k))
+        assert_layers_equal(eng, ref)
+    assert same_geometry(eng.geometry(), ref.geometry())
+
+
 def test_unaligned_device_pointers_fall_back_to_scalar_kernel(gpu, R):
     import torch
     wl = gpu.synth.vlp16(n_scans=1)
