@@ -433,3 +433,36 @@ def test_p2_fading_memory_and_marker_choice(gpu, R):
         run_both(eng, ref, s, T(), T())
     assert_layers_equal(eng, ref)
     assert eng.layer("n_points").max() == 8.0
+
+
+def test_tiled_engines_with_halo_exchange_match_single_map(gpu, R):
+    """SURVEY.md §8e on one GPU: four tile engines (owned block + 6-cell halo ring) integrate the
+    same scans, exchange halos through the HIP pack/unpack kernels, and every stored window then
+    equals the untiled map — owned cells AND halo ring."""
+    import torch
+    from fastdem_amd import tiling
+    wl = gpu.synth.global_map(n_scans=3, size_m=60.0, n_az=1024, radius=12.0)
+    whole = gpu.Engine(wl.width, wl.height, wl.resolution, wl.apply_to(gpu.capi.default_config()))
+    world = 4
+    plans = [tiling.make_plan(r, world, whole.rows, whole.cols, halo=6) for r in range(world)]
+    engs = [gpu.Engine(wl.width, wl.height, wl.resolution, wl.apply_to(gpu.capi.default_config()),
+                       tile=p.fdm_tile()) for p in plans]
+    tiles = [tiling.EngineTile(e, p, "cuda:0") for e, p in zip(engs, plans)]
+    names = ["elevation", "variance", "elevation_min", "elevation_max", "upper_bound", "lower_bound",
+             "n_points", "obstacle"]
+    for k in range(3):
+        s = wl.scan(k)
+        for e in [whole] + engs:
+            e.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k))
+        # in-process stand-in for the RCCL isend/irecv pairs of tiling.exchange_halos
+        for r, p in enumerate(plans):
+            for other, rect in p.sends.items():
+                buf = tiles[r].pack(rect, names)
+                tiles[r].fence()
+                assert plans[other].recvs[r] == rect
+                tiles[other].unpack(rect, names, buf)
+        torch.cuda.synchronize()
+    for p, e in zip(plans, engs):
+        st = p.stored
+        for n in names:
+            assert_arrays_close(e.layer(n), whole.layer(n)[st.r0:st.r1, st.c0:st.c1], n, 0.0, 0.0)
