@@ -74,6 +74,8 @@ PROTOTYPES = {
     "fdm_last_error": (C.c_char_p, []),
     "fdm_engine_create": (C.c_int, [C.POINTER(FdmGeometry), C.POINTER(FdmConfig),
                                     C.POINTER(FdmTile), C.c_int, C.POINTER(_P)]),
+    "fdm_engine_create_map": (C.c_int, [C.POINTER(FdmGeometry), C.POINTER(FdmTile), C.c_int,
+                                        C.POINTER(_P)]),
     "fdm_engine_destroy": (None, [_P]),
     "fdm_engine_set_config": (C.c_int, [_P, C.POINTER(FdmConfig)]),
     "fdm_engine_set_stream": (C.c_int, [_P, _P]),

@@ -1,0 +1,196 @@
+// fastdem/fastdem.hpp — fastdem::FastDEM, the drop-in facade (fastdem/include/fastdem/fastdem.hpp:54-158,
+// fastdem/src/fastdem.cpp).  Same constructors, fluent setters, integrate() overloads, return
+// values and log messages; the body of integrateImpl() is one call into the HIP engine.
+//
+// Not thread-safe (same contract as fastdem.hpp:48-53): the caller serialises integrate()
+// against map reads.
+#pragma once
+#include <cstdio>
+#include <functional>
+#include <memory>
+#include <vector>
+
+#include "fastdem/config/fastdem.hpp"
+#include "fastdem/elevation_map.hpp"
+#include "fastdem/mapping/elevation_mapping.hpp"
+#include "fastdem/point_types.hpp"
+#include "fastdem/sensors/sensor_model.hpp"
+#include "fastdem/transform_interface.hpp"
+
+namespace fastdem {
+
+class FastDEM {
+ public:
+  using CloudCallback = std::function<void(const PointCloud&)>;
+
+  explicit FastDEM(ElevationMap& map) : FastDEM(map, Config{}) {}
+  FastDEM(ElevationMap& map, const Config& cfg) : map_(map), cfg_(cfg) {
+    sensor_model_ = createSensorModel(cfg_.sensor_model);
+    mapping_ = std::make_unique<ElevationMapping>(map_, cfg_);
+  }
+  ~FastDEM() = default;
+  FastDEM(const FastDEM&) = delete;
+  FastDEM& operator=(const FastDEM&) = delete;
+
+  FastDEM& setMappingMode(MappingMode mode) {
+    cfg_.mapping.mode = mode;
+    mapping_->setConfig(cfg_);
+    return *this;
+  }
+  FastDEM& setEstimatorType(EstimationType type) {
+    cfg_.mapping.estimation_type = type;
+    mapping_->setConfig(cfg_);
+    return *this;
+  }
+  FastDEM& setSensorModel(SensorType type) {
+    cfg_.sensor_model.type = type;
+    sensor_model_ = createSensorModel(cfg_.sensor_model);
+    return *this;
+  }
+  FastDEM& setSensorModel(std::unique_ptr<SensorModel> model) noexcept {
+    sensor_model_ = std::move(model);
+    return *this;
+  }
+  FastDEM& setHeightFilter(float z_min, float z_max) noexcept {
+    cfg_.point_filter.z_min = z_min;
+    cfg_.point_filter.z_max = z_max;
+    return *this;
+  }
+  FastDEM& setRangeFilter(float range_min, float range_max) noexcept {
+    cfg_.point_filter.range_min = range_min;
+    cfg_.point_filter.range_max = range_max;
+    return *this;
+  }
+  FastDEM& enableRaycasting(bool enabled = true) noexcept {
+    cfg_.raycasting.enabled = enabled;  // accepted, not executed by the engine yet
+    return *this;
+  }
+  FastDEM& setCalibrationProvider(std::shared_ptr<Calibration> c) noexcept {
+    calibration_ = std::move(c);
+    return *this;
+  }
+  FastDEM& setOdometryProvider(std::shared_ptr<Odometry> o) noexcept {
+    odometry_ = std::move(o);
+    return *this;
+  }
+  template <typename T>
+  FastDEM& setTransformProvider(std::shared_ptr<T> system) {
+    setCalibrationProvider(system);
+    setOdometryProvider(system);
+    return *this;
+  }
+
+  void reset() { map_.clearAll(); }
+  const Config& config() const noexcept { return cfg_; }
+  bool hasTransformProvider() const noexcept { return calibration_ != nullptr && odometry_ != nullptr; }
+
+  /// Online mode (fastdem.cpp:83-120).
+  bool integrate(std::shared_ptr<PointCloud> cloud) {
+    if (!calibration_ || !odometry_) {
+      std::fprintf(stderr, "[error] [FastDEM] Transform providers not set. Call setTransformProvider() or "
+                           "setCalibrationProvider()/setOdometryProvider() first, or use integrate(cloud, "
+                           "T_base_sensor, T_world_base) for explicit transforms.\n");
+      return false;
+    }
+    if (!cloud || cloud->empty()) {
+      std::fprintf(stderr, "[warn] [FastDEM] Received empty or null cloud. Skipping...\n");
+      return false;
+    }
+    if (cloud->frameId().empty()) {
+      std::fprintf(stderr, "[error] [FastDEM] Input cloud has no frameId. Skipping...\n");
+      return false;
+    }
+    auto T_base_sensor = calibration_->getExtrinsic(cloud->frameId());
+    if (!T_base_sensor) {
+      std::fprintf(stderr, "[warn] [FastDEM] Calibration not available for '%s'. Skipping...\n", cloud->frameId().c_str());
+      return false;
+    }
+    auto T_world_base = odometry_->getPoseAt(cloud->timestamp());
+    if (!T_world_base) {
+      std::fprintf(stderr, "[warn] [FastDEM] Odometry not available at %llu. Skipping...\n",
+                   static_cast<unsigned long long>(cloud->timestamp()));
+      return false;
+    }
+    return integrateImpl(*cloud, *T_base_sensor, *T_world_base);
+  }
+
+  /// Explicit transforms (fastdem.cpp:122-131).
+  bool integrate(const PointCloud& cloud, const Eigen::Isometry3d& T_base_sensor,
+                 const Eigen::Isometry3d& T_world_base) {
+    if (cloud.empty()) {
+      std::fprintf(stderr, "[warn] [FastDEM] Received empty cloud. Skipping...\n");
+      return false;
+    }
+    return integrateImpl(cloud, T_base_sensor, T_world_base);
+  }
+
+  /// Scan callbacks (fastdem.hpp:129-136).  The preprocessed / rasterized clouds live in HBM;
+  /// materialising them on the host is not implemented yet — registering one logs this once.
+  void onScanPreprocessed(CloudCallback cb) { on_preprocessed_ = std::move(cb); warnCallbacks(); }
+  void onScanRasterized(CloudCallback cb) { on_rasterized_ = std::move(cb); warnCallbacks(); }
+
+  /// Statistics of the last integrate() (not in the reference).
+  const fdm_scan_stats& lastStats() const { return last_; }
+
+ private:
+  // integrateImpl (fastdem.cpp:133-162): preprocessScan + ElevationMapping::update, on the device
+  bool integrateImpl(const PointCloud& cloud, const Eigen::Isometry3d& T_base_sensor,
+                     const Eigen::Isometry3d& T_world_base) {
+    map_.flushToDevice();
+    Config eff = cfg_;
+    const float* sigma = nullptr;
+    SensorType builtin;
+    if (sensor_model_ && sensor_model_->builtin(builtin)) {
+      // built-in model: evaluated on the device with the parameters the OBJECT carries
+      eff.sensor_model.type = builtin;
+      if (auto* l = dynamic_cast<const LiDARSensorModel*>(sensor_model_.get())) {
+        eff.sensor_model.lidar.range_noise = l->rangeNoise();
+        eff.sensor_model.lidar.angular_noise = l->angularNoise();
+      } else if (auto* r = dynamic_cast<const RGBDSensorModel*>(sensor_model_.get())) {
+        eff.sensor_model.rgbd.normal_a = r->a();
+        eff.sensor_model.rgbd.normal_b = r->b();
+        eff.sensor_model.rgbd.normal_c = r->c();
+        eff.sensor_model.rgbd.lateral_factor = r->k();
+      } else if (auto* c = dynamic_cast<const ConstantUncertaintyModel*>(sensor_model_.get())) {
+        eff.sensor_model.constant.uncertainty = c->uncertainty();
+      }
+    } else if (sensor_model_) {
+      // user SensorModel subclass: evaluate on the host, hand over sigma_z^2 = (R Sigma R^T)(2,2)
+      const Eigen::Matrix3f R = (T_world_base * T_base_sensor).rotation().cast<float>();
+      sigma_.resize(cloud.size());
+      for (size_t i = 0; i < cloud.size(); ++i) {
+        const Eigen::Matrix3f S = sensor_model_->computeCovariance(cloud.point(i));
+        float m2[3];
+        for (int j = 0; j < 3; ++j) m2[j] = R(2, 0) * S(0, j) + (R(2, 1) * S(1, j) + R(2, 2) * S(2, j));
+        sigma_[i] = m2[0] * R(2, 0) + (m2[1] * R(2, 1) + m2[2] * R(2, 2));
+      }
+      sigma = sigma_.data();
+    }
+    const fdm_config f = detail::toEngineConfig(eff);
+    detail::ck(fdm_engine_set_config(map_.engine(), &f), "fdm_engine_set_config");
+    const int rc = fdm_engine_integrate(map_.engine(), cloud.size(), cloud.xData(), cloud.yData(), cloud.zData(),
+                                        cloud.intensityData(), cloud.rgbData(), sigma,
+                                        T_base_sensor.matrix().data(), T_world_base.matrix().data(), &last_);
+    detail::ck(rc, "fdm_engine_integrate");
+    map_.invalidateHost();
+    return rc == FDM_OK;  // FDM_SKIP_ALL_FILTERED == the reference's `if (points.empty()) return false`
+  }
+  void warnCallbacks() {
+    if (warned_) return;
+    warned_ = true;
+    std::fprintf(stderr, "[warn] [FastDEM] scan callbacks are accepted but not yet fed by the device engine\n");
+  }
+
+  ElevationMap& map_;
+  Config cfg_;
+  std::unique_ptr<SensorModel> sensor_model_;
+  std::unique_ptr<ElevationMapping> mapping_;
+  std::shared_ptr<Calibration> calibration_;
+  std::shared_ptr<Odometry> odometry_;
+  CloudCallback on_preprocessed_, on_rasterized_;
+  std::vector<float> sigma_;
+  fdm_scan_stats last_{};
+  bool warned_ = false;
+};
+
+}  // namespace fastdem

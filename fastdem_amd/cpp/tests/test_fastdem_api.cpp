@@ -1,0 +1,426 @@
+// The reference's own API-level tests re-expressed against the MI355X engine through the C++
+// mirror of fastdem::FastDEM / ElevationMap (each TEST cites the gtest it restates).  Needs a GPU.
+//   fastdem/tests/test_elevation_map.cpp, test_fastdem_integration.cpp, test_online_mode.cpp,
+//   test_dual_layer.cpp, test_config.cpp (validation), test_sensor_models.cpp (host classes)
+#include <cmath>
+#include <memory>
+#include <optional>
+
+#include "fastdem/fastdem.hpp"
+#include "mini_test.hpp"
+
+using namespace fastdem;
+
+namespace {
+PointCloud makeGroundCloud(float height, int grid_half = 3, float spacing = 0.3f) {
+  PointCloud cloud;  // 7x7 grid at 0.3 m (test_fastdem_integration.cpp:32-41)
+  for (int i = -grid_half; i <= grid_half; ++i)
+    for (int j = -grid_half; j <= grid_half; ++j) cloud.add(i * spacing, j * spacing, height);
+  return cloud;
+}
+struct Fixture {
+  ElevationMap map;
+  Eigen::Isometry3d T_base_sensor = Eigen::Isometry3d::Identity();
+  Eigen::Isometry3d T_world_base = Eigen::Isometry3d::Identity();
+  Fixture() { map.setGeometry(10.0f, 10.0f, 0.5f); }
+};
+}  // namespace
+
+// ---------------------------------------------------------------- test_elevation_map.cpp ----
+TEST(ElevationMap, DefaultConstructorAndGeometry) {  // :17-38
+  ElevationMap m;
+  EXPECT_FALSE(m.isInitialized());
+  m.setGeometry(10.0f, 10.0f, 0.5f);
+  EXPECT_TRUE(m.isInitialized());
+  EXPECT_EQ(m.getSize()(0), 20);
+  EXPECT_EQ(m.getSize()(1), 20);
+  EXPECT_TRUE(m.exists(layer::elevation));
+  EXPECT_TRUE(m.exists(layer::elevation_min));
+  EXPECT_TRUE(m.exists(layer::elevation_max));
+  EXPECT_TRUE(m.isEmpty());
+  EXPECT_TRUE(m.isInside(nanogrid::Position(0.0, 0.0)));
+  EXPECT_FALSE(m.isInside(nanogrid::Position(100.0, 100.0)));
+}
+TEST(ElevationMap, AtAndElevationAtRoundTrip) {  // :40-71, :142-151
+  ElevationMap m(10.0f, 10.0f, 0.5f, "map");
+  EXPECT_EQ(m.getFrameId(), std::string("map"));
+  nanogrid::Index idx;
+  ASSERT_TRUE(m.getIndex(nanogrid::Position(1.0, 2.0), idx));
+  m.at(layer::elevation, idx) = 5.0f;
+  EXPECT_FLOAT_EQ(m.elevationAt(idx), 5.0f);
+  EXPECT_FLOAT_EQ(m.elevationAt(nanogrid::Position(1.0, 2.0)), 5.0f);
+  EXPECT_TRUE(m.hasElevationAt(idx));
+  EXPECT_FALSE(m.isEmptyAt(idx));
+  EXPECT_TRUE(std::isnan(m.elevationAt(nanogrid::Position(100.0, 100.0))));
+  m.clearAt(idx);
+  EXPECT_TRUE(m.isEmptyAt(idx));
+  nanogrid::Position p;
+  ASSERT_TRUE(m.getPosition(idx, p));
+  nanogrid::Index back;
+  ASSERT_TRUE(m.getIndex(p, back));
+  EXPECT_EQ(back(0), idx(0));
+  EXPECT_EQ(back(1), idx(1));
+}
+TEST(ElevationMap, HostWritesReachTheDeviceAndSnapshot) {
+  Fixture f;
+  nanogrid::Index idx;
+  ASSERT_TRUE(f.map.getIndex(nanogrid::Position(0.0, 0.0), idx));
+  f.map.at(layer::elevation, idx) = 7.0f;  // written on the host BEFORE the engine runs
+  FastDEM mapper(f.map);
+  mapper.setSensorModel(SensorType::Constant).setMappingMode(MappingMode::GLOBAL);
+  mapper.integrate(makeGroundCloud(1.0f), f.T_base_sensor, f.T_world_base);
+  // The device saw the host-written 7.0: with the stored P = 0 the Kalman gain is 0, so the
+  // estimate stays 7.0, P is clamped up to min_variance and the count goes 0 -> 1
+  // (kalman_estimation.hpp:115-126).  Had the write been lost, the cell would read 1.0.
+  const float fused = f.map.elevationAt(idx);
+  EXPECT_FLOAT_EQ(fused, 7.0f);
+  EXPECT_FLOAT_EQ(f.map.at(layer::kalman_p, idx), 0.0001f);
+  EXPECT_FLOAT_EQ(f.map.at(layer::n_points, idx), 1.0f);
+  ElevationMap snap = f.map.snapshot({layer::elevation, "does_not_exist"});
+  EXPECT_FLOAT_EQ(snap.elevationAt(idx), fused);
+  EXPECT_FALSE(snap.exists(layer::variance));
+}
+
+// -------------------------------------------------------- test_fastdem_integration.cpp ----
+TEST(FastDEMIntegration, IntegrateUpdatesElevation) {  // :46-60
+  Fixture f;
+  FastDEM mapper(f.map);
+  mapper.setHeightFilter(-2.0f, 5.0f).setRangeFilter(0.0f, 20.0f).setSensorModel(SensorType::Constant)
+      .setEstimatorType(EstimationType::Kalman);
+  mapper.integrate(makeGroundCloud(1.0f), f.T_base_sensor, f.T_world_base);
+  nanogrid::Position center(0.0, 0.0);
+  ASSERT_TRUE(f.map.hasElevationAt(center));
+  EXPECT_NEAR(f.map.elevationAt(center), 1.0f, 0.1f);
+}
+TEST(FastDEMIntegration, EmptyCloudIsNoOp) {  // :62-70
+  Fixture f;
+  FastDEM mapper(f.map);
+  PointCloud empty;
+  mapper.integrate(empty, f.T_base_sensor, f.T_world_base);
+  EXPECT_TRUE(f.map.isEmpty());
+}
+TEST(FastDEMIntegration, HeightFilterRejectsOutOfRange) {  // :72-80
+  Fixture f;
+  FastDEM mapper(f.map);
+  mapper.setHeightFilter(0.0f, 2.0f);
+  mapper.integrate(makeGroundCloud(10.0f), f.T_base_sensor, f.T_world_base);
+  EXPECT_TRUE(f.map.isEmpty());
+}
+TEST(FastDEMIntegration, MultipleIntegrations) {  // :82-100
+  Fixture f;
+  FastDEM mapper(f.map);
+  mapper.setHeightFilter(-5.0f, 15.0f).setRangeFilter(0.0f, 20.0f).setSensorModel(SensorType::Constant)
+      .setEstimatorType(EstimationType::Kalman);
+  mapper.integrate(makeGroundCloud(1.0f), f.T_base_sensor, f.T_world_base);
+  mapper.integrate(makeGroundCloud(1.5f), f.T_base_sensor, f.T_world_base);
+  nanogrid::Position center(0.0, 0.0);
+  ASSERT_TRUE(f.map.hasElevationAt(center));
+  EXPECT_GT(f.map.elevationAt(center), 0.9f);
+  EXPECT_LT(f.map.elevationAt(center), 1.6f);
+}
+TEST(FastDEMIntegration, SensorModelsTimesEstimators) {  // :129-175
+  for (SensorType s : {SensorType::Constant, SensorType::LiDAR, SensorType::RGBD})
+    for (EstimationType e : {EstimationType::Kalman, EstimationType::P2Quantile}) {
+      Fixture f;
+      f.T_base_sensor.translation().z() = 0.5;
+      FastDEM mapper(f.map);
+      mapper.setHeightFilter(-5.0f, 15.0f).setSensorModel(s).setEstimatorType(e);
+      for (int k = 0; k < 6; ++k) EXPECT_TRUE(mapper.integrate(makeGroundCloud(1.0f), f.T_base_sensor, f.T_world_base));
+      EXPECT_FALSE(f.map.isEmpty());
+      EXPECT_TRUE(f.map.exists(layer::variance));
+      EXPECT_TRUE(f.map.exists(e == EstimationType::Kalman ? layer::kalman_p : layer::p2_q0));
+    }
+}
+TEST(FastDEMIntegration, GlobalModeFixedOrigin) {  // :179-196
+  Fixture f;
+  FastDEM mapper(f.map);
+  mapper.setMappingMode(MappingMode::GLOBAL).setHeightFilter(-5.0f, 15.0f).setSensorModel(SensorType::Constant);
+  mapper.integrate(makeGroundCloud(1.0f), f.T_base_sensor, f.T_world_base);
+  f.T_world_base.translation().x() = 3.0;
+  mapper.integrate(makeGroundCloud(2.0f), f.T_base_sensor, f.T_world_base);
+  EXPECT_TRUE(f.map.hasElevationAt(nanogrid::Position(0.0, 0.0)));
+}
+TEST(FastDEMIntegration, LocalModeFollowsRobot) {  // :198-215
+  Fixture f;
+  FastDEM mapper(f.map);
+  mapper.setMappingMode(MappingMode::LOCAL).setHeightFilter(-5.0f, 15.0f).setSensorModel(SensorType::Constant);
+  mapper.integrate(makeGroundCloud(1.0f), f.T_base_sensor, f.T_world_base);
+  f.T_world_base.translation().x() = 100.0;
+  mapper.integrate(makeGroundCloud(2.0f), f.T_base_sensor, f.T_world_base);
+  EXPECT_FALSE(f.map.isInside(nanogrid::Position(0.0, 0.0)));
+}
+TEST(FastDEMIntegration, ConstructFromConfig) {  // :219-236
+  Fixture f;
+  Config cfg;
+  cfg.mapping.estimation_type = EstimationType::Kalman;
+  cfg.sensor_model.type = SensorType::Constant;
+  cfg.point_filter.z_min = -2.0f;
+  cfg.point_filter.z_max = 5.0f;
+  cfg.raycasting.enabled = false;
+  FastDEM mapper(f.map, cfg);
+  EXPECT_TRUE(mapper.integrate(makeGroundCloud(1.0f), f.T_base_sensor, f.T_world_base));
+  ASSERT_TRUE(f.map.hasElevationAt(nanogrid::Position(0.0, 0.0)));
+  EXPECT_NEAR(f.map.elevationAt(nanogrid::Position(0.0, 0.0)), 1.0f, 0.1f);
+}
+TEST(FastDEMIntegration, ConfigPointFilterApplied) {  // :238-249
+  Fixture f;
+  Config cfg;
+  cfg.point_filter.z_min = 0.0f;
+  cfg.point_filter.z_max = 2.0f;
+  FastDEM mapper(f.map, cfg);
+  mapper.integrate(makeGroundCloud(5.0f), f.T_base_sensor, f.T_world_base);
+  EXPECT_TRUE(f.map.isEmpty());
+}
+TEST(FastDEMIntegration, SensorOffsetApplied) {  // :253-267
+  Fixture f;
+  f.T_base_sensor.translation().z() = 1.0;
+  FastDEM mapper(f.map);
+  mapper.setHeightFilter(-5.0f, 15.0f).setSensorModel(SensorType::Constant);
+  mapper.integrate(makeGroundCloud(0.0f), f.T_base_sensor, f.T_world_base);
+  ASSERT_TRUE(f.map.hasElevationAt(nanogrid::Position(0.0, 0.0)));
+  EXPECT_NEAR(f.map.elevationAt(nanogrid::Position(0.0, 0.0)), 1.0f, 0.2f);
+}
+TEST(FastDEMIntegration, RotatedTransform) {  // :269-283
+  Fixture f;
+  f.T_world_base.rotate(Eigen::AngleAxisd(M_PI / 2, Eigen::Vector3d::UnitZ()));
+  FastDEM mapper(f.map);
+  mapper.setHeightFilter(-5.0f, 15.0f).setSensorModel(SensorType::Constant);
+  EXPECT_TRUE(mapper.integrate(makeGroundCloud(1.0f), f.T_base_sensor, f.T_world_base));
+  EXPECT_FALSE(f.map.isEmpty());
+}
+TEST(FastDEMIntegration, RangeFilterRejectsClosePoints) {  // :287-296
+  Fixture f;
+  FastDEM mapper(f.map);
+  mapper.setRangeFilter(5.0f, 20.0f);
+  mapper.integrate(makeGroundCloud(1.0f, 2, 0.3f), f.T_base_sensor, f.T_world_base);
+  EXPECT_TRUE(f.map.isEmpty());
+}
+TEST(FastDEMIntegration, CombinedHeightAndRangeFilter) {  // :298-316
+  Fixture f;
+  FastDEM mapper(f.map);
+  mapper.setHeightFilter(0.0f, 3.0f).setRangeFilter(0.0f, 20.0f).setSensorModel(SensorType::Constant);
+  mapper.integrate(makeGroundCloud(1.0f), f.T_base_sensor, f.T_world_base);
+  EXPECT_FALSE(f.map.isEmpty());
+  f.map.clearAll();
+  mapper.integrate(makeGroundCloud(5.0f), f.T_base_sensor, f.T_world_base);
+  EXPECT_TRUE(f.map.isEmpty());
+}
+TEST(FastDEMIntegration, ReturnValues) {  // :357-378
+  Fixture f;
+  FastDEM mapper(f.map);
+  mapper.setHeightFilter(-5.0f, 15.0f).setSensorModel(SensorType::Constant);
+  EXPECT_TRUE(mapper.integrate(makeGroundCloud(1.0f), f.T_base_sensor, f.T_world_base));
+  PointCloud empty;
+  EXPECT_FALSE(mapper.integrate(empty, f.T_base_sensor, f.T_world_base));
+  mapper.setHeightFilter(100.0f, 200.0f);
+  EXPECT_FALSE(mapper.integrate(makeGroundCloud(1.0f), f.T_base_sensor, f.T_world_base));
+  mapper.reset();
+  EXPECT_TRUE(f.map.isEmpty());
+}
+TEST(FastDEMIntegration, CustomSensorModelSubclass) {  // fastdem.hpp:79-80
+  struct Wide : SensorModel {  // user model: 1 m^2 isotropic
+    Eigen::Matrix3f computeCovariance(const Eigen::Vector3f&) const override { return Eigen::Matrix3f::Identity() * 0.005f; }
+  };
+  Fixture f;
+  FastDEM mapper(f.map);
+  mapper.setMappingMode(MappingMode::GLOBAL).setSensorModel(std::make_unique<Wide>());
+  EXPECT_TRUE(mapper.integrate(makeGroundCloud(1.0f), f.T_base_sensor, f.T_world_base));
+  nanogrid::Index idx;
+  ASSERT_TRUE(f.map.getIndex(nanogrid::Position(0.0, 0.0), idx));
+  EXPECT_FLOAT_EQ(f.map.at(layer::kalman_p, idx), 0.005f);  // first update: P = R = sigma_z^2
+}
+
+// ---------------------------------------------------------------- test_online_mode.cpp ----
+namespace {
+class MockCalibration : public Calibration {
+ public:
+  explicit MockCalibration(Eigen::Isometry3d e = Eigen::Isometry3d::Identity()) : extrinsic_(e) {}
+  std::optional<Eigen::Isometry3d> getExtrinsic(const std::string& frame) const override {
+    if (frame == "unknown_sensor") return std::nullopt;
+    return extrinsic_;
+  }
+  std::string getBaseFrame() const override { return "base_link"; }
+ private:
+  Eigen::Isometry3d extrinsic_;
+};
+class MockOdometry : public Odometry {
+ public:
+  std::optional<Eigen::Isometry3d> getPoseAt(uint64_t) const override {
+    if (fail_) return std::nullopt;
+    return pose_;
+  }
+  std::string getWorldFrame() const override { return "map"; }
+  void setPose(const Eigen::Isometry3d& p) { pose_ = p; }
+  void setFail(bool f) { fail_ = f; }
+ private:
+  Eigen::Isometry3d pose_ = Eigen::Isometry3d::Identity();
+  bool fail_ = false;
+};
+std::shared_ptr<PointCloud> makeSharedCloud(float h = 1.0f, const std::string& frame = "lidar") {
+  auto c = std::make_shared<PointCloud>(makeGroundCloud(h));
+  c->setFrameId(frame);
+  c->setTimestamp(1000000000ULL);
+  return c;
+}
+}  // namespace
+
+TEST(OnlineMode, IntegrateWithTransformProvider) {  // :98-114
+  Fixture f;
+  auto cal = std::make_shared<MockCalibration>();
+  auto odo = std::make_shared<MockOdometry>();
+  FastDEM mapper(f.map);
+  mapper.setHeightFilter(-2.0f, 5.0f).setRangeFilter(0.0f, 20.0f).setSensorModel(SensorType::Constant)
+      .setCalibrationProvider(cal).setOdometryProvider(odo);
+  ASSERT_TRUE(mapper.hasTransformProvider());
+  EXPECT_TRUE(mapper.integrate(makeSharedCloud(1.0f)));
+  ASSERT_TRUE(f.map.hasElevationAt(nanogrid::Position(0.0, 0.0)));
+  EXPECT_NEAR(f.map.elevationAt(nanogrid::Position(0.0, 0.0)), 1.0f, 0.1f);
+}
+TEST(OnlineMode, ValidationFailuresReturnFalse) {  // :129-175
+  Fixture f;
+  auto cal = std::make_shared<MockCalibration>();
+  auto odo = std::make_shared<MockOdometry>();
+  FastDEM mapper(f.map);
+  EXPECT_FALSE(mapper.hasTransformProvider());
+  EXPECT_FALSE(mapper.integrate(makeSharedCloud()));                 // no providers
+  mapper.setCalibrationProvider(cal);
+  EXPECT_FALSE(mapper.hasTransformProvider());
+  mapper.setOdometryProvider(odo);
+  EXPECT_TRUE(mapper.hasTransformProvider());
+  EXPECT_FALSE(mapper.integrate(std::shared_ptr<PointCloud>()));     // null cloud
+  EXPECT_FALSE(mapper.integrate(std::make_shared<PointCloud>()));    // empty cloud
+  EXPECT_FALSE(mapper.integrate(makeSharedCloud(1.0f, "")));         // no frame id
+  EXPECT_FALSE(mapper.integrate(makeSharedCloud(1.0f, "unknown_sensor")));
+  odo->setFail(true);
+  EXPECT_FALSE(mapper.integrate(makeSharedCloud()));
+  EXPECT_TRUE(f.map.isEmpty());
+}
+TEST(OnlineMode, PoseOffsetLandsDataAtRobot) {  // :221-241
+  Fixture f;
+  auto cal = std::make_shared<MockCalibration>();
+  auto odo = std::make_shared<MockOdometry>();
+  Eigen::Isometry3d pose = Eigen::Isometry3d::Identity();
+  pose.translation().x() = 2.0;
+  odo->setPose(pose);
+  FastDEM mapper(f.map);
+  mapper.setHeightFilter(-5.0f, 15.0f).setSensorModel(SensorType::Constant).setCalibrationProvider(cal)
+      .setOdometryProvider(odo);
+  EXPECT_TRUE(mapper.integrate(makeSharedCloud(1.0f)));
+  EXPECT_TRUE(f.map.hasElevationAt(nanogrid::Position(2.0, 0.0)));
+}
+
+// ------------------------------------------------------------------ test_dual_layer.cpp ----
+namespace {
+PointCloud cloudOf(std::initializer_list<std::array<float, 3>> pts) {
+  PointCloud c;
+  for (const auto& p : pts) c.add(p[0], p[1], p[2]);
+  return c;
+}
+config::Mapping kalmanMapping() {
+  config::Mapping cfg;
+  cfg.mode = MappingMode::GLOBAL;
+  cfg.estimation_type = EstimationType::Kalman;
+  cfg.kalman.min_variance = 0.0001f;
+  cfg.kalman.max_variance = 1.0f;
+  cfg.kalman.process_noise = 0.0f;
+  return cfg;
+}
+}  // namespace
+TEST(DualLayer, GroundObstacleSeparationAndOverwrite) {  // :66-83, :121-143
+  Fixture f;
+  ElevationMapping mapping(f.map, kalmanMapping());
+  Eigen::Vector2d robot(0.0, 0.0);
+  mapping.update(cloudOf({{0, 0, 0.0f}, {0, 0, 3.0f}}), robot);
+  nanogrid::Index idx;
+  ASSERT_TRUE(f.map.getIndex(nanogrid::Position(0, 0), idx));
+  EXPECT_NEAR(f.map.at(layer::elevation, idx), 0.0f, 0.1f);
+  EXPECT_NEAR(f.map.at(layer::obstacle, idx), 3.0f, 0.1f);
+  mapping.update(cloudOf({{0, 0, 0.1f}, {0, 0, 3.1f}}), robot);
+  EXPECT_GT(f.map.at(layer::elevation, idx), -0.05f);
+  EXPECT_LT(f.map.at(layer::elevation, idx), 0.15f);
+  EXPECT_FLOAT_EQ(f.map.at(layer::obstacle, idx), 3.1f);
+}
+TEST(DualLayer, SinglePointOnlyGroundAndObstacleClears) {  // :106-119, :188-203
+  Fixture f;
+  ElevationMapping mapping(f.map, kalmanMapping());
+  Eigen::Vector2d robot(0.0, 0.0);
+  nanogrid::Index idx;
+  ASSERT_TRUE(f.map.getIndex(nanogrid::Position(0, 0), idx));
+  auto obs = mapping.update(cloudOf({{0, 0, 0.0f}, {0, 0, 2.0f}}), robot);
+  EXPECT_EQ(obs.size(), size_t(1));
+  EXPECT_FLOAT_EQ(f.map.at(layer::obstacle, idx), 2.0f);
+  mapping.update(cloudOf({{0, 0, 0.0f}}), robot);
+  EXPECT_TRUE(std::isnan(f.map.at(layer::obstacle, idx)));
+}
+TEST(DualLayer, ElevationMaxReflectsTrueMaxAndQuantile) {  // :145-186
+  Fixture f;
+  ElevationMapping mapping(f.map, kalmanMapping());
+  Eigen::Vector2d robot(0.0, 0.0);
+  nanogrid::Index idx;
+  ASSERT_TRUE(f.map.getIndex(nanogrid::Position(0, 0), idx));
+  mapping.update(cloudOf({{0, 0, 0.0f}, {0, 0, 3.0f}}), robot);
+  EXPECT_FLOAT_EQ(f.map.at(layer::elevation_max, idx), 3.0f);
+  mapping.update(cloudOf({{0, 0, 0.0f}, {0, 0, 5.0f}}), robot);
+  EXPECT_FLOAT_EQ(f.map.at(layer::elevation_max, idx), 5.0f);
+  Fixture g;
+  config::Mapping q;
+  q.mode = MappingMode::GLOBAL;
+  q.estimation_type = EstimationType::P2Quantile;
+  ElevationMapping qm(g.map, q);
+  for (int i = 0; i < 10; ++i) {
+    const float noise = (i % 2 == 0) ? 0.05f : -0.05f;
+    qm.update(cloudOf({{0, 0, 0.0f + noise}, {0, 0, 5.0f + noise}}), robot);
+  }
+  ASSERT_TRUE(g.map.getIndex(nanogrid::Position(0, 0), idx));
+  EXPECT_NEAR(g.map.at(layer::elevation, idx), 0.0f, 0.5f);
+  EXPECT_NEAR(g.map.at(layer::obstacle, idx), 5.0f, 0.1f);
+}
+
+// ---------------------------------------------------------- test_config.cpp (validation) ----
+TEST(Config, DefaultsAndValidation) {  // test_config.cpp:36-344, config_fastdem.cpp:128-260
+  Config c;
+  EXPECT_TRUE(c.mapping.mode == MappingMode::LOCAL);
+  EXPECT_TRUE(c.mapping.estimation_type == EstimationType::Kalman);
+  EXPECT_TRUE(c.sensor_model.type == SensorType::LiDAR);
+  EXPECT_FLOAT_EQ(c.mapping.kalman.min_variance, 0.0001f);
+  EXPECT_FLOAT_EQ(c.mapping.kalman.max_variance, 0.01f);
+  EXPECT_FLOAT_EQ(c.mapping.p2.dn3, 0.84f);
+  EXPECT_EQ(c.mapping.p2.elevation_marker, 3);
+  EXPECT_FALSE(c.raycasting.enabled);
+  EXPECT_NO_THROW(validated(c));
+  Config bad = c;
+  bad.mapping.kalman.min_variance = 0.5f;
+  bad.mapping.kalman.max_variance = 0.1f;
+  EXPECT_THROW(validated(bad), std::invalid_argument);
+  Config unsorted = c;
+  unsorted.mapping.p2.dn1 = 0.9f;
+  EXPECT_THROW(validated(unsorted), std::invalid_argument);
+  Config clamp = c;
+  clamp.mapping.p2.elevation_marker = 9;
+  clamp.sensor_model.lidar.range_noise = -1.0f;
+  clamp.mapping.kalman.process_noise = -2.0f;
+  const Config v = validated(clamp);
+  EXPECT_EQ(v.mapping.p2.elevation_marker, 4);
+  EXPECT_FLOAT_EQ(v.sensor_model.lidar.range_noise, 0.02f);
+  EXPECT_FLOAT_EQ(v.mapping.kalman.process_noise, 0.0f);
+}
+
+// ------------------------------------------------------------- test_sensor_models.cpp ----
+TEST(SensorModels, HostClassesAndFactory) {  // test_sensor_models.cpp:17-262
+  config::SensorModel cfg;
+  SensorType t;
+  cfg.type = SensorType::Constant;
+  EXPECT_TRUE(createSensorModel(cfg)->builtin(t) && t == SensorType::Constant);
+  cfg.type = SensorType::RGBD;
+  EXPECT_TRUE(createSensorModel(cfg)->builtin(t) && t == SensorType::RGBD);
+  LiDARSensorModel lidar(0.02f, 0.001f);
+  const auto cov = lidar.computeCovariance(Eigen::Vector3f(10.0f, 0.0f, 0.0f));
+  EXPECT_NEAR(cov(0, 0), 0.02f * 0.02f, 1e-6f);
+  EXPECT_NEAR(cov(1, 1), 0.01f * 0.01f, 1e-6f);
+  EXPECT_NEAR(lidar.computeCovariance(Eigen::Vector3f(0, 0, 0))(2, 2), 0.01f, 1e-6f);
+  RGBDSensorModel rgbd;
+  EXPECT_NEAR(rgbd.computeCovariance(Eigen::Vector3f(0, 0, 0.4f))(2, 2), 0.001f * 0.001f, 1e-10f);
+  EXPECT_NEAR(rgbd.computeCovariance(Eigen::Vector3f(1, 2, -0.5f))(0, 0), 0.01f, 1e-6f);
+}
+
+int main(int argc, char** argv) { return mini::run(argc > 1 ? argv[1] : nullptr); }

@@ -80,6 +80,7 @@ struct fdm_engine {
   unsigned n_tiles = 0;
   std::vector<uint32_t> h_upd_part;
   bool obst_dense_pending = false;  // host wrote the obstacle layer: next scan clears it densely
+  bool estimator_ready = false;     // ElevationMapping ctor ran (ensureLayers + obstacle layer)
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   float last_ms[3] = {0.f, 0.f, 0.f};
 };
@@ -259,6 +260,10 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     P.sp[0] = std::fabs(e->cfg.lidar_range_noise);
     P.sp[1] = std::fabs(e->cfg.lidar_angular_noise);
     P.sp[2] = P.sp[3] = 0.f;
+  }
+  if (!e->estimator_ready) {  // a bare map: behave as if FastDEM(map) had been constructed
+    if ((rc = ensure_estimator_layers(e))) return rc;
+    e->estimator_ready = true;
   }
   if ((rc = ensure_scratch_channels(e, P.has_intensity, P.has_color))) return rc;
   if ((rc = refresh_layer_ptrs(e))) return rc;
@@ -516,8 +521,8 @@ void fdm_default_config(fdm_config* c) {
 
 const char* fdm_last_error(void) { return g_err.c_str(); }
 
-int fdm_engine_create(const fdm_geometry* g, const fdm_config* cfg, const fdm_tile* tile, int device,
-                      fdm_engine** out) {
+static int create_impl(const fdm_geometry* g, const fdm_config* cfg, const fdm_tile* tile, int device,
+                       bool with_estimator, fdm_engine** out) {
   if (!g || !cfg || !out) return fail(FDM_ERR_INVALID, "null argument");
   if (!(g->resolution > 0.0) || !(g->length_x > 0.0) || !(g->length_y > 0.0))
     return fail(FDM_ERR_INVALID, "length and resolution must be positive");
@@ -624,12 +629,27 @@ int fdm_engine_create(const fdm_geometry* g, const fdm_config* cfg, const fdm_ti
   CK(add_layer(e, "elevation", NAN));
   CK(add_layer(e, "elevation_min", NAN));
   CK(add_layer(e, "elevation_max", NAN));
-  CK(ensure_estimator_layers(e));
+  if (with_estimator) {
+    CK(ensure_estimator_layers(e));
+    e->estimator_ready = true;
+  }
   HCK(hipStreamSynchronize(e->stream));
 #undef CK
 #undef HCK
   *out = e;
   return FDM_OK;
+}
+
+int fdm_engine_create(const fdm_geometry* g, const fdm_config* cfg, const fdm_tile* tile, int device,
+                      fdm_engine** out) {
+  return create_impl(g, cfg, tile, device, true, out);
+}
+
+int fdm_engine_create_map(const fdm_geometry* g, const fdm_tile* tile, int device, fdm_engine** out) {
+  fdm_config cfg;
+  fdm_default_config(&cfg);
+  if (tile) cfg.mode = 1;
+  return create_impl(g, &cfg, tile, device, false, out);
 }
 
 void fdm_engine_destroy(fdm_engine* e) {
@@ -662,6 +682,7 @@ int fdm_engine_set_config(fdm_engine* e, const fdm_config* cfg) {
   if (cfg->mode != 1 && (e->G.s_rows != e->G.rows || e->G.s_cols != e->G.cols))
     return fail(FDM_ERR_INVALID, "tiled engines require GLOBAL mode");
   e->cfg = *cfg;
+  e->estimator_ready = true;
   return ensure_estimator_layers(e);
 }
 

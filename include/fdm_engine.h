@@ -91,6 +91,10 @@ const char* fdm_last_error(void);              /* text of the last <0 status on 
  * g->length_*, resolution, position_* are read; tile may be NULL (whole map). */
 int fdm_engine_create(const fdm_geometry* g, const fdm_config* cfg, const fdm_tile* tile,
                       int device, fdm_engine** out);
+/* ElevationMap(width,height,resolution,frame) ALONE (elevation_map.hpp:101-116): the three
+ * default layers, no estimator layers yet.  fdm_engine_set_config() then plays the role of
+ * constructing FastDEM / ElevationMapping on that map (ensureLayers + obstacle layer). */
+int fdm_engine_create_map(const fdm_geometry* g, const fdm_tile* tile, int device, fdm_engine** out);
 void fdm_engine_destroy(fdm_engine* e);
 
 /* FastDEM fluent setters (fastdem.cpp:28-62): filters/sensor params take effect on
@@ -166,7 +170,10 @@ int fdm_engine_enable_profile(fdm_engine* e, int on);
 int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2);
 
 /* Tuning knobs for A/B measurements (bench.py); unknown keys are an error.
- *   "wave_merge" 0/1 : merge same-cell runs inside the wavefront before the atomics */
+ *   "wave_merge"  0/1   : k_bin merges same-cell runs inside the wavefront before the atomics
+ *   "bin_variant" 0/1/4 : bin kernel by scan size (0), one point per thread (1), LDS-staged (4)
+ *   "dense"       0/1   : update sweep visits every tile (1) or only stamped tiles (0)
+ *   "dbg_*"             : measurement-only switches used by scripts/ab_kernels.py */
 int fdm_engine_set_option(fdm_engine* e, const char* key, int value);
 
 #ifdef __cplusplus

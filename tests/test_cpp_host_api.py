@@ -1,0 +1,35 @@
+"""The C++17 host mirror of fastdem::FastDEM / ElevationMap (fastdem_amd/cpp) — the reference's
+API-level gtests re-expressed in fastdem_amd/cpp/tests/test_fastdem_api.cpp and run as a binary."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "fastdem_amd", "cpp", "build", "fdm_cpp_tests")
+
+
+def test_cpp_spec_tests_are_built():
+    if not os.path.exists(BIN):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "fastdem_amd", "cpp")])
+    assert os.access(BIN, os.X_OK)
+
+
+def test_cpp_api_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    # host-only tests (config validation, sensor-model classes) still pass ...
+    r = subprocess.run([BIN, "Config."], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # ... anything that needs the map raises: there is no CPU fallback behind the API
+    r = subprocess.run([BIN, "ElevationMap.Default"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "no HIP device" in (r.stdout + r.stderr)
+
+
+@pytest.mark.gpu
+def test_cpp_api_spec_tests_on_gpu():
+    r = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-4000:])
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert " 0 failures" in r.stdout
