@@ -104,6 +104,9 @@ PROTOTYPES = {
                                          C.POINTER(C.c_char_p), C.c_int, _P]),
     "fdm_engine_region_unpack": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            C.POINTER(C.c_char_p), C.c_int, _P]),
+    "fdm_engine_capture": (C.c_int, [_P, C.c_int, C.c_int]),
+    "fdm_engine_last_preprocessed": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, C.POINTER(C.c_uint64)]),
+    "fdm_engine_last_rasterized": (C.c_int, [_P, C.c_uint64, _P, _P, _P, C.POINTER(C.c_uint64)]),
     "fdm_engine_enable_cell_ids": (C.c_int, [_P, C.c_int]),
     "fdm_engine_last_cell_ids": (C.c_int, [_P, _P, C.c_uint64]),
     "fdm_engine_enable_profile": (C.c_int, [_P, C.c_int]),

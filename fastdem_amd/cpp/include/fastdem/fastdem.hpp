@@ -124,10 +124,12 @@ class FastDEM {
     return integrateImpl(cloud, T_base_sensor, T_world_base);
   }
 
-  /// Scan callbacks (fastdem.hpp:129-136).  The preprocessed / rasterized clouds live in HBM;
-  /// materialising them on the host is not implemented yet — registering one logs this once.
-  void onScanPreprocessed(CloudCallback cb) { on_preprocessed_ = std::move(cb); warnCallbacks(); }
-  void onScanRasterized(CloudCallback cb) { on_rasterized_ = std::move(cb); warnCallbacks(); }
+  /// Scan callbacks (fastdem.hpp:129-136).  The clouds are captured on the device and
+  /// materialised on the host only while a callback is registered: the preprocessed scan (points
+  /// that survived the filters, map frame, input order) and the rasterized scan (one point per
+  /// observed cell at the cell centre, z = min_z; fastdem.cpp:200-214).
+  void onScanPreprocessed(CloudCallback cb) { on_preprocessed_ = std::move(cb); syncCapture(); }
+  void onScanRasterized(CloudCallback cb) { on_rasterized_ = std::move(cb); syncCapture(); }
 
   /// Statistics of the last integrate() (not in the reference).
   const fdm_scan_stats& lastStats() const { return last_; }
@@ -173,12 +175,29 @@ class FastDEM {
                                         T_base_sensor.matrix().data(), T_world_base.matrix().data(), &last_);
     detail::ck(rc, "fdm_engine_integrate");
     map_.invalidateHost();
-    return rc == FDM_OK;  // FDM_SKIP_ALL_FILTERED == the reference's `if (points.empty()) return false`
+    if (rc != FDM_OK) return false;  // FDM_SKIP_ALL_FILTERED == `if (points.empty()) return false`
+    if (on_preprocessed_) on_preprocessed_(fetch(true, cloud.size()));              // fastdem.cpp:139-141
+    if (on_rasterized_ && last_.n_cells_touched > 0) on_rasterized_(fetch(false, last_.n_cells_touched));  // :148-150
+    return true;
   }
-  void warnCallbacks() {
-    if (warned_) return;
-    warned_ = true;
-    std::fprintf(stderr, "[warn] [FastDEM] scan callbacks are accepted but not yet fed by the device engine\n");
+  void syncCapture() {
+    detail::ck(fdm_engine_capture(map_.engine(), on_preprocessed_ ? 1 : 0, on_rasterized_ ? 1 : 0),
+               "fdm_engine_capture");
+  }
+  PointCloud fetch(bool preprocessed, size_t cap) {
+    std::vector<float> x(cap), y(cap), z(cap);
+    uint64_t n = 0;
+    if (preprocessed)
+      detail::ck(fdm_engine_last_preprocessed(map_.engine(), cap, x.data(), y.data(), z.data(), nullptr, &n),
+                 "fdm_engine_last_preprocessed");
+    else
+      detail::ck(fdm_engine_last_rasterized(map_.engine(), cap, x.data(), y.data(), z.data(), &n),
+                 "fdm_engine_last_rasterized");
+    PointCloud out;
+    out.reserve(n);
+    for (uint64_t i = 0; i < n && i < cap; ++i) out.add(x[i], y[i], z[i]);
+    out.setFrameId(map_.getFrameId());
+    return out;
   }
 
   ElevationMap& map_;
@@ -190,7 +209,6 @@ class FastDEM {
   CloudCallback on_preprocessed_, on_rasterized_;
   std::vector<float> sigma_;
   fdm_scan_stats last_{};
-  bool warned_ = false;
 };
 
 }  // namespace fastdem

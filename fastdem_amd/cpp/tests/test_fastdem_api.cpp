@@ -217,6 +217,23 @@ TEST(FastDEMIntegration, ReturnValues) {  // :357-378
   mapper.reset();
   EXPECT_TRUE(f.map.isEmpty());
 }
+TEST(FastDEMIntegration, ScanCallbacksFire) {  // :320-353
+  Fixture f;
+  FastDEM mapper(f.map);
+  mapper.setHeightFilter(-5.0f, 15.0f).setSensorModel(SensorType::Constant);
+  bool pre = false, ras = false;
+  size_t n_pre = 0, n_ras = 0;
+  float z_ras = 0.f;
+  mapper.onScanPreprocessed([&](const PointCloud& c) { pre = true; n_pre = c.size(); });
+  mapper.onScanRasterized([&](const PointCloud& c) { ras = true; n_ras = c.size(); z_ras = c.point(0)[2]; });
+  mapper.integrate(makeGroundCloud(1.0f), f.T_base_sensor, f.T_world_base);
+  EXPECT_TRUE(pre);
+  EXPECT_EQ(n_pre, size_t(49));
+  EXPECT_TRUE(ras);
+  EXPECT_EQ(n_ras, size_t(mapper.lastStats().n_cells_touched));
+  EXPECT_GT(n_ras, 0u);
+  EXPECT_FLOAT_EQ(z_ras, 1.0f);
+}
 TEST(FastDEMIntegration, CustomSensorModelSubclass) {  // fastdem.hpp:79-80
   struct Wide : SensorModel {  // user model: 1 m^2 isotropic
     Eigen::Matrix3f computeCovariance(const Eigen::Vector3f&) const override { return Eigen::Matrix3f::Identity() * 0.005f; }

@@ -71,7 +71,7 @@ struct fdm_engine {
   bool want_ids = false;
   bool profile = false;
   bool wave_merge = true;
-  bool dbg_no_atomics = false;
+  int dbg_no_atomics = 0;
   int dbg_upd = 0;
   int bin_variant = 0;  // 0 = by scan size, 4 = k_bin4 (LDS-staged), 1 = k_bin (one point/thread)
   size_t bin_part_cap = 0;   // blocks
@@ -81,6 +81,11 @@ struct fdm_engine {
   std::vector<uint32_t> h_upd_part;
   bool obst_dense_pending = false;  // host wrote the obstacle layer: next scan clears it densely
   bool estimator_ready = false;     // ElevationMapping ctor ran (ensureLayers + obstacle layer)
+  bool cap_pre = false, cap_ras = false;  // scan-callback captures
+  float* d_cap = nullptr;            // 4 channels x cap_cap points
+  size_t cap_cap = 0;
+  float* d_ras = nullptr;            // ncell
+  bool saved_want_ids = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   float last_ms[3] = {0.f, 0.f, 0.f};
 };
@@ -268,6 +273,26 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   if ((rc = ensure_scratch_channels(e, P.has_intensity, P.has_color))) return rc;
   if ((rc = refresh_layer_ptrs(e))) return rc;
   if ((rc = ensure_ids(e, n))) return rc;
+  // scan-callback captures (off unless fdm_engine_capture enabled them)
+  e->S.cap_x = e->S.cap_y = e->S.cap_z = e->S.cap_var = nullptr;
+  e->S.ras_z = nullptr;
+  if (e->cap_pre && n) {
+    if (n > e->cap_cap) {
+      HIPCK(hipStreamSynchronize(e->stream));
+      if (e->d_cap) HIPCK(hipFree(e->d_cap));
+      e->cap_cap = n + n / 4 + 1024;
+      HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_cap), e->cap_cap * 4 * sizeof(float)));
+    }
+    e->S.cap_x = e->d_cap;
+    e->S.cap_y = e->d_cap + e->cap_cap;
+    e->S.cap_z = e->d_cap + 2 * e->cap_cap;
+    e->S.cap_var = e->d_cap + 3 * e->cap_cap;
+  }
+  if (e->cap_ras) {
+    if (!e->d_ras) HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_ras), e->ncell * sizeof(float)));
+    if ((rc = fill_async(e, e->d_ras, NAN, e->ncell))) return rc;
+    e->S.ras_z = e->d_ras;
+  }
 
   // k_bin4 (4 consecutive points per thread, float4 loads) needs 16-byte aligned channels
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
@@ -283,7 +308,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     HIPCK(hipMalloc(reinterpret_cast<void**>(&e->S.bin_part), e->bin_part_cap * sizeof(unsigned long long)));
   }
   e->last_bin_blocks = bin_blocks;
-  P.dbg_no_atomics = e->dbg_no_atomics ? 1 : 0;
+  P.dbg_no_atomics = e->dbg_no_atomics;
   P.dbg_upd = e->dbg_upd;
   if (e->profile) HIPCK(hipEventRecord(e->ev[0], e->stream));
   int32_t* ids = e->want_ids ? e->d_cell_ids : nullptr;
@@ -671,6 +696,8 @@ void fdm_engine_destroy(fdm_engine* e) {
   if (e->h_state) (void)hipHostFree(e->h_state);
   if (e->d_stage) (void)hipFree(e->d_stage);
   if (e->d_cell_ids) (void)hipFree(e->d_cell_ids);
+  if (e->d_cap) (void)hipFree(e->d_cap);
+  if (e->d_ras) (void)hipFree(e->d_ras);
   for (auto& ev : e->ev)
     if (ev) (void)hipEventDestroy(ev);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -941,6 +968,74 @@ int fdm_engine_region_unpack(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, 
   return region_copy(e, r0, c0, nr, nc, names, n_layers, const_cast<float*>(d_buf), 0);
 }
 
+int fdm_engine_capture(fdm_engine* e, int preprocessed, int rasterized) {
+  if (!e) return fail(FDM_ERR_INVALID, "null engine");
+  e->cap_pre = preprocessed != 0;
+  e->cap_ras = rasterized != 0;
+  if (e->cap_pre) e->want_ids = true;  // the per-point pass flag rides on the cell-id buffer
+  return FDM_OK;
+}
+
+int fdm_engine_last_preprocessed(fdm_engine* e, uint64_t cap, float* x, float* y, float* z,
+                                 float* sigma_z2, uint64_t* n_out) {
+  if (!e || !n_out) return fail(FDM_ERR_INVALID, "null argument");
+  *n_out = 0;
+  if (!e->cap_pre) return fail(FDM_ERR_INVALID, "preprocessed-scan capture is off");
+  const size_t n = e->last_n;
+  if (!e->have_scan || n == 0 || !e->d_cap || !e->d_cell_ids) return FDM_OK;
+  HIPCK(hipStreamSynchronize(e->stream));
+  std::vector<float> h(4 * n);
+  std::vector<int32_t> ids(n);
+  for (int c = 0; c < 4; ++c)
+    HIPCK(hipMemcpy(h.data() + c * n, e->d_cap + c * e->cap_cap, n * sizeof(float), hipMemcpyDeviceToHost));
+  HIPCK(hipMemcpy(ids.data(), e->d_cell_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  uint64_t w = 0;
+  for (size_t i = 0; i < n; ++i) {  // order-preserving compaction = marshalling, like filterInPlace
+    if (ids[i] == -1) continue;     // dropped by cropRange / cropZ
+    if (w < cap) {
+      if (x) x[w] = h[i];
+      if (y) y[w] = h[n + i];
+      if (z) z[w] = h[2 * n + i];
+      if (sigma_z2) sigma_z2[w] = h[3 * n + i];
+    }
+    ++w;
+  }
+  *n_out = w;
+  return FDM_OK;
+}
+
+int fdm_engine_last_rasterized(fdm_engine* e, uint64_t cap, float* x, float* y, float* z,
+                               uint64_t* n_out) {
+  if (!e || !n_out) return fail(FDM_ERR_INVALID, "null argument");
+  *n_out = 0;
+  if (!e->cap_ras) return fail(FDM_ERR_INVALID, "rasterized-scan capture is off");
+  if (!e->have_scan || !e->d_ras) return FDM_OK;
+  HIPCK(hipStreamSynchronize(e->stream));
+  std::vector<float> h(e->ncell);
+  HIPCK(hipMemcpy(h.data(), e->d_ras, e->ncell * sizeof(float), hipMemcpyDeviceToHost));
+  fdm_geometry g;
+  if (int rc = fdm_engine_get_geometry(e, &g)) return rc;
+  uint64_t w = 0;
+  const GeomConst& G = e->G;
+  for (size_t o = 0; o < e->ncell; ++o) {
+    if (std::isnan(h[o])) continue;
+    if (w < cap) {
+      const int r = int(o % size_t(G.s_rows)) + G.s_r0, c = int(o / size_t(G.s_rows)) + G.s_c0;
+      int ur = r - g.start_row, uc = c - g.start_col;  // getPositionFromIndex (grid_map_core)
+      if (ur < 0) ur += G.rows;
+      if (uc < 0) uc += G.cols;
+      const double px = g.position_x + (0.5 * G.len_x - 0.5 * G.res) + G.res * double(-ur);
+      const double py = g.position_y + (0.5 * G.len_y - 0.5 * G.res) + G.res * double(-uc);
+      if (x) x[w] = float(px);
+      if (y) y[w] = float(py);
+      if (z) z[w] = h[o];
+    }
+    ++w;
+  }
+  *n_out = w;
+  return FDM_OK;
+}
+
 int fdm_engine_enable_cell_ids(fdm_engine* e, int on) {
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
   e->want_ids = on != 0;
@@ -999,7 +1094,7 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
     return FDM_OK;
   }
   if (std::strcmp(key, "dbg_no_atomics") == 0) {  // measurement only: results are wrong when set
-    e->dbg_no_atomics = value != 0;
+    e->dbg_no_atomics = value;
     return FDM_OK;
   }
   return fail(FDM_ERR_INVALID, std::string("unknown option ") + key);

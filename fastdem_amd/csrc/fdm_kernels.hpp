@@ -48,6 +48,12 @@ struct Scratch {
   uint32_t* imax;                // ord(max non-NaN intensity), 0 = none
   uint32_t* first;               // lowest point index in the cell (intensity NaN-first rule)
   uint32_t* last;                // highest point index in the cell (colour = last point wins)
+  // optional captures for the scan callbacks (null unless fdm_engine_capture enabled them)
+  float* cap_x;                  // [n] map-frame coordinates of every input point
+  float* cap_y;
+  float* cap_z;
+  float* cap_var;                // [n] sigma_z^2 of every input point
+  float* ras_z;                  // [cells] min z observed by this scan (NaN = not observed)
 };
 
 struct KalmanLayers {
@@ -194,8 +200,18 @@ __global__ __launch_bounds__(256) void k_bin4(const ScanParams P, const GeomCons
   bool any_glob = false;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
+    if (P.dbg_no_atomics >= 3) {  // measurement only: loads without the arithmetic
+      cells[j] = (xs[j] + ys[j] + zs[j] == 12345.f) ? 0 : -1;
+      continue;
+    }
     const bool live = i0 + j < P.n;
+    float cvar = 0.f;
+    if (S.cap_var && live && P.integrate_mode) cvar = sigma_z2(P, xs[j], ys[j], zs[j]);
     const bool pass = preprocess_point(P, xs[j], ys[j], zs[j]) && live;
+    if (S.cap_x && live) {
+      S.cap_x[i0 + j] = xs[j]; S.cap_y[i0 + j] = ys[j]; S.cap_z[i0 + j] = zs[j];
+      S.cap_var[i0 + j] = cvar;
+    }
     cells[j] = pass ? owned_cell(xs[j], ys[j], cand, G) : -1;
     n_pass += pass ? 1u : 0u;
     n_in += cells[j] >= 0 ? 1u : 0u;
@@ -208,7 +224,7 @@ __global__ __launch_bounds__(256) void k_bin4(const ScanParams P, const GeomCons
   unsigned long long run_key = kEmptyKey;
   uint32_t run_zmx = 0, run_imx = 0, run_fst = kNoIdx, run_lst = 0;
   auto fold_run = [&]() {
-    if (run_cell < 0) return;
+    if (run_cell < 0 || P.dbg_no_atomics >= 2) return;
     uint32_t h = uint32_t(run_cell) & (kHashSlots - 1);
     while (true) {
       const uint32_t seen = h_cell[h];
@@ -301,7 +317,13 @@ __global__ __launch_bounds__(256) void k_bin(const ScanParams P, const GeomConst
   if (i < P.n) {
     float x = px[i], y = py[i];
     z = pz[i];
+    float cvar = 0.f;
+    if (S.cap_var && P.integrate_mode) cvar = sigma_z2(P, x, y, z);
     pass = preprocess_point(P, x, y, z);
+    if (S.cap_x) {
+      S.cap_x[i] = x; S.cap_y[i] = y; S.cap_z[i] = z;
+      S.cap_var[i] = cvar;
+    }
     if (pass) cell = owned_cell(x, y, cand, G);
     if (cell_ids) cell_ids[i] = cell >= 0 ? cell : (!pass ? -1 : (cell == -2 ? -3 : -2));
   }
@@ -575,6 +597,7 @@ __global__ __launch_bounds__(256) void k_update(
         min_z = z;
       }
       const float max_z = zm ? unord(zm) : -kFltMax;
+      if (S.ras_z) S.ras_z[o] = min_z;
       POLICY::step_store(L, o, stt, min_z, min_z_var);
       if (isnan(smin) || min_z < smin) L.elevation_min[o] = min_z;
       if (isnan(smax) || max_z > smax) L.elevation_max[o] = max_z;

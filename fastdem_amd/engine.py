@@ -203,6 +203,22 @@ class Engine:
         _ck(self._lib.fdm_engine_region_unpack(self._h, r0, c0, nr, nc, arr, len(names),
                                                C.c_void_p(dbuf_ptr)))
 
+    # -- scan callbacks --
+    def capture(self, preprocessed=True, rasterized=True):
+        _ck(self._lib.fdm_engine_capture(self._h, int(preprocessed), int(rasterized)))
+
+    def last_preprocessed(self, cap):
+        a = [np.empty(cap, dtype=np.float32) for _ in range(4)]
+        n = C.c_uint64(0)
+        _ck(self._lib.fdm_engine_last_preprocessed(self._h, cap, *[_ptr(v) for v in a], C.byref(n)))
+        return [v[:n.value] for v in a]
+
+    def last_rasterized(self, cap):
+        a = [np.empty(cap, dtype=np.float32) for _ in range(3)]
+        n = C.c_uint64(0)
+        _ck(self._lib.fdm_engine_last_rasterized(self._h, cap, *[_ptr(v) for v in a], C.byref(n)))
+        return [v[:n.value] for v in a]
+
     # -- instrumentation --
     def enable_cell_ids(self, on=True):
         _ck(self._lib.fdm_engine_enable_cell_ids(self._h, int(on)))

@@ -161,6 +161,21 @@ int fdm_engine_region_pack(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, in
 int fdm_engine_region_unpack(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, int32_t nc,
                              const char* const* names, int n_layers, const float* d_buf);
 
+/* Scan callbacks of the reference (fastdem.hpp:129-136, fastdem.cpp:139-150): when enabled the
+ * kernels also keep (a) every point in the map frame + whether it survived the crops and (b) the
+ * min-z observation of every observed cell.
+ *   last_preprocessed: the cloud handed to onScanPreprocessed — points that survived cropRange and
+ *     cropZ, in input order, map frame, with sigma_z2 = cov(2,2) (nullable).
+ *   last_rasterized:   the cloud handed to onScanRasterized — one point per observed cell at the
+ *     cell centre (GridMap::getPosition) with z = min_z (fastdem.cpp:200-214); order unspecified,
+ *     as in the reference (hash-map iteration order).
+ * Both return the number of points through n_out; `cap` is the capacity of the output arrays. */
+int fdm_engine_capture(fdm_engine* e, int preprocessed, int rasterized);
+int fdm_engine_last_preprocessed(fdm_engine* e, uint64_t cap, float* x, float* y, float* z,
+                                 float* sigma_z2, uint64_t* n_out);
+int fdm_engine_last_rasterized(fdm_engine* e, uint64_t cap, float* x, float* y, float* z,
+                               uint64_t* n_out);
+
 /* Parity / measurement instrumentation (not in the reference). */
 int fdm_engine_enable_cell_ids(fdm_engine* e, int on);
 /* per input point of the last scan: linear cell id (col*rows+row), -1 cropped, -2 outside map */

@@ -87,6 +87,11 @@ int fdmref_layer_add(void* e, const char* name, float value);
 int fdmref_clear(void* e, const char* name /* NULL = all */);
 int fdmref_last_cell_ids(void* e, int32_t* out, uint64_t n);
 
+/* scan callbacks: keep the preprocessed cloud / rasterized observations of the last integrate() */
+void fdmref_keep_scan(void* e, int on);
+uint64_t fdmref_last_preprocessed(void* e, uint64_t cap, float* x, float* y, float* z, float* var);
+uint64_t fdmref_last_rasterized(void* e, uint64_t cap, float* x, float* y, float* z);
+
 /* unit-level entry points for the reference's known-answer tests */
 void fdmref_sensor_covariance(const fdmref_config* cfg, const float* p3, float* cov9_colmajor);
 /* state8 = {x, P, count, sample_mean, sample_var, m2, upper, lower} */

@@ -463,6 +463,9 @@ class Engine {
   std::vector<int32_t> last_cell_ids;  // per INPUT point: linear id, -1 cropped, -2 outside map
   bool time_stages = false;
   StageTimes times;
+  bool keep_scan = false;             // parity bookkeeping for the scan callbacks
+  Cloud last_preprocessed;            // what on_preprocessed_ receives (fastdem.cpp:139-141)
+  std::vector<std::array<float, 3>> last_rasterized;  // toPointCloud(obs) (fastdem.cpp:200-214)
 
   // FastDEM::integrate(cloud, T_base_sensor, T_world_base)  (fastdem.cpp:122-162)
   Status integrate(const Cloud& cloud, const double* T_bs, const double* T_wb, ScanStats* st) {
@@ -479,8 +482,17 @@ class Engine {
       if (st) *st = s;
       return SKIP_ALL_FILTERED;
     }
+    if (keep_scan) last_preprocessed = points;
     // robot_position = T_world_base.translation().head<2>()
-    update(points, T_wb[12], T_wb[13], &s);
+    const auto obs = update(points, T_wb[12], T_wb[13], &s);
+    if (keep_scan) {
+      last_rasterized.clear();
+      for (const auto& [index, cell] : obs) {  // FastDEM::toPointCloud
+        double px = 0.0, py = 0.0;
+        map_.getPosition(index, px, py);
+        last_rasterized.push_back({float(px), float(py), cell.min_z});
+      }
+    }
     if (st) *st = s;
     return OK;
   }

@@ -191,6 +191,27 @@ int fdmref_last_cell_ids(void* e, int32_t* out, uint64_t n) {
   return 0;
 }
 
+void fdmref_keep_scan(void* e, int on) { E(e)->keep_scan = on != 0; }
+uint64_t fdmref_last_preprocessed(void* e, uint64_t cap, float* x, float* y, float* z, float* var) {
+  const Cloud& c = E(e)->last_preprocessed;
+  for (uint64_t i = 0; i < c.size() && i < cap; ++i) {
+    x[i] = c.pts[i][0];
+    y[i] = c.pts[i][1];
+    z[i] = c.pts[i][2];
+    if (var) var[i] = M3(c.cov[i], 2, 2);
+  }
+  return c.size();
+}
+uint64_t fdmref_last_rasterized(void* e, uint64_t cap, float* x, float* y, float* z) {
+  const auto& r = E(e)->last_rasterized;
+  for (uint64_t i = 0; i < r.size() && i < cap; ++i) {
+    x[i] = r[i][0];
+    y[i] = r[i][1];
+    z[i] = r[i][2];
+  }
+  return r.size();
+}
+
 void fdmref_sensor_covariance(const fdmref_config* cfg, const float* p3, float* cov9) {
   const Mat3f m = sensorCovariance(toConfig(cfg), p3);
   std::memcpy(cov9, m.data(), sizeof(float) * 9);

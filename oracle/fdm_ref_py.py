@@ -109,6 +109,11 @@ def load(native=False):
     lib.fdmref_clear.argtypes = [P, C.c_char_p]
     lib.fdmref_last_cell_ids.restype = C.c_int
     lib.fdmref_last_cell_ids.argtypes = [P, P, C.c_uint64]
+    lib.fdmref_keep_scan.argtypes = [P, C.c_int]
+    lib.fdmref_last_preprocessed.restype = C.c_uint64
+    lib.fdmref_last_preprocessed.argtypes = [P, C.c_uint64, P, P, P, P]
+    lib.fdmref_last_rasterized.restype = C.c_uint64
+    lib.fdmref_last_rasterized.argtypes = [P, C.c_uint64, P, P, P]
     lib.fdmref_sensor_covariance.argtypes = [C.POINTER(RefConfig), P, P]
     lib.fdmref_kalman_update.argtypes = [C.c_float, C.c_float, C.c_float, P, C.c_float, C.c_float,
                                          C.c_int]
@@ -264,6 +269,19 @@ class RefEngine:
 
     def clear(self, name=None):
         self._lib.fdmref_clear(self._h, None if name is None else name.encode())
+
+    def capture(self, on=True):
+        self._lib.fdmref_keep_scan(self._h, int(on))
+
+    def last_preprocessed(self, cap):
+        a = [np.empty(cap, dtype=np.float32) for _ in range(4)]
+        n = self._lib.fdmref_last_preprocessed(self._h, cap, *[_ptr(v) for v in a])
+        return [v[:n] for v in a]
+
+    def last_rasterized(self, cap):
+        a = [np.empty(cap, dtype=np.float32) for _ in range(3)]
+        n = self._lib.fdmref_last_rasterized(self._h, cap, *[_ptr(v) for v in a])
+        return [v[:n] for v in a]
 
     def enable_cell_ids(self, on=True):
         self._lib.fdmref_track_ids(self._h, int(on))

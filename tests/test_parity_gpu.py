@@ -466,3 +466,27 @@ def test_tiled_engines_with_halo_exchange_match_single_map(gpu, R):
         st = p.stored
         for n in names:
             assert_arrays_close(e.layer(n), whole.layer(n)[st.r0:st.r1, st.c0:st.c1], n, 0.0, 0.0)
+
+
+@pytest.mark.parametrize("big", [False, True])
+def test_scan_callback_clouds_match_the_reference(gpu, R, big):
+    """onScanPreprocessed / onScanRasterized payloads (fastdem.cpp:139-150, 200-214): the
+    preprocessed cloud is bit-identical in input order incl. cov(2,2); the rasterized cloud is the
+    same SET of (cell centre, min_z) points (the reference's order is hash-map order)."""
+    wl = gpu.synth.lidar128(n_scans=3, n_az=1024) if big else gpu.synth.vlp16(n_scans=3)
+    eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
+    eng.capture(True, True)
+    ref.capture(True)
+    for k in range(3):
+        run_both(eng, ref, wl.scan(k), wl.T_base_sensor, wl.pose(k))
+        n = wl.n_points
+        pe, pr = eng.last_preprocessed(n), ref.last_preprocessed(n)
+        assert pe[0].size == pr[0].size > 0
+        for a, b, name in zip(pe, pr, "xyzv"):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"preprocessed {name} differs"
+        re_, rr = eng.last_rasterized(eng.rows * eng.cols), ref.last_rasterized(eng.rows * eng.cols)
+        assert re_[0].size == rr[0].size == eng.last_stats()[1]["n_cells_touched"]
+        se = sorted(zip(*[v.tolist() for v in re_]))
+        sr = sorted(zip(*[v.tolist() for v in rr]))
+        assert se == sr
+    assert_layers_equal(eng, ref)
