@@ -167,7 +167,17 @@ def cpu_baseline(wl, target_s=12.0):
     except OSError:
         pass
     names = ["sensor_cov", "transform_filter", "cov_transform", "rasterize", "map_update"]
+    # courtesy row: the same source built with -march=native
+    native = None
+    try:
+        rn = R.RefEngine(wl.width, wl.height, wl.resolution, wl.apply_to(R.default_config()), native=True)
+        rn.time_integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, poses, 5, **kw)
+        it2 = max(5, iters // 4)
+        native = n * it2 / rn.time_integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, poses, it2, **kw) / 1e6
+    except Exception:
+        pass
     return {"value": n * iters / dt / 1e6, "unit": "Mpts/s", "cores": 1, "kind": "port",
+            "march_native_value": native,
             "ms_per_scan": dt / iters * 1e3,
             "sample": f"{iters} integrate() calls of the {n}-pt scan ({dt:.1f} s), "
                       f"oracle/libfdm_ref.so -O3 no -march, 1 thread",

@@ -456,7 +456,7 @@ struct KalmanPolicy {
     t.s.P = L.kalman_p[o];
     t.s.count = L.n_points[o];
     t.s.mean = L.sample_mean[o];
-    t.s.var = L.variance[o];
+    t.s.var = 0.0f;  // write-only: Kalman::update always overwrites the sample variance
     t.s.m2 = L.sample_m2[o];
   }
   static __device__ __forceinline__ void set_nan(State& t) {

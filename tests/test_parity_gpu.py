@@ -490,3 +490,31 @@ def test_scan_callback_clouds_match_the_reference(gpu, R, big):
         sr = sorted(zip(*[v.tolist() for v in rr]))
         assert se == sr
     assert_layers_equal(eng, ref)
+
+
+def test_engine_on_a_caller_provided_stream(gpu, R):
+    """fdm_engine_set_stream: the engine enqueues on the caller's HIP stream (here a torch stream),
+    so torch.cuda events on that stream bracket its kernels and results are unchanged."""
+    import torch
+    wl = gpu.synth.vlp16(n_scans=2)
+    eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
+    stream = torch.cuda.Stream()
+    eng.set_stream(stream.cuda_stream)
+    dev = [{k: (torch.from_numpy(v).cuda() if v is not None else None) for k, v in s.items()} for s in wl.scans]
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        e0.record()
+        for k in range(6):
+            d = dev[k % 2]
+            eng.integrate_device(d["x"], d["y"], d["z"], wl.T_base_sensor, wl.pose(k), intensity=d["intensity"])
+        e1.record()
+    stream.synchronize()
+    assert 0.0 < e0.elapsed_time(e1) < 50.0
+    for k in range(6):
+        s = wl.scan(k)
+        ref.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k), intensity=s["intensity"])
+    assert_layers_equal(eng, ref)
+    eng.set_stream(0)  # back to the engine's own stream
+    run_both(eng, ref, wl.scan(0), wl.T_base_sensor, wl.pose(6))
+    assert_layers_equal(eng, ref)
