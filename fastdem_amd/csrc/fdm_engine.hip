@@ -73,6 +73,7 @@ struct fdm_engine {
   bool wave_merge = true;
   int dbg_no_atomics = 0;
   int dbg_upd = 0;
+  int bin_threads = 256;             // k_bin4 block size (128 / 256 / 512): 4 points per thread
   int bin_variant = 0;  // 0 = by scan size, 4 = k_bin4 (LDS-staged), 1 = k_bin (one point/thread)
   size_t bin_part_cap = 0;   // blocks
   unsigned last_bin_blocks = 0;
@@ -299,7 +300,8 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   // k_bin4 trades latency for fewer memory-side atomics: worth it from ~64 K points up
   const bool want4 = e->bin_variant == 4 || (e->bin_variant == 0 && n >= 65536);
   const bool use_bin4 = want4 && al16(dx) && al16(dy) && al16(dz) && al16(dint);
-  const unsigned per_block = use_bin4 ? 1024u : 256u;
+  const unsigned bin_threads = use_bin4 ? unsigned(e->bin_threads) : 256u;
+  const unsigned per_block = use_bin4 ? bin_threads * 4u : 256u;
   const unsigned bin_blocks = n ? unsigned((n + per_block - 1) / per_block) : 1u;
   if (bin_blocks > e->bin_part_cap) {
     HIPCK(hipStreamSynchronize(e->stream));
@@ -315,13 +317,18 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   if (use_bin4) {
     const bool hi = P.has_intensity != 0, hc = P.has_color != 0;
     auto launch4 = [&](auto kern) {
-      hipLaunchKernelGGL(kern, dim3(bin_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state, dx, dy,
-                         dz, dint, e->S, ids);
+      hipLaunchKernelGGL(kern, dim3(bin_blocks), dim3(bin_threads), 0, e->stream, P, e->G, e->d_state, dx,
+                         dy, dz, dint, e->S, ids);
     };
-    if (hi && hc) launch4(k_bin4<true, true>);
-    else if (hi) launch4(k_bin4<true, false>);
-    else if (hc) launch4(k_bin4<false, true>);
-    else launch4(k_bin4<false, false>);
+#define FDM_BIN4(T)                                         \
+    if (hi && hc) launch4(k_bin4<true, true, T>);           \
+    else if (hi) launch4(k_bin4<true, false, T>);           \
+    else if (hc) launch4(k_bin4<false, true, T>);           \
+    else launch4(k_bin4<false, false, T>);
+    if (bin_threads == 128) { FDM_BIN4(128) }
+    else if (bin_threads == 512) { FDM_BIN4(512) }
+    else { FDM_BIN4(256) }
+#undef FDM_BIN4
   } else {
     auto launch_bin = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(bin_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state, dx, dy,
@@ -1077,6 +1084,11 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
   if (!e || !key) return fail(FDM_ERR_INVALID, "null argument");
   if (std::strcmp(key, "wave_merge") == 0) {
     e->wave_merge = value != 0;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "bin_threads") == 0) {
+    if (value != 128 && value != 256 && value != 512) return fail(FDM_ERR_INVALID, "bin_threads must be 128, 256 or 512");
+    e->bin_threads = value;
     return FDM_OK;
   }
   if (std::strcmp(key, "bin_variant") == 0) {

@@ -139,17 +139,17 @@ __device__ __forceinline__ DevCand block_candidate(const ScanParams& P, const Ge
 // ---------------------------------------------------------------------------------------------
 // k_bin4 — production bin kernel for large scans: 1024 consecutive points per 256-thread block,
 // four CONSECUTIVE points per thread (dwordx4 loads).
-constexpr int kHashSlots = 1024;  // == points per block: enough for every point in its own cell
 constexpr uint32_t kEmptyCell = 0xFFFFFFFFu;
 
-template <bool HAS_INT, bool HAS_COL>
-__global__ __launch_bounds__(256) void k_bin4(const ScanParams P, const GeomConst G,
+template <bool HAS_INT, bool HAS_COL, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_bin4(const ScanParams P, const GeomConst G,
                                               DevState* __restrict__ st,
                                               const float* __restrict__ px,
                                               const float* __restrict__ py,
                                               const float* __restrict__ pz,
                                               const float* __restrict__ pint, const Scratch S,
                                               int32_t* __restrict__ cell_ids) {
+  constexpr int kHashSlots = THREADS * 4;  // == points per block: room for every point in its own cell
   __shared__ unsigned long long h_key[kHashSlots];
   __shared__ uint32_t h_cell[kHashSlots];
   __shared__ uint32_t h_zmax[kHashSlots];
@@ -157,11 +157,11 @@ __global__ __launch_bounds__(256) void k_bin4(const ScanParams P, const GeomCons
   __shared__ uint32_t h_first[HAS_INT ? kHashSlots : 1];
   __shared__ uint32_t h_last[HAS_COL ? kHashSlots : 1];
   __shared__ DevCand s_cand;
-  __shared__ unsigned s_cnt[4];
+  __shared__ unsigned s_cnt[THREADS / 64];
 
   // the point loads go out first: they are in flight while the table is initialised and
   // thread 0 works out the post-move geometry
-  const unsigned i0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+  const unsigned i0 = (blockIdx.x * unsigned(THREADS) + threadIdx.x) * 4u;
   float xs[4], ys[4], zs[4], vs[4];
   if (i0 + 3 < P.n) {
     const float4 a = *reinterpret_cast<const float4*>(px + i0);
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_bin4(const ScanParams P, const GeomCons
     }
   }
 
-  for (int k = threadIdx.x; k < kHashSlots; k += 256) {
+  for (int k = threadIdx.x; k < kHashSlots; k += THREADS) {
     h_key[k] = kEmptyKey;
     h_cell[k] = kEmptyCell;
     h_zmax[k] = 0u;
@@ -277,8 +277,8 @@ __global__ __launch_bounds__(256) void k_bin4(const ScanParams P, const GeomCons
   // phase 3: one global atomic set per unique cell of the block
   if (!P.dbg_no_atomics) {
 #pragma unroll
-    for (int q = 0; q < kHashSlots / 256; ++q) {
-      const int k = threadIdx.x + q * 256;
+    for (int q = 0; q < kHashSlots / THREADS; ++q) {
+      const int k = threadIdx.x + q * THREADS;
       const uint32_t cell = h_cell[k];
       if (cell == kEmptyCell) continue;
       scratch_merge<HAS_INT, HAS_COL>(S, P.scan_no, cell, h_key[k], h_zmax[k],
@@ -287,8 +287,8 @@ __global__ __launch_bounds__(256) void k_bin4(const ScanParams P, const GeomCons
     }
   }
   if (threadIdx.x == 0) {
-    const unsigned tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    const unsigned np = tot & 0xFFFFu, ni = tot >> 16;
+    unsigned np = 0, ni = 0;
+    for (int w = 0; w < THREADS / 64; ++w) { np += s_cnt[w] & 0xFFFFu; ni += s_cnt[w] >> 16; }
     if (np) st->flags[P.slot].any_pass = 1u;
     S.bin_part[blockIdx.x] = (unsigned long long)np | ((unsigned long long)ni << 32);
   }

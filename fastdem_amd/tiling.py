@@ -153,6 +153,11 @@ class EngineTile:
         """Packed buffers are produced on the engine's stream, consumed by the collective."""
         self.eng.sync()
 
+    def after_comm(self):
+        """NCCL/RCCL `wait()` orders the CURRENT TORCH STREAM after the transfer, not the host and
+        not the engine's stream: drain it before the unpack kernels are enqueued on the engine."""
+        self.torch.cuda.current_stream().synchronize()
+
 
 def exchange_halos(tile, plan: TilePlan, names: Sequence[str], dist, group=None):
     """One halo exchange: post every irecv/isend of the plan, wait, unpack."""
@@ -172,6 +177,8 @@ def exchange_halos(tile, plan: TilePlan, names: Sequence[str], dist, group=None)
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+    if hasattr(tile, "after_comm"):
+        tile.after_comm()
     for other, buf in recv_bufs.items():
         tile.unpack(plan.recvs[other], names, buf)
     return nbytes
