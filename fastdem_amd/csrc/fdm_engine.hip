@@ -39,9 +39,19 @@ int fail(int code, const std::string& msg) {
 
 struct Layer {
   std::string name;
-  float* d = nullptr;
+  float* d = nullptr;    // own array (stride 1), or nullptr when the layer is a record field
+  int field = -1;        // index inside the cell record, -1 = own array
   bool pending = false;  // allocated, but not yet visible (lazy intensity / colour layers)
 };
+
+// field order inside the cell records (KalmanField / P2Field in fdm_kernels.hpp)
+const char* const kKalmanFields[KF_COUNT] = {"elevation", "elevation_min", "elevation_max", "variance",
+                                             "n_points", "_kalman_p", "_sample_mean", "_sample_m2",
+                                             "upper_bound", "lower_bound"};
+const char* const kP2Fields[PF_COUNT] = {"elevation", "elevation_min", "elevation_max", "variance",
+                                         "n_points", "_p2_q0", "_p2_q1", "_p2_q2", "_p2_q3", "_p2_q4",
+                                         "_p2_n0", "_p2_n1", "_p2_n2", "_p2_n3", "_p2_n4",
+                                         "upper_bound", "lower_bound"};
 
 }  // namespace
 
@@ -82,6 +92,11 @@ struct fdm_engine {
   std::vector<uint32_t> h_upd_part;
   bool obst_dense_pending = false;  // host wrote the obstacle layer: next scan clears it densely
   bool estimator_ready = false;     // ElevationMapping ctor ran (ensureLayers + obstacle layer)
+  bool use_records = true;          // pack the active estimator's state into cell records
+  float* d_rec = nullptr;           // [ncell][rec_floats]
+  int rec_kind = -1;                // -1 none, 0 Kalman, 1 P2
+  int rec_floats = 0;
+  float* d_tmp = nullptr;           // ncell floats: contiguous staging for strided layer transfers
   bool cap_pre = false, cap_ras = false;  // scan-callback captures
   float* d_cap = nullptr;            // 4 channels x cap_cap points
   size_t cap_cap = 0;
@@ -99,18 +114,32 @@ Layer* find_layer(fdm_engine* e, const char* name) {
   return nullptr;
 }
 
-int fill_async(fdm_engine* e, float* p, float v, size_t n) {
+// A layer as the kernels see it: base pointer + element stride (1, or the record size).
+float* lptr(fdm_engine* e, const Layer& l) { return l.field >= 0 ? e->d_rec + l.field : l.d; }
+int lstride(fdm_engine* e, const Layer& l) { return l.field >= 0 ? e->rec_floats : 1; }
+
+int fill_async(fdm_engine* e, float* p, float v, size_t n, int stride = 1) {
   if (n == 0) return FDM_OK;
   const int blocks = int(std::min<size_t>((n + 255) / 256, 4096));
-  hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, e->stream, p, v, n);
+  hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, e->stream, p, v, n, stride);
   HIPCK(hipGetLastError());
+  return FDM_OK;
+}
+int copy_strided(fdm_engine* e, float* dst, int ds, const float* src, int ss) {
+  const int blocks = int(std::min<size_t>((e->ncell + 255) / 256, 4096));
+  hipLaunchKernelGGL(k_copy_strided, dim3(blocks), dim3(256), 0, e->stream, dst, ds, src, ss, e->ncell);
+  HIPCK(hipGetLastError());
+  return FDM_OK;
+}
+int ensure_tmp(fdm_engine* e) {
+  if (!e->d_tmp) HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_tmp), e->ncell * sizeof(float)));
   return FDM_OK;
 }
 
 int add_layer(fdm_engine* e, const char* name, float value, bool pending = false) {
   if (Layer* l = find_layer(e, name)) {  // GridMap::add on an existing layer overwrites it
     l->pending = l->pending && pending;
-    return fill_async(e, l->d, value, e->ncell);
+    return fill_async(e, lptr(e, *l), value, e->ncell, lstride(e, *l));
   }
   if (e->layers.size() >= size_t(kMaxLayers)) return fail(FDM_ERR_INVALID, "too many layers (max 64)");
   Layer l;
@@ -132,6 +161,8 @@ int ensure_layer(fdm_engine* e, const char* name, float value) {
 
 const char* kP2Q[5] = {"_p2_q0", "_p2_q1", "_p2_q2", "_p2_q3", "_p2_q4"};
 const char* kP2N[5] = {"_p2_n0", "_p2_n1", "_p2_n2", "_p2_n3", "_p2_n4"};
+
+int activate_records(fdm_engine* e, int kind);
 
 // ElevationMapping ctor (elevation_mapping.cpp:11-39) + Kalman/P2 ensureLayers
 // (kalman_estimation.hpp:64-82, quantile_estimation.hpp:97-115): add what is missing.
@@ -155,19 +186,23 @@ int ensure_estimator_layers(fdm_engine* e) {
     if ((rc = ensure_layer(e, "upper_bound", NAN))) return rc;
     if ((rc = ensure_layer(e, "lower_bound", NAN))) return rc;
   }
-  return ensure_layer(e, "obstacle", NAN);
+  if ((rc = ensure_layer(e, "obstacle", NAN))) return rc;
+  return activate_records(e, e->cfg.estimation_type == 1 ? 1 : 0);
 }
 
 int refresh_layer_ptrs(fdm_engine* e) {
   if (!e->layer_ptrs_dirty) return FDM_OK;
   std::vector<float*> ptrs;
-  for (auto& l : e->layers) ptrs.push_back(l.d);
+  for (auto& l : e->layers)
+    if (l.field < 0) ptrs.push_back(l.d);  // record fields are cleared with the record
+  if (ptrs.empty()) ptrs.push_back(nullptr);
   // the old array may still be referenced by an in-flight kernel: drain first
   HIPCK(hipStreamSynchronize(e->stream));
   if (e->d_layer_ptrs) HIPCK(hipFree(e->d_layer_ptrs));
   HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_layer_ptrs), ptrs.size() * sizeof(float*)));
   HIPCK(hipMemcpy(e->d_layer_ptrs, ptrs.data(), ptrs.size() * sizeof(float*), hipMemcpyHostToDevice));
-  e->n_layer_ptrs = int(ptrs.size());
+  e->n_layer_ptrs = 0;
+  for (auto& l : e->layers) e->n_layer_ptrs += l.field < 0 ? 1 : 0;
   e->layer_ptrs_dirty = false;
   return FDM_OK;
 }
@@ -235,6 +270,53 @@ int ensure_scratch_channels(fdm_engine* e, bool intensity, bool color) {
 float* L(fdm_engine* e, const char* n) {
   Layer* l = find_layer(e, n);
   return l ? l->d : nullptr;
+}
+
+// ---- cell records: (de)activate the packed layout for the active estimator ----
+// Leaving the record layout: every field goes back to its own array.
+int deactivate_records(fdm_engine* e) {
+  if (e->rec_kind < 0) return FDM_OK;
+  for (auto& l : e->layers) {
+    if (l.field < 0) continue;
+    float* own = nullptr;
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&own), e->ncell * sizeof(float)));
+    if (int rc = copy_strided(e, own, 1, e->d_rec + l.field, e->rec_floats)) return rc;
+    l.d = own;
+    l.field = -1;
+  }
+  HIPCK(hipStreamSynchronize(e->stream));
+  HIPCK(hipFree(e->d_rec));
+  e->d_rec = nullptr;
+  e->rec_kind = -1;
+  e->rec_floats = 0;
+  e->layer_ptrs_dirty = true;
+  return FDM_OK;
+}
+// Entering it: the estimator's layers (which must all exist) are gathered into the records.
+int activate_records(fdm_engine* e, int kind) {
+  if (!e->use_records) return deactivate_records(e);
+  if (e->rec_kind == kind) return FDM_OK;
+  if (int rc = deactivate_records(e)) return rc;
+  const int nf = kind == 1 ? int(PF_COUNT) : int(KF_COUNT);
+  const char* const* names = kind == 1 ? kP2Fields : kKalmanFields;
+  e->rec_floats = kind == 1 ? kP2Rec : kKalmanRec;
+  HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_rec), e->ncell * size_t(e->rec_floats) * sizeof(float)));
+  if (int rc = fill_async(e, e->d_rec, NAN, e->ncell * size_t(e->rec_floats))) return rc;  // padding too
+  for (int f = 0; f < nf; ++f) {
+    Layer* l = find_layer(e, names[f]);
+    if (!l) return fail(FDM_ERR_NO_LAYER, std::string("estimator layer missing: ") + names[f]);
+    if (int rc = copy_strided(e, e->d_rec + f, e->rec_floats, l->d, 1)) return rc;
+  }
+  HIPCK(hipStreamSynchronize(e->stream));
+  for (int f = 0; f < nf; ++f) {
+    Layer* l = find_layer(e, names[f]);
+    HIPCK(hipFree(l->d));
+    l->d = nullptr;
+    l->field = f;
+  }
+  e->rec_kind = kind;
+  e->layer_ptrs_dirty = true;
+  return FDM_OK;
 }
 
 // One scan = k_bin + k_update on the stream.  All pointers are device pointers.
@@ -347,7 +429,35 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     e->obst_dense_pending = false;
   }
   const unsigned upd_blocks = e->n_tiles;  // one block per map tile
-  if (e->cfg.estimation_type == 1) {
+  // P2Quantile ctor (quantile_estimation.hpp:84-95): clamp, then enforce monotone dn
+  P2Params p2{};
+  {
+    auto clamp01 = [](float v) { return v < 0.f ? 0.f : (1.f < v ? 1.f : v); };
+    for (int k = 0; k < 5; ++k) p2.dn[k] = clamp01(e->cfg.p2_dn[k]);
+    for (int k = 1; k < 5; ++k) p2.dn[k] = std::max(p2.dn[k], p2.dn[k - 1]);
+    p2.marker = std::min(std::max(e->cfg.p2_elevation_marker, 0), 4);
+    p2.max_count = std::max(e->cfg.p2_max_sample_count, 0.0f);
+  }
+  auto launch_upd = [&](auto kern, const auto& layers) {
+    hipLaunchKernelGGL(kern, dim3(upd_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state, layers,
+                       e->d_layer_ptrs, e->n_layer_ptrs, e->S, dx, dy, dz, dint, drgb, dvar,
+                       unsigned(e->ncell));
+  };
+  const bool p2mode = e->cfg.estimation_type == 1;
+  if (e->rec_kind >= 0) {  // cell records
+    if (p2mode) {
+      P2RecLayers Lr{};
+      Lr.rec = e->d_rec; Lr.obstacle = L(e, "obstacle"); Lr.intensity = L(e, "intensity"); Lr.color = L(e, "color");
+      Lr.p = p2;
+      launch_upd(k_update<P2RecPolicy>, Lr);
+    } else {
+      KalmanRecLayers Lr{};
+      Lr.rec = e->d_rec; Lr.obstacle = L(e, "obstacle"); Lr.intensity = L(e, "intensity"); Lr.color = L(e, "color");
+      Lr.min_var = e->cfg.kalman_min_variance; Lr.max_var = e->cfg.kalman_max_variance;
+      Lr.q = e->cfg.kalman_process_noise;
+      launch_upd(k_update<KalmanRecPolicy>, Lr);
+    }
+  } else if (p2mode) {
     P2Layers Lp{};
     Lp.elevation = L(e, "elevation");
     Lp.elevation_min = L(e, "elevation_min");
@@ -363,15 +473,8 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
       Lp.q[k] = L(e, kP2Q[k]);
       Lp.n[k] = L(e, kP2N[k]);
     }
-    // P2Quantile ctor (quantile_estimation.hpp:84-95): clamp, then enforce monotone dn
-    auto clamp01 = [](float v) { return v < 0.f ? 0.f : (1.f < v ? 1.f : v); };
-    for (int k = 0; k < 5; ++k) Lp.p.dn[k] = clamp01(e->cfg.p2_dn[k]);
-    for (int k = 1; k < 5; ++k) Lp.p.dn[k] = std::max(Lp.p.dn[k], Lp.p.dn[k - 1]);
-    Lp.p.marker = std::min(std::max(e->cfg.p2_elevation_marker, 0), 4);
-    Lp.p.max_count = std::max(e->cfg.p2_max_sample_count, 0.0f);
-    hipLaunchKernelGGL(k_update<P2Policy>, dim3(upd_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state,
-                       Lp, e->d_layer_ptrs, e->n_layer_ptrs, e->S, dx, dy, dz, dint, drgb, dvar,
-                       unsigned(e->ncell));
+    Lp.p = p2;
+    launch_upd(k_update<P2Policy>, Lp);
   } else {
     KalmanLayers Lk{};
     Lk.elevation = L(e, "elevation");
@@ -390,9 +493,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     Lk.min_var = e->cfg.kalman_min_variance;
     Lk.max_var = e->cfg.kalman_max_variance;
     Lk.q = e->cfg.kalman_process_noise;
-    hipLaunchKernelGGL(k_update<KalmanPolicy>, dim3(upd_blocks), dim3(256), 0, e->stream, P, e->G,
-                       e->d_state, Lk, e->d_layer_ptrs, e->n_layer_ptrs, e->S, dx, dy, dz, dint, drgb,
-                       dvar, unsigned(e->ncell));
+    launch_upd(k_update<KalmanPolicy>, Lk);
   }
   HIPCK(hipGetLastError());
   if (e->profile) {
@@ -690,6 +791,8 @@ void fdm_engine_destroy(fdm_engine* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (auto& l : e->layers)
     if (l.d) (void)hipFree(l.d);
+  if (e->d_rec) (void)hipFree(e->d_rec);
+  if (e->d_tmp) (void)hipFree(e->d_tmp);
   if (e->d_layer_ptrs) (void)hipFree(e->d_layer_ptrs);
   if (e->S.key) (void)hipFree(e->S.key);
   if (e->S.zmax) (void)hipFree(e->S.zmax);
@@ -910,7 +1013,13 @@ int fdm_engine_layer_download(fdm_engine* e, const char* name, float* host, int3
   if (int rc = resolve_pending(e)) return rc;
   Layer* l = find_layer(e, name);
   if (!l || l->pending) return fail(FDM_ERR_NO_LAYER, std::string("no layer ") + name);
-  HIPCK(hipMemcpyAsync(host, l->d, e->ncell * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  const float* src = l->d;
+  if (l->field >= 0) {  // record field: gather into a contiguous staging array first
+    if (int rc = ensure_tmp(e)) return rc;
+    if (int rc = copy_strided(e, e->d_tmp, 1, lptr(e, *l), lstride(e, *l))) return rc;
+    src = e->d_tmp;
+  }
+  HIPCK(hipMemcpyAsync(host, src, e->ncell * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   HIPCK(hipStreamSynchronize(e->stream));
   return FDM_OK;
 }
@@ -926,7 +1035,13 @@ int fdm_engine_layer_upload(fdm_engine* e, const char* name, const float* host, 
   }
   l->pending = false;
   if (std::strcmp(name, "obstacle") == 0) e->obst_dense_pending = true;
-  HIPCK(hipMemcpyAsync(l->d, host, e->ncell * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  if (l->field >= 0) {
+    if (int rc = ensure_tmp(e)) return rc;
+    HIPCK(hipMemcpyAsync(e->d_tmp, host, e->ncell * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    if (int rc = copy_strided(e, lptr(e, *l), lstride(e, *l), e->d_tmp, 1)) return rc;
+  } else {
+    HIPCK(hipMemcpyAsync(l->d, host, e->ncell * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  }
   HIPCK(hipStreamSynchronize(e->stream));
   return FDM_OK;
 }
@@ -934,7 +1049,7 @@ int fdm_engine_layer_upload(fdm_engine* e, const char* name, const float* host, 
 float* fdm_engine_layer_device_ptr(fdm_engine* e, const char* name) {
   if (!e || !name) return nullptr;
   Layer* l = find_layer(e, name);
-  return l ? l->d : nullptr;
+  return (l && l->field < 0) ? l->d : nullptr;  // record fields have no contiguous array
 }
 
 int fdm_engine_clear(fdm_engine* e, const char* name) {
@@ -943,10 +1058,10 @@ int fdm_engine_clear(fdm_engine* e, const char* name) {
   if (name) {
     Layer* l = find_layer(e, name);
     if (!l || l->pending) return fail(FDM_ERR_NO_LAYER, std::string("no layer ") + name);
-    return fill_async(e, l->d, NAN, e->ncell);
+    return fill_async(e, lptr(e, *l), NAN, e->ncell, lstride(e, *l));
   }
   for (auto& l : e->layers)
-    if (int rc = fill_async(e, l.d, NAN, e->ncell)) return rc;
+    if (int rc = fill_async(e, lptr(e, l), NAN, e->ncell, lstride(e, l))) return rc;
   return FDM_OK;
 }
 
@@ -959,8 +1074,8 @@ static int region_copy(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, int32_
   for (int k = 0; k < n_layers; ++k) {
     Layer* l = find_layer(e, names[k]);
     if (!l) return fail(FDM_ERR_NO_LAYER, std::string("no layer ") + names[k]);
-    hipLaunchKernelGGL(k_region_copy, dim3((nr + 255) / 256, nc), dim3(256), 0, e->stream, l->d,
-                       d_buf + size_t(k) * nr * nc, e->G.s_rows, r0, c0, nr, nc, to_buf);
+    hipLaunchKernelGGL(k_region_copy, dim3((nr + 255) / 256, nc), dim3(256), 0, e->stream, lptr(e, *l),
+                       lstride(e, *l), d_buf + size_t(k) * nr * nc, e->G.s_rows, r0, c0, nr, nc, to_buf);
     HIPCK(hipGetLastError());
   }
   return FDM_OK;
@@ -1094,6 +1209,11 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
   if (std::strcmp(key, "bin_variant") == 0) {
     if (value != 0 && value != 1 && value != 4) return fail(FDM_ERR_INVALID, "bin_variant must be 0, 1 or 4");
     e->bin_variant = value;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "records") == 0) {  // cell-record layout (1, default) or one array per layer (0)
+    e->use_records = value != 0;
+    if (e->estimator_ready) return activate_records(e, e->cfg.estimation_type == 1 ? 1 : 0);
     return FDM_OK;
   }
   if (std::strcmp(key, "dense") == 0) {  // force stamp-gated (0) or dense (1) update sweeps

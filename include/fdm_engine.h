@@ -149,7 +149,8 @@ int fdm_engine_layer_exists(fdm_engine* e, const char* name);
 int fdm_engine_layer_add(fdm_engine* e, const char* name, float value);
 int fdm_engine_layer_download(fdm_engine* e, const char* name, float* host, int32_t rows, int32_t cols);
 int fdm_engine_layer_upload(fdm_engine* e, const char* name, const float* host, int32_t rows, int32_t cols);
-float* fdm_engine_layer_device_ptr(fdm_engine* e, const char* name); /* NULL if absent */
+float* fdm_engine_layer_device_ptr(fdm_engine* e, const char* name); /* NULL if absent or if the layer is
+                                                                      a field of the packed cell records */
 int fdm_engine_clear(fdm_engine* e, const char* name /* NULL = clearAll */);
 
 /* Halo exchange support for spatial tiling: pack the rectangle [r0,r0+nr) x [c0,c0+nc)
@@ -188,6 +189,7 @@ int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2);
  *   "wave_merge"  0/1   : k_bin merges same-cell runs inside the wavefront before the atomics
  *   "bin_variant" 0/1/4 : bin kernel by scan size (0), one point per thread (1), LDS-staged (4)
  *   "dense"       0/1   : update sweep visits every tile (1) or only stamped tiles (0)
+ *   "records"     0/1   : estimator state packed into per-cell records (1) or one array per layer (0)
  *   "dbg_*"             : measurement-only switches used by scripts/ab_kernels.py */
 int fdm_engine_set_option(fdm_engine* e, const char* key, int value);
 

@@ -518,3 +518,42 @@ def test_engine_on_a_caller_provided_stream(gpu, R):
     eng.set_stream(0)  # back to the engine's own stream
     run_both(eng, ref, wl.scan(0), wl.T_base_sensor, wl.pose(6))
     assert_layers_equal(eng, ref)
+
+
+@pytest.mark.parametrize("est", [0, 1])
+def test_per_layer_layout_equals_cell_records(gpu, R, est):
+    """The default packs the estimator state into 64 B / 128 B cell records; option records=0 keeps
+    one array per layer.  Both must match the oracle through moves, uploads and clears."""
+    def fill(c):
+        c.estimation_type = est
+
+    rng = np.random.default_rng(77 + est)
+    a, ref = pair(gpu, R, 10.0, 8.0, 0.2, fill)
+    b = gpu.Engine(10.0, 8.0, 0.2, a.cfg)
+    b.set_option("records", 0)
+    tag = rng.normal(0, 1, (a.rows, a.cols)).astype(F32)
+    for e in (a, b, ref):
+        e.set_layer("elevation", tag)           # host write into a record field
+        e.add("extra", 0.25)
+    for k in range(8):
+        n = 3000
+        s = {"x": rng.uniform(-5, 5, n).astype(F32), "y": rng.uniform(-4, 4, n).astype(F32),
+             "z": rng.normal(0, 0.3, n).astype(F32), "intensity": rng.random(n, dtype=F32)}
+        run_both(a, ref, s, T(z=0.4), T(0.31 * k, -0.17 * k, yaw=0.03 * k))
+        b.integrate(s["x"], s["y"], s["z"], T(z=0.4), T(0.31 * k, -0.17 * k, yaw=0.03 * k),
+                    intensity=s["intensity"])
+        if k == 4:
+            for e in (a, b, ref):
+                e.clear("variance")
+    assert_layers_equal(a, ref)
+    for n in a.layers():
+        assert_arrays_close(a.layer(n), b.layer(n), n, 0.0, 0.0)
+    a.set_option("records", 0)   # unpack on the fly, keep going
+    b.set_option("records", 1)   # pack on the fly
+    s = {"x": rng.uniform(-5, 5, 500).astype(F32), "y": rng.uniform(-4, 4, 500).astype(F32),
+         "z": rng.normal(0, 0.3, 500).astype(F32), "intensity": None}
+    run_both(a, ref, s, T(z=0.4), T(2.9, -1.4))
+    b.integrate(s["x"], s["y"], s["z"], T(z=0.4), T(2.9, -1.4))
+    assert_layers_equal(a, ref)
+    for n in a.layers():
+        assert_arrays_close(a.layer(n), b.layer(n), n, 0.0, 0.0)
