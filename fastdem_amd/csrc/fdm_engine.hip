@@ -246,24 +246,9 @@ int ensure_ids(fdm_engine* e, size_t n) {
 }
 
 int ensure_scratch_channels(fdm_engine* e, bool intensity, bool color) {
-  auto alloc_u32 = [&](uint32_t** p, uint32_t init) -> int {
-    if (*p) return FDM_OK;
-    HIPCK(hipMalloc(reinterpret_cast<void**>(p), e->ncell * sizeof(uint32_t)));
-    const int blocks = int(std::min<size_t>((e->ncell + 255) / 256, 4096));
-    hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, e->stream, *p, init, e->ncell);
-    HIPCK(hipGetLastError());
-    return FDM_OK;
-  };
   int rc;
-  if (intensity) {
-    if ((rc = alloc_u32(&e->S.imax, 0u))) return rc;
-    if ((rc = alloc_u32(&e->S.first, kNoIdx))) return rc;
-    if (!find_layer(e, "intensity") && (rc = add_layer(e, "intensity", NAN, true))) return rc;
-  }
-  if (color) {
-    if ((rc = alloc_u32(&e->S.last, 0u))) return rc;
-    if (!find_layer(e, "color") && (rc = add_layer(e, "color", NAN, true))) return rc;
-  }
+  if (intensity && !find_layer(e, "intensity") && (rc = add_layer(e, "intensity", NAN, true))) return rc;
+  if (color && !find_layer(e, "color") && (rc = add_layer(e, "color", NAN, true))) return rc;
   return FDM_OK;
 }
 
@@ -323,6 +308,7 @@ int activate_records(fdm_engine* e, int kind) {
 int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, const float* dy,
                  const float* dz, const float* dint, const uint32_t* drgb, const float* dvar) {
   if (n >= 0xFFFFFFFEull) return fail(FDM_ERR_INVALID, "point count exceeds 2^32-2");
+  if (dint && n >= 0x7FFFFFFFull) return fail(FDM_ERR_INVALID, "point count exceeds 2^31-1 (intensity channel)");
   int rc;
   P.n = uint32_t(n);
   P.scan_no = uint32_t(e->scan_no);
@@ -745,13 +731,13 @@ static int create_impl(const fdm_geometry* g, const fdm_config* cfg, const fdm_t
   e->S.dense = e->ncell <= (size_t(4) << 20) ? 1 : 0;
   e->n_tiles = unsigned((e->ncell + 255) >> 8);
   HCK(hipMalloc(reinterpret_cast<void**>(&e->S.key), e->ncell * sizeof(unsigned long long)));
-  HCK(hipMalloc(reinterpret_cast<void**>(&e->S.zmax), e->ncell * sizeof(uint32_t)));
+  HCK(hipMalloc(reinterpret_cast<void**>(&e->S.aux), e->ncell * sizeof(uint4)));
   HCK(hipMalloc(reinterpret_cast<void**>(&e->S.upd_part), e->n_tiles * sizeof(uint32_t)));
   HCK(hipMalloc(reinterpret_cast<void**>(&e->S.tile_stamp), e->n_tiles * sizeof(uint32_t)));
   {
     const int blocks = int(std::min<size_t>((e->ncell + 255) / 256, 4096));
     hipLaunchKernelGGL(k_fill_u64, dim3(blocks), dim3(256), 0, e->stream, e->S.key, kEmptyKey, e->ncell);
-    hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, e->stream, e->S.zmax, 0u, e->ncell);
+    hipLaunchKernelGGL(k_fill_aux, dim3(blocks), dim3(256), 0, e->stream, e->S.aux, e->ncell);
     hipLaunchKernelGGL(k_fill_u32, dim3(64), dim3(256), 0, e->stream, e->S.tile_stamp, 0xFFFFFFFEu,
                        size_t(e->n_tiles));
     hipLaunchKernelGGL(k_fill_u32, dim3(64), dim3(256), 0, e->stream, e->S.upd_part, 0u,
@@ -795,10 +781,7 @@ void fdm_engine_destroy(fdm_engine* e) {
   if (e->d_tmp) (void)hipFree(e->d_tmp);
   if (e->d_layer_ptrs) (void)hipFree(e->d_layer_ptrs);
   if (e->S.key) (void)hipFree(e->S.key);
-  if (e->S.zmax) (void)hipFree(e->S.zmax);
-  if (e->S.imax) (void)hipFree(e->S.imax);
-  if (e->S.first) (void)hipFree(e->S.first);
-  if (e->S.last) (void)hipFree(e->S.last);
+  if (e->S.aux) (void)hipFree(e->S.aux);
   if (e->S.bin_part) (void)hipFree(e->S.bin_part);
   if (e->S.upd_part) (void)hipFree(e->S.upd_part);
   if (e->S.tile_stamp) (void)hipFree(e->S.tile_stamp);

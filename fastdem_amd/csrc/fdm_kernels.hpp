@@ -44,10 +44,15 @@ struct Scratch {
   uint32_t* tile_stamp;          // [tiles] number of the last scan that touched a cell of the tile
   int dense;                     // 1: every tile is visited (small/medium maps); 0: stamp-gated
   unsigned long long* key;       // (ord(z) << 32 | point index), min-reduced; kEmptyKey = untouched
-  uint32_t* zmax;                // ord(max z), 0 = none
-  uint32_t* imax;                // ord(max non-NaN intensity), 0 = none
-  uint32_t* first;               // lowest point index in the cell (intensity NaN-first rule)
-  uint32_t* last;                // highest point index in the cell (colour = last point wins)
+  // aux[cell] = {zmax, imax, first, last}: one 16 B group per cell, so the update kernel reads and
+  // resets the whole group with one access.
+  //   zmax  ord(max z), 0 = none
+  //   imax  ord(max non-NaN intensity), 0 = none
+  //   first (lowest point index in the cell << 1) | that point's intensity is NaN
+  //         — the reference keeps the FIRST point's intensity unconditionally, so a NaN there
+  //         sticks (elevation_mapping.cpp:73-79); kNoIdx = none
+  //   last  highest point index in the cell (colour = last point wins)
+  uint4* aux;
   // optional captures for the scan callbacks (null unless fdm_engine_capture enabled them)
   float* cap_x;                  // [n] map-frame coordinates of every input point
   float* cap_y;
@@ -133,12 +138,13 @@ __device__ __forceinline__ void scratch_merge(const Scratch& S, unsigned scan_no
                                               unsigned long long key, uint32_t zmx, uint32_t imx,
                                               uint32_t fst, uint32_t lst) {
   atomicMin(&S.key[cell], key);
-  if (zmx) atomicMax(&S.zmax[cell], zmx);
+  uint32_t* a = reinterpret_cast<uint32_t*>(S.aux) + size_t(cell) * 4;
+  if (zmx) atomicMax(a + 0, zmx);
   if (HAS_INT) {
-    if (imx) atomicMax(&S.imax[cell], imx);
-    atomicMin(&S.first[cell], fst);
+    if (imx) atomicMax(a + 1, imx);
+    atomicMin(a + 2, fst);
   }
-  if (HAS_COL) atomicMax(&S.last[cell], lst);
+  if (HAS_COL) atomicMax(a + 3, lst);
   if (!S.dense) S.tile_stamp[cell >> kTileShift] = scan_no;  // benign race: all writers store the same value
 }
 
@@ -273,14 +279,15 @@ __global__ __launch_bounds__(THREADS) void k_bin4(const ScanParams P, const Geom
     const unsigned long long key = make_key(zs[j], i);
     const uint32_t zmx = make_zmax(zs[j]);
     uint32_t imx = 0;
-    if (HAS_INT) imx = isnan(vs[j]) ? 0u : ord(vs[j]);
+    bool vnan = false;
+    if (HAS_INT) { vnan = isnan(vs[j]); imx = vnan ? 0u : ord(vs[j]); }
     if (cells[j] != run_cell) {
       fold_run();
       run_cell = cells[j];
       run_key = key;
       run_zmx = zmx;
       run_imx = imx;
-      run_fst = i;
+      run_fst = (i << 1) | (vnan ? 1u : 0u);
     } else {
       run_key = key < run_key ? key : run_key;
       run_zmx = zmx > run_zmx ? zmx : run_zmx;
@@ -365,8 +372,9 @@ __global__ __launch_bounds__(256) void k_bin(const ScanParams P, const GeomConst
     key = make_key(z, i);
     zmx = make_zmax(z);
     if (P.has_intensity) {
-      imx = isnan(vint) ? 0u : ord(vint);
-      fst = i;
+      const bool vnan = isnan(vint);
+      imx = vnan ? 0u : ord(vint);
+      fst = (i << 1) | (vnan ? 1u : 0u);
     }
     lst = i;
   }
@@ -624,7 +632,7 @@ __global__ __launch_bounds__(256) void k_update(
     const ScanParams P, const GeomConst G, DevState* __restrict__ st,
     const typename POLICY::Layers L, float* const* __restrict__ all_layers, int n_layers,
     const Scratch S, const float* __restrict__ px, const float* __restrict__ py,
-    const float* __restrict__ pz, const float* __restrict__ pint,
+    const float* __restrict__ pz, const float* __restrict__ /*pint: folded into aux by k_bin*/,
     const uint32_t* __restrict__ prgb, const float* __restrict__ pvar, unsigned ncell) {
   const float nanv = __uint_as_float(0x7FC00000u);
   __shared__ unsigned s_t[4];
@@ -673,10 +681,8 @@ __global__ __launch_bounds__(256) void k_update(
         gz = pz[idx];
         if (P.has_var) gvar = pvar[idx];
       }
-      const uint32_t zm = S.zmax[o];
-      uint32_t imx = 0u, fst = kNoIdx, lst = 0u;
-      if (P.has_intensity) { imx = S.imax[o]; fst = S.first[o]; }
-      if (P.has_color) lst = S.last[o];
+      const uint4 ax = S.aux[o];
+      const uint32_t zm = ax.x, imx = ax.y, fst = ax.z, lst = ax.w;
       float sint = nanv;
       typename POLICY::State stt;
       if (in_strip) {
@@ -685,10 +691,8 @@ __global__ __launch_bounds__(256) void k_update(
         POLICY::load(L, o, stt);
         if (P.has_intensity) sint = L.intensity[o];
       }
-      float vfirst = 0.f;
       uint32_t rgb = 0u;
-      // ---- round 3 (only with intensity / colour channels): first point's intensity, last colour
-      if (P.has_intensity) vfirst = pint[fst];
+      // ---- round 3 (colour channel only): the last point's colour
       if (P.has_color) rgb = prgb[lst];
 
       // ---- one estimator update per touched cell (elevation_mapping.cpp:94-175) ----
@@ -705,17 +709,12 @@ __global__ __launch_bounds__(256) void k_update(
       POLICY::update(L, o, stt, min_z, min_z_var, max_z);
       L.obstacle[o] = (max_z > min_z) ? max_z : nanv;
       if (P.has_intensity) {
-        const float obs = isnan(vfirst) ? vfirst : unord(imx);
+        const float obs = (fst & 1u) ? nanv : unord(imx);  // first point NaN -> NaN (see Scratch)
         if (isnan(sint) || obs > sint) L.intensity[o] = obs;
-        S.imax[o] = 0u;
-        S.first[o] = kNoIdx;
       }
-      if (P.has_color) {
-        reinterpret_cast<uint32_t*>(L.color)[o] = rgb & 0x00FFFFFFu;
-        S.last[o] = 0u;
-      }
+      if (P.has_color) reinterpret_cast<uint32_t*>(L.color)[o] = rgb & 0x00FFFFFFu;
       S.key[o] = kEmptyKey;  // scratch is clean again for the next scan
-      S.zmax[o] = 0u;
+      S.aux[o] = make_uint4(0u, 0u, kNoIdx, 0u);
     }
   }
   // per-tile touched-cell count (plain store; summed by the host on demand)
@@ -749,6 +748,11 @@ __global__ void k_copy_strided(float* __restrict__ dst, int ds, const float* __r
   size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t stride = size_t(gridDim.x) * blockDim.x;
   for (; i < n; i += stride) dst[i * size_t(ds)] = src[i * size_t(ss)];
+}
+__global__ void k_fill_aux(uint4* __restrict__ p, size_t n) {
+  size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const size_t stride = size_t(gridDim.x) * blockDim.x;
+  for (; i < n; i += stride) p[i] = make_uint4(0u, 0u, kNoIdx, 0u);
 }
 __global__ void k_fill_u64(unsigned long long* __restrict__ p, unsigned long long v, size_t n) {
   size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
