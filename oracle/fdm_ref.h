@@ -30,6 +30,9 @@ typedef struct fdmref_config {
   float p2_dn[5];
   int32_t p2_elevation_marker;
   float p2_max_sample_count;
+  int32_t raycast_enabled;                             /* config/postprocess.hpp:16-23 */
+  float rc_height_conflict_threshold, rc_log_odds_observed, rc_log_odds_ghost, rc_log_odds_max,
+      rc_clear_threshold;
 } fdmref_config;
 
 typedef struct fdmref_stats {
@@ -91,6 +94,22 @@ int fdmref_last_cell_ids(void* e, int32_t* out, uint64_t n);
 void fdmref_keep_scan(void* e, int on);
 uint64_t fdmref_last_preprocessed(void* e, uint64_t cap, float* x, float* y, float* z, float* var);
 uint64_t fdmref_last_rasterized(void* e, uint64_t cap, float* x, float* y, float* z);
+
+/* raycasting stage (fdm_ref_raycast.hpp).  stats5 = {n_rays, n_observed, n_ray_cells, n_conflicts,
+ * n_cleared}.  voxel tie order: 1 = by original index (default; what the engine reproduces),
+ * 0 = std::sort on the key exactly as the reference. */
+void fdmref_set_voxel_stable(void* e, int on);
+void fdmref_last_ray_stats(void* e, uint32_t* stats5);
+/* applyRaycasting(map, scan, sensor_origin, cfg) on a map-frame cloud (raycasting.cpp:204-249) */
+int fdmref_apply_raycasting(void* e, uint64_t n, const float* x, const float* y, const float* z,
+                            const float* origin3, uint32_t* stats5);
+/* filters::voxelGrid(cloud, size, VoxelMode::ANY): original indices of the selected points in
+ * output order; returns their count, -1 if voxel_size is outside [0.001, 100] (the reference throws) */
+int64_t fdmref_voxel_any(uint64_t n, const float* x, const float* y, const float* z, float voxel_size,
+                         int stable, uint32_t* out_idx);
+/* voxel::pack (nanopcl/core/voxel.hpp:28-43) */
+uint64_t fdmref_voxel_pack(float x, float y, float z, float inv_voxel_size);
+void fdmref_sensor_origin(const double* T_base_sensor, const double* T_world_base, float* out3);
 
 /* unit-level entry points for the reference's known-answer tests */
 void fdmref_sensor_covariance(const fdmref_config* cfg, const float* p3, float* cov9_colmajor);

@@ -41,6 +41,7 @@
 #include <vector>
 
 #include "fdm_grid.hpp"
+#include "fdm_ref_raycast.hpp"
 
 namespace fdmref {
 
@@ -68,6 +69,20 @@ struct Config {
   float p2_dn[5] = {0.01f, 0.16f, 0.50f, 0.84f, 0.99f};
   int32_t p2_elevation_marker = 3;
   float p2_max_sample_count = 0.0f;
+  // config::Raycasting (config/postprocess.hpp:16-23)
+  int32_t raycast_enabled = 0;
+  float rc_height_conflict_threshold = 0.05f, rc_log_odds_observed = 0.4f, rc_log_odds_ghost = 0.2f,
+        rc_log_odds_max = 2.0f, rc_clear_threshold = -1.0f;
+  RaycastConfig raycasting() const {
+    RaycastConfig r;
+    r.enabled = raycast_enabled != 0;
+    r.height_conflict_threshold = rc_height_conflict_threshold;
+    r.log_odds_observed = rc_log_odds_observed;
+    r.log_odds_ghost = rc_log_odds_ghost;
+    r.log_odds_max = rc_log_odds_max;
+    r.clear_threshold = rc_clear_threshold;
+    return r;
+  }
 };
 
 // layer names (elevation_map.hpp:28-46, kalman_estimation.hpp:27-31,
@@ -493,9 +508,21 @@ class Engine {
         last_rasterized.push_back({float(px), float(py), cell.min_z});
       }
     }
+    // 3. raycasting (fastdem.cpp:152-159)
+    if (cfg_.raycast_enabled) {
+      float origin[3];
+      sensorOrigin(T_wb, T_bs, origin);
+      const auto sel = voxelGridAny(points.pts, static_cast<float>(map_.resolution()), voxel_stable);
+      std::vector<std::array<float, 4>> ray_scan(sel.size());
+      for (size_t k = 0; k < sel.size(); ++k) ray_scan[k] = points.pts[sel[k]];
+      last_ray = applyRaycasting(map_, ray_scan, origin, cfg_.raycasting());
+    }
     if (st) *st = s;
     return OK;
   }
+
+  bool voxel_stable = true;  // tie order inside a voxel for VoxelMode::ANY (see fdm_ref_raycast.hpp)
+  RayStats last_ray;
 
   // ElevationMapping::update (elevation_mapping.cpp:110-125) — also the public entry
   // tests/test_dual_layer.cpp:71 drives directly (cloud in map frame, no covariance).

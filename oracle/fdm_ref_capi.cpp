@@ -62,7 +62,13 @@ int fdmref_integrate(void* e, uint64_t n, const float* x, const float* y, const 
                      const double* T_wb, fdmref_stats* out) {
   Cloud c = buildCloud(n, x, y, z, intensity, rgb);
   ScanStats s;
-  const Status st = E(e)->integrate(c, T_bs, T_wb, &s);
+  Status st;
+  try {
+    st = E(e)->integrate(c, T_bs, T_wb, &s);
+  } catch (const std::invalid_argument&) {  // voxelGrid range check (voxel_grid_impl.hpp:31-33)
+    copyStats(s, out);
+    return -1;
+  }
   copyStats(s, out);
   return st;
 }
@@ -210,6 +216,38 @@ uint64_t fdmref_last_rasterized(void* e, uint64_t cap, float* x, float* y, float
     z[i] = r[i][2];
   }
   return r.size();
+}
+
+void fdmref_set_voxel_stable(void* e, int on) { E(e)->voxel_stable = on != 0; }
+static void copyRay(const RayStats& r, uint32_t* s5) {
+  if (!s5) return;
+  s5[0] = r.n_rays; s5[1] = r.n_observed; s5[2] = r.n_ray_cells; s5[3] = r.n_conflicts; s5[4] = r.n_cleared;
+}
+void fdmref_last_ray_stats(void* e, uint32_t* stats5) { copyRay(E(e)->last_ray, stats5); }
+int fdmref_apply_raycasting(void* e, uint64_t n, const float* x, const float* y, const float* z,
+                            const float* origin3, uint32_t* stats5) {
+  std::vector<std::array<float, 4>> scan(n);
+  for (uint64_t i = 0; i < n; ++i) scan[i] = {x[i], y[i], z[i], 1.0f};
+  Engine* en = E(e);
+  en->last_ray = applyRaycasting(en->map(), scan, origin3, en->config().raycasting());
+  copyRay(en->last_ray, stats5);
+  return 0;
+}
+int64_t fdmref_voxel_any(uint64_t n, const float* x, const float* y, const float* z, float voxel_size,
+                         int stable, uint32_t* out_idx) {
+  std::vector<std::array<float, 4>> pts(n);
+  for (uint64_t i = 0; i < n; ++i) pts[i] = {x[i], y[i], z[i], 1.0f};
+  try {
+    const auto sel = voxelGridAny(pts, voxel_size, stable != 0);
+    std::memcpy(out_idx, sel.data(), sel.size() * sizeof(uint32_t));
+    return int64_t(sel.size());
+  } catch (const std::invalid_argument&) {
+    return -1;
+  }
+}
+uint64_t fdmref_voxel_pack(float x, float y, float z, float inv) { return voxel::pack(x, y, z, inv); }
+void fdmref_sensor_origin(const double* T_bs, const double* T_wb, float* out3) {
+  sensorOrigin(T_wb, T_bs, out3);
 }
 
 void fdmref_sensor_covariance(const fdmref_config* cfg, const float* p3, float* cov9) {

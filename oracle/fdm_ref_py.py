@@ -32,6 +32,10 @@ class RefConfig(C.Structure):
         ("p2_dn", C.c_float * 5),
         ("p2_elevation_marker", C.c_int32),
         ("p2_max_sample_count", C.c_float),
+        ("raycast_enabled", C.c_int32),
+        ("rc_height_conflict_threshold", C.c_float), ("rc_log_odds_observed", C.c_float),
+        ("rc_log_odds_ghost", C.c_float), ("rc_log_odds_max", C.c_float),
+        ("rc_clear_threshold", C.c_float),
     ]
 
 
@@ -114,6 +118,15 @@ def load(native=False):
     lib.fdmref_last_preprocessed.argtypes = [P, C.c_uint64, P, P, P, P]
     lib.fdmref_last_rasterized.restype = C.c_uint64
     lib.fdmref_last_rasterized.argtypes = [P, C.c_uint64, P, P, P]
+    lib.fdmref_set_voxel_stable.argtypes = [P, C.c_int]
+    lib.fdmref_last_ray_stats.argtypes = [P, P]
+    lib.fdmref_apply_raycasting.restype = C.c_int
+    lib.fdmref_apply_raycasting.argtypes = [P, C.c_uint64, P, P, P, P, P]
+    lib.fdmref_voxel_any.restype = C.c_int64
+    lib.fdmref_voxel_any.argtypes = [C.c_uint64, P, P, P, C.c_float, C.c_int, P]
+    lib.fdmref_sensor_origin.argtypes = [D, D, P]
+    lib.fdmref_voxel_pack.restype = C.c_uint64
+    lib.fdmref_voxel_pack.argtypes = [C.c_float] * 4
     lib.fdmref_sensor_covariance.argtypes = [C.POINTER(RefConfig), P, P]
     lib.fdmref_kalman_update.argtypes = [C.c_float, C.c_float, C.c_float, P, C.c_float, C.c_float,
                                          C.c_int]
@@ -283,6 +296,24 @@ class RefEngine:
         n = self._lib.fdmref_last_rasterized(self._h, cap, *[_ptr(v) for v in a])
         return [v[:n] for v in a]
 
+    # -- raycasting stage --
+    RAY_STATS = ("n_rays", "n_observed", "n_ray_cells", "n_conflicts", "n_cleared")
+
+    def set_voxel_stable(self, on=True):
+        self._lib.fdmref_set_voxel_stable(self._h, int(on))
+
+    def last_ray_stats(self):
+        s = np.zeros(5, dtype=np.uint32)
+        self._lib.fdmref_last_ray_stats(self._h, _ptr(s))
+        return dict(zip(self.RAY_STATS, (int(v) for v in s)))
+
+    def apply_raycasting(self, x, y, z, sensor_origin):
+        x, y, z = _f32(x), _f32(y), _f32(z)
+        o = _f32(sensor_origin)
+        s = np.zeros(5, dtype=np.uint32)
+        self._lib.fdmref_apply_raycasting(self._h, x.size, _ptr(x), _ptr(y), _ptr(z), _ptr(o), _ptr(s))
+        return dict(zip(self.RAY_STATS, (int(v) for v in s)))
+
     def enable_cell_ids(self, on=True):
         self._lib.fdmref_track_ids(self._h, int(on))
 
@@ -294,6 +325,28 @@ class RefEngine:
 
 
 # ---- unit-level helpers for the reference's known-answer tests ----
+def voxel_any(x, y, z, voxel_size, stable=True):
+    """filters::voxelGrid(..., VoxelMode::ANY): original indices of the kept points, output order."""
+    x, y, z = _f32(x), _f32(y), _f32(z)
+    out = np.empty(max(x.size, 1), dtype=np.uint32)
+    n = load().fdmref_voxel_any(x.size, _ptr(x), _ptr(y), _ptr(z), float(voxel_size), int(stable), _ptr(out))
+    if n < 0:
+        raise ValueError("voxel_size must be in [0.001, 100]")
+    return out[:n].copy()
+
+
+def voxel_pack(x, y, z, inv):
+    k = int(load().fdmref_voxel_pack(float(x), float(y), float(z), float(inv)))
+    off = 1 << 20
+    return k, ((k & 0x1FFFFF) - off, ((k >> 21) & 0x1FFFFF) - off, ((k >> 42) & 0x1FFFFF) - off)
+
+
+def sensor_origin(T_base_sensor, T_world_base):
+    out = np.zeros(3, dtype=np.float32)
+    load().fdmref_sensor_origin(_dp(_colmajor16(T_base_sensor)), _dp(_colmajor16(T_world_base)), _ptr(out))
+    return out
+
+
 def sensor_covariance(cfg, p):
     p = _f32(p)
     out = np.zeros(9, dtype=np.float32)
