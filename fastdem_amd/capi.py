@@ -27,6 +27,11 @@ class FdmConfig(C.Structure):
         ("p2_dn", C.c_float * 5),
         ("p2_elevation_marker", C.c_int32),
         ("p2_max_sample_count", C.c_float),
+        # config::Raycasting (config/postprocess.hpp:16-23)
+        ("raycast_enabled", C.c_int32),
+        ("rc_height_conflict_threshold", C.c_float), ("rc_log_odds_observed", C.c_float),
+        ("rc_log_odds_ghost", C.c_float), ("rc_log_odds_max", C.c_float),
+        ("rc_clear_threshold", C.c_float),
     ]
 
 
@@ -107,6 +112,10 @@ PROTOTYPES = {
     "fdm_engine_capture": (C.c_int, [_P, C.c_int, C.c_int]),
     "fdm_engine_last_preprocessed": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, C.POINTER(C.c_uint64)]),
     "fdm_engine_last_rasterized": (C.c_int, [_P, C.c_uint64, _P, _P, _P, C.POINTER(C.c_uint64)]),
+    "fdm_engine_apply_raycasting": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _F]),
+    "fdm_engine_apply_raycasting_device": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _F]),
+    "fdm_engine_voxel_any": (C.c_int, [_P, C.c_uint64, _P, _P, _P, C.c_float, _P, C.POINTER(C.c_uint64)]),
+    "fdm_engine_last_ray_ms": (C.c_int, [_P, _F]),
     "fdm_engine_enable_cell_ids": (C.c_int, [_P, C.c_int]),
     "fdm_engine_last_cell_ids": (C.c_int, [_P, _P, C.c_uint64]),
     "fdm_engine_enable_profile": (C.c_int, [_P, C.c_int]),

@@ -36,7 +36,8 @@ struct DevCand {  // geometry after the LOCAL-mode move of this scan + the index
 struct DevFlags {
   unsigned any_pass;    // some point survived cropRange+cropZ (fastdem.cpp:138)
   unsigned any_inside;  // some point landed in the map (elevation_mapping.cpp:118)
-  unsigned pad0, pad1;
+  unsigned ray_any;     // the voxel-downsampled ray scan is not empty (raycasting.cpp:207)
+  unsigned pad1;
 };
 struct DevObst {       // the last scan that updated the map (observed >= 1 cell): the tiles it
   unsigned scan;       // stamped are the only ones whose obstacle layer can hold non-NaN cells
@@ -48,7 +49,7 @@ struct DevState {
   DevCand cand[4];
   DevFlags flags[4];
   DevObst obst[4];
-  unsigned sticky;  // bit0: intensity layer written, bit1: colour layer written
+  unsigned sticky;  // bit0: intensity layer written, bit1: colour layer written, bit2: raycasting ran
   unsigned pad[3];
 };
 
@@ -65,6 +66,7 @@ struct ScanParams {
   float min_sq, max_sq, z_min, z_max;
   float sp[4];             // sensor-model parameters
   double robot_x, robot_y;
+  float ray_ox, ray_oy, ray_oz;  // sensor origin in the map frame (raycasting stage, integrate only)
   unsigned n;
   unsigned scan_no;
   int slot;

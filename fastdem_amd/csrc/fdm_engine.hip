@@ -17,7 +17,10 @@
 #include <string>
 #include <vector>
 
+#include <rocprim/device/device_radix_sort.hpp>  // stable (key, index) sort of the voxel filter
+
 #include "fdm_kernels.hpp"
+#include "fdm_raycast.hpp"
 
 using namespace fdm;
 
@@ -104,6 +107,17 @@ struct fdm_engine {
   bool saved_want_ids = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   float last_ms[3] = {0.f, 0.f, 0.f};
+  // raycasting stage (fdm_raycast.hpp)
+  uint32_t* rc_cnt = nullptr;        // [ncell] ray-scan points observed in the cell this frame
+  uint32_t* rc_min = nullptr;        // [ncell] ord(min ray height), kRayEmpty = not traversed
+  unsigned long long* vkeys[2] = {nullptr, nullptr};  // voxel keys: unsorted / sorted
+  uint32_t* vidx[2] = {nullptr, nullptr};             // point indices: unsorted / sorted
+  uint32_t* vsel = nullptr;          // voxel_any output staging
+  size_t vcap = 0;
+  void* sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  hipEvent_t ev_ray[2] = {nullptr, nullptr};
+  bool ray_timed = false;
 };
 
 namespace {
@@ -219,6 +233,9 @@ int resolve_pending(fdm_engine* e) {
   for (auto& l : e->layers) {
     if (l.pending && l.name == "intensity" && (sticky & 1u)) l.pending = false;
     if (l.pending && l.name == "color" && (sticky & 2u)) l.pending = false;
+    if (l.pending && (sticky & 4u) &&
+        (l.name == "ghost_removal" || l.name == "raycasting" || l.name == "_visibility_logodds"))
+      l.pending = false;
   }
   return FDM_OK;
 }
@@ -304,6 +321,111 @@ int activate_records(fdm_engine* e, int kind) {
   return FDM_OK;
 }
 
+// ---- raycasting stage (fdm_raycast.hpp) ----
+bool voxel_size_ok(float v) { return v >= 0.001f && v <= 100.0f; }  // voxel_grid_impl.hpp:31-33
+
+// raycasting.cpp:223-226: created on first use; invisible until a frame passed the preconditions
+int ensure_ray_layers(fdm_engine* e) {
+  int rc;
+  for (const char* n : {"ghost_removal", "raycasting", "_visibility_logodds"})
+    if (!find_layer(e, n) && (rc = add_layer(e, n, NAN, true))) return rc;
+  return FDM_OK;
+}
+
+int ensure_ray_cells(fdm_engine* e) {
+  if (e->rc_cnt) return FDM_OK;
+  HIPCK(hipMalloc(reinterpret_cast<void**>(&e->rc_cnt), e->ncell * sizeof(uint32_t)));
+  HIPCK(hipMalloc(reinterpret_cast<void**>(&e->rc_min), e->ncell * sizeof(uint32_t)));
+  const int blocks = int(std::min<size_t>((e->ncell + 255) / 256, 4096));
+  hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, e->stream, e->rc_cnt, 0u, e->ncell);
+  hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, e->stream, e->rc_min, kRayEmpty, e->ncell);
+  HIPCK(hipGetLastError());
+  return FDM_OK;
+}
+
+int ensure_voxel_buffers(fdm_engine* e, size_t n) {
+  if (n <= e->vcap) return FDM_OK;
+  HIPCK(hipStreamSynchronize(e->stream));
+  for (int k = 0; k < 2; ++k) {
+    if (e->vkeys[k]) HIPCK(hipFree(e->vkeys[k]));
+    if (e->vidx[k]) HIPCK(hipFree(e->vidx[k]));
+  }
+  if (e->vsel) HIPCK(hipFree(e->vsel));
+  if (e->sort_tmp) HIPCK(hipFree(e->sort_tmp));
+  e->vcap = n + n / 4 + 1024;
+  for (int k = 0; k < 2; ++k) {
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->vkeys[k]), e->vcap * sizeof(unsigned long long)));
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->vidx[k]), e->vcap * sizeof(uint32_t)));
+  }
+  HIPCK(hipMalloc(reinterpret_cast<void**>(&e->vsel), e->vcap * sizeof(uint32_t)));
+  e->sort_tmp_bytes = 0;
+  HIPCK(rocprim::radix_sort_pairs(nullptr, e->sort_tmp_bytes, e->vkeys[0], e->vkeys[1], e->vidx[0],
+                                  e->vidx[1], e->vcap, 0, 64, e->stream));
+  HIPCK(hipMalloc(&e->sort_tmp, e->sort_tmp_bytes ? e->sort_tmp_bytes : 16));
+  return FDM_OK;
+}
+
+// keys -> stable sort: vkeys[1] / vidx[1] hold the voxel-ordered scan afterwards
+int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slot, const float* dx,
+                       const float* dy, const float* dz) {
+  if (int rc = ensure_voxel_buffers(e, n)) return rc;
+  const float inv = 1.0f / voxel_size;  // voxel_grid_impl.hpp:46
+  hipLaunchKernelGGL(k_voxel_keys, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, inv, flag_slot,
+                     e->d_state, dx, dy, dz, e->vkeys[0], e->vidx[0]);
+  HIPCK(hipGetLastError());
+  size_t bytes = e->sort_tmp_bytes;
+  HIPCK(rocprim::radix_sort_pairs(e->sort_tmp, bytes, e->vkeys[0], e->vkeys[1], e->vidx[0], e->vidx[1],
+                                  size_t(n), 0, 64, e->stream));
+  return FDM_OK;
+}
+
+RayParams make_ray_params(fdm_engine* e, const float* origin, unsigned n, int slot, int flag_slot) {
+  RayParams Q{};
+  Q.ox = origin[0]; Q.oy = origin[1]; Q.oz = origin[2];
+  Q.l_obs = e->cfg.rc_log_odds_observed;
+  Q.l_ghost = e->cfg.rc_log_odds_ghost;
+  Q.l_max = e->cfg.rc_log_odds_max;
+  Q.clear_thr = e->cfg.rc_clear_threshold;
+  Q.conflict_thr = e->cfg.rc_height_conflict_threshold;
+  Q.resolution = static_cast<float>(e->G.res);
+  Q.inv_voxel = 1.0f / Q.resolution;
+  Q.n = n;
+  Q.slot = slot;
+  Q.flag_slot = flag_slot;
+  return Q;
+}
+
+// processScan + resolveGhostCells on the stream.  voxel: the points are vkeys[1]/vidx[1] runs.
+int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float* dx, const float* dy,
+                      const float* dz) {
+  int rc;
+  if ((rc = ensure_ray_cells(e))) return rc;
+  Layer* elev = find_layer(e, "elevation");
+  if (!elev) return FDM_OK;  // raycasting.cpp:213-216
+  RayLayers L{};
+  L.elevation = lptr(e, *elev);
+  L.elevation_stride = lstride(e, *elev);
+  L.logodds = find_layer(e, "_visibility_logodds")->d;
+  L.ray_min = find_layer(e, "raycasting")->d;
+  L.ghost = find_layer(e, "ghost_removal")->d;
+  L.rec = e->d_rec;
+  L.rec_floats = e->rec_floats;
+  const unsigned blocks = (Q.n + 255u) / 256u;
+  if (voxel)
+    hipLaunchKernelGGL(k_ray<true>, dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx, dy, dz,
+                       e->vkeys[1], e->vidx[1], e->rc_cnt, e->rc_min);
+  else
+    hipLaunchKernelGGL(k_ray<false>, dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx, dy,
+                       dz, static_cast<const unsigned long long*>(nullptr),
+                       static_cast<const uint32_t*>(nullptr), e->rc_cnt, e->rc_min);
+  HIPCK(hipGetLastError());
+  hipLaunchKernelGGL(k_ray_resolve, dim3(unsigned((e->ncell + 255) / 256)), dim3(256), 0, e->stream, Q,
+                     e->G, e->d_state, L, e->d_layer_ptrs, e->n_layer_ptrs, e->rc_cnt, e->rc_min,
+                     unsigned(e->ncell));
+  HIPCK(hipGetLastError());
+  return FDM_OK;
+}
+
 // One scan = k_bin + k_update on the stream.  All pointers are device pointers.
 int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, const float* dy,
                  const float* dz, const float* dint, const uint32_t* drgb, const float* dvar) {
@@ -340,12 +462,19 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     e->estimator_ready = true;
   }
   if ((rc = ensure_scratch_channels(e, P.has_intensity, P.has_color))) return rc;
+  const bool ray_on = P.integrate_mode && e->cfg.raycast_enabled && n > 0;
+  if (ray_on) {
+    if (!voxel_size_ok(static_cast<float>(e->G.res)))
+      return fail(FDM_ERR_INVALID, "raycasting: voxel_size (= map resolution) must be in [0.001, 100]");
+    if ((rc = ensure_ray_layers(e))) return rc;
+  }
   if ((rc = refresh_layer_ptrs(e))) return rc;
   if ((rc = ensure_ids(e, n))) return rc;
   // scan-callback captures (off unless fdm_engine_capture enabled them)
   e->S.cap_x = e->S.cap_y = e->S.cap_z = e->S.cap_var = nullptr;
   e->S.ras_z = nullptr;
-  if (e->cap_pre && n) {
+  e->S.cap_drop_nan = ray_on ? 1 : 0;
+  if ((e->cap_pre || ray_on) && n) {
     if (n > e->cap_cap) {
       HIPCK(hipStreamSynchronize(e->stream));
       if (e->d_cap) HIPCK(hipFree(e->d_cap));
@@ -355,7 +484,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     e->S.cap_x = e->d_cap;
     e->S.cap_y = e->d_cap + e->cap_cap;
     e->S.cap_z = e->d_cap + 2 * e->cap_cap;
-    e->S.cap_var = e->d_cap + 3 * e->cap_cap;
+    if (e->cap_pre) e->S.cap_var = e->d_cap + 3 * e->cap_cap;
   }
   if (e->cap_ras) {
     if (!e->d_ras) HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_ras), e->ncell * sizeof(float)));
@@ -489,6 +618,20 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     HIPCK(hipEventRecord(e->ev[2], e->stream));
     HIPCK(hipEventRecord(e->ev[3], e->stream));  // back-to-back pair: the event-to-event overhead
   }
+  e->ray_timed = false;
+  if (ray_on) {  // step 3 of integrateImpl (fastdem.cpp:152-159) on the map this scan just updated
+    if (e->profile) HIPCK(hipEventRecord(e->ev_ray[0], e->stream));
+    const float origin[3] = {P.ray_ox, P.ray_oy, P.ray_oz};
+    if ((rc = enqueue_voxel_sort(e, P.n, static_cast<float>(e->G.res), P.slot, e->S.cap_x, e->S.cap_y,
+                                 e->S.cap_z)))
+      return rc;
+    const RayParams Q = make_ray_params(e, origin, P.n, (P.slot + 1) & 3, P.slot);
+    if ((rc = enqueue_ray_stage(e, Q, true, e->S.cap_x, e->S.cap_y, e->S.cap_z))) return rc;
+    if (e->profile) {
+      HIPCK(hipEventRecord(e->ev_ray[1], e->stream));
+      e->ray_timed = true;
+    }
+  }
   e->scan_no++;
   e->have_scan = true;
   e->last_n = uint32_t(n);
@@ -510,6 +653,15 @@ void fill_integrate_params(fdm_engine* e, ScanParams& P, const double* Tbs, cons
   P.z_max = e->cfg.z_max;
   P.robot_x = Twb[12];  // T_world_base.translation().head<2>() (fastdem.cpp:144)
   P.robot_y = Twb[13];
+  {  // (T_world_base * T_base_sensor).translation().cast<float>() (fastdem.cpp:153-154):
+     // L_wb * t_bs (3-term coeff redux a0 + (a1 + a2)) + t_wb, in double, then the cast
+    float o[3];
+    for (int i = 0; i < 3; ++i) {
+      const double a0 = Twb[0 * 4 + i] * Tbs[12], a1 = Twb[1 * 4 + i] * Tbs[13], a2 = Twb[2 * 4 + i] * Tbs[14];
+      o[i] = static_cast<float>((a0 + (a1 + a2)) + Twb[12 + i]);
+    }
+    P.ray_ox = o[0]; P.ray_oy = o[1]; P.ray_oz = o[2];
+  }
   P.integrate_mode = 1;
   P.do_move = e->cfg.mode == 0 ? 1 : 0;
   P.gate_on_filter = 1;
@@ -639,6 +791,12 @@ void fdm_default_config(fdm_config* c) {
   for (int k = 0; k < 5; ++k) c->p2_dn[k] = dn[k];
   c->p2_elevation_marker = 3;
   c->p2_max_sample_count = 0.0f;
+  c->raycast_enabled = 0;  // config/postprocess.hpp:16-23
+  c->rc_height_conflict_threshold = 0.05f;
+  c->rc_log_odds_observed = 0.4f;
+  c->rc_log_odds_ghost = 0.2f;
+  c->rc_log_odds_max = 2.0f;
+  c->rc_clear_threshold = -1.0f;
 }
 
 const char* fdm_last_error(void) { return g_err.c_str(); }
@@ -717,6 +875,7 @@ static int create_impl(const fdm_geometry* g, const fdm_config* cfg, const fdm_t
 
   HCK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   for (auto& ev : e->ev) HCK(hipEventCreate(&ev));
+  for (auto& ev : e->ev_ray) HCK(hipEventCreate(&ev));
   HCK(hipMalloc(reinterpret_cast<void**>(&e->d_state), sizeof(DevState)));
   HCK(hipHostMalloc(reinterpret_cast<void**>(&e->h_state), sizeof(DevState)));
   std::memset(e->h_state, 0, sizeof(DevState));
@@ -796,6 +955,16 @@ void fdm_engine_destroy(fdm_engine* e) {
   if (e->d_ras) (void)hipFree(e->d_ras);
   for (auto& ev : e->ev)
     if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : e->ev_ray)
+    if (ev) (void)hipEventDestroy(ev);
+  if (e->rc_cnt) (void)hipFree(e->rc_cnt);
+  if (e->rc_min) (void)hipFree(e->rc_min);
+  for (int k = 0; k < 2; ++k) {
+    if (e->vkeys[k]) (void)hipFree(e->vkeys[k]);
+    if (e->vidx[k]) (void)hipFree(e->vidx[k]);
+  }
+  if (e->vsel) (void)hipFree(e->vsel);
+  if (e->sort_tmp) (void)hipFree(e->sort_tmp);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -1162,6 +1331,74 @@ int fdm_engine_last_cell_ids(fdm_engine* e, int32_t* host_out, uint64_t n) {
 int fdm_engine_enable_profile(fdm_engine* e, int on) {
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
   e->profile = on != 0;
+  return FDM_OK;
+}
+
+// ---- raycasting entry points ----
+int fdm_engine_apply_raycasting_device(fdm_engine* e, uint64_t n, const float* dx, const float* dy,
+                                       const float* dz, const float origin[3]) {
+  if (!e || !origin) return fail(FDM_ERR_INVALID, "null argument");
+  if (!e->cfg.raycast_enabled || n == 0) return FDM_OK;  // raycasting.cpp:207-209
+  if (!dx || !dy || !dz) return fail(FDM_ERR_INVALID, "null xyz");
+  if (n >= 0xFFFFFFFEull) return fail(FDM_ERR_INVALID, "point count exceeds 2^32-2");
+  HIPCK(hipSetDevice(e->device));
+  int rc;
+  if (!find_layer(e, "elevation")) return FDM_OK;
+  if ((rc = ensure_ray_layers(e))) return rc;
+  if ((rc = refresh_layer_ptrs(e))) return rc;
+  const RayParams Q = make_ray_params(e, origin, unsigned(n), int(e->scan_no & 3), -1);
+  return enqueue_ray_stage(e, Q, false, dx, dy, dz);
+}
+
+int fdm_engine_apply_raycasting(fdm_engine* e, uint64_t n, const float* x, const float* y,
+                                const float* z, const float origin[3]) {
+  if (!e || !origin) return fail(FDM_ERR_INVALID, "null argument");
+  if (!e->cfg.raycast_enabled || n == 0) return FDM_OK;
+  if (!x || !y || !z) return fail(FDM_ERR_INVALID, "null xyz");
+  HIPCK(hipSetDevice(e->device));
+  const float *dx, *dy, *dz, *da, *dv;
+  const uint32_t* dc;
+  int rc = stage_inputs(e, n, x, y, z, nullptr, nullptr, nullptr, &dx, &dy, &dz, &da, &dc, &dv);
+  if (rc) return rc;
+  if ((rc = fdm_engine_apply_raycasting_device(e, n, dx, dy, dz, origin))) return rc;
+  HIPCK(hipStreamSynchronize(e->stream));
+  return FDM_OK;
+}
+
+int fdm_engine_voxel_any(fdm_engine* e, uint64_t n, const float* x, const float* y, const float* z,
+                         float voxel_size, uint32_t* out_idx, uint64_t* n_out) {
+  if (!e || !n_out) return fail(FDM_ERR_INVALID, "null argument");
+  *n_out = 0;
+  if (!voxel_size_ok(voxel_size)) return fail(FDM_ERR_INVALID, "voxel_size must be in [0.001, 100]");
+  if (n == 0) return FDM_OK;
+  if (!x || !y || !z || !out_idx) return fail(FDM_ERR_INVALID, "null argument");
+  if (n >= 0xFFFFFFFEull) return fail(FDM_ERR_INVALID, "point count exceeds 2^32-2");
+  HIPCK(hipSetDevice(e->device));
+  const float *dx, *dy, *dz, *da, *dv;
+  const uint32_t* dc;
+  int rc = stage_inputs(e, n, x, y, z, nullptr, nullptr, nullptr, &dx, &dy, &dz, &da, &dc, &dv);
+  if (rc) return rc;
+  if ((rc = enqueue_voxel_sort(e, unsigned(n), voxel_size, -1, dx, dy, dz))) return rc;
+  hipLaunchKernelGGL(k_voxel_select, dim3(unsigned((n + 255) / 256)), dim3(256), 0, e->stream, unsigned(n),
+                     e->vkeys[1], e->vidx[1], e->vsel);
+  HIPCK(hipGetLastError());
+  std::vector<uint32_t> h(n);
+  HIPCK(hipMemcpyAsync(h.data(), e->vsel, n * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+  HIPCK(hipStreamSynchronize(e->stream));
+  uint64_t w = 0;
+  for (uint64_t i = 0; i < n; ++i)  // order-preserving compaction = marshalling
+    if (h[i] != kNoIdx) out_idx[w++] = h[i];
+  *n_out = w;
+  return FDM_OK;
+}
+
+int fdm_engine_last_ray_ms(fdm_engine* e, float* ms) {
+  if (!e || !ms) return fail(FDM_ERR_INVALID, "null argument");
+  if (!e->profile) return fail(FDM_ERR_INVALID, "profiling is off");
+  *ms = 0.f;
+  if (!e->ray_timed) return FDM_OK;
+  HIPCK(hipStreamSynchronize(e->stream));
+  HIPCK(hipEventElapsedTime(ms, e->ev_ray[0], e->ev_ray[1]));
   return FDM_OK;
 }
 

@@ -57,7 +57,8 @@ struct Scratch {
   float* cap_x;                  // [n] map-frame coordinates of every input point
   float* cap_y;
   float* cap_z;
-  float* cap_var;                // [n] sigma_z^2 of every input point
+  float* cap_var;                // [n] sigma_z^2 of every input point (nullable on its own)
+  int cap_drop_nan;              // 1: a point the crops dropped is stored with x = NaN (ray stage input)
   float* ras_z;                  // [cells] min z observed by this scan (NaN = not observed)
 };
 
@@ -238,8 +239,9 @@ __global__ __launch_bounds__(THREADS) void k_bin4(const ScanParams P, const Geom
     if (S.cap_var && live && P.integrate_mode) cvar = sigma_z2(P, xs[j], ys[j], zs[j]);
     const bool pass = preprocess_point(P, xs[j], ys[j], zs[j]) && live;
     if (S.cap_x && live) {
-      S.cap_x[i0 + j] = xs[j]; S.cap_y[i0 + j] = ys[j]; S.cap_z[i0 + j] = zs[j];
-      S.cap_var[i0 + j] = cvar;
+      S.cap_x[i0 + j] = (S.cap_drop_nan && !pass) ? __uint_as_float(0x7FC00000u) : xs[j];
+      S.cap_y[i0 + j] = ys[j]; S.cap_z[i0 + j] = zs[j];
+      if (S.cap_var) S.cap_var[i0 + j] = cvar;
     }
     cells[j] = pass ? owned_cell(xs[j], ys[j], cand, G) : -1;
     n_pass += pass ? 1u : 0u;
@@ -357,8 +359,9 @@ __global__ __launch_bounds__(256) void k_bin(const ScanParams P, const GeomConst
     if (S.cap_var && P.integrate_mode) cvar = sigma_z2(P, x, y, z);
     pass = preprocess_point(P, x, y, z);
     if (S.cap_x) {
-      S.cap_x[i] = x; S.cap_y[i] = y; S.cap_z[i] = z;
-      S.cap_var[i] = cvar;
+      S.cap_x[i] = (S.cap_drop_nan && !pass) ? __uint_as_float(0x7FC00000u) : x;
+      S.cap_y[i] = y; S.cap_z[i] = z;
+      if (S.cap_var) S.cap_var[i] = cvar;
     }
     if (pass) cell = owned_cell(x, y, cand, G);
     if (cell_ids) cell_ids[i] = cell >= 0 ? cell : (!pass ? -1 : (cell == -2 ? -3 : -2));
@@ -466,6 +469,7 @@ __device__ __forceinline__ void make_ctx(const ScanParams& P, DevState* __restri
     st->obst[nxt].scan = u.do_update ? P.scan_no : ob_scan;
     st->flags[nn].any_pass = 0u;
     st->flags[nn].any_inside = 0u;
+    st->flags[nn].ray_any = 0u;
     if (u.do_update) {
       unsigned f = 0;
       if (P.has_intensity) f |= 1u;

@@ -1,0 +1,283 @@
+// fdm_raycast.hpp — ghost-obstacle removal stage of FastDEM::integrateImpl on the device
+// (SURVEY.md §8 row f1).  gfx950 only.
+//
+// Reference being reproduced (file:line under /root/reference/fastdem):
+//   src/fastdem.cpp:152-159                               sensor origin, voxelGrid(ANY), applyRaycasting
+//   lib/nanoPCL/include/nanopcl/core/voxel.hpp:28-43      voxel key [z:21][y:21][x:21]
+//   lib/nanoPCL/include/nanopcl/filters/impl/voxel_grid_impl.hpp:30-60,171-189   VoxelMode::ANY
+//   src/raycasting.cpp:46-140 traceRay, :142-173 processScan, :175-202 resolveGhostCells, :204-249
+//   include/fastdem/elevation_map.hpp:131-135             clearAt
+//
+// The reference walks the scan sequentially; every step it takes is order-free once restated per
+// cell, which is what the kernels below exploit:
+//   * observed evidence: logodds = min(logodds + L_obs, L_max) once per ray-scan point in the cell
+//     -> the same constant folded k times; k is counted with an integer atomicAdd;
+//   * min ray height: min over rays of the height at the cell exit -> atomicMin on the monotone
+//     uint encoding of the float (a plain L2 load filters out the rays that cannot lower it);
+//   * ghost resolution: one independent decision per traversed cell, after both of the above.
+// Pipeline (one stream, no host round trip):
+//   k_voxel_keys -> stable radix sort of (key, point index) -> k_ray<true> -> k_ray_resolve
+// VoxelMode::ANY picks idx[start + (count*7 + start*13) % count] of each voxel's run in the sorted
+// array.  The reference sorts with std::sort on the key only (unstable: the order inside a voxel is
+// whatever that libstdc++'s introsort leaves); the engine sorts stably, i.e. ties in original point
+// order (both are valid outcomes of "ANY"; see DESIGN.md, raycasting section).
+#pragma once
+
+#include "fdm_device.hpp"
+
+namespace fdm {
+
+constexpr uint32_t kRayEmpty = 0xFFFFFFFFu;       // ord() of no float that can occur (NaN pattern)
+constexpr uint64_t kInvalidVoxel = ~0ull;         // voxel::INVALID_KEY: sorts behind every real key
+
+struct RayParams {
+  float ox, oy, oz;     // sensor origin, map frame (scalars: see the DevObst note in fdm_device.hpp)
+  float l_obs, l_ghost, l_max, clear_thr, conflict_thr;
+  float inv_voxel;      // 1.0f / voxel_size
+  float resolution;     // float(map.getResolution())
+  unsigned n;           // points (VOXEL: sorted entries)
+  int slot;             // geometry ring slot holding the map geometry the stage runs on
+  int flag_slot;        // >= 0: DevFlags slot whose ray_any gates the stage (integrate); -1: ungated
+};
+
+// voxel::pack.  float -> int32 outside the int range is UB in C++; the reference's x86 build
+// (cvttss2si) produces INT_MIN for both signs, restated here explicitly.
+__device__ __forceinline__ int32_t cvt_x86(float v) {
+  if (!(v >= -2147483648.0f && v < 2147483648.0f)) return INT32_MIN;
+  return static_cast<int32_t>(v);
+}
+__device__ __forceinline__ uint64_t voxel_pack(float x, float y, float z, float inv) {
+  constexpr int32_t kOff = 1 << 20, kMin = -kOff, kMax = kOff - 1;
+  int32_t ix = cvt_x86(floorf(x * inv)), iy = cvt_x86(floorf(y * inv)), iz = cvt_x86(floorf(z * inv));
+  ix = ix < kMin ? kMin : (ix > kMax ? kMax : ix);
+  iy = iy < kMin ? kMin : (iy > kMax ? kMax : iy);
+  iz = iz < kMin ? kMin : (iz > kMax ? kMax : iz);
+  return (uint64_t(iz + kOff) << 42) | (uint64_t(iy + kOff) << 21) | uint64_t(ix + kOff);
+}
+
+// (key, index) per point; non-finite points (and points the crops dropped, stored with x = NaN)
+// get the invalid key and therefore sort to the tail (voxel_grid_impl.hpp:50-55).
+__global__ __launch_bounds__(256) void k_voxel_keys(unsigned n, float inv_voxel, int flag_slot,
+                                                    DevState* __restrict__ st,
+                                                    const float* __restrict__ x,
+                                                    const float* __restrict__ y,
+                                                    const float* __restrict__ z,
+                                                    unsigned long long* __restrict__ keys,
+                                                    uint32_t* __restrict__ idx) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  bool valid = false;
+  if (i < n) {
+    const float a = x[i], b = y[i], c = z[i];
+    valid = isfinite(a) && isfinite(b) && isfinite(c);
+    keys[i] = valid ? voxel_pack(a, b, c, inv_voxel) : kInvalidVoxel;
+    idx[i] = i;
+  }
+  if (flag_slot >= 0 && __ballot(valid) && (threadIdx.x & 63) == 0) st->flags[flag_slot].ray_any = 1u;
+}
+
+// Representative of the voxel whose run starts at sorted position i (caller checked it is a head).
+__device__ __forceinline__ uint32_t voxel_pick(const unsigned long long* __restrict__ keys,
+                                               const uint32_t* __restrict__ idx, unsigned i, unsigned n) {
+  const unsigned long long key = keys[i];
+  unsigned count = 1;
+  while (count < 16 && i + count < n && keys[i + count] == key) ++count;
+  if (count == 16 && i + count < n && keys[i + count] == key) {  // long run: upper bound by bisection
+    unsigned lo = i + count, hi = n;                              // keys[lo] == key, first != key in (lo, hi]
+    while (hi - lo > 1) {
+      const unsigned mid = lo + (hi - lo) / 2;
+      if (keys[mid] == key) lo = mid; else hi = mid;
+    }
+    count = hi - i;
+  }
+  const unsigned long long c = count, s = i;  // size_t arithmetic in the reference
+  return idx[i + unsigned((c * 7ull + s * 13ull) % c)];
+}
+
+__device__ __forceinline__ bool map_contains(double x, double y, const DevGeom& g, const GeomConst& G) {
+  const double tx = -((x - g.px) - G.half_x), ty = -((y - g.py) - G.half_y);  // GridMap::isInside
+  return tx >= 0.0 && tx < G.len_x && ty >= 0.0 && ty < G.len_y;
+}
+
+// stage preconditions (raycasting.cpp:207-220), identical in every thread of every stage kernel
+__device__ __forceinline__ bool ray_stage_runs(const RayParams& Q, const DevState* __restrict__ st,
+                                               const DevGeom& g, const GeomConst& G) {
+  if (Q.flag_slot >= 0 && st->flags[Q.flag_slot].ray_any == 0u) return false;  // scan.empty()
+  return map_contains(double(Q.ox), double(Q.oy), g, G);
+}
+
+// storage-linear cell of buffer index (mr, mc) if this engine owns it, else -1
+__device__ __forceinline__ int owned_storage(int mr, int mc, const GeomConst& G) {
+  const int lr = mr - G.o_r0, lc = mc - G.o_c0;
+  if (lr < 0 || lc < 0 || lr >= G.o_rows || lc >= G.o_cols) return -1;
+  return (mc - G.s_c0) * G.s_rows + (mr - G.s_r0);
+}
+
+// processScan (raycasting.cpp:142-173): one ray-scan point per thread.
+//   VOXEL  = true : thread i looks at sorted position i and works only if it heads a voxel run
+//   VOXEL  = false: thread i takes point i of the caller's cloud (applyRaycasting called directly)
+template <bool VOXEL>
+__global__ __launch_bounds__(256) void k_ray(const RayParams Q, const GeomConst G,
+                                             DevState* __restrict__ st,
+                                             const float* __restrict__ x, const float* __restrict__ y,
+                                             const float* __restrict__ z,
+                                             const unsigned long long* __restrict__ keys,
+                                             const uint32_t* __restrict__ idx,
+                                             uint32_t* __restrict__ rc_cnt,
+                                             uint32_t* __restrict__ rc_min) {
+  const DevGeom g = st->geom[Q.slot];
+  if (!ray_stage_runs(Q, st, g, G)) return;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i == 0) st->sticky |= 4u;  // the three layers become visible (raycasting.cpp:223-226)
+  if (i >= Q.n) return;
+  unsigned pi = i;
+  if (VOXEL) {
+    const unsigned long long key = keys[i];
+    if (key == kInvalidVoxel) return;
+    if (i > 0 && keys[i - 1] == key) return;
+    pi = voxel_pick(keys, idx, i, Q.n);
+  }
+  const float ex = x[pi], ey = y[pi], ez = z[pi];
+  if (!VOXEL && !(isfinite(ex) && isfinite(ey) && isfinite(ez))) return;
+
+  // observed evidence: the point's own cell (nanoGrid getIndex, fp64)
+  {
+    DevCand c;
+    c.px = g.px; c.py = g.py; c.sr = g.sr; c.sc = g.sc; c.shr = 0; c.shc = 0;
+    const int o = owned_cell(ex, ey, c, G);
+    if (o >= 0) atomicAdd(&rc_cnt[o], 1u);
+  }
+  if (ez >= Q.oz) return;  // upward ray
+
+  // traceRay (raycasting.cpp:46-140), fp32 exactly as written there
+  const float sx = Q.ox, sy = Q.oy, sz = Q.oz;
+  const float dx = ex - sx, dy = ey - sy;
+  const float ray_len_2d = sqrtf(dx * dx + dy * dy);
+  if (ray_len_2d < 1e-4f) return;
+  const float dz = ez - sz;
+  const float res = Q.resolution;
+  const int nrows = G.rows, ncols = G.cols;
+  const float origin_x = static_cast<float>(g.px) + float(nrows) * res * 0.5f;
+  const float origin_y = static_cast<float>(g.py) + float(ncols) * res * 0.5f;
+  const float gr0 = (origin_x - sx) / res, gc0 = (origin_y - sy) / res;
+  const float gr1 = (origin_x - ex) / res, gc1 = (origin_y - ey) / res;
+  const float dr = gr1 - gr0, dc = gc1 - gc0;
+  int r = static_cast<int>(floorf(gr0));
+  int c = static_cast<int>(floorf(gc0));
+  constexpr float kInf = 1e30f;
+  int step_r = 0, step_c = 0;
+  float t_max_r = kInf, t_max_c = kInf, t_delta_r = kInf, t_delta_c = kInf;
+  if (fabsf(dr) > 1e-8f) {
+    step_r = dr > 0 ? 1 : -1;
+    const float boundary = step_r > 0 ? (float(r) + 1.0f) : float(r);
+    t_max_r = (boundary - gr0) / dr;
+    t_delta_r = float(step_r) / dr;
+  }
+  if (fabsf(dc) > 1e-8f) {
+    step_c = dc > 0 ? 1 : -1;
+    const float boundary = step_c > 0 ? (float(c) + 1.0f) : float(c);
+    t_max_c = (boundary - gc0) / dc;
+    t_delta_c = float(step_c) / dc;
+  }
+  const int max_steps = nrows + ncols;
+  for (int s = 0; s < max_steps; ++s) {
+    if (r >= 0 && r < nrows && c >= 0 && c < ncols) {
+      int mr = r + g.sr, mc = c + g.sc;  // (r + start) % size with both operands in [0, size)
+      if (mr >= nrows) mr -= nrows;
+      if (mc >= ncols) mc -= ncols;
+      const int o = owned_storage(mr, mc, G);
+      if (o >= 0) {
+        const float t_exit = (t_max_c < t_max_r) ? t_max_c : t_max_r;  // std::min(t_max_r, t_max_c)
+        const float height = sz + ((1.0f < t_exit) ? 1.0f : t_exit) * dz;
+        const uint32_t h = ord(height);
+        // rc_min only ever decreases, so a value read from L2 that is already <= h settles it;
+        // a stale (larger) value merely costs one redundant atomic
+        const uint32_t seen = __hip_atomic_load(&rc_min[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (h < seen) atomicMin(&rc_min[o], h);
+      }
+    }
+    if (t_max_r < t_max_c) {
+      if (t_max_r >= 1.0f) break;
+      r += step_r;
+      t_max_r += t_delta_r;
+    } else {
+      if (t_max_c >= 1.0f) break;
+      c += step_c;
+      t_max_c += t_delta_c;
+    }
+  }
+}
+
+// voxelGrid(ANY) on its own (fdm_engine_voxel_any): sel[i] = picked point index if sorted position
+// i heads a run, else kNoIdx.  Output order of the filter == ascending i.
+__global__ __launch_bounds__(256) void k_voxel_select(unsigned n,
+                                                      const unsigned long long* __restrict__ keys,
+                                                      const uint32_t* __restrict__ idx,
+                                                      uint32_t* __restrict__ sel) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long key = keys[i];
+  const bool head = key != kInvalidVoxel && (i == 0 || keys[i - 1] != key);
+  sel[i] = head ? voxel_pick(keys, idx, i, n) : kNoIdx;
+}
+
+struct RayLayers {
+  const float* elevation;  // base + stride (record field or own array)
+  int elevation_stride;
+  float* logodds;          // _visibility_logodds
+  float* ray_min;          // raycasting (per-frame min ray height)
+  float* ghost;            // ghost_removal
+  float* rec;              // cell records (nullable) and their size in floats: clearAt wipes them
+  int rec_floats;
+};
+
+// One thread per stored cell: fold the observed evidence, publish the frame's min ray height,
+// resolve the ghost decision (raycasting.cpp:175-202), and leave the two scratch arrays clean.
+__global__ __launch_bounds__(256) void k_ray_resolve(const RayParams Q, const GeomConst G,
+                                                     DevState* __restrict__ st, const RayLayers L,
+                                                     float* const* __restrict__ layer_ptrs,
+                                                     int n_layer_ptrs, uint32_t* __restrict__ rc_cnt,
+                                                     uint32_t* __restrict__ rc_min, unsigned ncell) {
+  const DevGeom g = st->geom[Q.slot];
+  if (!ray_stage_runs(Q, st, g, G)) return;
+  const unsigned o = blockIdx.x * 256u + threadIdx.x;
+  if (o >= ncell) return;
+  const float nanv = __uint_as_float(0x7FC00000u);
+  const uint32_t cnt = rc_cnt[o];
+  const uint32_t hmin = rc_min[o];
+  if (cnt) rc_cnt[o] = 0u;
+  if (hmin != kRayEmpty) rc_min[o] = kRayEmpty;
+  const bool visited = hmin != kRayEmpty;
+  float lo = L.logodds[o];
+  bool lo_dirty = false;
+  if (cnt) {
+    if (isnan(lo)) lo = 0.0f;
+    for (uint32_t k = 0; k < cnt; ++k) {
+      const float a = lo + Q.l_obs;
+      const float nx = (Q.l_max < a) ? Q.l_max : a;  // std::min(a, l_max)
+      if (nx == lo) break;  // fixed point reached: the remaining folds change nothing
+      lo = nx;
+    }
+    lo_dirty = true;
+  }
+  float ray = nanv;  // map.clear(raycasting) + this frame's rays
+  if (visited) {
+    ray = unord(hmin);
+    const float elev = L.elevation[size_t(o) * L.elevation_stride];
+    if (!isnan(elev) && elev > ray + Q.conflict_thr) {
+      if (isnan(lo)) lo = 0.0f;
+      lo -= Q.l_ghost;
+      lo_dirty = true;
+      if (lo < Q.clear_thr) {  // ElevationMap::clearAt: NaN in every layer, then the marker
+        for (int k = 0; k < n_layer_ptrs; ++k) layer_ptrs[k][o] = nanv;
+        if (L.rec)
+          for (int f = 0; f < L.rec_floats; ++f) L.rec[size_t(o) * L.rec_floats + f] = nanv;
+        L.ghost[o] = 1.0f;
+        return;
+      }
+    }
+  }
+  L.ray_min[o] = ray;
+  if (lo_dirty) L.logodds[o] = lo;
+}
+
+}  // namespace fdm

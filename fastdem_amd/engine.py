@@ -203,6 +203,32 @@ class Engine:
         _ck(self._lib.fdm_engine_region_unpack(self._h, r0, c0, nr, nc, arr, len(names),
                                                C.c_void_p(dbuf_ptr)))
 
+    # -- raycasting stage --
+    def apply_raycasting(self, x, y, z, sensor_origin):
+        """fastdem::applyRaycasting(map, scan, sensor_origin, cfg.raycasting); host arrays, sync."""
+        x, y, z = _f32(x), _f32(y), _f32(z)
+        o = (C.c_float * 3)(*[float(v) for v in sensor_origin])
+        _ck(self._lib.fdm_engine_apply_raycasting(self._h, x.size, _ptr(x), _ptr(y), _ptr(z), o))
+
+    def apply_raycasting_device(self, x, y, z, sensor_origin):
+        o = (C.c_float * 3)(*[float(v) for v in sensor_origin])
+        _ck(self._lib.fdm_engine_apply_raycasting_device(self._h, x.numel(), _dptr(x), _dptr(y),
+                                                         _dptr(z), o))
+
+    def voxel_any(self, x, y, z, voxel_size):
+        """filters::voxelGrid(cloud, voxel_size, VoxelMode::ANY): original indices, output order."""
+        x, y, z = _f32(x), _f32(y), _f32(z)
+        out = np.empty(max(x.size, 1), dtype=np.uint32)
+        n = C.c_uint64(0)
+        _ck(self._lib.fdm_engine_voxel_any(self._h, x.size, _ptr(x), _ptr(y), _ptr(z),
+                                           float(voxel_size), _ptr(out), C.byref(n)))
+        return out[:n.value].copy()
+
+    def last_ray_ms(self):
+        ms = C.c_float(0)
+        _ck(self._lib.fdm_engine_last_ray_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
     # -- scan callbacks --
     def capture(self, preprocessed=True, rasterized=True):
         _ck(self._lib.fdm_engine_capture(self._h, int(preprocessed), int(rasterized)))

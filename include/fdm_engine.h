@@ -31,7 +31,7 @@ typedef struct fdm_engine fdm_engine;
 
 /* Mirrors fastdem::Config for this path, field for field
  * (config/fastdem.hpp:23-38, config/sensor_model.hpp:10-37, config/mapping.hpp:10-48).
- * config::Raycasting is out of scope. */
+ * The last six fields are config::Raycasting (config/postprocess.hpp:16-23). */
 typedef struct fdm_config {
   float z_min, z_max, range_min, range_max;     /* config::PointFilter */
   int32_t sensor_type;                          /* SensorType: 0 Constant, 1 LiDAR, 2 RGBD */
@@ -44,6 +44,9 @@ typedef struct fdm_config {
   float p2_dn[5];
   int32_t p2_elevation_marker;
   float p2_max_sample_count;
+  int32_t raycast_enabled;                      /* config::Raycasting::enabled (default 0) */
+  float rc_height_conflict_threshold, rc_log_odds_observed, rc_log_odds_ghost, rc_log_odds_max,
+      rc_clear_threshold;
 } fdm_config;
 
 /* nanogrid::GridMap geometry (length, resolution, position, circular-buffer start).
@@ -176,6 +179,33 @@ int fdm_engine_last_preprocessed(fdm_engine* e, uint64_t cap, float* x, float* y
                                  float* sigma_z2, uint64_t* n_out);
 int fdm_engine_last_rasterized(fdm_engine* e, uint64_t cap, float* x, float* y, float* z,
                                uint64_t* n_out);
+
+/* ---- Raycasting stage ----
+ * With cfg.raycast_enabled the integrate entry points also run step 3 of integrateImpl
+ * (fastdem.cpp:152-159) on the device: sensor origin = (T_world_base*T_base_sensor).translation(),
+ * voxelGrid(points, resolution, VoxelMode::ANY), applyRaycasting.  Layers `ghost_removal`,
+ * `raycasting`, `_visibility_logodds` appear as in raycasting.cpp:223-226.  A resolution outside
+ * voxelGrid's [0.001, 100] range makes integrate return FDM_ERR_INVALID (the reference throws,
+ * voxel_grid_impl.hpp:31-33).
+ *
+ * fastdem::applyRaycasting(map, scan, sensor_origin, cfg.raycasting) called directly
+ * (postprocess/raycasting.hpp:47-49; tests/test_postprocess.cpp:73-190): `scan` is used as given,
+ * no voxel filter.  A no-op when raycasting is disabled in the config, n == 0, or the sensor origin
+ * lies outside the map.  Host arrays, synchronous / device arrays, enqueue-only. */
+int fdm_engine_apply_raycasting(fdm_engine* e, uint64_t n, const float* x, const float* y,
+                                const float* z, const float sensor_origin[3]);
+int fdm_engine_apply_raycasting_device(fdm_engine* e, uint64_t n, const float* d_x, const float* d_y,
+                                       const float* d_z, const float sensor_origin[3]);
+/* nanopcl::filters::voxelGrid(cloud, voxel_size, VoxelMode::ANY) (voxel_grid_impl.hpp:30-60,171-189)
+ * on the device: writes the ORIGINAL indices of the kept points, in the filter's output order
+ * (ascending voxel key), to out_idx (capacity n) and their count to n_out.  Ties inside a voxel are
+ * in original point order (the reference: whatever std::sort leaves — see DESIGN.md).
+ * FDM_ERR_INVALID for a voxel_size outside [0.001, 100]. */
+int fdm_engine_voxel_any(fdm_engine* e, uint64_t n, const float* x, const float* y, const float* z,
+                         float voxel_size, uint32_t* out_idx, uint64_t* n_out);
+/* HIP-event duration of the last scan's raycasting stage (keys + sort + rays + resolve), ms;
+ * needs fdm_engine_enable_profile. */
+int fdm_engine_last_ray_ms(fdm_engine* e, float* ms);
 
 /* Parity / measurement instrumentation (not in the reference). */
 int fdm_engine_enable_cell_ids(fdm_engine* e, int on);

@@ -40,7 +40,7 @@ def test_python_prototypes_cover_the_header():
 def test_config_struct_layout_and_defaults():
     from fastdem_amd import capi
     cfg = capi.default_config()
-    assert ctypes.sizeof(capi.FdmConfig) == 4 * 4 + 4 + 4 * 7 + 4 * 2 + 4 * 3 + 4 * 5 + 4 + 4
+    assert ctypes.sizeof(capi.FdmConfig) == 4 * 4 + 4 + 4 * 7 + 4 * 2 + 4 * 3 + 4 * 5 + 4 + 4 + 4 * 6
     # Config{} defaults (config/fastdem.hpp:23-28, mapping.hpp:24-48, sensor_model.hpp:19-37)
     assert cfg.mode == 0 and cfg.estimation_type == 0 and cfg.sensor_type == 1
     assert cfg.range_min == 0.0 and cfg.z_max > 3e38 and cfg.z_min < -3e38

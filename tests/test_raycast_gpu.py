@@ -1,0 +1,357 @@
+"""Raycasting stage of the HIP engine, through the C ABI, against the CPU oracle.
+
+* the reference's own raycasting tests (fastdem/tests/test_postprocess.cpp:73-190) re-run on the engine
+* voxelGrid(ANY): selected point indices bit-exact vs the oracle's stable-tie variant, and a valid
+  "ANY" outcome vs the reference-literal std::sort variant (same voxels, a member of each)
+* applyRaycasting and integrate()+raycasting: every layer (incl. `raycasting`, `_visibility_logodds`,
+  `ghost_removal`, and the clearAt NaNs in the estimator layers) identical to the oracle
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_layers_equal, pair, run_both, same_geometry
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def ray_cfg(**kw):
+    def fill(cfg):
+        cfg.raycast_enabled = 1
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        return cfg
+    return fill
+
+
+def post_pair(gpu, R, **kw):
+    """PostprocessTest fixture: 10x10 m @ 0.5 (test_postprocess.cpp:24-36), engine + oracle."""
+    return pair(gpu, R, 10.0, 10.0, 0.5, ray_cfg(**kw))
+
+
+def set_cell(objs, name, rc, v):
+    for o in objs:
+        a = o.layer(name)
+        a[rc] = v
+        o.set_layer(name, a)
+
+
+def both(objs, fn):
+    return [fn(o) for o in objs]
+
+
+ORIGIN = [0.0, 0.0, 5.0]
+
+
+# ------------------------------------------------- the reference's own tests ----
+class TestReferenceRaycastingTestsOnEngine:
+    def test_creates_layers(self, gpu, R):  # test_postprocess.cpp:75-92
+        eng, ref = post_pair(gpu, R)
+        _, c = ref.get_index(0.0, 0.0)
+        set_cell((eng, ref), "elevation", c, 1.0)
+        both((eng, ref), lambda o: o.apply_raycasting([1.0], [0.0], [0.5], ORIGIN))
+        for n in ("ghost_removal", "raycasting", "_visibility_logodds"):
+            assert eng.exists(n)
+        assert_layers_equal(eng, ref)
+
+    def test_clears_ghost_cell(self, gpu, R):  # :94-117
+        eng, ref = post_pair(gpu, R, rc_height_conflict_threshold=0.05, rc_log_odds_ghost=0.5,
+                             rc_clear_threshold=-0.4)
+        _, g = ref.get_index(2.0, 0.0)
+        set_cell((eng, ref), "elevation", g, 10.0)
+        both((eng, ref), lambda o: o.apply_raycasting([4.0], [0.0], [0.0], ORIGIN))
+        assert np.isnan(eng.layer("elevation")[g]) and eng.layer("ghost_removal")[g] == F32(1.0)
+        assert_layers_equal(eng, ref)
+
+    def test_observed_cell_protected(self, gpu, R):  # :119-146
+        eng, ref = post_pair(gpu, R, rc_log_odds_observed=0.8, rc_log_odds_ghost=0.5, rc_clear_threshold=-0.4)
+        _, c = ref.get_index(2.0, 0.0)
+        set_cell((eng, ref), "elevation", c, 2.0)
+        both((eng, ref), lambda o: o.apply_raycasting([4.0, 2.0], [0.0, 0.0], [0.0, 0.3], ORIGIN))
+        assert not np.isnan(eng.layer("elevation")[c])
+        assert_layers_equal(eng, ref)
+
+    def test_ghost_requires_accumulation(self, gpu, R):  # :148-175
+        eng, ref = post_pair(gpu, R, rc_log_odds_ghost=0.2, rc_clear_threshold=-0.9)
+        _, g = ref.get_index(2.0, 0.0)
+        for _ in range(4):
+            set_cell((eng, ref), "elevation", g, 10.0)
+            both((eng, ref), lambda o: o.apply_raycasting([4.0], [0.0], [0.0], ORIGIN))
+        assert not np.isnan(eng.layer("elevation")[g])
+        assert_layers_equal(eng, ref)
+        both((eng, ref), lambda o: o.apply_raycasting([4.0], [0.0], [0.0], ORIGIN))
+        assert np.isnan(eng.layer("elevation")[g])
+        assert_layers_equal(eng, ref)
+
+    def test_disabled_is_noop(self, gpu, R):  # :177-190
+        eng, ref = post_pair(gpu, R, raycast_enabled=0)
+        both((eng, ref), lambda o: o.apply_raycasting([1.0], [0.0], [0.5], ORIGIN))
+        for n in ("ghost_removal", "raycasting", "_visibility_logodds"):
+            assert not eng.exists(n)
+
+
+# --------------------------------------------------------------- voxelGrid ANY ----
+def check_voxel(gpu, R, x, y, z, size):
+    eng = gpu.Engine(4.0, 4.0, 0.5)
+    sel = eng.voxel_any(x, y, z, size)
+    want = R.voxel_any(x, y, z, size, stable=True)
+    assert np.array_equal(sel, want), f"{(sel != want).sum() if sel.size == want.size else 'size'} differ"
+    # vs the reference-literal std::sort variant: same voxels, one member of each
+    lit = R.voxel_any(x, y, z, size, stable=False)
+    assert lit.size == sel.size
+    inv = F32(1.0) / F32(size)
+    xs, ys, zs = (np.asarray(v, dtype=F32) for v in (x, y, z))
+    for a in (xs, ys, zs):
+        ka, kb = np.floor(a[sel] * inv), np.floor(a[lit] * inv)
+        assert np.array_equal(ka, kb)
+    return sel
+
+
+class TestVoxelGridAny:
+    def test_random_cloud(self, gpu, R):
+        rng = np.random.default_rng(3)
+        n = 200_000
+        x, y, z = (rng.uniform(-6, 6, n).astype(F32) for _ in range(3))
+        sel = check_voxel(gpu, R, x, y, z, 0.25)
+        assert 1000 < sel.size < n
+
+    def test_dense_voxels_and_long_runs(self, gpu, R):
+        rng = np.random.default_rng(4)
+        n = 100_000  # ~100 voxels: runs of ~1000 points exercise the bisection of voxel_pick
+        x, y = (rng.uniform(0, 1, n).astype(F32) for _ in range(2))
+        z = np.zeros(n, dtype=F32)
+        check_voxel(gpu, R, x, y, z, 0.1)
+
+    def test_everything_in_one_voxel(self, gpu, R):
+        n = 70_001
+        x = np.full(n, 0.01, dtype=F32)
+        sel = check_voxel(gpu, R, x, x, x, 1.0)
+        assert sel.size == 1 and sel[0] == (n * 7) % n
+
+    def test_nonfinite_points_are_dropped(self, gpu, R):  # voxel_grid_impl.hpp:52-54
+        x = np.array([1.0, np.nan, 4.0, np.inf, 1.01, -np.inf], dtype=F32)
+        y = np.array([2.0, 0.0, 5.0, 0.0, 2.01, 0.0], dtype=F32)
+        z = np.array([3.0, 0.0, 6.0, 0.0, 3.01, 0.0], dtype=F32)
+        sel = check_voxel(gpu, R, x, y, z, 1.0)
+        assert set(sel) <= {0, 2, 4} and sel.size == 2
+
+    def test_single_empty_and_range(self, gpu, R):  # test_filters.cpp:786-798, voxel_grid_impl.hpp:31-33
+        eng = gpu.Engine(4.0, 4.0, 0.5)
+        assert eng.voxel_any([], [], [], 1.0).size == 0
+        assert list(eng.voxel_any([1.0], [2.0], [3.0], 1.0)) == [0]
+        for bad in (0.0005, 100.5):
+            with pytest.raises(gpu.EngineError):
+                eng.voxel_any([0.0], [0.0], [0.0], bad)
+
+    def test_clamped_and_negative_coordinates(self, gpu, R):  # test_voxel.cpp:53-85
+        x = np.array([-5.5, 2.0e6, -2.0e6, 3.0e9, -3.0e9, -0.05, 0.05], dtype=F32)
+        y = np.array([-10.3, 0.0, 0.0, 0.0, 0.0, -0.05, 0.05], dtype=F32)
+        z = np.array([-0.1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0], dtype=F32)
+        check_voxel(gpu, R, x, y, z, 1.0)
+
+    def test_preprocessed_lidar_scan(self, gpu, R):
+        wl = gpu.synth.vlp16(n_scans=1)
+        s = wl.scan(0)
+        check_voxel(gpu, R, s["x"], s["y"], s["z"], 0.1)
+
+
+# ------------------------------------------------------------ applyRaycasting ----
+def random_scene(rng, n, span, zlo, zhi):
+    x, y = (rng.uniform(-span, span, n).astype(F32) for _ in range(2))
+    z = rng.uniform(zlo, zhi, n).astype(F32)
+    return x, y, z
+
+
+class TestApplyRaycasting:
+    def test_random_cloud_on_a_populated_map(self, gpu, R):
+        rng = np.random.default_rng(11)
+        eng, ref = pair(gpu, R, 20.0, 20.0, 0.1, ray_cfg(rc_log_odds_ghost=0.6, rc_clear_threshold=-1.0))
+        elev = rng.uniform(-0.5, 2.5, (eng.rows, eng.cols)).astype(F32)
+        elev[rng.uniform(size=elev.shape) < 0.3] = np.nan
+        both((eng, ref), lambda o: o.set_layer("elevation", elev))
+        for frame in range(3):  # logodds accumulates; some cells clear on frame 2
+            x, y, z = random_scene(rng, 30_000, 12.0, -0.5, 3.0)  # some targets outside the map, some above the sensor
+            both((eng, ref), lambda o: o.apply_raycasting(x, y, z, [0.3, -0.2, 2.0]))
+            assert_layers_equal(eng, ref)
+        st = ref.last_ray_stats()
+        assert st["n_cleared"] > 0 and st["n_conflicts"] > st["n_cleared"]
+        assert np.nansum(eng.layer("ghost_removal")) > 0
+
+    def test_duplicate_points_fold_observed_evidence(self, gpu, R):
+        eng, ref = post_pair(gpu, R, rc_log_odds_observed=0.7, rc_log_odds_max=2.0)
+        x = np.full(5, 1.0, dtype=F32)
+        both((eng, ref), lambda o: o.apply_raycasting(x, x * 0, x * 0 + 6.0, ORIGIN))  # 5 x +0.7, clamped at 2
+        _, c = ref.get_index(1.0, 0.0)
+        assert eng.layer("_visibility_logodds")[c] == F32(2.0)
+        assert_layers_equal(eng, ref)
+
+    def test_wrapped_buffer_and_moved_map(self, gpu, R):
+        rng = np.random.default_rng(12)
+        eng, ref = pair(gpu, R, 12.0, 12.0, 0.1, ray_cfg())
+        both((eng, ref), lambda o: o.move(1.7, -2.3))
+        assert same_geometry(eng.geometry(), ref.geometry())
+        elev = rng.uniform(0.0, 2.0, (eng.rows, eng.cols)).astype(F32)
+        both((eng, ref), lambda o: o.set_layer("elevation", elev))
+        x, y, z = random_scene(rng, 20_000, 8.0, -0.2, 1.5)
+        both((eng, ref), lambda o: o.apply_raycasting(x + 1.7, y - 2.3, z, [1.7, -2.3, 1.8]))
+        assert np.isfinite(eng.layer("raycasting")).sum() > 1000
+        assert_layers_equal(eng, ref)
+
+    def test_sensor_outside_map_is_noop(self, gpu, R):  # raycasting.cpp:217-220
+        eng, ref = post_pair(gpu, R)
+        both((eng, ref), lambda o: o.apply_raycasting([1.0], [0.0], [0.5], [50.0, 0.0, 5.0]))
+        assert not eng.exists("raycasting") and not ref.exists("raycasting")
+        assert_layers_equal(eng, ref)
+
+    def test_device_entry_point(self, gpu, R):
+        import torch
+        rng = np.random.default_rng(13)
+        eng, ref = post_pair(gpu, R)
+        x, y, z = random_scene(rng, 5000, 6.0, -1.0, 4.0)
+        dx, dy, dz = (torch.from_numpy(v).cuda() for v in (x, y, z))
+        eng.apply_raycasting_device(dx, dy, dz, ORIGIN)
+        eng.sync()
+        ref.apply_raycasting(x, y, z, ORIGIN)
+        assert_layers_equal(eng, ref)
+
+
+# ------------------------------------------------- integrate() with raycasting ----
+def run_ray_workload(gpu, R, wl, n_scans, ghosts=None, **rc):
+    def fill(cfg):
+        wl.apply_to(cfg)
+        return ray_cfg(**rc)(cfg)
+    eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, fill)
+    cleared = 0
+    for k in range(n_scans):
+        if ghosts is not None and k == 1:  # plant phantom obstacles after the first scan
+            both((eng, ref), ghosts)
+        run_both(eng, ref, wl.scan(k), wl.T_base_sensor, wl.pose(k))
+        assert_layers_equal(eng, ref)
+        assert same_geometry(eng.geometry(), ref.geometry())
+        cleared += ref.last_ray_stats()["n_cleared"]
+    return eng, ref, cleared
+
+
+def plant_ghost_block(o):
+    e = o.layer("elevation")
+    r, c = e.shape
+    e[r // 2 + 8: r // 2 + 20, c // 2 - 6: c // 2 + 6] = 1.5  # phantom boxes the rays pass through,
+    e[r // 2 - 20: r // 2 - 8, c // 2 - 6: c // 2 + 6] = 1.5  # behind and ahead of the robot
+    o.set_layer("elevation", e)
+
+
+class TestIntegrateWithRaycasting:
+    def test_c2_vlp16_kalman_local(self, gpu, R):
+        wl = gpu.synth.vlp16(n_scans=8)
+        eng, ref, cleared = run_ray_workload(gpu, R, wl, 8, ghosts=plant_ghost_block,
+                                             rc_log_odds_ghost=0.6, rc_clear_threshold=-1.0)
+        assert cleared > 0 and np.nansum(eng.layer("ghost_removal")) > 0
+        assert {"ghost_removal", "raycasting", "_visibility_logodds"} <= set(eng.layers())
+
+    def test_c3_rgbd_p2_records_cleared(self, gpu, R):
+        """P2 cell records (128 B) wiped by clearAt.  The depth image observes every cell it can ray
+        through except the strip between the camera and the nearest ground hit: ghosts go there."""
+        def plant_under_camera(o):
+            e = o.layer("elevation")
+            r, c = e.shape
+            e[r // 2 - 12: r // 2 + 3, c // 2 - 4: c // 2 + 5] = 1.5
+            o.set_layer("elevation", e)
+        wl = gpu.synth.rgbd(n_scans=4)
+        eng, ref, cleared = run_ray_workload(gpu, R, wl, 4, ghosts=plant_under_camera,
+                                             rc_log_odds_ghost=1.2, rc_clear_threshold=-1.0)
+        assert cleared > 0
+        g = eng.layer("ghost_removal") == 1.0
+        assert g.any() and np.isnan(eng.layer("_p2_n0")[g]).all()
+
+    def test_c4_lidar128_reduced(self, gpu, R):
+        wl = gpu.synth.lidar128(n_scans=3, n_az=2048)
+        run_ray_workload(gpu, R, wl, 3, ghosts=plant_ghost_block, rc_log_odds_ghost=1.2)
+
+    def test_per_layer_storage(self, gpu, R):
+        wl = gpu.synth.vlp16(n_scans=4)
+
+        def fill(cfg):
+            wl.apply_to(cfg)
+            return ray_cfg(rc_log_odds_ghost=1.2)(cfg)
+        ce, cr = gpu.capi.default_config(), R.default_config()
+        fill(ce), fill(cr)
+        eng = gpu.Engine(wl.width, wl.height, wl.resolution, ce)
+        eng.set_option("records", 0)
+        eng.set_config(ce)
+        ref = R.RefEngine(wl.width, wl.height, wl.resolution, cr)
+        for k in range(4):
+            if k == 1:
+                both((eng, ref), plant_ghost_block)
+            run_both(eng, ref, wl.scan(k), wl.T_base_sensor, wl.pose(k), check_ids=False)
+            assert_layers_equal(eng, ref)
+
+    def test_global_mode_sensor_leaves_the_map(self, gpu, R):
+        """GLOBAL map at the origin; the robot drives out of it: while the sensor is outside the
+        stage must not run (raycasting.cpp:217-220) — layers appear only once it has been inside."""
+        wl = gpu.synth.vlp16(n_scans=1)
+
+        def fill(cfg):
+            wl.apply_to(cfg)
+            cfg.mode = 1
+            return ray_cfg()(cfg)
+        eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, fill)
+        s = wl.scan(0)
+        far = np.eye(4)
+        far[0, 3] = 12.0  # sensor 12 m from the centre of a 15 m map: outside
+        run_both(eng, ref, s, wl.T_base_sensor, far)
+        assert not eng.exists("raycasting")
+        assert_layers_equal(eng, ref)
+        run_both(eng, ref, s, wl.T_base_sensor, np.eye(4))
+        assert eng.exists("raycasting")
+        assert_layers_equal(eng, ref)
+        run_both(eng, ref, s, wl.T_base_sensor, far)  # outside again: the frame layer keeps its values
+        assert_layers_equal(eng, ref)
+
+    def test_everything_filtered_skips_the_stage(self, gpu, R):
+        wl = gpu.synth.vlp16(n_scans=1)
+
+        def fill(cfg):
+            wl.apply_to(cfg)
+            cfg.z_min, cfg.z_max = 100.0, 101.0
+            return ray_cfg()(cfg)
+        eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, fill)
+        rc, _ = run_both(eng, ref, wl.scan(0), wl.T_base_sensor, wl.pose(0))
+        assert rc == 2 and not eng.exists("raycasting")
+        assert_layers_equal(eng, ref)
+
+    def test_tiled_engines_reassemble(self, gpu, R):
+        """2x2 spatial tiles of a GLOBAL map, every tile sees the whole scan: the stage needs no
+        exchange (rays are traced in the global grid, each tile keeps its own cells)."""
+        wl = gpu.synth.global_map(n_scans=3, size_m=60.0, n_az=1024, radius=10.0)
+
+        def fill(cfg):
+            wl.apply_to(cfg)
+            return ray_cfg(rc_log_odds_ghost=1.2)(cfg)
+        eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, fill)
+        rows, cols = eng.rows, eng.cols
+        hr, hc = rows // 2, cols // 2
+        tiles = []
+        for tr in range(2):
+            for tc in range(2):
+                r0, c0 = tr * hr, tc * hc
+                t = gpu.Engine(wl.width, wl.height, wl.resolution, fill(gpu.capi.default_config()),
+                               tile=(r0, c0, hr, hc, r0, c0, hr, hc))
+                tiles.append((r0, c0, t))
+        for k in range(3):
+            if k == 1:
+                both((eng, ref), plant_ghost_block)
+                for r0, c0, t in tiles:
+                    e = eng.layer("elevation")
+                    t.set_layer("elevation", e[r0:r0 + hr, c0:c0 + hc])
+            s = wl.scan(k)
+            run_both(eng, ref, s, wl.T_base_sensor, wl.pose(k))
+            for _, _, t in tiles:
+                t.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k),
+                            intensity=s.get("intensity"))
+        assert_layers_equal(eng, ref)
+        for name in eng.layers():
+            full = eng.layer(name)
+            for r0, c0, t in tiles:
+                a, b = t.layer(name), full[r0:r0 + hr, c0:c0 + hc]
+                assert np.array_equal(np.isnan(a), np.isnan(b)), name
+                assert np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)]), name
