@@ -35,6 +35,16 @@ class FdmConfig(C.Structure):
     ]
 
 
+class FdmRaycastConfig(C.Structure):
+    """fdm_raycast_config == config::Raycasting (config/postprocess.hpp:16-23)."""
+
+    _fields_ = [
+        ("enabled", C.c_int32),
+        ("height_conflict_threshold", C.c_float), ("log_odds_observed", C.c_float),
+        ("log_odds_ghost", C.c_float), ("log_odds_max", C.c_float), ("clear_threshold", C.c_float),
+    ]
+
+
 class FdmGeometry(C.Structure):
     _fields_ = [
         ("length_x", C.c_double), ("length_y", C.c_double), ("resolution", C.c_double),
@@ -112,8 +122,9 @@ PROTOTYPES = {
     "fdm_engine_capture": (C.c_int, [_P, C.c_int, C.c_int]),
     "fdm_engine_last_preprocessed": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, C.POINTER(C.c_uint64)]),
     "fdm_engine_last_rasterized": (C.c_int, [_P, C.c_uint64, _P, _P, _P, C.POINTER(C.c_uint64)]),
-    "fdm_engine_apply_raycasting": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _F]),
-    "fdm_engine_apply_raycasting_device": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _F]),
+    "fdm_engine_apply_raycasting": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _F, C.POINTER(FdmRaycastConfig)]),
+    "fdm_engine_apply_raycasting_device": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _F,
+                                                     C.POINTER(FdmRaycastConfig)]),
     "fdm_engine_voxel_any": (C.c_int, [_P, C.c_uint64, _P, _P, _P, C.c_float, _P, C.POINTER(C.c_uint64)]),
     "fdm_engine_last_ray_ms": (C.c_int, [_P, _F]),
     "fdm_engine_enable_cell_ids": (C.c_int, [_P, C.c_int]),

@@ -1,6 +1,6 @@
 // fastdem/config/postprocess.hpp — only config::Raycasting is part of fastdem::Config
-// (fastdem/include/fastdem/config/postprocess.hpp:16-23).  Raycasting itself is the "next" row
-// f1 of SURVEY.md §8 and is not executed by this engine yet; the struct keeps the surface.
+// (fastdem/include/fastdem/config/postprocess.hpp:16-23); the stage runs on the device
+// (fdm_engine.h raycasting section).
 #pragma once
 namespace fastdem::config {
 struct Raycasting {

@@ -14,6 +14,7 @@
 #include "fastdem/elevation_map.hpp"
 #include "fastdem/mapping/elevation_mapping.hpp"
 #include "fastdem/point_types.hpp"
+#include "fastdem/postprocess/raycasting.hpp"
 #include "fastdem/sensors/sensor_model.hpp"
 #include "fastdem/transform_interface.hpp"
 
@@ -62,7 +63,7 @@ class FastDEM {
     return *this;
   }
   FastDEM& enableRaycasting(bool enabled = true) noexcept {
-    cfg_.raycasting.enabled = enabled;  // accepted, not executed by the engine yet
+    cfg_.raycasting.enabled = enabled;  // step 3 of integrateImpl (fastdem.cpp:152-159), on the device
     return *this;
   }
   FastDEM& setCalibrationProvider(std::shared_ptr<Calibration> c) noexcept {

@@ -39,6 +39,12 @@ inline fdm_config toEngineConfig(const Config& c) {
   f.p2_dn[4] = c.mapping.p2.dn4;
   f.p2_elevation_marker = c.mapping.p2.elevation_marker;
   f.p2_max_sample_count = c.mapping.p2.max_sample_count;
+  f.raycast_enabled = c.raycasting.enabled ? 1 : 0;
+  f.rc_height_conflict_threshold = c.raycasting.height_conflict_threshold;
+  f.rc_log_odds_observed = c.raycasting.log_odds_observed;
+  f.rc_log_odds_ghost = c.raycasting.log_odds_ghost;
+  f.rc_log_odds_max = c.raycasting.log_odds_max;
+  f.rc_clear_threshold = c.raycasting.clear_threshold;
   return f;
 }
 inline void ck(int rc, const char* what) {

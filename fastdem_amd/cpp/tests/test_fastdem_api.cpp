@@ -1,7 +1,8 @@
 // The reference's own API-level tests re-expressed against the MI355X engine through the C++
 // mirror of fastdem::FastDEM / ElevationMap (each TEST cites the gtest it restates).  Needs a GPU.
 //   fastdem/tests/test_elevation_map.cpp, test_fastdem_integration.cpp, test_online_mode.cpp,
-//   test_dual_layer.cpp, test_config.cpp (validation), test_sensor_models.cpp (host classes)
+//   test_dual_layer.cpp, test_config.cpp (validation), test_sensor_models.cpp (host classes),
+//   test_postprocess.cpp:73-190 (raycasting)
 #include <cmath>
 #include <memory>
 #include <optional>
@@ -391,6 +392,105 @@ TEST(DualLayer, ElevationMaxReflectsTrueMaxAndQuantile) {  // :145-186
   ASSERT_TRUE(g.map.getIndex(nanogrid::Position(0, 0), idx));
   EXPECT_NEAR(g.map.at(layer::elevation, idx), 0.0f, 0.5f);
   EXPECT_NEAR(g.map.at(layer::obstacle, idx), 5.0f, 0.1f);
+}
+
+// ------------------------------------------------ test_postprocess.cpp (raycasting) ----
+namespace {
+struct PostFixture {  // test_postprocess.cpp:24-36
+  ElevationMap map;
+  PostFixture() { map.setGeometry(10.0f, 10.0f, 0.5f); }
+  nanogrid::Index at(double x, double y) const {
+    nanogrid::Index idx;
+    map.getIndex(nanogrid::Position(x, y), idx);
+    return idx;
+  }
+};
+}  // namespace
+TEST(Raycasting, CreatesLayers) {  // :75-92
+  PostFixture f;
+  f.map.at(layer::elevation, f.at(0.0, 0.0)) = 1.0f;
+  PointCloud cloud;
+  cloud.add(1.0f, 0.0f, 0.5f);
+  config::Raycasting cfg;
+  cfg.enabled = true;
+  applyRaycasting(f.map, cloud, Eigen::Vector3f(0.0f, 0.0f, 5.0f), cfg);
+  EXPECT_TRUE(f.map.exists(layer::ghost_removal));
+  EXPECT_TRUE(f.map.exists(layer::raycasting));
+  EXPECT_TRUE(f.map.exists(layer::visibility_logodds));
+}
+TEST(Raycasting, ClearsGhostCell) {  // :94-117
+  PostFixture f;
+  const nanogrid::Index ghost = f.at(2.0, 0.0);
+  f.map.at(layer::elevation, ghost) = 10.0f;
+  PointCloud cloud;
+  cloud.add(4.0f, 0.0f, 0.0f);
+  config::Raycasting cfg;
+  cfg.enabled = true;
+  cfg.height_conflict_threshold = 0.05f;
+  cfg.log_odds_ghost = 0.5f;
+  cfg.clear_threshold = -0.4f;
+  applyRaycasting(f.map, cloud, Eigen::Vector3f(0.0f, 0.0f, 5.0f), cfg);
+  EXPECT_TRUE(std::isnan(f.map.at(layer::elevation, ghost)));
+  EXPECT_FLOAT_EQ(f.map.at(layer::ghost_removal, ghost), 1.0f);
+}
+TEST(Raycasting, ObservedCellProtected) {  // :119-146
+  PostFixture f;
+  const nanogrid::Index cell = f.at(2.0, 0.0);
+  f.map.at(layer::elevation, cell) = 2.0f;
+  PointCloud cloud;
+  cloud.add(4.0f, 0.0f, 0.0f);
+  cloud.add(2.0f, 0.0f, 0.3f);
+  config::Raycasting cfg;
+  cfg.enabled = true;
+  cfg.log_odds_observed = 0.8f;
+  cfg.log_odds_ghost = 0.5f;
+  cfg.clear_threshold = -0.4f;
+  applyRaycasting(f.map, cloud, Eigen::Vector3f(0.0f, 0.0f, 5.0f), cfg);
+  EXPECT_FALSE(std::isnan(f.map.at(layer::elevation, cell)));
+}
+TEST(Raycasting, GhostRequiresAccumulation) {  // :148-175
+  PostFixture f;
+  const nanogrid::Index ghost = f.at(2.0, 0.0);
+  PointCloud cloud;
+  cloud.add(4.0f, 0.0f, 0.0f);
+  config::Raycasting cfg;
+  cfg.enabled = true;
+  cfg.log_odds_ghost = 0.2f;
+  cfg.clear_threshold = -0.9f;
+  for (int i = 0; i < 4; ++i) {
+    f.map.at(layer::elevation, ghost) = 10.0f;
+    applyRaycasting(f.map, cloud, Eigen::Vector3f(0.0f, 0.0f, 5.0f), cfg);
+  }
+  EXPECT_FALSE(std::isnan(f.map.at(layer::elevation, ghost)));
+  applyRaycasting(f.map, cloud, Eigen::Vector3f(0.0f, 0.0f, 5.0f), cfg);
+  EXPECT_TRUE(std::isnan(f.map.at(layer::elevation, ghost)));
+}
+TEST(Raycasting, DisabledIsNoOp) {  // :177-190
+  PostFixture f;
+  PointCloud cloud;
+  cloud.add(1.0f, 0.0f, 0.5f);
+  config::Raycasting cfg;
+  cfg.enabled = false;
+  applyRaycasting(f.map, cloud, Eigen::Vector3f(0.0f, 0.0f, 5.0f), cfg);
+  EXPECT_FALSE(f.map.exists(layer::ghost_removal));
+  EXPECT_FALSE(f.map.exists(layer::raycasting));
+  EXPECT_FALSE(f.map.exists(layer::visibility_logodds));
+}
+TEST(Raycasting, EnabledThroughIntegrate) {  // fastdem.cpp:152-159, default.yaml:40-41
+  Fixture f;
+  FastDEM mapper(f.map);
+  mapper.setSensorModel(SensorType::Constant).enableRaycasting(true);
+  f.T_base_sensor.translation() = Eigen::Vector3d(0.0, 0.0, 5.0);
+  PointCloud cloud;
+  cloud.add(4.0f, 0.0f, -5.0f);  // ground point 4 m ahead, seen from 5 m up
+  ASSERT_TRUE(mapper.integrate(cloud, f.T_base_sensor, f.T_world_base));
+  EXPECT_TRUE(f.map.exists(layer::raycasting));
+  nanogrid::Index mid;
+  ASSERT_TRUE(f.map.getIndex(nanogrid::Position(2.0, 0.0), mid));
+  EXPECT_NEAR(f.map.at(layer::raycasting, mid), 2.5f, 1e-4f);  // x = 2.0 is the far edge of its cell: t = 0.5
+  nanogrid::Index hit;
+  ASSERT_TRUE(f.map.getIndex(nanogrid::Position(4.0, 0.0), hit));
+  EXPECT_FLOAT_EQ(f.map.at(layer::visibility_logodds, hit), 0.4f);
 }
 
 // ---------------------------------------------------------- test_config.cpp (validation) ----

@@ -50,7 +50,8 @@ struct DevState {
   DevFlags flags[4];
   DevObst obst[4];
   unsigned sticky;  // bit0: intensity layer written, bit1: colour layer written, bit2: raycasting ran
-  unsigned pad[3];
+  unsigned ray_count;  // rays queued by k_ray_compact for k_ray; k_ray_resolve puts it back to 0
+  unsigned pad1, pad2;
 };
 
 struct GeomConst {

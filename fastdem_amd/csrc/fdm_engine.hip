@@ -118,6 +118,7 @@ struct fdm_engine {
   size_t sort_tmp_bytes = 0;
   hipEvent_t ev_ray[2] = {nullptr, nullptr};
   bool ray_timed = false;
+  int dbg_ray = 0;
 };
 
 namespace {
@@ -371,7 +372,7 @@ int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slo
   if (int rc = ensure_voxel_buffers(e, n)) return rc;
   const float inv = 1.0f / voxel_size;  // voxel_grid_impl.hpp:46
   hipLaunchKernelGGL(k_voxel_keys, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, inv, flag_slot,
-                     e->d_state, dx, dy, dz, e->vkeys[0], e->vidx[0]);
+                     e->d_state, dx, dy, dz, e->vkeys[0], e->vidx[0], e->vsel);
   HIPCK(hipGetLastError());
   size_t bytes = e->sort_tmp_bytes;
   HIPCK(rocprim::radix_sort_pairs(e->sort_tmp, bytes, e->vkeys[0], e->vkeys[1], e->vidx[0], e->vidx[1],
@@ -379,19 +380,32 @@ int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slo
   return FDM_OK;
 }
 
-RayParams make_ray_params(fdm_engine* e, const float* origin, unsigned n, int slot, int flag_slot) {
+fdm_raycast_config ray_config_of(const fdm_config& c) {
+  fdm_raycast_config r;
+  r.enabled = c.raycast_enabled;
+  r.height_conflict_threshold = c.rc_height_conflict_threshold;
+  r.log_odds_observed = c.rc_log_odds_observed;
+  r.log_odds_ghost = c.rc_log_odds_ghost;
+  r.log_odds_max = c.rc_log_odds_max;
+  r.clear_threshold = c.rc_clear_threshold;
+  return r;
+}
+
+RayParams make_ray_params(fdm_engine* e, const fdm_raycast_config& c, const float* origin, unsigned n,
+                          int slot, int flag_slot) {
   RayParams Q{};
   Q.ox = origin[0]; Q.oy = origin[1]; Q.oz = origin[2];
-  Q.l_obs = e->cfg.rc_log_odds_observed;
-  Q.l_ghost = e->cfg.rc_log_odds_ghost;
-  Q.l_max = e->cfg.rc_log_odds_max;
-  Q.clear_thr = e->cfg.rc_clear_threshold;
-  Q.conflict_thr = e->cfg.rc_height_conflict_threshold;
+  Q.l_obs = c.log_odds_observed;
+  Q.l_ghost = c.log_odds_ghost;
+  Q.l_max = c.log_odds_max;
+  Q.clear_thr = c.clear_threshold;
+  Q.conflict_thr = c.height_conflict_threshold;
   Q.resolution = static_cast<float>(e->G.res);
   Q.inv_voxel = 1.0f / Q.resolution;
   Q.n = n;
   Q.slot = slot;
   Q.flag_slot = flag_slot;
+  Q.dbg = e->dbg_ray;
   return Q;
 }
 
@@ -411,13 +425,25 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float
   L.rec = e->d_rec;
   L.rec_floats = e->rec_floats;
   const unsigned blocks = (Q.n + 255u) / 256u;
-  if (voxel)
-    hipLaunchKernelGGL(k_ray<true>, dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx, dy, dz,
-                       e->vkeys[1], e->vidx[1], e->rc_cnt, e->rc_min);
-  else
-    hipLaunchKernelGGL(k_ray<false>, dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx, dy,
-                       dz, static_cast<const unsigned long long*>(nullptr),
-                       static_cast<const uint32_t*>(nullptr), e->rc_cnt, e->rc_min);
+  if ((rc = ensure_voxel_buffers(e, Q.n))) return rc;  // vidx[0] doubles as the ray queue
+  uint32_t* ray_list = e->vidx[0];
+  if (voxel) {
+    hipLaunchKernelGGL(k_voxel_mark, dim3(blocks), dim3(256), 0, e->stream, Q.n, e->vkeys[1], e->vidx[1],
+                       e->vsel);
+    hipLaunchKernelGGL(k_ray_compact<true>, dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx,
+                       dy, dz, e->vsel, e->rc_cnt, ray_list);
+  } else {
+    hipLaunchKernelGGL(k_ray_compact<false>, dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx,
+                       dy, dz, static_cast<const uint32_t*>(nullptr), e->rc_cnt, ray_list);
+  }
+  HIPCK(hipGetLastError());
+  const bool tiled = e->G.o_rows != e->G.rows || e->G.o_cols != e->G.cols || e->G.s_rows != e->G.rows ||
+                     e->G.s_cols != e->G.cols;
+  auto launch_ray = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx, dy, dz, ray_list,
+                       e->rc_min);
+  };
+  tiled ? launch_ray(k_ray<true>) : launch_ray(k_ray<false>);
   HIPCK(hipGetLastError());
   hipLaunchKernelGGL(k_ray_resolve, dim3(unsigned((e->ncell + 255) / 256)), dim3(256), 0, e->stream, Q,
                      e->G, e->d_state, L, e->d_layer_ptrs, e->n_layer_ptrs, e->rc_cnt, e->rc_min,
@@ -625,7 +651,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     if ((rc = enqueue_voxel_sort(e, P.n, static_cast<float>(e->G.res), P.slot, e->S.cap_x, e->S.cap_y,
                                  e->S.cap_z)))
       return rc;
-    const RayParams Q = make_ray_params(e, origin, P.n, (P.slot + 1) & 3, P.slot);
+    const RayParams Q = make_ray_params(e, ray_config_of(e->cfg), origin, P.n, (P.slot + 1) & 3, P.slot);
     if ((rc = enqueue_ray_stage(e, Q, true, e->S.cap_x, e->S.cap_y, e->S.cap_z))) return rc;
     if (e->profile) {
       HIPCK(hipEventRecord(e->ev_ray[1], e->stream));
@@ -1336,9 +1362,11 @@ int fdm_engine_enable_profile(fdm_engine* e, int on) {
 
 // ---- raycasting entry points ----
 int fdm_engine_apply_raycasting_device(fdm_engine* e, uint64_t n, const float* dx, const float* dy,
-                                       const float* dz, const float origin[3]) {
+                                       const float* dz, const float origin[3],
+                                       const fdm_raycast_config* rcfg) {
   if (!e || !origin) return fail(FDM_ERR_INVALID, "null argument");
-  if (!e->cfg.raycast_enabled || n == 0) return FDM_OK;  // raycasting.cpp:207-209
+  const fdm_raycast_config c = rcfg ? *rcfg : ray_config_of(e->cfg);
+  if (!c.enabled || n == 0) return FDM_OK;  // raycasting.cpp:207-209
   if (!dx || !dy || !dz) return fail(FDM_ERR_INVALID, "null xyz");
   if (n >= 0xFFFFFFFEull) return fail(FDM_ERR_INVALID, "point count exceeds 2^32-2");
   HIPCK(hipSetDevice(e->device));
@@ -1346,21 +1374,21 @@ int fdm_engine_apply_raycasting_device(fdm_engine* e, uint64_t n, const float* d
   if (!find_layer(e, "elevation")) return FDM_OK;
   if ((rc = ensure_ray_layers(e))) return rc;
   if ((rc = refresh_layer_ptrs(e))) return rc;
-  const RayParams Q = make_ray_params(e, origin, unsigned(n), int(e->scan_no & 3), -1);
+  const RayParams Q = make_ray_params(e, c, origin, unsigned(n), int(e->scan_no & 3), -1);
   return enqueue_ray_stage(e, Q, false, dx, dy, dz);
 }
 
 int fdm_engine_apply_raycasting(fdm_engine* e, uint64_t n, const float* x, const float* y,
-                                const float* z, const float origin[3]) {
+                                const float* z, const float origin[3], const fdm_raycast_config* rcfg) {
   if (!e || !origin) return fail(FDM_ERR_INVALID, "null argument");
-  if (!e->cfg.raycast_enabled || n == 0) return FDM_OK;
+  if (!(rcfg ? rcfg->enabled : e->cfg.raycast_enabled) || n == 0) return FDM_OK;
   if (!x || !y || !z) return fail(FDM_ERR_INVALID, "null xyz");
   HIPCK(hipSetDevice(e->device));
   const float *dx, *dy, *dz, *da, *dv;
   const uint32_t* dc;
   int rc = stage_inputs(e, n, x, y, z, nullptr, nullptr, nullptr, &dx, &dy, &dz, &da, &dc, &dv);
   if (rc) return rc;
-  if ((rc = fdm_engine_apply_raycasting_device(e, n, dx, dy, dz, origin))) return rc;
+  if ((rc = fdm_engine_apply_raycasting_device(e, n, dx, dy, dz, origin, rcfg))) return rc;
   HIPCK(hipStreamSynchronize(e->stream));
   return FDM_OK;
 }
@@ -1422,6 +1450,10 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
   if (!e || !key) return fail(FDM_ERR_INVALID, "null argument");
   if (std::strcmp(key, "wave_merge") == 0) {
     e->wave_merge = value != 0;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "dbg_ray") == 0) {
+    e->dbg_ray = value;
     return FDM_OK;
   }
   if (std::strcmp(key, "bin_threads") == 0) {

@@ -16,7 +16,8 @@
 //     uint encoding of the float (a plain L2 load filters out the rays that cannot lower it);
 //   * ghost resolution: one independent decision per traversed cell, after both of the above.
 // Pipeline (one stream, no host round trip):
-//   k_voxel_keys -> stable radix sort of (key, point index) -> k_ray<true> -> k_ray_resolve
+//   k_voxel_keys -> stable radix sort of (key, point index) -> k_voxel_mark -> k_ray_compact
+//   -> k_ray -> k_ray_resolve
 // VoxelMode::ANY picks idx[start + (count*7 + start*13) % count] of each voxel's run in the sorted
 // array.  The reference sorts with std::sort on the key only (unstable: the order inside a voxel is
 // whatever that libstdc++'s introsort leaves); the engine sorts stably, i.e. ties in original point
@@ -28,6 +29,7 @@
 namespace fdm {
 
 constexpr uint32_t kRayEmpty = 0xFFFFFFFFu;       // ord() of no float that can occur (NaN pattern)
+constexpr int kRayBatch = 8;                      // cells a ray walks between two rounds of loads
 constexpr uint64_t kInvalidVoxel = ~0ull;         // voxel::INVALID_KEY: sorts behind every real key
 
 struct RayParams {
@@ -38,6 +40,7 @@ struct RayParams {
   unsigned n;           // points (VOXEL: sorted entries)
   int slot;             // geometry ring slot holding the map geometry the stage runs on
   int flag_slot;        // >= 0: DevFlags slot whose ray_any gates the stage (integrate); -1: ungated
+  int dbg;              // measurement only: 1 = no atomics in k_ray, 2 = no loads either
 };
 
 // voxel::pack.  float -> int32 outside the int range is UB in C++; the reference's x86 build
@@ -63,7 +66,8 @@ __global__ __launch_bounds__(256) void k_voxel_keys(unsigned n, float inv_voxel,
                                                     const float* __restrict__ y,
                                                     const float* __restrict__ z,
                                                     unsigned long long* __restrict__ keys,
-                                                    uint32_t* __restrict__ idx) {
+                                                    uint32_t* __restrict__ idx,
+                                                    uint32_t* __restrict__ sel) {
   const unsigned i = blockIdx.x * 256u + threadIdx.x;
   bool valid = false;
   if (i < n) {
@@ -71,6 +75,7 @@ __global__ __launch_bounds__(256) void k_voxel_keys(unsigned n, float inv_voxel,
     valid = isfinite(a) && isfinite(b) && isfinite(c);
     keys[i] = valid ? voxel_pack(a, b, c, inv_voxel) : kInvalidVoxel;
     idx[i] = i;
+    sel[i] = 0u;  // k_voxel_mark sets the representatives
   }
   if (flag_slot >= 0 && __ballot(valid) && (threadIdx.x & 63) == 0) st->flags[flag_slot].ray_any = 1u;
 }
@@ -112,47 +117,91 @@ __device__ __forceinline__ int owned_storage(int mr, int mc, const GeomConst& G)
   return (mc - G.s_c0) * G.s_rows + (mr - G.s_r0);
 }
 
-// processScan (raycasting.cpp:142-173): one ray-scan point per thread.
-//   VOXEL  = true : thread i looks at sorted position i and works only if it heads a voxel run
-//   VOXEL  = false: thread i takes point i of the caller's cloud (applyRaycasting called directly)
+// The voxel filter's output as a flag per ORIGINAL point index: sel[p] = 1 iff point p represents
+// its voxel.  processScan is order-free, so the rays are then traced in the scan's own order:
+// consecutive points of a LiDAR firing sequence / an image row share their 2-D direction (nearly),
+// so the lanes of a wavefront walk the same cells at the same step and their loads coalesce into
+// a few L2 requests instead of 64.
+__global__ __launch_bounds__(256) void k_voxel_mark(unsigned n,
+                                                    const unsigned long long* __restrict__ keys,
+                                                    const uint32_t* __restrict__ idx,
+                                                    uint32_t* __restrict__ sel) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long key = keys[i];
+  if (key == kInvalidVoxel || (i > 0 && keys[i - 1] == key)) return;
+  sel[voxel_pick(keys, idx, i, n)] = 1u;
+}
+
+// processScan (raycasting.cpp:142-173), first half: one ray-scan point per thread.
+//   VOXEL = true : point i counts if the voxel filter kept it (sel[i] != 0)
+//   VOXEL = false: every finite point of the caller's cloud (applyRaycasting called directly)
+// Observed evidence is counted here; the downward rays are queued DENSELY for k_ray (order inside a
+// block = scan order, blocks land in whatever order their atomicAdd does — the result is order-free),
+// so k_ray's wavefronts are full and neighbouring lanes hold neighbouring rays of the scan.
 template <bool VOXEL>
-__global__ __launch_bounds__(256) void k_ray(const RayParams Q, const GeomConst G,
-                                             DevState* __restrict__ st,
-                                             const float* __restrict__ x, const float* __restrict__ y,
-                                             const float* __restrict__ z,
-                                             const unsigned long long* __restrict__ keys,
-                                             const uint32_t* __restrict__ idx,
-                                             uint32_t* __restrict__ rc_cnt,
-                                             uint32_t* __restrict__ rc_min) {
+__global__ __launch_bounds__(256) void k_ray_compact(const RayParams Q, const GeomConst G,
+                                                     DevState* __restrict__ st,
+                                                     const float* __restrict__ x,
+                                                     const float* __restrict__ y,
+                                                     const float* __restrict__ z,
+                                                     const uint32_t* __restrict__ sel,
+                                                     uint32_t* __restrict__ rc_cnt,
+                                                     uint32_t* __restrict__ ray_list) {
+  __shared__ unsigned s_wave[4];
+  __shared__ unsigned s_base;
   const DevGeom g = st->geom[Q.slot];
   if (!ray_stage_runs(Q, st, g, G)) return;
   const unsigned i = blockIdx.x * 256u + threadIdx.x;
   if (i == 0) st->sticky |= 4u;  // the three layers become visible (raycasting.cpp:223-226)
-  if (i >= Q.n) return;
-  unsigned pi = i;
-  if (VOXEL) {
-    const unsigned long long key = keys[i];
-    if (key == kInvalidVoxel) return;
-    if (i > 0 && keys[i - 1] == key) return;
-    pi = voxel_pick(keys, idx, i, Q.n);
+  bool ray = false;
+  if (i < Q.n && (!VOXEL || sel[i] != 0u)) {
+    const float ex = x[i], ey = y[i], ez = z[i];
+    if (VOXEL || (isfinite(ex) && isfinite(ey) && isfinite(ez))) {
+      DevCand c;  // observed evidence: the point's own cell (nanoGrid getIndex, fp64)
+      c.px = g.px; c.py = g.py; c.sr = g.sr; c.sc = g.sc; c.shr = 0; c.shc = 0;
+      const int o = owned_cell(ex, ey, c, G);
+      if (o >= 0) atomicAdd(&rc_cnt[o], 1u);
+      ray = ez < Q.oz;  // upward rays are skipped (raycasting.cpp:168)
+    }
   }
-  const float ex = x[pi], ey = y[pi], ez = z[pi];
-  if (!VOXEL && !(isfinite(ex) && isfinite(ey) && isfinite(ez))) return;
-
-  // observed evidence: the point's own cell (nanoGrid getIndex, fp64)
-  {
-    DevCand c;
-    c.px = g.px; c.py = g.py; c.sr = g.sr; c.sc = g.sc; c.shr = 0; c.shc = 0;
-    const int o = owned_cell(ex, ey, c, G);
-    if (o >= 0) atomicAdd(&rc_cnt[o], 1u);
+  const unsigned long long m = __ballot(ray);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) s_wave[w] = unsigned(__popcll(m));
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    s_base = tot ? atomicAdd(&st->ray_count, tot) : 0u;
   }
-  if (ez >= Q.oz) return;  // upward ray
+  __syncthreads();
+  if (ray) {
+    unsigned off = s_base + unsigned(__popcll(m & ((1ull << lane) - 1ull)));
+    for (int k = 0; k < w; ++k) off += s_wave[k];
+    ray_list[off] = i;
+  }
+}
 
-  // traceRay (raycasting.cpp:46-140), fp32 exactly as written there
+// processScan, second half — traceRay (raycasting.cpp:46-140) for the queued rays, one per lane.
+template <bool TILED>
+__global__ __launch_bounds__(256) void k_ray(const RayParams Q, const GeomConst G,
+                                             DevState* __restrict__ st,
+                                             const float* __restrict__ x, const float* __restrict__ y,
+                                             const float* __restrict__ z,
+                                             const uint32_t* __restrict__ ray_list,
+                                             uint32_t* __restrict__ rc_min) {
+  const unsigned n_rays = st->ray_count;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if ((i & ~63u) >= n_rays) return;  // whole wavefront beyond the queue
+  const DevGeom g = st->geom[Q.slot];
+  const bool have = i < n_rays;
+  const unsigned pi = have ? ray_list[i] : 0u;
+  const float ex = have ? x[pi] : 0.f, ey = have ? y[pi] : 0.f, ez = have ? z[pi] : 0.f;
+
+  // fp32 exactly as written in traceRay
   const float sx = Q.ox, sy = Q.oy, sz = Q.oz;
   const float dx = ex - sx, dy = ey - sy;
   const float ray_len_2d = sqrtf(dx * dx + dy * dy);
-  if (ray_len_2d < 1e-4f) return;
+  bool alive = have && !(ray_len_2d < 1e-4f);  // kMinRayLength
   const float dz = ez - sz;
   const float res = Q.resolution;
   const int nrows = G.rows, ncols = G.cols;
@@ -178,31 +227,68 @@ __global__ __launch_bounds__(256) void k_ray(const RayParams Q, const GeomConst 
     t_max_c = (boundary - gc0) / dc;
     t_delta_c = float(step_c) / dc;
   }
+  // The walk: a step is straight-line predicated code (in-map test by unsigned compare, wrap by one
+  // conditional subtract, DDA advance by selects).  kRayBatch cells are walked in registers, their
+  // loads go out together (one L2 round trip), then the atomics — which are what this kernel costs
+  // (memory-side, ~1 ns each when lanes hit one address):
+  //   * rc_min only ever decreases, so a value read from L2 that is already <= h settles the visit
+  //     (a stale, larger value merely costs a redundant atomic);
+  //   * neighbouring lanes are neighbouring rays of the scan and mostly stand in the SAME cell at
+  //     the same step: a segmented min-scan over runs of equal cell leaves one atomic per run.
+  // The loop is wave-uniform (all lanes stay in until the longest ray of the wavefront has ended)
+  // because of the cross-lane scan; a finished ray keeps stepping with its visits masked off.
+  const int lane = threadIdx.x & 63;
   const int max_steps = nrows + ncols;
-  for (int s = 0; s < max_steps; ++s) {
-    if (r >= 0 && r < nrows && c >= 0 && c < ncols) {
+  int s = 0;
+  while (__ballot(alive)) {
+    int cell[kRayBatch];
+    uint32_t hh[kRayBatch];
+#pragma unroll
+    for (int j = 0; j < kRayBatch; ++j) {
+      const bool row = t_max_r < t_max_c;
+      // == std::min(t_max_r, t_max_c): on a tie both hold the same value
+      const float t_exit = row ? t_max_r : t_max_c;
+      const bool in_map = alive && unsigned(r) < unsigned(nrows) && unsigned(c) < unsigned(ncols);
       int mr = r + g.sr, mc = c + g.sc;  // (r + start) % size with both operands in [0, size)
-      if (mr >= nrows) mr -= nrows;
-      if (mc >= ncols) mc -= ncols;
-      const int o = owned_storage(mr, mc, G);
-      if (o >= 0) {
-        const float t_exit = (t_max_c < t_max_r) ? t_max_c : t_max_r;  // std::min(t_max_r, t_max_c)
-        const float height = sz + ((1.0f < t_exit) ? 1.0f : t_exit) * dz;
-        const uint32_t h = ord(height);
-        // rc_min only ever decreases, so a value read from L2 that is already <= h settles it;
-        // a stale (larger) value merely costs one redundant atomic
-        const uint32_t seen = __hip_atomic_load(&rc_min[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (h < seen) atomicMin(&rc_min[o], h);
+      mr -= mr >= nrows ? nrows : 0;
+      mc -= mc >= ncols ? ncols : 0;
+      int o;
+      if (TILED) {
+        o = owned_storage(mr, mc, G);
+      } else {
+        o = mc * nrows + mr;
       }
+      const float height = sz + ((1.0f < t_exit) ? 1.0f : t_exit) * dz;
+      cell[j] = in_map ? o : -1;
+      hh[j] = ord(height);
+      alive = alive && !(t_exit >= 1.0f) && (s + j + 1 < max_steps);
+      r += row ? step_r : 0;
+      c += row ? 0 : step_c;
+      t_max_r = row ? t_max_r + t_delta_r : t_max_r;
+      t_max_c = row ? t_max_c : t_max_c + t_delta_c;
     }
-    if (t_max_r < t_max_c) {
-      if (t_max_r >= 1.0f) break;
-      r += step_r;
-      t_max_r += t_delta_r;
-    } else {
-      if (t_max_c >= 1.0f) break;
-      c += step_c;
-      t_max_c += t_delta_c;
+    s += kRayBatch;
+    // (the loads are unconditional — a masked step reads cell 0 — so that nothing but the loads
+    // sits between them and they leave back to back)
+    uint32_t seen[kRayBatch];
+#pragma unroll
+    for (int j = 0; j < kRayBatch; ++j)
+      seen[j] = __hip_atomic_load(&rc_min[cell[j] >= 0 ? cell[j] : 0], __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int j = 0; j < kRayBatch; ++j) {
+      const bool need = cell[j] >= 0 && hh[j] < seen[j];
+      if (__ballot(need) == 0ull) continue;  // wave-uniform: nobody lowers anything at this step
+      uint32_t v = cell[j] >= 0 ? hh[j] : 0xFFFFFFFFu;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int ocell = __shfl_up(cell[j], d);
+        const uint32_t ov = __shfl_up(v, d);
+        if (lane >= d && ocell == cell[j]) v = ov < v ? ov : v;
+      }
+      const int ncell = __shfl_down(cell[j], 1);
+      const bool tail = cell[j] >= 0 && (lane == 63 || ncell != cell[j]);
+      if (tail && v < seen[j] && Q.dbg != 1) atomicMin(&rc_min[cell[j]], v);
     }
   }
 }
@@ -240,6 +326,7 @@ __global__ __launch_bounds__(256) void k_ray_resolve(const RayParams Q, const Ge
   const DevGeom g = st->geom[Q.slot];
   if (!ray_stage_runs(Q, st, g, G)) return;
   const unsigned o = blockIdx.x * 256u + threadIdx.x;
+  if (o == 0) st->ray_count = 0u;  // the queue is consumed
   if (o >= ncell) return;
   const float nanv = __uint_as_float(0x7FC00000u);
   const uint32_t cnt = rc_cnt[o];

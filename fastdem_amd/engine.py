@@ -204,16 +204,19 @@ class Engine:
                                                C.c_void_p(dbuf_ptr)))
 
     # -- raycasting stage --
-    def apply_raycasting(self, x, y, z, sensor_origin):
-        """fastdem::applyRaycasting(map, scan, sensor_origin, cfg.raycasting); host arrays, sync."""
+    def apply_raycasting(self, x, y, z, sensor_origin, rc=None):
+        """fastdem::applyRaycasting(map, scan, sensor_origin, config); host arrays, sync.
+        rc: capi.FdmRaycastConfig, None = the raycasting fields of the engine config."""
         x, y, z = _f32(x), _f32(y), _f32(z)
         o = (C.c_float * 3)(*[float(v) for v in sensor_origin])
-        _ck(self._lib.fdm_engine_apply_raycasting(self._h, x.size, _ptr(x), _ptr(y), _ptr(z), o))
+        _ck(self._lib.fdm_engine_apply_raycasting(self._h, x.size, _ptr(x), _ptr(y), _ptr(z), o,
+                                                  None if rc is None else C.byref(rc)))
 
-    def apply_raycasting_device(self, x, y, z, sensor_origin):
+    def apply_raycasting_device(self, x, y, z, sensor_origin, rc=None):
         o = (C.c_float * 3)(*[float(v) for v in sensor_origin])
         _ck(self._lib.fdm_engine_apply_raycasting_device(self._h, x.numel(), _dptr(x), _dptr(y),
-                                                         _dptr(z), o))
+                                                         _dptr(z), o,
+                                                         None if rc is None else C.byref(rc)))
 
     def voxel_any(self, x, y, z, voxel_size):
         """filters::voxelGrid(cloud, voxel_size, VoxelMode::ANY): original indices, output order."""

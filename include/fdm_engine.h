@@ -49,6 +49,12 @@ typedef struct fdm_config {
       rc_clear_threshold;
 } fdm_config;
 
+/* config::Raycasting on its own (config/postprocess.hpp:16-23), for applyRaycasting called directly. */
+typedef struct fdm_raycast_config {
+  int32_t enabled;
+  float height_conflict_threshold, log_odds_observed, log_odds_ghost, log_odds_max, clear_threshold;
+} fdm_raycast_config;
+
 /* nanogrid::GridMap geometry (length, resolution, position, circular-buffer start).
  * rows/cols are outputs of create (size = round(length / resolution)). */
 typedef struct fdm_geometry {
@@ -188,14 +194,17 @@ int fdm_engine_last_rasterized(fdm_engine* e, uint64_t cap, float* x, float* y, 
  * voxelGrid's [0.001, 100] range makes integrate return FDM_ERR_INVALID (the reference throws,
  * voxel_grid_impl.hpp:31-33).
  *
- * fastdem::applyRaycasting(map, scan, sensor_origin, cfg.raycasting) called directly
+ * fastdem::applyRaycasting(map, scan, sensor_origin, config) called directly
  * (postprocess/raycasting.hpp:47-49; tests/test_postprocess.cpp:73-190): `scan` is used as given,
- * no voxel filter.  A no-op when raycasting is disabled in the config, n == 0, or the sensor origin
- * lies outside the map.  Host arrays, synchronous / device arrays, enqueue-only. */
+ * no voxel filter.  rc == NULL takes the raycasting fields of the engine's fdm_config.  A no-op
+ * when raycasting is disabled in that config, n == 0, or the sensor origin lies outside the map.
+ * Host arrays, synchronous / device arrays, enqueue-only. */
 int fdm_engine_apply_raycasting(fdm_engine* e, uint64_t n, const float* x, const float* y,
-                                const float* z, const float sensor_origin[3]);
+                                const float* z, const float sensor_origin[3],
+                                const fdm_raycast_config* rc);
 int fdm_engine_apply_raycasting_device(fdm_engine* e, uint64_t n, const float* d_x, const float* d_y,
-                                       const float* d_z, const float sensor_origin[3]);
+                                       const float* d_z, const float sensor_origin[3],
+                                       const fdm_raycast_config* rc);
 /* nanopcl::filters::voxelGrid(cloud, voxel_size, VoxelMode::ANY) (voxel_grid_impl.hpp:30-60,171-189)
  * on the device: writes the ORIGINAL indices of the kept points, in the filter's output order
  * (ascending voxel key), to out_idx (capacity n) and their count to n_out.  Ties inside a voxel are
