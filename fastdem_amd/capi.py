@@ -127,6 +127,12 @@ PROTOTYPES = {
                                                      C.POINTER(FdmRaycastConfig)]),
     "fdm_engine_voxel_any": (C.c_int, [_P, C.c_uint64, _P, _P, _P, C.c_float, _P, C.POINTER(C.c_uint64)]),
     "fdm_engine_last_ray_ms": (C.c_int, [_P, _F]),
+    "fdm_engine_pack_cloud": (C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
+                                        C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
+                                        C.c_char_p, C.c_uint64]),
+    "fdm_engine_pack_cloud_device": (C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                               C.POINTER(_P), C.POINTER(C.c_uint64),
+                                               C.POINTER(C.c_uint32)]),
     "fdm_engine_enable_cell_ids": (C.c_int, [_P, C.c_int]),
     "fdm_engine_last_cell_ids": (C.c_int, [_P, _P, C.c_uint64]),
     "fdm_engine_enable_profile": (C.c_int, [_P, C.c_int]),

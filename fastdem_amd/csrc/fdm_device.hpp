@@ -49,9 +49,13 @@ struct DevState {
   DevCand cand[4];
   DevFlags flags[4];
   DevObst obst[4];
-  unsigned sticky;  // bit0: intensity layer written, bit1: colour layer written, bit2: raycasting ran
+  // When a lazily created layer first became visible (0 = not yet), as an order stamp
+  // 3*scan_no + {2: updateIntensity/updateColor, 3: the scan's raycasting stage, 1: applyRaycasting
+  // called between scans}: GridMap::getLayers() lists layers in creation order, and the reference
+  // creates these on first use (elevation_mapping.cpp:154-175, raycasting.cpp:223-226).
+  unsigned vis_int;
   unsigned ray_count;  // rays queued by k_ray_compact for k_ray; k_ray_resolve puts it back to 0
-  unsigned pad1, pad2;
+  unsigned vis_col, vis_ray;
 };
 
 struct GeomConst {

@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdint>
@@ -21,6 +22,7 @@
 
 #include "fdm_kernels.hpp"
 #include "fdm_raycast.hpp"
+#include "fdm_egress.hpp"
 
 using namespace fdm;
 
@@ -119,6 +121,11 @@ struct fdm_engine {
   hipEvent_t ev_ray[2] = {nullptr, nullptr};
   bool ray_timed = false;
   int dbg_ray = 0;
+  // egress (fdm_egress.hpp)
+  uint32_t* pack_counts = nullptr;   // per-block valid counts / offsets (+1 for the total)
+  size_t pack_counts_cap = 0;
+  float* d_pack = nullptr;           // packed records
+  size_t pack_cap = 0;               // in floats
 };
 
 namespace {
@@ -229,15 +236,31 @@ int resolve_pending(fdm_engine* e) {
   for (auto& l : e->layers) any = any || l.pending;
   if (!any) return FDM_OK;
   HIPCK(hipStreamSynchronize(e->stream));
-  unsigned sticky = 0;
-  HIPCK(hipMemcpy(&sticky, &e->d_state->sticky, sizeof(unsigned), hipMemcpyDeviceToHost));
+  HIPCK(hipMemcpy(e->h_state, e->d_state, sizeof(DevState), hipMemcpyDeviceToHost));
+  const unsigned vi = e->h_state->vis_int, vc = e->h_state->vis_col, vr = e->h_state->vis_ray;
+  // newly visible layers move to the END of the list in the order the reference would have created
+  // them (getLayers() order is creation order and feeds the PointCloud2 field order)
+  std::vector<std::pair<unsigned long long, Layer>> born;
+  std::vector<Layer> keep;
+  unsigned seq = 0;
   for (auto& l : e->layers) {
-    if (l.pending && l.name == "intensity" && (sticky & 1u)) l.pending = false;
-    if (l.pending && l.name == "color" && (sticky & 2u)) l.pending = false;
-    if (l.pending && (sticky & 4u) &&
-        (l.name == "ghost_removal" || l.name == "raycasting" || l.name == "_visibility_logodds"))
+    unsigned stamp = 0;
+    if (l.pending) {
+      if (l.name == "intensity") stamp = vi;
+      else if (l.name == "color") stamp = vc;
+      else if (l.name == "ghost_removal" || l.name == "raycasting" || l.name == "_visibility_logodds") stamp = vr;
+    }
+    if (stamp) {
       l.pending = false;
+      born.emplace_back((static_cast<unsigned long long>(stamp) << 8) | seq++, l);
+    } else {
+      keep.push_back(l);
+    }
   }
+  if (born.empty()) return FDM_OK;
+  std::sort(born.begin(), born.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+  for (auto& b2 : born) keep.push_back(b2.second);
+  e->layers.swap(keep);
   return FDM_OK;
 }
 
@@ -405,6 +428,7 @@ RayParams make_ray_params(fdm_engine* e, const fdm_raycast_config& c, const floa
   Q.n = n;
   Q.slot = slot;
   Q.flag_slot = flag_slot;
+  Q.vis_stamp = 3u * unsigned(e->scan_no) + (flag_slot >= 0 ? 3u : 1u);
   Q.dbg = e->dbg_ray;
   return Q;
 }
@@ -983,6 +1007,8 @@ void fdm_engine_destroy(fdm_engine* e) {
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : e->ev_ray)
     if (ev) (void)hipEventDestroy(ev);
+  if (e->pack_counts) (void)hipFree(e->pack_counts);
+  if (e->d_pack) (void)hipFree(e->d_pack);
   if (e->rc_cnt) (void)hipFree(e->rc_cnt);
   if (e->rc_min) (void)hipFree(e->rc_min);
   for (int k = 0; k < 2; ++k) {
@@ -1185,6 +1211,7 @@ int fdm_engine_layer_add(fdm_engine* e, const char* name, float value) {
   if (!e || !name) return fail(FDM_ERR_INVALID, "null argument");
   HIPCK(hipSetDevice(e->device));
   if (std::strcmp(name, "obstacle") == 0) e->obst_dense_pending = true;
+  if (int rc = resolve_pending(e)) return rc;  // keeps getLayers() in the reference's creation order
   return add_layer(e, name, value, false);
 }
 
@@ -1357,6 +1384,129 @@ int fdm_engine_last_cell_ids(fdm_engine* e, int32_t* host_out, uint64_t n) {
 int fdm_engine_enable_profile(fdm_engine* e, int on) {
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
   e->profile = on != 0;
+  return FDM_OK;
+}
+
+// ---- map egress ----
+namespace {
+struct PackPlan {
+  PackParams Q{};
+  PackLayers L{};
+  std::vector<std::string> fields;
+  unsigned long long total = 0;
+  unsigned blocks = 0;
+};
+
+int plan_pack(fdm_engine* e, const char* elevation_layer, int32_t r0, int32_t c0, int32_t nr, int32_t nc,
+              PackPlan& pl) {
+  if (int rc = resolve_pending(e)) return rc;
+  Layer* elev = find_layer(e, elevation_layer);
+  if (!elev || elev->pending) return fail(FDM_ERR_NO_LAYER, std::string("no layer ") + elevation_layer);
+  if (nr >= 0) {
+    if (r0 < 0 || c0 < 0 || r0 >= e->G.rows || c0 >= e->G.cols || nr > e->G.rows || nc < 0 || nc > e->G.cols)
+      return fail(FDM_ERR_INVALID, "submap outside the buffer");
+  }
+  pl.Q.sub_r0 = r0; pl.Q.sub_c0 = c0; pl.Q.sub_rows = nr; pl.Q.sub_cols = nc;
+  pl.Q.slot = int(e->scan_no & 3);
+  pl.L.elev = lptr(e, *elev);
+  pl.L.elev_stride = lstride(e, *elev);
+  pl.fields = {"x", "y", "z"};
+  int nf = 0;
+  const Layer* color = nullptr;
+  for (auto& l : e->layers) {  // impl.hpp:66-77
+    if (l.pending) continue;
+    if (!l.name.empty() && l.name[0] == '_') continue;
+    if (l.name == elevation_layer) continue;
+    if (l.name == "color") { color = &l; continue; }
+    if (nf >= kPackMaxFields) return fail(FDM_ERR_INVALID, "too many layers to pack");
+    pl.L.ptr[nf] = lptr(e, l);
+    pl.L.stride[nf] = lstride(e, l);
+    pl.fields.push_back(l.name);
+    ++nf;
+  }
+  pl.Q.n_float = nf;
+  pl.Q.has_color = color ? 1 : 0;
+  pl.L.color = color ? color->d : nullptr;
+  if (color) pl.fields.push_back("rgb");
+  pl.total = nr < 0 ? (unsigned long long)e->G.rows * e->G.cols : (unsigned long long)nr * nc;
+  pl.blocks = unsigned((pl.total + 255) / 256);
+  return FDM_OK;
+}
+
+// count + scan; returns the number of valid cells (host sync)
+int pack_count(fdm_engine* e, const PackPlan& pl, uint64_t* n_points) {
+  *n_points = 0;
+  if (pl.total == 0) return FDM_OK;
+  if (size_t(pl.blocks) + 1 > e->pack_counts_cap) {
+    HIPCK(hipStreamSynchronize(e->stream));
+    if (e->pack_counts) HIPCK(hipFree(e->pack_counts));
+    e->pack_counts_cap = size_t(pl.blocks) + 1 + 1024;
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->pack_counts), e->pack_counts_cap * sizeof(uint32_t)));
+  }
+  hipLaunchKernelGGL(k_pack_count, dim3(pl.blocks), dim3(256), 0, e->stream, pl.Q, e->G, e->d_state, pl.L,
+                     e->pack_counts);
+  hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, e->stream, e->pack_counts, pl.blocks);
+  HIPCK(hipGetLastError());
+  uint32_t total = 0;
+  HIPCK(hipMemcpyAsync(&total, e->pack_counts + pl.blocks, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+  HIPCK(hipStreamSynchronize(e->stream));
+  *n_points = total;
+  return FDM_OK;
+}
+
+int pack_write(fdm_engine* e, const PackPlan& pl, uint64_t n_points) {
+  const size_t need = size_t(n_points) * pl.fields.size();
+  if (need > e->pack_cap) {
+    if (e->d_pack) HIPCK(hipFree(e->d_pack));
+    e->pack_cap = need + need / 8 + 1024;
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_pack), e->pack_cap * sizeof(float)));
+  }
+  if (n_points == 0) return FDM_OK;
+  hipLaunchKernelGGL(k_pack_write, dim3(pl.blocks), dim3(256), 0, e->stream, pl.Q, e->G, e->d_state, pl.L,
+                     e->pack_counts, e->d_pack);
+  HIPCK(hipGetLastError());
+  return FDM_OK;
+}
+
+void write_fields(const PackPlan& pl, char* buf, uint64_t cap) {
+  if (!buf || !cap) return;
+  std::string joined;
+  for (size_t k = 0; k < pl.fields.size(); ++k) joined += (k ? "\n" : "") + pl.fields[k];
+  std::snprintf(buf, cap, "%s", joined.c_str());
+}
+}  // namespace
+
+int fdm_engine_pack_cloud_device(fdm_engine* e, const char* elevation_layer, int32_t r0, int32_t c0,
+                                 int32_t nr, int32_t nc, void** d_out, uint64_t* n_points,
+                                 uint32_t* point_step) {
+  if (!e || !elevation_layer || !n_points) return fail(FDM_ERR_INVALID, "null argument");
+  HIPCK(hipSetDevice(e->device));
+  PackPlan pl;
+  int rc;
+  if ((rc = plan_pack(e, elevation_layer, r0, c0, nr, nc, pl))) return rc;
+  if (point_step) *point_step = uint32_t(pl.fields.size() * 4);
+  if ((rc = pack_count(e, pl, n_points))) return rc;
+  if ((rc = pack_write(e, pl, *n_points))) return rc;
+  if (d_out) *d_out = e->d_pack;
+  return FDM_OK;
+}
+
+int fdm_engine_pack_cloud(fdm_engine* e, const char* elevation_layer, int32_t r0, int32_t c0, int32_t nr,
+                          int32_t nc, void* host_out, uint64_t cap_bytes, uint64_t* n_points,
+                          uint32_t* point_step, char* fields_buf, uint64_t fields_cap) {
+  if (!e || !elevation_layer || !n_points) return fail(FDM_ERR_INVALID, "null argument");
+  HIPCK(hipSetDevice(e->device));
+  PackPlan pl;
+  int rc;
+  if ((rc = plan_pack(e, elevation_layer, r0, c0, nr, nc, pl))) return rc;
+  if (point_step) *point_step = uint32_t(pl.fields.size() * 4);
+  write_fields(pl, fields_buf, fields_cap);
+  if ((rc = pack_count(e, pl, n_points))) return rc;
+  const uint64_t bytes = *n_points * pl.fields.size() * 4;
+  if (!host_out || cap_bytes < bytes || bytes == 0) return FDM_OK;
+  if ((rc = pack_write(e, pl, *n_points))) return rc;
+  HIPCK(hipMemcpyAsync(host_out, e->d_pack, bytes, hipMemcpyDeviceToHost, e->stream));
+  HIPCK(hipStreamSynchronize(e->stream));
   return FDM_OK;
 }
 

@@ -471,10 +471,8 @@ __device__ __forceinline__ void make_ctx(const ScanParams& P, DevState* __restri
     st->flags[nn].any_inside = 0u;
     st->flags[nn].ray_any = 0u;
     if (u.do_update) {
-      unsigned f = 0;
-      if (P.has_intensity) f |= 1u;
-      if (P.has_color) f |= 2u;
-      if (f) st->sticky |= f;
+      if (P.has_intensity && st->vis_int == 0u) st->vis_int = 3u * P.scan_no + 2u;
+      if (P.has_color && st->vis_col == 0u) st->vis_col = 3u * P.scan_no + 2u;
     }
   }
   if (S.dense) {

@@ -40,6 +40,7 @@ struct RayParams {
   unsigned n;           // points (VOXEL: sorted entries)
   int slot;             // geometry ring slot holding the map geometry the stage runs on
   int flag_slot;        // >= 0: DevFlags slot whose ray_any gates the stage (integrate); -1: ungated
+  unsigned vis_stamp;   // DevState::vis_ray value if this is the first frame that runs
   int dbg;              // measurement only: 1 = no atomics in k_ray, 2 = no loads either
 };
 
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void k_ray_compact(const RayParams Q, const Ge
   const DevGeom g = st->geom[Q.slot];
   if (!ray_stage_runs(Q, st, g, G)) return;
   const unsigned i = blockIdx.x * 256u + threadIdx.x;
-  if (i == 0) st->sticky |= 4u;  // the three layers become visible (raycasting.cpp:223-226)
+  if (i == 0 && st->vis_ray == 0u) st->vis_ray = Q.vis_stamp;  // the three layers become visible (raycasting.cpp:223-226)
   bool ray = false;
   if (i < Q.n && (!VOXEL || sel[i] != 0u)) {
     const float ex = x[i], ey = y[i], ez = z[i];

@@ -203,6 +203,30 @@ class Engine:
         _ck(self._lib.fdm_engine_region_unpack(self._h, r0, c0, nr, nc, arr, len(names),
                                                C.c_void_p(dbuf_ptr)))
 
+    # -- egress --
+    def pack_cloud(self, elevation_layer="elevation", sub=None):
+        """toPointCloud2Impl on the device: (fields, point_step, data[n_points, n_fields] float32)."""
+        r0, c0, nr, nc = sub if sub is not None else (0, 0, -1, -1)
+        n, step = C.c_uint64(0), C.c_uint32(0)
+        names = C.create_string_buffer(4096)
+        name = elevation_layer.encode()
+        _ck(self._lib.fdm_engine_pack_cloud(self._h, name, r0, c0, nr, nc, None, 0, C.byref(n),
+                                            C.byref(step), names, 4096))
+        fields = names.value.decode().split("\n")
+        data = np.empty((n.value, len(fields)), dtype=np.float32)
+        if n.value:
+            _ck(self._lib.fdm_engine_pack_cloud(self._h, name, r0, c0, nr, nc, _ptr(data), data.nbytes,
+                                                C.byref(n), C.byref(step), None, 0))
+        return fields, step.value, data
+
+    def pack_cloud_device(self, elevation_layer="elevation", sub=None):
+        """Records stay in HBM: (device pointer, n_points, point_step)."""
+        r0, c0, nr, nc = sub if sub is not None else (0, 0, -1, -1)
+        n, step, d = C.c_uint64(0), C.c_uint32(0), C.c_void_p()
+        _ck(self._lib.fdm_engine_pack_cloud_device(self._h, elevation_layer.encode(), r0, c0, nr, nc,
+                                                   C.byref(d), C.byref(n), C.byref(step)))
+        return d.value, n.value, step.value
+
     # -- raycasting stage (SURVEY.md §8 f1) --
     def apply_raycasting(self, x, y, z, sensor_origin, rc=None):
         """fastdem::applyRaycasting(map, scan, sensor_origin, config); host arrays, sync.

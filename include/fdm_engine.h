@@ -216,6 +216,26 @@ int fdm_engine_voxel_any(fdm_engine* e, uint64_t n, const float* x, const float*
  * needs fdm_engine_enable_profile. */
 int fdm_engine_last_ray_ms(fdm_engine* e, float* ms);
 
+/* ---- Map egress ----
+ * fastdem::detail::toPointCloud2Impl (bridge/ros/impl.hpp:28-166) on the device: one record per cell
+ * with a finite `elevation_layer` value, in the reference's visiting order (column by column through
+ * the submap, starting at sub_start), each record = x, y, z, every non-internal layer (name not
+ * starting with '_', elevation_map.hpp:42-45) in getLayers() order, then the packed colour as `rgb`.
+ * All fields are 4 bytes (FLOAT32): point_step = 4 * n_fields.
+ *   sub_rows < 0 : the whole map (sub_start = start index, sub_size = size), impl.hpp:160-166
+ *   fields_buf   : receives the field names separated by '\n' (nullable)
+ *   host_out     : receives n_points * point_step bytes when cap_bytes allows; pass NULL (or a
+ *                  too small cap) to learn n_points / point_step first
+ * Compaction and packing run in HBM; the host sees one contiguous copy. */
+int fdm_engine_pack_cloud(fdm_engine* e, const char* elevation_layer, int32_t sub_r0, int32_t sub_c0,
+                          int32_t sub_rows, int32_t sub_cols, void* host_out, uint64_t cap_bytes,
+                          uint64_t* n_points, uint32_t* point_step, char* fields_buf,
+                          uint64_t fields_cap);
+/* Same, the packed records stay in an engine-owned HBM buffer (valid until the next pack call). */
+int fdm_engine_pack_cloud_device(fdm_engine* e, const char* elevation_layer, int32_t sub_r0,
+                                 int32_t sub_c0, int32_t sub_rows, int32_t sub_cols, void** d_out,
+                                 uint64_t* n_points, uint32_t* point_step);
+
 /* Parity / measurement instrumentation (not in the reference). */
 int fdm_engine_enable_cell_ids(fdm_engine* e, int on);
 /* per input point of the last scan: linear cell id (col*rows+row), -1 cropped, -2 outside map */

@@ -111,6 +111,13 @@ int64_t fdmref_voxel_any(uint64_t n, const float* x, const float* y, const float
 uint64_t fdmref_voxel_pack(float x, float y, float z, float inv_voxel_size);
 void fdmref_sensor_origin(const double* T_base_sensor, const double* T_world_base, float* out3);
 
+/* map -> PointCloud2 egress (fdm_ref_egress.hpp; bridge/ros/impl.hpp:28-166).  sub_rows < 0 = full map
+ * (sub_start = start index, sub_size = size).  fields: '\n'-separated names into fields_buf.
+ * Returns the number of points; data (nullable) receives n_points*point_step bytes if cap allows. */
+int64_t fdmref_pack_cloud(void* e, const char* elevation_layer, int sub_r0, int sub_c0, int sub_rows,
+                          int sub_cols, uint8_t* data, uint64_t cap_bytes, uint32_t* point_step,
+                          char* fields_buf, uint64_t fields_cap);
+
 /* unit-level entry points for the reference's known-answer tests */
 void fdmref_sensor_covariance(const fdmref_config* cfg, const float* p3, float* cov9_colmajor);
 /* state8 = {x, P, count, sample_mean, sample_var, m2, upper, lower} */

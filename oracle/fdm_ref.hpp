@@ -42,6 +42,7 @@
 
 #include "fdm_grid.hpp"
 #include "fdm_ref_raycast.hpp"
+#include "fdm_ref_egress.hpp"
 
 namespace fdmref {
 

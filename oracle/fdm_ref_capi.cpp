@@ -2,6 +2,7 @@
 // *** TEST INFRASTRUCTURE — NOT PRODUCT CODE. ***  (see fdm_ref.hpp header)
 #include "fdm_ref.h"
 
+#include <cstdio>
 #include <cstring>
 
 #include "fdm_ref.hpp"
@@ -216,6 +217,26 @@ uint64_t fdmref_last_rasterized(void* e, uint64_t cap, float* x, float* y, float
     z[i] = r[i][2];
   }
   return r.size();
+}
+
+int64_t fdmref_pack_cloud(void* e, const char* elevation_layer, int sub_r0, int sub_c0, int sub_rows,
+                          int sub_cols, uint8_t* data, uint64_t cap_bytes, uint32_t* point_step,
+                          char* fields_buf, uint64_t fields_cap) {
+  Grid& m = E(e)->map();
+  if (!m.exists(elevation_layer)) return -1;
+  if (sub_rows < 0) {
+    sub_r0 = m.startIndex()[0]; sub_c0 = m.startIndex()[1];
+    sub_rows = m.rows(); sub_cols = m.cols();
+  }
+  const PackedCloud pc = packCloud(m, elevation_layer, sub_r0, sub_c0, sub_rows, sub_cols);
+  if (point_step) *point_step = pc.point_step;
+  if (fields_buf && fields_cap) {
+    std::string joined;
+    for (size_t k = 0; k < pc.fields.size(); ++k) joined += (k ? "\n" : "") + pc.fields[k];
+    std::snprintf(fields_buf, fields_cap, "%s", joined.c_str());
+  }
+  if (data && cap_bytes >= pc.data.size()) std::memcpy(data, pc.data.data(), pc.data.size());
+  return int64_t(pc.n_points);
 }
 
 void fdmref_set_voxel_stable(void* e, int on) { E(e)->voxel_stable = on != 0; }

@@ -118,6 +118,9 @@ def load(native=False):
     lib.fdmref_last_preprocessed.argtypes = [P, C.c_uint64, P, P, P, P]
     lib.fdmref_last_rasterized.restype = C.c_uint64
     lib.fdmref_last_rasterized.argtypes = [P, C.c_uint64, P, P, P]
+    lib.fdmref_pack_cloud.restype = C.c_int64
+    lib.fdmref_pack_cloud.argtypes = [P, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, P, C.c_uint64,
+                                      C.POINTER(C.c_uint32), C.c_char_p, C.c_uint64]
     lib.fdmref_set_voxel_stable.argtypes = [P, C.c_int]
     lib.fdmref_last_ray_stats.argtypes = [P, P]
     lib.fdmref_apply_raycasting.restype = C.c_int
@@ -295,6 +298,22 @@ class RefEngine:
         a = [np.empty(cap, dtype=np.float32) for _ in range(3)]
         n = self._lib.fdmref_last_rasterized(self._h, cap, *[_ptr(v) for v in a])
         return [v[:n] for v in a]
+
+    # -- egress --
+    def pack_cloud(self, elevation_layer="elevation", sub=None):
+        """toPointCloud2Impl: (fields, point_step, data[n_points, n_fields] float32 view)."""
+        r0, c0, nr, nc = sub if sub is not None else (0, 0, -1, -1)
+        step = C.c_uint32(0)
+        names = C.create_string_buffer(4096)
+        cap = self.rows * self.cols * 4 * 70
+        buf = np.empty(cap, dtype=np.uint8)
+        n = self._lib.fdmref_pack_cloud(self._h, elevation_layer.encode(), r0, c0, nr, nc, _ptr(buf), cap,
+                                        C.byref(step), names, 4096)
+        if n < 0:
+            raise KeyError(elevation_layer)
+        fields = names.value.decode().split("\n")
+        data = buf[:n * step.value].view(np.float32).reshape(n, len(fields)).copy()
+        return fields, step.value, data
 
     # -- raycasting stage --
     RAY_STATS = ("n_rays", "n_observed", "n_ray_cells", "n_conflicts", "n_cleared")
