@@ -43,6 +43,7 @@ inline int run(const char* filter) {
 #define EXPECT_TRUE(x) do { if (!(x)) FAIL_MSG("EXPECT_TRUE(" #x ")"); } while (0)
 #define EXPECT_FALSE(x) do { if (x) FAIL_MSG("EXPECT_FALSE(" #x ")"); } while (0)
 #define ASSERT_TRUE(x) do { if (!(x)) { FAIL_MSG("ASSERT_TRUE(" #x ")"); return; } } while (0)
+#define ASSERT_EQ(a, b) do { if (!((a) == (b))) { FAIL_MSG("ASSERT_EQ(" #a ", " #b ")"); return; } } while (0)
 #define EXPECT_EQ(a, b) do { if (!((a) == (b))) FAIL_MSG("EXPECT_EQ(" #a ", " #b ")"); } while (0)
 #define EXPECT_NEAR(a, b, tol) do { if (!(std::fabs(double(a) - double(b)) <= double(tol))) { std::printf("  %s:%d: EXPECT_NEAR(" #a ", " #b "): %g vs %g\n", __FILE__, __LINE__, double(a), double(b)); ++mini::failures(); } } while (0)
 #define EXPECT_FLOAT_EQ(a, b) do { if (!mini::float_eq(float(a), float(b))) { std::printf("  %s:%d: EXPECT_FLOAT_EQ(" #a ", " #b "): %g vs %g\n", __FILE__, __LINE__, double(a), double(b)); ++mini::failures(); } } while (0)

@@ -4,10 +4,15 @@
 //   test_dual_layer.cpp, test_config.cpp (validation), test_sensor_models.cpp (host classes),
 //   test_postprocess.cpp:73-190 (raycasting)
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iterator>
 #include <memory>
 #include <optional>
 
 #include "fastdem/fastdem.hpp"
+#include "fastdem/io/npz.hpp"
 #include "mini_test.hpp"
 
 using namespace fastdem;
@@ -491,6 +496,120 @@ TEST(Raycasting, EnabledThroughIntegrate) {  // fastdem.cpp:152-159, default.yam
   nanogrid::Index hit;
   ASSERT_TRUE(f.map.getIndex(nanogrid::Position(4.0, 0.0), hit));
   EXPECT_FLOAT_EQ(f.map.at(layer::visibility_logodds, hit), 0.4f);
+}
+
+// ------------------------------------------------------- test_map_io.cpp (NPZ) ----
+namespace {
+struct NpzFixture {  // test_map_io.cpp:19-41
+  ElevationMap map;
+  std::string path;
+  explicit NpzFixture(const char* file = "fdm_cpp_test_io.npz") {
+    map = ElevationMap(10.0f, 8.0f, 0.5f, "map");
+    auto& elev = map.get(layer::elevation);
+    for (size_t i = 0; i < elev.size(); ++i) elev.data()[i] = static_cast<float>(i) * 0.1f;
+    elev(0, 0) = NAN;
+    elev(1, 1) = NAN;
+    const char* tmp = std::getenv("TMPDIR");
+    path = std::string(tmp ? tmp : "/tmp") + "/" + file;
+  }
+  ~NpzFixture() { std::remove(path.c_str()); }
+};
+}  // namespace
+TEST(Npz, RoundTrip) {  // :43-73
+  NpzFixture f;
+  ASSERT_TRUE(io::saveNpz(f.path, f.map));
+  ElevationMap loaded;
+  ASSERT_TRUE(io::loadNpz(f.path, loaded));
+  EXPECT_FLOAT_EQ(float(loaded.getResolution()), float(f.map.getResolution()));
+  EXPECT_EQ(loaded.getSize()(0), f.map.getSize()(0));
+  EXPECT_EQ(loaded.getSize()(1), f.map.getSize()(1));
+  EXPECT_EQ(loaded.getFrameId(), std::string("map"));
+  EXPECT_NEAR(loaded.getPosition()(0), f.map.getPosition()(0), 1e-4);
+  EXPECT_NEAR(loaded.getPosition()(1), f.map.getPosition()(1), 1e-4);
+  ASSERT_TRUE(loaded.exists(layer::elevation));
+  const auto& a = f.map.get(layer::elevation);
+  const auto& b = loaded.get(layer::elevation);
+  ASSERT_EQ(a.rows(), b.rows());
+  ASSERT_EQ(a.cols(), b.cols());
+  size_t bad = 0;
+  for (size_t i = 0; i < a.size(); ++i) {
+    const float x = a.data()[i], y = b.data()[i];
+    if (std::isnan(x) ? !std::isnan(y) : !(x == y)) ++bad;
+  }
+  EXPECT_EQ(bad, size_t(0));
+}
+TEST(Npz, RoundTripWithStartIndex) {  // :75-87
+  NpzFixture f;
+  f.map.setStartIndex(nanogrid::Index(5, 3));
+  ASSERT_TRUE(io::saveNpz(f.path, f.map));
+  ElevationMap loaded;
+  ASSERT_TRUE(io::loadNpz(f.path, loaded));
+  EXPECT_EQ(loaded.getStartIndex()(0), 5);
+  EXPECT_EQ(loaded.getStartIndex()(1), 3);
+}
+TEST(Npz, MultipleLayersSelectiveAndMissing) {  // :89-137
+  NpzFixture f;
+  f.map.add("variance");
+  auto& var = f.map.get("variance");
+  for (size_t i = 0; i < var.size(); ++i) var.data()[i] = static_cast<float>(i) * 0.01f;
+  f.map.add("intensity");
+  ASSERT_TRUE(io::saveNpz(f.path, f.map, {layer::elevation, "variance", "no_such_layer"}));
+  ElevationMap loaded;
+  ASSERT_TRUE(io::loadNpz(f.path, loaded));
+  EXPECT_TRUE(loaded.exists(layer::elevation));
+  ASSERT_TRUE(loaded.exists("variance"));
+  EXPECT_FALSE(loaded.exists("intensity"));
+  EXPECT_FALSE(loaded.exists("no_such_layer"));
+  const auto& v = loaded.get("variance");
+  size_t bad = 0;
+  for (size_t i = 0; i < v.size(); ++i) bad += v.data()[i] == static_cast<float>(i) * 0.01f ? 0 : 1;
+  EXPECT_EQ(bad, size_t(0));
+}
+TEST(Npz, EmptyMap) {  // :139-153
+  NpzFixture f;
+  ElevationMap empty(4.0f, 4.0f, 0.5f, "empty");
+  ASSERT_TRUE(io::saveNpz(f.path, empty));
+  ElevationMap loaded;
+  ASSERT_TRUE(io::loadNpz(f.path, loaded));
+  EXPECT_FLOAT_EQ(float(loaded.getResolution()), float(empty.getResolution()));
+  EXPECT_EQ(loaded.getSize()(0), empty.getSize()(0));
+  EXPECT_TRUE(loaded.get(layer::elevation).allNaN());
+}
+TEST(Npz, FutureVersionRejected) {  // :155-177
+  NpzFixture f;
+  ASSERT_TRUE(io::saveNpz(f.path, f.map));
+  std::ifstream ifs(f.path, std::ios::binary);
+  std::string content((std::istreambuf_iterator<char>(ifs)), std::istreambuf_iterator<char>());
+  ifs.close();
+  const auto pos = content.find("\"version\": 1");
+  ASSERT_TRUE(pos != std::string::npos);
+  content.replace(pos, 12, "\"version\":99");
+  std::ofstream ofs(f.path, std::ios::binary);
+  ofs.write(content.data(), std::streamsize(content.size()));
+  ofs.close();
+  ElevationMap loaded;
+  EXPECT_FALSE(io::loadNpz(f.path, loaded));
+}
+TEST(Npz, BadPaths) {  // :179-187
+  NpzFixture f;
+  ElevationMap loaded;
+  EXPECT_FALSE(io::loadNpz("/tmp/does_not_exist.npz", loaded));
+  EXPECT_FALSE(io::saveNpz("/nonexistent/dir/test.npz", f.map));
+}
+TEST(Npz, CheckpointOfAMappedSceneForNumpy) {  // the file tests/test_cpp_host_api.py opens with numpy
+  Fixture f;
+  FastDEM mapper(f.map);
+  mapper.setSensorModel(SensorType::Constant);
+  f.T_world_base.translation() = Eigen::Vector3d(1.0, -0.5, 0.0);
+  ASSERT_TRUE(mapper.integrate(makeGroundCloud(1.25f), f.T_base_sensor, f.T_world_base));
+  const char* tmp = std::getenv("TMPDIR");
+  const std::string path = std::string(tmp ? tmp : "/tmp") + "/fdm_cpp_checkpoint.npz";
+  ASSERT_TRUE(io::saveNpz(path, f.map));
+  ElevationMap back;
+  ASSERT_TRUE(io::loadNpz(path, back));
+  EXPECT_EQ(back.getLayers().size(), f.map.getLayers().size());
+  EXPECT_EQ(back.getStartIndex()(0), f.map.getStartIndex()(0));
+  EXPECT_EQ(back.get(layer::elevation).countFinite(), f.map.get(layer::elevation).countFinite());
 }
 
 // ---------------------------------------------------------- test_config.cpp (validation) ----

@@ -33,3 +33,17 @@ def test_cpp_api_spec_tests_on_gpu():
     print(r.stdout[-4000:])
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
     assert " 0 failures" in r.stdout
+    # the .npz checkpoint the C++ side wrote (fastdem/io/npz.hpp) is a plain NumPy archive
+    import tempfile
+    import numpy as np
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "fdm_cpp_checkpoint.npz")
+    assert os.path.exists(path), tempfile.gettempdir()
+    z = np.load(path)
+    meta = __import__("json").loads(bytes(z["meta"]).decode())
+    assert meta["version"] == 1 and meta["size"] == [20, 20] and meta["frame_id"] == ""
+    assert abs(meta["resolution"] - 0.5) < 1e-6 and meta["start_index"] != [0, 0]
+    elev = z["elevation"]
+    assert elev.dtype == np.float32 and elev.shape == (20, 20) and elev.flags.f_contiguous
+    assert np.isfinite(elev).sum() == 16 and np.allclose(elev[np.isfinite(elev)], 1.25)
+    assert {"variance", "n_points", "_kalman_p", "obstacle"} <= set(z.files)
+    os.remove(path)
