@@ -45,6 +45,17 @@ class FdmRaycastConfig(C.Structure):
     ]
 
 
+class FdmCloud2Layout(C.Structure):
+    """fdm_cloud2_layout: byte offsets of the PointCloud2 fields integrate() consumes (-1 = absent)."""
+
+    _fields_ = [
+        ("point_step", C.c_uint32),
+        ("off_x", C.c_int32), ("off_y", C.c_int32), ("off_z", C.c_int32),
+        ("off_intensity", C.c_int32), ("intensity_type", C.c_int32),
+        ("off_rgb", C.c_int32),
+    ]
+
+
 class FdmGeometry(C.Structure):
     _fields_ = [
         ("length_x", C.c_double), ("length_y", C.c_double), ("resolution", C.c_double),
@@ -127,6 +138,13 @@ PROTOTYPES = {
                                                      C.POINTER(FdmRaycastConfig)]),
     "fdm_engine_voxel_any": (C.c_int, [_P, C.c_uint64, _P, _P, _P, C.c_float, _P, C.POINTER(C.c_uint64)]),
     "fdm_engine_last_ray_ms": (C.c_int, [_P, _F]),
+    "fdm_engine_ingest_cloud2": (C.c_int, [_P, _P, C.c_int, C.c_uint64, C.POINTER(FdmCloud2Layout),
+                                           C.POINTER(C.c_uint64)]),
+    "fdm_engine_ingested": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
+                                      C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "fdm_engine_integrate_cloud2": (C.c_int, [_P, _P, C.c_int, C.c_uint64, C.POINTER(FdmCloud2Layout),
+                                              C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                              C.POINTER(FdmScanStats)]),
     "fdm_engine_pack_cloud": (C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
                                         C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
                                         C.c_char_p, C.c_uint64]),

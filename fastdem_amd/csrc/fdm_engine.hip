@@ -23,6 +23,7 @@
 #include "fdm_kernels.hpp"
 #include "fdm_raycast.hpp"
 #include "fdm_egress.hpp"
+#include "fdm_ingest.hpp"
 
 using namespace fdm;
 
@@ -121,6 +122,13 @@ struct fdm_engine {
   hipEvent_t ev_ray[2] = {nullptr, nullptr};
   bool ray_timed = false;
   int dbg_ray = 0;
+  // ingest (fdm_ingest.hpp)
+  uint8_t* d_blob = nullptr;         // raw message bytes
+  size_t blob_cap = 0;
+  float* d_in = nullptr;             // 5 channels x in_cap: x y z intensity rgb
+  size_t in_cap = 0;
+  uint64_t in_n = 0;
+  bool in_has_int = false, in_has_rgb = false;
   // egress (fdm_egress.hpp)
   uint32_t* pack_counts = nullptr;   // per-block valid counts / offsets (+1 for the total)
   size_t pack_counts_cap = 0;
@@ -1007,6 +1015,8 @@ void fdm_engine_destroy(fdm_engine* e) {
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : e->ev_ray)
     if (ev) (void)hipEventDestroy(ev);
+  if (e->d_blob) (void)hipFree(e->d_blob);
+  if (e->d_in) (void)hipFree(e->d_in);
   if (e->pack_counts) (void)hipFree(e->pack_counts);
   if (e->d_pack) (void)hipFree(e->d_pack);
   if (e->rc_cnt) (void)hipFree(e->rc_cnt);
@@ -1385,6 +1395,109 @@ int fdm_engine_enable_profile(fdm_engine* e, int on) {
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
   e->profile = on != 0;
   return FDM_OK;
+}
+
+// ---- ingest ----
+int fdm_engine_ingest_cloud2(fdm_engine* e, const void* data, int on_device, uint64_t n_points,
+                             const fdm_cloud2_layout* lay, uint64_t* n_valid) {
+  if (!e || !lay) return fail(FDM_ERR_INVALID, "null argument");
+  if (n_valid) *n_valid = 0;
+  e->in_n = 0;
+  e->in_has_int = e->in_has_rgb = false;
+  if (n_points == 0) return FDM_OK;                                        // impl.hpp:178-181
+  if (lay->off_x < 0 || lay->off_y < 0 || lay->off_z < 0) return FDM_OK;   // impl.hpp:183-186: no xyz
+  if (!data) return fail(FDM_ERR_INVALID, "null data");
+  if (n_points >= 0xFFFFFFFEull) return fail(FDM_ERR_INVALID, "point count exceeds 2^32-2");
+  const uint32_t step = lay->point_step;
+  auto fits = [&](int32_t off, uint32_t len) { return off < 0 || uint64_t(off) + len <= step; };
+  const uint32_t ilen = lay->intensity_type == 8 ? 8 : (lay->intensity_type == 7 ? 4 : (lay->intensity_type == 4 ? 2 : 1));
+  if (step == 0 || !fits(lay->off_x, 4) || !fits(lay->off_y, 4) || !fits(lay->off_z, 4) ||
+      !fits(lay->off_intensity, ilen) || !fits(lay->off_rgb, 4))
+    return fail(FDM_ERR_INVALID, "field offset outside the point record");
+  HIPCK(hipSetDevice(e->device));
+  const size_t bytes = size_t(n_points) * step;
+  const uint8_t* blob = static_cast<const uint8_t*>(data);
+  if (!on_device) {
+    if (bytes > e->blob_cap) {
+      HIPCK(hipStreamSynchronize(e->stream));
+      if (e->d_blob) HIPCK(hipFree(e->d_blob));
+      e->blob_cap = bytes + bytes / 4 + 4096;
+      HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_blob), e->blob_cap));
+    }
+    HIPCK(hipMemcpyAsync(e->d_blob, data, bytes, hipMemcpyHostToDevice, e->stream));
+    blob = e->d_blob;
+  }
+  if (n_points > e->in_cap) {
+    HIPCK(hipStreamSynchronize(e->stream));
+    if (e->d_in) HIPCK(hipFree(e->d_in));
+    e->in_cap = ((n_points + n_points / 4 + 1024) + 3) & ~size_t(3);  // channels stay 16-byte aligned
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_in), e->in_cap * 5 * sizeof(float)));
+  }
+  IngestLayout L{};
+  L.point_step = step;
+  L.off_x = lay->off_x; L.off_y = lay->off_y; L.off_z = lay->off_z;
+  L.off_intensity = lay->off_intensity; L.intensity_type = lay->intensity_type;
+  L.off_rgb = lay->off_rgb;
+  auto al4 = [](int32_t off) { return off < 0 || (off & 3) == 0; };
+  L.aligned = (reinterpret_cast<uintptr_t>(blob) & 3u) == 0 && (step & 3u) == 0 && al4(L.off_x) && al4(L.off_y) &&
+              al4(L.off_z) && al4(L.off_rgb) && (L.intensity_type < 7 || al4(L.off_intensity));
+  const unsigned blocks = unsigned((n_points + 255) / 256);
+  if (size_t(blocks) + 1 > e->pack_counts_cap) {
+    HIPCK(hipStreamSynchronize(e->stream));
+    if (e->pack_counts) HIPCK(hipFree(e->pack_counts));
+    e->pack_counts_cap = size_t(blocks) + 1 + 1024;
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->pack_counts), e->pack_counts_cap * sizeof(uint32_t)));
+  }
+  const bool hi = lay->off_intensity >= 0, hc = lay->off_rgb >= 0;
+  hipLaunchKernelGGL(k_ingest_count, dim3(blocks), dim3(256), 0, e->stream, blob, L, n_points, e->pack_counts);
+  hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, e->stream, e->pack_counts, blocks);
+  hipLaunchKernelGGL(k_ingest_write, dim3(blocks), dim3(256), 0, e->stream, blob, L, n_points, e->pack_counts,
+                     e->d_in, e->d_in + e->in_cap, e->d_in + 2 * e->in_cap,
+                     hi ? e->d_in + 3 * e->in_cap : static_cast<float*>(nullptr),
+                     hc ? reinterpret_cast<uint32_t*>(e->d_in + 4 * e->in_cap) : static_cast<uint32_t*>(nullptr));
+  HIPCK(hipGetLastError());
+  uint32_t total = 0;
+  HIPCK(hipMemcpyAsync(&total, e->pack_counts + blocks, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+  HIPCK(hipStreamSynchronize(e->stream));
+  e->in_n = total;
+  e->in_has_int = hi;
+  e->in_has_rgb = hc;
+  if (n_valid) *n_valid = total;
+  return FDM_OK;
+}
+
+int fdm_engine_ingested(fdm_engine* e, const float** dx, const float** dy, const float** dz,
+                        const float** dint, const uint32_t** drgb, uint64_t* n) {
+  if (!e) return fail(FDM_ERR_INVALID, "null engine");
+  if (dx) *dx = e->d_in;
+  if (dy) *dy = e->d_in ? e->d_in + e->in_cap : nullptr;
+  if (dz) *dz = e->d_in ? e->d_in + 2 * e->in_cap : nullptr;
+  if (dint) *dint = e->in_has_int ? e->d_in + 3 * e->in_cap : nullptr;
+  if (drgb) *drgb = e->in_has_rgb ? reinterpret_cast<const uint32_t*>(e->d_in + 4 * e->in_cap) : nullptr;
+  if (n) *n = e->in_n;
+  return FDM_OK;
+}
+
+int fdm_engine_integrate_cloud2(fdm_engine* e, const void* data, int on_device, uint64_t n_points,
+                                const fdm_cloud2_layout* lay, const double Tbs[16], const double Twb[16],
+                                fdm_scan_stats* out) {
+  if (!e || !lay || !Tbs || !Twb) return fail(FDM_ERR_INVALID, "null argument");
+  uint64_t n = 0;
+  int rc = fdm_engine_ingest_cloud2(e, data, on_device, n_points, lay, &n);
+  if (rc) return rc;
+  if (n == 0) {  // fastdem.cpp:125-128
+    if (out) std::memset(out, 0, sizeof(*out));
+    return FDM_SKIP_EMPTY_CLOUD;
+  }
+  const float *dx, *dy, *dz, *di;
+  const uint32_t* dc;
+  fdm_engine_ingested(e, &dx, &dy, &dz, &di, &dc, nullptr);
+  ScanParams P;
+  fill_integrate_params(e, P, Tbs, Twb);
+  if ((rc = enqueue_scan(e, P, n, dx, dy, dz, di, dc, nullptr))) return rc;
+  int status = FDM_OK;
+  if ((rc = read_stats(e, out, &status))) return rc;
+  return status;
 }
 
 // ---- map egress ----

@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import FdmConfig, FdmGeometry, FdmScanStats, FdmTile
+from .capi import FdmCloud2Layout, FdmConfig, FdmGeometry, FdmScanStats, FdmTile
 
 
 class EngineError(RuntimeError):
@@ -202,6 +202,52 @@ class Engine:
         arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
         _ck(self._lib.fdm_engine_region_unpack(self._h, r0, c0, nr, nc, arr, len(names),
                                                C.c_void_p(dbuf_ptr)))
+
+    # -- ingest --
+    @staticmethod
+    def cloud2_layout(point_step, x, y, z, intensity=-1, intensity_type=7, rgb=-1):
+        return FdmCloud2Layout(int(point_step), int(x), int(y), int(z), int(intensity),
+                               int(intensity_type), int(rgb))
+
+    def ingest_cloud2(self, blob, n_points, layout):
+        """nanopcl::from(PointCloud2): decode a host byte blob into SoA channels in HBM.
+        Returns dict of numpy copies of the kept points' channels (for tests)."""
+        b = np.ascontiguousarray(np.frombuffer(blob, dtype=np.uint8))
+        n = C.c_uint64(0)
+        _ck(self._lib.fdm_engine_ingest_cloud2(self._h, _ptr(b), 0, int(n_points), C.byref(layout),
+                                               C.byref(n)))
+        ptrs = [C.c_void_p() for _ in range(5)]
+        m = C.c_uint64(0)
+        _ck(self._lib.fdm_engine_ingested(self._h, *[C.byref(p) for p in ptrs], C.byref(m)))
+        assert m.value == n.value
+        import torch
+        out = {}
+        for name, p, dt in zip(("x", "y", "z", "intensity", "rgb"), ptrs,
+                               (np.float32,) * 4 + (np.uint32,)):
+            if not p.value or n.value == 0:
+                out[name] = None if name in ("intensity", "rgb") and not p.value else np.empty(0, dt)
+                continue
+            h = np.empty(n.value, dtype=dt)
+            hip = C.CDLL("libamdhip64.so")
+            assert hip.hipMemcpy(_ptr(h), p, h.nbytes, 2) == 0
+            out[name] = h
+        del torch
+        return out
+
+    def integrate_cloud2(self, blob, n_points, layout, T_base_sensor, T_world_base, on_device_ptr=None):
+        """from_impl + integrate in one call; blob = bytes-like (host) or a device pointer."""
+        tbs, twb = _colmajor16(T_base_sensor), _colmajor16(T_world_base)
+        st = FdmScanStats()
+        if on_device_ptr is not None:
+            data, dev = C.c_void_p(on_device_ptr), 1
+        else:
+            b = np.ascontiguousarray(np.frombuffer(blob, dtype=np.uint8))
+            data, dev = _ptr(b), 0
+        rc = _ck(self._lib.fdm_engine_integrate_cloud2(
+            self._h, data, dev, int(n_points), C.byref(layout),
+            tbs.ctypes.data_as(C.POINTER(C.c_double)), twb.ctypes.data_as(C.POINTER(C.c_double)),
+            C.byref(st)))
+        return rc, st.as_dict()
 
     # -- egress (SURVEY.md §8 f3) --
     def pack_cloud(self, elevation_layer="elevation", sub=None):

@@ -236,6 +236,36 @@ int fdm_engine_pack_cloud_device(fdm_engine* e, const char* elevation_layer, int
                                  int32_t sub_c0, int32_t sub_rows, int32_t sub_cols, void** d_out,
                                  uint64_t* n_points, uint32_t* point_step);
 
+/* ---- Ingest ----
+ * nanopcl::from(sensor_msgs::PointCloud2) (nanopcl/bridge/ros/impl.hpp:174-246) on the device.
+ * The layout carries the byte offsets the reference parses from msg.fields (impl.hpp:65-99):
+ * x, y, z are FLOAT32 and required; intensity (datatype UINT8=2, UINT16=4, FLOAT32=7, FLOAT64=8,
+ * anything else reads as 0, impl.hpp:104-118) and rgb / rgba (packed 0x00RRGGBB, impl.hpp:163-171)
+ * are optional: offset -1 = absent.  ring / time / label / normals are not consumed by integrate(). */
+typedef struct fdm_cloud2_layout {
+  uint32_t point_step;           /* msg.point_step */
+  int32_t off_x, off_y, off_z;
+  int32_t off_intensity, intensity_type;
+  int32_t off_rgb;
+} fdm_cloud2_layout;
+
+/* from_impl: decode n_points records (msg.data, width*height of them) into the engine's SoA
+ * channels in HBM, dropping points with a non-finite coordinate and keeping the order.
+ * `data` is a host pointer (copied once) or, with data_on_device != 0, already in HBM.
+ * n_valid receives the number of points kept (host sync). */
+int fdm_engine_ingest_cloud2(fdm_engine* e, const void* data, int data_on_device, uint64_t n_points,
+                             const fdm_cloud2_layout* layout, uint64_t* n_valid);
+/* The channels the last ingest produced (device pointers, engine-owned, valid until the next
+ * ingest): intensity / rgb are NULL when the message has no such field. */
+int fdm_engine_ingested(fdm_engine* e, const float** d_x, const float** d_y, const float** d_z,
+                        const float** d_intensity, const uint32_t** d_rgb, uint64_t* n);
+/* from_impl + FastDEM::integrate(cloud, T_base_sensor, T_world_base) in one call (what the ROS
+ * callback does, ros1/src/fastdem_ros_node.cpp:171-182).  Status as fdm_engine_integrate; a message
+ * without x/y/z or whose points are all non-finite is an empty cloud (FDM_SKIP_EMPTY_CLOUD). */
+int fdm_engine_integrate_cloud2(fdm_engine* e, const void* data, int data_on_device, uint64_t n_points,
+                                const fdm_cloud2_layout* layout, const double T_base_sensor[16],
+                                const double T_world_base[16], fdm_scan_stats* out);
+
 /* Parity / measurement instrumentation (not in the reference). */
 int fdm_engine_enable_cell_ids(fdm_engine* e, int on);
 /* per input point of the last scan: linear cell id (col*rows+row), -1 cropped, -2 outside map */

@@ -118,6 +118,22 @@ int64_t fdmref_pack_cloud(void* e, const char* elevation_layer, int sub_r0, int 
                           int sub_cols, uint8_t* data, uint64_t cap_bytes, uint32_t* point_step,
                           char* fields_buf, uint64_t fields_cap);
 
+/* PointCloud2 ingest (fdm_ref_ingest.hpp; nanopcl/bridge/ros/impl.hpp:174-246).  Offsets are byte
+ * offsets inside one point record, -1 = field absent; intensity_type = PointField datatype code. */
+typedef struct fdmref_cloud2_layout {
+  uint32_t point_step;
+  int32_t off_x, off_y, off_z;
+  int32_t off_intensity, intensity_type;
+  int32_t off_rgb;
+} fdmref_cloud2_layout;
+/* from_impl: writes the kept points' channels (nullable outputs, capacity n_points); returns their count */
+uint64_t fdmref_from_cloud2(const void* data, uint64_t n_points, const fdmref_cloud2_layout* layout,
+                            float* x, float* y, float* z, float* intensity, uint32_t* rgb);
+/* from_impl + FastDEM::integrate */
+int fdmref_integrate_cloud2(void* e, const void* data, uint64_t n_points,
+                            const fdmref_cloud2_layout* layout, const double* T_base_sensor,
+                            const double* T_world_base, fdmref_stats* out);
+
 /* unit-level entry points for the reference's known-answer tests */
 void fdmref_sensor_covariance(const fdmref_config* cfg, const float* p3, float* cov9_colmajor);
 /* state8 = {x, P, count, sample_mean, sample_var, m2, upper, lower} */

@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "fdm_ref.hpp"
+#include "fdm_ref_ingest.hpp"
 
 using namespace fdmref;
 
@@ -237,6 +238,36 @@ int64_t fdmref_pack_cloud(void* e, const char* elevation_layer, int sub_r0, int 
   }
   if (data && cap_bytes >= pc.data.size()) std::memcpy(data, pc.data.data(), pc.data.size());
   return int64_t(pc.n_points);
+}
+
+static Cloud2Layout toLayout(const fdmref_cloud2_layout* l) {
+  Cloud2Layout o;
+  o.point_step = l->point_step;
+  o.off_x = l->off_x; o.off_y = l->off_y; o.off_z = l->off_z;
+  o.off_intensity = l->off_intensity; o.intensity_type = l->intensity_type;
+  o.off_rgb = l->off_rgb;
+  return o;
+}
+uint64_t fdmref_from_cloud2(const void* data, uint64_t n_points, const fdmref_cloud2_layout* layout,
+                            float* x, float* y, float* z, float* intensity, uint32_t* rgb) {
+  const Cloud c = fromCloud2(static_cast<const uint8_t*>(data), n_points, toLayout(layout));
+  for (size_t i = 0; i < c.size(); ++i) {
+    if (x) x[i] = c.pts[i][0];
+    if (y) y[i] = c.pts[i][1];
+    if (z) z[i] = c.pts[i][2];
+    if (intensity && c.has_intensity) intensity[i] = c.intensity[i];
+    if (rgb && c.has_color) rgb[i] = packColor(c.color[i][0], c.color[i][1], c.color[i][2]);
+  }
+  return c.size();
+}
+int fdmref_integrate_cloud2(void* e, const void* data, uint64_t n_points,
+                            const fdmref_cloud2_layout* layout, const double* T_bs, const double* T_wb,
+                            fdmref_stats* out) {
+  const Cloud c = fromCloud2(static_cast<const uint8_t*>(data), n_points, toLayout(layout));
+  ScanStats s;
+  const Status st = E(e)->integrate(c, T_bs, T_wb, &s);
+  copyStats(s, out);
+  return st;
 }
 
 void fdmref_set_voxel_stable(void* e, int on) { E(e)->voxel_stable = on != 0; }

@@ -39,6 +39,15 @@ class RefConfig(C.Structure):
     ]
 
 
+class RefCloud2Layout(C.Structure):
+    _fields_ = [
+        ("point_step", C.c_uint32),
+        ("off_x", C.c_int32), ("off_y", C.c_int32), ("off_z", C.c_int32),
+        ("off_intensity", C.c_int32), ("intensity_type", C.c_int32),
+        ("off_rgb", C.c_int32),
+    ]
+
+
 class RefStats(C.Structure):
     _fields_ = [
         ("n_input", C.c_uint32), ("n_after_filter", C.c_uint32),
@@ -118,6 +127,11 @@ def load(native=False):
     lib.fdmref_last_preprocessed.argtypes = [P, C.c_uint64, P, P, P, P]
     lib.fdmref_last_rasterized.restype = C.c_uint64
     lib.fdmref_last_rasterized.argtypes = [P, C.c_uint64, P, P, P]
+    lib.fdmref_from_cloud2.restype = C.c_uint64
+    lib.fdmref_from_cloud2.argtypes = [P, C.c_uint64, C.POINTER(RefCloud2Layout), P, P, P, P, P]
+    lib.fdmref_integrate_cloud2.restype = C.c_int
+    lib.fdmref_integrate_cloud2.argtypes = [P, P, C.c_uint64, C.POINTER(RefCloud2Layout), D, D,
+                                            C.POINTER(RefStats)]
     lib.fdmref_pack_cloud.restype = C.c_int64
     lib.fdmref_pack_cloud.argtypes = [P, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, P, C.c_uint64,
                                       C.POINTER(C.c_uint32), C.c_char_p, C.c_uint64]
@@ -299,6 +313,16 @@ class RefEngine:
         n = self._lib.fdmref_last_rasterized(self._h, cap, *[_ptr(v) for v in a])
         return [v[:n] for v in a]
 
+    # -- ingest --
+    def integrate_cloud2(self, blob, n_points, layout, T_base_sensor, T_world_base):
+        b = np.ascontiguousarray(np.frombuffer(blob, dtype=np.uint8))
+        lay = RefCloud2Layout(*[getattr(layout, k) for k, _ in RefCloud2Layout._fields_])
+        tbs, twb = _colmajor16(T_base_sensor), _colmajor16(T_world_base)
+        st = RefStats()
+        rc = self._lib.fdmref_integrate_cloud2(self._h, _ptr(b), int(n_points), C.byref(lay), _dp(tbs),
+                                               _dp(twb), C.byref(st))
+        return rc, st.as_dict()
+
     # -- egress --
     def pack_cloud(self, elevation_layer="elevation", sub=None):
         """toPointCloud2Impl: (fields, point_step, data[n_points, n_fields] float32 view)."""
@@ -352,6 +376,19 @@ def voxel_any(x, y, z, voxel_size, stable=True):
     if n < 0:
         raise ValueError("voxel_size must be in [0.001, 100]")
     return out[:n].copy()
+
+
+def from_cloud2(blob, n_points, layout):
+    """nanopcl from_impl: dict of the kept points' channels."""
+    b = np.ascontiguousarray(np.frombuffer(blob, dtype=np.uint8))
+    lay = RefCloud2Layout(*[getattr(layout, k) for k, _ in RefCloud2Layout._fields_])
+    x, y, z, a = (np.empty(max(n_points, 1), dtype=np.float32) for _ in range(4))
+    c = np.empty(max(n_points, 1), dtype=np.uint32)
+    n = load().fdmref_from_cloud2(_ptr(b), int(n_points), C.byref(lay), _ptr(x), _ptr(y), _ptr(z), _ptr(a),
+                                  _ptr(c))
+    return {"x": x[:n].copy(), "y": y[:n].copy(), "z": z[:n].copy(),
+            "intensity": a[:n].copy() if lay.off_intensity >= 0 else None,
+            "rgb": c[:n].copy() if lay.off_rgb >= 0 else None}
 
 
 def voxel_pack(x, y, z, inv):
