@@ -1,7 +1,7 @@
 // fastdem/config/fastdem.hpp (fastdem/include/fastdem/config/fastdem.hpp:23-38) + the
 // validation semantics of fastdem/src/config_fastdem.cpp:128-260 (throw on min_var >= max_var and
-// on unsorted P2 markers, otherwise warn + clamp).  The YAML loader (parseConfig / loadConfig)
-// is the "next" row f4: yaml-cpp is not available here, so configs are filled programmatically.
+// on unsorted P2 markers, otherwise warn + clamp), and the YAML loader parseConfig / loadConfig
+// (config_fastdem.cpp:57-126,262-277) over the YAML subset in yaml_lite.hpp.
 #pragma once
 #include <algorithm>
 #include <cstdio>
@@ -12,6 +12,7 @@
 #include "fastdem/config/mapping.hpp"
 #include "fastdem/config/postprocess.hpp"
 #include "fastdem/config/sensor_model.hpp"
+#include "fastdem/config/yaml_lite.hpp"
 
 namespace fastdem {
 namespace config {
@@ -71,6 +72,100 @@ inline void validate(Config& m) {
   if (s.rgbd.lateral_factor < 0.0f) { warn("sensor.rgbd.lateral_factor must be >= 0, clamping to 0"); s.rgbd.lateral_factor = 0.0f; }
 }
 }  // namespace detail
+
+namespace detail {
+template <typename T>
+inline void load(const yaml::Node& node, const std::string& key, T& value) {  // config_fastdem.cpp:26-31
+  if (node[key]) value = node[key].as<T>();
+}
+// detail::parse of config_fastdem.cpp:57-126: every key optional, unknown enum strings warn + default
+inline Config parse(const yaml::Node& root) {
+  Config cfg;
+  if (const auto& n = root["mapping"]) {
+    auto& m = cfg.mapping;
+    std::string mode, type;
+    load(n, "mode", mode);
+    if (!mode.empty()) {
+      if (mode == "local") m.mode = MappingMode::LOCAL;
+      else if (mode == "global") m.mode = MappingMode::GLOBAL;
+      else { warn("Unknown mapping mode '" + mode + "', defaulting to local"); m.mode = MappingMode::LOCAL; }
+    }
+    load(n, "type", type);
+    if (!type.empty()) {
+      if (type == "kalman_filter") m.estimation_type = EstimationType::Kalman;
+      else if (type == "p2_quantile") m.estimation_type = EstimationType::P2Quantile;
+      else { warn("Unknown estimation type '" + type + "', defaulting to kalman_filter"); m.estimation_type = EstimationType::Kalman; }
+    }
+    if (const auto& k = n["kalman"]) {
+      load(k, "min_variance", m.kalman.min_variance);
+      load(k, "max_variance", m.kalman.max_variance);
+      load(k, "process_noise", m.kalman.process_noise);
+    }
+    if (const auto& p = n["p2"]) {
+      load(p, "dn0", m.p2.dn0);
+      load(p, "dn1", m.p2.dn1);
+      load(p, "dn2", m.p2.dn2);
+      load(p, "dn3", m.p2.dn3);
+      load(p, "dn4", m.p2.dn4);
+      load(p, "elevation_marker", m.p2.elevation_marker);
+      load(p, "max_sample_count", m.p2.max_sample_count);
+    }
+  }
+  if (const auto& n = root["point_filter"]) {
+    load(n, "z_min", cfg.point_filter.z_min);
+    load(n, "z_max", cfg.point_filter.z_max);
+    load(n, "range_min", cfg.point_filter.range_min);
+    load(n, "range_max", cfg.point_filter.range_max);
+  }
+  if (const auto& n = root["raycasting"]) {
+    load(n, "enabled", cfg.raycasting.enabled);
+    load(n, "height_conflict_threshold", cfg.raycasting.height_conflict_threshold);
+    load(n, "log_odds_observed", cfg.raycasting.log_odds_observed);
+    load(n, "log_odds_ghost", cfg.raycasting.log_odds_ghost);
+    load(n, "log_odds_max", cfg.raycasting.log_odds_max);
+    load(n, "clear_threshold", cfg.raycasting.clear_threshold);
+  }
+  if (const auto& n = root["sensor_model"]) {
+    std::string type;
+    load(n, "type", type);
+    if (!type.empty()) {
+      if (type == "lidar" || type == "laser") cfg.sensor_model.type = SensorType::LiDAR;
+      else if (type == "rgbd") cfg.sensor_model.type = SensorType::RGBD;
+      else if (type == "constant" || type == "none") cfg.sensor_model.type = SensorType::Constant;
+      else { warn("Unknown sensor_model.type '" + type + "', defaulting to LiDAR"); cfg.sensor_model.type = SensorType::LiDAR; }
+    }
+    if (const auto& l = n["lidar"]) {
+      load(l, "range_noise", cfg.sensor_model.lidar.range_noise);
+      load(l, "angular_noise", cfg.sensor_model.lidar.angular_noise);
+    }
+    if (const auto& r = n["rgbd"]) {
+      load(r, "normal_a", cfg.sensor_model.rgbd.normal_a);
+      load(r, "normal_b", cfg.sensor_model.rgbd.normal_b);
+      load(r, "normal_c", cfg.sensor_model.rgbd.normal_c);
+      load(r, "lateral_factor", cfg.sensor_model.rgbd.lateral_factor);
+    }
+    if (const auto& c = n["constant"]) load(c, "uncertainty", cfg.sensor_model.constant.uncertainty);
+  }
+  return cfg;
+}
+}  // namespace detail
+
+/// parseConfig (config_fastdem.cpp:262-266): parse + validate.
+inline Config parseConfig(const yaml::Node& root) {
+  Config cfg = detail::parse(root);
+  detail::validate(cfg);
+  return cfg;
+}
+/// The same from YAML text.
+inline Config parseConfigText(const std::string& text) { return parseConfig(yaml::parse(text)); }
+/// loadConfig (config_fastdem.cpp:268-275): std::runtime_error when the file cannot be read or parsed.
+inline Config loadConfig(const std::string& path) {
+  try {
+    return parseConfig(yaml::loadFile(path));
+  } catch (const yaml::Error& e) {
+    throw std::runtime_error("Failed to load config: " + path + " - " + e.what());
+  }
+}
 
 /// Validate + clamp a programmatically built config exactly like parseConfig() does after parsing.
 inline Config validated(Config cfg) {

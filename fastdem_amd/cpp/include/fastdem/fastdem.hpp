@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <functional>
 #include <memory>
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "fastdem/config/fastdem.hpp"
@@ -125,6 +127,45 @@ class FastDEM {
     return integrateImpl(cloud, T_base_sensor, T_world_base);
   }
 
+  /// sensor_msgs/PointCloud2-shaped message straight to the device (what the ROS scan callback does
+  /// with nanopcl::from + integrate, ros1/src/fastdem_ros_node.cpp:171-182): the raw bytes cross
+  /// PCIe once; field decoding, the finite-point filter of from_impl
+  /// (nanopcl/bridge/ros/impl.hpp:174-246) and the map update all run in HBM.
+  /// Msg needs: width, height, point_step, data (contiguous bytes), fields[] with name / offset /
+  /// datatype.  Built-in sensor models only (a user SensorModel subclass needs host points: decode
+  /// with your bridge and call integrate(PointCloud, ...)).
+  template <typename Msg>
+  bool integrateCloud2(const Msg& msg, const Eigen::Isometry3d& T_base_sensor,
+                       const Eigen::Isometry3d& T_world_base) {
+    SensorType builtin;
+    if (sensor_model_ && !sensor_model_->builtin(builtin))
+      throw std::invalid_argument("integrateCloud2: custom SensorModel needs host points");
+    fdm_cloud2_layout lay{};
+    lay.point_step = msg.point_step;
+    lay.off_x = lay.off_y = lay.off_z = lay.off_intensity = lay.off_rgb = -1;
+    for (const auto& f : msg.fields) {  // FieldOffsets::parse (impl.hpp:65-99)
+      const std::string name = f.name;
+      if (name == "x") lay.off_x = int32_t(f.offset);
+      else if (name == "y") lay.off_y = int32_t(f.offset);
+      else if (name == "z") lay.off_z = int32_t(f.offset);
+      else if (name == "intensity") { lay.off_intensity = int32_t(f.offset); lay.intensity_type = int32_t(f.datatype); }
+      else if (name == "rgb" || name == "rgba") lay.off_rgb = int32_t(f.offset);
+    }
+    const uint64_t n = uint64_t(msg.width) * uint64_t(msg.height);
+    map_.flushToDevice();
+    const fdm_config f = detail::toEngineConfig(effectiveConfig());
+    detail::ck(fdm_engine_set_config(map_.engine(), &f), "fdm_engine_set_config");
+    const int rc = fdm_engine_integrate_cloud2(map_.engine(), msg.data.data(), 0, n, &lay,
+                                               T_base_sensor.matrix().data(), T_world_base.matrix().data(), &last_);
+    detail::ck(rc, "fdm_engine_integrate_cloud2");
+    map_.invalidateHost();
+    if (rc == FDM_SKIP_EMPTY_CLOUD) std::fprintf(stderr, "[warn] [FastDEM] Received empty cloud. Skipping...\n");
+    if (rc != FDM_OK) return false;
+    if (on_preprocessed_) on_preprocessed_(fetch(true, last_.n_input));
+    if (on_rasterized_ && last_.n_cells_touched > 0) on_rasterized_(fetch(false, last_.n_cells_touched));
+    return true;
+  }
+
   /// Scan callbacks (fastdem.hpp:129-136).  The clouds are captured on the device and
   /// materialised on the host only while a callback is registered: the preprocessed scan (points
   /// that survived the filters, map frame, input order) and the rasterized scan (one point per
@@ -136,15 +177,11 @@ class FastDEM {
   const fdm_scan_stats& lastStats() const { return last_; }
 
  private:
-  // integrateImpl (fastdem.cpp:133-162): preprocessScan + ElevationMapping::update, on the device
-  bool integrateImpl(const PointCloud& cloud, const Eigen::Isometry3d& T_base_sensor,
-                     const Eigen::Isometry3d& T_world_base) {
-    map_.flushToDevice();
+  // cfg_ with the built-in sensor model's parameters taken from the model OBJECT
+  Config effectiveConfig() const {
     Config eff = cfg_;
-    const float* sigma = nullptr;
     SensorType builtin;
     if (sensor_model_ && sensor_model_->builtin(builtin)) {
-      // built-in model: evaluated on the device with the parameters the OBJECT carries
       eff.sensor_model.type = builtin;
       if (auto* l = dynamic_cast<const LiDARSensorModel*>(sensor_model_.get())) {
         eff.sensor_model.lidar.range_noise = l->rangeNoise();
@@ -157,6 +194,18 @@ class FastDEM {
       } else if (auto* c = dynamic_cast<const ConstantUncertaintyModel*>(sensor_model_.get())) {
         eff.sensor_model.constant.uncertainty = c->uncertainty();
       }
+    }
+    return eff;
+  }
+  // integrateImpl (fastdem.cpp:133-162): preprocessScan + ElevationMapping::update, on the device
+  bool integrateImpl(const PointCloud& cloud, const Eigen::Isometry3d& T_base_sensor,
+                     const Eigen::Isometry3d& T_world_base) {
+    map_.flushToDevice();
+    Config eff = effectiveConfig();
+    const float* sigma = nullptr;
+    SensorType builtin;
+    if (sensor_model_ && sensor_model_->builtin(builtin)) {
+      // evaluated on the device with the parameters the OBJECT carries (effectiveConfig)
     } else if (sensor_model_) {
       // user SensorModel subclass: evaluate on the host, hand over sigma_z^2 = (R Sigma R^T)(2,2)
       const Eigen::Matrix3f R = (T_world_base * T_base_sensor).rotation().cast<float>();

@@ -498,6 +498,53 @@ TEST(Raycasting, EnabledThroughIntegrate) {  // fastdem.cpp:152-159, default.yam
   EXPECT_FLOAT_EQ(f.map.at(layer::visibility_logodds, hit), 0.4f);
 }
 
+// ------------------------------------------- PointCloud2-shaped message straight to the device ----
+namespace {
+struct FakeField { std::string name; uint32_t offset; uint8_t datatype; uint32_t count; };
+struct FakeCloud2 {  // the members of sensor_msgs::PointCloud2 that nanopcl::from reads
+  uint32_t height = 1, width = 0, point_step = 0;
+  std::vector<FakeField> fields;
+  std::vector<uint8_t> data;
+};
+}  // namespace
+TEST(Cloud2, IntegrateMessageEqualsIntegrateCloud) {  // nanopcl/bridge/ros/impl.hpp:174-246
+  Fixture a, b;
+  FastDEM ma(a.map), mb(b.map);
+  const PointCloud cloud = makeGroundCloud(0.75f);
+  FakeCloud2 msg;
+  msg.point_step = 20;
+  msg.fields = {{"x", 0, 7, 1}, {"y", 4, 7, 1}, {"z", 8, 7, 1}, {"ring", 12, 4, 1}, {"intensity", 16, 7, 1}};
+  const float nanv = NAN;
+  for (size_t i = 0; i <= cloud.size(); ++i) {  // one extra NaN point: from_impl drops it
+    const bool extra = i == cloud.size();
+    float rec[5] = {extra ? nanv : cloud.xData()[i], extra ? 0.f : cloud.yData()[i], extra ? 0.f : cloud.zData()[i], 0.f,
+                    0.5f};
+    const uint8_t* p = reinterpret_cast<const uint8_t*>(rec);
+    msg.data.insert(msg.data.end(), p, p + 20);
+  }
+  msg.width = uint32_t(cloud.size() + 1);
+  ASSERT_TRUE(ma.integrateCloud2(msg, a.T_base_sensor, a.T_world_base));
+  PointCloud with_i;
+  for (size_t i = 0; i < cloud.size(); ++i) with_i.add(cloud.xData()[i], cloud.yData()[i], cloud.zData()[i], nanopcl::Intensity(0.5f));
+  ASSERT_TRUE(mb.integrate(with_i, b.T_base_sensor, b.T_world_base));
+  EXPECT_EQ(ma.lastStats().n_input, uint32_t(cloud.size()));
+  ASSERT_TRUE(a.map.exists(layer::intensity));
+  for (const auto& name : b.map.getLayers()) {
+    const auto& x = a.map.get(name);
+    const auto& y = b.map.get(name);
+    size_t bad = 0;
+    for (size_t i = 0; i < x.size(); ++i) {
+      const float u = x.data()[i], v = y.data()[i];
+      if (std::isnan(u) ? !std::isnan(v) : !(u == v)) ++bad;
+    }
+    EXPECT_EQ(bad, size_t(0));
+  }
+  FakeCloud2 empty = msg;
+  empty.width = 0;
+  empty.data.clear();
+  EXPECT_FALSE(ma.integrateCloud2(empty, a.T_base_sensor, a.T_world_base));
+}
+
 // ------------------------------------------------------- test_map_io.cpp (NPZ) ----
 namespace {
 struct NpzFixture {  // test_map_io.cpp:19-41
@@ -610,6 +657,77 @@ TEST(Npz, CheckpointOfAMappedSceneForNumpy) {  // the file tests/test_cpp_host_a
   EXPECT_EQ(back.getLayers().size(), f.map.getLayers().size());
   EXPECT_EQ(back.getStartIndex()(0), f.map.getStartIndex()(0));
   EXPECT_EQ(back.get(layer::elevation).countFinite(), f.map.get(layer::elevation).countFinite());
+}
+
+// ------------------------------------------------------ test_config.cpp (YAML loading) ----
+namespace {
+std::string writeTempYaml(const std::string& content, const std::string& name) {  // test_config.cpp:24-30
+  const char* tmp = std::getenv("TMPDIR");
+  const std::string path = std::string(tmp ? tmp : "/tmp") + "/fdm_" + name;
+  std::ofstream fs(path);
+  fs << content;
+  return path;
+}
+}  // namespace
+TEST(ConfigLoad, ShippedDefaultYaml) {  // :36-43 (fastdem_amd/config/default.yaml carries the same values)
+  const char* dir = std::getenv("FDM_CONFIG_DIR");
+  const Config cfg = loadConfig(std::string(dir ? dir : "fastdem_amd/config") + "/default.yaml");
+  EXPECT_TRUE(cfg.mapping.estimation_type == EstimationType::Kalman);
+  EXPECT_TRUE(cfg.sensor_model.type == SensorType::LiDAR);
+  EXPECT_TRUE(cfg.raycasting.enabled);
+  EXPECT_FLOAT_EQ(cfg.point_filter.z_min, -1.0f);
+  EXPECT_FLOAT_EQ(cfg.point_filter.range_max, 20.0f);
+  EXPECT_FLOAT_EQ(cfg.mapping.p2.dn3, 0.84f);
+  EXPECT_FLOAT_EQ(cfg.sensor_model.rgbd.normal_c, 0.4f);
+  EXPECT_FLOAT_EQ(cfg.raycasting.clear_threshold, -1.0f);
+}
+TEST(ConfigLoad, MissingFileAndDefaults) {  // :45-58, :109-113, :149-158
+  EXPECT_THROW(loadConfig("/nonexistent/path.yaml"), std::runtime_error);
+  const Config cfg = loadConfig(writeTempYaml("# empty config\n", "test_empty.yaml"));
+  const Config d;
+  EXPECT_TRUE(cfg.mapping.mode == d.mapping.mode);
+  EXPECT_TRUE(cfg.mapping.estimation_type == d.mapping.estimation_type);
+  EXPECT_TRUE(cfg.sensor_model.type == d.sensor_model.type);
+  EXPECT_FLOAT_EQ(cfg.point_filter.z_min, d.point_filter.z_min);
+  EXPECT_FLOAT_EQ(cfg.point_filter.range_max, d.point_filter.range_max);
+  EXPECT_FALSE(cfg.raycasting.enabled);
+}
+TEST(ConfigLoad, PartialAndEnumValues) {  // :60-107
+  const Config p2 = loadConfig(writeTempYaml("mapping:\n  type: p2_quantile\n", "test_partial.yaml"));
+  EXPECT_TRUE(p2.mapping.estimation_type == EstimationType::P2Quantile);
+  EXPECT_TRUE(p2.mapping.mode == MappingMode::LOCAL);
+  EXPECT_FLOAT_EQ(p2.sensor_model.lidar.range_noise, 0.02f);
+  EXPECT_TRUE(parseConfigText("mapping:\n  type: kalman_filter\n").mapping.estimation_type == EstimationType::Kalman);
+  EXPECT_TRUE(parseConfigText("sensor_model:\n  type: lidar\n").sensor_model.type == SensorType::LiDAR);
+  EXPECT_TRUE(parseConfigText("sensor_model:\n  type: rgbd\n").sensor_model.type == SensorType::RGBD);
+  EXPECT_TRUE(parseConfigText("sensor_model:\n  type: constant\n").sensor_model.type == SensorType::Constant);
+  EXPECT_TRUE(parseConfigText("sensor_model:\n  type: \"laser\"\n").sensor_model.type == SensorType::LiDAR);
+  EXPECT_TRUE(parseConfigText("sensor_model:\n  type: bogus\n").sensor_model.type == SensorType::LiDAR);
+  EXPECT_TRUE(parseConfigText("mapping:\n  mode: global\n").mapping.mode == MappingMode::GLOBAL);
+}
+TEST(ConfigLoad, NumericBlocks) {  // :115-147
+  const Config k = parseConfigText(
+      "mapping:\n  type: kalman_filter\n  kalman:\n    min_variance: 0.001\n    max_variance: 0.05\n"
+      "    process_noise: 0.001\n");
+  EXPECT_FLOAT_EQ(k.mapping.kalman.min_variance, 0.001f);
+  EXPECT_FLOAT_EQ(k.mapping.kalman.max_variance, 0.05f);
+  EXPECT_FLOAT_EQ(k.mapping.kalman.process_noise, 0.001f);
+  const Config f = parseConfigText(
+      "point_filter:\n  z_min: -0.5   # metres\n  z_max: 2.0\n  range_min: 0.5\n  range_max: 20.0\n"
+      "raycasting:\n  enabled: true\n  log_odds_ghost: 0.3\n");
+  EXPECT_FLOAT_EQ(f.point_filter.z_min, -0.5f);
+  EXPECT_FLOAT_EQ(f.point_filter.z_max, 2.0f);
+  EXPECT_FLOAT_EQ(f.point_filter.range_min, 0.5f);
+  EXPECT_FLOAT_EQ(f.point_filter.range_max, 20.0f);
+  EXPECT_TRUE(f.raycasting.enabled);
+  EXPECT_FLOAT_EQ(f.raycasting.log_odds_ghost, 0.3f);
+}
+TEST(ConfigLoad, ValidationRunsAfterParsingAndBadYamlThrows) {  // :160-183; yaml-cpp bad conversion -> runtime_error
+  EXPECT_THROW(parseConfigText("mapping:\n  kalman:\n    min_variance: 0.1\n    max_variance: 0.01\n"), std::invalid_argument);
+  EXPECT_THROW(parseConfigText("mapping:\n  p2:\n    dn0: 0.9\n    dn1: 0.1\n"), std::invalid_argument);
+  EXPECT_FLOAT_EQ(parseConfigText("sensor_model:\n  lidar:\n    range_noise: -1.0\n").sensor_model.lidar.range_noise, 0.02f);
+  EXPECT_THROW(loadConfig(writeTempYaml("point_filter:\n  z_min: not_a_number\n", "test_bad.yaml")), std::runtime_error);
+  EXPECT_THROW(loadConfig(writeTempYaml("point_filter:\n  - 1\n  - 2\n", "test_seq.yaml")), std::runtime_error);
 }
 
 // ---------------------------------------------------------- test_config.cpp (validation) ----
