@@ -127,16 +127,23 @@ __global__ __launch_bounds__(256) void k_pack_write(const PackParams Q, const Ge
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 0) s_w[w] = unsigned(__popcll(m));
   __syncthreads();
-  if (!pc.valid) return;
-  unsigned rank = unsigned(__popcll(m & ((1ull << lane) - 1ull)));
-  for (int q = 0; q < w; ++q) rank += s_w[q];
+  // records are staged in LDS (rank-major) and leave as one contiguous, fully coalesced run
+  extern __shared__ float s_rec[];
   const int nf = 3 + Q.n_float + (Q.has_color ? 1 : 0);
-  float* p = out + (size_t(offsets[blockIdx.x]) + rank) * size_t(nf);
-  p[0] = pc.x;
-  p[1] = pc.y;
-  p[2] = pc.z;
-  for (int k = 0; k < Q.n_float; ++k) p[3 + k] = L.ptr[k][pc.o * size_t(L.stride[k])];
-  if (Q.has_color) p[3 + Q.n_float] = L.color[pc.o];
+  if (pc.valid) {
+    unsigned rank = unsigned(__popcll(m & ((1ull << lane) - 1ull)));
+    for (int q = 0; q < w; ++q) rank += s_w[q];
+    float* p = s_rec + size_t(rank) * nf;
+    p[0] = pc.x;
+    p[1] = pc.y;
+    p[2] = pc.z;
+    for (int k = 0; k < Q.n_float; ++k) p[3 + k] = L.ptr[k][pc.o * size_t(L.stride[k])];
+    if (Q.has_color) p[3 + Q.n_float] = L.color[pc.o];
+  }
+  __syncthreads();
+  const unsigned n_out = (s_w[0] + s_w[1] + s_w[2] + s_w[3]) * unsigned(nf);
+  float* dst = out + size_t(offsets[blockIdx.x]) * size_t(nf);
+  for (unsigned k = threadIdx.x; k < n_out; k += 256u) dst[k] = s_rec[k];
 }
 
 }  // namespace fdm

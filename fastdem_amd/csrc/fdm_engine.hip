@@ -1575,7 +1575,8 @@ int pack_write(fdm_engine* e, const PackPlan& pl, uint64_t n_points) {
     HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_pack), e->pack_cap * sizeof(float)));
   }
   if (n_points == 0) return FDM_OK;
-  hipLaunchKernelGGL(k_pack_write, dim3(pl.blocks), dim3(256), 0, e->stream, pl.Q, e->G, e->d_state, pl.L,
+  const size_t lds = 256 * pl.fields.size() * sizeof(float);  // <= 256 * 68 * 4 = 68 KB of the CU's 160 KB
+  hipLaunchKernelGGL(k_pack_write, dim3(pl.blocks), dim3(256), lds, e->stream, pl.Q, e->G, e->d_state, pl.L,
                      e->pack_counts, e->d_pack);
   HIPCK(hipGetLastError());
   return FDM_OK;

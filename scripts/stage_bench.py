@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Device time of the stages either side of the hot path (SURVEY.md §8 f3 egress, f4 ingest), with the
+algorithmic bytes each moves and the CPU oracle beside it.   python scripts/stage_bench.py [c2|c4]
+One JSON line per stage.  Timing: HIP events on the engine's... the entry points are synchronous
+(they return counts), so wall time of the call with inputs resident in HBM is reported, plus the
+kernel-only time from rocprofv3 when run under scripts/prof_stages.sh."""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import bench  # noqa: E402
+from fastdem_amd import synth  # noqa: E402
+from cloud2 import make_blob  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("workload", nargs="?", default="c4")
+ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--cpu-iters", type=int, default=3)
+a = ap.parse_args()
+wl = synth.make(a.workload)
+res = bench.Resident(wl, 0)
+for k in range(12):
+    res.step(k)
+res.eng.sync()
+eng = res.eng
+HBM = 8.0e12
+
+
+def timed(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+# ---- egress: toPointCloud2 compaction + packing, records stay in HBM ----
+d_ptr, n_pts, step = eng.pack_cloud_device()
+t = timed(lambda: eng.pack_cloud_device(), a.iters)
+cells = eng.rows * eng.cols
+nf = step // 4
+alg = cells * 4 * 2 + n_pts * ((nf - 2) * 4 + step)  # elevation read by count+fill, layers read, records written
+import fdm_ref_py as R  # noqa: E402  (CPU baseline only)
+ref = R.RefEngine(wl.width, wl.height, wl.resolution, wl.apply_to(R.default_config()))
+for name in eng.layers():
+    ref.set_layer(name, eng.layer(name))
+g = eng.geometry()
+ref.set_position(g.position_x, g.position_y)
+ref.set_start_index(g.start_row, g.start_col)
+t0 = time.perf_counter()
+for _ in range(a.cpu_iters):
+    f_ref, s_ref, d_ref = ref.pack_cloud()
+t_cpu = (time.perf_counter() - t0) / a.cpu_iters
+assert d_ref.shape[0] == n_pts and s_ref == step
+print(json.dumps({"stage": "egress_pack_cloud", "workload": a.workload, "cells": cells, "points_out": n_pts,
+                  "point_step": step, "gpu_ms": round(t * 1e3, 4), "algorithmic_MB": round(alg / 1e6, 2),
+                  "GBps": round(alg / t / 1e9, 1), "hbm_frac": round(alg / t / HBM, 4),
+                  "cpu_oracle_ms": round(t_cpu * 1e3, 2), "speedup": round(t_cpu / t, 1)}))
+
+# ---- ingest: PointCloud2 blob (32-byte records, x y z _ intensity ring time) already in HBM ----
+s = wl.scans[0]
+blob, lay = make_blob(s["x"], s["y"], s["z"], intensity=s["intensity"] if s["intensity"] is not None else np.zeros_like(s["x"]),
+                      offsets=dict(x=0, y=4, z=8, intensity=16), point_step=32)
+n = s["x"].size
+d_blob = torch.from_numpy(np.ascontiguousarray(blob)).cuda()
+layout = eng.cloud2_layout(lay.point_step, lay.off_x, lay.off_y, lay.off_z, lay.off_intensity, lay.intensity_type, lay.off_rgb)
+import ctypes as C  # noqa: E402
+nv = C.c_uint64(0)
+
+
+def ingest():
+    rc = eng._lib.fdm_engine_ingest_cloud2(eng._h, C.c_void_p(d_blob.data_ptr()), 1, n, C.byref(layout), C.byref(nv))
+    assert rc == 0
+
+
+t = timed(ingest, a.iters)
+alg = n * 32 + n * 12 + nv.value * 16  # records read (count pass reads xyz only), SoA written
+t0 = time.perf_counter()
+for _ in range(a.cpu_iters):
+    c_ref = R.from_cloud2(blob, n, lay)
+t_cpu = (time.perf_counter() - t0) / a.cpu_iters
+assert c_ref["x"].size == nv.value
+print(json.dumps({"stage": "ingest_cloud2", "workload": a.workload, "points": n, "kept": nv.value, "point_step": 32,
+                  "gpu_ms": round(t * 1e3, 4), "algorithmic_MB": round(alg / 1e6, 2), "GBps": round(alg / t / 1e9, 1),
+                  "hbm_frac": round(alg / t / HBM, 4), "cpu_oracle_ms": round(t_cpu * 1e3, 2),
+                  "speedup": round(t_cpu / t, 1)}))
