@@ -134,6 +134,17 @@ int fdmref_integrate_cloud2(void* e, const void* data, uint64_t n_points,
                             const fdmref_cloud2_layout* layout, const double* T_base_sensor,
                             const double* T_world_base, fdmref_stats* out);
 
+/* stencil post-processing (fdm_ref_post.hpp): inpainting.cpp:21-67, spatial_smoothing.hpp:38-67,
+ * uncertainty_fusion.cpp:103-186, feature_extraction.cpp:28-118 */
+void fdmref_apply_inpainting(void* e, int max_iterations, int min_valid_neighbors, int inplace);
+void fdmref_apply_spatial_smoothing(void* e, const char* layer, int kernel_size, int min_valid_neighbors);
+void fdmref_apply_uncertainty_fusion(void* e, int enabled, float search_radius, float spatial_sigma,
+                                     float quantile_lower, float quantile_upper, int min_valid_neighbors);
+void fdmref_apply_feature_extraction(void* e, float analysis_radius, int min_valid_neighbors,
+                                     float step_lower_percentile, float step_upper_percentile);
+/* Eigen SelfAdjointEigenSolver<Matrix3f>::computeDirect restated: cov9 column-major -> val3 ascending, vec9 */
+void fdmref_eig3(const float* cov9, float* val3, float* vec9);
+
 /* unit-level entry points for the reference's known-answer tests */
 void fdmref_sensor_covariance(const fdmref_config* cfg, const float* p3, float* cov9_colmajor);
 /* state8 = {x, P, count, sample_mean, sample_var, m2, upper, lower} */

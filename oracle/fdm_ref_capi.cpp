@@ -7,6 +7,7 @@
 
 #include "fdm_ref.hpp"
 #include "fdm_ref_ingest.hpp"
+#include "fdm_ref_post.hpp"
 
 using namespace fdmref;
 
@@ -268,6 +269,27 @@ int fdmref_integrate_cloud2(void* e, const void* data, uint64_t n_points,
   const Status st = E(e)->integrate(c, T_bs, T_wb, &s);
   copyStats(s, out);
   return st;
+}
+
+void fdmref_apply_inpainting(void* e, int it, int mv, int inplace) {
+  applyInpainting(E(e)->map(), it, mv, inplace != 0);
+}
+void fdmref_apply_spatial_smoothing(void* e, const char* layer, int k, int mv) {
+  applySpatialSmoothing(E(e)->map(), layer, k, mv);
+}
+void fdmref_apply_uncertainty_fusion(void* e, int enabled, float r, float s, float ql, float qu, int mv) {
+  FusionConfig c;
+  c.enabled = enabled != 0; c.search_radius = r; c.spatial_sigma = s; c.quantile_lower = ql;
+  c.quantile_upper = qu; c.min_valid_neighbors = mv;
+  applyUncertaintyFusion(E(e)->map(), c);
+}
+void fdmref_apply_feature_extraction(void* e, float r, int mv, float lo, float hi) {
+  applyFeatureExtraction(E(e)->map(), r, mv, lo, hi);
+}
+void fdmref_eig3(const float* cov9, float* val3, float* vec9) {
+  const Eig3 r = computeDirect3(cov9);
+  std::memcpy(val3, r.val, sizeof(r.val));
+  std::memcpy(vec9, r.vec, sizeof(r.vec));
 }
 
 void fdmref_set_voxel_stable(void* e, int on) { E(e)->voxel_stable = on != 0; }

@@ -127,6 +127,11 @@ def load(native=False):
     lib.fdmref_last_preprocessed.argtypes = [P, C.c_uint64, P, P, P, P]
     lib.fdmref_last_rasterized.restype = C.c_uint64
     lib.fdmref_last_rasterized.argtypes = [P, C.c_uint64, P, P, P]
+    lib.fdmref_apply_inpainting.argtypes = [P, C.c_int, C.c_int, C.c_int]
+    lib.fdmref_apply_spatial_smoothing.argtypes = [P, C.c_char_p, C.c_int, C.c_int]
+    lib.fdmref_apply_uncertainty_fusion.argtypes = [P, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]
+    lib.fdmref_apply_feature_extraction.argtypes = [P, C.c_float, C.c_int, C.c_float, C.c_float]
+    lib.fdmref_eig3.argtypes = [P, P, P]
     lib.fdmref_from_cloud2.restype = C.c_uint64
     lib.fdmref_from_cloud2.argtypes = [P, C.c_uint64, C.POINTER(RefCloud2Layout), P, P, P, P, P]
     lib.fdmref_integrate_cloud2.restype = C.c_int
@@ -313,6 +318,23 @@ class RefEngine:
         n = self._lib.fdmref_last_rasterized(self._h, cap, *[_ptr(v) for v in a])
         return [v[:n] for v in a]
 
+    # -- stencil post-processing --
+    def apply_inpainting(self, max_iterations=3, min_valid_neighbors=2, inplace=False):
+        self._lib.fdmref_apply_inpainting(self._h, max_iterations, min_valid_neighbors, int(inplace))
+
+    def apply_spatial_smoothing(self, layer, kernel_size=3, min_valid_neighbors=5):
+        self._lib.fdmref_apply_spatial_smoothing(self._h, layer.encode(), kernel_size, min_valid_neighbors)
+
+    def apply_uncertainty_fusion(self, enabled=True, search_radius=0.15, spatial_sigma=0.05,
+                                 quantile_lower=0.01, quantile_upper=0.99, min_valid_neighbors=3):
+        self._lib.fdmref_apply_uncertainty_fusion(self._h, int(enabled), search_radius, spatial_sigma,
+                                                  quantile_lower, quantile_upper, min_valid_neighbors)
+
+    def apply_feature_extraction(self, analysis_radius=0.3, min_valid_neighbors=4,
+                                 step_lower_percentile=0.05, step_upper_percentile=0.95):
+        self._lib.fdmref_apply_feature_extraction(self._h, analysis_radius, min_valid_neighbors,
+                                                  step_lower_percentile, step_upper_percentile)
+
     # -- ingest --
     def integrate_cloud2(self, blob, n_points, layout, T_base_sensor, T_world_base):
         b = np.ascontiguousarray(np.frombuffer(blob, dtype=np.uint8))
@@ -376,6 +398,14 @@ def voxel_any(x, y, z, voxel_size, stable=True):
     if n < 0:
         raise ValueError("voxel_size must be in [0.001, 100]")
     return out[:n].copy()
+
+
+def eig3(cov):
+    """Eigen computeDirect restated: (values ascending, vectors as columns)."""
+    c = np.asfortranarray(np.asarray(cov, dtype=np.float32).reshape(3, 3))
+    val, vec = np.zeros(3, dtype=np.float32), np.zeros(9, dtype=np.float32)
+    load().fdmref_eig3(_ptr(c), _ptr(val), _ptr(vec))
+    return val, vec.reshape(3, 3).T.copy()
 
 
 def from_cloud2(blob, n_points, layout):
