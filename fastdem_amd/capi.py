@@ -56,6 +56,17 @@ class FdmCloud2Layout(C.Structure):
     ]
 
 
+class FdmFusionConfig(C.Structure):
+    """fdm_fusion_config == config::UncertaintyFusion (config/postprocess.hpp:32-39)."""
+
+    _fields_ = [
+        ("enabled", C.c_int32),
+        ("search_radius", C.c_float), ("spatial_sigma", C.c_float),
+        ("quantile_lower", C.c_float), ("quantile_upper", C.c_float),
+        ("min_valid_neighbors", C.c_int32),
+    ]
+
+
 class FdmGeometry(C.Structure):
     _fields_ = [
         ("length_x", C.c_double), ("length_y", C.c_double), ("resolution", C.c_double),
@@ -138,6 +149,10 @@ PROTOTYPES = {
                                                      C.POINTER(FdmRaycastConfig)]),
     "fdm_engine_voxel_any": (C.c_int, [_P, C.c_uint64, _P, _P, _P, C.c_float, _P, C.POINTER(C.c_uint64)]),
     "fdm_engine_last_ray_ms": (C.c_int, [_P, _F]),
+    "fdm_engine_apply_inpainting": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    "fdm_engine_apply_spatial_smoothing": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int]),
+    "fdm_engine_apply_uncertainty_fusion": (C.c_int, [_P, C.POINTER(FdmFusionConfig)]),
+    "fdm_engine_apply_feature_extraction": (C.c_int, [_P, C.c_float, C.c_int, C.c_float, C.c_float]),
     "fdm_engine_ingest_cloud2": (C.c_int, [_P, _P, C.c_int, C.c_uint64, C.POINTER(FdmCloud2Layout),
                                            C.POINTER(C.c_uint64)]),
     "fdm_engine_ingested": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),

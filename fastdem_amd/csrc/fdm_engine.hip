@@ -24,6 +24,7 @@
 #include "fdm_raycast.hpp"
 #include "fdm_egress.hpp"
 #include "fdm_ingest.hpp"
+#include "fdm_post.hpp"
 
 using namespace fdm;
 
@@ -122,6 +123,9 @@ struct fdm_engine {
   hipEvent_t ev_ray[2] = {nullptr, nullptr};
   bool ray_timed = false;
   int dbg_ray = 0;
+  // stencil post-processing (fdm_post.hpp)
+  RegionEntry* d_region = nullptr;   // kMaxRegion entries
+  float* d_tmp2 = nullptr;           // second ncell staging array (fusion works on two layers)
   // ingest (fdm_ingest.hpp)
   uint8_t* d_blob = nullptr;         // raw message bytes
   size_t blob_cap = 0;
@@ -1015,6 +1019,8 @@ void fdm_engine_destroy(fdm_engine* e) {
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : e->ev_ray)
     if (ev) (void)hipEventDestroy(ev);
+  if (e->d_region) (void)hipFree(e->d_region);
+  if (e->d_tmp2) (void)hipFree(e->d_tmp2);
   if (e->d_blob) (void)hipFree(e->d_blob);
   if (e->d_in) (void)hipFree(e->d_in);
   if (e->pack_counts) (void)hipFree(e->pack_counts);
@@ -1394,6 +1400,152 @@ int fdm_engine_last_cell_ids(fdm_engine* e, int32_t* host_out, uint64_t n) {
 int fdm_engine_enable_profile(fdm_engine* e, int on) {
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
   e->profile = on != 0;
+  return FDM_OK;
+}
+
+// ---- stencil post-processing ----
+namespace {
+bool is_tiled(const fdm_engine* e) {
+  return e->G.o_rows != e->G.rows || e->G.o_cols != e->G.cols || e->G.s_rows != e->G.rows || e->G.s_cols != e->G.cols;
+}
+// neighbourhood offsets, dr-major / dc-minor; box = region(Size(k,k)), disc = region(radius)
+int upload_region(fdm_engine* e, const std::vector<RegionEntry>& reg) {
+  if (reg.size() > size_t(kMaxRegion)) return fail(FDM_ERR_INVALID, "neighbourhood larger than 256 cells");
+  if (!e->d_region) HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_region), kMaxRegion * sizeof(RegionEntry)));
+  HIPCK(hipMemcpyAsync(e->d_region, reg.data(), reg.size() * sizeof(RegionEntry), hipMemcpyHostToDevice, e->stream));
+  HIPCK(hipStreamSynchronize(e->stream));  // `reg` is a host temporary
+  return FDM_OK;
+}
+void region_disc(const fdm_engine* e, float radius, std::vector<RegionEntry>& reg) {
+  reg.clear();
+  const float res = static_cast<float>(e->G.res);
+  const int k = static_cast<int>(std::floor(radius / res + 1e-4f));
+  const float r2 = radius * radius;
+  for (int dr = -k; dr <= k; ++dr)
+    for (int dc = -k; dc <= k; ++dc) {
+      const float d2 = static_cast<float>(dr * dr + dc * dc) * (res * res);
+      if (d2 <= r2 * (1.0f + 1e-5f)) reg.push_back({dr, dc, d2, 0.f});
+    }
+}
+unsigned cell_blocks(const fdm_engine* e) { return unsigned((e->ncell + 255) / 256); }
+int ensure_tmp2(fdm_engine* e) {
+  if (!e->d_tmp2) HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_tmp2), e->ncell * sizeof(float)));
+  return FDM_OK;
+}
+}  // namespace
+
+int fdm_engine_apply_inpainting(fdm_engine* e, int max_iterations, int min_valid, int inplace) {
+  if (!e) return fail(FDM_ERR_INVALID, "null engine");
+  if (is_tiled(e)) return fail(FDM_ERR_INVALID, "post-processing needs a whole-map engine");
+  HIPCK(hipSetDevice(e->device));
+  int rc;
+  if ((rc = resolve_pending(e))) return rc;
+  Layer* elev = find_layer(e, "elevation");
+  if (!elev) return fail(FDM_ERR_NO_LAYER, "no layer elevation");
+  const char* out_name = inplace ? "elevation" : "elevation_inpainted";
+  if (!find_layer(e, out_name) && (rc = add_layer(e, out_name, NAN, false))) return rc;
+  elev = find_layer(e, "elevation");
+  Layer* out = find_layer(e, out_name);
+  if ((rc = ensure_tmp(e))) return rc;
+  float* A = lptr(e, *out);
+  const int As = lstride(e, *out);
+  float* B = e->d_tmp;
+  const int slot = int(e->scan_no & 3);
+  // `inpainted = elevation`, then up to max_iterations passes ping-ponging output layer <-> staging;
+  // the reference stops after a pass that changed nothing — further passes are identities, so all
+  // of them are simply run.  The copy goes to whichever side makes the LAST pass land in the layer.
+  const int iters = max_iterations > 0 ? max_iterations : 0;
+  const bool start_in_layer = (iters % 2) == 0;
+  if (!inplace || !start_in_layer) {
+    if ((rc = copy_strided(e, start_in_layer ? A : B, start_in_layer ? As : 1, lptr(e, *elev), lstride(e, *elev))))
+      return rc;
+  }
+  bool in_layer = start_in_layer;
+  for (int it = 0; it < iters; ++it) {
+    hipLaunchKernelGGL(k_inpaint_pass, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state, slot,
+                       in_layer ? A : B, in_layer ? As : 1, in_layer ? B : A, in_layer ? 1 : As, min_valid,
+                       unsigned(e->ncell));
+    in_layer = !in_layer;
+  }
+  HIPCK(hipGetLastError());
+  return FDM_OK;
+}
+
+int fdm_engine_apply_spatial_smoothing(fdm_engine* e, const char* layer, int kernel_size, int min_valid) {
+  if (!e || !layer) return fail(FDM_ERR_INVALID, "null argument");
+  if (is_tiled(e)) return fail(FDM_ERR_INVALID, "post-processing needs a whole-map engine");
+  if (kernel_size < 1 || kernel_size > 15 || (kernel_size & 1) == 0)
+    return fail(FDM_ERR_INVALID, "kernel_size must be odd and in [1, 15]");
+  HIPCK(hipSetDevice(e->device));
+  int rc;
+  if ((rc = resolve_pending(e))) return rc;
+  Layer* l = find_layer(e, layer);
+  if (!l || l->pending) return FDM_OK;  // spatial_smoothing.hpp:42
+  if ((rc = ensure_tmp(e))) return rc;
+  if ((rc = copy_strided(e, e->d_tmp, 1, lptr(e, *l), lstride(e, *l)))) return rc;  // the double buffer
+  hipLaunchKernelGGL(k_median, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state,
+                     int(e->scan_no & 3), e->d_tmp, lptr(e, *l), lstride(e, *l), kernel_size, min_valid,
+                     unsigned(e->ncell));
+  HIPCK(hipGetLastError());
+  if (std::strcmp(layer, "obstacle") == 0) e->obst_dense_pending = true;
+  return FDM_OK;
+}
+
+int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* cfg) {
+  if (!e || !cfg) return fail(FDM_ERR_INVALID, "null argument");
+  if (!cfg->enabled) return FDM_OK;
+  if (is_tiled(e)) return fail(FDM_ERR_INVALID, "post-processing needs a whole-map engine");
+  HIPCK(hipSetDevice(e->device));
+  int rc;
+  if ((rc = resolve_pending(e))) return rc;
+  Layer* up = find_layer(e, "upper_bound");
+  Layer* lo = find_layer(e, "lower_bound");
+  if (!up || !lo) return FDM_OK;  // uncertainty_fusion.cpp:108-113: warn + return
+  std::vector<RegionEntry> reg;
+  region_disc(e, cfg->search_radius, reg);
+  if ((rc = upload_region(e, reg))) return rc;
+  if ((rc = ensure_tmp(e)) || (rc = ensure_tmp2(e))) return rc;
+  if ((rc = copy_strided(e, e->d_tmp, 1, lptr(e, *up), lstride(e, *up)))) return rc;
+  if ((rc = copy_strided(e, e->d_tmp2, 1, lptr(e, *lo), lstride(e, *lo)))) return rc;
+  FusionParams F{};
+  F.inv_2s2 = 1.0f / (2.0f * cfg->spatial_sigma * cfg->spatial_sigma);
+  F.q_lower = cfg->quantile_lower;
+  F.q_upper = cfg->quantile_upper;
+  F.min_valid = cfg->min_valid_neighbors;
+  F.n_entries = int(reg.size());
+  hipLaunchKernelGGL(k_fusion, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state,
+                     int(e->scan_no & 3), e->d_region, F, e->d_tmp, e->d_tmp2, lptr(e, *up), lstride(e, *up),
+                     lptr(e, *lo), lstride(e, *lo), unsigned(e->ncell));
+  HIPCK(hipGetLastError());
+  return FDM_OK;
+}
+
+int fdm_engine_apply_feature_extraction(fdm_engine* e, float radius, int min_valid, float lo_pct, float hi_pct) {
+  if (!e) return fail(FDM_ERR_INVALID, "null engine");
+  if (is_tiled(e)) return fail(FDM_ERR_INVALID, "post-processing needs a whole-map engine");
+  HIPCK(hipSetDevice(e->device));
+  int rc;
+  if ((rc = resolve_pending(e))) return rc;
+  if (!find_layer(e, "elevation")) return FDM_OK;  // feature_extraction.cpp:33
+  const char* names[7] = {"step", "slope", "roughness", "curvature", "_normal_x", "_normal_y", "_normal_z"};
+  for (const char* n : names)
+    if (!find_layer(e, n) && (rc = add_layer(e, n, NAN, false))) return rc;
+  std::vector<RegionEntry> reg;
+  region_disc(e, radius, reg);
+  if ((rc = upload_region(e, reg))) return rc;
+  Layer* elev = find_layer(e, "elevation");
+  FeatureParams F{};
+  F.resf = static_cast<float>(e->G.res);
+  F.lo_pct = lo_pct;
+  F.hi_pct = hi_pct;
+  F.min_valid = min_valid;
+  F.n_entries = int(reg.size());
+  FeatureOut O{};
+  float** outs[7] = {&O.step, &O.slope, &O.roughness, &O.curvature, &O.nx, &O.ny, &O.nz};
+  for (int k = 0; k < 7; ++k) *outs[k] = find_layer(e, names[k])->d;
+  hipLaunchKernelGGL(k_features, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state,
+                     int(e->scan_no & 3), e->d_region, F, lptr(e, *elev), lstride(e, *elev), O, unsigned(e->ncell));
+  HIPCK(hipGetLastError());
   return FDM_OK;
 }
 

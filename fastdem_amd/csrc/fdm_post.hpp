@@ -1,0 +1,336 @@
+// fdm_post.hpp — stencil post-processing on the device.  gfx950 only.
+//
+// Reference being reproduced (file:line under /root/reference/fastdem):
+//   src/inpainting.cpp:21-67                                  applyInpainting
+//   include/fastdem/postprocess/spatial_smoothing.hpp:38-67   applySpatialSmoothing
+//   src/uncertainty_fusion.cpp:28-186                         weighted-ECDF bound fusion
+//   src/feature_extraction.cpp:28-118                         local PCA features
+//   lib/nanoPCL/include/nanopcl/geometry/impl/pca.hpp:66-88   computePCA -> Eigen computeDirect (3x3)
+// One thread per cell, threads of a wave are consecutive LOGICAL rows of one column, so the centre
+// loads and (away from the buffer seam) every neighbour load of a wave coalesce; the 3x3 .. 13x13
+// neighbourhoods overlap almost entirely between neighbouring lanes and are served by L1/L2.
+// Neighbourhood semantics (logical coordinates, clipped at the border, centre included, entry order
+// dr-major / dc-minor) are the ones stated in DESIGN.md §7 f2: nanoGrid's cells()/region()/neighbors()
+// are not on disk, so these are this repo's definition.
+#pragma once
+
+#include "fdm_device.hpp"
+
+namespace fdm {
+
+constexpr int kMaxRegion = 256;  // entries of a disc / box neighbourhood the kernels accept
+
+struct RegionEntry { int dr, dc; float dist_sq; float pad; };
+
+struct PostGeom {
+  int rows, cols, sr, sc;
+};
+__device__ __forceinline__ PostGeom post_geom(const DevState* __restrict__ st, int slot, const GeomConst& G) {
+  const DevGeom g = st->geom[slot];
+  PostGeom p;
+  p.rows = G.rows; p.cols = G.cols; p.sr = g.sr; p.sc = g.sc;
+  return p;
+}
+__device__ __forceinline__ size_t post_index(const PostGeom& p, int lr, int lc) {
+  int r = lr + p.sr, c = lc + p.sc;
+  r -= r >= p.rows ? p.rows : 0;
+  c -= c >= p.cols ? p.cols : 0;
+  return size_t(c) * p.rows + r;
+}
+__device__ __forceinline__ bool post_inside(const PostGeom& p, int lr, int lc) {
+  return unsigned(lr) < unsigned(p.rows) && unsigned(lc) < unsigned(p.cols);
+}
+
+// ---- inpainting: one pass (inpainting.cpp:41-64); the caller ping-pongs two buffers ----
+__global__ __launch_bounds__(256) void k_inpaint_pass(const GeomConst G, const DevState* __restrict__ st, int slot,
+                                                      const float* __restrict__ in, int in_stride,
+                                                      float* __restrict__ out, int out_stride,
+                                                      int min_valid, unsigned ncell) {
+  const unsigned t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= ncell) return;
+  const PostGeom p = post_geom(st, slot, G);
+  const int lc = int(t / unsigned(p.rows)), lr = int(t - unsigned(lc) * unsigned(p.rows));
+  const size_t ci = post_index(p, lr, lc);
+  float v = in[ci * in_stride];
+  if (isnan(v)) {
+    float sum = 0.0f;
+    int count = 0;
+#pragma unroll
+    for (int dr = -1; dr <= 1; ++dr)
+#pragma unroll
+      for (int dc = -1; dc <= 1; ++dc) {
+        if (dr == 0 && dc == 0) continue;
+        if (!post_inside(p, lr + dr, lc + dc)) continue;
+        const float n = in[post_index(p, lr + dr, lc + dc) * in_stride];
+        if (isfinite(n)) {
+          sum += n;
+          ++count;
+        }
+      }
+    if (count >= min_valid) v = sum / float(count);
+  }
+  out[ci * out_stride] = v;
+}
+
+// ---- spatial median smoothing (spatial_smoothing.hpp:52-66); `in` is a private copy ----
+__global__ __launch_bounds__(256) void k_median(const GeomConst G, const DevState* __restrict__ st, int slot,
+                                                const float* __restrict__ in, float* __restrict__ out,
+                                                int out_stride, int kernel, int min_valid, unsigned ncell) {
+  const unsigned t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= ncell) return;
+  const PostGeom p = post_geom(st, slot, G);
+  const int lc = int(t / unsigned(p.rows)), lr = int(t - unsigned(lc) * unsigned(p.rows));
+  const size_t ci = post_index(p, lr, lc);
+  if (!isfinite(in[ci])) return;
+  float win[kMaxRegion];
+  int n = 0;
+  const int h = kernel / 2;
+  for (int dr = -h; dr <= h; ++dr)
+    for (int dc = -h; dc <= h; ++dc) {
+      if (!post_inside(p, lr + dr, lc + dc)) continue;
+      const float v = in[post_index(p, lr + dr, lc + dc)];
+      if (!isfinite(v)) continue;
+      int k = n++;  // insertion sort: the window is at most kernel^2 values
+      while (k > 0 && win[k - 1] > v) { win[k] = win[k - 1]; --k; }
+      win[k] = v;
+    }
+  if (n < min_valid) return;
+  out[ci * out_stride] = win[n / 2];  // nth_element(size/2)
+}
+
+// ---- uncertainty fusion (uncertainty_fusion.cpp:135-181); upper/lower are private copies ----
+struct FusionParams {
+  float inv_2s2, q_lower, q_upper;
+  int min_valid, n_entries;
+};
+// SimpleWeightedECDF::quantile over samples sorted by value (uncertainty_fusion.cpp:63-91)
+__device__ __forceinline__ float ecdf_quantile(const float* val, const float* wgt, int n, float p) {
+  if (n == 0) return __uint_as_float(0x7FC00000u);
+  if (n == 1) return val[0];
+  float total = 0.0f;
+  for (int k = 0; k < n; ++k) total += wgt[k];
+  if (total <= 0.0f) return __uint_as_float(0x7FC00000u);
+  const float target = p * total;
+  float cumulative = 0.0f;
+  for (int k = 0; k < n; ++k) {
+    cumulative += wgt[k];
+    if (cumulative >= target) return val[k];
+  }
+  return val[n - 1];
+}
+__global__ __launch_bounds__(256) void k_fusion(const GeomConst G, const DevState* __restrict__ st, int slot,
+                                                const RegionEntry* __restrict__ reg, const FusionParams F,
+                                                const float* __restrict__ up_in, const float* __restrict__ lo_in,
+                                                float* __restrict__ up_out, int up_stride,
+                                                float* __restrict__ lo_out, int lo_stride, unsigned ncell) {
+  const unsigned t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= ncell) return;
+  const PostGeom p = post_geom(st, slot, G);
+  const int lc = int(t / unsigned(p.rows)), lr = int(t - unsigned(lc) * unsigned(p.rows));
+  const size_t ci = post_index(p, lr, lc);
+  if (!isfinite(up_in[ci]) || !isfinite(lo_in[ci])) return;
+  float lv[kMaxRegion], lw[kMaxRegion], uv[kMaxRegion], uw[kMaxRegion];
+  int nl = 0, nu = 0, valid = 0;
+  for (int e = 0; e < F.n_entries; ++e) {
+    const RegionEntry re = reg[e];
+    if (!post_inside(p, lr + re.dr, lc + re.dc)) continue;
+    const size_t ni = post_index(p, lr + re.dr, lc + re.dc);
+    const float nu_v = up_in[ni], nl_v = lo_in[ni];
+    if (!isfinite(nu_v) || !isfinite(nl_v)) continue;
+    // std::exp(float): evaluated in double and rounded, which agrees with a correctly rounded expf
+    const float w_spatial = static_cast<float>(exp(static_cast<double>(-re.dist_sq * F.inv_2s2)));
+    const float range = nu_v - nl_v;
+    const float w_range = 1.0f / (range + 1e-4f);
+    const float weight = w_spatial * w_range;
+    if (weight > 1e-6f) {  // SimpleWeightedECDF::add; the values are finite here
+      int k = nl++;
+      while (k > 0 && lv[k - 1] > nl_v) { lv[k] = lv[k - 1]; lw[k] = lw[k - 1]; --k; }
+      lv[k] = nl_v; lw[k] = weight;
+      k = nu++;
+      while (k > 0 && uv[k - 1] > nu_v) { uv[k] = uv[k - 1]; uw[k] = uw[k - 1]; --k; }
+      uv[k] = nu_v; uw[k] = weight;
+    }
+    ++valid;
+  }
+  if (valid < F.min_valid) return;
+  const float lower = ecdf_quantile(lv, lw, nl, F.q_lower);
+  const float upper = ecdf_quantile(uv, uw, nu, F.q_upper);
+  if (isfinite(lower) && isfinite(upper)) {
+    up_out[ci * up_stride] = upper;
+    lo_out[ci * lo_stride] = lower;
+  }
+}
+
+// ---- Eigen::SelfAdjointEigenSolver<Matrix3f>::computeDirect (Eigen 3.4, 3x3 closed form) ----
+// transcendental steps are evaluated in double and rounded (closest to the host libm's float results)
+__device__ __forceinline__ void eig3_cross(const float* a, const float* b, float* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ float eig3_sqnorm(const float* a) { return a[0] * a[0] + (a[1] * a[1] + a[2] * a[2]); }
+__device__ __forceinline__ void eig3_kernel(const float* mat, float* res, float* representative) {
+  int i0 = 0;
+  float best = fabsf(mat[0]);
+  if (fabsf(mat[4]) > best) { best = fabsf(mat[4]); i0 = 1; }
+  if (fabsf(mat[8]) > best) { best = fabsf(mat[8]); i0 = 2; }
+  const int i1 = (i0 + 1) % 3, i2 = (i0 + 2) % 3;
+  float rep[3], a[3], b[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    rep[r] = i0 == 0 ? mat[r] : (i0 == 1 ? mat[3 + r] : mat[6 + r]);
+    a[r] = i1 == 0 ? mat[r] : (i1 == 1 ? mat[3 + r] : mat[6 + r]);
+    b[r] = i2 == 0 ? mat[r] : (i2 == 1 ? mat[3 + r] : mat[6 + r]);
+    representative[r] = rep[r];
+  }
+  float c0[3], c1[3];
+  eig3_cross(rep, a, c0);
+  eig3_cross(rep, b, c1);
+  const float n0 = eig3_sqnorm(c0), n1 = eig3_sqnorm(c1);
+  if (n0 > n1) {
+    const float s = sqrtf(n0);
+    res[0] = c0[0] / s; res[1] = c0[1] / s; res[2] = c0[2] / s;
+  } else {
+    const float s = sqrtf(n1);
+    res[0] = c1[0] / s; res[1] = c1[1] / s; res[2] = c1[2] / s;
+  }
+}
+// cov column-major; returns eigenvalues ascending in val, the eigenvector of val[0] in v0
+__device__ __forceinline__ void eig3_direct(const float* cov, float* val, float* v0) {
+  const float shift = (cov[0] + cov[4] + cov[8]) / 3.0f;
+  float sm[9];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) sm[c * 3 + r] = r >= c ? cov[c * 3 + r] : cov[r * 3 + c];
+  sm[0] -= shift; sm[4] -= shift; sm[8] -= shift;
+  float scale = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) scale = fmaxf(scale, fabsf(sm[k]));
+  if (scale > 0.0f) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sm[k] /= scale;
+  }
+  // computeRoots
+  const float s_inv3 = 1.0f / 3.0f, s_sqrt3 = sqrtf(3.0f);
+  const float c0 = sm[0] * sm[4] * sm[8] + 2.0f * sm[1] * sm[2] * sm[5] - sm[0] * sm[5] * sm[5] -
+                   sm[4] * sm[2] * sm[2] - sm[8] * sm[1] * sm[1];
+  const float c1 = sm[0] * sm[4] - sm[1] * sm[1] + sm[0] * sm[8] - sm[2] * sm[2] + sm[4] * sm[8] - sm[5] * sm[5];
+  const float c2 = sm[0] + sm[4] + sm[8];
+  const float c2_over_3 = c2 * s_inv3;
+  float a_over_3 = (c2 * c2_over_3 - c1) * s_inv3;
+  a_over_3 = fmaxf(a_over_3, 0.0f);
+  const float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+  float q = a_over_3 * a_over_3 * a_over_3 - half_b * half_b;
+  q = fmaxf(q, 0.0f);
+  const float rho = sqrtf(a_over_3);
+  const float theta = static_cast<float>(atan2(static_cast<double>(sqrtf(q)), static_cast<double>(half_b))) * s_inv3;
+  const float cos_theta = static_cast<float>(cos(static_cast<double>(theta)));
+  const float sin_theta = static_cast<float>(sin(static_cast<double>(theta)));
+  float ev[3];
+  ev[0] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+  ev[1] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+  ev[2] = c2_over_3 + 2.0f * rho * cos_theta;
+  // only the eigenvector of the SMALLEST eigenvalue is consumed (feature_extraction.cpp:96)
+  const float eps = 1.1920929e-07f;
+  if ((ev[2] - ev[0]) <= eps) {
+    v0[0] = 1.0f; v0[1] = 0.0f; v0[2] = 0.0f;  // eivecs.setIdentity()
+  } else {
+    float d0 = ev[2] - ev[1];
+    const float d1 = ev[1] - ev[0];
+    int k = 0, l = 2;
+    if (d0 > d1) { k = 2; l = 0; d0 = d1; }
+    float tmp[9], vk[3], vl[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tmp[i] = sm[i];
+    const float evk = k == 0 ? ev[0] : ev[2], evl = l == 0 ? ev[0] : ev[2];
+    tmp[0] -= evk; tmp[4] -= evk; tmp[8] -= evk;
+    eig3_kernel(tmp, vk, vl);
+    if (k == 0) {
+      v0[0] = vk[0]; v0[1] = vk[1]; v0[2] = vk[2];
+    } else {  // column 0 is the l-th: second kernel or the re-orthonormalised representative
+      if (d0 <= 2.0f * eps * d1) {
+        const float dot = vk[0] * vl[0] + (vk[1] * vl[1] + vk[2] * vl[2]);
+        vl[0] -= dot * vl[0]; vl[1] -= dot * vl[1]; vl[2] -= dot * vl[2];
+        const float n = sqrtf(eig3_sqnorm(vl));
+        vl[0] /= n; vl[1] /= n; vl[2] /= n;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tmp[i] = sm[i];
+        tmp[0] -= evl; tmp[4] -= evl; tmp[8] -= evl;
+        float dummy[3];
+        eig3_kernel(tmp, vl, dummy);
+      }
+      v0[0] = vl[0]; v0[1] = vl[1]; v0[2] = vl[2];
+    }
+  }
+  val[0] = ev[0] * scale + shift;
+  val[1] = ev[1] * scale + shift;
+  val[2] = ev[2] * scale + shift;
+}
+
+// ---- feature extraction (feature_extraction.cpp:59-116) ----
+struct FeatureParams {
+  float resf, lo_pct, hi_pct;
+  int min_valid, n_entries;
+};
+struct FeatureOut {
+  float *step, *slope, *roughness, *curvature, *nx, *ny, *nz;
+};
+__global__ __launch_bounds__(256) void k_features(const GeomConst G, const DevState* __restrict__ st, int slot,
+                                                  const RegionEntry* __restrict__ reg, const FeatureParams F,
+                                                  const float* __restrict__ elev, int elev_stride,
+                                                  const FeatureOut O, unsigned ncell) {
+  const unsigned t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= ncell) return;
+  const PostGeom p = post_geom(st, slot, G);
+  const int lc = int(t / unsigned(p.rows)), lr = int(t - unsigned(lc) * unsigned(p.rows));
+  const size_t ci = post_index(p, lr, lc);
+  const float center_z = elev[ci * elev_stride];
+  if (!isfinite(center_z)) return;
+  float sum[3] = {0.f, 0.f, 0.f};
+  float sq[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float zs[kMaxRegion];
+  int count = 0;
+  for (int e = 0; e < F.n_entries; ++e) {
+    const RegionEntry re = reg[e];
+    if (!post_inside(p, lr + re.dr, lc + re.dc)) continue;
+    const float nz = elev[post_index(p, lr + re.dr, lc + re.dc) * elev_stride];
+    if (!isfinite(nz)) continue;
+    const float d[3] = {float(-re.dr) * F.resf, float(-re.dc) * F.resf, nz - center_z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sum[k] += d[k];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) sq[c * 3 + r] += d[r] * d[c];
+    int k = count++;  // z_vals kept sorted (std::sort at feature_extraction.cpp:100)
+    while (k > 0 && zs[k - 1] > nz) { zs[k] = zs[k - 1]; --k; }
+    zs[k] = nz;
+  }
+  if (count < F.min_valid) return;
+  const float inv_n = 1.0f / float(count);
+  const float mean[3] = {sum[0] * inv_n, sum[1] * inv_n, sum[2] * inv_n};
+  float cov[9];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) cov[c * 3 + r] = sq[c * 3 + r] * inv_n - mean[r] * mean[c];
+  const float trace = cov[0] + cov[4] + cov[8];
+  if (trace < 1.1920929e-07f) return;  // computePCA: degenerate covariance
+  float val[3], normal[3];
+  eig3_direct(cov, val, normal);
+  if (val[1] < 1e-8f) return;  // kMinEigenvalue
+  if (normal[2] < 0.0f) { normal[0] = -normal[0]; normal[1] = -normal[1]; normal[2] = -normal[2]; }
+  const int lo = static_cast<int>(F.lo_pct * float(count - 1));
+  const int hi = static_cast<int>(F.hi_pct * float(count - 1));
+  O.step[ci] = zs[hi] - zs[lo];
+  O.slope[ci] = static_cast<float>(acos(static_cast<double>(fabsf(normal[2])))) * 180.0f / 3.14159274101257324f;
+  O.roughness[ci] = sqrtf(val[0]);
+  O.curvature[ci] = (trace > 0.0f) ? fabsf(val[0] / trace) : 0.0f;
+  O.nx[ci] = normal[0];
+  O.ny[ci] = normal[1];
+  O.nz[ci] = normal[2];
+}
+
+}  // namespace fdm

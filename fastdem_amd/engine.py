@@ -203,6 +203,26 @@ class Engine:
         _ck(self._lib.fdm_engine_region_unpack(self._h, r0, c0, nr, nc, arr, len(names),
                                                C.c_void_p(dbuf_ptr)))
 
+    # -- stencil post-processing --
+    def apply_inpainting(self, max_iterations=3, min_valid_neighbors=2, inplace=False):
+        _ck(self._lib.fdm_engine_apply_inpainting(self._h, int(max_iterations), int(min_valid_neighbors),
+                                                  int(inplace)))
+
+    def apply_spatial_smoothing(self, layer, kernel_size=3, min_valid_neighbors=5):
+        _ck(self._lib.fdm_engine_apply_spatial_smoothing(self._h, layer.encode(), int(kernel_size),
+                                                         int(min_valid_neighbors)))
+
+    def apply_uncertainty_fusion(self, enabled=True, search_radius=0.15, spatial_sigma=0.05,
+                                 quantile_lower=0.01, quantile_upper=0.99, min_valid_neighbors=3):
+        cfg = capi.FdmFusionConfig(int(enabled), search_radius, spatial_sigma, quantile_lower,
+                                   quantile_upper, int(min_valid_neighbors))
+        _ck(self._lib.fdm_engine_apply_uncertainty_fusion(self._h, C.byref(cfg)))
+
+    def apply_feature_extraction(self, analysis_radius=0.3, min_valid_neighbors=4,
+                                 step_lower_percentile=0.05, step_upper_percentile=0.95):
+        _ck(self._lib.fdm_engine_apply_feature_extraction(self._h, analysis_radius, int(min_valid_neighbors),
+                                                          step_lower_percentile, step_upper_percentile))
+
     # -- ingest --
     @staticmethod
     def cloud2_layout(point_step, x, y, z, intensity=-1, intensity_type=7, rgb=-1):

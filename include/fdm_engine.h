@@ -266,6 +266,29 @@ int fdm_engine_integrate_cloud2(fdm_engine* e, const void* data, int data_on_dev
                                 const fdm_cloud2_layout* layout, const double T_base_sensor[16],
                                 const double T_world_base[16], fdm_scan_stats* out);
 
+/* ---- Stencil post-processing ----
+ * The reference's post-processing functions (called by the ROS timers on a snapshot of the map) on
+ * the device-resident layers; each call only enqueues kernels.  Neighbourhoods are taken in logical
+ * (unwrapped) coordinates and clipped at the map border; see DESIGN.md §7 f2 for the exact
+ * neighbourhood definition (nanoGrid's region()/neighbors() are not on disk).  Whole-map engines only
+ * (tiled engines: FDM_ERR_INVALID).
+ *   applyInpainting(map, max_iterations, min_valid_neighbors, inplace)        src/inpainting.cpp:21-67
+ *   applySpatialSmoothing(map, layer, kernel_size, min_valid_neighbors)       postprocess/spatial_smoothing.hpp:38-67
+ *   applyUncertaintyFusion(map, config::UncertaintyFusion)                    src/uncertainty_fusion.cpp:103-186
+ *   applyFeatureExtraction(map, radius, min_valid, lower_pct, upper_pct)      src/feature_extraction.cpp:28-118
+ * kernel_size must be odd and <= 15; a disc radius may cover at most 256 cells. */
+typedef struct fdm_fusion_config {          /* config::UncertaintyFusion (config/postprocess.hpp:32-39) */
+  int32_t enabled;
+  float search_radius, spatial_sigma, quantile_lower, quantile_upper;
+  int32_t min_valid_neighbors;
+} fdm_fusion_config;
+int fdm_engine_apply_inpainting(fdm_engine* e, int max_iterations, int min_valid_neighbors, int inplace);
+int fdm_engine_apply_spatial_smoothing(fdm_engine* e, const char* layer, int kernel_size,
+                                       int min_valid_neighbors);
+int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* cfg);
+int fdm_engine_apply_feature_extraction(fdm_engine* e, float analysis_radius, int min_valid_neighbors,
+                                        float step_lower_percentile, float step_upper_percentile);
+
 /* Parity / measurement instrumentation (not in the reference). */
 int fdm_engine_enable_cell_ids(fdm_engine* e, int on);
 /* per input point of the last scan: linear cell id (col*rows+row), -1 cropped, -2 outside map */

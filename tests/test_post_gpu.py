@@ -1,0 +1,168 @@
+"""Stencil post-processing of the HIP engine through the C ABI vs the oracle.
+
+Tolerances (stated per stage):
+  inpainting / median smoothing / uncertainty fusion: bit-exact (same float operation order; the
+    fusion's exp() is evaluated in double on the device and agrees with libm's expf);
+  feature extraction: the closed-form 3x3 eigen-solver goes through atan2 / cos / sin / acos, whose
+    last-ulp differences between the device and the host libm are amplified by the cancellation in
+    the roots; eigen-derived layers are compared with atol 2e-4 (+ rtol 1e-4), slope in degrees with
+    atol 0.05 (acos is ill-conditioned at normal_z -> 1); `step` (order statistics) is bit-exact.
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_arrays_close, assert_layers_equal, pair, run_both
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def both(objs, fn):
+    return [fn(o) for o in objs]
+
+
+def terrain(rng, shape, holes=0.3, noise=0.02):
+    r, c = np.meshgrid(np.arange(shape[0]), np.arange(shape[1]), indexing="ij")
+    z = 0.4 * np.sin(r * 0.11) * np.cos(c * 0.07) + 0.002 * r + rng.normal(0, noise, shape)
+    z = z.astype(F32)
+    z[rng.uniform(size=shape) < holes] = np.nan
+    return z
+
+
+def exact(eng, ref, names=None):
+    assert sorted(eng.layers()) == sorted(ref.layers())
+    for n in (names or ref.layers()):
+        assert_arrays_close(eng.layer(n), ref.layer(n), n, 0.0, 0.0)
+
+
+# ------------------------------------------------- the reference's own tests on the engine ----
+class TestReferencePostprocessTestsOnEngine:  # fastdem/tests/test_postprocess.cpp
+    def fixture(self, gpu, R):
+        return pair(gpu, R, 10.0, 10.0, 0.5)
+
+    def test_inpainting_fills_simple_hole(self, gpu, R):  # :39-57
+        eng, ref = self.fixture(gpu, R)
+        _, (r, c) = ref.get_index(0.0, 0.0)
+        el = np.full((20, 20), np.nan, dtype=F32)
+        el[r - 1:r + 2, c - 1:c + 2] = 1.0
+        el[r, c] = np.nan
+        both((eng, ref), lambda o: (o.set_layer("elevation", el), o.apply_inpainting(3, 2)))
+        assert abs(eng.layer("elevation_inpainted")[r, c] - 1.0) < 0.01
+        exact(eng, ref)
+
+    def test_smoothing_removes_spike(self, gpu, R):  # :243-259
+        eng, ref = self.fixture(gpu, R)
+        _, (r, c) = ref.get_index(0.0, 0.0)
+        el = np.full((20, 20), np.nan, dtype=F32)
+        el[r - 2:r + 3, c - 2:c + 3] = 1.0
+        el[r, c] = 100.0
+        both((eng, ref), lambda o: (o.set_layer("elevation", el), o.apply_spatial_smoothing("elevation", 3, 5)))
+        assert abs(eng.layer("elevation")[r, c] - 1.0) < 0.01
+        both((eng, ref), lambda o: o.apply_spatial_smoothing("nonexistent_layer"))  # :261-264
+        exact(eng, ref)
+
+    def test_fusion_computes_bounds(self, gpu, R):  # :192-226
+        eng, ref = self.fixture(gpu, R)
+        _, (r, c) = ref.get_index(0.0, 0.0)
+        up, lo = (np.full((20, 20), np.nan, dtype=F32) for _ in range(2))
+        for dr in (-1, 0, 1):
+            for dc in (-1, 0, 1):
+                h = F32(1.0) + F32(0.1) * dr
+                up[r + dr, c + dc], lo[r + dr, c + dc] = h + F32(0.2), h - F32(0.2)
+        both((eng, ref), lambda o: (o.set_layer("upper_bound", up), o.set_layer("lower_bound", lo),
+                                    o.apply_uncertainty_fusion(True, 0.6, 0.3, 0.01, 0.99, 1)))
+        assert eng.layer("upper_bound")[r, c] > eng.layer("lower_bound")[r, c]
+        exact(eng, ref)
+
+    def test_feature_extraction_planes(self, gpu, R):  # :268-315
+        eng, ref = self.fixture(gpu, R)
+        rows = np.arange(20, dtype=F32)[:, None] * F32(0.25)
+        both((eng, ref), lambda o: (o.set_layer("elevation", np.broadcast_to(rows, (20, 20)).copy()),
+                                    o.apply_feature_extraction(0.6, 4)))
+        _, rc = ref.get_index(0.0, 0.0)
+        s = eng.layer("slope")[rc]
+        assert abs(s - np.degrees(np.arctan(0.5))) < 0.05 and eng.layer("_normal_z")[rc] > 0
+        for n in ("step", "slope", "roughness", "curvature", "_normal_x", "_normal_y", "_normal_z"):
+            assert eng.exists(n)
+
+
+# --------------------------------------------------------------------- parity on terrain ----
+def rolled_pair(gpu, R, rng, size=24.0, res=0.1):
+    eng, ref = pair(gpu, R, size, size, res)
+    both((eng, ref), lambda o: o.move(3.7, -5.2))  # the circular buffer seam crosses the map
+    shape = (eng.rows, eng.cols)
+    return eng, ref, shape
+
+
+def test_inpainting_parity(gpu, R):
+    rng = np.random.default_rng(21)
+    eng, ref, shape = rolled_pair(gpu, R, rng)
+    el = terrain(rng, shape, holes=0.55)
+    for iters, mv, inplace in ((3, 2, False), (1, 3, False), (4, 1, True), (0, 2, False)):
+        both((eng, ref), lambda o: (o.set_layer("elevation", el), o.apply_inpainting(iters, mv, inplace)))
+        exact(eng, ref)
+    both((eng, ref), lambda o: o.apply_inpainting(3, 2))
+    assert np.isfinite(eng.layer("elevation_inpainted")).sum() > np.isfinite(el).sum()
+
+
+def test_median_smoothing_parity(gpu, R):
+    rng = np.random.default_rng(22)
+    eng, ref, shape = rolled_pair(gpu, R, rng)
+    el = terrain(rng, shape, holes=0.2)
+    el[rng.uniform(size=shape) < 0.02] = 50.0  # spikes
+    for k, mv in ((3, 5), (5, 9), (7, 1)):
+        both((eng, ref), lambda o: (o.set_layer("elevation", el), o.apply_spatial_smoothing("elevation", k, mv)))
+        exact(eng, ref, ["elevation"])
+    with pytest.raises(gpu.EngineError):
+        eng.apply_spatial_smoothing("elevation", 4, 5)
+
+
+def test_uncertainty_fusion_parity(gpu, R):
+    rng = np.random.default_rng(23)
+    eng, ref, shape = rolled_pair(gpu, R, rng, size=20.0, res=0.05)
+    el = terrain(rng, shape, holes=0.25)
+    half = np.abs(rng.normal(0.05, 0.03, shape)).astype(F32) + F32(0.005)
+    for cfgv in ((True, 0.15, 0.05, 0.01, 0.99, 3), (True, 0.3, 0.1, 0.25, 0.75, 5)):
+        both((eng, ref), lambda o: (o.set_layer("upper_bound", el + half), o.set_layer("lower_bound", el - half),
+                                    o.apply_uncertainty_fusion(*cfgv)))
+        exact(eng, ref, ["upper_bound", "lower_bound"])
+    assert not np.array_equal(eng.layer("upper_bound"), el + half, equal_nan=True)
+
+
+def test_feature_extraction_parity(gpu, R):
+    rng = np.random.default_rng(24)
+    eng, ref, shape = rolled_pair(gpu, R, rng, size=20.0, res=0.05)
+    el = terrain(rng, shape, holes=0.15, noise=0.01)
+    el[:, shape[1] // 2:] += F32(0.3)  # a step edge
+    both((eng, ref), lambda o: (o.set_layer("elevation", el), o.apply_feature_extraction(0.3, 4, 0.05, 0.95)))
+    assert sorted(eng.layers()) == sorted(ref.layers())
+    assert_arrays_close(eng.layer("step"), ref.layer("step"), "step", 0.0, 0.0)
+    for n, atol, rtol in (("roughness", 2e-4, 1e-4), ("curvature", 2e-4, 1e-4), ("_normal_x", 2e-4, 1e-4),
+                          ("_normal_y", 2e-4, 1e-4), ("_normal_z", 2e-4, 1e-4), ("slope", 0.05, 1e-4)):
+        a, b = eng.layer(n), ref.layer(n)
+        assert np.array_equal(np.isnan(a), np.isnan(b)), f"{n}: NaN pattern differs in {(np.isnan(a) != np.isnan(b)).sum()}"
+        ok = np.isfinite(b)
+        err = np.abs(a[ok].astype(np.float64) - b[ok]) - rtol * np.abs(b[ok])
+        assert err.max() <= atol, f"{n}: max abs err {err.max():.3e}"
+    assert np.isfinite(eng.layer("slope")).sum() > 0.5 * el.size
+
+
+def test_after_real_scans_with_records(gpu, R):
+    """The stages read/write record fields (elevation, upper/lower bounds) of a mapped scene."""
+    wl = gpu.synth.vlp16(n_scans=6)
+    eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
+    for k in range(6):
+        run_both(eng, ref, wl.scan(k), wl.T_base_sensor, wl.pose(k))
+    both((eng, ref), lambda o: o.apply_uncertainty_fusion(True, 0.25, 0.1, 0.01, 0.99, 3))
+    both((eng, ref), lambda o: o.apply_inpainting(3, 2))
+    both((eng, ref), lambda o: o.apply_spatial_smoothing("elevation_inpainted", 3, 5))
+    exact(eng, ref)
+    run_both(eng, ref, wl.scan(0), wl.T_base_sensor, wl.pose(6))  # mapping goes on afterwards
+    exact(eng, ref)
+
+
+def test_tiled_engine_is_refused(gpu, R):
+    t = gpu.Engine(20.0, 20.0, 0.1, tile=(0, 0, 100, 200, 0, 0, 100, 200),
+                   cfg=(lambda c: (setattr(c, "mode", 1), c)[1])(gpu.capi.default_config()))
+    with pytest.raises(gpu.EngineError):
+        t.apply_inpainting()
