@@ -13,6 +13,10 @@
 
 #include "fastdem/fastdem.hpp"
 #include "fastdem/io/npz.hpp"
+#include "fastdem/postprocess/feature_extraction.hpp"
+#include "fastdem/postprocess/inpainting.hpp"
+#include "fastdem/postprocess/spatial_smoothing.hpp"
+#include "fastdem/postprocess/uncertainty_fusion.hpp"
 #include "mini_test.hpp"
 
 using namespace fastdem;
@@ -496,6 +500,101 @@ TEST(Raycasting, EnabledThroughIntegrate) {  // fastdem.cpp:152-159, default.yam
   nanogrid::Index hit;
   ASSERT_TRUE(f.map.getIndex(nanogrid::Position(4.0, 0.0), hit));
   EXPECT_FLOAT_EQ(f.map.at(layer::visibility_logodds, hit), 0.4f);
+}
+
+// -------------------------------- test_postprocess.cpp (inpainting / fusion / smoothing / features) ----
+TEST(Postprocess, InpaintingFillsHoleAndPreservesValues) {  // :39-69
+  PostFixture f;
+  const nanogrid::Index c = f.at(0.0, 0.0);
+  for (int dr = -1; dr <= 1; ++dr)
+    for (int dc = -1; dc <= 1; ++dc)
+      if (dr || dc) f.map.at(layer::elevation, nanogrid::Index(c(0) + dr, c(1) + dc)) = 1.0f;
+  ASSERT_TRUE(std::isnan(f.map.at(layer::elevation, c)));
+  applyInpainting(f.map, 3, 2);
+  ASSERT_TRUE(f.map.exists(layer::elevation_inpainted));
+  EXPECT_TRUE(std::isfinite(f.map.at(layer::elevation_inpainted, c)));
+  EXPECT_NEAR(f.map.at(layer::elevation_inpainted, c), 1.0f, 0.01f);
+  PostFixture g;
+  g.map.get(layer::elevation).setConstant(2.0f);
+  applyInpainting(g.map, 3, 2);
+  EXPECT_FLOAT_EQ(g.map.at(layer::elevation_inpainted, g.at(0.0, 0.0)), 2.0f);
+}
+TEST(Postprocess, UncertaintyFusion) {  // :192-240
+  PostFixture f;
+  f.map.add(layer::upper_bound, NAN);
+  f.map.add(layer::lower_bound, NAN);
+  const nanogrid::Index c = f.at(0.0, 0.0);
+  for (int dr = -1; dr <= 1; ++dr)
+    for (int dc = -1; dc <= 1; ++dc) {
+      const nanogrid::Index idx(c(0) + dr, c(1) + dc);
+      const float h = 1.0f + 0.1f * dr;
+      f.map.at(layer::elevation, idx) = h;
+      f.map.at(layer::upper_bound, idx) = h + 0.2f;
+      f.map.at(layer::lower_bound, idx) = h - 0.2f;
+    }
+  config::UncertaintyFusion cfg;
+  cfg.enabled = true;
+  cfg.search_radius = 0.6f;
+  cfg.spatial_sigma = 0.3f;
+  cfg.min_valid_neighbors = 1;
+  applyUncertaintyFusion(f.map, cfg);
+  const float upper = f.map.at(layer::upper_bound, c), lower = f.map.at(layer::lower_bound, c);
+  EXPECT_TRUE(std::isfinite(upper));
+  EXPECT_TRUE(std::isfinite(lower));
+  EXPECT_GT(upper, lower);
+  ElevationMap empty_map;  // missing bounds: returns early, no crash
+  empty_map.setGeometry(10.0f, 10.0f, 0.5f);
+  EXPECT_NO_THROW(applyUncertaintyFusion(empty_map, cfg));
+  PostFixture g;
+  cfg.enabled = false;
+  applyUncertaintyFusion(g.map, cfg);
+  EXPECT_FALSE(g.map.exists(layer::upper_bound));
+}
+TEST(Postprocess, SpatialSmoothing) {  // :243-264
+  PostFixture f;
+  const nanogrid::Index c = f.at(0.0, 0.0);
+  for (int dr = -2; dr <= 2; ++dr)
+    for (int dc = -2; dc <= 2; ++dc) f.map.at(layer::elevation, nanogrid::Index(c(0) + dr, c(1) + dc)) = 1.0f;
+  f.map.at(layer::elevation, c) = 100.0f;
+  applySpatialSmoothing(f.map, layer::elevation, 3, 5);
+  EXPECT_NEAR(f.map.at(layer::elevation, c), 1.0f, 0.01f);
+  EXPECT_NO_THROW(applySpatialSmoothing(f.map, "nonexistent_layer"));
+}
+TEST(Postprocess, FeatureExtraction) {  // :268-400
+  PostFixture f;
+  f.map.get(layer::elevation).setConstant(1.0f);
+  applyFeatureExtraction(f.map, 0.6f, 4);
+  for (const char* n : {layer::step, layer::slope, layer::roughness, layer::curvature, layer::normal_x,
+                        layer::normal_y, layer::normal_z})
+    EXPECT_TRUE(f.map.exists(n));
+  const nanogrid::Index c = f.at(0.0, 0.0);
+  EXPECT_NEAR(f.map.at(layer::slope, c), 0.0f, 1.0f);
+  EXPECT_NEAR(f.map.at(layer::roughness, c), 0.0f, 0.001f);
+  EXPECT_NEAR(f.map.at(layer::step, c), 0.0f, 0.001f);
+  EXPECT_NEAR(f.map.at(layer::normal_z, c), 1.0f, 0.01f);
+  PostFixture t;  // tilted plane: 0.5 rise / run along the rows
+  auto& el = t.map.get(layer::elevation);
+  for (int r = 0; r < el.rows(); ++r)
+    for (int col = 0; col < el.cols(); ++col) el(r, col) = float(r) * 0.5f * 0.5f;
+  applyFeatureExtraction(t.map, 0.6f, 4);
+  EXPECT_GT(t.map.at(layer::slope, t.at(0.0, 0.0)), 10.0f);
+  EXPECT_LT(t.map.at(layer::slope, t.at(0.0, 0.0)), 45.0f);
+  EXPECT_GT(t.map.at(layer::normal_z, t.at(0.0, 0.0)), 0.0f);
+  PostFixture s;  // step edge between the two halves
+  auto& es = s.map.get(layer::elevation);
+  for (int r = 0; r < es.rows(); ++r)
+    for (int col = 0; col < es.cols(); ++col) es(r, col) = col < es.cols() / 2 ? 0.0f : 1.0f;
+  applyFeatureExtraction(s.map, 0.6f, 4);
+  EXPECT_GT(s.map.at(layer::step, s.at(0.0, 0.0)), 0.5f);
+  ElevationMap empty_map;  // default-constructed: no crash
+  EXPECT_NO_THROW(applyFeatureExtraction(empty_map));
+  PostFixture n;  // all NaN: layers exist, nothing computed; a single cell has too few neighbours
+  applyFeatureExtraction(n.map, 0.6f, 4);
+  EXPECT_TRUE(n.map.exists(layer::slope));
+  EXPECT_FALSE(std::isfinite(n.map.at(layer::slope, n.at(0.0, 0.0))));
+  n.map.at(layer::elevation, n.at(0.0, 0.0)) = 1.0f;
+  applyFeatureExtraction(n.map, 0.6f, 4);
+  EXPECT_FALSE(std::isfinite(n.map.at(layer::slope, n.at(0.0, 0.0))));
 }
 
 // ------------------------------------------- PointCloud2-shaped message straight to the device ----

@@ -1503,6 +1503,10 @@ int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* 
   if (!up || !lo) return FDM_OK;  // uncertainty_fusion.cpp:108-113: warn + return
   std::vector<RegionEntry> reg;
   region_disc(e, cfg->search_radius, reg);
+  {  // spatial weight of each offset (uncertainty_fusion.cpp:122-123,158): std::exp on a float
+    const float inv_2s2 = 1.0f / (2.0f * cfg->spatial_sigma * cfg->spatial_sigma);
+    for (auto& r : reg) r.w = std::exp(-r.dist_sq * inv_2s2);
+  }
   if ((rc = upload_region(e, reg))) return rc;
   if ((rc = ensure_tmp(e)) || (rc = ensure_tmp2(e))) return rc;
   if ((rc = copy_strided(e, e->d_tmp, 1, lptr(e, *up), lstride(e, *up)))) return rc;
@@ -1513,9 +1517,24 @@ int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* 
   F.q_upper = cfg->quantile_upper;
   F.min_valid = cfg->min_valid_neighbors;
   F.n_entries = int(reg.size());
-  hipLaunchKernelGGL(k_fusion, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state,
-                     int(e->scan_no & 3), e->d_region, F, e->d_tmp, e->d_tmp2, lptr(e, *up), lstride(e, *up),
-                     lptr(e, *lo), lstride(e, *lo), unsigned(e->ncell));
+  const unsigned fblocks = unsigned((e->ncell + kFusionThreads - 1) / kFusionThreads);
+  if (int(reg.size()) <= kFusionLdsEntries) {  // sample lists in LDS
+    const size_t lds = size_t(4) * reg.size() * kFusionThreads * sizeof(float);
+    static bool raised = false;
+    if (!raised) {
+      HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fusion<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                int(size_t(4) * kFusionLdsEntries * kFusionThreads * sizeof(float))));
+      raised = true;
+    }
+    hipLaunchKernelGGL(k_fusion<true>, dim3(fblocks), dim3(kFusionThreads), lds, e->stream, e->G, e->d_state,
+                       int(e->scan_no & 3), e->d_region, F, e->d_tmp, e->d_tmp2, lptr(e, *up), lstride(e, *up),
+                       lptr(e, *lo), lstride(e, *lo), unsigned(e->ncell));
+  } else {
+    hipLaunchKernelGGL(k_fusion<false>, dim3(fblocks), dim3(kFusionThreads), 0, e->stream, e->G, e->d_state,
+                       int(e->scan_no & 3), e->d_region, F, e->d_tmp, e->d_tmp2, lptr(e, *up), lstride(e, *up),
+                       lptr(e, *lo), lstride(e, *lo), unsigned(e->ncell));
+  }
   HIPCK(hipGetLastError());
   return FDM_OK;
 }
@@ -1543,8 +1562,18 @@ int fdm_engine_apply_feature_extraction(fdm_engine* e, float radius, int min_val
   FeatureOut O{};
   float** outs[7] = {&O.step, &O.slope, &O.roughness, &O.curvature, &O.nx, &O.ny, &O.nz};
   for (int k = 0; k < 7; ++k) *outs[k] = find_layer(e, names[k])->d;
-  hipLaunchKernelGGL(k_features, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state,
-                     int(e->scan_no & 3), e->d_region, F, lptr(e, *elev), lstride(e, *elev), O, unsigned(e->ncell));
+  // order statistics needed by `step`: index lo from the bottom, (count-1-hi) from the top; both grow
+  // with count, so the full region bounds them
+  const int nmax = int(reg.size());
+  const int need_lo = nmax > 0 ? static_cast<int>(lo_pct * float(nmax - 1)) + 1 : 1;
+  const int need_hi = nmax > 0 ? (nmax - 1) - static_cast<int>(hi_pct * float(nmax - 1)) + 1 : 1;
+  const bool pct_ok = lo_pct >= 0.0f && hi_pct <= 1.0f && lo_pct <= 1.0f && hi_pct >= 0.0f;
+  auto launch_feat = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state, int(e->scan_no & 3),
+                       e->d_region, F, lptr(e, *elev), lstride(e, *elev), O, unsigned(e->ncell));
+  };
+  if (pct_ok && need_lo <= 16 && need_hi <= 16) launch_feat(k_features<16>);
+  else launch_feat(k_features<0>);
   HIPCK(hipGetLastError());
   return FDM_OK;
 }

@@ -20,7 +20,7 @@ namespace fdm {
 
 constexpr int kMaxRegion = 256;  // entries of a disc / box neighbourhood the kernels accept
 
-struct RegionEntry { int dr, dc; float dist_sq; float pad; };
+struct RegionEntry { int dr, dc; float dist_sq; float w; };  // w: per-entry weight the host precomputed (fusion)
 
 struct PostGeom {
   int rows, cols, sr, sc;
@@ -103,8 +103,22 @@ struct FusionParams {
   float inv_2s2, q_lower, q_upper;
   int min_valid, n_entries;
 };
-// SimpleWeightedECDF::quantile over samples sorted by value (uncertainty_fusion.cpp:63-91)
-__device__ __forceinline__ float ecdf_quantile(const float* val, const float* wgt, int n, float p) {
+// SimpleWeightedECDF::quantile over samples sorted by value (uncertainty_fusion.cpp:63-91): ecdf_quantile_t
+// Per-thread sample lists live in LDS when the disc is small enough (slot-major, thread-minor: the
+// lanes of a wave hit consecutive banks), in scratch otherwise.  The lists are kept sorted by
+// insertion, which is what makes the kernel O(n^2) per cell and is the price of summing the weights
+// in the reference's (sorted) order.
+constexpr int kFusionThreads = 128;
+constexpr int kFusionLdsEntries = 64;  // 4 lists x 64 entries x 128 threads x 4 B = 128 KB of the CU's 160 KB
+
+template <bool USE_LDS>
+struct SampleList {
+  float* base;  // LDS: list[slot * kFusionThreads]; scratch: list[slot]
+  __device__ __forceinline__ float& operator[](int k) const { return USE_LDS ? base[k * kFusionThreads] : base[k]; }
+};
+template <bool USE_LDS>
+__device__ __forceinline__ float ecdf_quantile_t(const SampleList<USE_LDS>& val, const SampleList<USE_LDS>& wgt, int n,
+                                                 float p) {
   if (n == 0) return __uint_as_float(0x7FC00000u);
   if (n == 1) return val[0];
   float total = 0.0f;
@@ -118,18 +132,27 @@ __device__ __forceinline__ float ecdf_quantile(const float* val, const float* wg
   }
   return val[n - 1];
 }
-__global__ __launch_bounds__(256) void k_fusion(const GeomConst G, const DevState* __restrict__ st, int slot,
-                                                const RegionEntry* __restrict__ reg, const FusionParams F,
-                                                const float* __restrict__ up_in, const float* __restrict__ lo_in,
-                                                float* __restrict__ up_out, int up_stride,
-                                                float* __restrict__ lo_out, int lo_stride, unsigned ncell) {
-  const unsigned t = blockIdx.x * 256u + threadIdx.x;
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(kFusionThreads) void k_fusion(const GeomConst G, const DevState* __restrict__ st,
+                                                           int slot, const RegionEntry* __restrict__ reg,
+                                                           const FusionParams F, const float* __restrict__ up_in,
+                                                           const float* __restrict__ lo_in,
+                                                           float* __restrict__ up_out, int up_stride,
+                                                           float* __restrict__ lo_out, int lo_stride,
+                                                           unsigned ncell) {
+  extern __shared__ float s_lists[];
+  float scratch[USE_LDS ? 1 : 4 * kMaxRegion];
+  const int cap = USE_LDS ? F.n_entries : kMaxRegion;  // LDS is sized for the region actually used
+  float* pool = USE_LDS ? s_lists + threadIdx.x : scratch;
+  const int pitch = USE_LDS ? cap * kFusionThreads : cap;
+  const SampleList<USE_LDS> lv{pool}, lw{pool + pitch}, uv{pool + 2 * pitch}, uw{pool + 3 * pitch};
+  const unsigned t = blockIdx.x * unsigned(kFusionThreads) + threadIdx.x;
   if (t >= ncell) return;
   const PostGeom p = post_geom(st, slot, G);
   const int lc = int(t / unsigned(p.rows)), lr = int(t - unsigned(lc) * unsigned(p.rows));
   const size_t ci = post_index(p, lr, lc);
   if (!isfinite(up_in[ci]) || !isfinite(lo_in[ci])) return;
-  float lv[kMaxRegion], lw[kMaxRegion], uv[kMaxRegion], uw[kMaxRegion];
   int nl = 0, nu = 0, valid = 0;
   for (int e = 0; e < F.n_entries; ++e) {
     const RegionEntry re = reg[e];
@@ -137,8 +160,7 @@ __global__ __launch_bounds__(256) void k_fusion(const GeomConst G, const DevStat
     const size_t ni = post_index(p, lr + re.dr, lc + re.dc);
     const float nu_v = up_in[ni], nl_v = lo_in[ni];
     if (!isfinite(nu_v) || !isfinite(nl_v)) continue;
-    // std::exp(float): evaluated in double and rounded, which agrees with a correctly rounded expf
-    const float w_spatial = static_cast<float>(exp(static_cast<double>(-re.dist_sq * F.inv_2s2)));
+    const float w_spatial = re.w;  // std::exp(-dist_sq * inv_2sigma_sq): a property of the entry, from the host
     const float range = nu_v - nl_v;
     const float w_range = 1.0f / (range + 1e-4f);
     const float weight = w_spatial * w_range;
@@ -153,8 +175,8 @@ __global__ __launch_bounds__(256) void k_fusion(const GeomConst G, const DevStat
     ++valid;
   }
   if (valid < F.min_valid) return;
-  const float lower = ecdf_quantile(lv, lw, nl, F.q_lower);
-  const float upper = ecdf_quantile(uv, uw, nu, F.q_upper);
+  const float lower = ecdf_quantile_t<USE_LDS>(lv, lw, nl, F.q_lower);
+  const float upper = ecdf_quantile_t<USE_LDS>(uv, uw, nu, F.q_upper);
   if (isfinite(lower) && isfinite(upper)) {
     up_out[ci * up_stride] = upper;
     lo_out[ci * lo_stride] = lower;
@@ -277,6 +299,11 @@ struct FeatureParams {
 struct FeatureOut {
   float *step, *slope, *roughness, *curvature, *nx, *ny, *nz;
 };
+// `step` needs two order statistics of the neighbourhood's heights (feature_extraction.cpp:100-103).
+// TOPK > 0: they are among the TOPK smallest / TOPK largest values, which are kept in registers by
+// unrolled compare-exchange chains (the host checks the percentiles make that true for the region);
+// TOPK == 0: any percentile pair, full insertion sort in scratch.
+template <int TOPK>
 __global__ __launch_bounds__(256) void k_features(const GeomConst G, const DevState* __restrict__ st, int slot,
                                                   const RegionEntry* __restrict__ reg, const FeatureParams F,
                                                   const float* __restrict__ elev, int elev_stride,
@@ -290,7 +317,12 @@ __global__ __launch_bounds__(256) void k_features(const GeomConst G, const DevSt
   if (!isfinite(center_z)) return;
   float sum[3] = {0.f, 0.f, 0.f};
   float sq[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  float zs[kMaxRegion];
+  float zs[TOPK > 0 ? 1 : kMaxRegion];
+  float small[TOPK > 0 ? TOPK : 1], large[TOPK > 0 ? TOPK : 1];
+  if (TOPK > 0) {
+#pragma unroll
+    for (int j = 0; j < TOPK; ++j) { small[j] = 3.402823466e+38f; large[j] = -3.402823466e+38f; }
+  }
   int count = 0;
   for (int e = 0; e < F.n_entries; ++e) {
     const RegionEntry re = reg[e];
@@ -304,9 +336,22 @@ __global__ __launch_bounds__(256) void k_features(const GeomConst G, const DevSt
     for (int c = 0; c < 3; ++c)
 #pragma unroll
       for (int r = 0; r < 3; ++r) sq[c * 3 + r] += d[r] * d[c];
-    int k = count++;  // z_vals kept sorted (std::sort at feature_extraction.cpp:100)
-    while (k > 0 && zs[k - 1] > nz) { zs[k] = zs[k - 1]; --k; }
-    zs[k] = nz;
+    if (TOPK > 0) {
+      float a = nz, b = nz;
+#pragma unroll
+      for (int j = 0; j < TOPK; ++j) {  // small[] ascending, large[] descending
+        const float lo_j = small[j], hi_j = large[j];
+        small[j] = a < lo_j ? a : lo_j;
+        a = a < lo_j ? lo_j : a;
+        large[j] = b > hi_j ? b : hi_j;
+        b = b > hi_j ? hi_j : b;
+      }
+      ++count;
+    } else {
+      int k = count++;  // z_vals kept sorted (std::sort at feature_extraction.cpp:100)
+      while (k > 0 && zs[k - 1] > nz) { zs[k] = zs[k - 1]; --k; }
+      zs[k] = nz;
+    }
   }
   if (count < F.min_valid) return;
   const float inv_n = 1.0f / float(count);
@@ -324,7 +369,21 @@ __global__ __launch_bounds__(256) void k_features(const GeomConst G, const DevSt
   if (normal[2] < 0.0f) { normal[0] = -normal[0]; normal[1] = -normal[1]; normal[2] = -normal[2]; }
   const int lo = static_cast<int>(F.lo_pct * float(count - 1));
   const int hi = static_cast<int>(F.hi_pct * float(count - 1));
-  O.step[ci] = zs[hi] - zs[lo];
+  float z_lo, z_hi;
+  if (TOPK > 0) {
+    const int from_top = count - 1 - hi;
+    z_lo = small[0];
+    z_hi = large[0];
+#pragma unroll
+    for (int j = 1; j < TOPK; ++j) {
+      z_lo = lo == j ? small[j] : z_lo;
+      z_hi = from_top == j ? large[j] : z_hi;
+    }
+  } else {
+    z_lo = zs[lo];
+    z_hi = zs[hi];
+  }
+  O.step[ci] = z_hi - z_lo;
   O.slope[ci] = static_cast<float>(acos(static_cast<double>(fabsf(normal[2])))) * 180.0f / 3.14159274101257324f;
   O.roughness[ci] = sqrtf(val[0]);
   O.curvature[ci] = (trace > 0.0f) ? fabsf(val[0] / trace) : 0.0f;

@@ -12,6 +12,6 @@ import csv, sys
 for w in sys.argv[1:]:
     print(w)
     for r in csv.DictReader(open(f"gpurun_out/prof_stage_{w}/{w}_kernel_stats.csv")):
-        if "k_pack" in r["Name"] or "k_ingest" in r["Name"]:
+        if any(k in r["Name"] for k in ("k_pack", "k_ingest", "k_inpaint", "k_median", "k_fusion", "k_features")):
             print("  %-40s calls=%5s avg=%9.1f us" % (r["Name"].split("(")[0][-40:], r["Calls"], float(r["AverageNs"])/1e3))
 PY

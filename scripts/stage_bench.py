@@ -89,3 +89,20 @@ print(json.dumps({"stage": "ingest_cloud2", "workload": a.workload, "points": n,
                   "gpu_ms": round(t * 1e3, 4), "algorithmic_MB": round(alg / 1e6, 2), "GBps": round(alg / t / 1e9, 1),
                   "hbm_frac": round(alg / t / HBM, 4), "cpu_oracle_ms": round(t_cpu * 1e3, 2),
                   "speedup": round(t_cpu / t, 1)}))
+
+# ---- stencil post-processing on the mapped scene ----
+for name, fn_gpu, fn_cpu, alg_bytes in (
+        ("post_inpainting(3 passes)", lambda: eng.apply_inpainting(3, 2), lambda: ref.apply_inpainting(3, 2), cells * 4 * 2 * 4),
+        ("post_median_3x3", lambda: eng.apply_spatial_smoothing("elevation_inpainted", 3, 5),
+         lambda: ref.apply_spatial_smoothing("elevation_inpainted", 3, 5), cells * 4 * 3),
+        ("post_uncertainty_fusion(r=0.15)", lambda: eng.apply_uncertainty_fusion(True, 0.15, 0.05, 0.01, 0.99, 3),
+         lambda: ref.apply_uncertainty_fusion(True, 0.15, 0.05, 0.01, 0.99, 3), cells * 4 * 6),
+        ("post_feature_extraction(r=0.3)", lambda: eng.apply_feature_extraction(0.3, 4, 0.05, 0.95),
+         lambda: ref.apply_feature_extraction(0.3, 4, 0.05, 0.95), cells * 4 * 8)):
+    t = timed(fn_gpu, max(3, a.iters // 4))
+    t0 = time.perf_counter()
+    fn_cpu()
+    t_cpu = time.perf_counter() - t0
+    print(json.dumps({"stage": name, "workload": a.workload, "cells": cells, "gpu_ms": round(t * 1e3, 4),
+                      "algorithmic_MB": round(alg_bytes / 1e6, 2), "GBps": round(alg_bytes / t / 1e9, 1),
+                      "cpu_oracle_ms": round(t_cpu * 1e3, 2), "speedup": round(t_cpu / t, 1)}))

@@ -20,7 +20,7 @@ def test_cpp_api_without_gpu_fails_loudly():
     if torch.cuda.is_available():
         pytest.skip("a GPU is present")
     # host-only tests (config validation, sensor-model classes) still pass ...
-    r = subprocess.run([BIN, "Config."], capture_output=True, text=True, timeout=60)
+    r = subprocess.run([BIN, "Config."], capture_output=True, text=True, timeout=60, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
     # ... anything that needs the map raises: there is no CPU fallback behind the API
     r = subprocess.run([BIN, "ElevationMap.Default"], capture_output=True, text=True, timeout=60)
@@ -29,7 +29,8 @@ def test_cpp_api_without_gpu_fails_loudly():
 
 @pytest.mark.gpu
 def test_cpp_api_spec_tests_on_gpu():
-    r = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
+    env = dict(os.environ, FDM_CONFIG_DIR=os.path.join(ROOT, "fastdem_amd", "config"))
+    r = subprocess.run([BIN], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     print(r.stdout[-4000:])
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
     assert " 0 failures" in r.stdout
