@@ -23,4 +23,12 @@ for W in c2 c4; do
   python3 $R/scripts/pmc_traffic.py $W $O/pmc_$W $O/pmc_traffic.json
 done
 cd $R
+# the widened rows: stage timings + kernel traces
+for W in c2 c3 c4; do python scripts/ray_bench.py $W --steps 20 --cpu-iters 2 >> $O/ray_bench.jsonl 2>> $O/ray_bench.err; done
+bash scripts/prof_ray.sh c2 c4 > $O/prof_ray.txt 2>&1
+bash scripts/prof_stages.sh c2 c4 > $O/prof_stages.txt 2>&1
+for W in c2 c4; do
+  cp gpurun_out/prof_ray_$W/${W}_kernel_stats.csv $O/rocprof_ray_${W}_kernel_stats.csv
+  cp gpurun_out/prof_stage_$W/${W}_kernel_stats.csv $O/rocprof_stages_${W}_kernel_stats.csv
+done
 tail -c 600 $O/bench_c2.json; echo; cat $O/pytest_gpu.txt
