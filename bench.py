@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large", action="store_true")
     ap.add_argument("--wave-merge", type=int, default=1)
+    ap.add_argument("--overlap", type=int, default=1, help="bin(t+1) || update(t) on two streams (A/B switch)")
     return ap.parse_args()
 
 
@@ -54,13 +55,14 @@ def colmajor16(T):
 class Resident:
     """One workload with its scans resident in HBM and a device-side engine."""
 
-    def __init__(self, wl, device, wave_merge=1):
+    def __init__(self, wl, device, wave_merge=1, overlap=1):
         import torch
         from fastdem_amd import Engine, capi
         self.wl = wl
         self.eng = Engine(wl.width, wl.height, wl.resolution, wl.apply_to(capi.default_config()),
                           device=device)
         self.eng.set_option("wave_merge", wave_merge)
+        self.eng.set_option("overlap", overlap)
         self.dev = []
         for s in wl.scans:
             d = {k: (torch.from_numpy(v).to(f"cuda:{device}") if v is not None else None)
@@ -207,7 +209,7 @@ def main():
     else:
         kw = {"order": args.order} if args.workload in ("c2", "c4") else {}
         wl = synth.make(args.workload, **kw)
-        res = Resident(wl, local_rank, args.wave_merge)
+        res = Resident(wl, local_rank, args.wave_merge, args.overlap)
 
         def barrier():
             res.eng.sync()
@@ -263,7 +265,7 @@ def main():
                                   intensity=s["intensity"], rgb=s["rgb"])
             result["host_buffers_ms_per_scan"] = (time.perf_counter() - t0) / 50 * 1e3
             if world == 1 and not args.no_large and args.workload != "c4":
-                big = Resident(synth.lidar128(n_scans=2), local_rank, args.wave_merge)
+                big = Resident(synth.lidar128(n_scans=2), local_rank, args.wave_merge, args.overlap)
                 for i in range(10):
                     big.step(i)
                 big.eng.sync()

@@ -80,6 +80,9 @@ struct ScanParams {
   int gate_on_filter;  // integrate(): nothing happens when every point is filtered
   int sensor_type;     // 0 Constant, 1 LiDAR, 2 RGBD
   int has_intensity, has_color, has_var;
+  int chain_prev;      // 1: the previous scan's update may still be running on the update stream:
+  int prev_do_move;    //    derive this scan's base geometry from the PREVIOUS slot (geom, cand, any_pass)
+  int prev_gate;       //    exactly as that update will commit it, instead of reading the committed slot
   int dbg_no_atomics;  // experiment switch (bench A/B only): skip the scratch atomics
   int dbg_upd;         // experiment switch: 1 = k_update returns after the context, 2 = after round 1
 };

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <string>
 #include <vector>
@@ -123,6 +124,16 @@ struct fdm_engine {
   hipEvent_t ev_ray[2] = {nullptr, nullptr};
   bool ray_timed = false;
   int dbg_ray = 0;
+  // update(t) || bin(t+1) in ONE launch (k_update_bin): the update of the last small scan is held back
+  // until the next scan arrives (or any other entry point / sync flushes it); the scratch is
+  // double-buffered by scan parity.
+  unsigned long long* key2[2] = {nullptr, nullptr};  // scratch of even / odd scans ([0] == the original allocation)
+  uint4* aux2[2] = {nullptr, nullptr};
+  bool overlap = true;          // option "overlap"
+  bool chain = false;           // an update is held back: the next bin derives its geometry from the previous slot
+  std::function<int()> upd_alone;   // launches the held-back update on its own
+  std::function<int(const ScanParams&, const Scratch&, const ScanInputs&, int32_t*, unsigned, bool)> upd_fused;
+  int last_do_move = 0, last_gate = 0;
   // stencil post-processing (fdm_post.hpp)
   RegionEntry* d_region = nullptr;   // kMaxRegion entries
   float* d_tmp2 = nullptr;           // second ncell staging array (fusion works on two layers)
@@ -141,6 +152,26 @@ struct fdm_engine {
 };
 
 namespace {
+
+// Launch the held-back update kernel, if any.  Called at the top of every entry point that is not
+// the next scan of the chain, and before anything that syncs or reallocates.
+int join_streams(fdm_engine* e) {
+  if (e->chain) {
+    e->chain = false;
+    std::function<int()> f = std::move(e->upd_alone);
+    e->upd_alone = nullptr;
+    e->upd_fused = nullptr;
+    if (f) {
+      if (int rc = f()) return rc;
+    }
+  }
+  return FDM_OK;
+}
+int sync_all(fdm_engine* e) {
+  if (int rc = join_streams(e)) return rc;
+  HIPCK(hipStreamSynchronize(e->stream));
+  return FDM_OK;
+}
 
 Layer* find_layer(fdm_engine* e, const char* name) {
   for (auto& l : e->layers)
@@ -231,7 +262,7 @@ int refresh_layer_ptrs(fdm_engine* e) {
     if (l.field < 0) ptrs.push_back(l.d);  // record fields are cleared with the record
   if (ptrs.empty()) ptrs.push_back(nullptr);
   // the old array may still be referenced by an in-flight kernel: drain first
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   if (e->d_layer_ptrs) HIPCK(hipFree(e->d_layer_ptrs));
   HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_layer_ptrs), ptrs.size() * sizeof(float*)));
   HIPCK(hipMemcpy(e->d_layer_ptrs, ptrs.data(), ptrs.size() * sizeof(float*), hipMemcpyHostToDevice));
@@ -247,7 +278,7 @@ int resolve_pending(fdm_engine* e) {
   bool any = false;
   for (auto& l : e->layers) any = any || l.pending;
   if (!any) return FDM_OK;
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   HIPCK(hipMemcpy(e->h_state, e->d_state, sizeof(DevState), hipMemcpyDeviceToHost));
   const unsigned vi = e->h_state->vis_int, vc = e->h_state->vis_col, vr = e->h_state->vis_ray;
   // newly visible layers move to the END of the list in the order the reference would have created
@@ -290,7 +321,7 @@ void rotation_of_product(const double* Twb, const double* Tbs, float* R) {
 int ensure_ids(fdm_engine* e, size_t n) {
   if (!e->want_ids) return FDM_OK;
   if (n > e->ids_cap) {
-    HIPCK(hipStreamSynchronize(e->stream));
+    if (int rc_sync = sync_all(e)) return rc_sync;
     if (e->d_cell_ids) HIPCK(hipFree(e->d_cell_ids));
     e->ids_cap = n + n / 4 + 1024;
     HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_cell_ids), e->ids_cap * sizeof(int32_t)));
@@ -322,7 +353,7 @@ int deactivate_records(fdm_engine* e) {
     l.d = own;
     l.field = -1;
   }
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   HIPCK(hipFree(e->d_rec));
   e->d_rec = nullptr;
   e->rec_kind = -1;
@@ -345,7 +376,7 @@ int activate_records(fdm_engine* e, int kind) {
     if (!l) return fail(FDM_ERR_NO_LAYER, std::string("estimator layer missing: ") + names[f]);
     if (int rc = copy_strided(e, e->d_rec + f, e->rec_floats, l->d, 1)) return rc;
   }
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   for (int f = 0; f < nf; ++f) {
     Layer* l = find_layer(e, names[f]);
     HIPCK(hipFree(l->d));
@@ -381,7 +412,7 @@ int ensure_ray_cells(fdm_engine* e) {
 
 int ensure_voxel_buffers(fdm_engine* e, size_t n) {
   if (n <= e->vcap) return FDM_OK;
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   for (int k = 0; k < 2; ++k) {
     if (e->vkeys[k]) HIPCK(hipFree(e->vkeys[k]));
     if (e->vidx[k]) HIPCK(hipFree(e->vidx[k]));
@@ -538,7 +569,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   e->S.cap_drop_nan = ray_on ? 1 : 0;
   if ((e->cap_pre || ray_on) && n) {
     if (n > e->cap_cap) {
-      HIPCK(hipStreamSynchronize(e->stream));
+      if (int rc_sync = sync_all(e)) return rc_sync;
       if (e->d_cap) HIPCK(hipFree(e->d_cap));
       e->cap_cap = n + n / 4 + 1024;
       HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_cap), e->cap_cap * 4 * sizeof(float)));
@@ -554,6 +585,18 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     e->S.ras_z = e->d_ras;
   }
 
+  // ---- launch plan.  Small scans are launch/latency-bound (two dependent launches of ~100 blocks),
+  // so the update of scan t is held back and leaves together with the bin of scan t+1 in one launch
+  // (k_update_bin): they share nothing — the scratch is double-buffered by scan parity and a
+  // chained bin derives its base geometry from slot t (ScanParams::chain_prev).
+  const int parity = int(e->scan_no & 1);
+  if (e->key2[1]) {  // the scratch set of this scan's parity
+    e->S.key = e->key2[parity];
+    e->S.aux = e->aux2[parity];
+  }
+  const bool plain = e->overlap && e->key2[1] && e->S.dense && !e->profile && !ray_on && !e->cap_pre &&
+                     !e->cap_ras && !e->obst_dense_pending;
+
   // k_bin4 (4 consecutive points per thread, float4 loads) needs 16-byte aligned channels
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
   // k_bin4 trades latency for fewer memory-side atomics: worth it from ~64 K points up
@@ -566,7 +609,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   const unsigned per_block = use_bin4 ? bin_threads * 4u : 256u;
   const unsigned bin_blocks = n ? unsigned((n + per_block - 1) / per_block) : 1u;
   if (bin_blocks > e->bin_part_cap) {
-    HIPCK(hipStreamSynchronize(e->stream));
+    if (int rc_sync = sync_all(e)) return rc_sync;
     if (e->S.bin_part) HIPCK(hipFree(e->S.bin_part));
     e->bin_part_cap = bin_blocks + bin_blocks / 4 + 64;
     HIPCK(hipMalloc(reinterpret_cast<void**>(&e->S.bin_part), e->bin_part_cap * sizeof(unsigned long long)));
@@ -574,6 +617,10 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   e->last_bin_blocks = bin_blocks;
   P.dbg_no_atomics = e->dbg_no_atomics;
   P.dbg_upd = e->dbg_upd;
+  // a held-back update leaves now: fused with this bin if this scan is a plain small one, alone otherwise
+  const bool fuse_now = e->chain && plain && !use_bin4 && e->upd_fused;
+  if (e->chain && !fuse_now && (rc = join_streams(e))) return rc;
+  P.chain_prev = 0;
   if (e->profile) HIPCK(hipEventRecord(e->ev[0], e->stream));
   int32_t* ids = e->want_ids ? e->d_cell_ids : nullptr;
   if (use_bin4) {
@@ -591,6 +638,16 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     else if (bin_threads == 512) { FDM_BIN4(512) }
     else { FDM_BIN4(256) }
 #undef FDM_BIN4
+  } else if (fuse_now) {  // the held-back update of the previous scan + this scan's bin, one launch
+    P.chain_prev = 1;
+    P.prev_do_move = e->last_do_move;
+    P.prev_gate = e->last_gate;
+    const ScanInputs in_b{dx, dy, dz, dint, drgb, dvar};
+    auto fused = std::move(e->upd_fused);
+    e->upd_fused = nullptr;
+    e->upd_alone = nullptr;
+    e->chain = false;
+    if ((rc = fused(P, e->S, in_b, ids, bin_blocks, e->wave_merge))) return rc;
   } else {
     auto launch_bin = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(bin_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state, dx, dy,
@@ -618,10 +675,40 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     p2.marker = std::min(std::max(e->cfg.p2_elevation_marker, 0), 4);
     p2.max_count = std::max(e->cfg.p2_max_sample_count, 0.0f);
   }
-  auto launch_upd = [&](auto kern, const auto& layers) {
-    hipLaunchKernelGGL(kern, dim3(upd_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state, layers,
-                       e->d_layer_ptrs, e->n_layer_ptrs, e->S, dx, dy, dz, dint, drgb, dvar,
-                       unsigned(e->ncell));
+  const bool hold = plain && !use_bin4;  // the next scan's launch (or a flush) carries this update
+  const ScanInputs in_u{dx, dy, dz, dint, drgb, dvar};
+  auto launch_upd = [&](auto policy_tag, const auto& layers) {
+    using POLICY = decltype(policy_tag);
+    if (!hold) {
+      hipLaunchKernelGGL(k_update<POLICY>, dim3(upd_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state,
+                         layers, e->d_layer_ptrs, e->n_layer_ptrs, e->S, dx, dy, dz, dint, drgb, dvar,
+                         unsigned(e->ncell));
+      return;
+    }
+    const ScanParams Pu = P;
+    const Scratch Su = e->S;
+    const auto Lu = layers;
+    e->upd_alone = [e, Pu, Su, Lu, in_u, upd_blocks]() -> int {
+      hipLaunchKernelGGL(k_update<POLICY>, dim3(upd_blocks), dim3(256), 0, e->stream, Pu, e->G, e->d_state, Lu,
+                         e->d_layer_ptrs, e->n_layer_ptrs, Su, in_u.x, in_u.y, in_u.z, in_u.intensity, in_u.rgb,
+                         in_u.var, unsigned(e->ncell));
+      HIPCK(hipGetLastError());
+      return FDM_OK;
+    };
+    e->upd_fused = [e, Pu, Su, Lu, in_u, upd_blocks](const ScanParams& Pb, const Scratch& Sb, const ScanInputs& Ib,
+                                                     int32_t* ids_b, unsigned bin_blocks_b, bool wave_merge) -> int {
+      auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(upd_blocks + bin_blocks_b), dim3(256), 0, e->stream, Pu, e->G, e->d_state,
+                           Lu, e->d_layer_ptrs, e->n_layer_ptrs, Su, in_u, unsigned(e->ncell), upd_blocks, Pb, Sb,
+                           Ib, ids_b);
+      };
+      wave_merge ? go(k_update_bin<POLICY, true>) : go(k_update_bin<POLICY, false>);
+      HIPCK(hipGetLastError());
+      return FDM_OK;
+    };
+    e->chain = true;
+    e->last_do_move = P.do_move;
+    e->last_gate = P.gate_on_filter;
   };
   const bool p2mode = e->cfg.estimation_type == 1;
   if (e->rec_kind >= 0) {  // cell records
@@ -629,13 +716,13 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
       P2RecLayers Lr{};
       Lr.rec = e->d_rec; Lr.obstacle = L(e, "obstacle"); Lr.intensity = L(e, "intensity"); Lr.color = L(e, "color");
       Lr.p = p2;
-      launch_upd(k_update<P2RecPolicy>, Lr);
+      launch_upd(P2RecPolicy{}, Lr);
     } else {
       KalmanRecLayers Lr{};
       Lr.rec = e->d_rec; Lr.obstacle = L(e, "obstacle"); Lr.intensity = L(e, "intensity"); Lr.color = L(e, "color");
       Lr.min_var = e->cfg.kalman_min_variance; Lr.max_var = e->cfg.kalman_max_variance;
       Lr.q = e->cfg.kalman_process_noise;
-      launch_upd(k_update<KalmanRecPolicy>, Lr);
+      launch_upd(KalmanRecPolicy{}, Lr);
     }
   } else if (p2mode) {
     P2Layers Lp{};
@@ -654,7 +741,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
       Lp.n[k] = L(e, kP2N[k]);
     }
     Lp.p = p2;
-    launch_upd(k_update<P2Policy>, Lp);
+    launch_upd(P2Policy{}, Lp);
   } else {
     KalmanLayers Lk{};
     Lk.elevation = L(e, "elevation");
@@ -673,7 +760,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     Lk.min_var = e->cfg.kalman_min_variance;
     Lk.max_var = e->cfg.kalman_max_variance;
     Lk.q = e->cfg.kalman_process_noise;
-    launch_upd(k_update<KalmanPolicy>, Lk);
+    launch_upd(KalmanPolicy{}, Lk);
   }
   HIPCK(hipGetLastError());
   if (e->profile) {
@@ -740,7 +827,7 @@ void fill_update_params(fdm_engine* e, ScanParams& P, double rx, double ry, bool
 
 int ensure_stage(fdm_engine* e, size_t n) {
   if (n <= e->stage_cap) return FDM_OK;
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   if (e->d_stage) HIPCK(hipFree(e->d_stage));
   e->stage_cap = n + n / 4 + 1024;
   HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_stage), e->stage_cap * 6 * sizeof(float)));
@@ -783,7 +870,7 @@ int stage_inputs(fdm_engine* e, uint64_t n, const float* x, const float* y, cons
 }
 
 int read_stats(fdm_engine* e, fdm_scan_stats* out, int* status) {
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   fdm_scan_stats s{};
   *status = FDM_OK;
   if (!e->have_scan) {
@@ -958,6 +1045,15 @@ static int create_impl(const fdm_geometry* g, const fdm_config* cfg, const fdm_t
   HCK(hipMalloc(reinterpret_cast<void**>(&e->S.aux), e->ncell * sizeof(uint4)));
   HCK(hipMalloc(reinterpret_cast<void**>(&e->S.upd_part), e->n_tiles * sizeof(uint32_t)));
   HCK(hipMalloc(reinterpret_cast<void**>(&e->S.tile_stamp), e->n_tiles * sizeof(uint32_t)));
+  e->key2[0] = e->S.key;
+  e->aux2[0] = e->S.aux;
+  if (e->S.dense) {  // second scratch set: scan t+1 bins while scan t still updates (24 B/cell, <= 100 MB)
+    HCK(hipMalloc(reinterpret_cast<void**>(&e->key2[1]), e->ncell * sizeof(unsigned long long)));
+    HCK(hipMalloc(reinterpret_cast<void**>(&e->aux2[1]), e->ncell * sizeof(uint4)));
+    const int blocks2 = int(std::min<size_t>((e->ncell + 255) / 256, 4096));
+    hipLaunchKernelGGL(k_fill_u64, dim3(blocks2), dim3(256), 0, e->stream, e->key2[1], kEmptyKey, e->ncell);
+    hipLaunchKernelGGL(k_fill_aux, dim3(blocks2), dim3(256), 0, e->stream, e->aux2[1], e->ncell);
+  }
   {
     const int blocks = int(std::min<size_t>((e->ncell + 255) / 256, 4096));
     hipLaunchKernelGGL(k_fill_u64, dim3(blocks), dim3(256), 0, e->stream, e->S.key, kEmptyKey, e->ncell);
@@ -1004,8 +1100,13 @@ void fdm_engine_destroy(fdm_engine* e) {
   if (e->d_rec) (void)hipFree(e->d_rec);
   if (e->d_tmp) (void)hipFree(e->d_tmp);
   if (e->d_layer_ptrs) (void)hipFree(e->d_layer_ptrs);
-  if (e->S.key) (void)hipFree(e->S.key);
-  if (e->S.aux) (void)hipFree(e->S.aux);
+  e->upd_alone = nullptr;
+  e->upd_fused = nullptr;
+  if (e->key2[0]) (void)hipFree(e->key2[0]);
+  if (e->aux2[0]) (void)hipFree(e->aux2[0]);
+  if (e->key2[1]) (void)hipFree(e->key2[1]);
+  if (e->aux2[1]) (void)hipFree(e->aux2[1]);
+
   if (e->S.bin_part) (void)hipFree(e->S.bin_part);
   if (e->S.upd_part) (void)hipFree(e->S.upd_part);
   if (e->S.tile_stamp) (void)hipFree(e->S.tile_stamp);
@@ -1038,6 +1139,7 @@ void fdm_engine_destroy(fdm_engine* e) {
 }
 
 int fdm_engine_set_config(fdm_engine* e, const fdm_config* cfg) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !cfg) return fail(FDM_ERR_INVALID, "null argument");
   if (cfg->mode != 1 && (e->G.s_rows != e->G.rows || e->G.s_cols != e->G.cols))
     return fail(FDM_ERR_INVALID, "tiled engines require GLOBAL mode");
@@ -1047,8 +1149,9 @@ int fdm_engine_set_config(fdm_engine* e, const fdm_config* cfg) {
 }
 
 int fdm_engine_set_stream(fdm_engine* e, void* hip_stream) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   if (hip_stream) {
     if (e->own_stream && e->stream) HIPCK(hipStreamDestroy(e->stream));
     e->stream = static_cast<hipStream_t>(hip_stream);
@@ -1081,6 +1184,7 @@ int fdm_engine_integrate_device(fdm_engine* e, uint64_t n, const float* dx, cons
 int fdm_engine_integrate(fdm_engine* e, uint64_t n, const float* x, const float* y, const float* z,
                          const float* intensity, const uint32_t* rgb, const float* sigma_z2,
                          const double Tbs[16], const double Twb[16], fdm_scan_stats* out) {
+  if (e) { if (int rc_join = join_streams(e)) return rc_join; }
   if (!e || !Tbs || !Twb) return fail(FDM_ERR_INVALID, "null argument");
   if (n == 0) {
     if (out) {
@@ -1116,6 +1220,7 @@ int fdm_engine_update_device(fdm_engine* e, uint64_t n, const float* dx, const f
 int fdm_engine_update(fdm_engine* e, uint64_t n, const float* x, const float* y, const float* z,
                       const float* z_var, const float* intensity, const uint32_t* rgb, double rx,
                       double ry, fdm_scan_stats* out) {
+  if (e) { if (int rc_join = join_streams(e)) return rc_join; }
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
   if (n && (!x || !y || !z)) return fail(FDM_ERR_INVALID, "null xyz");
   HIPCK(hipSetDevice(e->device));
@@ -1133,15 +1238,17 @@ int fdm_engine_update(fdm_engine* e, uint64_t n, const float* x, const float* y,
 }
 
 int fdm_engine_sync(fdm_engine* e) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   return FDM_OK;
 }
 
 int fdm_engine_last_stats(fdm_engine* e, fdm_scan_stats* out) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
   if (e->have_scan && e->last_was_integrate && e->last_n == 0) {
-    HIPCK(hipStreamSynchronize(e->stream));
+    if (int rc_sync = sync_all(e)) return rc_sync;
     if (out) std::memset(out, 0, sizeof(*out));
     return FDM_SKIP_EMPTY_CLOUD;
   }
@@ -1151,6 +1258,7 @@ int fdm_engine_last_stats(fdm_engine* e, fdm_scan_stats* out) {
 }
 
 int fdm_engine_move(fdm_engine* e, double x, double y) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
   if (e->G.s_rows != e->G.rows || e->G.s_cols != e->G.cols)
     return fail(FDM_ERR_INVALID, "move() is not defined for tiled engines");
@@ -1161,8 +1269,9 @@ int fdm_engine_move(fdm_engine* e, double x, double y) {
 }
 
 int fdm_engine_get_geometry(fdm_engine* e, fdm_geometry* out) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !out) return fail(FDM_ERR_INVALID, "null argument");
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   DevGeom g;
   HIPCK(hipMemcpy(&g, &e->d_state->geom[e->scan_no & 3], sizeof(DevGeom), hipMemcpyDeviceToHost));
   out->length_x = e->G.len_x;
@@ -1178,26 +1287,29 @@ int fdm_engine_get_geometry(fdm_engine* e, fdm_geometry* out) {
 }
 
 int fdm_engine_set_position(fdm_engine* e, double x, double y) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   const double p[2] = {x, y};
   HIPCK(hipMemcpy(&e->d_state->geom[e->scan_no & 3].px, p, sizeof(p), hipMemcpyHostToDevice));
   return FDM_OK;
 }
 
 int fdm_engine_set_start_index(fdm_engine* e, int32_t row, int32_t col) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
   if (row < 0 || col < 0 || row >= e->G.rows || col >= e->G.cols)
     return fail(FDM_ERR_INVALID, "start index out of range");
   if ((row || col) && (e->G.s_rows != e->G.rows || e->G.s_cols != e->G.cols))
     return fail(FDM_ERR_INVALID, "tiled engines need start index 0");
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   const int s[2] = {row, col};
   HIPCK(hipMemcpy(&e->d_state->geom[e->scan_no & 3].sr, s, sizeof(s), hipMemcpyHostToDevice));
   return FDM_OK;
 }
 
 int fdm_engine_num_layers(fdm_engine* e) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
   if (int rc = resolve_pending(e)) return rc;
   int n = 0;
@@ -1206,6 +1318,7 @@ int fdm_engine_num_layers(fdm_engine* e) {
 }
 
 const char* fdm_engine_layer_name(fdm_engine* e, int i) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return nullptr; } }
   if (!e) return nullptr;
   if (resolve_pending(e)) return nullptr;
   int k = 0;
@@ -1217,6 +1330,7 @@ const char* fdm_engine_layer_name(fdm_engine* e, int i) {
 }
 
 int fdm_engine_layer_exists(fdm_engine* e, const char* name) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !name) return fail(FDM_ERR_INVALID, "null argument");
   if (int rc = resolve_pending(e)) return rc;
   Layer* l = find_layer(e, name);
@@ -1224,6 +1338,7 @@ int fdm_engine_layer_exists(fdm_engine* e, const char* name) {
 }
 
 int fdm_engine_layer_add(fdm_engine* e, const char* name, float value) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !name) return fail(FDM_ERR_INVALID, "null argument");
   HIPCK(hipSetDevice(e->device));
   if (std::strcmp(name, "obstacle") == 0) e->obst_dense_pending = true;
@@ -1232,6 +1347,7 @@ int fdm_engine_layer_add(fdm_engine* e, const char* name, float value) {
 }
 
 int fdm_engine_layer_download(fdm_engine* e, const char* name, float* host, int32_t rows, int32_t cols) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !name || !host) return fail(FDM_ERR_INVALID, "null argument");
   if (rows != e->G.s_rows || cols != e->G.s_cols) return fail(FDM_ERR_INVALID, "shape mismatch");
   if (int rc = resolve_pending(e)) return rc;
@@ -1244,11 +1360,12 @@ int fdm_engine_layer_download(fdm_engine* e, const char* name, float* host, int3
     src = e->d_tmp;
   }
   HIPCK(hipMemcpyAsync(host, src, e->ncell * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   return FDM_OK;
 }
 
 int fdm_engine_layer_upload(fdm_engine* e, const char* name, const float* host, int32_t rows, int32_t cols) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !name || !host) return fail(FDM_ERR_INVALID, "null argument");
   if (rows != e->G.s_rows || cols != e->G.s_cols) return fail(FDM_ERR_INVALID, "shape mismatch");
   HIPCK(hipSetDevice(e->device));
@@ -1266,17 +1383,19 @@ int fdm_engine_layer_upload(fdm_engine* e, const char* name, const float* host, 
   } else {
     HIPCK(hipMemcpyAsync(l->d, host, e->ncell * sizeof(float), hipMemcpyHostToDevice, e->stream));
   }
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   return FDM_OK;
 }
 
 float* fdm_engine_layer_device_ptr(fdm_engine* e, const char* name) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return nullptr; } }
   if (!e || !name) return nullptr;
   Layer* l = find_layer(e, name);
   return (l && l->field < 0) ? l->d : nullptr;  // record fields have no contiguous array
 }
 
 int fdm_engine_clear(fdm_engine* e, const char* name) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
   HIPCK(hipSetDevice(e->device));
   if (name) {
@@ -1307,14 +1426,17 @@ static int region_copy(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, int32_
 
 int fdm_engine_region_pack(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, int32_t nc,
                            const char* const* names, int n_layers, float* d_buf) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   return region_copy(e, r0, c0, nr, nc, names, n_layers, d_buf, 1);
 }
 int fdm_engine_region_unpack(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, int32_t nc,
                              const char* const* names, int n_layers, const float* d_buf) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   return region_copy(e, r0, c0, nr, nc, names, n_layers, const_cast<float*>(d_buf), 0);
 }
 
 int fdm_engine_capture(fdm_engine* e, int preprocessed, int rasterized) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
   e->cap_pre = preprocessed != 0;
   e->cap_ras = rasterized != 0;
@@ -1324,12 +1446,13 @@ int fdm_engine_capture(fdm_engine* e, int preprocessed, int rasterized) {
 
 int fdm_engine_last_preprocessed(fdm_engine* e, uint64_t cap, float* x, float* y, float* z,
                                  float* sigma_z2, uint64_t* n_out) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !n_out) return fail(FDM_ERR_INVALID, "null argument");
   *n_out = 0;
   if (!e->cap_pre) return fail(FDM_ERR_INVALID, "preprocessed-scan capture is off");
   const size_t n = e->last_n;
   if (!e->have_scan || n == 0 || !e->d_cap || !e->d_cell_ids) return FDM_OK;
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   std::vector<float> h(4 * n);
   std::vector<int32_t> ids(n);
   for (int c = 0; c < 4; ++c)
@@ -1352,11 +1475,12 @@ int fdm_engine_last_preprocessed(fdm_engine* e, uint64_t cap, float* x, float* y
 
 int fdm_engine_last_rasterized(fdm_engine* e, uint64_t cap, float* x, float* y, float* z,
                                uint64_t* n_out) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !n_out) return fail(FDM_ERR_INVALID, "null argument");
   *n_out = 0;
   if (!e->cap_ras) return fail(FDM_ERR_INVALID, "rasterized-scan capture is off");
   if (!e->have_scan || !e->d_ras) return FDM_OK;
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   std::vector<float> h(e->ncell);
   HIPCK(hipMemcpy(h.data(), e->d_ras, e->ncell * sizeof(float), hipMemcpyDeviceToHost));
   fdm_geometry g;
@@ -1383,21 +1507,24 @@ int fdm_engine_last_rasterized(fdm_engine* e, uint64_t cap, float* x, float* y, 
 }
 
 int fdm_engine_enable_cell_ids(fdm_engine* e, int on) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
   e->want_ids = on != 0;
   return FDM_OK;
 }
 
 int fdm_engine_last_cell_ids(fdm_engine* e, int32_t* host_out, uint64_t n) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !host_out) return fail(FDM_ERR_INVALID, "null argument");
   if (!e->want_ids || !e->d_cell_ids || n != e->last_n)
     return fail(FDM_ERR_INVALID, "cell ids not recorded for the last scan");
   HIPCK(hipMemcpyAsync(host_out, e->d_cell_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   return FDM_OK;
 }
 
 int fdm_engine_enable_profile(fdm_engine* e, int on) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
   e->profile = on != 0;
   return FDM_OK;
@@ -1413,7 +1540,7 @@ int upload_region(fdm_engine* e, const std::vector<RegionEntry>& reg) {
   if (reg.size() > size_t(kMaxRegion)) return fail(FDM_ERR_INVALID, "neighbourhood larger than 256 cells");
   if (!e->d_region) HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_region), kMaxRegion * sizeof(RegionEntry)));
   HIPCK(hipMemcpyAsync(e->d_region, reg.data(), reg.size() * sizeof(RegionEntry), hipMemcpyHostToDevice, e->stream));
-  HIPCK(hipStreamSynchronize(e->stream));  // `reg` is a host temporary
+  if (int rc_sync = sync_all(e)) return rc_sync;  // `reg` is a host temporary
   return FDM_OK;
 }
 void region_disc(const fdm_engine* e, float radius, std::vector<RegionEntry>& reg) {
@@ -1435,6 +1562,7 @@ int ensure_tmp2(fdm_engine* e) {
 }  // namespace
 
 int fdm_engine_apply_inpainting(fdm_engine* e, int max_iterations, int min_valid, int inplace) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
   if (is_tiled(e)) return fail(FDM_ERR_INVALID, "post-processing needs a whole-map engine");
   HIPCK(hipSetDevice(e->device));
@@ -1472,6 +1600,7 @@ int fdm_engine_apply_inpainting(fdm_engine* e, int max_iterations, int min_valid
 }
 
 int fdm_engine_apply_spatial_smoothing(fdm_engine* e, const char* layer, int kernel_size, int min_valid) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !layer) return fail(FDM_ERR_INVALID, "null argument");
   if (is_tiled(e)) return fail(FDM_ERR_INVALID, "post-processing needs a whole-map engine");
   if (kernel_size < 1 || kernel_size > 15 || (kernel_size & 1) == 0)
@@ -1492,6 +1621,7 @@ int fdm_engine_apply_spatial_smoothing(fdm_engine* e, const char* layer, int ker
 }
 
 int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* cfg) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !cfg) return fail(FDM_ERR_INVALID, "null argument");
   if (!cfg->enabled) return FDM_OK;
   if (is_tiled(e)) return fail(FDM_ERR_INVALID, "post-processing needs a whole-map engine");
@@ -1540,6 +1670,7 @@ int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* 
 }
 
 int fdm_engine_apply_feature_extraction(fdm_engine* e, float radius, int min_valid, float lo_pct, float hi_pct) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
   if (is_tiled(e)) return fail(FDM_ERR_INVALID, "post-processing needs a whole-map engine");
   HIPCK(hipSetDevice(e->device));
@@ -1581,6 +1712,7 @@ int fdm_engine_apply_feature_extraction(fdm_engine* e, float radius, int min_val
 // ---- ingest ----
 int fdm_engine_ingest_cloud2(fdm_engine* e, const void* data, int on_device, uint64_t n_points,
                              const fdm_cloud2_layout* lay, uint64_t* n_valid) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !lay) return fail(FDM_ERR_INVALID, "null argument");
   if (n_valid) *n_valid = 0;
   e->in_n = 0;
@@ -1600,7 +1732,7 @@ int fdm_engine_ingest_cloud2(fdm_engine* e, const void* data, int on_device, uin
   const uint8_t* blob = static_cast<const uint8_t*>(data);
   if (!on_device) {
     if (bytes > e->blob_cap) {
-      HIPCK(hipStreamSynchronize(e->stream));
+      if (int rc_sync = sync_all(e)) return rc_sync;
       if (e->d_blob) HIPCK(hipFree(e->d_blob));
       e->blob_cap = bytes + bytes / 4 + 4096;
       HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_blob), e->blob_cap));
@@ -1609,7 +1741,7 @@ int fdm_engine_ingest_cloud2(fdm_engine* e, const void* data, int on_device, uin
     blob = e->d_blob;
   }
   if (n_points > e->in_cap) {
-    HIPCK(hipStreamSynchronize(e->stream));
+    if (int rc_sync = sync_all(e)) return rc_sync;
     if (e->d_in) HIPCK(hipFree(e->d_in));
     e->in_cap = ((n_points + n_points / 4 + 1024) + 3) & ~size_t(3);  // channels stay 16-byte aligned
     HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_in), e->in_cap * 5 * sizeof(float)));
@@ -1624,7 +1756,7 @@ int fdm_engine_ingest_cloud2(fdm_engine* e, const void* data, int on_device, uin
               al4(L.off_z) && al4(L.off_rgb) && (L.intensity_type < 7 || al4(L.off_intensity));
   const unsigned blocks = unsigned((n_points + 255) / 256);
   if (size_t(blocks) + 1 > e->pack_counts_cap) {
-    HIPCK(hipStreamSynchronize(e->stream));
+    if (int rc_sync = sync_all(e)) return rc_sync;
     if (e->pack_counts) HIPCK(hipFree(e->pack_counts));
     e->pack_counts_cap = size_t(blocks) + 1 + 1024;
     HIPCK(hipMalloc(reinterpret_cast<void**>(&e->pack_counts), e->pack_counts_cap * sizeof(uint32_t)));
@@ -1639,7 +1771,7 @@ int fdm_engine_ingest_cloud2(fdm_engine* e, const void* data, int on_device, uin
   HIPCK(hipGetLastError());
   uint32_t total = 0;
   HIPCK(hipMemcpyAsync(&total, e->pack_counts + blocks, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   e->in_n = total;
   e->in_has_int = hi;
   e->in_has_rgb = hc;
@@ -1662,6 +1794,7 @@ int fdm_engine_ingested(fdm_engine* e, const float** dx, const float** dy, const
 int fdm_engine_integrate_cloud2(fdm_engine* e, const void* data, int on_device, uint64_t n_points,
                                 const fdm_cloud2_layout* lay, const double Tbs[16], const double Twb[16],
                                 fdm_scan_stats* out) {
+  if (e) { if (int rc_join = join_streams(e)) return rc_join; }
   if (!e || !lay || !Tbs || !Twb) return fail(FDM_ERR_INVALID, "null argument");
   uint64_t n = 0;
   int rc = fdm_engine_ingest_cloud2(e, data, on_device, n_points, lay, &n);
@@ -1732,7 +1865,7 @@ int pack_count(fdm_engine* e, const PackPlan& pl, uint64_t* n_points) {
   *n_points = 0;
   if (pl.total == 0) return FDM_OK;
   if (size_t(pl.blocks) + 1 > e->pack_counts_cap) {
-    HIPCK(hipStreamSynchronize(e->stream));
+    if (int rc_sync = sync_all(e)) return rc_sync;
     if (e->pack_counts) HIPCK(hipFree(e->pack_counts));
     e->pack_counts_cap = size_t(pl.blocks) + 1 + 1024;
     HIPCK(hipMalloc(reinterpret_cast<void**>(&e->pack_counts), e->pack_counts_cap * sizeof(uint32_t)));
@@ -1743,7 +1876,7 @@ int pack_count(fdm_engine* e, const PackPlan& pl, uint64_t* n_points) {
   HIPCK(hipGetLastError());
   uint32_t total = 0;
   HIPCK(hipMemcpyAsync(&total, e->pack_counts + pl.blocks, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   *n_points = total;
   return FDM_OK;
 }
@@ -1774,6 +1907,7 @@ void write_fields(const PackPlan& pl, char* buf, uint64_t cap) {
 int fdm_engine_pack_cloud_device(fdm_engine* e, const char* elevation_layer, int32_t r0, int32_t c0,
                                  int32_t nr, int32_t nc, void** d_out, uint64_t* n_points,
                                  uint32_t* point_step) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !elevation_layer || !n_points) return fail(FDM_ERR_INVALID, "null argument");
   HIPCK(hipSetDevice(e->device));
   PackPlan pl;
@@ -1789,6 +1923,7 @@ int fdm_engine_pack_cloud_device(fdm_engine* e, const char* elevation_layer, int
 int fdm_engine_pack_cloud(fdm_engine* e, const char* elevation_layer, int32_t r0, int32_t c0, int32_t nr,
                           int32_t nc, void* host_out, uint64_t cap_bytes, uint64_t* n_points,
                           uint32_t* point_step, char* fields_buf, uint64_t fields_cap) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !elevation_layer || !n_points) return fail(FDM_ERR_INVALID, "null argument");
   HIPCK(hipSetDevice(e->device));
   PackPlan pl;
@@ -1801,7 +1936,7 @@ int fdm_engine_pack_cloud(fdm_engine* e, const char* elevation_layer, int32_t r0
   if (!host_out || cap_bytes < bytes || bytes == 0) return FDM_OK;
   if ((rc = pack_write(e, pl, *n_points))) return rc;
   HIPCK(hipMemcpyAsync(host_out, e->d_pack, bytes, hipMemcpyDeviceToHost, e->stream));
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   return FDM_OK;
 }
 
@@ -1809,6 +1944,7 @@ int fdm_engine_pack_cloud(fdm_engine* e, const char* elevation_layer, int32_t r0
 int fdm_engine_apply_raycasting_device(fdm_engine* e, uint64_t n, const float* dx, const float* dy,
                                        const float* dz, const float origin[3],
                                        const fdm_raycast_config* rcfg) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !origin) return fail(FDM_ERR_INVALID, "null argument");
   const fdm_raycast_config c = rcfg ? *rcfg : ray_config_of(e->cfg);
   if (!c.enabled || n == 0) return FDM_OK;  // raycasting.cpp:207-209
@@ -1825,6 +1961,7 @@ int fdm_engine_apply_raycasting_device(fdm_engine* e, uint64_t n, const float* d
 
 int fdm_engine_apply_raycasting(fdm_engine* e, uint64_t n, const float* x, const float* y,
                                 const float* z, const float origin[3], const fdm_raycast_config* rcfg) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !origin) return fail(FDM_ERR_INVALID, "null argument");
   if (!(rcfg ? rcfg->enabled : e->cfg.raycast_enabled) || n == 0) return FDM_OK;
   if (!x || !y || !z) return fail(FDM_ERR_INVALID, "null xyz");
@@ -1834,12 +1971,13 @@ int fdm_engine_apply_raycasting(fdm_engine* e, uint64_t n, const float* x, const
   int rc = stage_inputs(e, n, x, y, z, nullptr, nullptr, nullptr, &dx, &dy, &dz, &da, &dc, &dv);
   if (rc) return rc;
   if ((rc = fdm_engine_apply_raycasting_device(e, n, dx, dy, dz, origin, rcfg))) return rc;
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   return FDM_OK;
 }
 
 int fdm_engine_voxel_any(fdm_engine* e, uint64_t n, const float* x, const float* y, const float* z,
                          float voxel_size, uint32_t* out_idx, uint64_t* n_out) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !n_out) return fail(FDM_ERR_INVALID, "null argument");
   *n_out = 0;
   if (!voxel_size_ok(voxel_size)) return fail(FDM_ERR_INVALID, "voxel_size must be in [0.001, 100]");
@@ -1857,7 +1995,7 @@ int fdm_engine_voxel_any(fdm_engine* e, uint64_t n, const float* x, const float*
   HIPCK(hipGetLastError());
   std::vector<uint32_t> h(n);
   HIPCK(hipMemcpyAsync(h.data(), e->vsel, n * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   uint64_t w = 0;
   for (uint64_t i = 0; i < n; ++i)  // order-preserving compaction = marshalling
     if (h[i] != kNoIdx) out_idx[w++] = h[i];
@@ -1866,19 +2004,21 @@ int fdm_engine_voxel_any(fdm_engine* e, uint64_t n, const float* x, const float*
 }
 
 int fdm_engine_last_ray_ms(fdm_engine* e, float* ms) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !ms) return fail(FDM_ERR_INVALID, "null argument");
   if (!e->profile) return fail(FDM_ERR_INVALID, "profiling is off");
   *ms = 0.f;
   if (!e->ray_timed) return FDM_OK;
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   HIPCK(hipEventElapsedTime(ms, e->ev_ray[0], e->ev_ray[1]));
   return FDM_OK;
 }
 
 int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !ms2) return fail(FDM_ERR_INVALID, "null argument");
   if (!e->profile) return fail(FDM_ERR_INVALID, "profiling is off");
-  HIPCK(hipStreamSynchronize(e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
   // an event pair around ONE short kernel also times the gap to the next command; the empty
   // pair (ev2 -> ev3) measures that gap and is subtracted, so the figures agree with rocprofv3
   float raw0 = 0.f, raw1 = 0.f, gap = 0.f;
@@ -1892,9 +2032,14 @@ int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2) {
 
 /* tuning knob used by bench.py's A/B runs (not part of the reference surface) */
 int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !key) return fail(FDM_ERR_INVALID, "null argument");
   if (std::strcmp(key, "wave_merge") == 0) {
     e->wave_merge = value != 0;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "overlap") == 0) {
+    e->overlap = value != 0;
     return FDM_OK;
   }
   if (std::strcmp(key, "dbg_ray") == 0) {

@@ -150,9 +150,21 @@ __device__ __forceinline__ void scratch_merge(const Scratch& S, unsigned scan_no
 }
 
 __device__ __forceinline__ DevCand block_candidate(const ScanParams& P, const GeomConst& G,
-                                                   DevState* __restrict__ st, DevCand* s_cand) {
+                                                   DevState* __restrict__ st, DevCand* s_cand,
+                                                   unsigned bid) {
   if (threadIdx.x == 0) {
-    const DevGeom g = st->geom[P.slot];
+    DevGeom g;
+    if (P.chain_prev) {  // what k_update of the previous scan commits to geom[P.slot] (make_ctx)
+      const int ps = (P.slot + 3) & 3;
+      g = st->geom[ps];
+      const bool applied = P.prev_do_move && (!P.prev_gate || st->flags[ps].any_pass != 0u);
+      if (applied) {
+        const DevCand pc = st->cand[ps];
+        g.px = pc.px; g.py = pc.py; g.sr = pc.sr; g.sc = pc.sc;
+      }
+    } else {
+      g = st->geom[P.slot];
+    }
     DevCand c;
     if (P.do_move) {
       c = move_candidate(g, G, P.robot_x, P.robot_y);
@@ -160,7 +172,7 @@ __device__ __forceinline__ DevCand block_candidate(const ScanParams& P, const Ge
       c.px = g.px; c.py = g.py; c.sr = g.sr; c.sc = g.sc; c.shr = 0; c.shc = 0;
     }
     *s_cand = c;
-    if (blockIdx.x == 0) st->cand[P.slot] = c;
+    if (bid == 0) st->cand[P.slot] = c;
   }
   __syncthreads();
   return *s_cand;
@@ -222,7 +234,7 @@ __global__ __launch_bounds__(THREADS) void k_bin4(const ScanParams P, const Geom
     if (HAS_INT) { h_imax[k] = 0u; h_first[k] = kNoIdx; }
     if (HAS_COL) h_last[k] = 0u;
   }
-  const DevCand cand = block_candidate(P, G, st, &s_cand);  // contains the __syncthreads
+  const DevCand cand = block_candidate(P, G, st, &s_cand, blockIdx.x);  // contains the __syncthreads
 
   // phase 1: all four points through the arithmetic (independent chains -> ILP)
   int cells[4];
@@ -331,18 +343,16 @@ __global__ __launch_bounds__(THREADS) void k_bin4(const ScanParams P, const Geom
 // unaligned channel pointers).  Same-cell runs of neighbouring lanes are merged inside the
 // wavefront with a segmented scan; run tails go to the scratch.
 template <bool WAVE_MERGE>
-__global__ __launch_bounds__(256) void k_bin(const ScanParams P, const GeomConst G,
-                                             DevState* __restrict__ st,
-                                             const float* __restrict__ px,
-                                             const float* __restrict__ py,
-                                             const float* __restrict__ pz,
-                                             const float* __restrict__ pint, const Scratch S,
-                                             int32_t* __restrict__ cell_ids) {
+__device__ __forceinline__ void bin_body(const ScanParams& P, const GeomConst& G,
+                                         DevState* __restrict__ st, const float* __restrict__ px,
+                                         const float* __restrict__ py, const float* __restrict__ pz,
+                                         const float* __restrict__ pint, const Scratch& S,
+                                         int32_t* __restrict__ cell_ids, const unsigned bid) {
   __shared__ DevCand s_cand;
   __shared__ unsigned s_pass[4], s_in[4];
   // the point (and intensity) loads go out first: they are in flight while thread 0 reads the
   // geometry and works out the post-move candidate
-  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  const unsigned i = bid * 256u + threadIdx.x;
   float x = 0.f, y = 0.f, z = 0.0f, vint = 0.f;
   if (i < P.n) {
     x = px[i];
@@ -350,7 +360,7 @@ __global__ __launch_bounds__(256) void k_bin(const ScanParams P, const GeomConst
     z = pz[i];
     if (P.has_intensity) vint = pint[i];
   }
-  const DevCand cand = block_candidate(P, G, st, &s_cand);
+  const DevCand cand = block_candidate(P, G, st, &s_cand, bid);
 
   bool pass = false;
   int cell = -1;
@@ -427,8 +437,19 @@ __global__ __launch_bounds__(256) void k_bin(const ScanParams P, const GeomConst
     const unsigned np = s_pass[0] + s_pass[1] + s_pass[2] + s_pass[3];
     const unsigned ni = s_in[0] + s_in[1] + s_in[2] + s_in[3];
     if (np) st->flags[P.slot].any_pass = 1u;
-    S.bin_part[blockIdx.x] = (unsigned long long)np | ((unsigned long long)ni << 32);
+    S.bin_part[bid] = (unsigned long long)np | ((unsigned long long)ni << 32);
   }
+}
+
+template <bool WAVE_MERGE>
+__global__ __launch_bounds__(256) void k_bin(const ScanParams P, const GeomConst G,
+                                             DevState* __restrict__ st,
+                                             const float* __restrict__ px,
+                                             const float* __restrict__ py,
+                                             const float* __restrict__ pz,
+                                             const float* __restrict__ pint, const Scratch S,
+                                             int32_t* __restrict__ cell_ids) {
+  bin_body<WAVE_MERGE>(P, G, st, px, py, pz, pint, S, cell_ids, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -453,7 +474,7 @@ struct UpdateCtx {
 };
 
 __device__ __forceinline__ void make_ctx(const ScanParams& P, DevState* __restrict__ st,
-                                         const Scratch& S, UpdateCtx& u) {
+                                         const Scratch& S, UpdateCtx& u, unsigned bid) {
   const int slot = P.slot;
   const bool any_pass = st->flags[slot].any_pass != 0u;
   u.do_update = st->flags[slot].any_inside != 0u;
@@ -461,7 +482,7 @@ __device__ __forceinline__ void make_ctx(const ScanParams& P, DevState* __restri
   const unsigned ob_scan = st->obst[slot].scan;
   u.E = st->geom[slot];
   u.C = st->cand[slot];
-  if (blockIdx.x == 0 && threadIdx.x == 0) {  // commit geometry + ring bookkeeping
+  if (bid == 0 && threadIdx.x == 0) {  // commit geometry + ring bookkeeping
     const int nxt = (slot + 1) & 3, nn = (slot + 2) & 3;
     DevGeom g = u.E;
     if (u.applied) { g.px = u.C.px; g.py = u.C.py; g.sr = u.C.sr; g.sc = u.C.sc; }
@@ -479,7 +500,7 @@ __device__ __forceinline__ void make_ctx(const ScanParams& P, DevState* __restri
     u.cur = u.do_update;
     u.obst_tile = u.do_update;
   } else {
-    const unsigned stamp = S.tile_stamp[blockIdx.x];
+    const unsigned stamp = S.tile_stamp[bid];
     u.cur = u.do_update && stamp == P.scan_no;
     u.obst_tile = u.do_update && (u.cur || stamp == ob_scan);
   }
@@ -630,22 +651,22 @@ struct P2RecPolicy {  // cell records
 };
 
 template <typename POLICY>
-__global__ __launch_bounds__(256) void k_update(
-    const ScanParams P, const GeomConst G, DevState* __restrict__ st,
-    const typename POLICY::Layers L, float* const* __restrict__ all_layers, int n_layers,
-    const Scratch S, const float* __restrict__ px, const float* __restrict__ py,
-    const float* __restrict__ pz, const float* __restrict__ /*pint: folded into aux by k_bin*/,
-    const uint32_t* __restrict__ prgb, const float* __restrict__ pvar, unsigned ncell) {
+__device__ __forceinline__ void update_body(
+    const ScanParams& P, const GeomConst& G, DevState* __restrict__ st,
+    const typename POLICY::Layers& L, float* const* __restrict__ all_layers, int n_layers,
+    const Scratch& S, const float* __restrict__ px, const float* __restrict__ py,
+    const float* __restrict__ pz, const uint32_t* __restrict__ prgb, const float* __restrict__ pvar,
+    unsigned ncell, const unsigned bid) {
   const float nanv = __uint_as_float(0x7FC00000u);
   __shared__ unsigned s_t[4];
-  const unsigned o = blockIdx.x * 256u + threadIdx.x;
+  const unsigned o = bid * 256u + threadIdx.x;
   const bool valid = o < ncell;
 
   // ---- round 1: the cell's key (dense mode: independent of the context) + the scan context ----
   unsigned long long key = kEmptyKey;
   if (S.dense && valid) key = S.key[o];
   UpdateCtx u;
-  make_ctx(P, st, S, u);
+  make_ctx(P, st, S, u, bid);
   bool touched = false;
   if (valid && (u.cur || u.obst_tile || u.strips) && P.dbg_upd != 1) {
     if (!S.dense && u.cur) key = S.key[o];
@@ -723,7 +744,40 @@ __global__ __launch_bounds__(256) void k_update(
   const unsigned long long m = __ballot(touched);
   if ((threadIdx.x & 63) == 0) s_t[threadIdx.x >> 6] = unsigned(__popcll(m));
   __syncthreads();
-  if (threadIdx.x == 0) S.upd_part[blockIdx.x] = s_t[0] + s_t[1] + s_t[2] + s_t[3];
+  if (threadIdx.x == 0) S.upd_part[bid] = s_t[0] + s_t[1] + s_t[2] + s_t[3];
+}
+
+template <typename POLICY>
+__global__ __launch_bounds__(256) void k_update(
+    const ScanParams P, const GeomConst G, DevState* __restrict__ st,
+    const typename POLICY::Layers L, float* const* __restrict__ all_layers, int n_layers,
+    const Scratch S, const float* __restrict__ px, const float* __restrict__ py,
+    const float* __restrict__ pz, const float* __restrict__ /*pint: folded into aux by k_bin*/,
+    const uint32_t* __restrict__ prgb, const float* __restrict__ pvar, unsigned ncell) {
+  update_body<POLICY>(P, G, st, L, all_layers, n_layers, S, px, py, pz, prgb, pvar, ncell, blockIdx.x);
+}
+
+// One launch for two scans: blocks [0, upd_blocks) finish scan t (its update), the rest start scan
+// t+1 (its bin).  The two halves share nothing — the scratch is double-buffered by scan parity and
+// the chained bin derives its base geometry from slot t (ScanParams::chain_prev) — so a stream of
+// small scans costs one launch and max(bin, update) per scan instead of two launches and their sum.
+struct ScanInputs {
+  const float *x, *y, *z, *intensity;
+  const uint32_t* rgb;
+  const float* var;
+};
+template <typename POLICY, bool WAVE_MERGE>
+__global__ __launch_bounds__(256) void k_update_bin(
+    const ScanParams Pu, const GeomConst G, DevState* __restrict__ st, const typename POLICY::Layers L,
+    float* const* __restrict__ all_layers, int n_layers, const Scratch Su, const ScanInputs Iu, unsigned ncell,
+    unsigned upd_blocks, const ScanParams Pb, const Scratch Sb, const ScanInputs Ib,
+    int32_t* __restrict__ cell_ids) {
+  if (blockIdx.x < upd_blocks) {
+    update_body<POLICY>(Pu, G, st, L, all_layers, n_layers, Su, Iu.x, Iu.y, Iu.z, Iu.rgb, Iu.var, ncell,
+                        blockIdx.x);
+  } else {
+    bin_body<WAVE_MERGE>(Pb, G, st, Ib.x, Ib.y, Ib.z, Ib.intensity, Sb, cell_ids, blockIdx.x - upd_blocks);
+  }
 }
 
 // The host wrote the obstacle layer (upload / add): the touched-cell lists no longer bound the

@@ -125,7 +125,14 @@ int fdm_engine_integrate(fdm_engine* e, uint64_t n, const float* x, const float*
 
 /* Same, inputs already resident in HBM; enqueue-only (no host sync).  The skip
  * decisions of fastdem.cpp:125-138 are taken on the device; read them back with
- * fdm_engine_last_stats(). */
+ * fdm_engine_last_stats().
+ * For small scans (one-point-per-thread bin kernel, map <= 4 M cells) the map update of the scan is
+ * HELD BACK and leaves in the same launch as the next scan's bin kernel (one launch per scan
+ * instead of two); every other entry point — fdm_engine_sync() included — first launches a held-back
+ * update, so the map is always current when it is read through this API.  A caller that reads
+ * layers through raw device pointers on its own stream must call fdm_engine_sync() (or any entry
+ * point) first; the input arrays must stay valid until then.  fdm_engine_set_option(e, "overlap", 0)
+ * turns the hold-back off. */
 int fdm_engine_integrate_device(fdm_engine* e, uint64_t n, const float* d_x, const float* d_y,
                                 const float* d_z, const float* d_intensity, const uint32_t* d_rgb,
                                 const float* d_sigma_z2, const double T_base_sensor[16],
@@ -302,6 +309,7 @@ int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2);
  *   "bin_variant" 0/1/4 : bin kernel by scan size (0), one point per thread (1), LDS-staged (4)
  *   "dense"       0/1   : update sweep visits every tile (1) or only stamped tiles (0)
  *   "records"     0/1   : estimator state packed into per-cell records (1) or one array per layer (0)
+ *   "overlap"     0/1   : hold the update of a small scan back and fuse it with the next scan's bin launch
  *   "dbg_*"             : measurement-only switches used by scripts/ab_kernels.py */
 int fdm_engine_set_option(fdm_engine* e, const char* key, int value);
 
