@@ -17,6 +17,7 @@
 #include <functional>
 #include <limits>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>  // stable (key, index) sort of the voxel filter
@@ -132,7 +133,10 @@ struct fdm_engine {
   bool overlap = true;          // option "overlap"
   bool chain = false;           // an update is held back: the next bin derives its geometry from the previous slot
   std::function<int()> upd_alone;   // launches the held-back update on its own
-  std::function<int(const ScanParams&, const Scratch&, const ScanInputs&, int32_t*, unsigned, bool)> upd_fused;
+  struct BinVariant { bool bin4, has_int, has_col, wave_merge; unsigned threads; };
+  std::function<int(const ScanParams&, const Scratch&, const ScanInputs&, int32_t*, unsigned, BinVariant)> upd_fused;
+  bool upd_fuses_bin4 = false;  // the held-back update can ride with a k_bin4 launch (record policies only)
+  unsigned upd_tiles = 0;
   int last_do_move = 0, last_gate = 0;
   // stencil post-processing (fdm_post.hpp)
   RegionEntry* d_region = nullptr;   // kMaxRegion entries
@@ -618,12 +622,24 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   P.dbg_no_atomics = e->dbg_no_atomics;
   P.dbg_upd = e->dbg_upd;
   // a held-back update leaves now: fused with this bin if this scan is a plain small one, alone otherwise
-  const bool fuse_now = e->chain && plain && !use_bin4 && e->upd_fused;
+  const bool bin4_fusable = use_bin4 && (bin_threads == 256 || bin_threads == 512) && e->upd_fuses_bin4;
+  const bool fuse_now = e->chain && plain && (!use_bin4 || bin4_fusable) && e->upd_fused;
   if (e->chain && !fuse_now && (rc = join_streams(e))) return rc;
   P.chain_prev = 0;
   if (e->profile) HIPCK(hipEventRecord(e->ev[0], e->stream));
   int32_t* ids = e->want_ids ? e->d_cell_ids : nullptr;
-  if (use_bin4) {
+  if (fuse_now) {  // the held-back update of the previous scan + this scan's bin, one launch
+    P.chain_prev = 1;
+    P.prev_do_move = e->last_do_move;
+    P.prev_gate = e->last_gate;
+    const ScanInputs in_b{dx, dy, dz, dint, drgb, dvar};
+    auto fused = std::move(e->upd_fused);
+    e->upd_fused = nullptr;
+    e->upd_alone = nullptr;
+    e->chain = false;
+    const fdm_engine::BinVariant bv{use_bin4, P.has_intensity != 0, P.has_color != 0, e->wave_merge, bin_threads};
+    if ((rc = fused(P, e->S, in_b, ids, bin_blocks, bv))) return rc;
+  } else if (use_bin4) {
     const bool hi = P.has_intensity != 0, hc = P.has_color != 0;
     auto launch4 = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(bin_blocks), dim3(bin_threads), 0, e->stream, P, e->G, e->d_state, dx,
@@ -638,16 +654,6 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     else if (bin_threads == 512) { FDM_BIN4(512) }
     else { FDM_BIN4(256) }
 #undef FDM_BIN4
-  } else if (fuse_now) {  // the held-back update of the previous scan + this scan's bin, one launch
-    P.chain_prev = 1;
-    P.prev_do_move = e->last_do_move;
-    P.prev_gate = e->last_gate;
-    const ScanInputs in_b{dx, dy, dz, dint, drgb, dvar};
-    auto fused = std::move(e->upd_fused);
-    e->upd_fused = nullptr;
-    e->upd_alone = nullptr;
-    e->chain = false;
-    if ((rc = fused(P, e->S, in_b, ids, bin_blocks, e->wave_merge))) return rc;
   } else {
     auto launch_bin = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(bin_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state, dx, dy,
@@ -675,7 +681,8 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     p2.marker = std::min(std::max(e->cfg.p2_elevation_marker, 0), 4);
     p2.max_count = std::max(e->cfg.p2_max_sample_count, 0.0f);
   }
-  const bool hold = plain && !use_bin4;  // the next scan's launch (or a flush) carries this update
+  // the next scan's launch (or a flush) carries this update
+  const bool hold = plain;
   const ScanInputs in_u{dx, dy, dz, dint, drgb, dvar};
   auto launch_upd = [&](auto policy_tag, const auto& layers) {
     using POLICY = decltype(policy_tag);
@@ -695,14 +702,29 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
       HIPCK(hipGetLastError());
       return FDM_OK;
     };
+    constexpr bool kRec = std::is_same<POLICY, KalmanRecPolicy>::value || std::is_same<POLICY, P2RecPolicy>::value;
+    e->upd_fuses_bin4 = kRec;
     e->upd_fused = [e, Pu, Su, Lu, in_u, upd_blocks](const ScanParams& Pb, const Scratch& Sb, const ScanInputs& Ib,
-                                                     int32_t* ids_b, unsigned bin_blocks_b, bool wave_merge) -> int {
-      auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(upd_blocks + bin_blocks_b), dim3(256), 0, e->stream, Pu, e->G, e->d_state,
-                           Lu, e->d_layer_ptrs, e->n_layer_ptrs, Su, in_u, unsigned(e->ncell), upd_blocks, Pb, Sb,
-                           Ib, ids_b);
+                                                     int32_t* ids_b, unsigned bin_blocks_b,
+                                                     fdm_engine::BinVariant bv) -> int {
+      auto go = [&](auto kern, unsigned threads) {
+        const unsigned ub = (upd_blocks + threads / 256u - 1u) / (threads / 256u);  // tiles per update block
+        hipLaunchKernelGGL(kern, dim3(ub + bin_blocks_b), dim3(threads), 0, e->stream, Pu, e->G, e->d_state, Lu,
+                           e->d_layer_ptrs, e->n_layer_ptrs, Su, in_u, unsigned(e->ncell), ub, Pb, Sb, Ib, ids_b);
       };
-      wave_merge ? go(k_update_bin<POLICY, true>) : go(k_update_bin<POLICY, false>);
+      if (!bv.bin4) {
+        bv.wave_merge ? go(k_update_bin<POLICY, true>, 256u) : go(k_update_bin<POLICY, false>, 256u);
+      } else if constexpr (kRec) {
+#define FDM_FUSED4(T)                                                              \
+        if (bv.has_int && bv.has_col) go(k_update_bin4<POLICY, true, true, T>, T);   \
+        else if (bv.has_int) go(k_update_bin4<POLICY, true, false, T>, T);           \
+        else if (bv.has_col) go(k_update_bin4<POLICY, false, true, T>, T);           \
+        else go(k_update_bin4<POLICY, false, false, T>, T);
+        if (bv.threads == 512u) { FDM_FUSED4(512) } else { FDM_FUSED4(256) }
+#undef FDM_FUSED4
+      } else {
+        return fail(FDM_ERR_INVALID, "internal: k_bin4 fused with a per-layer policy");
+      }
       HIPCK(hipGetLastError());
       return FDM_OK;
     };

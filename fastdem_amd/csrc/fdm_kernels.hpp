@@ -184,13 +184,11 @@ __device__ __forceinline__ DevCand block_candidate(const ScanParams& P, const Ge
 constexpr uint32_t kEmptyCell = 0xFFFFFFFFu;
 
 template <bool HAS_INT, bool HAS_COL, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_bin4(const ScanParams P, const GeomConst G,
-                                              DevState* __restrict__ st,
-                                              const float* __restrict__ px,
-                                              const float* __restrict__ py,
-                                              const float* __restrict__ pz,
-                                              const float* __restrict__ pint, const Scratch S,
-                                              int32_t* __restrict__ cell_ids) {
+__device__ __forceinline__ void bin4_body(const ScanParams& P, const GeomConst& G,
+                                          DevState* __restrict__ st, const float* __restrict__ px,
+                                          const float* __restrict__ py, const float* __restrict__ pz,
+                                          const float* __restrict__ pint, const Scratch& S,
+                                          int32_t* __restrict__ cell_ids, const unsigned bid) {
   constexpr int kHashSlots = THREADS * 4;  // == points per block: room for every point in its own cell
   __shared__ unsigned long long h_key[kHashSlots];
   __shared__ uint32_t h_cell[kHashSlots];
@@ -203,7 +201,7 @@ __global__ __launch_bounds__(THREADS) void k_bin4(const ScanParams P, const Geom
 
   // the point loads go out first: they are in flight while the table is initialised and
   // thread 0 works out the post-move geometry
-  const unsigned i0 = (blockIdx.x * unsigned(THREADS) + threadIdx.x) * 4u;
+  const unsigned i0 = (bid * unsigned(THREADS) + threadIdx.x) * 4u;
   float xs[4], ys[4], zs[4], vs[4];
   if (i0 + 3 < P.n) {
     const float4 a = *reinterpret_cast<const float4*>(px + i0);
@@ -234,7 +232,7 @@ __global__ __launch_bounds__(THREADS) void k_bin4(const ScanParams P, const Geom
     if (HAS_INT) { h_imax[k] = 0u; h_first[k] = kNoIdx; }
     if (HAS_COL) h_last[k] = 0u;
   }
-  const DevCand cand = block_candidate(P, G, st, &s_cand, blockIdx.x);  // contains the __syncthreads
+  const DevCand cand = block_candidate(P, G, st, &s_cand, bid);  // contains the __syncthreads
 
   // phase 1: all four points through the arithmetic (independent chains -> ILP)
   int cells[4];
@@ -334,8 +332,19 @@ __global__ __launch_bounds__(THREADS) void k_bin4(const ScanParams P, const Geom
     unsigned np = 0, ni = 0;
     for (int w = 0; w < THREADS / 64; ++w) { np += s_cnt[w] & 0xFFFFu; ni += s_cnt[w] >> 16; }
     if (np) st->flags[P.slot].any_pass = 1u;
-    S.bin_part[blockIdx.x] = (unsigned long long)np | ((unsigned long long)ni << 32);
+    S.bin_part[bid] = (unsigned long long)np | ((unsigned long long)ni << 32);
   }
+}
+
+template <bool HAS_INT, bool HAS_COL, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_bin4(const ScanParams P, const GeomConst G,
+                                              DevState* __restrict__ st,
+                                              const float* __restrict__ px,
+                                              const float* __restrict__ py,
+                                              const float* __restrict__ pz,
+                                              const float* __restrict__ pint, const Scratch S,
+                                              int32_t* __restrict__ cell_ids) {
+  bin4_body<HAS_INT, HAS_COL, THREADS>(P, G, st, px, py, pz, pint, S, cell_ids, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -474,7 +483,8 @@ struct UpdateCtx {
 };
 
 __device__ __forceinline__ void make_ctx(const ScanParams& P, DevState* __restrict__ st,
-                                         const Scratch& S, UpdateCtx& u, unsigned bid) {
+                                         const Scratch& S, UpdateCtx& u, unsigned tile, unsigned lt,
+                                         bool tile_ok) {
   const int slot = P.slot;
   const bool any_pass = st->flags[slot].any_pass != 0u;
   u.do_update = st->flags[slot].any_inside != 0u;
@@ -482,7 +492,7 @@ __device__ __forceinline__ void make_ctx(const ScanParams& P, DevState* __restri
   const unsigned ob_scan = st->obst[slot].scan;
   u.E = st->geom[slot];
   u.C = st->cand[slot];
-  if (bid == 0 && threadIdx.x == 0) {  // commit geometry + ring bookkeeping
+  if (tile == 0 && lt == 0) {  // commit geometry + ring bookkeeping
     const int nxt = (slot + 1) & 3, nn = (slot + 2) & 3;
     DevGeom g = u.E;
     if (u.applied) { g.px = u.C.px; g.py = u.C.py; g.sr = u.C.sr; g.sc = u.C.sc; }
@@ -500,7 +510,7 @@ __device__ __forceinline__ void make_ctx(const ScanParams& P, DevState* __restri
     u.cur = u.do_update;
     u.obst_tile = u.do_update;
   } else {
-    const unsigned stamp = S.tile_stamp[bid];
+    const unsigned stamp = tile_ok ? S.tile_stamp[tile] : 0xFFFFFFFEu;
     u.cur = u.do_update && stamp == P.scan_no;
     u.obst_tile = u.do_update && (u.cur || stamp == ob_scan);
   }
@@ -650,7 +660,9 @@ struct P2RecPolicy {  // cell records
   }
 };
 
-template <typename POLICY>
+// BLOCK = 256: one 256-cell tile per block; BLOCK = 512: two (so that the body fits into a launch of
+// 512-thread blocks next to the large-scan bin kernel).
+template <typename POLICY, int BLOCK = 256>
 __device__ __forceinline__ void update_body(
     const ScanParams& P, const GeomConst& G, DevState* __restrict__ st,
     const typename POLICY::Layers& L, float* const* __restrict__ all_layers, int n_layers,
@@ -658,15 +670,16 @@ __device__ __forceinline__ void update_body(
     const float* __restrict__ pz, const uint32_t* __restrict__ prgb, const float* __restrict__ pvar,
     unsigned ncell, const unsigned bid) {
   const float nanv = __uint_as_float(0x7FC00000u);
-  __shared__ unsigned s_t[4];
-  const unsigned o = bid * 256u + threadIdx.x;
+  __shared__ unsigned s_t[BLOCK / 64];
+  const unsigned tile = bid * unsigned(BLOCK / 256) + (threadIdx.x >> 8), lt = threadIdx.x & 255u;
+  const unsigned o = tile * 256u + lt;
   const bool valid = o < ncell;
 
   // ---- round 1: the cell's key (dense mode: independent of the context) + the scan context ----
   unsigned long long key = kEmptyKey;
   if (S.dense && valid) key = S.key[o];
   UpdateCtx u;
-  make_ctx(P, st, S, u, bid);
+  make_ctx(P, st, S, u, tile, lt, tile * 256u < ncell);
   bool touched = false;
   if (valid && (u.cur || u.obst_tile || u.strips) && P.dbg_upd != 1) {
     if (!S.dense && u.cur) key = S.key[o];
@@ -744,7 +757,10 @@ __device__ __forceinline__ void update_body(
   const unsigned long long m = __ballot(touched);
   if ((threadIdx.x & 63) == 0) s_t[threadIdx.x >> 6] = unsigned(__popcll(m));
   __syncthreads();
-  if (threadIdx.x == 0) S.upd_part[bid] = s_t[0] + s_t[1] + s_t[2] + s_t[3];
+  if (lt == 0 && tile * 256u < ncell) {
+    const unsigned* w = s_t + (threadIdx.x >> 8) * 4;
+    S.upd_part[tile] = w[0] + w[1] + w[2] + w[3];
+  }
 }
 
 template <typename POLICY>
@@ -766,6 +782,21 @@ struct ScanInputs {
   const uint32_t* rgb;
   const float* var;
 };
+template <typename POLICY, bool HAS_INT, bool HAS_COL, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_update_bin4(
+    const ScanParams Pu, const GeomConst G, DevState* __restrict__ st, const typename POLICY::Layers L,
+    float* const* __restrict__ all_layers, int n_layers, const Scratch Su, const ScanInputs Iu, unsigned ncell,
+    unsigned upd_blocks, const ScanParams Pb, const Scratch Sb, const ScanInputs Ib,
+    int32_t* __restrict__ cell_ids) {
+  if (blockIdx.x < upd_blocks) {
+    update_body<POLICY, THREADS>(Pu, G, st, L, all_layers, n_layers, Su, Iu.x, Iu.y, Iu.z, Iu.rgb, Iu.var, ncell,
+                                 blockIdx.x);
+  } else {
+    bin4_body<HAS_INT, HAS_COL, THREADS>(Pb, G, st, Ib.x, Ib.y, Ib.z, Ib.intensity, Sb, cell_ids,
+                                         blockIdx.x - upd_blocks);
+  }
+}
+
 template <typename POLICY, bool WAVE_MERGE>
 __global__ __launch_bounds__(256) void k_update_bin(
     const ScanParams Pu, const GeomConst G, DevState* __restrict__ st, const typename POLICY::Layers L,

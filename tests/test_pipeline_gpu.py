@@ -162,3 +162,35 @@ def test_destroy_with_a_held_back_update(gpu, R):
     d = dev(wl.scan(0))
     enqueue(eng, d, wl.T_base_sensor, wl.pose(0))
     eng.close()  # nothing read back: the held-back closure is dropped with the engine
+
+
+@pytest.mark.parametrize("n_az,scans", [(2048, 6), (16384, 3)])
+def test_chain_of_large_scans(gpu, R, n_az, scans):
+    """k_bin4 launches (256-thread blocks below 1 M points, 512-thread blocks above) carrying the
+    previous scan's update, with an 8-cell rolling shift per scan."""
+    wl = gpu.synth.lidar128(n_scans=scans, n_az=n_az)
+    eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
+    keep = []
+    for k in range(scans):
+        d = dev(wl.scan(k))
+        keep.append(d)
+        enqueue(eng, d, wl.T_base_sensor, wl.pose(k))
+        rc_r, st_r = ref_step(ref, wl.scan(k), wl.T_base_sensor, wl.pose(k))
+    rc, st = eng.last_stats()
+    assert rc == rc_r and st == st_r and st["shift_rows"] == -8
+    assert_layers_equal(eng, ref)
+    assert same_geometry(eng.geometry(), ref.geometry())
+
+
+def test_chain_rgbd_p2_colour_large(gpu, R):
+    """configs[2] through the chain: P2 cell records (128 B), colour channel, k_bin4<false,true,256>."""
+    wl = gpu.synth.rgbd(n_scans=5)
+    eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
+    keep = []
+    for k in range(5):
+        d = dev(wl.scan(k))
+        keep.append(d)
+        enqueue(eng, d, wl.T_base_sensor, wl.pose(k))
+        ref_step(ref, wl.scan(k), wl.T_base_sensor, wl.pose(k))
+    assert_layers_equal(eng, ref)
+    assert "color" in eng.layers()
