@@ -598,7 +598,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     e->S.key = e->key2[parity];
     e->S.aux = e->aux2[parity];
   }
-  const bool plain = e->overlap && e->key2[1] && e->S.dense && !e->profile && !ray_on && !e->cap_pre &&
+  const bool plain = e->overlap && e->key2[1] && e->S.dense && !ray_on && !e->cap_pre &&
                      !e->cap_ras && !e->obst_dense_pending;
 
   // k_bin4 (4 consecutive points per thread, float4 loads) needs 16-byte aligned channels
@@ -2037,10 +2037,9 @@ int fdm_engine_last_ray_ms(fdm_engine* e, float* ms) {
 }
 
 int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !ms2) return fail(FDM_ERR_INVALID, "null argument");
   if (!e->profile) return fail(FDM_ERR_INVALID, "profiling is off");
-  if (int rc_sync = sync_all(e)) return rc_sync;
+  HIPCK(hipEventSynchronize(e->ev[3]));  // no flush: a held-back update stays held (the chain is what is timed)
   // an event pair around ONE short kernel also times the gap to the next command; the empty
   // pair (ev2 -> ev3) measures that gap and is subtracted, so the figures agree with rocprofv3
   float raw0 = 0.f, raw1 = 0.f, gap = 0.f;
@@ -2048,7 +2047,7 @@ int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2) {
   HIPCK(hipEventElapsedTime(&raw1, e->ev[1], e->ev[2]));
   HIPCK(hipEventElapsedTime(&gap, e->ev[2], e->ev[3]));
   ms2[0] = raw0 > gap ? raw0 - gap : raw0;
-  ms2[1] = raw1 > gap ? raw1 - gap : raw1;
+  ms2[1] = e->chain ? 0.0f : (raw1 > gap ? raw1 - gap : raw1);  // held back: it rides with the next launch
   return FDM_OK;
 }
 

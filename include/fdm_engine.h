@@ -301,7 +301,9 @@ int fdm_engine_enable_cell_ids(fdm_engine* e, int on);
 /* per input point of the last scan: linear cell id (col*rows+row), -1 cropped, -2 outside map */
 int fdm_engine_last_cell_ids(fdm_engine* e, int32_t* host_out, uint64_t n);
 int fdm_engine_enable_profile(fdm_engine* e, int on);
-/* HIP-event durations of the last scan's kernels: ms[0] = bin kernel, ms[1] = update kernel */
+/* HIP-event durations of the last scan's launches: ms[0] = bin kernel, ms[1] = update kernel.
+ * When the update was held back (see fdm_engine_integrate_device) ms[0] is the fused launch
+ * (previous scan's update + this scan's bin) and ms[1] ~ 0. */
 int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2);
 
 /* Tuning knobs for A/B measurements (bench.py); unknown keys are an error.

@@ -12,10 +12,12 @@ for w in ("c2", "c4"):
     for f in sorted(glob.glob(os.path.join(rd, f"pmc_{w}", "p*", "p_counter_collection.csv"))):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
-            k = "k_bin" if "k_bin" in name else ("k_update" if "k_update" in name else None)
+            k = "k_update_bin" if "k_update_bin" in name else ("k_bin" if "k_bin" in name else ("k_update" if "k_update" in name else None))
             if k:
                 acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k in ("k_bin", "k_update"):
+    for k in ("k_update_bin", "k_bin", "k_update"):
+        if not acc[k]:
+            continue
         t = traffic.get(w, {}).get(k, {})
         lines.append(f"[{w}] {k}: launches={t.get('launches', '?')} hbm_bytes/launch={t.get('hbm_bytes_per_launch', 0):.0f} "
                      f"(read {t.get('read_bytes_per_launch', 0):.0f}, write {t.get('write_bytes_per_launch', 0):.0f})")

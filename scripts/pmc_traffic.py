@@ -10,8 +10,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/p*/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
-        if "fdm::k_bin" in name:
-            k = "k_bin"
+XX
         elif "fdm::k_update" in name:
             k = "k_update"
         else:
