@@ -123,6 +123,8 @@ PROTOTYPES = {
                                     C.c_double, C.POINTER(FdmScanStats)]),
     "fdm_engine_update_device": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, C.c_double,
                                            C.c_double]),
+    "fdm_engine_flush": (C.c_int, [_P]),
+    "fdm_engine_stream": (_P, [_P]),
     "fdm_engine_sync": (C.c_int, [_P]),
     "fdm_engine_last_stats": (C.c_int, [_P, C.POINTER(FdmScanStats)]),
     "fdm_engine_move": (C.c_int, [_P, C.c_double, C.c_double]),

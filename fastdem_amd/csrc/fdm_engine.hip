@@ -1259,6 +1259,13 @@ int fdm_engine_update(fdm_engine* e, uint64_t n, const float* x, const float* y,
   return FDM_OK;
 }
 
+int fdm_engine_flush(fdm_engine* e) {
+  if (!e) return fail(FDM_ERR_INVALID, "null engine");
+  return join_streams(e);
+}
+
+void* fdm_engine_stream(fdm_engine* e) { return e ? static_cast<void*>(e->stream) : nullptr; }
+
 int fdm_engine_sync(fdm_engine* e) {
   if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e) return fail(FDM_ERR_INVALID, "null engine");

@@ -140,6 +140,14 @@ class Engine:
                                         C.byref(st)))
         return st.as_dict()
 
+    def flush(self):
+        """Launch a held-back map update (no wait)."""
+        _ck(self._lib.fdm_engine_flush(self._h))
+
+    def stream(self):
+        """hipStream_t of the engine as an int."""
+        return self._lib.fdm_engine_stream(self._h)
+
     def sync(self):
         _ck(self._lib.fdm_engine_sync(self._h))
 

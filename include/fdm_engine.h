@@ -148,6 +148,11 @@ int fdm_engine_update_device(fdm_engine* e, uint64_t n, const float* d_x, const 
                              const float* d_z, const float* d_z_var, const float* d_intensity,
                              const uint32_t* d_rgb, double robot_x, double robot_y);
 
+/* Launch a held-back map update now, without waiting for it (see fdm_engine_integrate_device). */
+int fdm_engine_flush(fdm_engine* e);
+/* The HIP stream (hipStream_t) the engine launches on: for callers that bracket engine work with
+ * their own HIP events or order their own kernels after it. */
+void* fdm_engine_stream(fdm_engine* e);
 int fdm_engine_sync(fdm_engine* e);
 /* Waits for the stream, returns the status (0/1/2) and stats of the last enqueued scan. */
 int fdm_engine_last_stats(fdm_engine* e, fdm_scan_stats* out);

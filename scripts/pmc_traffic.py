@@ -10,7 +10,10 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/p*/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
-XX
+        if "fdm::k_update_bin" in name:
+            k = "k_update_bin"  # one launch: update of scan t + bin of scan t+1
+        elif "fdm::k_bin" in name:
+            k = "k_bin"
         elif "fdm::k_update" in name:
             k = "k_update"
         else:
