@@ -687,6 +687,12 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   auto launch_upd = [&](auto policy_tag, const auto& layers) {
     using POLICY = decltype(policy_tag);
     if (!hold) {
+      if (!e->S.dense) {  // stamp-gated: 16 tiles per block, idle tiles cost one scalar load
+        hipLaunchKernelGGL(k_update_stamped<POLICY>, dim3((upd_blocks + kStampTiles - 1) / kStampTiles), dim3(256),
+                           0, e->stream, P, e->G, e->d_state, layers, e->d_layer_ptrs, e->n_layer_ptrs, e->S, dx,
+                           dy, dz, dint, drgb, dvar, unsigned(e->ncell));
+        return;
+      }
       hipLaunchKernelGGL(k_update<POLICY>, dim3(upd_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state,
                          layers, e->d_layer_ptrs, e->n_layer_ptrs, e->S, dx, dy, dz, dint, drgb, dvar,
                          unsigned(e->ncell));

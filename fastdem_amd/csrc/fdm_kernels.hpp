@@ -773,6 +773,50 @@ __global__ __launch_bounds__(256) void k_update(
   update_body<POLICY>(P, G, st, L, all_layers, n_layers, S, px, py, pz, prgb, pvar, ncell, blockIdx.x);
 }
 
+// Stamp-gated maps (> 4 M cells): almost every 256-cell tile is idle in a scan, and a block per tile
+// would spend its life loading the scan context only to find that out (64 M cells = 250 K blocks:
+// 165 us of nothing).  Here a block looks at kStampTiles consecutive tiles, decides "idle" from the
+// tile stamp alone and runs the update body only for the live ones (and always for tile 0, which
+// commits the geometry ring).
+constexpr unsigned kStampTiles = 32;  // <= 64: one lane of the first wave per tile (16: 62 us, 32: 60 us, 64: 73 us at C5)
+template <typename POLICY>
+__global__ __launch_bounds__(256) void k_update_stamped(
+    const ScanParams P, const GeomConst G, DevState* __restrict__ st,
+    const typename POLICY::Layers L, float* const* __restrict__ all_layers, int n_layers,
+    const Scratch S, const float* __restrict__ px, const float* __restrict__ py,
+    const float* __restrict__ pz, const float* __restrict__ /*pint*/,
+    const uint32_t* __restrict__ prgb, const float* __restrict__ pvar, unsigned ncell) {
+  const int slot = P.slot;
+  const bool do_update = st->flags[slot].any_inside != 0u;
+  const bool applied = P.do_move && (!P.gate_on_filter || st->flags[slot].any_pass != 0u);
+  const int shr = st->cand[slot].shr, shc = st->cand[slot].shc;
+  const bool strips = applied && (shr != 0 || shc != 0);  // a move: every tile may hold vacated cells
+  const unsigned ob_scan = st->obst[slot].scan;
+  const unsigned n_tiles = (ncell + 255u) >> 8;
+  // all kStampTiles stamps in ONE round trip: lane q of the first wave looks at tile q
+  __shared__ unsigned long long s_live;
+  if (threadIdx.x < 64u) {
+    const unsigned tile = blockIdx.x * kStampTiles + threadIdx.x;
+    bool live = false;
+    if (threadIdx.x < kStampTiles && tile < n_tiles) {
+      const unsigned stamp = S.tile_stamp[tile];
+      live = tile == 0u || strips || (do_update && (stamp == P.scan_no || stamp == ob_scan));
+      if (!live) S.upd_part[tile] = 0u;
+    }
+    const unsigned long long m = __ballot(live);
+    if (threadIdx.x == 0) s_live = m;
+  }
+  __syncthreads();
+  unsigned long long live_mask = s_live;
+  while (live_mask) {  // block-uniform
+    const unsigned q = unsigned(__ffsll((long long)live_mask)) - 1u;
+    live_mask &= live_mask - 1ull;
+    update_body<POLICY, 256>(P, G, st, L, all_layers, n_layers, S, px, py, pz, prgb, pvar, ncell,
+                             blockIdx.x * kStampTiles + q);
+    __syncthreads();  // the body's shared counters are reused by the next live tile
+  }
+}
+
 // One launch for two scans: blocks [0, upd_blocks) finish scan t (its update), the rest start scan
 // t+1 (its bin).  The two halves share nothing — the scratch is double-buffered by scan parity and
 // the chained bin derives its base geometry from slot t (ScanParams::chain_prev) — so a stream of
