@@ -72,6 +72,7 @@ struct ScanParams {
   float sp[4];             // sensor-model parameters
   double robot_x, robot_y;
   float ray_ox, ray_oy, ray_oz;  // sensor origin in the map frame (raycasting stage, integrate only)
+  double base_x, base_y, base_z;  // T_world_base translation: centre of the cropRange ball (host-side use)
   unsigned n;
   unsigned scan_no;
   int slot;

@@ -432,21 +432,57 @@ int ensure_voxel_buffers(fdm_engine* e, size_t n) {
   e->sort_tmp_bytes = 0;
   HIPCK(rocprim::radix_sort_pairs(nullptr, e->sort_tmp_bytes, e->vkeys[0], e->vkeys[1], e->vidx[0],
                                   e->vidx[1], e->vcap, 0, 64, e->stream));
+  {  // the compact-key sort reuses the same allocations (uint32 view of the key buffers)
+    size_t b32 = 0;
+    HIPCK(rocprim::radix_sort_pairs(nullptr, b32, reinterpret_cast<uint32_t*>(e->vkeys[0]),
+                                    reinterpret_cast<uint32_t*>(e->vkeys[1]), e->vidx[0], e->vidx[1], e->vcap, 0,
+                                    32, e->stream));
+    e->sort_tmp_bytes = std::max(e->sort_tmp_bytes, b32);
+  }
   HIPCK(hipMalloc(&e->sort_tmp, e->sort_tmp_bytes ? e->sort_tmp_bytes : 16));
   return FDM_OK;
 }
 
-// keys -> stable sort: vkeys[1] / vidx[1] hold the voxel-ordered scan afterwards
+// keys -> stable sort: vkeys[1] / vidx[1] hold the voxel-ordered scan afterwards.
+// `box` (nullable): centre + half extent [m] of a box that holds every finite point of the cloud;
+// with it the compact 32-bit key is used when 3 * bits <= 31.  Returns through *compact which key
+// type the sorted buffer holds.
 int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slot, const float* dx,
-                       const float* dy, const float* dz) {
+                       const float* dy, const float* dz, const double* box, bool* compact) {
   if (int rc = ensure_voxel_buffers(e, n)) return rc;
   const float inv = 1.0f / voxel_size;  // voxel_grid_impl.hpp:46
-  hipLaunchKernelGGL(k_voxel_keys, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, inv, flag_slot,
-                     e->d_state, dx, dy, dz, e->vkeys[0], e->vidx[0], e->vsel);
-  HIPCK(hipGetLastError());
+  VoxelCompact C{0, 0, 0, 0};
+  if (box && std::isfinite(box[3]) && box[3] > 0.0 && box[3] * double(inv) < 4.0e6) {
+    const double half = box[3] + 2.0 * double(voxel_size);  // 2-cell margin for the float transforms
+    const int span = int(std::ceil(2.0 * half * double(inv))) + 4;
+    int bits = 1;
+    while ((1 << bits) < span) ++bits;
+    if (3 * bits <= 62 && bits <= 21) {
+      C.bits = bits;
+      C.x0 = int(std::floor((box[0] - half) * double(inv))) - 1;
+      C.y0 = int(std::floor((box[1] - half) * double(inv))) - 1;
+      C.z0 = int(std::floor((box[2] - half) * double(inv))) - 1;
+    }
+  }
+  *compact = C.bits > 0 && 3 * C.bits <= 31;  // true: the sorted buffer holds uint32 keys
   size_t bytes = e->sort_tmp_bytes;
-  HIPCK(rocprim::radix_sort_pairs(e->sort_tmp, bytes, e->vkeys[0], e->vkeys[1], e->vidx[0], e->vidx[1],
-                                  size_t(n), 0, 64, e->stream));
+  if (*compact) {
+    uint32_t* k0 = reinterpret_cast<uint32_t*>(e->vkeys[0]);
+    uint32_t* k1 = reinterpret_cast<uint32_t*>(e->vkeys[1]);
+    hipLaunchKernelGGL(k_voxel_keys<uint32_t>, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, inv, flag_slot, C,
+                       e->d_state, dx, dy, dz, k0, e->vidx[0], e->vsel);
+    HIPCK(hipGetLastError());
+    // bits 3*bits .. 31 are zero in every valid key and one in the invalid key (all ones): sorting
+    // one bit past the fields is enough to keep the dropped points behind every voxel
+    HIPCK(rocprim::radix_sort_pairs(e->sort_tmp, bytes, k0, k1, e->vidx[0], e->vidx[1], size_t(n), 0,
+                                    unsigned(3 * C.bits + 1), e->stream));
+  } else {
+    hipLaunchKernelGGL(k_voxel_keys<unsigned long long>, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, inv,
+                       flag_slot, C, e->d_state, dx, dy, dz, e->vkeys[0], e->vidx[0], e->vsel);
+    HIPCK(hipGetLastError());
+    HIPCK(rocprim::radix_sort_pairs(e->sort_tmp, bytes, e->vkeys[0], e->vkeys[1], e->vidx[0], e->vidx[1],
+                                    size_t(n), 0, C.bits > 0 ? unsigned(3 * C.bits + 1) : 64u, e->stream));
+  }
   return FDM_OK;
 }
 
@@ -482,7 +518,7 @@ RayParams make_ray_params(fdm_engine* e, const fdm_raycast_config& c, const floa
 
 // processScan + resolveGhostCells on the stream.  voxel: the points are vkeys[1]/vidx[1] runs.
 int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float* dx, const float* dy,
-                      const float* dz) {
+                      const float* dz, bool compact_keys = false) {
   int rc;
   if ((rc = ensure_ray_cells(e))) return rc;
   Layer* elev = find_layer(e, "elevation");
@@ -499,8 +535,12 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float
   if ((rc = ensure_voxel_buffers(e, Q.n))) return rc;  // vidx[0] doubles as the ray queue
   uint32_t* ray_list = e->vidx[0];
   if (voxel) {
-    hipLaunchKernelGGL(k_voxel_mark, dim3(blocks), dim3(256), 0, e->stream, Q.n, e->vkeys[1], e->vidx[1],
-                       e->vsel);
+    if (compact_keys)
+      hipLaunchKernelGGL(k_voxel_mark<uint32_t>, dim3(blocks), dim3(256), 0, e->stream, Q.n,
+                         reinterpret_cast<const uint32_t*>(e->vkeys[1]), e->vidx[1], e->vsel);
+    else
+      hipLaunchKernelGGL(k_voxel_mark<unsigned long long>, dim3(blocks), dim3(256), 0, e->stream, Q.n,
+                         e->vkeys[1], e->vidx[1], e->vsel);
     hipLaunchKernelGGL(k_ray_compact<true>, dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx,
                        dy, dz, e->vsel, e->rc_cnt, ray_list);
   } else {
@@ -510,11 +550,21 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float
   HIPCK(hipGetLastError());
   const bool tiled = e->G.o_rows != e->G.rows || e->G.o_cols != e->G.cols || e->G.s_rows != e->G.rows ||
                      e->G.s_cols != e->G.cols;
-  auto launch_ray = [&](auto kern) {
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx, dy, dz, ray_list,
-                       e->rc_min);
+  auto launch_ray = [&](auto kern, unsigned seg) {
+    // upper bound of the queue: every point a ray, padded to whole wavefronts per segment
+    const unsigned threads = ((Q.n + 63u) & ~63u) * seg;
+    hipLaunchKernelGGL(kern, dim3((threads + 255u) / 256u), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx, dy,
+                       dz, ray_list, e->rc_min);
   };
-  tiled ? launch_ray(k_ray<true>) : launch_ray(k_ray<false>);
+  // small scans are a few hundred wavefronts of dependent round trips: 16 / 8 lanes share a ray
+  // (C2: k_ray 60 -> 25 (8) -> 16 us (16)); the point count bounds the ray count from above
+  if (Q.n < (1u << 16)) {
+    tiled ? launch_ray(k_ray<true, 16>, 16u) : launch_ray(k_ray<false, 16>, 16u);
+  } else if (Q.n < (1u << 20)) {
+    tiled ? launch_ray(k_ray<true, 8>, 8u) : launch_ray(k_ray<false, 8>, 8u);
+  } else {
+    tiled ? launch_ray(k_ray<true, 1>, 1u) : launch_ray(k_ray<false, 1>, 1u);
+  }
   HIPCK(hipGetLastError());
   hipLaunchKernelGGL(k_ray_resolve, dim3(unsigned((e->ncell + 255) / 256)), dim3(256), 0, e->stream, Q,
                      e->G, e->d_state, L, e->d_layer_ptrs, e->n_layer_ptrs, e->rc_cnt, e->rc_min,
@@ -799,11 +849,14 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   if (ray_on) {  // step 3 of integrateImpl (fastdem.cpp:152-159) on the map this scan just updated
     if (e->profile) HIPCK(hipEventRecord(e->ev_ray[0], e->stream));
     const float origin[3] = {P.ray_ox, P.ray_oy, P.ray_oz};
+    // cropRange keeps d^2 <= range_max^2 around the BASE origin, i.e. around T_world_base's translation
+    const double box[4] = {P.base_x, P.base_y, P.base_z, double(e->cfg.range_max)};
+    bool compact = false;
     if ((rc = enqueue_voxel_sort(e, P.n, static_cast<float>(e->G.res), P.slot, e->S.cap_x, e->S.cap_y,
-                                 e->S.cap_z)))
+                                 e->S.cap_z, box, &compact)))
       return rc;
     const RayParams Q = make_ray_params(e, ray_config_of(e->cfg), origin, P.n, (P.slot + 1) & 3, P.slot);
-    if ((rc = enqueue_ray_stage(e, Q, true, e->S.cap_x, e->S.cap_y, e->S.cap_z))) return rc;
+    if ((rc = enqueue_ray_stage(e, Q, true, e->S.cap_x, e->S.cap_y, e->S.cap_z, compact))) return rc;
     if (e->profile) {
       HIPCK(hipEventRecord(e->ev_ray[1], e->stream));
       e->ray_timed = true;
@@ -838,6 +891,7 @@ void fill_integrate_params(fdm_engine* e, ScanParams& P, const double* Tbs, cons
       o[i] = static_cast<float>((a0 + (a1 + a2)) + Twb[12 + i]);
     }
     P.ray_ox = o[0]; P.ray_oy = o[1]; P.ray_oz = o[2];
+    P.base_x = Twb[12]; P.base_y = Twb[13]; P.base_z = Twb[14];
   }
   P.integrate_mode = 1;
   P.do_move = e->cfg.mode == 0 ? 1 : 0;
@@ -2024,7 +2078,8 @@ int fdm_engine_voxel_any(fdm_engine* e, uint64_t n, const float* x, const float*
   const uint32_t* dc;
   int rc = stage_inputs(e, n, x, y, z, nullptr, nullptr, nullptr, &dx, &dy, &dz, &da, &dc, &dv);
   if (rc) return rc;
-  if ((rc = enqueue_voxel_sort(e, unsigned(n), voxel_size, -1, dx, dy, dz))) return rc;
+  bool compact = false;
+  if ((rc = enqueue_voxel_sort(e, unsigned(n), voxel_size, -1, dx, dy, dz, nullptr, &compact))) return rc;
   hipLaunchKernelGGL(k_voxel_select, dim3(unsigned((n + 255) / 256)), dim3(256), 0, e->stream, unsigned(n),
                      e->vkeys[1], e->vidx[1], e->vsel);
   HIPCK(hipGetLastError());

@@ -59,14 +59,46 @@ __device__ __forceinline__ uint64_t voxel_pack(float x, float y, float z, float 
   return (uint64_t(iz + kOff) << 42) | (uint64_t(iy + kOff) << 21) | uint64_t(ix + kOff);
 }
 
+// Order-preserving compact key for scans whose extent the host can bound (cropRange with a finite
+// range_max keeps every point within range_max of the base origin): the three voxel indices are
+// rebased to the corner of that box and packed into 3*bits <= 31 bits of a uint32, [z][y][x] like the
+// reference key, so the sorted order, the runs and therefore `start` / `count` are the ones of the
+// 63-bit key — at half the key traffic and 28 instead of 64 sorted bits.  Larger boxes (3*bits <= 62)
+// use the same packing in a uint64 and still sort only 3*bits + 1 bits.
+struct VoxelCompact {
+  int x0, y0, z0;  // voxel index of the box corner
+  int bits;        // per axis; 0 = use the full 63-bit key
+};
+constexpr uint32_t kInvalidVoxel32 = 0xFFFFFFFFu;
+template <typename KEY>
+__device__ __forceinline__ KEY voxel_pack_compact(float x, float y, float z, float inv, const VoxelCompact& C) {
+  const int hi = (1 << C.bits) - 1;
+  int fx = cvt_x86(floorf(x * inv)) - C.x0, fy = cvt_x86(floorf(y * inv)) - C.y0, fz = cvt_x86(floorf(z * inv)) - C.z0;
+  fx = fx < 0 ? 0 : (fx > hi ? hi : fx);  // cannot trigger inside the box the host derived (2-cell margin)
+  fy = fy < 0 ? 0 : (fy > hi ? hi : fy);
+  fz = fz < 0 ? 0 : (fz > hi ? hi : fz);
+  return (KEY(fz) << (2 * C.bits)) | (KEY(fy) << C.bits) | KEY(fx);
+}
+template <typename KEY>
+struct VoxelKeyTraits;
+template <>
+struct VoxelKeyTraits<unsigned long long> {
+  static constexpr unsigned long long invalid = ~0ull;
+};
+template <>
+struct VoxelKeyTraits<uint32_t> {
+  static constexpr uint32_t invalid = 0xFFFFFFFFu;
+};
+
 // (key, index) per point; non-finite points (and points the crops dropped, stored with x = NaN)
 // get the invalid key and therefore sort to the tail (voxel_grid_impl.hpp:50-55).
+template <typename KEY>
 __global__ __launch_bounds__(256) void k_voxel_keys(unsigned n, float inv_voxel, int flag_slot,
-                                                    DevState* __restrict__ st,
+                                                    const VoxelCompact C, DevState* __restrict__ st,
                                                     const float* __restrict__ x,
                                                     const float* __restrict__ y,
                                                     const float* __restrict__ z,
-                                                    unsigned long long* __restrict__ keys,
+                                                    KEY* __restrict__ keys,
                                                     uint32_t* __restrict__ idx,
                                                     uint32_t* __restrict__ sel) {
   const unsigned i = blockIdx.x * 256u + threadIdx.x;
@@ -74,7 +106,9 @@ __global__ __launch_bounds__(256) void k_voxel_keys(unsigned n, float inv_voxel,
   if (i < n) {
     const float a = x[i], b = y[i], c = z[i];
     valid = isfinite(a) && isfinite(b) && isfinite(c);
-    keys[i] = valid ? voxel_pack(a, b, c, inv_voxel) : kInvalidVoxel;
+    KEY k = VoxelKeyTraits<KEY>::invalid;
+    if (valid) k = C.bits > 0 ? voxel_pack_compact<KEY>(a, b, c, inv_voxel, C) : KEY(voxel_pack(a, b, c, inv_voxel));
+    keys[i] = k;
     idx[i] = i;
     sel[i] = 0u;  // k_voxel_mark sets the representatives
   }
@@ -82,9 +116,10 @@ __global__ __launch_bounds__(256) void k_voxel_keys(unsigned n, float inv_voxel,
 }
 
 // Representative of the voxel whose run starts at sorted position i (caller checked it is a head).
-__device__ __forceinline__ uint32_t voxel_pick(const unsigned long long* __restrict__ keys,
+template <typename KEY>
+__device__ __forceinline__ uint32_t voxel_pick(const KEY* __restrict__ keys,
                                                const uint32_t* __restrict__ idx, unsigned i, unsigned n) {
-  const unsigned long long key = keys[i];
+  const KEY key = keys[i];
   unsigned count = 1;
   while (count < 16 && i + count < n && keys[i + count] == key) ++count;
   if (count == 16 && i + count < n && keys[i + count] == key) {  // long run: upper bound by bisection
@@ -123,14 +158,14 @@ __device__ __forceinline__ int owned_storage(int mr, int mc, const GeomConst& G)
 // consecutive points of a LiDAR firing sequence / an image row share their 2-D direction (nearly),
 // so the lanes of a wavefront walk the same cells at the same step and their loads coalesce into
 // a few L2 requests instead of 64.
-__global__ __launch_bounds__(256) void k_voxel_mark(unsigned n,
-                                                    const unsigned long long* __restrict__ keys,
+template <typename KEY>
+__global__ __launch_bounds__(256) void k_voxel_mark(unsigned n, const KEY* __restrict__ keys,
                                                     const uint32_t* __restrict__ idx,
                                                     uint32_t* __restrict__ sel) {
   const unsigned i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
-  const unsigned long long key = keys[i];
-  if (key == kInvalidVoxel || (i > 0 && keys[i - 1] == key)) return;
+  const KEY key = keys[i];
+  if (key == VoxelKeyTraits<KEY>::invalid || (i > 0 && keys[i - 1] == key)) return;
   sel[voxel_pick(keys, idx, i, n)] = 1u;
 }
 
@@ -183,7 +218,14 @@ __global__ __launch_bounds__(256) void k_ray_compact(const RayParams Q, const Ge
 }
 
 // processScan, second half — traceRay (raycasting.cpp:46-140) for the queued rays, one per lane.
-template <bool TILED>
+// SEG > 1 (small scans: a few hundred wavefronts, each a chain of ~L/8 dependent L2 round trips):
+// a ray is walked by SEG lanes, lane k covering steps [k*S, (k+1)*S) (the last one to the end).  The
+// DDA state of step k*S is reached by replaying the walk from the start WITHOUT touching memory —
+// the same float operations in the same order, so every visited cell and height is bit-identical —
+// which trades cheap ALU work for an SEG times shorter dependent chain.  The SEG copies of a ray
+// sit in different wavefronts (thread = seg * padded_rays + ray), so the lanes of a wavefront are
+// still neighbouring rays at the same step and the segmented min-scan keeps working.
+template <bool TILED, int SEG>
 __global__ __launch_bounds__(256) void k_ray(const RayParams Q, const GeomConst G,
                                              DevState* __restrict__ st,
                                              const float* __restrict__ x, const float* __restrict__ y,
@@ -191,8 +233,17 @@ __global__ __launch_bounds__(256) void k_ray(const RayParams Q, const GeomConst 
                                              const uint32_t* __restrict__ ray_list,
                                              uint32_t* __restrict__ rc_min) {
   const unsigned n_rays = st->ray_count;
-  const unsigned i = blockIdx.x * 256u + threadIdx.x;
-  if ((i & ~63u) >= n_rays) return;  // whole wavefront beyond the queue
+  const unsigned gid = blockIdx.x * 256u + threadIdx.x;
+  const unsigned n_pad = (n_rays + 63u) & ~63u;  // whole wavefronts per segment
+  unsigned i = gid, seg = 0;
+  if (SEG > 1) {
+    if (n_pad == 0u) return;
+    seg = gid / n_pad;
+    i = gid - seg * n_pad;
+    if (seg >= unsigned(SEG)) return;  // wave-uniform: n_pad is a multiple of 64
+  } else if ((gid & ~63u) >= n_rays) {
+    return;  // whole wavefront beyond the queue
+  }
   const DevGeom g = st->geom[Q.slot];
   const bool have = i < n_rays;
   const unsigned pi = have ? ray_list[i] : 0u;
@@ -241,6 +292,27 @@ __global__ __launch_bounds__(256) void k_ray(const RayParams Q, const GeomConst 
   const int lane = threadIdx.x & 63;
   const int max_steps = nrows + ncols;
   int s = 0;
+  int s_end = max_steps;
+  if (SEG > 1) {
+    // cells the ray crosses: one per row / column boundary between the two end cells (+ slack; an
+    // underestimate only makes the last segment longer, coverage stays exact)
+    const float est_f = fabsf(floorf(gr1) - float(r)) + fabsf(floorf(gc1) - float(c)) + 2.0f;
+    const int est = est_f < float(max_steps) ? int(est_f) : max_steps;
+    int seg_len = (est + SEG - 1) / SEG;
+    seg_len = (seg_len + kRayBatch - 1) / kRayBatch * kRayBatch;
+    const int s_begin = int(seg) * seg_len;
+    if (int(seg) != SEG - 1) s_end = s_begin + seg_len;
+    for (; s < s_begin && alive; ++s) {  // replay: the walk without the visits
+      const bool row = t_max_r < t_max_c;
+      const float t_exit = row ? t_max_r : t_max_c;
+      alive = alive && !(t_exit >= 1.0f) && (s + 1 < max_steps);
+      r += row ? step_r : 0;
+      c += row ? 0 : step_c;
+      t_max_r = row ? t_max_r + t_delta_r : t_max_r;
+      t_max_c = row ? t_max_c : t_max_c + t_delta_c;
+    }
+    alive = alive && s == s_begin && s < s_end;
+  }
   while (__ballot(alive)) {
     int cell[kRayBatch];
     uint32_t hh[kRayBatch];
@@ -262,7 +334,7 @@ __global__ __launch_bounds__(256) void k_ray(const RayParams Q, const GeomConst 
       const float height = sz + ((1.0f < t_exit) ? 1.0f : t_exit) * dz;
       cell[j] = in_map ? o : -1;
       hh[j] = ord(height);
-      alive = alive && !(t_exit >= 1.0f) && (s + j + 1 < max_steps);
+      alive = alive && !(t_exit >= 1.0f) && (s + j + 1 < s_end);
       r += row ? step_r : 0;
       c += row ? 0 : step_c;
       t_max_r = row ? t_max_r + t_delta_r : t_max_r;
