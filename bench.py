@@ -321,6 +321,19 @@ def main():
                 res.eng.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k + 1000 + i),
                                   intensity=s["intensity"], rgb=s["rgb"])
             result["host_buffers_ms_per_scan"] = (time.perf_counter() - t0) / 50 * 1e3
+            # steady-state stream from PINNED host memory, no per-scan wait (SURVEY.md §8d iii): PCIe-inclusive
+            pin = {c: torch.from_numpy(s[c]).pin_memory() for c in ("x", "y", "z", "intensity", "rgb") if s.get(c) is not None}
+            hp = {c: C.c_void_p(t.data_ptr()) for c, t in pin.items()}
+            for i in range(20):
+                res.eng.integrate_async_raw(s["x"].size, hp["x"], hp["y"], hp["z"], res.tbs, res.pose(k + 2000 + i),
+                                            hp.get("intensity"), hp.get("rgb"))
+            res.eng.sync()
+            t0 = time.perf_counter()
+            for i in range(200):
+                res.eng.integrate_async_raw(s["x"].size, hp["x"], hp["y"], hp["z"], res.tbs, res.pose(k + 2000 + i % 60),
+                                            hp.get("intensity"), hp.get("rgb"))
+            res.eng.sync()
+            result["host_stream_pinned_ms_per_scan"] = (time.perf_counter() - t0) / 200 * 1e3
             if world == 1 and not args.no_large and args.workload != "c4":
                 big = Resident(synth.lidar128(n_scans=2), local_rank, args.wave_merge, args.overlap)
                 for i in range(10):

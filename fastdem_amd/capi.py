@@ -119,6 +119,8 @@ PROTOTYPES = {
     "fdm_engine_integrate": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, _D, _D,
                                        C.POINTER(FdmScanStats)]),
     "fdm_engine_integrate_device": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, _D, _D]),
+    "fdm_engine_integrate_async": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_double),
+                                             C.POINTER(C.c_double)]),
     "fdm_engine_update": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, C.c_double,
                                     C.c_double, C.POINTER(FdmScanStats)]),
     "fdm_engine_update_device": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, C.c_double,

@@ -85,6 +85,7 @@ struct fdm_engine {
   // staging for the host-pointer entry points
   float* d_stage = nullptr;
   size_t stage_cap = 0;  // in points
+  int stage_rr = 0;      // rotating staging block
   int32_t* d_cell_ids = nullptr;
   size_t ids_cap = 0;
   bool want_ids = false;
@@ -907,12 +908,17 @@ void fill_update_params(fdm_engine* e, ScanParams& P, double rx, double ry, bool
   P.gate_on_filter = 0;
 }
 
+// Staging for host-array entry points: kStageSlots rotating blocks of 6 channels.  A block is reused
+// three scans later, when the update that gathers from it (held back by at most one scan) has long
+// been launched ahead of the new copy on the same stream.
+constexpr int kStageSlots = 3;
+
 int ensure_stage(fdm_engine* e, size_t n) {
   if (n <= e->stage_cap) return FDM_OK;
   if (int rc_sync = sync_all(e)) return rc_sync;
   if (e->d_stage) HIPCK(hipFree(e->d_stage));
   e->stage_cap = n + n / 4 + 1024;
-  HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_stage), e->stage_cap * 6 * sizeof(float)));
+  HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_stage), e->stage_cap * 6 * kStageSlots * sizeof(float)));
   return FDM_OK;
 }
 
@@ -923,8 +929,9 @@ int stage_inputs(fdm_engine* e, uint64_t n, const float* x, const float* y, cons
                  const float** dv) {
   int rc;
   if ((rc = ensure_stage(e, n))) return rc;
-  float* base = e->d_stage;
+  e->stage_rr = (e->stage_rr + 1) % kStageSlots;
   const size_t cap = e->stage_cap;
+  float* base = e->d_stage + size_t(e->stage_rr) * 6 * cap;
   auto up = [&](const void* src, int k) -> int {
     HIPCK(hipMemcpyAsync(base + cap * k, src, n * sizeof(float), hipMemcpyHostToDevice, e->stream));
     return FDM_OK;
@@ -1286,6 +1293,20 @@ int fdm_engine_integrate(fdm_engine* e, uint64_t n, const float* x, const float*
   int status = FDM_OK;
   if ((rc = read_stats(e, out, &status))) return rc;
   return status;
+}
+
+int fdm_engine_integrate_async(fdm_engine* e, uint64_t n, const float* x, const float* y, const float* z,
+                               const float* intensity, const uint32_t* rgb, const float* sigma_z2,
+                               const double Tbs[16], const double Twb[16]) {
+  if (!e || !Tbs || !Twb) return fail(FDM_ERR_INVALID, "null argument");
+  if (n == 0) return fdm_engine_integrate_device(e, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, Tbs, Twb);
+  if (!x || !y || !z) return fail(FDM_ERR_INVALID, "null xyz");
+  HIPCK(hipSetDevice(e->device));
+  const float *dx, *dy, *dz, *da, *dv;
+  const uint32_t* dc;
+  int rc = stage_inputs(e, n, x, y, z, intensity, rgb, sigma_z2, &dx, &dy, &dz, &da, &dc, &dv);
+  if (rc) return rc;
+  return fdm_engine_integrate_device(e, n, dx, dy, dz, da, dc, dv, Tbs, Twb);
 }
 
 int fdm_engine_update_device(fdm_engine* e, uint64_t n, const float* dx, const float* dy,

@@ -124,6 +124,19 @@ class Engine:
             _dptr(sigma_z2), tbs.ctypes.data_as(C.POINTER(C.c_double)),
             twb.ctypes.data_as(C.POINTER(C.c_double))))
 
+    def integrate_async(self, x, y, z, T_base_sensor, T_world_base, intensity=None, rgb=None):
+        """Host arrays (ideally pinned), enqueue-only: H2D copy + scan on the engine stream."""
+        x, y, z = _f32(x), _f32(y), _f32(z)
+        a, c = _f32(intensity), _u32(rgb)
+        tbs, twb = _colmajor16(T_base_sensor), _colmajor16(T_world_base)
+        _ck(self._lib.fdm_engine_integrate_async(
+            self._h, x.size, _ptr(x), _ptr(y), _ptr(z), _ptr(a), _ptr(c), None,
+            tbs.ctypes.data_as(C.POINTER(C.c_double)), twb.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def integrate_async_raw(self, n, hx, hy, hz, tbs16, twb16, hint=None, hrgb=None):
+        """Raw host pointers + pre-flattened transforms: the minimum-overhead streaming call."""
+        return self._lib.fdm_engine_integrate_async(self._h, n, hx, hy, hz, hint, hrgb, None, tbs16, twb16)
+
     def integrate_device_raw(self, n, dx, dy, dz, tbs16, twb16, dint=None, drgb=None, dvar=None):
         """Pre-flattened column-major transforms (ctypes double arrays) + raw device pointers:
         the minimum-overhead call used inside bench.py's timed loop."""

@@ -138,6 +138,16 @@ int fdm_engine_integrate_device(fdm_engine* e, uint64_t n, const float* d_x, con
                                 const float* d_sigma_z2, const double T_base_sensor[16],
                                 const double T_world_base[16]);
 
+/* Same, HOST arrays, enqueue-only: the channels are copied into a rotating staging block with
+ * hipMemcpyAsync on the engine's stream and the scan is enqueued behind the copy; nothing waits.
+ * For a stream of scans from host memory (bag replay): pass pinned (hipHostMalloc / hipHostRegister)
+ * arrays so the copies are truly asynchronous, and keep each scan's arrays untouched until its copy
+ * has run (fdm_engine_sync(), or an event recorded on fdm_engine_stream()). */
+int fdm_engine_integrate_async(fdm_engine* e, uint64_t n, const float* x, const float* y,
+                               const float* z, const float* intensity, const uint32_t* rgb,
+                               const float* sigma_z2, const double T_base_sensor[16],
+                               const double T_world_base[16]);
+
 /* ElevationMapping::update(cloud, robot_position) — elevation_mapping.cpp:110-125 —
  * for a cloud already in the map frame (tests/test_dual_layer.cpp:71).  z_var NULL
  * == cloud without covariance channel (pt_z_var = 0, elevation_mapping.cpp:57-60). */
