@@ -85,3 +85,73 @@ def test_golden_exercises_shifts_and_edges():
     assert (np.abs(shifts) >= 40).any()  # a multi-metre jump (wrap-around / large strip)
     ids = g["ids_10"]
     assert (ids == -1).any() and (ids == -2).any() and (ids >= 0).any()
+
+
+# ---- the rows either side of the hot path: tests/golden/widened_rows.npz ----
+FEATURE_TOL = {"roughness": 2e-4, "curvature": 2e-4, "_normal_x": 2e-4, "_normal_y": 2e-4, "_normal_z": 2e-4,
+               "slope": 0.05}  # eigen-derived layers (see tests/test_post_gpu.py for why)
+
+
+class _Layout:
+    def __init__(self, v):
+        (self.point_step, self.off_x, self.off_y, self.off_z, self.off_intensity, self.intensity_type,
+         self.off_rgb) = (int(x) for x in v)
+
+
+def replay_rows(engine, g, lay, exact):
+    """ingest -> integrate + raycasting -> stencils -> egress, checked against the fixture."""
+    gr, gc = g["ghost_rows"], g["ghost_cols"]
+    for k in range(4):
+        if k == 1:
+            e = engine.layer("elevation")
+            e[gr[0]:gr[1], gc[0]:gc[1]] = float(g["ghost_value"])
+            engine.set_layer("elevation", e)
+        blob = g[f"blob_{k}"]
+        rc, _ = engine.integrate_cloud2(blob, blob.size // lay.point_step, lay, g["T_base_sensor"], g["poses"][k])
+        assert rc == 0
+    engine.apply_uncertainty_fusion(True, 0.25, 0.1, 0.01, 0.99, 3)
+    engine.apply_inpainting(3, 2)
+    engine.apply_spatial_smoothing("elevation_inpainted", 3, 5)
+    engine.apply_feature_extraction(0.3, 4, 0.05, 0.95)
+    geo = engine.geometry()
+    assert [geo.position_x, geo.position_y, geo.start_row, geo.start_col] == list(g["geom"])
+    assert list(engine.layers()) == list(g["layer_names"])  # creation order included
+    for n in engine.layers():
+        got, exp = engine.layer(n), g["layer_" + n]
+        if exact or n not in FEATURE_TOL:
+            assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), n
+        else:
+            assert np.array_equal(np.isnan(got), np.isnan(exp)), n
+            ok = np.isfinite(exp)
+            assert np.abs(got[ok].astype(np.float64) - exp[ok]).max() <= FEATURE_TOL[n] + 1e-4 * np.abs(exp[ok]).max(), n
+    assert np.nansum(engine.layer("ghost_removal")) > 0
+
+
+def test_oracle_reproduces_widened_rows_golden(R):
+    g = load("widened_rows")
+    ref = R.RefEngine(float(g["width"]), float(g["height"]), float(g["resolution"]), fill_cfg(R.default_config(), g))
+    lay = _Layout(g["layout"])
+    d = R.from_cloud2(g["blob_3"], g["blob_3"].size // lay.point_step, lay)
+    for ch in ("x", "y", "z", "intensity"):
+        assert np.array_equal(d[ch].view(np.uint32), g["decoded3_" + ch].view(np.uint32))
+    replay_rows(ref, g, lay, exact=True)
+    fields, step, data = ref.pack_cloud()
+    assert list(fields) == list(g["cloud_fields"]) and step == int(g["cloud_step"])
+    assert np.array_equal(data.view(np.uint32), g["cloud_data"].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_engine_reproduces_widened_rows_golden(gpu):
+    g = load("widened_rows")
+    eng = gpu.Engine(float(g["width"]), float(g["height"]), float(g["resolution"]),
+                     fill_cfg(gpu.capi.default_config(), g))
+    v = _Layout(g["layout"])
+    lay = gpu.Engine.cloud2_layout(v.point_step, v.off_x, v.off_y, v.off_z, v.off_intensity, v.intensity_type, v.off_rgb)
+    d = eng.ingest_cloud2(g["blob_3"], g["blob_3"].size // v.point_step, lay)
+    for ch in ("x", "y", "z", "intensity"):
+        assert np.array_equal(d[ch].view(np.uint32), g["decoded3_" + ch].view(np.uint32))
+    replay_rows(eng, g, lay, exact=False)
+    fields, step, data = eng.pack_cloud()
+    assert list(fields) == list(g["cloud_fields"]) and step == int(g["cloud_step"])
+    cols = [i for i, f in enumerate(fields) if f not in FEATURE_TOL]
+    assert np.array_equal(data[:, cols].view(np.uint32), g["cloud_data"][:, cols].view(np.uint32))
