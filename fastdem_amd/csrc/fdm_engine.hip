@@ -1642,8 +1642,16 @@ int fdm_engine_enable_profile(fdm_engine* e, int on) {
 
 // ---- stencil post-processing ----
 namespace {
-bool is_tiled(const fdm_engine* e) {
-  return e->G.o_rows != e->G.rows || e->G.o_cols != e->G.cols || e->G.s_rows != e->G.rows || e->G.s_cols != e->G.cols;
+// Spatial tiles: a stencil that reaches `need` cells is exact on the owned cells iff every window side
+// that is not a map side carries a halo at least that wide.
+int check_halo(const fdm_engine* e, int need) {
+  const GeomConst& G = e->G;
+  const int top = G.o_r0 - G.s_r0, left = G.o_c0 - G.s_c0;
+  const int bottom = (G.s_r0 + G.s_rows) - (G.o_r0 + G.o_rows), right = (G.s_c0 + G.s_cols) - (G.o_c0 + G.o_cols);
+  const bool ok = (G.s_r0 == 0 || top >= need) && (G.s_c0 == 0 || left >= need) &&
+                  (G.s_r0 + G.s_rows == G.rows || bottom >= need) && (G.s_c0 + G.s_cols == G.cols || right >= need);
+  if (!ok) return fail(FDM_ERR_INVALID, "tile halo narrower than the stencil (" + std::to_string(need) + " cells needed)");
+  return FDM_OK;
 }
 // neighbourhood offsets, dr-major / dc-minor; box = region(Size(k,k)), disc = region(radius)
 int upload_region(fdm_engine* e, const std::vector<RegionEntry>& reg) {
@@ -1674,9 +1682,9 @@ int ensure_tmp2(fdm_engine* e) {
 int fdm_engine_apply_inpainting(fdm_engine* e, int max_iterations, int min_valid, int inplace) {
   if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
-  if (is_tiled(e)) return fail(FDM_ERR_INVALID, "post-processing needs a whole-map engine");
   HIPCK(hipSetDevice(e->device));
   int rc;
+  if ((rc = check_halo(e, max_iterations > 0 ? max_iterations : 0))) return rc;  // one cell per pass
   if ((rc = resolve_pending(e))) return rc;
   Layer* elev = find_layer(e, "elevation");
   if (!elev) return fail(FDM_ERR_NO_LAYER, "no layer elevation");
@@ -1712,11 +1720,11 @@ int fdm_engine_apply_inpainting(fdm_engine* e, int max_iterations, int min_valid
 int fdm_engine_apply_spatial_smoothing(fdm_engine* e, const char* layer, int kernel_size, int min_valid) {
   if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !layer) return fail(FDM_ERR_INVALID, "null argument");
-  if (is_tiled(e)) return fail(FDM_ERR_INVALID, "post-processing needs a whole-map engine");
   if (kernel_size < 1 || kernel_size > 15 || (kernel_size & 1) == 0)
     return fail(FDM_ERR_INVALID, "kernel_size must be odd and in [1, 15]");
   HIPCK(hipSetDevice(e->device));
   int rc;
+  if ((rc = check_halo(e, kernel_size / 2))) return rc;
   if ((rc = resolve_pending(e))) return rc;
   Layer* l = find_layer(e, layer);
   if (!l || l->pending) return FDM_OK;  // spatial_smoothing.hpp:42
@@ -1734,9 +1742,9 @@ int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* 
   if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !cfg) return fail(FDM_ERR_INVALID, "null argument");
   if (!cfg->enabled) return FDM_OK;
-  if (is_tiled(e)) return fail(FDM_ERR_INVALID, "post-processing needs a whole-map engine");
   HIPCK(hipSetDevice(e->device));
   int rc;
+  if ((rc = check_halo(e, int(std::floor(cfg->search_radius / static_cast<float>(e->G.res) + 1e-4f))))) return rc;
   if ((rc = resolve_pending(e))) return rc;
   Layer* up = find_layer(e, "upper_bound");
   Layer* lo = find_layer(e, "lower_bound");
@@ -1782,9 +1790,9 @@ int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* 
 int fdm_engine_apply_feature_extraction(fdm_engine* e, float radius, int min_valid, float lo_pct, float hi_pct) {
   if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
-  if (is_tiled(e)) return fail(FDM_ERR_INVALID, "post-processing needs a whole-map engine");
   HIPCK(hipSetDevice(e->device));
   int rc;
+  if ((rc = check_halo(e, int(std::floor(radius / static_cast<float>(e->G.res) + 1e-4f))))) return rc;
   if ((rc = resolve_pending(e))) return rc;
   if (!find_layer(e, "elevation")) return FDM_OK;  // feature_extraction.cpp:33
   const char* names[7] = {"step", "slope", "roughness", "curvature", "_normal_x", "_normal_y", "_normal_z"};

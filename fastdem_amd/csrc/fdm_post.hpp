@@ -25,10 +25,17 @@ struct RegionEntry { int dr, dc; float dist_sq; float w; };  // w: per-entry wei
 struct PostGeom {
   int rows, cols, sr, sc;
 };
+// The neighbourhood space of a kernel = the cells this engine STORES: the whole circular buffer
+// (logical coordinates through the start index), or — spatial tiles of a GLOBAL map, start index 0 —
+// the stored window incl. its halo ring.  At a window edge that is not a map edge the neighbourhood
+// is clipped, which only ever affects halo cells as long as the halo is at least as wide as the
+// stencil reaches (checked by the host); halos are refreshed from their owners afterwards.
 __device__ __forceinline__ PostGeom post_geom(const DevState* __restrict__ st, int slot, const GeomConst& G) {
-  const DevGeom g = st->geom[slot];
   PostGeom p;
-  p.rows = G.rows; p.cols = G.cols; p.sr = g.sr; p.sc = g.sc;
+  p.rows = G.s_rows; p.cols = G.s_cols;
+  const bool whole = G.s_rows == G.rows && G.s_cols == G.cols;
+  p.sr = whole ? st->geom[slot].sr : 0;
+  p.sc = whole ? st->geom[slot].sc : 0;
   return p;
 }
 __device__ __forceinline__ size_t post_index(const PostGeom& p, int lr, int lc) {

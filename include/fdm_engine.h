@@ -292,8 +292,11 @@ int fdm_engine_integrate_cloud2(fdm_engine* e, const void* data, int data_on_dev
  * The reference's post-processing functions (called by the ROS timers on a snapshot of the map) on
  * the device-resident layers; each call only enqueues kernels.  Neighbourhoods are taken in logical
  * (unwrapped) coordinates and clipped at the map border; see DESIGN.md §7 f2 for the exact
- * neighbourhood definition (nanoGrid's region()/neighbors() are not on disk).  Whole-map engines only
- * (tiled engines: FDM_ERR_INVALID).
+ * neighbourhood definition (nanoGrid's region()/neighbors() are not on disk).  On a spatial tile the
+ * stage is exact for the OWNED cells provided the halo ring is at least as wide as the stencil
+ * reaches (inpainting: one cell per pass; median: kernel/2; the discs: radius/resolution) —
+ * otherwise FDM_ERR_INVALID; halo cells must be refreshed from their owners afterwards
+ * (fdm_engine_region_pack/_unpack).
  *   applyInpainting(map, max_iterations, min_valid_neighbors, inplace)        src/inpainting.cpp:21-67
  *   applySpatialSmoothing(map, layer, kernel_size, min_valid_neighbors)       postprocess/spatial_smoothing.hpp:38-67
  *   applyUncertaintyFusion(map, config::UncertaintyFusion)                    src/uncertainty_fusion.cpp:103-186

@@ -161,8 +161,48 @@ def test_after_real_scans_with_records(gpu, R):
     exact(eng, ref)
 
 
-def test_tiled_engine_is_refused(gpu, R):
-    t = gpu.Engine(20.0, 20.0, 0.1, tile=(0, 0, 100, 200, 0, 0, 100, 200),
-                   cfg=(lambda c: (setattr(c, "mode", 1), c)[1])(gpu.capi.default_config()))
+def test_tiled_engines_with_halo(gpu, R):
+    """2x2 spatial tiles of a GLOBAL map, 6-cell halo: every stage is exact on the owned cells (the
+    halo is as wide as the stencils reach) and refused when the halo is too narrow."""
+    rng = np.random.default_rng(31)
+    W, RES, HALO = 20.0, 0.1, 6
+    gcfg = gpu.capi.default_config()
+    gcfg.mode = 1
+    whole = gpu.Engine(W, W, RES, gcfg)
+    rows, cols = whole.rows, whole.cols
+    el = terrain(rng, (rows, cols), holes=0.3)
+    half = np.abs(rng.normal(0.05, 0.02, (rows, cols))).astype(F32) + F32(0.005)
+    hr, hc = rows // 2, cols // 2
+    tiles = []
+    for tr in range(2):
+        for tc in range(2):
+            o_r0, o_c0 = tr * hr, tc * hc
+            s_r0, s_c0 = max(0, o_r0 - HALO), max(0, o_c0 - HALO)
+            s_r1, s_c1 = min(rows, o_r0 + hr + HALO), min(cols, o_c0 + hc + HALO)
+            t = gpu.Engine(W, W, RES, gcfg, tile=(s_r0, s_c0, s_r1 - s_r0, s_c1 - s_c0, o_r0, o_c0, hr, hc))
+            tiles.append((t, (s_r0, s_r1, s_c0, s_c1), (o_r0, o_r0 + hr, o_c0, o_c0 + hc)))
+    for name, arr in (("elevation", el), ("upper_bound", el + half), ("lower_bound", el - half)):
+        whole.set_layer(name, arr)
+        for t, (a, b, c, d), _ in tiles:
+            t.set_layer(name, arr[a:b, c:d])
+
+    def run(o):
+        o.apply_uncertainty_fusion(True, 0.6, 0.2, 0.05, 0.95, 3)   # 6 cells
+        o.apply_inpainting(3, 2)                                    # 3 cells
+        o.apply_spatial_smoothing("elevation_inpainted", 5, 5)      # 2 cells
+        o.apply_feature_extraction(0.6, 4, 0.05, 0.95)              # 6 cells
+    run(whole)
+    for t, _, _ in tiles:
+        run(t)
+    for name in ("upper_bound", "lower_bound", "elevation_inpainted", "step", "slope", "_normal_z", "roughness"):
+        full = whole.layer(name)
+        for t, (a, b, c, d), (oa, ob, oc, od) in tiles:
+            got = t.layer(name)[oa - a:ob - a, oc - c:od - c]
+            want = full[oa:ob, oc:od]
+            assert np.array_equal(np.isnan(got), np.isnan(want)), name
+            assert np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)]), name
+    t0 = tiles[0][0]
     with pytest.raises(gpu.EngineError):
-        t.apply_inpainting()
+        t0.apply_feature_extraction(0.75, 4)          # 7 cells > halo
+    with pytest.raises(gpu.EngineError):
+        t0.apply_inpainting(7, 2)
