@@ -84,6 +84,7 @@ struct ScanParams {
   int chain_prev;      // 1: the previous scan's update may still be running on the update stream:
   int prev_do_move;    //    derive this scan's base geometry from the PREVIOUS slot (geom, cand, any_pass)
   int prev_gate;       //    exactly as that update will commit it, instead of reading the committed slot
+  int bin_table;       // k_bin: fold the block's run tails into an LDS table before going to memory
   int dbg_no_atomics;  // experiment switch (bench A/B only): skip the scratch atomics
   int dbg_upd;         // experiment switch: 1 = k_update returns after the context, 2 = after round 1
 };

@@ -91,6 +91,7 @@ struct fdm_engine {
   bool want_ids = false;
   bool profile = false;
   bool wave_merge = true;
+  int bin_table = 1;                 // k_bin: per-block LDS cell table (option "bin_table")
   int dbg_no_atomics = 0;
   int dbg_upd = 0;
   int bin_threads = 0;               // k_bin4 block size (0 = auto, 128 / 256 / 512): 4 points per thread
@@ -671,6 +672,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   }
   e->last_bin_blocks = bin_blocks;
   P.dbg_no_atomics = e->dbg_no_atomics;
+  P.bin_table = e->bin_table;
   P.dbg_upd = e->dbg_upd;
   // a held-back update leaves now: fused with this bin if this scan is a plain small one, alone otherwise
   const bool bin4_fusable = use_bin4 && (bin_threads == 256 || bin_threads == 512) && e->upd_fuses_bin4;
@@ -2154,6 +2156,10 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
   if (!e || !key) return fail(FDM_ERR_INVALID, "null argument");
   if (std::strcmp(key, "wave_merge") == 0) {
     e->wave_merge = value != 0;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "bin_table") == 0) {
+    e->bin_table = value != 0;
     return FDM_OK;
   }
   if (std::strcmp(key, "overlap") == 0) {

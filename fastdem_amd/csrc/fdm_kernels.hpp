@@ -359,6 +359,16 @@ __device__ __forceinline__ void bin_body(const ScanParams& P, const GeomConst& G
                                          int32_t* __restrict__ cell_ids, const unsigned bid) {
   __shared__ DevCand s_cand;
   __shared__ unsigned s_pass[4], s_in[4];
+  // per-block table of the cells this block's 256 points fall into (P.bin_table): the run tails of
+  // the wave merge fold into it with LDS atomics and only its occupied slots go to memory — a firing-
+  // order scan puts the 16 samples a block holds of each beam into 2-3 cells, but 16 lanes apart
+  __shared__ unsigned long long t_key[256];
+  __shared__ uint32_t t_cell[256], t_zmx[256], t_imx[256], t_fst[256], t_lst[256];
+  if (P.bin_table) {
+    t_key[threadIdx.x] = kEmptyKey;
+    t_cell[threadIdx.x] = kEmptyCell;
+    t_zmx[threadIdx.x] = 0u; t_imx[threadIdx.x] = 0u; t_fst[threadIdx.x] = kNoIdx; t_lst[threadIdx.x] = 0u;
+  }  // (made visible by the barrier inside block_candidate)
   // the point (and intensity) loads go out first: they are in flight while thread 0 reads the
   // geometry and works out the post-move candidate
   const unsigned i = bid * 256u + threadIdx.x;
@@ -424,7 +434,30 @@ __device__ __forceinline__ void bin_body(const ScanParams& P, const GeomConst& G
     const int ncell = __shfl_down(cell, 1);
     commit = inside && (lane == 63 || ncell != cell);
   }
-  if (commit && !P.dbg_no_atomics) {
+  // a wave whose adjacent-lane merge already found long runs (ring-major scans: few tails) goes to
+  // memory directly; one whose lanes are mostly their own tail (firing order) folds into the table
+  const bool use_table = P.bin_table && 2 * __popcll(__ballot(commit)) > __popcll(__ballot(inside));
+  if (use_table) {
+    if (commit) {
+      uint32_t h = uint32_t(cell) & 255u;
+      while (true) {
+        const uint32_t seen = t_cell[h];
+        if (seen == uint32_t(cell)) break;
+        if (seen == kEmptyCell) {
+          const uint32_t prev = atomicCAS(&t_cell[h], kEmptyCell, uint32_t(cell));
+          if (prev == kEmptyCell || prev == uint32_t(cell)) break;
+        }
+        h = (h + 1) & 255u;
+      }
+      atomicMin(&t_key[h], key);
+      if (zmx) atomicMax(&t_zmx[h], zmx);
+      if (P.has_intensity) {
+        if (imx) atomicMax(&t_imx[h], imx);
+        atomicMin(&t_fst[h], fst);
+      }
+      if (P.has_color) atomicMax(&t_lst[h], lst);
+    }
+  } else if (commit && !P.dbg_no_atomics) {
     if (P.has_intensity && P.has_color)
       scratch_merge<true, true>(S, P.scan_no, cell, key, zmx, imx, fst, lst);
     else if (P.has_intensity)
@@ -442,6 +475,17 @@ __device__ __forceinline__ void bin_body(const ScanParams& P, const GeomConst& G
     if (mg) st->flags[P.slot].any_inside = 1u;
   }
   __syncthreads();
+  if (P.bin_table && !P.dbg_no_atomics) {  // one slot per thread
+    const uint32_t tc = t_cell[threadIdx.x];
+    if (tc != kEmptyCell) {
+      const unsigned long long tk = t_key[threadIdx.x];
+      const uint32_t a = t_zmx[threadIdx.x], b2 = t_imx[threadIdx.x], c2 = t_fst[threadIdx.x], d2 = t_lst[threadIdx.x];
+      if (P.has_intensity && P.has_color) scratch_merge<true, true>(S, P.scan_no, tc, tk, a, b2, c2, d2);
+      else if (P.has_intensity) scratch_merge<true, false>(S, P.scan_no, tc, tk, a, b2, c2, d2);
+      else if (P.has_color) scratch_merge<false, true>(S, P.scan_no, tc, tk, a, b2, c2, d2);
+      else scratch_merge<false, false>(S, P.scan_no, tc, tk, a, b2, c2, d2);
+    }
+  }
   if (threadIdx.x == 0) {
     const unsigned np = s_pass[0] + s_pass[1] + s_pass[2] + s_pass[3];
     const unsigned ni = s_in[0] + s_in[1] + s_in[2] + s_in[3];

@@ -329,6 +329,7 @@ int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2);
  *   "bin_variant" 0/1/4 : bin kernel by scan size (0), one point per thread (1), LDS-staged (4)
  *   "dense"       0/1   : update sweep visits every tile (1) or only stamped tiles (0)
  *   "records"     0/1   : estimator state packed into per-cell records (1) or one array per layer (0)
+ *   "bin_table"   0/1   : k_bin folds poorly merged waves into a per-block LDS cell table before the atomics
  *   "overlap"     0/1   : hold the update of a small scan back and fuse it with the next scan's bin launch
  *   "dbg_*"             : measurement-only switches used by scripts/ab_kernels.py */
 int fdm_engine_set_option(fdm_engine* e, const char* key, int value);
