@@ -138,7 +138,6 @@ struct fdm_engine {
   struct BinVariant { bool bin4, has_int, has_col, wave_merge; unsigned threads; };
   std::function<int(const ScanParams&, const Scratch&, const ScanInputs&, int32_t*, unsigned, BinVariant)> upd_fused;
   bool upd_fuses_bin4 = false;  // the held-back update can ride with a k_bin4 launch (record policies only)
-  unsigned upd_tiles = 0;
   int last_do_move = 0, last_gate = 0;
   // stencil post-processing (fdm_post.hpp)
   RegionEntry* d_region = nullptr;   // kMaxRegion entries
