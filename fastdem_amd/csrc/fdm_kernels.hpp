@@ -876,12 +876,17 @@ __global__ __launch_bounds__(THREADS) void k_update_bin4(
     float* const* __restrict__ all_layers, int n_layers, const Scratch Su, const ScanInputs Iu, unsigned ncell,
     unsigned upd_blocks, const ScanParams Pb, const Scratch Sb, const ScanInputs Ib,
     int32_t* __restrict__ cell_ids) {
-  if (blockIdx.x < upd_blocks) {
-    update_body<POLICY, THREADS>(Pu, G, st, L, all_layers, n_layers, Su, Iu.x, Iu.y, Iu.z, Iu.rgb, Iu.var, ncell,
-                                 blockIdx.x);
+  // the two kinds of block are interleaved in proportion over the grid, so that the bandwidth-bound
+  // update half and the atomic/latency-bound bin half are resident together for the whole launch
+  // (update blocks first, then bin blocks, only overlapped where one kind ran out)
+  const unsigned long long total = gridDim.x;
+  const unsigned u0 = unsigned((blockIdx.x * (unsigned long long)upd_blocks) / total);
+  const unsigned u1 = unsigned(((blockIdx.x + 1ull) * (unsigned long long)upd_blocks) / total);
+  if (u1 > u0) {
+    update_body<POLICY, THREADS>(Pu, G, st, L, all_layers, n_layers, Su, Iu.x, Iu.y, Iu.z, Iu.rgb, Iu.var, ncell, u0);
   } else {
     bin4_body<HAS_INT, HAS_COL, THREADS>(Pb, G, st, Ib.x, Ib.y, Ib.z, Ib.intensity, Sb, cell_ids,
-                                         blockIdx.x - upd_blocks);
+                                         blockIdx.x - u0);
   }
 }
 
