@@ -829,6 +829,48 @@ TEST(ConfigLoad, ValidationRunsAfterParsingAndBadYamlThrows) {  // :160-183; yam
   EXPECT_THROW(loadConfig(writeTempYaml("point_filter:\n  - 1\n  - 2\n", "test_seq.yaml")), std::runtime_error);
 }
 
+TEST(ConfigLoad, PostProcessYaml) {  // test_config.cpp:227-333
+  const config::PostProcess all = config::loadPostProcess(writeTempYaml(
+      "inpainting:\n  enabled: true\n  max_iterations: 5\n  min_valid_neighbors: 3\n"
+      "uncertainty_fusion:\n  enabled: true\n  search_radius: 0.2\n  spatial_sigma: 0.1\n  quantile_lower: 0.05\n"
+      "  quantile_upper: 0.95\n  min_valid_neighbors: 4\n"
+      "feature_extraction:\n  enabled: true\n  analysis_radius: 0.5\n  min_valid_neighbors: 6\n",
+      "test_postprocess_all.yaml"));
+  EXPECT_TRUE(all.inpainting.enabled);
+  EXPECT_EQ(all.inpainting.max_iterations, 5);
+  EXPECT_EQ(all.inpainting.min_valid_neighbors, 3);
+  EXPECT_TRUE(all.uncertainty_fusion.enabled);
+  EXPECT_FLOAT_EQ(all.uncertainty_fusion.search_radius, 0.2f);
+  EXPECT_FLOAT_EQ(all.uncertainty_fusion.spatial_sigma, 0.1f);
+  EXPECT_FLOAT_EQ(all.uncertainty_fusion.quantile_lower, 0.05f);
+  EXPECT_FLOAT_EQ(all.uncertainty_fusion.quantile_upper, 0.95f);
+  EXPECT_EQ(all.uncertainty_fusion.min_valid_neighbors, 4);
+  EXPECT_TRUE(all.feature_extraction.enabled);
+  EXPECT_FLOAT_EQ(all.feature_extraction.analysis_radius, 0.5f);
+  EXPECT_EQ(all.feature_extraction.min_valid_neighbors, 6);
+  const config::PostProcess empty = config::loadPostProcess(writeTempYaml("# empty\n", "test_postprocess_empty.yaml"));
+  EXPECT_FALSE(empty.inpainting.enabled);
+  EXPECT_FALSE(empty.uncertainty_fusion.enabled);
+  EXPECT_FALSE(empty.feature_extraction.enabled);
+  const char* dir = std::getenv("FDM_CONFIG_DIR");
+  const config::PostProcess shipped =
+      config::loadPostProcess(std::string(dir ? dir : "fastdem_amd/config") + "/postprocess.yaml");
+  EXPECT_TRUE(shipped.uncertainty_fusion.enabled);
+  EXPECT_FALSE(shipped.inpainting.enabled);
+  EXPECT_FALSE(shipped.feature_extraction.enabled);
+  // clamping (nothing throws)
+  auto pp = [](const char* text) { return config::parsePostProcess(yaml::parse(text)); };
+  EXPECT_GT(pp("uncertainty_fusion:\n  search_radius: -0.5\n").uncertainty_fusion.search_radius, 0.0f);
+  EXPECT_GT(pp("uncertainty_fusion:\n  spatial_sigma: 0.0\n").uncertainty_fusion.spatial_sigma, 0.0f);
+  const auto inv = pp("uncertainty_fusion:\n  quantile_lower: 0.95\n  quantile_upper: 0.05\n");
+  EXPECT_LT(inv.uncertainty_fusion.quantile_lower, inv.uncertainty_fusion.quantile_upper);
+  EXPECT_GT(pp("feature_extraction:\n  analysis_radius: -1.0\n").feature_extraction.analysis_radius, 0.0f);
+  const auto neg = pp("inpainting:\n  max_iterations: -2\n  min_valid_neighbors: -1\n");
+  EXPECT_GE(neg.inpainting.max_iterations, 1);
+  EXPECT_GE(neg.inpainting.min_valid_neighbors, 1);
+  EXPECT_THROW(config::loadPostProcess("/nonexistent/pp.yaml"), std::runtime_error);
+}
+
 // ---------------------------------------------------------- test_config.cpp (validation) ----
 TEST(Config, DefaultsAndValidation) {  // test_config.cpp:36-344, config_fastdem.cpp:128-260
   Config c;
