@@ -393,186 +393,16 @@ int activate_records(fdm_engine* e, int kind) {
   return FDM_OK;
 }
 
-// ---- raycasting stage (fdm_raycast.hpp) ----
-bool voxel_size_ok(float v) { return v >= 0.001f && v <= 100.0f; }  // voxel_grid_impl.hpp:31-33
-
-// raycasting.cpp:223-226: created on first use; invisible until a frame passed the preconditions
-int ensure_ray_layers(fdm_engine* e) {
-  int rc;
-  for (const char* n : {"ghost_removal", "raycasting", "_visibility_logodds"})
-    if (!find_layer(e, n) && (rc = add_layer(e, n, NAN, true))) return rc;
-  return FDM_OK;
-}
-
-int ensure_ray_cells(fdm_engine* e) {
-  if (e->rc_cnt) return FDM_OK;
-  HIPCK(hipMalloc(reinterpret_cast<void**>(&e->rc_cnt), e->ncell * sizeof(uint32_t)));
-  HIPCK(hipMalloc(reinterpret_cast<void**>(&e->rc_min), e->ncell * sizeof(uint32_t)));
-  const int blocks = int(std::min<size_t>((e->ncell + 255) / 256, 4096));
-  hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, e->stream, e->rc_cnt, 0u, e->ncell);
-  hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, e->stream, e->rc_min, kRayEmpty, e->ncell);
-  HIPCK(hipGetLastError());
-  return FDM_OK;
-}
-
-int ensure_voxel_buffers(fdm_engine* e, size_t n) {
-  if (n <= e->vcap) return FDM_OK;
-  if (int rc_sync = sync_all(e)) return rc_sync;
-  for (int k = 0; k < 2; ++k) {
-    if (e->vkeys[k]) HIPCK(hipFree(e->vkeys[k]));
-    if (e->vidx[k]) HIPCK(hipFree(e->vidx[k]));
-  }
-  if (e->vsel) HIPCK(hipFree(e->vsel));
-  if (e->sort_tmp) HIPCK(hipFree(e->sort_tmp));
-  e->vcap = n + n / 4 + 1024;
-  for (int k = 0; k < 2; ++k) {
-    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->vkeys[k]), e->vcap * sizeof(unsigned long long)));
-    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->vidx[k]), e->vcap * sizeof(uint32_t)));
-  }
-  HIPCK(hipMalloc(reinterpret_cast<void**>(&e->vsel), e->vcap * sizeof(uint32_t)));
-  e->sort_tmp_bytes = 0;
-  HIPCK(rocprim::radix_sort_pairs(nullptr, e->sort_tmp_bytes, e->vkeys[0], e->vkeys[1], e->vidx[0],
-                                  e->vidx[1], e->vcap, 0, 64, e->stream));
-  {  // the compact-key sort reuses the same allocations (uint32 view of the key buffers)
-    size_t b32 = 0;
-    HIPCK(rocprim::radix_sort_pairs(nullptr, b32, reinterpret_cast<uint32_t*>(e->vkeys[0]),
-                                    reinterpret_cast<uint32_t*>(e->vkeys[1]), e->vidx[0], e->vidx[1], e->vcap, 0,
-                                    32, e->stream));
-    e->sort_tmp_bytes = std::max(e->sort_tmp_bytes, b32);
-  }
-  HIPCK(hipMalloc(&e->sort_tmp, e->sort_tmp_bytes ? e->sort_tmp_bytes : 16));
-  return FDM_OK;
-}
-
-// keys -> stable sort: vkeys[1] / vidx[1] hold the voxel-ordered scan afterwards.
-// `box` (nullable): centre + half extent [m] of a box that holds every finite point of the cloud;
-// with it the compact 32-bit key is used when 3 * bits <= 31.  Returns through *compact which key
-// type the sorted buffer holds.
+// ---- raycasting stage: defined in fdm_engine_ray.inl (same translation unit) ----
+bool voxel_size_ok(float v);
+int ensure_ray_layers(fdm_engine* e);
 int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slot, const float* dx,
-                       const float* dy, const float* dz, const double* box, bool* compact) {
-  if (int rc = ensure_voxel_buffers(e, n)) return rc;
-  const float inv = 1.0f / voxel_size;  // voxel_grid_impl.hpp:46
-  VoxelCompact C{0, 0, 0, 0};
-  if (box && std::isfinite(box[3]) && box[3] > 0.0 && box[3] * double(inv) < 4.0e6) {
-    const double half = box[3] + 2.0 * double(voxel_size);  // 2-cell margin for the float transforms
-    const int span = int(std::ceil(2.0 * half * double(inv))) + 4;
-    int bits = 1;
-    while ((1 << bits) < span) ++bits;
-    if (3 * bits <= 62 && bits <= 21) {
-      C.bits = bits;
-      C.x0 = int(std::floor((box[0] - half) * double(inv))) - 1;
-      C.y0 = int(std::floor((box[1] - half) * double(inv))) - 1;
-      C.z0 = int(std::floor((box[2] - half) * double(inv))) - 1;
-    }
-  }
-  *compact = C.bits > 0 && 3 * C.bits <= 31;  // true: the sorted buffer holds uint32 keys
-  size_t bytes = e->sort_tmp_bytes;
-  if (*compact) {
-    uint32_t* k0 = reinterpret_cast<uint32_t*>(e->vkeys[0]);
-    uint32_t* k1 = reinterpret_cast<uint32_t*>(e->vkeys[1]);
-    hipLaunchKernelGGL(k_voxel_keys<uint32_t>, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, inv, flag_slot, C,
-                       e->d_state, dx, dy, dz, k0, e->vidx[0], e->vsel);
-    HIPCK(hipGetLastError());
-    // bits 3*bits .. 31 are zero in every valid key and one in the invalid key (all ones): sorting
-    // one bit past the fields is enough to keep the dropped points behind every voxel
-    HIPCK(rocprim::radix_sort_pairs(e->sort_tmp, bytes, k0, k1, e->vidx[0], e->vidx[1], size_t(n), 0,
-                                    unsigned(3 * C.bits + 1), e->stream));
-  } else {
-    hipLaunchKernelGGL(k_voxel_keys<unsigned long long>, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, inv,
-                       flag_slot, C, e->d_state, dx, dy, dz, e->vkeys[0], e->vidx[0], e->vsel);
-    HIPCK(hipGetLastError());
-    HIPCK(rocprim::radix_sort_pairs(e->sort_tmp, bytes, e->vkeys[0], e->vkeys[1], e->vidx[0], e->vidx[1],
-                                    size_t(n), 0, C.bits > 0 ? unsigned(3 * C.bits + 1) : 64u, e->stream));
-  }
-  return FDM_OK;
-}
-
-fdm_raycast_config ray_config_of(const fdm_config& c) {
-  fdm_raycast_config r;
-  r.enabled = c.raycast_enabled;
-  r.height_conflict_threshold = c.rc_height_conflict_threshold;
-  r.log_odds_observed = c.rc_log_odds_observed;
-  r.log_odds_ghost = c.rc_log_odds_ghost;
-  r.log_odds_max = c.rc_log_odds_max;
-  r.clear_threshold = c.rc_clear_threshold;
-  return r;
-}
-
+                       const float* dy, const float* dz, const double* box, bool* compact);
+fdm_raycast_config ray_config_of(const fdm_config& c);
 RayParams make_ray_params(fdm_engine* e, const fdm_raycast_config& c, const float* origin, unsigned n,
-                          int slot, int flag_slot) {
-  RayParams Q{};
-  Q.ox = origin[0]; Q.oy = origin[1]; Q.oz = origin[2];
-  Q.l_obs = c.log_odds_observed;
-  Q.l_ghost = c.log_odds_ghost;
-  Q.l_max = c.log_odds_max;
-  Q.clear_thr = c.clear_threshold;
-  Q.conflict_thr = c.height_conflict_threshold;
-  Q.resolution = static_cast<float>(e->G.res);
-  Q.inv_voxel = 1.0f / Q.resolution;
-  Q.n = n;
-  Q.slot = slot;
-  Q.flag_slot = flag_slot;
-  Q.vis_stamp = 3u * unsigned(e->scan_no) + (flag_slot >= 0 ? 3u : 1u);
-  Q.dbg = e->dbg_ray;
-  return Q;
-}
-
-// processScan + resolveGhostCells on the stream.  voxel: the points are vkeys[1]/vidx[1] runs.
+                          int slot, int flag_slot);
 int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float* dx, const float* dy,
-                      const float* dz, bool compact_keys = false) {
-  int rc;
-  if ((rc = ensure_ray_cells(e))) return rc;
-  Layer* elev = find_layer(e, "elevation");
-  if (!elev) return FDM_OK;  // raycasting.cpp:213-216
-  RayLayers L{};
-  L.elevation = lptr(e, *elev);
-  L.elevation_stride = lstride(e, *elev);
-  L.logodds = find_layer(e, "_visibility_logodds")->d;
-  L.ray_min = find_layer(e, "raycasting")->d;
-  L.ghost = find_layer(e, "ghost_removal")->d;
-  L.rec = e->d_rec;
-  L.rec_floats = e->rec_floats;
-  const unsigned blocks = (Q.n + 255u) / 256u;
-  if ((rc = ensure_voxel_buffers(e, Q.n))) return rc;  // vidx[0] doubles as the ray queue
-  uint32_t* ray_list = e->vidx[0];
-  if (voxel) {
-    if (compact_keys)
-      hipLaunchKernelGGL(k_voxel_mark<uint32_t>, dim3(blocks), dim3(256), 0, e->stream, Q.n,
-                         reinterpret_cast<const uint32_t*>(e->vkeys[1]), e->vidx[1], e->vsel);
-    else
-      hipLaunchKernelGGL(k_voxel_mark<unsigned long long>, dim3(blocks), dim3(256), 0, e->stream, Q.n,
-                         e->vkeys[1], e->vidx[1], e->vsel);
-    hipLaunchKernelGGL(k_ray_compact<true>, dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx,
-                       dy, dz, e->vsel, e->rc_cnt, ray_list);
-  } else {
-    hipLaunchKernelGGL(k_ray_compact<false>, dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx,
-                       dy, dz, static_cast<const uint32_t*>(nullptr), e->rc_cnt, ray_list);
-  }
-  HIPCK(hipGetLastError());
-  const bool tiled = e->G.o_rows != e->G.rows || e->G.o_cols != e->G.cols || e->G.s_rows != e->G.rows ||
-                     e->G.s_cols != e->G.cols;
-  auto launch_ray = [&](auto kern, unsigned seg) {
-    // upper bound of the queue: every point a ray, padded to whole wavefronts per segment
-    const unsigned threads = ((Q.n + 63u) & ~63u) * seg;
-    hipLaunchKernelGGL(kern, dim3((threads + 255u) / 256u), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx, dy,
-                       dz, ray_list, e->rc_min);
-  };
-  // small scans are a few hundred wavefronts of dependent round trips: 16 / 8 lanes share a ray
-  // (C2: k_ray 60 -> 25 (8) -> 16 us (16)); the point count bounds the ray count from above
-  if (Q.n < (1u << 16)) {
-    tiled ? launch_ray(k_ray<true, 16>, 16u) : launch_ray(k_ray<false, 16>, 16u);
-  } else if (Q.n < (1u << 20)) {
-    tiled ? launch_ray(k_ray<true, 8>, 8u) : launch_ray(k_ray<false, 8>, 8u);
-  } else {
-    tiled ? launch_ray(k_ray<true, 1>, 1u) : launch_ray(k_ray<false, 1>, 1u);
-  }
-  HIPCK(hipGetLastError());
-  hipLaunchKernelGGL(k_ray_resolve, dim3(unsigned((e->ncell + 255) / 256)), dim3(256), 0, e->stream, Q,
-                     e->G, e->d_state, L, e->d_layer_ptrs, e->n_layer_ptrs, e->rc_cnt, e->rc_min,
-                     unsigned(e->ncell));
-  HIPCK(hipGetLastError());
-  return FDM_OK;
-}
+                      const float* dz, bool compact_keys = false);
 
 // One scan = k_bin + k_update on the stream.  All pointers are device pointers.
 int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, const float* dy,
@@ -1641,499 +1471,6 @@ int fdm_engine_enable_profile(fdm_engine* e, int on) {
   return FDM_OK;
 }
 
-// ---- stencil post-processing ----
-namespace {
-// Spatial tiles: a stencil that reaches `need` cells is exact on the owned cells iff every window side
-// that is not a map side carries a halo at least that wide.
-int check_halo(const fdm_engine* e, int need) {
-  const GeomConst& G = e->G;
-  const int top = G.o_r0 - G.s_r0, left = G.o_c0 - G.s_c0;
-  const int bottom = (G.s_r0 + G.s_rows) - (G.o_r0 + G.o_rows), right = (G.s_c0 + G.s_cols) - (G.o_c0 + G.o_cols);
-  const bool ok = (G.s_r0 == 0 || top >= need) && (G.s_c0 == 0 || left >= need) &&
-                  (G.s_r0 + G.s_rows == G.rows || bottom >= need) && (G.s_c0 + G.s_cols == G.cols || right >= need);
-  if (!ok) return fail(FDM_ERR_INVALID, "tile halo narrower than the stencil (" + std::to_string(need) + " cells needed)");
-  return FDM_OK;
-}
-// neighbourhood offsets, dr-major / dc-minor; box = region(Size(k,k)), disc = region(radius)
-int upload_region(fdm_engine* e, const std::vector<RegionEntry>& reg) {
-  if (reg.size() > size_t(kMaxRegion)) return fail(FDM_ERR_INVALID, "neighbourhood larger than 256 cells");
-  if (!e->d_region) HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_region), kMaxRegion * sizeof(RegionEntry)));
-  HIPCK(hipMemcpyAsync(e->d_region, reg.data(), reg.size() * sizeof(RegionEntry), hipMemcpyHostToDevice, e->stream));
-  if (int rc_sync = sync_all(e)) return rc_sync;  // `reg` is a host temporary
-  return FDM_OK;
-}
-void region_disc(const fdm_engine* e, float radius, std::vector<RegionEntry>& reg) {
-  reg.clear();
-  const float res = static_cast<float>(e->G.res);
-  const int k = static_cast<int>(std::floor(radius / res + 1e-4f));
-  const float r2 = radius * radius;
-  for (int dr = -k; dr <= k; ++dr)
-    for (int dc = -k; dc <= k; ++dc) {
-      const float d2 = static_cast<float>(dr * dr + dc * dc) * (res * res);
-      if (d2 <= r2 * (1.0f + 1e-5f)) reg.push_back({dr, dc, d2, 0.f});
-    }
-}
-unsigned cell_blocks(const fdm_engine* e) { return unsigned((e->ncell + 255) / 256); }
-int ensure_tmp2(fdm_engine* e) {
-  if (!e->d_tmp2) HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_tmp2), e->ncell * sizeof(float)));
-  return FDM_OK;
-}
-}  // namespace
-
-int fdm_engine_apply_inpainting(fdm_engine* e, int max_iterations, int min_valid, int inplace) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e) return fail(FDM_ERR_INVALID, "null engine");
-  HIPCK(hipSetDevice(e->device));
-  int rc;
-  if ((rc = check_halo(e, max_iterations > 0 ? max_iterations : 0))) return rc;  // one cell per pass
-  if ((rc = resolve_pending(e))) return rc;
-  Layer* elev = find_layer(e, "elevation");
-  if (!elev) return fail(FDM_ERR_NO_LAYER, "no layer elevation");
-  const char* out_name = inplace ? "elevation" : "elevation_inpainted";
-  if (!find_layer(e, out_name) && (rc = add_layer(e, out_name, NAN, false))) return rc;
-  elev = find_layer(e, "elevation");
-  Layer* out = find_layer(e, out_name);
-  if ((rc = ensure_tmp(e))) return rc;
-  float* A = lptr(e, *out);
-  const int As = lstride(e, *out);
-  float* B = e->d_tmp;
-  const int slot = int(e->scan_no & 3);
-  // `inpainted = elevation`, then up to max_iterations passes ping-ponging output layer <-> staging;
-  // the reference stops after a pass that changed nothing — further passes are identities, so all
-  // of them are simply run.  The copy goes to whichever side makes the LAST pass land in the layer.
-  const int iters = max_iterations > 0 ? max_iterations : 0;
-  const bool start_in_layer = (iters % 2) == 0;
-  if (!inplace || !start_in_layer) {
-    if ((rc = copy_strided(e, start_in_layer ? A : B, start_in_layer ? As : 1, lptr(e, *elev), lstride(e, *elev))))
-      return rc;
-  }
-  bool in_layer = start_in_layer;
-  for (int it = 0; it < iters; ++it) {
-    hipLaunchKernelGGL(k_inpaint_pass, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state, slot,
-                       in_layer ? A : B, in_layer ? As : 1, in_layer ? B : A, in_layer ? 1 : As, min_valid,
-                       unsigned(e->ncell));
-    in_layer = !in_layer;
-  }
-  HIPCK(hipGetLastError());
-  return FDM_OK;
-}
-
-int fdm_engine_apply_spatial_smoothing(fdm_engine* e, const char* layer, int kernel_size, int min_valid) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e || !layer) return fail(FDM_ERR_INVALID, "null argument");
-  if (kernel_size < 1 || kernel_size > 15 || (kernel_size & 1) == 0)
-    return fail(FDM_ERR_INVALID, "kernel_size must be odd and in [1, 15]");
-  HIPCK(hipSetDevice(e->device));
-  int rc;
-  if ((rc = check_halo(e, kernel_size / 2))) return rc;
-  if ((rc = resolve_pending(e))) return rc;
-  Layer* l = find_layer(e, layer);
-  if (!l || l->pending) return FDM_OK;  // spatial_smoothing.hpp:42
-  if ((rc = ensure_tmp(e))) return rc;
-  if ((rc = copy_strided(e, e->d_tmp, 1, lptr(e, *l), lstride(e, *l)))) return rc;  // the double buffer
-  hipLaunchKernelGGL(k_median, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state,
-                     int(e->scan_no & 3), e->d_tmp, lptr(e, *l), lstride(e, *l), kernel_size, min_valid,
-                     unsigned(e->ncell));
-  HIPCK(hipGetLastError());
-  if (std::strcmp(layer, "obstacle") == 0) e->obst_dense_pending = true;
-  return FDM_OK;
-}
-
-int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* cfg) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e || !cfg) return fail(FDM_ERR_INVALID, "null argument");
-  if (!cfg->enabled) return FDM_OK;
-  HIPCK(hipSetDevice(e->device));
-  int rc;
-  if ((rc = check_halo(e, int(std::floor(cfg->search_radius / static_cast<float>(e->G.res) + 1e-4f))))) return rc;
-  if ((rc = resolve_pending(e))) return rc;
-  Layer* up = find_layer(e, "upper_bound");
-  Layer* lo = find_layer(e, "lower_bound");
-  if (!up || !lo) return FDM_OK;  // uncertainty_fusion.cpp:108-113: warn + return
-  std::vector<RegionEntry> reg;
-  region_disc(e, cfg->search_radius, reg);
-  {  // spatial weight of each offset (uncertainty_fusion.cpp:122-123,158): std::exp on a float
-    const float inv_2s2 = 1.0f / (2.0f * cfg->spatial_sigma * cfg->spatial_sigma);
-    for (auto& r : reg) r.w = std::exp(-r.dist_sq * inv_2s2);
-  }
-  if ((rc = upload_region(e, reg))) return rc;
-  if ((rc = ensure_tmp(e)) || (rc = ensure_tmp2(e))) return rc;
-  if ((rc = copy_strided(e, e->d_tmp, 1, lptr(e, *up), lstride(e, *up)))) return rc;
-  if ((rc = copy_strided(e, e->d_tmp2, 1, lptr(e, *lo), lstride(e, *lo)))) return rc;
-  FusionParams F{};
-  F.inv_2s2 = 1.0f / (2.0f * cfg->spatial_sigma * cfg->spatial_sigma);
-  F.q_lower = cfg->quantile_lower;
-  F.q_upper = cfg->quantile_upper;
-  F.min_valid = cfg->min_valid_neighbors;
-  F.n_entries = int(reg.size());
-  const unsigned fblocks = unsigned((e->ncell + kFusionThreads - 1) / kFusionThreads);
-  if (int(reg.size()) <= kFusionLdsEntries) {  // sample lists in LDS
-    const size_t lds = size_t(4) * reg.size() * kFusionThreads * sizeof(float);
-    static bool raised = false;
-    if (!raised) {
-      HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fusion<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                int(size_t(4) * kFusionLdsEntries * kFusionThreads * sizeof(float))));
-      raised = true;
-    }
-    hipLaunchKernelGGL(k_fusion<true>, dim3(fblocks), dim3(kFusionThreads), lds, e->stream, e->G, e->d_state,
-                       int(e->scan_no & 3), e->d_region, F, e->d_tmp, e->d_tmp2, lptr(e, *up), lstride(e, *up),
-                       lptr(e, *lo), lstride(e, *lo), unsigned(e->ncell));
-  } else {
-    hipLaunchKernelGGL(k_fusion<false>, dim3(fblocks), dim3(kFusionThreads), 0, e->stream, e->G, e->d_state,
-                       int(e->scan_no & 3), e->d_region, F, e->d_tmp, e->d_tmp2, lptr(e, *up), lstride(e, *up),
-                       lptr(e, *lo), lstride(e, *lo), unsigned(e->ncell));
-  }
-  HIPCK(hipGetLastError());
-  return FDM_OK;
-}
-
-int fdm_engine_apply_feature_extraction(fdm_engine* e, float radius, int min_valid, float lo_pct, float hi_pct) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e) return fail(FDM_ERR_INVALID, "null engine");
-  HIPCK(hipSetDevice(e->device));
-  int rc;
-  if ((rc = check_halo(e, int(std::floor(radius / static_cast<float>(e->G.res) + 1e-4f))))) return rc;
-  if ((rc = resolve_pending(e))) return rc;
-  if (!find_layer(e, "elevation")) return FDM_OK;  // feature_extraction.cpp:33
-  const char* names[7] = {"step", "slope", "roughness", "curvature", "_normal_x", "_normal_y", "_normal_z"};
-  for (const char* n : names)
-    if (!find_layer(e, n) && (rc = add_layer(e, n, NAN, false))) return rc;
-  std::vector<RegionEntry> reg;
-  region_disc(e, radius, reg);
-  if ((rc = upload_region(e, reg))) return rc;
-  Layer* elev = find_layer(e, "elevation");
-  FeatureParams F{};
-  F.resf = static_cast<float>(e->G.res);
-  F.lo_pct = lo_pct;
-  F.hi_pct = hi_pct;
-  F.min_valid = min_valid;
-  F.n_entries = int(reg.size());
-  FeatureOut O{};
-  float** outs[7] = {&O.step, &O.slope, &O.roughness, &O.curvature, &O.nx, &O.ny, &O.nz};
-  for (int k = 0; k < 7; ++k) *outs[k] = find_layer(e, names[k])->d;
-  // order statistics needed by `step`: index lo from the bottom, (count-1-hi) from the top; both grow
-  // with count, so the full region bounds them
-  const int nmax = int(reg.size());
-  const int need_lo = nmax > 0 ? static_cast<int>(lo_pct * float(nmax - 1)) + 1 : 1;
-  const int need_hi = nmax > 0 ? (nmax - 1) - static_cast<int>(hi_pct * float(nmax - 1)) + 1 : 1;
-  const bool pct_ok = lo_pct >= 0.0f && hi_pct <= 1.0f && lo_pct <= 1.0f && hi_pct >= 0.0f;
-  auto launch_feat = [&](auto kern) {
-    hipLaunchKernelGGL(kern, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state, int(e->scan_no & 3),
-                       e->d_region, F, lptr(e, *elev), lstride(e, *elev), O, unsigned(e->ncell));
-  };
-  if (pct_ok && need_lo <= 16 && need_hi <= 16) launch_feat(k_features<16>);
-  else launch_feat(k_features<0>);
-  HIPCK(hipGetLastError());
-  return FDM_OK;
-}
-
-// ---- ingest ----
-int fdm_engine_ingest_cloud2(fdm_engine* e, const void* data, int on_device, uint64_t n_points,
-                             const fdm_cloud2_layout* lay, uint64_t* n_valid) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e || !lay) return fail(FDM_ERR_INVALID, "null argument");
-  if (n_valid) *n_valid = 0;
-  e->in_n = 0;
-  e->in_has_int = e->in_has_rgb = false;
-  if (n_points == 0) return FDM_OK;                                        // impl.hpp:178-181
-  if (lay->off_x < 0 || lay->off_y < 0 || lay->off_z < 0) return FDM_OK;   // impl.hpp:183-186: no xyz
-  if (!data) return fail(FDM_ERR_INVALID, "null data");
-  if (n_points >= 0xFFFFFFFEull) return fail(FDM_ERR_INVALID, "point count exceeds 2^32-2");
-  const uint32_t step = lay->point_step;
-  auto fits = [&](int32_t off, uint32_t len) { return off < 0 || uint64_t(off) + len <= step; };
-  const uint32_t ilen = lay->intensity_type == 8 ? 8 : (lay->intensity_type == 7 ? 4 : (lay->intensity_type == 4 ? 2 : 1));
-  if (step == 0 || !fits(lay->off_x, 4) || !fits(lay->off_y, 4) || !fits(lay->off_z, 4) ||
-      !fits(lay->off_intensity, ilen) || !fits(lay->off_rgb, 4))
-    return fail(FDM_ERR_INVALID, "field offset outside the point record");
-  HIPCK(hipSetDevice(e->device));
-  const size_t bytes = size_t(n_points) * step;
-  const uint8_t* blob = static_cast<const uint8_t*>(data);
-  if (!on_device) {
-    if (bytes > e->blob_cap) {
-      if (int rc_sync = sync_all(e)) return rc_sync;
-      if (e->d_blob) HIPCK(hipFree(e->d_blob));
-      e->blob_cap = bytes + bytes / 4 + 4096;
-      HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_blob), e->blob_cap));
-    }
-    HIPCK(hipMemcpyAsync(e->d_blob, data, bytes, hipMemcpyHostToDevice, e->stream));
-    blob = e->d_blob;
-  }
-  if (n_points > e->in_cap) {
-    if (int rc_sync = sync_all(e)) return rc_sync;
-    if (e->d_in) HIPCK(hipFree(e->d_in));
-    e->in_cap = ((n_points + n_points / 4 + 1024) + 3) & ~size_t(3);  // channels stay 16-byte aligned
-    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_in), e->in_cap * 5 * sizeof(float)));
-  }
-  IngestLayout L{};
-  L.point_step = step;
-  L.off_x = lay->off_x; L.off_y = lay->off_y; L.off_z = lay->off_z;
-  L.off_intensity = lay->off_intensity; L.intensity_type = lay->intensity_type;
-  L.off_rgb = lay->off_rgb;
-  auto al4 = [](int32_t off) { return off < 0 || (off & 3) == 0; };
-  L.aligned = (reinterpret_cast<uintptr_t>(blob) & 3u) == 0 && (step & 3u) == 0 && al4(L.off_x) && al4(L.off_y) &&
-              al4(L.off_z) && al4(L.off_rgb) && (L.intensity_type < 7 || al4(L.off_intensity));
-  const unsigned blocks = unsigned((n_points + 255) / 256);
-  if (size_t(blocks) + 1 > e->pack_counts_cap) {
-    if (int rc_sync = sync_all(e)) return rc_sync;
-    if (e->pack_counts) HIPCK(hipFree(e->pack_counts));
-    e->pack_counts_cap = size_t(blocks) + 1 + 1024;
-    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->pack_counts), e->pack_counts_cap * sizeof(uint32_t)));
-  }
-  const bool hi = lay->off_intensity >= 0, hc = lay->off_rgb >= 0;
-  hipLaunchKernelGGL(k_ingest_count, dim3(blocks), dim3(256), 0, e->stream, blob, L, n_points, e->pack_counts);
-  hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, e->stream, e->pack_counts, blocks);
-  hipLaunchKernelGGL(k_ingest_write, dim3(blocks), dim3(256), 0, e->stream, blob, L, n_points, e->pack_counts,
-                     e->d_in, e->d_in + e->in_cap, e->d_in + 2 * e->in_cap,
-                     hi ? e->d_in + 3 * e->in_cap : static_cast<float*>(nullptr),
-                     hc ? reinterpret_cast<uint32_t*>(e->d_in + 4 * e->in_cap) : static_cast<uint32_t*>(nullptr));
-  HIPCK(hipGetLastError());
-  uint32_t total = 0;
-  HIPCK(hipMemcpyAsync(&total, e->pack_counts + blocks, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-  if (int rc_sync = sync_all(e)) return rc_sync;
-  e->in_n = total;
-  e->in_has_int = hi;
-  e->in_has_rgb = hc;
-  if (n_valid) *n_valid = total;
-  return FDM_OK;
-}
-
-int fdm_engine_ingested(fdm_engine* e, const float** dx, const float** dy, const float** dz,
-                        const float** dint, const uint32_t** drgb, uint64_t* n) {
-  if (!e) return fail(FDM_ERR_INVALID, "null engine");
-  if (dx) *dx = e->d_in;
-  if (dy) *dy = e->d_in ? e->d_in + e->in_cap : nullptr;
-  if (dz) *dz = e->d_in ? e->d_in + 2 * e->in_cap : nullptr;
-  if (dint) *dint = e->in_has_int ? e->d_in + 3 * e->in_cap : nullptr;
-  if (drgb) *drgb = e->in_has_rgb ? reinterpret_cast<const uint32_t*>(e->d_in + 4 * e->in_cap) : nullptr;
-  if (n) *n = e->in_n;
-  return FDM_OK;
-}
-
-int fdm_engine_integrate_cloud2(fdm_engine* e, const void* data, int on_device, uint64_t n_points,
-                                const fdm_cloud2_layout* lay, const double Tbs[16], const double Twb[16],
-                                fdm_scan_stats* out) {
-  if (e) { if (int rc_join = join_streams(e)) return rc_join; }
-  if (!e || !lay || !Tbs || !Twb) return fail(FDM_ERR_INVALID, "null argument");
-  uint64_t n = 0;
-  int rc = fdm_engine_ingest_cloud2(e, data, on_device, n_points, lay, &n);
-  if (rc) return rc;
-  if (n == 0) {  // fastdem.cpp:125-128
-    if (out) std::memset(out, 0, sizeof(*out));
-    return FDM_SKIP_EMPTY_CLOUD;
-  }
-  const float *dx, *dy, *dz, *di;
-  const uint32_t* dc;
-  fdm_engine_ingested(e, &dx, &dy, &dz, &di, &dc, nullptr);
-  ScanParams P;
-  fill_integrate_params(e, P, Tbs, Twb);
-  if ((rc = enqueue_scan(e, P, n, dx, dy, dz, di, dc, nullptr))) return rc;
-  int status = FDM_OK;
-  if ((rc = read_stats(e, out, &status))) return rc;
-  return status;
-}
-
-// ---- map egress ----
-namespace {
-struct PackPlan {
-  PackParams Q{};
-  PackLayers L{};
-  std::vector<std::string> fields;
-  unsigned long long total = 0;
-  unsigned blocks = 0;
-};
-
-int plan_pack(fdm_engine* e, const char* elevation_layer, int32_t r0, int32_t c0, int32_t nr, int32_t nc,
-              PackPlan& pl) {
-  if (int rc = resolve_pending(e)) return rc;
-  Layer* elev = find_layer(e, elevation_layer);
-  if (!elev || elev->pending) return fail(FDM_ERR_NO_LAYER, std::string("no layer ") + elevation_layer);
-  if (nr >= 0) {
-    if (r0 < 0 || c0 < 0 || r0 >= e->G.rows || c0 >= e->G.cols || nr > e->G.rows || nc < 0 || nc > e->G.cols)
-      return fail(FDM_ERR_INVALID, "submap outside the buffer");
-  }
-  pl.Q.sub_r0 = r0; pl.Q.sub_c0 = c0; pl.Q.sub_rows = nr; pl.Q.sub_cols = nc;
-  pl.Q.slot = int(e->scan_no & 3);
-  pl.L.elev = lptr(e, *elev);
-  pl.L.elev_stride = lstride(e, *elev);
-  pl.fields = {"x", "y", "z"};
-  int nf = 0;
-  const Layer* color = nullptr;
-  for (auto& l : e->layers) {  // impl.hpp:66-77
-    if (l.pending) continue;
-    if (!l.name.empty() && l.name[0] == '_') continue;
-    if (l.name == elevation_layer) continue;
-    if (l.name == "color") { color = &l; continue; }
-    if (nf >= kPackMaxFields) return fail(FDM_ERR_INVALID, "too many layers to pack");
-    pl.L.ptr[nf] = lptr(e, l);
-    pl.L.stride[nf] = lstride(e, l);
-    pl.fields.push_back(l.name);
-    ++nf;
-  }
-  pl.Q.n_float = nf;
-  pl.Q.has_color = color ? 1 : 0;
-  pl.L.color = color ? color->d : nullptr;
-  if (color) pl.fields.push_back("rgb");
-  pl.total = nr < 0 ? (unsigned long long)e->G.rows * e->G.cols : (unsigned long long)nr * nc;
-  pl.blocks = unsigned((pl.total + 255) / 256);
-  return FDM_OK;
-}
-
-// count + scan; returns the number of valid cells (host sync)
-int pack_count(fdm_engine* e, const PackPlan& pl, uint64_t* n_points) {
-  *n_points = 0;
-  if (pl.total == 0) return FDM_OK;
-  if (size_t(pl.blocks) + 1 > e->pack_counts_cap) {
-    if (int rc_sync = sync_all(e)) return rc_sync;
-    if (e->pack_counts) HIPCK(hipFree(e->pack_counts));
-    e->pack_counts_cap = size_t(pl.blocks) + 1 + 1024;
-    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->pack_counts), e->pack_counts_cap * sizeof(uint32_t)));
-  }
-  hipLaunchKernelGGL(k_pack_count, dim3(pl.blocks), dim3(256), 0, e->stream, pl.Q, e->G, e->d_state, pl.L,
-                     e->pack_counts);
-  hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, e->stream, e->pack_counts, pl.blocks);
-  HIPCK(hipGetLastError());
-  uint32_t total = 0;
-  HIPCK(hipMemcpyAsync(&total, e->pack_counts + pl.blocks, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-  if (int rc_sync = sync_all(e)) return rc_sync;
-  *n_points = total;
-  return FDM_OK;
-}
-
-int pack_write(fdm_engine* e, const PackPlan& pl, uint64_t n_points) {
-  const size_t need = size_t(n_points) * pl.fields.size();
-  if (need > e->pack_cap) {
-    if (e->d_pack) HIPCK(hipFree(e->d_pack));
-    e->pack_cap = need + need / 8 + 1024;
-    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_pack), e->pack_cap * sizeof(float)));
-  }
-  if (n_points == 0) return FDM_OK;
-  const size_t lds = 256 * pl.fields.size() * sizeof(float);  // <= 256 * 68 * 4 = 68 KB of the CU's 160 KB
-  hipLaunchKernelGGL(k_pack_write, dim3(pl.blocks), dim3(256), lds, e->stream, pl.Q, e->G, e->d_state, pl.L,
-                     e->pack_counts, e->d_pack);
-  HIPCK(hipGetLastError());
-  return FDM_OK;
-}
-
-void write_fields(const PackPlan& pl, char* buf, uint64_t cap) {
-  if (!buf || !cap) return;
-  std::string joined;
-  for (size_t k = 0; k < pl.fields.size(); ++k) joined += (k ? "\n" : "") + pl.fields[k];
-  std::snprintf(buf, cap, "%s", joined.c_str());
-}
-}  // namespace
-
-int fdm_engine_pack_cloud_device(fdm_engine* e, const char* elevation_layer, int32_t r0, int32_t c0,
-                                 int32_t nr, int32_t nc, void** d_out, uint64_t* n_points,
-                                 uint32_t* point_step) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e || !elevation_layer || !n_points) return fail(FDM_ERR_INVALID, "null argument");
-  HIPCK(hipSetDevice(e->device));
-  PackPlan pl;
-  int rc;
-  if ((rc = plan_pack(e, elevation_layer, r0, c0, nr, nc, pl))) return rc;
-  if (point_step) *point_step = uint32_t(pl.fields.size() * 4);
-  if ((rc = pack_count(e, pl, n_points))) return rc;
-  if ((rc = pack_write(e, pl, *n_points))) return rc;
-  if (d_out) *d_out = e->d_pack;
-  return FDM_OK;
-}
-
-int fdm_engine_pack_cloud(fdm_engine* e, const char* elevation_layer, int32_t r0, int32_t c0, int32_t nr,
-                          int32_t nc, void* host_out, uint64_t cap_bytes, uint64_t* n_points,
-                          uint32_t* point_step, char* fields_buf, uint64_t fields_cap) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e || !elevation_layer || !n_points) return fail(FDM_ERR_INVALID, "null argument");
-  HIPCK(hipSetDevice(e->device));
-  PackPlan pl;
-  int rc;
-  if ((rc = plan_pack(e, elevation_layer, r0, c0, nr, nc, pl))) return rc;
-  if (point_step) *point_step = uint32_t(pl.fields.size() * 4);
-  write_fields(pl, fields_buf, fields_cap);
-  if ((rc = pack_count(e, pl, n_points))) return rc;
-  const uint64_t bytes = *n_points * pl.fields.size() * 4;
-  if (!host_out || cap_bytes < bytes || bytes == 0) return FDM_OK;
-  if ((rc = pack_write(e, pl, *n_points))) return rc;
-  HIPCK(hipMemcpyAsync(host_out, e->d_pack, bytes, hipMemcpyDeviceToHost, e->stream));
-  if (int rc_sync = sync_all(e)) return rc_sync;
-  return FDM_OK;
-}
-
-// ---- raycasting entry points ----
-int fdm_engine_apply_raycasting_device(fdm_engine* e, uint64_t n, const float* dx, const float* dy,
-                                       const float* dz, const float origin[3],
-                                       const fdm_raycast_config* rcfg) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e || !origin) return fail(FDM_ERR_INVALID, "null argument");
-  const fdm_raycast_config c = rcfg ? *rcfg : ray_config_of(e->cfg);
-  if (!c.enabled || n == 0) return FDM_OK;  // raycasting.cpp:207-209
-  if (!dx || !dy || !dz) return fail(FDM_ERR_INVALID, "null xyz");
-  if (n >= 0xFFFFFFFEull) return fail(FDM_ERR_INVALID, "point count exceeds 2^32-2");
-  HIPCK(hipSetDevice(e->device));
-  int rc;
-  if (!find_layer(e, "elevation")) return FDM_OK;
-  if ((rc = ensure_ray_layers(e))) return rc;
-  if ((rc = refresh_layer_ptrs(e))) return rc;
-  const RayParams Q = make_ray_params(e, c, origin, unsigned(n), int(e->scan_no & 3), -1);
-  return enqueue_ray_stage(e, Q, false, dx, dy, dz);
-}
-
-int fdm_engine_apply_raycasting(fdm_engine* e, uint64_t n, const float* x, const float* y,
-                                const float* z, const float origin[3], const fdm_raycast_config* rcfg) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e || !origin) return fail(FDM_ERR_INVALID, "null argument");
-  if (!(rcfg ? rcfg->enabled : e->cfg.raycast_enabled) || n == 0) return FDM_OK;
-  if (!x || !y || !z) return fail(FDM_ERR_INVALID, "null xyz");
-  HIPCK(hipSetDevice(e->device));
-  const float *dx, *dy, *dz, *da, *dv;
-  const uint32_t* dc;
-  int rc = stage_inputs(e, n, x, y, z, nullptr, nullptr, nullptr, &dx, &dy, &dz, &da, &dc, &dv);
-  if (rc) return rc;
-  if ((rc = fdm_engine_apply_raycasting_device(e, n, dx, dy, dz, origin, rcfg))) return rc;
-  if (int rc_sync = sync_all(e)) return rc_sync;
-  return FDM_OK;
-}
-
-int fdm_engine_voxel_any(fdm_engine* e, uint64_t n, const float* x, const float* y, const float* z,
-                         float voxel_size, uint32_t* out_idx, uint64_t* n_out) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e || !n_out) return fail(FDM_ERR_INVALID, "null argument");
-  *n_out = 0;
-  if (!voxel_size_ok(voxel_size)) return fail(FDM_ERR_INVALID, "voxel_size must be in [0.001, 100]");
-  if (n == 0) return FDM_OK;
-  if (!x || !y || !z || !out_idx) return fail(FDM_ERR_INVALID, "null argument");
-  if (n >= 0xFFFFFFFEull) return fail(FDM_ERR_INVALID, "point count exceeds 2^32-2");
-  HIPCK(hipSetDevice(e->device));
-  const float *dx, *dy, *dz, *da, *dv;
-  const uint32_t* dc;
-  int rc = stage_inputs(e, n, x, y, z, nullptr, nullptr, nullptr, &dx, &dy, &dz, &da, &dc, &dv);
-  if (rc) return rc;
-  bool compact = false;
-  if ((rc = enqueue_voxel_sort(e, unsigned(n), voxel_size, -1, dx, dy, dz, nullptr, &compact))) return rc;
-  hipLaunchKernelGGL(k_voxel_select, dim3(unsigned((n + 255) / 256)), dim3(256), 0, e->stream, unsigned(n),
-                     e->vkeys[1], e->vidx[1], e->vsel);
-  HIPCK(hipGetLastError());
-  std::vector<uint32_t> h(n);
-  HIPCK(hipMemcpyAsync(h.data(), e->vsel, n * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-  if (int rc_sync = sync_all(e)) return rc_sync;
-  uint64_t w = 0;
-  for (uint64_t i = 0; i < n; ++i)  // order-preserving compaction = marshalling
-    if (h[i] != kNoIdx) out_idx[w++] = h[i];
-  *n_out = w;
-  return FDM_OK;
-}
-
-int fdm_engine_last_ray_ms(fdm_engine* e, float* ms) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e || !ms) return fail(FDM_ERR_INVALID, "null argument");
-  if (!e->profile) return fail(FDM_ERR_INVALID, "profiling is off");
-  *ms = 0.f;
-  if (!e->ray_timed) return FDM_OK;
-  if (int rc_sync = sync_all(e)) return rc_sync;
-  HIPCK(hipEventElapsedTime(ms, e->ev_ray[0], e->ev_ray[1]));
-  return FDM_OK;
-}
-
 int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2) {
   if (!e || !ms2) return fail(FDM_ERR_INVALID, "null argument");
   if (!e->profile) return fail(FDM_ERR_INVALID, "profiling is off");
@@ -2202,3 +1539,9 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
 }
 
 }  // extern "C"
+
+// The stages either side of the hot path, same translation unit (they share the engine struct and
+// the helpers above): raycasting, stencil post-processing, PointCloud2 ingest / map egress.
+#include "fdm_engine_ray.inl"
+#include "fdm_engine_post.inl"
+#include "fdm_engine_io.inl"

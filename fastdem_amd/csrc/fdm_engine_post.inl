@@ -1,0 +1,194 @@
+// fdm_engine_post.inl — host side of the stencil post-processing stages (kernels: fdm_post.hpp).
+// Part of fdm_engine.hip's translation unit (included at its end): do not compile on its own.
+
+extern "C" {
+
+// ---- stencil post-processing ----
+namespace {
+// Spatial tiles: a stencil that reaches `need` cells is exact on the owned cells iff every window side
+// that is not a map side carries a halo at least that wide.
+int check_halo(const fdm_engine* e, int need) {
+  const GeomConst& G = e->G;
+  const int top = G.o_r0 - G.s_r0, left = G.o_c0 - G.s_c0;
+  const int bottom = (G.s_r0 + G.s_rows) - (G.o_r0 + G.o_rows), right = (G.s_c0 + G.s_cols) - (G.o_c0 + G.o_cols);
+  const bool ok = (G.s_r0 == 0 || top >= need) && (G.s_c0 == 0 || left >= need) &&
+                  (G.s_r0 + G.s_rows == G.rows || bottom >= need) && (G.s_c0 + G.s_cols == G.cols || right >= need);
+  if (!ok) return fail(FDM_ERR_INVALID, "tile halo narrower than the stencil (" + std::to_string(need) + " cells needed)");
+  return FDM_OK;
+}
+// neighbourhood offsets, dr-major / dc-minor; box = region(Size(k,k)), disc = region(radius)
+int upload_region(fdm_engine* e, const std::vector<RegionEntry>& reg) {
+  if (reg.size() > size_t(kMaxRegion)) return fail(FDM_ERR_INVALID, "neighbourhood larger than 256 cells");
+  if (!e->d_region) HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_region), kMaxRegion * sizeof(RegionEntry)));
+  HIPCK(hipMemcpyAsync(e->d_region, reg.data(), reg.size() * sizeof(RegionEntry), hipMemcpyHostToDevice, e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;  // `reg` is a host temporary
+  return FDM_OK;
+}
+void region_disc(const fdm_engine* e, float radius, std::vector<RegionEntry>& reg) {
+  reg.clear();
+  const float res = static_cast<float>(e->G.res);
+  const int k = static_cast<int>(std::floor(radius / res + 1e-4f));
+  const float r2 = radius * radius;
+  for (int dr = -k; dr <= k; ++dr)
+    for (int dc = -k; dc <= k; ++dc) {
+      const float d2 = static_cast<float>(dr * dr + dc * dc) * (res * res);
+      if (d2 <= r2 * (1.0f + 1e-5f)) reg.push_back({dr, dc, d2, 0.f});
+    }
+}
+unsigned cell_blocks(const fdm_engine* e) { return unsigned((e->ncell + 255) / 256); }
+int ensure_tmp2(fdm_engine* e) {
+  if (!e->d_tmp2) HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_tmp2), e->ncell * sizeof(float)));
+  return FDM_OK;
+}
+}  // namespace
+
+int fdm_engine_apply_inpainting(fdm_engine* e, int max_iterations, int min_valid, int inplace) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
+  if (!e) return fail(FDM_ERR_INVALID, "null engine");
+  HIPCK(hipSetDevice(e->device));
+  int rc;
+  if ((rc = check_halo(e, max_iterations > 0 ? max_iterations : 0))) return rc;  // one cell per pass
+  if ((rc = resolve_pending(e))) return rc;
+  Layer* elev = find_layer(e, "elevation");
+  if (!elev) return fail(FDM_ERR_NO_LAYER, "no layer elevation");
+  const char* out_name = inplace ? "elevation" : "elevation_inpainted";
+  if (!find_layer(e, out_name) && (rc = add_layer(e, out_name, NAN, false))) return rc;
+  elev = find_layer(e, "elevation");
+  Layer* out = find_layer(e, out_name);
+  if ((rc = ensure_tmp(e))) return rc;
+  float* A = lptr(e, *out);
+  const int As = lstride(e, *out);
+  float* B = e->d_tmp;
+  const int slot = int(e->scan_no & 3);
+  // `inpainted = elevation`, then up to max_iterations passes ping-ponging output layer <-> staging;
+  // the reference stops after a pass that changed nothing — further passes are identities, so all
+  // of them are simply run.  The copy goes to whichever side makes the LAST pass land in the layer.
+  const int iters = max_iterations > 0 ? max_iterations : 0;
+  const bool start_in_layer = (iters % 2) == 0;
+  if (!inplace || !start_in_layer) {
+    if ((rc = copy_strided(e, start_in_layer ? A : B, start_in_layer ? As : 1, lptr(e, *elev), lstride(e, *elev))))
+      return rc;
+  }
+  bool in_layer = start_in_layer;
+  for (int it = 0; it < iters; ++it) {
+    hipLaunchKernelGGL(k_inpaint_pass, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state, slot,
+                       in_layer ? A : B, in_layer ? As : 1, in_layer ? B : A, in_layer ? 1 : As, min_valid,
+                       unsigned(e->ncell));
+    in_layer = !in_layer;
+  }
+  HIPCK(hipGetLastError());
+  return FDM_OK;
+}
+
+int fdm_engine_apply_spatial_smoothing(fdm_engine* e, const char* layer, int kernel_size, int min_valid) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
+  if (!e || !layer) return fail(FDM_ERR_INVALID, "null argument");
+  if (kernel_size < 1 || kernel_size > 15 || (kernel_size & 1) == 0)
+    return fail(FDM_ERR_INVALID, "kernel_size must be odd and in [1, 15]");
+  HIPCK(hipSetDevice(e->device));
+  int rc;
+  if ((rc = check_halo(e, kernel_size / 2))) return rc;
+  if ((rc = resolve_pending(e))) return rc;
+  Layer* l = find_layer(e, layer);
+  if (!l || l->pending) return FDM_OK;  // spatial_smoothing.hpp:42
+  if ((rc = ensure_tmp(e))) return rc;
+  if ((rc = copy_strided(e, e->d_tmp, 1, lptr(e, *l), lstride(e, *l)))) return rc;  // the double buffer
+  hipLaunchKernelGGL(k_median, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state,
+                     int(e->scan_no & 3), e->d_tmp, lptr(e, *l), lstride(e, *l), kernel_size, min_valid,
+                     unsigned(e->ncell));
+  HIPCK(hipGetLastError());
+  if (std::strcmp(layer, "obstacle") == 0) e->obst_dense_pending = true;
+  return FDM_OK;
+}
+
+int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* cfg) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
+  if (!e || !cfg) return fail(FDM_ERR_INVALID, "null argument");
+  if (!cfg->enabled) return FDM_OK;
+  HIPCK(hipSetDevice(e->device));
+  int rc;
+  if ((rc = check_halo(e, int(std::floor(cfg->search_radius / static_cast<float>(e->G.res) + 1e-4f))))) return rc;
+  if ((rc = resolve_pending(e))) return rc;
+  Layer* up = find_layer(e, "upper_bound");
+  Layer* lo = find_layer(e, "lower_bound");
+  if (!up || !lo) return FDM_OK;  // uncertainty_fusion.cpp:108-113: warn + return
+  std::vector<RegionEntry> reg;
+  region_disc(e, cfg->search_radius, reg);
+  {  // spatial weight of each offset (uncertainty_fusion.cpp:122-123,158): std::exp on a float
+    const float inv_2s2 = 1.0f / (2.0f * cfg->spatial_sigma * cfg->spatial_sigma);
+    for (auto& r : reg) r.w = std::exp(-r.dist_sq * inv_2s2);
+  }
+  if ((rc = upload_region(e, reg))) return rc;
+  if ((rc = ensure_tmp(e)) || (rc = ensure_tmp2(e))) return rc;
+  if ((rc = copy_strided(e, e->d_tmp, 1, lptr(e, *up), lstride(e, *up)))) return rc;
+  if ((rc = copy_strided(e, e->d_tmp2, 1, lptr(e, *lo), lstride(e, *lo)))) return rc;
+  FusionParams F{};
+  F.inv_2s2 = 1.0f / (2.0f * cfg->spatial_sigma * cfg->spatial_sigma);
+  F.q_lower = cfg->quantile_lower;
+  F.q_upper = cfg->quantile_upper;
+  F.min_valid = cfg->min_valid_neighbors;
+  F.n_entries = int(reg.size());
+  const unsigned fblocks = unsigned((e->ncell + kFusionThreads - 1) / kFusionThreads);
+  if (int(reg.size()) <= kFusionLdsEntries) {  // sample lists in LDS
+    const size_t lds = size_t(4) * reg.size() * kFusionThreads * sizeof(float);
+    static bool raised = false;
+    if (!raised) {
+      HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fusion<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                int(size_t(4) * kFusionLdsEntries * kFusionThreads * sizeof(float))));
+      raised = true;
+    }
+    hipLaunchKernelGGL(k_fusion<true>, dim3(fblocks), dim3(kFusionThreads), lds, e->stream, e->G, e->d_state,
+                       int(e->scan_no & 3), e->d_region, F, e->d_tmp, e->d_tmp2, lptr(e, *up), lstride(e, *up),
+                       lptr(e, *lo), lstride(e, *lo), unsigned(e->ncell));
+  } else {
+    hipLaunchKernelGGL(k_fusion<false>, dim3(fblocks), dim3(kFusionThreads), 0, e->stream, e->G, e->d_state,
+                       int(e->scan_no & 3), e->d_region, F, e->d_tmp, e->d_tmp2, lptr(e, *up), lstride(e, *up),
+                       lptr(e, *lo), lstride(e, *lo), unsigned(e->ncell));
+  }
+  HIPCK(hipGetLastError());
+  return FDM_OK;
+}
+
+int fdm_engine_apply_feature_extraction(fdm_engine* e, float radius, int min_valid, float lo_pct, float hi_pct) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
+  if (!e) return fail(FDM_ERR_INVALID, "null engine");
+  HIPCK(hipSetDevice(e->device));
+  int rc;
+  if ((rc = check_halo(e, int(std::floor(radius / static_cast<float>(e->G.res) + 1e-4f))))) return rc;
+  if ((rc = resolve_pending(e))) return rc;
+  if (!find_layer(e, "elevation")) return FDM_OK;  // feature_extraction.cpp:33
+  const char* names[7] = {"step", "slope", "roughness", "curvature", "_normal_x", "_normal_y", "_normal_z"};
+  for (const char* n : names)
+    if (!find_layer(e, n) && (rc = add_layer(e, n, NAN, false))) return rc;
+  std::vector<RegionEntry> reg;
+  region_disc(e, radius, reg);
+  if ((rc = upload_region(e, reg))) return rc;
+  Layer* elev = find_layer(e, "elevation");
+  FeatureParams F{};
+  F.resf = static_cast<float>(e->G.res);
+  F.lo_pct = lo_pct;
+  F.hi_pct = hi_pct;
+  F.min_valid = min_valid;
+  F.n_entries = int(reg.size());
+  FeatureOut O{};
+  float** outs[7] = {&O.step, &O.slope, &O.roughness, &O.curvature, &O.nx, &O.ny, &O.nz};
+  for (int k = 0; k < 7; ++k) *outs[k] = find_layer(e, names[k])->d;
+  // order statistics needed by `step`: index lo from the bottom, (count-1-hi) from the top; both grow
+  // with count, so the full region bounds them
+  const int nmax = int(reg.size());
+  const int need_lo = nmax > 0 ? static_cast<int>(lo_pct * float(nmax - 1)) + 1 : 1;
+  const int need_hi = nmax > 0 ? (nmax - 1) - static_cast<int>(hi_pct * float(nmax - 1)) + 1 : 1;
+  const bool pct_ok = lo_pct >= 0.0f && hi_pct <= 1.0f && lo_pct <= 1.0f && hi_pct >= 0.0f;
+  auto launch_feat = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state, int(e->scan_no & 3),
+                       e->d_region, F, lptr(e, *elev), lstride(e, *elev), O, unsigned(e->ncell));
+  };
+  if (pct_ok && need_lo <= 16 && need_hi <= 16) launch_feat(k_features<16>);
+  else launch_feat(k_features<0>);
+  HIPCK(hipGetLastError());
+  return FDM_OK;
+}
+
+
+}  // extern "C"

@@ -1,0 +1,269 @@
+// fdm_engine_ray.inl — host side of the raycasting stage (kernels: fdm_raycast.hpp): voxel sort, ray
+// queue, resolve; entry points fdm_engine_apply_raycasting*, fdm_engine_voxel_any, fdm_engine_last_ray_ms.
+// Part of fdm_engine.hip's translation unit (included at its end): do not compile on its own.
+
+namespace {
+
+// ---- raycasting stage (fdm_raycast.hpp) ----
+bool voxel_size_ok(float v) { return v >= 0.001f && v <= 100.0f; }  // voxel_grid_impl.hpp:31-33
+
+// raycasting.cpp:223-226: created on first use; invisible until a frame passed the preconditions
+int ensure_ray_layers(fdm_engine* e) {
+  int rc;
+  for (const char* n : {"ghost_removal", "raycasting", "_visibility_logodds"})
+    if (!find_layer(e, n) && (rc = add_layer(e, n, NAN, true))) return rc;
+  return FDM_OK;
+}
+
+int ensure_ray_cells(fdm_engine* e) {
+  if (e->rc_cnt) return FDM_OK;
+  HIPCK(hipMalloc(reinterpret_cast<void**>(&e->rc_cnt), e->ncell * sizeof(uint32_t)));
+  HIPCK(hipMalloc(reinterpret_cast<void**>(&e->rc_min), e->ncell * sizeof(uint32_t)));
+  const int blocks = int(std::min<size_t>((e->ncell + 255) / 256, 4096));
+  hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, e->stream, e->rc_cnt, 0u, e->ncell);
+  hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, e->stream, e->rc_min, kRayEmpty, e->ncell);
+  HIPCK(hipGetLastError());
+  return FDM_OK;
+}
+
+int ensure_voxel_buffers(fdm_engine* e, size_t n) {
+  if (n <= e->vcap) return FDM_OK;
+  if (int rc_sync = sync_all(e)) return rc_sync;
+  for (int k = 0; k < 2; ++k) {
+    if (e->vkeys[k]) HIPCK(hipFree(e->vkeys[k]));
+    if (e->vidx[k]) HIPCK(hipFree(e->vidx[k]));
+  }
+  if (e->vsel) HIPCK(hipFree(e->vsel));
+  if (e->sort_tmp) HIPCK(hipFree(e->sort_tmp));
+  e->vcap = n + n / 4 + 1024;
+  for (int k = 0; k < 2; ++k) {
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->vkeys[k]), e->vcap * sizeof(unsigned long long)));
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->vidx[k]), e->vcap * sizeof(uint32_t)));
+  }
+  HIPCK(hipMalloc(reinterpret_cast<void**>(&e->vsel), e->vcap * sizeof(uint32_t)));
+  e->sort_tmp_bytes = 0;
+  HIPCK(rocprim::radix_sort_pairs(nullptr, e->sort_tmp_bytes, e->vkeys[0], e->vkeys[1], e->vidx[0],
+                                  e->vidx[1], e->vcap, 0, 64, e->stream));
+  {  // the compact-key sort reuses the same allocations (uint32 view of the key buffers)
+    size_t b32 = 0;
+    HIPCK(rocprim::radix_sort_pairs(nullptr, b32, reinterpret_cast<uint32_t*>(e->vkeys[0]),
+                                    reinterpret_cast<uint32_t*>(e->vkeys[1]), e->vidx[0], e->vidx[1], e->vcap, 0,
+                                    32, e->stream));
+    e->sort_tmp_bytes = std::max(e->sort_tmp_bytes, b32);
+  }
+  HIPCK(hipMalloc(&e->sort_tmp, e->sort_tmp_bytes ? e->sort_tmp_bytes : 16));
+  return FDM_OK;
+}
+
+// keys -> stable sort: vkeys[1] / vidx[1] hold the voxel-ordered scan afterwards.
+// `box` (nullable): centre + half extent [m] of a box that holds every finite point of the cloud;
+// with it the compact 32-bit key is used when 3 * bits <= 31.  Returns through *compact which key
+// type the sorted buffer holds.
+int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slot, const float* dx,
+                       const float* dy, const float* dz, const double* box, bool* compact) {
+  if (int rc = ensure_voxel_buffers(e, n)) return rc;
+  const float inv = 1.0f / voxel_size;  // voxel_grid_impl.hpp:46
+  VoxelCompact C{0, 0, 0, 0};
+  if (box && std::isfinite(box[3]) && box[3] > 0.0 && box[3] * double(inv) < 4.0e6) {
+    const double half = box[3] + 2.0 * double(voxel_size);  // 2-cell margin for the float transforms
+    const int span = int(std::ceil(2.0 * half * double(inv))) + 4;
+    int bits = 1;
+    while ((1 << bits) < span) ++bits;
+    if (3 * bits <= 62 && bits <= 21) {
+      C.bits = bits;
+      C.x0 = int(std::floor((box[0] - half) * double(inv))) - 1;
+      C.y0 = int(std::floor((box[1] - half) * double(inv))) - 1;
+      C.z0 = int(std::floor((box[2] - half) * double(inv))) - 1;
+    }
+  }
+  *compact = C.bits > 0 && 3 * C.bits <= 31;  // true: the sorted buffer holds uint32 keys
+  size_t bytes = e->sort_tmp_bytes;
+  if (*compact) {
+    uint32_t* k0 = reinterpret_cast<uint32_t*>(e->vkeys[0]);
+    uint32_t* k1 = reinterpret_cast<uint32_t*>(e->vkeys[1]);
+    hipLaunchKernelGGL(k_voxel_keys<uint32_t>, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, inv, flag_slot, C,
+                       e->d_state, dx, dy, dz, k0, e->vidx[0], e->vsel);
+    HIPCK(hipGetLastError());
+    // bits 3*bits .. 31 are zero in every valid key and one in the invalid key (all ones): sorting
+    // one bit past the fields is enough to keep the dropped points behind every voxel
+    HIPCK(rocprim::radix_sort_pairs(e->sort_tmp, bytes, k0, k1, e->vidx[0], e->vidx[1], size_t(n), 0,
+                                    unsigned(3 * C.bits + 1), e->stream));
+  } else {
+    hipLaunchKernelGGL(k_voxel_keys<unsigned long long>, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, inv,
+                       flag_slot, C, e->d_state, dx, dy, dz, e->vkeys[0], e->vidx[0], e->vsel);
+    HIPCK(hipGetLastError());
+    HIPCK(rocprim::radix_sort_pairs(e->sort_tmp, bytes, e->vkeys[0], e->vkeys[1], e->vidx[0], e->vidx[1],
+                                    size_t(n), 0, C.bits > 0 ? unsigned(3 * C.bits + 1) : 64u, e->stream));
+  }
+  return FDM_OK;
+}
+
+fdm_raycast_config ray_config_of(const fdm_config& c) {
+  fdm_raycast_config r;
+  r.enabled = c.raycast_enabled;
+  r.height_conflict_threshold = c.rc_height_conflict_threshold;
+  r.log_odds_observed = c.rc_log_odds_observed;
+  r.log_odds_ghost = c.rc_log_odds_ghost;
+  r.log_odds_max = c.rc_log_odds_max;
+  r.clear_threshold = c.rc_clear_threshold;
+  return r;
+}
+
+RayParams make_ray_params(fdm_engine* e, const fdm_raycast_config& c, const float* origin, unsigned n,
+                          int slot, int flag_slot) {
+  RayParams Q{};
+  Q.ox = origin[0]; Q.oy = origin[1]; Q.oz = origin[2];
+  Q.l_obs = c.log_odds_observed;
+  Q.l_ghost = c.log_odds_ghost;
+  Q.l_max = c.log_odds_max;
+  Q.clear_thr = c.clear_threshold;
+  Q.conflict_thr = c.height_conflict_threshold;
+  Q.resolution = static_cast<float>(e->G.res);
+  Q.inv_voxel = 1.0f / Q.resolution;
+  Q.n = n;
+  Q.slot = slot;
+  Q.flag_slot = flag_slot;
+  Q.vis_stamp = 3u * unsigned(e->scan_no) + (flag_slot >= 0 ? 3u : 1u);
+  Q.dbg = e->dbg_ray;
+  return Q;
+}
+
+// processScan + resolveGhostCells on the stream.  voxel: the points are vkeys[1]/vidx[1] runs.
+int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float* dx, const float* dy,
+                      const float* dz, bool compact_keys) {
+  int rc;
+  if ((rc = ensure_ray_cells(e))) return rc;
+  Layer* elev = find_layer(e, "elevation");
+  if (!elev) return FDM_OK;  // raycasting.cpp:213-216
+  RayLayers L{};
+  L.elevation = lptr(e, *elev);
+  L.elevation_stride = lstride(e, *elev);
+  L.logodds = find_layer(e, "_visibility_logodds")->d;
+  L.ray_min = find_layer(e, "raycasting")->d;
+  L.ghost = find_layer(e, "ghost_removal")->d;
+  L.rec = e->d_rec;
+  L.rec_floats = e->rec_floats;
+  const unsigned blocks = (Q.n + 255u) / 256u;
+  if ((rc = ensure_voxel_buffers(e, Q.n))) return rc;  // vidx[0] doubles as the ray queue
+  uint32_t* ray_list = e->vidx[0];
+  if (voxel) {
+    if (compact_keys)
+      hipLaunchKernelGGL(k_voxel_mark<uint32_t>, dim3(blocks), dim3(256), 0, e->stream, Q.n,
+                         reinterpret_cast<const uint32_t*>(e->vkeys[1]), e->vidx[1], e->vsel);
+    else
+      hipLaunchKernelGGL(k_voxel_mark<unsigned long long>, dim3(blocks), dim3(256), 0, e->stream, Q.n,
+                         e->vkeys[1], e->vidx[1], e->vsel);
+    hipLaunchKernelGGL(k_ray_compact<true>, dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx,
+                       dy, dz, e->vsel, e->rc_cnt, ray_list);
+  } else {
+    hipLaunchKernelGGL(k_ray_compact<false>, dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx,
+                       dy, dz, static_cast<const uint32_t*>(nullptr), e->rc_cnt, ray_list);
+  }
+  HIPCK(hipGetLastError());
+  const bool tiled = e->G.o_rows != e->G.rows || e->G.o_cols != e->G.cols || e->G.s_rows != e->G.rows ||
+                     e->G.s_cols != e->G.cols;
+  auto launch_ray = [&](auto kern, unsigned seg) {
+    // upper bound of the queue: every point a ray, padded to whole wavefronts per segment
+    const unsigned threads = ((Q.n + 63u) & ~63u) * seg;
+    hipLaunchKernelGGL(kern, dim3((threads + 255u) / 256u), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx, dy,
+                       dz, ray_list, e->rc_min);
+  };
+  // small scans are a few hundred wavefronts of dependent round trips: 16 / 8 lanes share a ray
+  // (C2: k_ray 60 -> 25 (8) -> 16 us (16)); the point count bounds the ray count from above
+  if (Q.n < (1u << 16)) {
+    tiled ? launch_ray(k_ray<true, 16>, 16u) : launch_ray(k_ray<false, 16>, 16u);
+  } else if (Q.n < (1u << 20)) {
+    tiled ? launch_ray(k_ray<true, 8>, 8u) : launch_ray(k_ray<false, 8>, 8u);
+  } else {
+    tiled ? launch_ray(k_ray<true, 1>, 1u) : launch_ray(k_ray<false, 1>, 1u);
+  }
+  HIPCK(hipGetLastError());
+  hipLaunchKernelGGL(k_ray_resolve, dim3(unsigned((e->ncell + 255) / 256)), dim3(256), 0, e->stream, Q,
+                     e->G, e->d_state, L, e->d_layer_ptrs, e->n_layer_ptrs, e->rc_cnt, e->rc_min,
+                     unsigned(e->ncell));
+  HIPCK(hipGetLastError());
+  return FDM_OK;
+}
+
+
+}  // namespace
+
+extern "C" {
+
+// ---- raycasting entry points ----
+int fdm_engine_apply_raycasting_device(fdm_engine* e, uint64_t n, const float* dx, const float* dy,
+                                       const float* dz, const float origin[3],
+                                       const fdm_raycast_config* rcfg) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
+  if (!e || !origin) return fail(FDM_ERR_INVALID, "null argument");
+  const fdm_raycast_config c = rcfg ? *rcfg : ray_config_of(e->cfg);
+  if (!c.enabled || n == 0) return FDM_OK;  // raycasting.cpp:207-209
+  if (!dx || !dy || !dz) return fail(FDM_ERR_INVALID, "null xyz");
+  if (n >= 0xFFFFFFFEull) return fail(FDM_ERR_INVALID, "point count exceeds 2^32-2");
+  HIPCK(hipSetDevice(e->device));
+  int rc;
+  if (!find_layer(e, "elevation")) return FDM_OK;
+  if ((rc = ensure_ray_layers(e))) return rc;
+  if ((rc = refresh_layer_ptrs(e))) return rc;
+  const RayParams Q = make_ray_params(e, c, origin, unsigned(n), int(e->scan_no & 3), -1);
+  return enqueue_ray_stage(e, Q, false, dx, dy, dz);
+}
+
+int fdm_engine_apply_raycasting(fdm_engine* e, uint64_t n, const float* x, const float* y,
+                                const float* z, const float origin[3], const fdm_raycast_config* rcfg) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
+  if (!e || !origin) return fail(FDM_ERR_INVALID, "null argument");
+  if (!(rcfg ? rcfg->enabled : e->cfg.raycast_enabled) || n == 0) return FDM_OK;
+  if (!x || !y || !z) return fail(FDM_ERR_INVALID, "null xyz");
+  HIPCK(hipSetDevice(e->device));
+  const float *dx, *dy, *dz, *da, *dv;
+  const uint32_t* dc;
+  int rc = stage_inputs(e, n, x, y, z, nullptr, nullptr, nullptr, &dx, &dy, &dz, &da, &dc, &dv);
+  if (rc) return rc;
+  if ((rc = fdm_engine_apply_raycasting_device(e, n, dx, dy, dz, origin, rcfg))) return rc;
+  if (int rc_sync = sync_all(e)) return rc_sync;
+  return FDM_OK;
+}
+
+int fdm_engine_voxel_any(fdm_engine* e, uint64_t n, const float* x, const float* y, const float* z,
+                         float voxel_size, uint32_t* out_idx, uint64_t* n_out) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
+  if (!e || !n_out) return fail(FDM_ERR_INVALID, "null argument");
+  *n_out = 0;
+  if (!voxel_size_ok(voxel_size)) return fail(FDM_ERR_INVALID, "voxel_size must be in [0.001, 100]");
+  if (n == 0) return FDM_OK;
+  if (!x || !y || !z || !out_idx) return fail(FDM_ERR_INVALID, "null argument");
+  if (n >= 0xFFFFFFFEull) return fail(FDM_ERR_INVALID, "point count exceeds 2^32-2");
+  HIPCK(hipSetDevice(e->device));
+  const float *dx, *dy, *dz, *da, *dv;
+  const uint32_t* dc;
+  int rc = stage_inputs(e, n, x, y, z, nullptr, nullptr, nullptr, &dx, &dy, &dz, &da, &dc, &dv);
+  if (rc) return rc;
+  bool compact = false;
+  if ((rc = enqueue_voxel_sort(e, unsigned(n), voxel_size, -1, dx, dy, dz, nullptr, &compact))) return rc;
+  hipLaunchKernelGGL(k_voxel_select, dim3(unsigned((n + 255) / 256)), dim3(256), 0, e->stream, unsigned(n),
+                     e->vkeys[1], e->vidx[1], e->vsel);
+  HIPCK(hipGetLastError());
+  std::vector<uint32_t> h(n);
+  HIPCK(hipMemcpyAsync(h.data(), e->vsel, n * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+  if (int rc_sync = sync_all(e)) return rc_sync;
+  uint64_t w = 0;
+  for (uint64_t i = 0; i < n; ++i)  // order-preserving compaction = marshalling
+    if (h[i] != kNoIdx) out_idx[w++] = h[i];
+  *n_out = w;
+  return FDM_OK;
+}
+
+int fdm_engine_last_ray_ms(fdm_engine* e, float* ms) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
+  if (!e || !ms) return fail(FDM_ERR_INVALID, "null argument");
+  if (!e->profile) return fail(FDM_ERR_INVALID, "profiling is off");
+  *ms = 0.f;
+  if (!e->ray_timed) return FDM_OK;
+  if (int rc_sync = sync_all(e)) return rc_sync;
+  HIPCK(hipEventElapsedTime(ms, e->ev_ray[0], e->ev_ray[1]));
+  return FDM_OK;
+}
+
+
+}  // extern "C"
