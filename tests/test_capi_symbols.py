@@ -63,7 +63,7 @@ def test_product_never_references_the_oracle():
     bad = []
     for d, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
+            if f.endswith((".py", ".hip", ".hpp", ".inl", ".h", ".cpp", "Makefile")):
                 txt = open(os.path.join(d, f), errors="ignore").read()
                 if re.search(r"fdm_ref|fdmref|oracle/", txt):
                     bad.append(os.path.join(d, f))
