@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large", action="store_true")
     ap.add_argument("--wave-merge", type=int, default=1)
+    ap.add_argument("--set", action="append", default=[], help="engine option key=value (A/B switch)")
     ap.add_argument("--overlap", type=int, default=1, help="bin(t+1) || update(t) on two streams (A/B switch)")
     return ap.parse_args()
 
@@ -250,6 +251,8 @@ def main():
         kw = {"order": args.order} if args.workload in ("c2", "c4") else {}
         wl = synth.make(args.workload, **kw)
         res = Resident(wl, local_rank, args.wave_merge, args.overlap)
+        for kv in args.set:
+            res.eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 
         def barrier():
             res.eng.sync()
