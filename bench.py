@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measu
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=10000)
+    ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--order", default="azimuth", choices=["azimuth", "ring"])
     ap.add_argument("--profile-steps", type=int, default=200)
