@@ -161,6 +161,12 @@ class Engine:
         """hipStream_t of the engine as an int."""
         return self._lib.fdm_engine_stream(self._h)
 
+    def update_device(self, x, y, z, robot_xy=(0.0, 0.0), z_var=None, intensity=None, rgb=None):
+        """ElevationMapping::update on torch device tensors (map-frame cloud), enqueue only."""
+        _ck(self._lib.fdm_engine_update_device(self._h, x.numel(), _dptr(x), _dptr(y), _dptr(z), _dptr(z_var),
+                                               _dptr(intensity), _dptr(rgb), float(robot_xy[0]),
+                                               float(robot_xy[1])))
+
     def sync(self):
         _ck(self._lib.fdm_engine_sync(self._h))
 

@@ -213,3 +213,27 @@ def test_host_streaming_entry_point(gpu, R):
     assert rc == 0 and st["n_input"] == 28800
     assert_layers_equal(eng, ref)
     assert same_geometry(eng.geometry(), ref.geometry())
+
+
+def test_update_device_chain(gpu, R):
+    """ElevationMapping::update (cloud already in the map frame, tests/test_dual_layer.cpp:71) through
+    the enqueue-only entry point: LOCAL moves by the robot position, no crops, z variance channel."""
+    rng = np.random.default_rng(8)
+    eng, ref = pair(gpu, R, 12.0, 12.0, 0.1)
+    keep = []
+    for k in range(7):
+        n = 6000
+        rx, ry = 0.37 * k, -0.21 * k
+        x = (rng.uniform(-5, 5, n) + rx).astype(F32)
+        y = (rng.uniform(-5, 5, n) + ry).astype(F32)
+        z = rng.normal(0.2, 0.3, n).astype(F32)
+        var = rng.uniform(1e-4, 5e-3, n).astype(F32) if k % 2 == 0 else None
+        d = {c: torch.from_numpy(v).cuda() for c, v in (("x", x), ("y", y), ("z", z))}
+        dv = torch.from_numpy(var).cuda() if var is not None else None
+        keep.append((d, dv))
+        eng.update_device(d["x"], d["y"], d["z"], (rx, ry), z_var=dv)
+        st_r = ref.update(x, y, z, (rx, ry), z_var=var)
+    rc, st = eng.last_stats()
+    assert st == st_r
+    assert_layers_equal(eng, ref)
+    assert same_geometry(eng.geometry(), ref.geometry())
