@@ -324,8 +324,15 @@ def main():
                 res.eng.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k + 1000 + i),
                                   intensity=s["intensity"], rgb=s["rgb"])
             result["host_buffers_ms_per_scan"] = (time.perf_counter() - t0) / 50 * 1e3
-            # steady-state stream from PINNED host memory, no per-scan wait (SURVEY.md §8d iii): PCIe-inclusive
             pin = {c: torch.from_numpy(s[c]).pin_memory() for c in ("x", "y", "z", "intensity", "rgb") if s.get(c) is not None}
+            pn = {c: t.numpy() for c, t in pin.items()}
+            # the same synchronous call on PINNED arrays: read in place by the bin kernel, no copy commands
+            t0 = time.perf_counter()
+            for i in range(50):
+                res.eng.integrate(pn["x"], pn["y"], pn["z"], wl.T_base_sensor, wl.pose(k + 1000 + i),
+                                  intensity=pn.get("intensity"), rgb=pn.get("rgb"))
+            result["host_buffers_pinned_ms_per_scan"] = (time.perf_counter() - t0) / 50 * 1e3
+            # steady-state stream from PINNED host memory, no per-scan wait (SURVEY.md §8d iii): PCIe-inclusive
             hp = {c: C.c_void_p(t.data_ptr()) for c, t in pin.items()}
             for i in range(20):
                 res.eng.integrate_async_raw(s["x"].size, hp["x"], hp["y"], hp["z"], res.tbs, res.pose(k + 2000 + i),

@@ -9,6 +9,6 @@ Layout (only what the path needs):
   cpp/         C++17 host mirror of fastdem::FastDEM / ElevationMap over the C ABI
 """
 from . import capi, synth  # noqa: F401
-from .engine import Engine, EngineError  # noqa: F401
+from .engine import Engine, EngineError, HostArray, host_array  # noqa: F401
 
-__all__ = ["Engine", "EngineError", "capi", "synth"]
+__all__ = ["Engine", "EngineError", "HostArray", "host_array", "capi", "synth"]

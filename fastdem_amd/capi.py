@@ -125,6 +125,10 @@ PROTOTYPES = {
                                     C.c_double, C.POINTER(FdmScanStats)]),
     "fdm_engine_update_device": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, C.c_double,
                                            C.c_double]),
+    "fdm_host_alloc": (_P, [C.c_uint64]),
+    "fdm_host_free": (None, [_P]),
+    "fdm_host_trim": (None, []),
+    "fdm_host_is_pinned": (C.c_int, [_P]),
     "fdm_engine_flush": (C.c_int, [_P]),
     "fdm_engine_stream": (_P, [_P]),
     "fdm_engine_sync": (C.c_int, [_P]),

@@ -1,15 +1,41 @@
 // nanopcl/core.hpp — the nanopcl::PointCloud surface FastDEM::integrate() consumes
 // (fastdem/lib/nanoPCL/include/nanopcl/core/point_cloud.hpp:24-147, types.hpp), re-laid out as
 // SoA channels: x / y / z / intensity / packed rgb are separate contiguous float arrays, which is
-// exactly what the engine's C ABI takes — no AoS->SoA staging pass on the host.
+// exactly what the engine's C ABI takes — no AoS->SoA staging pass on the host.  The channels live in
+// pinned memory from the engine's pool (fdm_host_alloc), so FastDEM::integrate() reads a cloud in
+// place over PCIe instead of copying it first.
 #pragma once
+#include <cstddef>
 #include <cstdint>
+#include <new>
 #include <string>
 #include <vector>
 
 #include "fastdem/compat/mini_eigen.hpp"
+#include "fdm_engine.h"
 
 namespace nanopcl {
+
+// std::allocator over fdm_host_alloc / fdm_host_free (a free-list pop per cloud, not a driver call)
+template <typename T>
+struct HostAllocator {
+  using value_type = T;
+  HostAllocator() = default;
+  template <typename U>
+  HostAllocator(const HostAllocator<U>&) {}
+  T* allocate(std::size_t n) {
+    void* p = fdm_host_alloc(uint64_t(n) * sizeof(T));
+    if (!p) throw std::bad_alloc();
+    return static_cast<T*>(p);
+  }
+  void deallocate(T* p, std::size_t) { fdm_host_free(p); }
+  template <typename U>
+  bool operator==(const HostAllocator<U>&) const { return true; }
+  template <typename U>
+  bool operator!=(const HostAllocator<U>&) const { return false; }
+};
+template <typename T>
+using HostVector = std::vector<T, HostAllocator<T>>;
 
 using Point = Eigen::Vector3f;
 
@@ -93,8 +119,8 @@ class PointCloud {
 
  private:
   static uint32_t pack(const Color& c) { return (uint32_t(c.r) << 16) | (uint32_t(c.g) << 8) | uint32_t(c.b); }
-  std::vector<float> x_, y_, z_, intensity_;
-  std::vector<uint32_t> rgb_;  // 0x00RRGGBB
+  HostVector<float> x_, y_, z_, intensity_;
+  HostVector<uint32_t> rgb_;  // 0x00RRGGBB
   std::string frame_id_;
   uint64_t timestamp_ns_ = 0;
   bool use_intensity_ = false, use_color_ = false;

@@ -644,6 +644,57 @@ TEST(Cloud2, IntegrateMessageEqualsIntegrateCloud) {  // nanopcl/bridge/ros/impl
   EXPECT_FALSE(ma.integrateCloud2(empty, a.T_base_sensor, a.T_world_base));
 }
 
+// ------------------------------------------------------- pinned input clouds ----
+TEST(HostPool, BlocksAreReusedAndCloudsArePinned) {
+  void* a = fdm_host_alloc(100000);
+  ASSERT_TRUE(a != nullptr);
+  EXPECT_EQ(fdm_host_is_pinned(a), 1);  // this suite runs on a GPU box
+  fdm_host_free(a);
+  void* b = fdm_host_alloc(70000);      // same 128 KiB class: the idle block comes back
+  EXPECT_TRUE(a == b);
+  EXPECT_EQ(fdm_host_is_pinned(b), 1);
+  fdm_host_free(b);
+  EXPECT_EQ(fdm_host_is_pinned(b), 0);  // idle blocks are not live
+  fdm_host_free(b);                     // double free of a pooled block is ignored
+  int on_stack = 0;
+  fdm_host_free(&on_stack);             // foreign pointers are ignored
+  EXPECT_EQ(fdm_host_is_pinned(&on_stack), 0);
+  fdm_host_trim();
+  const PointCloud cloud = makeGroundCloud(0.5f);
+  EXPECT_EQ(fdm_host_is_pinned(cloud.xData()), 1);
+  EXPECT_EQ(fdm_host_is_pinned(cloud.zData()), 1);
+  PointCloud copy = cloud;              // copies get their own pinned blocks
+  EXPECT_TRUE(copy.xData() != cloud.xData());
+  EXPECT_EQ(fdm_host_is_pinned(copy.yData()), 1);
+}
+
+TEST(HostPool, InPlaceIntegrateEqualsCopiedIntegrate) {
+  // the same scans through integrate(): pinned clouds read in place by the bin kernel vs the
+  // copy path (option zero_copy = 0) — every layer identical
+  Fixture a, b;
+  FastDEM ma(a.map), mb(b.map);
+  for (int k = 0; k < 3; ++k) {
+    PointCloud cloud;
+    for (float x = -2.0f; x <= 2.0f; x += 0.05f)
+      for (float y = -2.0f; y <= 2.0f; y += 0.05f)
+        cloud.add(x, y, 0.1f * float(k) + 0.3f * std::sin(3.0f * x) * std::cos(2.0f * y), nanopcl::Intensity(x * y));
+    ASSERT_TRUE(ma.integrate(cloud, a.T_base_sensor, a.T_world_base));
+    ASSERT_EQ(fdm_engine_set_option(b.map.engine(), "zero_copy", 0), FDM_OK);
+    ASSERT_TRUE(mb.integrate(cloud, b.T_base_sensor, b.T_world_base));
+  }
+  for (const auto& name : b.map.getLayers()) {
+    const auto& x = a.map.get(name);
+    const auto& y = b.map.get(name);
+    size_t bad = 0;
+    for (size_t i = 0; i < x.size(); ++i) {
+      const float u = x.data()[i], v = y.data()[i];
+      if (std::isnan(u) ? !std::isnan(v) : !(u == v)) ++bad;
+    }
+    EXPECT_EQ(bad, size_t(0));
+  }
+  EXPECT_TRUE(a.map.hasElevationAt(nanogrid::Position(0.0, 0.0)));
+}
+
 // ------------------------------------------------------- test_map_io.cpp (NPZ) ----
 namespace {
 struct NpzFixture {  // test_map_io.cpp:19-41

@@ -16,8 +16,10 @@
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <type_traits>
+#include <unordered_map>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>  // stable (key, index) sort of the voxel filter
@@ -78,6 +80,9 @@ struct fdm_engine {
   Scratch S{};
   DevState* d_state = nullptr;
   DevState* h_state = nullptr;  // pinned mirror for read-backs
+  StatsOut* h_stats = nullptr;  // pinned + device-mapped: k_collect_stats writes here
+  StatsOut* h_stats_dev = nullptr;  // the device's alias of h_stats
+  StatsAcc* d_stats_acc = nullptr;
   uint64_t scan_no = 0;
   bool have_scan = false;
   uint32_t last_n = 0;
@@ -92,6 +97,9 @@ struct fdm_engine {
   bool profile = false;
   bool wave_merge = true;
   int bin_table = 1;                 // k_bin: per-block LDS cell table (option "bin_table")
+  // fdm_engine_integrate_async: scans of up to this many points whose arrays are PINNED host memory
+  // are read in place by the bin kernel (0 = always stage with copy commands; option "zero_copy")
+  int zero_copy = 1 << 30;
   int dbg_no_atomics = 0;
   int dbg_upd = 0;
   int bin_threads = 0;               // k_bin4 block size (0 = auto, 128 / 256 / 512): 4 points per thread
@@ -405,8 +413,13 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float
                       const float* dz, bool compact_keys = false);
 
 // One scan = k_bin + k_update on the stream.  All pointers are device pointers.
+// `gather` (nullable): where the UPDATE kernel reads the winning points from.  Set when dx..dvar are
+// pinned host arrays seen through PCIe: the bin kernel then writes the scan through to these HBM
+// arrays as it reads it (Scratch::wt_x), so the scan crosses the link exactly once and no copy is
+// queued.  Null: the update gathers from dx..dvar themselves.
 int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, const float* dy,
-                 const float* dz, const float* dint, const uint32_t* drgb, const float* dvar) {
+                 const float* dz, const float* dint, const uint32_t* drgb, const float* dvar,
+                 const ScanInputs* gather = nullptr) {
   if (n >= 0xFFFFFFFEull) return fail(FDM_ERR_INVALID, "point count exceeds 2^32-2");
   if (dint && n >= 0x7FFFFFFFull) return fail(FDM_ERR_INVALID, "point count exceeds 2^31-1 (intensity channel)");
   int rc;
@@ -452,6 +465,17 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   e->S.cap_x = e->S.cap_y = e->S.cap_z = e->S.cap_var = nullptr;
   e->S.ras_z = nullptr;
   e->S.cap_drop_nan = ray_on ? 1 : 0;
+  e->S.wt_x = e->S.wt_y = e->S.wt_z = e->S.wt_var = nullptr;
+  e->S.wt_rgb = nullptr;
+  e->S.wt_src_var = nullptr;
+  e->S.wt_src_rgb = nullptr;
+  if (gather && n) {
+    e->S.wt_x = const_cast<float*>(gather->x);
+    e->S.wt_y = const_cast<float*>(gather->y);
+    e->S.wt_z = const_cast<float*>(gather->z);
+    if (dvar) { e->S.wt_var = const_cast<float*>(gather->var); e->S.wt_src_var = dvar; }
+    if (drgb) { e->S.wt_rgb = const_cast<uint32_t*>(gather->rgb); e->S.wt_src_rgb = drgb; }
+  }
   if ((e->cap_pre || ray_on) && n) {
     if (n > e->cap_cap) {
       if (int rc_sync = sync_all(e)) return rc_sync;
@@ -565,19 +589,21 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   }
   // the next scan's launch (or a flush) carries this update
   const bool hold = plain;
-  const ScanInputs in_u{dx, dy, dz, dint, drgb, dvar};
+  const ScanInputs in_u = (gather && n) ? ScanInputs{gather->x, gather->y, gather->z, nullptr,
+                                                     drgb ? gather->rgb : nullptr, dvar ? gather->var : nullptr}
+                                        : ScanInputs{dx, dy, dz, dint, drgb, dvar};
   auto launch_upd = [&](auto policy_tag, const auto& layers) {
     using POLICY = decltype(policy_tag);
     if (!hold) {
       if (!e->S.dense) {  // stamp-gated: 16 tiles per block, idle tiles cost one scalar load
         hipLaunchKernelGGL(k_update_stamped<POLICY>, dim3((upd_blocks + kStampTiles - 1) / kStampTiles), dim3(256),
-                           0, e->stream, P, e->G, e->d_state, layers, e->d_layer_ptrs, e->n_layer_ptrs, e->S, dx,
-                           dy, dz, dint, drgb, dvar, unsigned(e->ncell));
+                           0, e->stream, P, e->G, e->d_state, layers, e->d_layer_ptrs, e->n_layer_ptrs, e->S,
+                           in_u.x, in_u.y, in_u.z, in_u.intensity, in_u.rgb, in_u.var, unsigned(e->ncell));
         return;
       }
       hipLaunchKernelGGL(k_update<POLICY>, dim3(upd_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state,
-                         layers, e->d_layer_ptrs, e->n_layer_ptrs, e->S, dx, dy, dz, dint, drgb, dvar,
-                         unsigned(e->ncell));
+                         layers, e->d_layer_ptrs, e->n_layer_ptrs, e->S, in_u.x, in_u.y, in_u.z, in_u.intensity,
+                         in_u.rgb, in_u.var, unsigned(e->ncell));
       return;
     }
     const ScanParams Pu = P;
@@ -748,21 +774,51 @@ int ensure_stage(fdm_engine* e, size_t n) {
   if (n <= e->stage_cap) return FDM_OK;
   if (int rc_sync = sync_all(e)) return rc_sync;
   if (e->d_stage) HIPCK(hipFree(e->d_stage));
-  e->stage_cap = n + n / 4 + 1024;
+  e->stage_cap = ((n + n / 4 + 1024) + 3) & ~size_t(3);  // channels stay 16-byte aligned (k_bin4's float4 loads)
   HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_stage), e->stage_cap * 6 * kStageSlots * sizeof(float)));
   return FDM_OK;
 }
 
-// H2D of the SoA channels into the staging block; returns device pointers (nullable ones stay null)
+// Device-visible alias of a pinned (hipHostMalloc / hipHostRegister) host pointer; null for anything else.
+const void* pinned_alias(const void* p) {
+  hipPointerAttribute_t a{};
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // pageable memory is reported as an error by older runtimes: not ours to keep
+    return nullptr;
+  }
+  return a.type == hipMemoryTypeHost ? a.devicePointer : nullptr;
+}
+
+// Host SoA channels -> what the kernels read.  PINNED arrays (up to `zero_copy` points) are not copied:
+// the bin kernel reads them in place through their device-visible alias and writes them through to
+// the staging block, which is where the update kernel gathers from (*gather; see enqueue_scan) — no
+// copy commands, the scan crosses PCIe exactly once.  Anything else is copied into the staging block
+// with hipMemcpyAsync and *gather stays unset (x = null); so is everything when gather == nullptr (callers
+// whose kernels have no write-through).  Nullable channels stay null.
 int stage_inputs(fdm_engine* e, uint64_t n, const float* x, const float* y, const float* z,
                  const float* a, const uint32_t* rgb, const float* v, const float** dx,
                  const float** dy, const float** dz, const float** da, const uint32_t** drgb,
-                 const float** dv) {
+                 const float** dv, ScanInputs* gather = nullptr) {
   int rc;
   if ((rc = ensure_stage(e, n))) return rc;
   e->stage_rr = (e->stage_rr + 1) % kStageSlots;
   const size_t cap = e->stage_cap;
   float* base = e->d_stage + size_t(e->stage_rr) * 6 * cap;
+  if (gather) *gather = ScanInputs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (gather && e->zero_copy && n <= uint64_t(e->zero_copy)) {
+    const float* mx = static_cast<const float*>(pinned_alias(x));
+    const float* my = mx ? static_cast<const float*>(pinned_alias(y)) : nullptr;
+    const float* mz = my ? static_cast<const float*>(pinned_alias(z)) : nullptr;
+    const float* ma = (mz && a) ? static_cast<const float*>(pinned_alias(a)) : nullptr;
+    const uint32_t* mc = (mz && rgb) ? static_cast<const uint32_t*>(pinned_alias(rgb)) : nullptr;
+    const float* mv = (mz && v) ? static_cast<const float*>(pinned_alias(v)) : nullptr;
+    if (mz && (!a || ma) && (!rgb || mc) && (!v || mv)) {
+      *dx = mx; *dy = my; *dz = mz; *da = ma; *drgb = mc; *dv = mv;
+      *gather = ScanInputs{base, base + cap, base + cap * 2, nullptr,
+                           reinterpret_cast<const uint32_t*>(base + cap * 4), base + cap * 5};
+      return FDM_OK;
+    }
+  }
   auto up = [&](const void* src, int k) -> int {
     HIPCK(hipMemcpyAsync(base + cap * k, src, n * sizeof(float), hipMemcpyHostToDevice, e->stream));
     return FDM_OK;
@@ -790,37 +846,32 @@ int stage_inputs(fdm_engine* e, uint64_t n, const float* x, const float* y, cons
 }
 
 int read_stats(fdm_engine* e, fdm_scan_stats* out, int* status) {
-  if (int rc_sync = sync_all(e)) return rc_sync;
+  if (int rc = join_streams(e)) return rc;
   fdm_scan_stats s{};
   *status = FDM_OK;
   if (!e->have_scan) {
+    if (int rc_sync = sync_all(e)) return rc_sync;
     if (out) *out = s;
     return FDM_OK;
   }
-  const int slot = int((e->scan_no - 1) & 3);
-  HIPCK(hipMemcpy(e->h_state, e->d_state, sizeof(DevState), hipMemcpyDeviceToHost));
-  const DevState& st = *e->h_state;
-  uint64_t np = 0, ni = 0;
-  e->h_bin_part.resize(e->last_bin_blocks);
-  HIPCK(hipMemcpy(e->h_bin_part.data(), e->S.bin_part, e->last_bin_blocks * sizeof(unsigned long long),
-                  hipMemcpyDeviceToHost));
-  for (unsigned long long v : e->h_bin_part) {
-    np += uint32_t(v);
-    ni += uint32_t(v >> 32);
+  {  // sum the partial counts behind the scan's kernels; the result lands in pinned host memory
+    const unsigned work = std::max<unsigned>(e->last_bin_blocks, unsigned(e->n_tiles));
+    const unsigned blocks = std::min(64u, std::max(1u, (work + 4095u) / 4096u));
+    hipLaunchKernelGGL(k_collect_stats, dim3(blocks), dim3(256), 0, e->stream, e->S.bin_part, e->last_bin_blocks,
+                       e->S.upd_part, unsigned(e->n_tiles), e->d_state, int((e->scan_no - 1) & 3), e->d_stats_acc,
+                       e->h_stats_dev);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(e->stream));
   }
-  uint64_t nt = 0;
-  e->h_upd_part.resize(e->n_tiles);
-  HIPCK(hipMemcpy(e->h_upd_part.data(), e->S.upd_part, e->n_tiles * sizeof(uint32_t),
-                  hipMemcpyDeviceToHost));
-  for (uint32_t v : e->h_upd_part) nt += v;
+  const uint64_t np = e->h_stats->n_pass, ni = e->h_stats->n_in, nt = e->h_stats->n_touched;
   s.n_input = e->last_n;
   s.n_after_filter = uint32_t(np);
   s.n_in_map = uint32_t(ni);
   s.n_cells_touched = uint32_t(nt);
   const bool applied = e->last_was_integrate ? (np > 0) : true;
   if (applied) {
-    s.shift_rows = st.cand[slot].shr;
-    s.shift_cols = st.cand[slot].shc;
+    s.shift_rows = e->h_stats->shr;
+    s.shift_cols = e->h_stats->shc;
   }
   if (e->last_was_integrate) {
     if (e->last_n == 0) *status = FDM_SKIP_EMPTY_CLOUD;
@@ -948,6 +999,11 @@ static int create_impl(const fdm_geometry* g, const fdm_config* cfg, const fdm_t
   HCK(hipMalloc(reinterpret_cast<void**>(&e->d_state), sizeof(DevState)));
   HCK(hipHostMalloc(reinterpret_cast<void**>(&e->h_state), sizeof(DevState)));
   std::memset(e->h_state, 0, sizeof(DevState));
+  HCK(hipHostMalloc(reinterpret_cast<void**>(&e->h_stats), sizeof(StatsOut), hipHostMallocMapped));
+  std::memset(e->h_stats, 0, sizeof(StatsOut));
+  HCK(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_stats_dev), e->h_stats, 0));
+  HCK(hipMalloc(reinterpret_cast<void**>(&e->d_stats_acc), sizeof(StatsAcc)));
+  HCK(hipMemset(e->d_stats_acc, 0, sizeof(StatsAcc)));
   for (int k = 0; k < 4; ++k) {
     e->h_state->geom[k].px = g->position_x;
     e->h_state->geom[k].py = g->position_y;
@@ -1032,6 +1088,8 @@ void fdm_engine_destroy(fdm_engine* e) {
   if (e->S.tile_stamp) (void)hipFree(e->S.tile_stamp);
   if (e->d_state) (void)hipFree(e->d_state);
   if (e->h_state) (void)hipHostFree(e->h_state);
+  if (e->h_stats) (void)hipHostFree(e->h_stats);
+  if (e->d_stats_acc) (void)hipFree(e->d_stats_acc);
   if (e->d_stage) (void)hipFree(e->d_stage);
   if (e->d_cell_ids) (void)hipFree(e->d_cell_ids);
   if (e->d_cap) (void)hipFree(e->d_cap);
@@ -1116,11 +1174,12 @@ int fdm_engine_integrate(fdm_engine* e, uint64_t n, const float* x, const float*
   HIPCK(hipSetDevice(e->device));
   const float *dx, *dy, *dz, *da, *dv;
   const uint32_t* dc;
-  int rc = stage_inputs(e, n, x, y, z, intensity, rgb, sigma_z2, &dx, &dy, &dz, &da, &dc, &dv);
+  ScanInputs gather;
+  int rc = stage_inputs(e, n, x, y, z, intensity, rgb, sigma_z2, &dx, &dy, &dz, &da, &dc, &dv, &gather);
   if (rc) return rc;
   ScanParams P;
   fill_integrate_params(e, P, Tbs, Twb);
-  if ((rc = enqueue_scan(e, P, n, dx, dy, dz, da, dc, dv))) return rc;
+  if ((rc = enqueue_scan(e, P, n, dx, dy, dz, da, dc, dv, gather.x ? &gather : nullptr))) return rc;
   int status = FDM_OK;
   if ((rc = read_stats(e, out, &status))) return rc;
   return status;
@@ -1135,9 +1194,12 @@ int fdm_engine_integrate_async(fdm_engine* e, uint64_t n, const float* x, const 
   HIPCK(hipSetDevice(e->device));
   const float *dx, *dy, *dz, *da, *dv;
   const uint32_t* dc;
-  int rc = stage_inputs(e, n, x, y, z, intensity, rgb, sigma_z2, &dx, &dy, &dz, &da, &dc, &dv);
+  ScanInputs gather;
+  int rc = stage_inputs(e, n, x, y, z, intensity, rgb, sigma_z2, &dx, &dy, &dz, &da, &dc, &dv, &gather);
   if (rc) return rc;
-  return fdm_engine_integrate_device(e, n, dx, dy, dz, da, dc, dv, Tbs, Twb);
+  ScanParams P;
+  fill_integrate_params(e, P, Tbs, Twb);
+  return enqueue_scan(e, P, n, dx, dy, dz, da, dc, dv, gather.x ? &gather : nullptr);
 }
 
 int fdm_engine_update_device(fdm_engine* e, uint64_t n, const float* dx, const float* dy,
@@ -1161,14 +1223,96 @@ int fdm_engine_update(fdm_engine* e, uint64_t n, const float* x, const float* y,
   const float *dx = nullptr, *dy = nullptr, *dz = nullptr, *da = nullptr, *dv = nullptr;
   const uint32_t* dc = nullptr;
   int rc;
-  if (n && (rc = stage_inputs(e, n, x, y, z, intensity, rgb, z_var, &dx, &dy, &dz, &da, &dc, &dv)))
+  ScanInputs gather{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (n && (rc = stage_inputs(e, n, x, y, z, intensity, rgb, z_var, &dx, &dy, &dz, &da, &dc, &dv, &gather)))
     return rc;
   ScanParams P;
   fill_update_params(e, P, rx, ry, false);
-  if ((rc = enqueue_scan(e, P, n, dx, dy, dz, da, dc, dv))) return rc;
+  if ((rc = enqueue_scan(e, P, n, dx, dy, dz, da, dc, dv, gather.x ? &gather : nullptr))) return rc;
   int status = FDM_OK;
   if ((rc = read_stats(e, out, &status))) return rc;
   return FDM_OK;
+}
+
+// ---- pinned host pool (fdm_host_alloc) ----
+namespace {
+struct HostPool {
+  static constexpr int kMinShift = 12, kMaxShift = 30;  // 4 KiB .. 1 GiB classes; larger blocks are not pooled
+  std::mutex mu;
+  std::unordered_map<const void*, int> live;            // block -> class (>= 0 pinned, -1 pinned unpooled, -2 pageable)
+  std::vector<void*> idle[kMaxShift + 1];
+};
+HostPool* host_pool() {
+  static HostPool* pool = new HostPool;  // never destroyed: clouds with static storage may be freed after main()
+  return pool;
+}
+}  // namespace
+
+void* fdm_host_alloc(uint64_t bytes) {
+  HostPool& hp = *host_pool();
+  int cls = HostPool::kMinShift;
+  while (cls <= HostPool::kMaxShift && (1ull << cls) < bytes) ++cls;
+  const bool pooled = cls <= HostPool::kMaxShift;
+  const size_t size = pooled ? (size_t(1) << cls) : size_t(bytes);
+  if (pooled) {
+    std::lock_guard<std::mutex> lock(hp.mu);
+    if (!hp.idle[cls].empty()) {
+      void* p = hp.idle[cls].back();
+      hp.idle[cls].pop_back();
+      hp.live[p] = cls;
+      return p;
+    }
+  }
+  void* p = nullptr;
+  int tag = pooled ? cls : -1;
+  if (hipHostMalloc(&p, size, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess || !p) {
+    (void)hipGetLastError();
+    p = std::aligned_alloc(64, (size + 63) & ~size_t(63));  // no usable GPU: pageable, the engine will copy
+    tag = -2;
+    if (!p) return nullptr;
+  }
+  std::lock_guard<std::mutex> lock(hp.mu);
+  hp.live[p] = tag;
+  return p;
+}
+
+void fdm_host_free(void* p) {
+  if (!p) return;
+  HostPool& hp = *host_pool();
+  int tag;
+  {
+    std::lock_guard<std::mutex> lock(hp.mu);
+    auto it = hp.live.find(p);
+    if (it == hp.live.end()) return;  // not ours
+    tag = it->second;
+    hp.live.erase(it);
+    if (tag >= 0) {
+      hp.idle[tag].push_back(p);
+      return;
+    }
+  }
+  if (tag == -1) (void)hipHostFree(p);
+  else std::free(p);
+}
+
+void fdm_host_trim(void) {
+  HostPool& hp = *host_pool();
+  std::vector<void*> drop;
+  {
+    std::lock_guard<std::mutex> lock(hp.mu);
+    for (auto& v : hp.idle) {
+      drop.insert(drop.end(), v.begin(), v.end());
+      v.clear();
+    }
+  }
+  for (void* p : drop) (void)hipHostFree(p);
+}
+
+int fdm_host_is_pinned(const void* p) {
+  HostPool& hp = *host_pool();
+  std::lock_guard<std::mutex> lock(hp.mu);
+  auto it = hp.live.find(p);
+  return (it != hp.live.end() && it->second != -2) ? 1 : 0;
 }
 
 int fdm_engine_flush(fdm_engine* e) {
@@ -1500,6 +1644,11 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
   }
   if (std::strcmp(key, "overlap") == 0) {
     e->overlap = value != 0;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "zero_copy") == 0) {
+    if (value < 0) return fail(FDM_ERR_INVALID, "zero_copy: a point count (0 = off)");
+    e->zero_copy = value;
     return FDM_OK;
   }
   if (std::strcmp(key, "dbg_ray") == 0) {

@@ -60,6 +60,15 @@ struct Scratch {
   float* cap_var;                // [n] sigma_z^2 of every input point (nullable on its own)
   int cap_drop_nan;              // 1: a point the crops dropped is stored with x = NaN (ray stage input)
   float* ras_z;                  // [cells] min z observed by this scan (NaN = not observed)
+  // optional write-through (fdm_engine_integrate_async on PINNED host arrays): the bin kernel reads
+  // the scan over PCIe exactly once and leaves a copy in HBM for the update kernel's gather
+  float* wt_x;                   // [n] null = off
+  float* wt_y;
+  float* wt_z;
+  float* wt_var;                 // [n] copy of wt_src_var (channels the bin kernel does not use itself)
+  uint32_t* wt_rgb;
+  const float* wt_src_var;
+  const uint32_t* wt_src_rgb;
 };
 
 struct KalmanLayers {
@@ -225,6 +234,15 @@ __device__ __forceinline__ void bin4_body(const ScanParams& P, const GeomConst& 
     }
   }
 
+  if (S.wt_x) {  // leave the raw scan in HBM for the update kernel (see Scratch::wt_x)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (i0 + j >= P.n) break;
+      S.wt_x[i0 + j] = xs[j]; S.wt_y[i0 + j] = ys[j]; S.wt_z[i0 + j] = zs[j];
+      if (S.wt_var) S.wt_var[i0 + j] = S.wt_src_var[i0 + j];
+      if (S.wt_rgb) S.wt_rgb[i0 + j] = S.wt_src_rgb[i0 + j];
+    }
+  }
   for (int k = threadIdx.x; k < kHashSlots; k += THREADS) {
     h_key[k] = kEmptyKey;
     h_cell[k] = kEmptyCell;
@@ -378,6 +396,11 @@ __device__ __forceinline__ void bin_body(const ScanParams& P, const GeomConst& G
     y = py[i];
     z = pz[i];
     if (P.has_intensity) vint = pint[i];
+    if (S.wt_x) {  // leave the raw scan in HBM for the update kernel (see Scratch::wt_x)
+      S.wt_x[i] = x; S.wt_y[i] = y; S.wt_z[i] = z;
+      if (S.wt_var) S.wt_var[i] = S.wt_src_var[i];
+      if (S.wt_rgb) S.wt_rgb[i] = S.wt_src_rgb[i];
+    }
   }
   const DevCand cand = block_candidate(P, G, st, &s_cand, bid);
 
@@ -858,6 +881,59 @@ __global__ __launch_bounds__(256) void k_update_stamped(
     update_body<POLICY, 256>(P, G, st, L, all_layers, n_layers, S, px, py, pz, prgb, pvar, ncell,
                              blockIdx.x * kStampTiles + q);
     __syncthreads();  // the body's shared counters are reused by the next live tile
+  }
+}
+
+// Scan statistics for the synchronous entry points (fdm_scan_stats): the per-block / per-tile
+// partial counts are summed on the device and the result is stored straight into a host-mapped
+// struct, so the host pays one stream sync and no copies (three blocking D2H copies before: ~50 us
+// of a 136 us synchronous integrate at C2).
+struct StatsAcc {  // device
+  unsigned long long n_pass, n_in, n_touched;
+  unsigned done;
+};
+struct StatsOut {  // pinned host memory, written by the last block
+  unsigned long long n_pass, n_in, n_touched;
+  int shr, shc;
+};
+__global__ __launch_bounds__(256) void k_collect_stats(const unsigned long long* __restrict__ bin_part,
+                                                       unsigned n_bin, const uint32_t* __restrict__ upd_part,
+                                                       unsigned n_tiles, const DevState* __restrict__ st, int slot,
+                                                       StatsAcc* __restrict__ acc, StatsOut* __restrict__ out) {
+  unsigned long long np = 0, ni = 0, nt = 0;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n_bin; i += gridDim.x * 256u) {
+    const unsigned long long v = bin_part[i];
+    np += uint32_t(v);
+    ni += uint32_t(v >> 32);
+  }
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n_tiles; i += gridDim.x * 256u) nt += upd_part[i];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    np += __shfl_down(np, d);
+    ni += __shfl_down(ni, d);
+    nt += __shfl_down(nt, d);
+  }
+  __shared__ unsigned long long s_sum[4][3];
+  __shared__ unsigned s_last;
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_sum[wave][0] = np; s_sum[wave][1] = ni; s_sum[wave][2] = nt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&acc->n_pass, s_sum[0][0] + s_sum[1][0] + s_sum[2][0] + s_sum[3][0]);
+    atomicAdd(&acc->n_in, s_sum[0][1] + s_sum[1][1] + s_sum[2][1] + s_sum[3][1]);
+    atomicAdd(&acc->n_touched, s_sum[0][2] + s_sum[1][2] + s_sum[2][2] + s_sum[3][2]);
+    __threadfence();
+    s_last = atomicAdd(&acc->done, 1u) == gridDim.x - 1u ? 1u : 0u;
+    if (s_last) {  // every block's sums are in: publish to the host and re-arm the accumulators
+      __threadfence();
+      out->n_pass = atomicExch(&acc->n_pass, 0ull);
+      out->n_in = atomicExch(&acc->n_in, 0ull);
+      out->n_touched = atomicExch(&acc->n_touched, 0ull);
+      out->shr = st->cand[slot].shr;
+      out->shc = st->cand[slot].shc;
+      acc->done = 0u;
+      __threadfence_system();
+    }
   }
 }
 

@@ -47,6 +47,35 @@ def _dptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+class HostArray:
+    """A 1-D numpy array over pinned memory from the engine's pool (fdm_host_alloc): what the host
+    entry points read IN PLACE instead of copying.  Returned to the pool when collected."""
+
+    def __init__(self, n, dtype=np.float32):
+        self._lib = capi.load()
+        dt = np.dtype(dtype)
+        self._p = self._lib.fdm_host_alloc(max(int(n) * dt.itemsize, 1))
+        if not self._p:
+            raise MemoryError("fdm_host_alloc failed")
+        buf = (C.c_char * (int(n) * dt.itemsize)).from_address(self._p)
+        self.array = np.frombuffer(buf, dtype=dt, count=int(n))
+        self.pinned = bool(self._lib.fdm_host_is_pinned(self._p))
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            self._lib.fdm_host_free(self._p)
+            self._p = None
+
+
+def host_array(values, dtype=np.float32):
+    """Copy `values` into a pooled pinned array; keep the returned HostArray alive while `.array` is used."""
+    v = np.ascontiguousarray(values, dtype=dtype).reshape(-1)
+    h = HostArray(v.size, dtype)
+    h.array[:] = v
+    return h
+
+
 class Engine:
     def __init__(self, width, height, resolution, cfg=None, position=(0.0, 0.0), tile=None,
                  device=0):

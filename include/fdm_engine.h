@@ -138,11 +138,16 @@ int fdm_engine_integrate_device(fdm_engine* e, uint64_t n, const float* d_x, con
                                 const float* d_sigma_z2, const double T_base_sensor[16],
                                 const double T_world_base[16]);
 
-/* Same, HOST arrays, enqueue-only: the channels are copied into a rotating staging block with
- * hipMemcpyAsync on the engine's stream and the scan is enqueued behind the copy; nothing waits.
- * For a stream of scans from host memory (bag replay): pass pinned (hipHostMalloc / hipHostRegister)
- * arrays so the copies are truly asynchronous, and keep each scan's arrays untouched until its copy
- * has run (fdm_engine_sync(), or an event recorded on fdm_engine_stream()). */
+/* Same, HOST arrays, enqueue-only; nothing waits.  For a stream of scans from host memory (bag replay,
+ * a ROS callback).
+ *   PINNED arrays (fdm_host_alloc / hipHostMalloc / hipHostRegister): no copy is queued — the bin kernel
+ *     reads the arrays in place over PCIe (once) and leaves a copy in an HBM staging block for the
+ *     update kernel; one launch per scan.  Keep a scan's arrays untouched until its launch has run
+ *     (fdm_engine_sync(), or an event recorded on fdm_engine_stream()).
+ *   pageable arrays: copied into a rotating staging block with hipMemcpyAsync (which the runtime
+ *     stages, i.e. the call blocks for the copy), scan enqueued behind the copies.
+ * The synchronous host entry points (fdm_engine_integrate, fdm_engine_update) make the same choice.
+ * fdm_engine_set_option(e, "zero_copy", max_points) bounds the in-place path (0 = always copy). */
 int fdm_engine_integrate_async(fdm_engine* e, uint64_t n, const float* x, const float* y,
                                const float* z, const float* intensity, const uint32_t* rgb,
                                const float* sigma_z2, const double T_base_sensor[16],
@@ -314,6 +319,18 @@ int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* 
 int fdm_engine_apply_feature_extraction(fdm_engine* e, float analysis_radius, int min_valid_neighbors,
                                         float step_lower_percentile, float step_upper_percentile);
 
+/* Pinned host memory for input clouds (the arrays fdm_engine_integrate* read in place, see
+ * fdm_engine_integrate_async).  Blocks come from a process-wide pool of hipHostMalloc'ed memory in
+ * power-of-two size classes — a cloud allocated per sensor message costs a free-list pop, not a
+ * driver call — and go back to the pool on fdm_host_free; fdm_host_trim() returns the pool's idle
+ * blocks to the system.  Thread-safe.  Without a usable GPU the block is ordinary (pageable) memory,
+ * which the engine then copies instead of reading in place; fdm_host_is_pinned tells which.
+ * (Replaces the std::vector storage behind nanopcl::PointCloud, point_cloud.hpp:126-134.) */
+void* fdm_host_alloc(uint64_t bytes);
+void fdm_host_free(void* p);
+void fdm_host_trim(void);
+int fdm_host_is_pinned(const void* p);
+
 /* Parity / measurement instrumentation (not in the reference). */
 int fdm_engine_enable_cell_ids(fdm_engine* e, int on);
 /* per input point of the last scan: linear cell id (col*rows+row), -1 cropped, -2 outside map */
@@ -330,6 +347,7 @@ int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2);
  *   "dense"       0/1   : update sweep visits every tile (1) or only stamped tiles (0)
  *   "records"     0/1   : estimator state packed into per-cell records (1) or one array per layer (0)
  *   "bin_table"   0/1   : k_bin folds poorly merged waves into a per-block LDS cell table before the atomics
+ *   "zero_copy"   n     : host entry points read PINNED input arrays of up to n points in place (0 = always copy)
  *   "overlap"     0/1   : hold the update of a small scan back and fuse it with the next scan's bin launch
  *   "dbg_*"             : measurement-only switches used by scripts/ab_kernels.py */
 int fdm_engine_set_option(fdm_engine* e, const char* key, int value);

@@ -196,11 +196,14 @@ def test_chain_rgbd_p2_colour_large(gpu, R):
     assert "color" in eng.layers()
 
 
-def test_host_streaming_entry_point(gpu, R):
-    """fdm_engine_integrate_async: pinned host arrays, H2D copy + scan enqueued per call, no waits;
-    three rotating staging blocks keep a held-back update's inputs alive."""
+@pytest.mark.parametrize("zero_copy", [0, 1 << 20])
+def test_host_streaming_entry_point(gpu, R, zero_copy):
+    """fdm_engine_integrate_async on PINNED host arrays, enqueue only.  zero_copy = 0: H2D copies into
+    three rotating staging blocks + the scan; default: the bin kernel reads the pinned arrays in place
+    and writes them through to the staging block the held-back update gathers from."""
     wl = gpu.synth.vlp16(n_scans=9)
     eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
+    eng.set_option("zero_copy", zero_copy)
     pinned = []
     for k in range(9):
         s = wl.scan(k)
@@ -213,6 +216,54 @@ def test_host_streaming_entry_point(gpu, R):
     assert rc == 0 and st["n_input"] == 28800
     assert_layers_equal(eng, ref)
     assert same_geometry(eng.geometry(), ref.geometry())
+
+
+def test_host_streaming_pageable_arrays_are_staged(gpu, R):
+    """Plain (pageable) numpy arrays are not device-visible: the same entry point falls back to copies."""
+    wl = gpu.synth.vlp16(n_scans=4)
+    eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
+    for k in range(4):
+        s = wl.scan(k)
+        eng.integrate_async(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k), intensity=s["intensity"])
+        ref_step(ref, s, wl.T_base_sensor, wl.pose(k))
+    assert_layers_equal(eng, ref)
+
+
+def test_host_streaming_rgbd_in_place(gpu, R):
+    """configs[2] from pinned memory: k_bin4 reads x/y/z in place, the colour channel (which only the
+    update kernel consumes) is copied through by the bin kernel as well."""
+    wl = gpu.synth.rgbd(n_scans=4)
+    eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
+    pinned = []
+    for k in range(4):
+        s = wl.scan(k)
+        h = {c: torch.from_numpy(np.ascontiguousarray(s[c])).pin_memory() for c in ("x", "y", "z", "rgb")}
+        pinned.append(h)
+        eng.integrate_async(h["x"].numpy(), h["y"].numpy(), h["z"].numpy(), wl.T_base_sensor, wl.pose(k),
+                            rgb=h["rgb"].numpy())
+        ref_step(ref, s, wl.T_base_sensor, wl.pose(k))
+    assert_layers_equal(eng, ref)
+    assert "color" in eng.layers()
+
+
+def test_host_streaming_in_place_with_raycasting(gpu, R):
+    """The in-place path with the ray stage on (not a plain scan: the update is not held back)."""
+    wl = gpu.synth.vlp16(n_scans=4)
+
+    def cfg(c):
+        c = wl.apply_to(c)
+        c.raycast_enabled = 1
+        return c
+    eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, cfg)
+    pinned = []
+    for k in range(4):
+        s = wl.scan(k)
+        h = {c: torch.from_numpy(np.ascontiguousarray(s[c])).pin_memory() for c in ("x", "y", "z", "intensity")}
+        pinned.append(h)
+        eng.integrate_async(h["x"].numpy(), h["y"].numpy(), h["z"].numpy(), wl.T_base_sensor, wl.pose(k),
+                            intensity=h["intensity"].numpy())
+        ref_step(ref, s, wl.T_base_sensor, wl.pose(k))
+    assert_layers_equal(eng, ref)
 
 
 def test_update_device_chain(gpu, R):
