@@ -405,12 +405,12 @@ int activate_records(fdm_engine* e, int kind) {
 bool voxel_size_ok(float v);
 int ensure_ray_layers(fdm_engine* e);
 int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slot, const float* dx,
-                       const float* dy, const float* dz, const double* box, bool* compact);
+                       const float* dy, const float* dz, const double* box, int* key_mode);
 fdm_raycast_config ray_config_of(const fdm_config& c);
 RayParams make_ray_params(fdm_engine* e, const fdm_raycast_config& c, const float* origin, unsigned n,
                           int slot, int flag_slot);
 int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float* dx, const float* dy,
-                      const float* dz, bool compact_keys = false);
+                      const float* dz, int key_mode = 0);
 
 // One scan = k_bin + k_update on the stream.  All pointers are device pointers.
 // `gather` (nullable): where the UPDATE kernel reads the winning points from.  Set when dx..dvar are
@@ -709,12 +709,12 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     const float origin[3] = {P.ray_ox, P.ray_oy, P.ray_oz};
     // cropRange keeps d^2 <= range_max^2 around the BASE origin, i.e. around T_world_base's translation
     const double box[4] = {P.base_x, P.base_y, P.base_z, double(e->cfg.range_max)};
-    bool compact = false;
+    int key_mode = 0;
     if ((rc = enqueue_voxel_sort(e, P.n, static_cast<float>(e->G.res), P.slot, e->S.cap_x, e->S.cap_y,
-                                 e->S.cap_z, box, &compact)))
+                                 e->S.cap_z, box, &key_mode)))
       return rc;
     const RayParams Q = make_ray_params(e, ray_config_of(e->cfg), origin, P.n, (P.slot + 1) & 3, P.slot);
-    if ((rc = enqueue_ray_stage(e, Q, true, e->S.cap_x, e->S.cap_y, e->S.cap_z, compact))) return rc;
+    if ((rc = enqueue_ray_stage(e, Q, true, e->S.cap_x, e->S.cap_y, e->S.cap_z, key_mode))) return rc;
     if (e->profile) {
       HIPCK(hipEventRecord(e->ev_ray[1], e->stream));
       e->ray_timed = true;

@@ -57,10 +57,10 @@ int ensure_voxel_buffers(fdm_engine* e, size_t n) {
 
 // keys -> stable sort: vkeys[1] / vidx[1] hold the voxel-ordered scan afterwards.
 // `box` (nullable): centre + half extent [m] of a box that holds every finite point of the cloud;
-// with it the compact 32-bit key is used when 3 * bits <= 31.  Returns through *compact which key
-// type the sorted buffer holds.
+// with it the compact 32-bit key is used when 3 * bits <= 31.  *key_mode tells what the buffers hold:
+// 0 = sorted uint64 keys, 1 = sorted uint32 compact keys.
 int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slot, const float* dx,
-                       const float* dy, const float* dz, const double* box, bool* compact) {
+                       const float* dy, const float* dz, const double* box, int* key_mode) {
   if (int rc = ensure_voxel_buffers(e, n)) return rc;
   const float inv = 1.0f / voxel_size;  // voxel_grid_impl.hpp:46
   VoxelCompact C{0, 0, 0, 0};
@@ -76,9 +76,10 @@ int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slo
       C.z0 = int(std::floor((box[2] - half) * double(inv))) - 1;
     }
   }
-  *compact = C.bits > 0 && 3 * C.bits <= 31;  // true: the sorted buffer holds uint32 keys
+  const bool compact = C.bits > 0 && 3 * C.bits <= 31;  // true: the sorted buffer holds uint32 keys
+  *key_mode = compact ? 1 : 0;
   size_t bytes = e->sort_tmp_bytes;
-  if (*compact) {
+  if (compact) {
     uint32_t* k0 = reinterpret_cast<uint32_t*>(e->vkeys[0]);
     uint32_t* k1 = reinterpret_cast<uint32_t*>(e->vkeys[1]);
     hipLaunchKernelGGL(k_voxel_keys<uint32_t>, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, inv, flag_slot, C,
@@ -130,7 +131,7 @@ RayParams make_ray_params(fdm_engine* e, const fdm_raycast_config& c, const floa
 
 // processScan + resolveGhostCells on the stream.  voxel: the points are vkeys[1]/vidx[1] runs.
 int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float* dx, const float* dy,
-                      const float* dz, bool compact_keys) {
+                      const float* dz, int key_mode) {
   int rc;
   if ((rc = ensure_ray_cells(e))) return rc;
   Layer* elev = find_layer(e, "elevation");
@@ -147,7 +148,7 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float
   if ((rc = ensure_voxel_buffers(e, Q.n))) return rc;  // vidx[0] doubles as the ray queue
   uint32_t* ray_list = e->vidx[0];
   if (voxel) {
-    if (compact_keys)
+    if (key_mode == 1)
       hipLaunchKernelGGL(k_voxel_mark<uint32_t>, dim3(blocks), dim3(256), 0, e->stream, Q.n,
                          reinterpret_cast<const uint32_t*>(e->vkeys[1]), e->vidx[1], e->vsel);
     else
@@ -239,8 +240,8 @@ int fdm_engine_voxel_any(fdm_engine* e, uint64_t n, const float* x, const float*
   const uint32_t* dc;
   int rc = stage_inputs(e, n, x, y, z, nullptr, nullptr, nullptr, &dx, &dy, &dz, &da, &dc, &dv);
   if (rc) return rc;
-  bool compact = false;
-  if ((rc = enqueue_voxel_sort(e, unsigned(n), voxel_size, -1, dx, dy, dz, nullptr, &compact))) return rc;
+  int key_mode = 0;  // no box: full 63-bit keys
+  if ((rc = enqueue_voxel_sort(e, unsigned(n), voxel_size, -1, dx, dy, dz, nullptr, &key_mode))) return rc;
   hipLaunchKernelGGL(k_voxel_select, dim3(unsigned((n + 255) / 256)), dim3(256), 0, e->stream, unsigned(n),
                      e->vkeys[1], e->vidx[1], e->vsel);
   HIPCK(hipGetLastError());

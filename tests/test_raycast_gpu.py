@@ -122,6 +122,20 @@ class TestVoxelGridAny:
         z = np.zeros(n, dtype=F32)
         check_voxel(gpu, R, x, y, z, 0.1)
 
+    def test_mixed_run_lengths_across_block_boundaries(self, gpu, R):
+        # runs of 1 .. ~700 sorted positions: ends inside the head's block, in the 256 positions
+        # after it (second boundary ballot) and beyond (bisection); NaNs make an invalid tail
+        rng = np.random.default_rng(14)
+        parts = []
+        for v in range(400):
+            m = int(rng.integers(1, 700))
+            c = rng.uniform(-8, 8, 3)
+            parts.append(c + rng.uniform(0, 0.09, (m, 3)))
+        pts = np.concatenate(parts).astype(F32)
+        pts = pts[rng.permutation(len(pts))]
+        pts[rng.integers(0, len(pts), 500), 0] = np.nan
+        check_voxel(gpu, R, pts[:, 0], pts[:, 1], pts[:, 2], 0.1)
+
     def test_everything_in_one_voxel(self, gpu, R):
         n = 70_001
         x = np.full(n, 0.01, dtype=F32)
