@@ -50,9 +50,11 @@ def test_c3_rgbd_p2_colour(gpu, R):
     assert "color" in eng.layers() and np.isfinite(eng.layer("elevation")).sum() > 1000
 
 
-def test_c4_lidar128_rolling_reduced(gpu, R):
-    """configs[3] at 1/8 azimuth density (262K pts): 60x60 m @ 0.05 m, 8-cell shift per scan."""
-    wl = gpu.synth.lidar128(n_scans=6, n_az=2048)
+@pytest.mark.parametrize("order", ["azimuth", "ring"])
+def test_c4_lidar128_rolling_reduced(gpu, R, order):
+    """configs[3] at 1/8 azimuth density (262K pts): 60x60 m @ 0.05 m, 8-cell shift per scan.
+    Ring-major order = long same-cell runs across the lanes of k_bin4 (cross-lane run merge)."""
+    wl = gpu.synth.lidar128(n_scans=6, n_az=2048, order=order)
     eng, ref, _ = run_workload(gpu, R, wl, 6, check_every=3)
     assert eng.last_stats()[1]["shift_rows"] == -8
 
@@ -211,6 +213,7 @@ def test_bin_kernel_variants_agree(gpu, R, order):
     wl = gpu.synth.vlp16(n_scans=3, order=order)
     engs = [gpu.Engine(wl.width, wl.height, wl.resolution, wl.apply_to(gpu.capi.default_config()))
             for _ in range(3)]
+    engs[0].set_option("bin_variant", 4)  # (a 28.8 K-point scan would take k_bin by itself)
     engs[1].set_option("bin_variant", 1)
     engs[2].set_option("bin_variant", 1)
     engs[2].set_option("wave_merge", 0)
