@@ -86,6 +86,7 @@ struct ScanParams {
   int prev_gate;       //    exactly as that update will commit it, instead of reading the committed slot
   int bin_table;       // k_bin: fold the block's run tails into an LDS table before going to memory
   int dbg_no_atomics;  // experiment switch (bench A/B only): skip the scratch atomics
+  int drop_nonfinite;  // 1: a point with a non-finite coordinate does not exist (PointCloud2 ingest, from_impl)
   int dbg_upd;         // experiment switch: 1 = k_update returns after the context, 2 = after round 1
 };
 

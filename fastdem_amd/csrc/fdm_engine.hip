@@ -85,7 +85,10 @@ struct fdm_engine {
   StatsAcc* d_stats_acc = nullptr;
   uint64_t scan_no = 0;
   bool have_scan = false;
-  uint32_t last_n = 0;
+  uint32_t last_n = 0;        // points of the last scan as enqueued (array length of the captures / cell ids)
+  uint32_t last_n_input = 0;  // ... as the reference counts them (cloud.size(): finite points of a PointCloud2)
+  int next_drop_nonfinite = 0;  // set by fdm_engine_integrate_cloud2 for the scan it enqueues
+  unsigned ingest_blocks = 0; // > 0: the last scan came through k_ingest_soa; its finite count is still on the device
   int last_was_integrate = 0;
   // staging for the host-pointer entry points
   float* d_stage = nullptr;
@@ -527,6 +530,8 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   P.dbg_no_atomics = e->dbg_no_atomics;
   P.bin_table = e->bin_table;
   P.dbg_upd = e->dbg_upd;
+  P.drop_nonfinite = e->next_drop_nonfinite;
+  e->next_drop_nonfinite = 0;
   // a held-back update leaves now: fused with this bin if this scan is a plain small one, alone otherwise
   const bool bin4_fusable = use_bin4 && (bin_threads == 256 || bin_threads == 512) && e->upd_fuses_bin4;
   const bool fuse_now = e->chain && plain && (!use_bin4 || bin4_fusable) && e->upd_fused;
@@ -723,6 +728,8 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   e->scan_no++;
   e->have_scan = true;
   e->last_n = uint32_t(n);
+  e->last_n_input = uint32_t(n);
+  e->ingest_blocks = 0;
   e->last_was_integrate = P.integrate_mode;
   return FDM_OK;
 }
@@ -858,13 +865,17 @@ int read_stats(fdm_engine* e, fdm_scan_stats* out, int* status) {
     const unsigned work = std::max<unsigned>(e->last_bin_blocks, unsigned(e->n_tiles));
     const unsigned blocks = std::min(64u, std::max(1u, (work + 4095u) / 4096u));
     hipLaunchKernelGGL(k_collect_stats, dim3(blocks), dim3(256), 0, e->stream, e->S.bin_part, e->last_bin_blocks,
-                       e->S.upd_part, unsigned(e->n_tiles), e->d_state, int((e->scan_no - 1) & 3), e->d_stats_acc,
-                       e->h_stats_dev);
+                       e->S.upd_part, unsigned(e->n_tiles), e->pack_counts, e->ingest_blocks, e->d_state,
+                       int((e->scan_no - 1) & 3), e->d_stats_acc, e->h_stats_dev);
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(e->stream));
   }
   const uint64_t np = e->h_stats->n_pass, ni = e->h_stats->n_in, nt = e->h_stats->n_touched;
-  s.n_input = e->last_n;
+  if (e->ingest_blocks) {  // PointCloud2 scan: cloud.size() is the number of finite points (from_impl)
+    e->last_n_input = uint32_t(e->h_stats->n_finite);
+    e->ingest_blocks = 0;
+  }
+  s.n_input = e->last_n_input;
   s.n_after_filter = uint32_t(np);
   s.n_in_map = uint32_t(ni);
   s.n_cells_touched = uint32_t(nt);
@@ -874,7 +885,7 @@ int read_stats(fdm_engine* e, fdm_scan_stats* out, int* status) {
     s.shift_cols = e->h_stats->shc;
   }
   if (e->last_was_integrate) {
-    if (e->last_n == 0) *status = FDM_SKIP_EMPTY_CLOUD;
+    if (e->last_n_input == 0) *status = FDM_SKIP_EMPTY_CLOUD;
     else if (np == 0) *status = FDM_SKIP_ALL_FILTERED;
   }
   if (out) *out = s;
@@ -1152,6 +1163,8 @@ int fdm_engine_integrate_device(fdm_engine* e, uint64_t n, const float* dx, cons
   if (n == 0) {  // fastdem.cpp:125-128: nothing is touched, not even the move
     e->have_scan = true;
     e->last_n = 0;
+    e->last_n_input = 0;
+    e->ingest_blocks = 0;
     e->last_was_integrate = 1;
     // consume no slot; last_stats reports SKIP_EMPTY_CLOUD
     return FDM_OK;

@@ -1,6 +1,26 @@
 // fdm_engine_io.inl — host side of PointCloud2 ingest (fdm_ingest.hpp) and map egress (fdm_egress.hpp).
 // Part of fdm_engine.hip's translation unit (included at its end): do not compile on its own.
 
+namespace {
+// fdm_cloud2_layout -> IngestLayout; L.aligned covers the record layout only (the caller adds the blob's address)
+int check_cloud2_layout(const fdm_cloud2_layout* lay, IngestLayout& L) {
+  const uint32_t step = lay->point_step;
+  auto fits = [&](int32_t off, uint32_t len) { return off < 0 || uint64_t(off) + len <= step; };
+  const uint32_t ilen = lay->intensity_type == 8 ? 8 : (lay->intensity_type == 7 ? 4 : (lay->intensity_type == 4 ? 2 : 1));
+  if (step == 0 || !fits(lay->off_x, 4) || !fits(lay->off_y, 4) || !fits(lay->off_z, 4) ||
+      !fits(lay->off_intensity, ilen) || !fits(lay->off_rgb, 4))
+    return fail(FDM_ERR_INVALID, "field offset outside the point record");
+  L.point_step = step;
+  L.off_x = lay->off_x; L.off_y = lay->off_y; L.off_z = lay->off_z;
+  L.off_intensity = lay->off_intensity; L.intensity_type = lay->intensity_type;
+  L.off_rgb = lay->off_rgb;
+  auto al4 = [](int32_t off) { return off < 0 || (off & 3) == 0; };
+  L.aligned = (step & 3u) == 0 && al4(L.off_x) && al4(L.off_y) && al4(L.off_z) && al4(L.off_rgb) &&
+              (L.intensity_type < 7 || al4(L.off_intensity));
+  return FDM_OK;
+}
+}  // namespace
+
 extern "C" {
 
 // ---- ingest ----
@@ -15,12 +35,9 @@ int fdm_engine_ingest_cloud2(fdm_engine* e, const void* data, int on_device, uin
   if (lay->off_x < 0 || lay->off_y < 0 || lay->off_z < 0) return FDM_OK;   // impl.hpp:183-186: no xyz
   if (!data) return fail(FDM_ERR_INVALID, "null data");
   if (n_points >= 0xFFFFFFFEull) return fail(FDM_ERR_INVALID, "point count exceeds 2^32-2");
-  const uint32_t step = lay->point_step;
-  auto fits = [&](int32_t off, uint32_t len) { return off < 0 || uint64_t(off) + len <= step; };
-  const uint32_t ilen = lay->intensity_type == 8 ? 8 : (lay->intensity_type == 7 ? 4 : (lay->intensity_type == 4 ? 2 : 1));
-  if (step == 0 || !fits(lay->off_x, 4) || !fits(lay->off_y, 4) || !fits(lay->off_z, 4) ||
-      !fits(lay->off_intensity, ilen) || !fits(lay->off_rgb, 4))
-    return fail(FDM_ERR_INVALID, "field offset outside the point record");
+  IngestLayout L{};
+  if (int rc_lay = check_cloud2_layout(lay, L)) return rc_lay;
+  const uint32_t step = L.point_step;
   HIPCK(hipSetDevice(e->device));
   const size_t bytes = size_t(n_points) * step;
   const uint8_t* blob = static_cast<const uint8_t*>(data);
@@ -40,14 +57,7 @@ int fdm_engine_ingest_cloud2(fdm_engine* e, const void* data, int on_device, uin
     e->in_cap = ((n_points + n_points / 4 + 1024) + 3) & ~size_t(3);  // channels stay 16-byte aligned
     HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_in), e->in_cap * 5 * sizeof(float)));
   }
-  IngestLayout L{};
-  L.point_step = step;
-  L.off_x = lay->off_x; L.off_y = lay->off_y; L.off_z = lay->off_z;
-  L.off_intensity = lay->off_intensity; L.intensity_type = lay->intensity_type;
-  L.off_rgb = lay->off_rgb;
-  auto al4 = [](int32_t off) { return off < 0 || (off & 3) == 0; };
-  L.aligned = (reinterpret_cast<uintptr_t>(blob) & 3u) == 0 && (step & 3u) == 0 && al4(L.off_x) && al4(L.off_y) &&
-              al4(L.off_z) && al4(L.off_rgb) && (L.intensity_type < 7 || al4(L.off_intensity));
+  L.aligned = L.aligned && (reinterpret_cast<uintptr_t>(blob) & 3u) == 0;
   const unsigned blocks = unsigned((n_points + 255) / 256);
   if (size_t(blocks) + 1 > e->pack_counts_cap) {
     if (int rc_sync = sync_all(e)) return rc_sync;
@@ -85,24 +95,67 @@ int fdm_engine_ingested(fdm_engine* e, const float** dx, const float** dy, const
   return FDM_OK;
 }
 
+// from_impl + integrate without a host round trip in between: one decode kernel writes the SoA
+// channels at the MESSAGE's indices (no compaction), the bin kernel drops the non-finite points
+// itself, and cloud.size() (n_input, the empty-cloud decision) is summed on the device with the
+// other statistics.  A pinned message (fdm_host_alloc) is decoded in place over PCIe.
 int fdm_engine_integrate_cloud2(fdm_engine* e, const void* data, int on_device, uint64_t n_points,
                                 const fdm_cloud2_layout* lay, const double Tbs[16], const double Twb[16],
                                 fdm_scan_stats* out) {
   if (e) { if (int rc_join = join_streams(e)) return rc_join; }
   if (!e || !lay || !Tbs || !Twb) return fail(FDM_ERR_INVALID, "null argument");
-  uint64_t n = 0;
-  int rc = fdm_engine_ingest_cloud2(e, data, on_device, n_points, lay, &n);
-  if (rc) return rc;
-  if (n == 0) {  // fastdem.cpp:125-128
+  auto empty = [&]() {  // fastdem.cpp:125-128
     if (out) std::memset(out, 0, sizeof(*out));
-    return FDM_SKIP_EMPTY_CLOUD;
+    return int(FDM_SKIP_EMPTY_CLOUD);
+  };
+  if (n_points == 0) return empty();                                              // impl.hpp:178-181
+  if (lay->off_x < 0 || lay->off_y < 0 || lay->off_z < 0) return empty();          // impl.hpp:183-186: no xyz
+  if (!data) return fail(FDM_ERR_INVALID, "null data");
+  if (n_points >= 0xFFFFFFFEull) return fail(FDM_ERR_INVALID, "point count exceeds 2^32-2");
+  IngestLayout L{};
+  int rc;
+  if ((rc = check_cloud2_layout(lay, L))) return rc;
+  HIPCK(hipSetDevice(e->device));
+  const size_t bytes = size_t(n_points) * L.point_step;
+  const uint8_t* blob = static_cast<const uint8_t*>(data);
+  if (!on_device) {
+    const void* alias = e->zero_copy ? pinned_alias(data) : nullptr;
+    if (alias) {
+      blob = static_cast<const uint8_t*>(alias);
+    } else {
+      if (bytes > e->blob_cap) {
+        if (int rc_sync = sync_all(e)) return rc_sync;
+        if (e->d_blob) HIPCK(hipFree(e->d_blob));
+        e->blob_cap = bytes + bytes / 4 + 4096;
+        HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_blob), e->blob_cap));
+      }
+      HIPCK(hipMemcpyAsync(e->d_blob, data, bytes, hipMemcpyHostToDevice, e->stream));
+      blob = e->d_blob;
+    }
   }
-  const float *dx, *dy, *dz, *di;
-  const uint32_t* dc;
-  fdm_engine_ingested(e, &dx, &dy, &dz, &di, &dc, nullptr);
+  L.aligned = L.aligned && (reinterpret_cast<uintptr_t>(blob) & 3u) == 0;
+  if ((rc = ensure_stage(e, n_points))) return rc;
+  e->stage_rr = (e->stage_rr + 1) % kStageSlots;
+  const size_t cap = e->stage_cap;
+  float* base = e->d_stage + size_t(e->stage_rr) * 6 * cap;
+  const unsigned blocks = unsigned((n_points + 255) / 256);
+  if (size_t(blocks) + 1 > e->pack_counts_cap) {
+    if (int rc_sync = sync_all(e)) return rc_sync;
+    if (e->pack_counts) HIPCK(hipFree(e->pack_counts));
+    e->pack_counts_cap = size_t(blocks) + 1 + 1024;
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->pack_counts), e->pack_counts_cap * sizeof(uint32_t)));
+  }
+  const bool hi = lay->off_intensity >= 0, hc = lay->off_rgb >= 0;
+  float* di = hi ? base + cap * 3 : nullptr;
+  uint32_t* dc = hc ? reinterpret_cast<uint32_t*>(base + cap * 4) : nullptr;
+  hipLaunchKernelGGL(k_ingest_soa, dim3(blocks), dim3(256), 0, e->stream, blob, L, n_points, e->pack_counts, base,
+                     base + cap, base + cap * 2, di, dc);
+  HIPCK(hipGetLastError());
   ScanParams P;
   fill_integrate_params(e, P, Tbs, Twb);
-  if ((rc = enqueue_scan(e, P, n, dx, dy, dz, di, dc, nullptr))) return rc;
+  e->next_drop_nonfinite = 1;
+  if ((rc = enqueue_scan(e, P, n_points, base, base + cap, base + cap * 2, di, dc, nullptr))) return rc;
+  e->ingest_blocks = blocks;  // read_stats sums the finite counts with the scan's other statistics
   int status = FDM_OK;
   if ((rc = read_stats(e, out, &status))) return rc;
   return status;

@@ -96,4 +96,45 @@ __global__ __launch_bounds__(256) void k_ingest_write(const uint8_t* __restrict_
   if (orgb) orgb[o] = load_u32(pt + L.off_rgb, L.aligned) & 0x00FFFFFFu;
 }
 
+// One-pass variant for fdm_engine_integrate_cloud2: decode in place (output index = message index),
+// no compaction.  Dropping the non-finite points is left to the bin kernel (ScanParams::
+// drop_nonfinite) — an order-preserving compaction changes no min / first / last decision, only
+// the indices — so the host needs neither the kept count nor a sync before it can size the scan's
+// launch.  counts[block] = finite points of the block (summed by k_collect_stats for n_input).
+__global__ __launch_bounds__(256) void k_ingest_soa(const uint8_t* __restrict__ blob, const IngestLayout L,
+                                                    unsigned long long n, uint32_t* __restrict__ counts,
+                                                    float* __restrict__ ox, float* __restrict__ oy,
+                                                    float* __restrict__ oz, float* __restrict__ oint,
+                                                    uint32_t* __restrict__ orgb) {
+  __shared__ unsigned s_w[4];
+  const unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+  const IngestPoint p = ingest_xyz(blob, L, i, n);
+  const unsigned long long m = __ballot(p.valid);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = unsigned(__popcll(m));
+  if (i < n) {
+    ox[i] = p.x;
+    oy[i] = p.y;
+    oz[i] = p.z;
+    const uint8_t* pt = blob + i * L.point_step;
+    if (oint) {
+      const uint8_t* q = pt + L.off_intensity;
+      float v = 0.0f;
+      if (L.intensity_type == 2) {
+        v = float(q[0]);
+      } else if (L.intensity_type == 4) {
+        v = float(unsigned(q[0]) | (unsigned(q[1]) << 8));
+      } else if (L.intensity_type == 7) {
+        v = __uint_as_float(load_u32(q, L.aligned));
+      } else if (L.intensity_type == 8) {
+        const unsigned long long lo = load_u32(q, L.aligned), hi = load_u32(q + 4, L.aligned);
+        v = static_cast<float>(__longlong_as_double((long long)(lo | (hi << 32))));
+      }
+      oint[i] = v;
+    }
+    if (orgb) orgb[i] = load_u32(pt + L.off_rgb, L.aligned) & 0x00FFFFFFu;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
 }  // namespace fdm

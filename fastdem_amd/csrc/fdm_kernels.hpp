@@ -265,7 +265,8 @@ __device__ __forceinline__ void bin4_body(const ScanParams& P, const GeomConst& 
     const bool live = i0 + j < P.n;
     float cvar = 0.f;
     if (S.cap_var && live && P.integrate_mode) cvar = sigma_z2(P, xs[j], ys[j], zs[j]);
-    const bool pass = preprocess_point(P, xs[j], ys[j], zs[j]) && live;
+    const bool exists = live && (!P.drop_nonfinite || (isfinite(xs[j]) && isfinite(ys[j]) && isfinite(zs[j])));
+    const bool pass = preprocess_point(P, xs[j], ys[j], zs[j]) && exists;
     if (S.cap_x && live) {
       S.cap_x[i0 + j] = (S.cap_drop_nan && !pass) ? __uint_as_float(0x7FC00000u) : xs[j];
       S.cap_y[i0 + j] = ys[j]; S.cap_z[i0 + j] = zs[j];
@@ -409,7 +410,8 @@ __device__ __forceinline__ void bin_body(const ScanParams& P, const GeomConst& G
   if (i < P.n) {
     float cvar = 0.f;
     if (S.cap_var && P.integrate_mode) cvar = sigma_z2(P, x, y, z);
-    pass = preprocess_point(P, x, y, z);
+    const bool exists = !P.drop_nonfinite || (isfinite(x) && isfinite(y) && isfinite(z));
+    pass = preprocess_point(P, x, y, z) && exists;
     if (S.cap_x) {
       S.cap_x[i] = (S.cap_drop_nan && !pass) ? __uint_as_float(0x7FC00000u) : x;
       S.cap_y[i] = y; S.cap_z[i] = z;
@@ -889,18 +891,20 @@ __global__ __launch_bounds__(256) void k_update_stamped(
 // struct, so the host pays one stream sync and no copies (three blocking D2H copies before: ~50 us
 // of a 136 us synchronous integrate at C2).
 struct StatsAcc {  // device
-  unsigned long long n_pass, n_in, n_touched;
+  unsigned long long n_pass, n_in, n_touched, n_finite;
   unsigned done;
 };
 struct StatsOut {  // pinned host memory, written by the last block
-  unsigned long long n_pass, n_in, n_touched;
+  unsigned long long n_pass, n_in, n_touched, n_finite;
   int shr, shc;
 };
 __global__ __launch_bounds__(256) void k_collect_stats(const unsigned long long* __restrict__ bin_part,
                                                        unsigned n_bin, const uint32_t* __restrict__ upd_part,
-                                                       unsigned n_tiles, const DevState* __restrict__ st, int slot,
+                                                       unsigned n_tiles, const uint32_t* __restrict__ ingest_part,
+                                                       unsigned n_ingest, const DevState* __restrict__ st, int slot,
                                                        StatsAcc* __restrict__ acc, StatsOut* __restrict__ out) {
-  unsigned long long np = 0, ni = 0, nt = 0;
+  unsigned long long np = 0, ni = 0, nt = 0, nf = 0;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n_ingest; i += gridDim.x * 256u) nf += ingest_part[i];
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n_bin; i += gridDim.x * 256u) {
     const unsigned long long v = bin_part[i];
     np += uint32_t(v);
@@ -912,16 +916,18 @@ __global__ __launch_bounds__(256) void k_collect_stats(const unsigned long long*
     np += __shfl_down(np, d);
     ni += __shfl_down(ni, d);
     nt += __shfl_down(nt, d);
+    nf += __shfl_down(nf, d);
   }
-  __shared__ unsigned long long s_sum[4][3];
+  __shared__ unsigned long long s_sum[4][4];
   __shared__ unsigned s_last;
   const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { s_sum[wave][0] = np; s_sum[wave][1] = ni; s_sum[wave][2] = nt; }
+  if ((threadIdx.x & 63) == 0) { s_sum[wave][0] = np; s_sum[wave][1] = ni; s_sum[wave][2] = nt; s_sum[wave][3] = nf; }
   __syncthreads();
   if (threadIdx.x == 0) {
     atomicAdd(&acc->n_pass, s_sum[0][0] + s_sum[1][0] + s_sum[2][0] + s_sum[3][0]);
     atomicAdd(&acc->n_in, s_sum[0][1] + s_sum[1][1] + s_sum[2][1] + s_sum[3][1]);
     atomicAdd(&acc->n_touched, s_sum[0][2] + s_sum[1][2] + s_sum[2][2] + s_sum[3][2]);
+    if (n_ingest) atomicAdd(&acc->n_finite, s_sum[0][3] + s_sum[1][3] + s_sum[2][3] + s_sum[3][3]);
     __threadfence();
     s_last = atomicAdd(&acc->done, 1u) == gridDim.x - 1u ? 1u : 0u;
     if (s_last) {  // every block's sums are in: publish to the host and re-arm the accumulators
@@ -929,6 +935,7 @@ __global__ __launch_bounds__(256) void k_collect_stats(const unsigned long long*
       out->n_pass = atomicExch(&acc->n_pass, 0ull);
       out->n_in = atomicExch(&acc->n_in, 0ull);
       out->n_touched = atomicExch(&acc->n_touched, 0ull);
+      out->n_finite = atomicExch(&acc->n_finite, 0ull);
       out->shr = st->cand[slot].shr;
       out->shc = st->cand[slot].shc;
       acc->done = 0u;

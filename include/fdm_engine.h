@@ -288,7 +288,11 @@ int fdm_engine_ingested(fdm_engine* e, const float** d_x, const float** d_y, con
                         const float** d_intensity, const uint32_t** d_rgb, uint64_t* n);
 /* from_impl + FastDEM::integrate(cloud, T_base_sensor, T_world_base) in one call (what the ROS
  * callback does, ros1/src/fastdem_ros_node.cpp:171-182).  Status as fdm_engine_integrate; a message
- * without x/y/z or whose points are all non-finite is an empty cloud (FDM_SKIP_EMPTY_CLOUD). */
+ * without x/y/z or whose points are all non-finite is an empty cloud (FDM_SKIP_EMPTY_CLOUD).
+ * One decode kernel + the scan, no host round trip in between: the channels are written at the
+ * message's indices, the bin kernel drops the non-finite points (the compaction from_impl does
+ * changes indices, not decisions) and cloud.size() comes back with the scan statistics.  A message in
+ * pinned memory (fdm_host_alloc) is decoded in place over PCIe; a pageable one is copied first. */
 int fdm_engine_integrate_cloud2(fdm_engine* e, const void* data, int data_on_device, uint64_t n_points,
                                 const fdm_cloud2_layout* layout, const double T_base_sensor[16],
                                 const double T_world_base[16], fdm_scan_stats* out);

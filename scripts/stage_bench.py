@@ -90,6 +90,36 @@ print(json.dumps({"stage": "ingest_cloud2", "workload": a.workload, "points": n,
                   "hbm_frac": round(alg / t / HBM, 4), "cpu_oracle_ms": round(t_cpu * 1e3, 2),
                   "speedup": round(t_cpu / t, 1)}))
 
+# ---- message -> map in one call (from_impl + integrate, fdm_engine_integrate_cloud2): one decode kernel +
+# the scan, no host round trip in between; blob in HBM / pinned message decoded over PCIe / pageable message
+import fastdem_amd  # noqa: E402
+eng2 = bench.Resident(wl, 0).eng
+tbs = bench.colmajor16(wl.T_base_sensor)
+twb = bench.colmajor16(wl.pose(0))
+st2 = fastdem_amd.capi.FdmScanStats()
+pin_msg = fastdem_amd.host_array(np.frombuffer(blob, dtype=np.uint8), dtype=np.uint8)
+page_msg = np.ascontiguousarray(np.frombuffer(blob, dtype=np.uint8)).copy()
+
+
+def msg_call(ptr, on_dev):
+    def f():
+        rc = eng2._lib.fdm_engine_integrate_cloud2(eng2._h, C.c_void_p(ptr), on_dev, n, C.byref(layout), tbs, twb, C.byref(st2))
+        assert rc == 0
+    return f
+
+
+t_hbm = timed(msg_call(d_blob.data_ptr(), 1), a.iters)
+t_pin = timed(msg_call(pin_msg.array.ctypes.data, 0), a.iters)
+t_page = timed(msg_call(page_msg.ctypes.data, 0), a.iters)
+t0 = time.perf_counter()
+for _ in range(a.cpu_iters):
+    ref.integrate_cloud2(blob, n, lay, wl.T_base_sensor, wl.pose(0))
+t_cpu = (time.perf_counter() - t0) / a.cpu_iters
+print(json.dumps({"stage": "integrate_cloud2 (message -> map, synchronous)", "workload": a.workload, "points": n,
+                  "point_step": 32, "gpu_ms_blob_in_hbm": round(t_hbm * 1e3, 4),
+                  "gpu_ms_pinned_message": round(t_pin * 1e3, 4), "gpu_ms_pageable_message": round(t_page * 1e3, 4),
+                  "cpu_oracle_ms": round(t_cpu * 1e3, 2), "speedup_pinned": round(t_cpu / t_pin, 1)}))
+
 # ---- stencil post-processing on the mapped scene ----
 for name, fn_gpu, fn_cpu, alg_bytes in (
         ("post_inpainting(3 passes)", lambda: eng.apply_inpainting(3, 2), lambda: ref.apply_inpainting(3, 2), cells * 4 * 2 * 4),

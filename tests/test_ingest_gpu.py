@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from cloud2 import make_blob
-from helpers import assert_layers_equal, pair
+from helpers import assert_layers_equal, pair, same_geometry
 
 pytestmark = pytest.mark.gpu
 F32 = np.float32
@@ -116,4 +116,58 @@ def test_blob_already_in_hbm(gpu, R):
                                       on_device_ptr=d.data_ptr())
     rc_r, st_r = ref.integrate_cloud2(blob, s["x"].size, lay, wl.T_base_sensor, wl.pose(0))
     assert rc_e == rc_r == 0 and st_e == st_r
+    assert_layers_equal(eng, ref)
+
+
+def test_integrate_cloud2_all_points_non_finite_is_an_empty_cloud(gpu, R):
+    """from_impl drops every point -> cloud.empty() -> integrate returns false before anything moves
+    (fastdem.cpp:125-128); the one-pass path decides that on the device."""
+    wl = gpu.synth.vlp16(n_scans=2)
+    eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
+    s = wl.scan(0)
+    blob, lay = make_blob(s["x"], s["y"], s["z"], intensity=s["intensity"], point_step=16)
+    for o, l in ((eng, lay_of(gpu, lay)), (ref, lay)):
+        rc, st = o.integrate_cloud2(blob, s["x"].size, l, wl.T_base_sensor, wl.pose(0))
+        assert rc == 0
+    bad = np.full(5000, np.nan, dtype=F32)
+    inf = np.full(5000, np.inf, dtype=F32)
+    blob2, lay2 = make_blob(bad, inf, -inf, point_step=16)
+    rc_e, st_e = eng.integrate_cloud2(blob2, bad.size, lay_of(gpu, lay2), wl.T_base_sensor, wl.pose(1))
+    rc_r, st_r = ref.integrate_cloud2(blob2, bad.size, lay2, wl.T_base_sensor, wl.pose(1))
+    assert rc_e == rc_r == gpu.capi.FDM_SKIP_EMPTY_CLOUD and st_e == st_r and st_e["n_input"] == 0
+    assert_layers_equal(eng, ref)
+    assert same_geometry(eng.geometry(), ref.geometry())  # the window did not move
+    assert eng.last_stats()[0] == gpu.capi.FDM_SKIP_EMPTY_CLOUD
+
+
+def test_integrate_cloud2_infinite_coordinates_are_dropped_before_the_crops(gpu, R):
+    """+Inf x passes cropRange with the default range_max (inf <= inf) when it reaches integrate();
+    through a PointCloud2 it never does (from_impl: isfinite) and must not count as a filtered-in point."""
+    eng, ref = pair(gpu, R, 8.0, 8.0, 0.1)
+    rng = np.random.default_rng(5)
+    n = 3000
+    x, y = (rng.uniform(-3, 3, n).astype(F32) for _ in range(2))
+    z = rng.normal(0, 0.1, n).astype(F32)
+    x[::7] = np.inf
+    y[3::11] = -np.inf
+    blob, lay = make_blob(x, y, z, point_step=12)
+    I = np.eye(4)
+    rc_e, st_e = eng.integrate_cloud2(blob, n, lay_of(gpu, lay), I, I)
+    rc_r, st_r = ref.integrate_cloud2(blob, n, lay, I, I)
+    assert rc_e == rc_r == 0 and st_e == st_r
+    assert st_e["n_input"] == st_e["n_after_filter"] == int((np.isfinite(x) & np.isfinite(y)).sum())
+    assert_layers_equal(eng, ref)
+
+
+def test_integrate_cloud2_pinned_message_is_decoded_in_place(gpu, R):
+    wl = gpu.synth.rgbd(n_scans=2)
+    eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
+    for k in range(2):
+        s = wl.scan(k)
+        blob, lay = make_blob(s["x"], s["y"], s["z"], rgb=s["rgb"], point_step=32)
+        msg = gpu.host_array(np.frombuffer(blob, dtype=np.uint8), dtype=np.uint8)
+        assert msg.pinned
+        rc_e, st_e = eng.integrate_cloud2(msg.array, s["x"].size, lay_of(gpu, lay), wl.T_base_sensor, wl.pose(k))
+        rc_r, st_r = ref.integrate_cloud2(blob, s["x"].size, lay, wl.T_base_sensor, wl.pose(k))
+        assert rc_e == rc_r == 0 and st_e == st_r
     assert_layers_equal(eng, ref)
