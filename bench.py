@@ -200,8 +200,19 @@ def cpu_baseline(wl, target_s=12.0):
     ref.time_integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, poses, 5, **kw)  # warm-up
     t1 = ref.time_integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, poses, 5, **kw) / 5
     iters = max(5, min(20000, int(target_s / max(t1, 1e-6))))
-    dt, stages = ref.time_integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, poses, iters,
-                                    stages=True, **kw)
+    # SURVEY.md §8d policy (nanoPCL benchmark_common.hpp:56-60): warm-up, then 50 timed samples ->
+    # median, mean +- CI95; a sample = iters/50 consecutive integrate() calls
+    per = max(1, iters // 50)
+    samples, stages = [], None
+    for _ in range(50):
+        d, st = ref.time_integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, poses, per, stages=True, **kw)
+        samples.append(d / per)
+        stages = st if stages is None else [a + b for a, b in zip(stages, st)]
+    iters = per * 50
+    dt = float(sum(samples)) * per
+    samples.sort()
+    mean = sum(samples) / len(samples)
+    sd = (sum((v - mean) ** 2 for v in samples) / (len(samples) - 1)) ** 0.5
     n = int(s["x"].size)
     cpu_model = ""
     try:
@@ -224,6 +235,8 @@ def cpu_baseline(wl, target_s=12.0):
     return {"value": n * iters / dt / 1e6, "unit": "Mpts/s", "cores": 1, "kind": "port",
             "march_native_value": native,
             "ms_per_scan": dt / iters * 1e3,
+            "ms_per_scan_median": samples[len(samples) // 2] * 1e3,
+            "ms_per_scan_ci95": 1.96 * sd / len(samples) ** 0.5 * 1e3,
             "sample": f"{iters} integrate() calls of the {n}-pt scan ({dt:.1f} s), "
                       f"oracle/libfdm_ref.so -O3 no -march, 1 thread",
             "stage_ms": {k: float(v) / iters * 1e3 for k, v in zip(names, stages)},
