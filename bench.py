@@ -188,6 +188,35 @@ def pmc_traffic(tag, kernel):
         return None
 
 
+def parity_gate(wl, R):
+    """SURVEY.md §8d "parity gate run with every benchmark": the engine that was just timed against the
+    CPU oracle (the checker) on the same workload after 1, 2 and 10 scans — cell ids bit-exact for every
+    point, every layer NaN-pattern identical and within 1e-5 relative (abs floor 1e-7)."""
+    import numpy as np
+    from fastdem_amd import Engine, capi
+    from __graft_entry__ import compare_layers
+    eng = Engine(wl.width, wl.height, wl.resolution, wl.apply_to(capi.default_config()))
+    ref = R.RefEngine(wl.width, wl.height, wl.resolution, wl.apply_to(R.default_config()))
+    eng.enable_cell_ids()
+    ref.enable_cell_ids()
+    worst, checked = 0.0, []
+    for k in range(10):
+        s = wl.scan(k)
+        kw = {c: s[c] for c in ("intensity", "rgb") if s.get(c) is not None}
+        rc_e, st_e = eng.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k), **kw)
+        rc_r, st_r = ref.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k), **kw)
+        if rc_e != rc_r or st_e != st_r:
+            raise SystemExit(f"parity gate: status/statistics differ at scan {k}: {rc_e} {st_e} vs {rc_r} {st_r}")
+        n = s["x"].size
+        if not np.array_equal(eng.last_cell_ids(n), ref.last_cell_ids(n)):
+            raise SystemExit(f"parity gate: cell ids differ at scan {k}")
+        if k + 1 in (1, 2, 10):
+            worst = max(worst, compare_layers(eng, ref))  # asserts NaN pattern + tolerance
+            checked.append(k + 1)
+    return {"after_scans": checked, "cell_ids": "bit-exact", "layers_max_rel_err": worst, "rtol": 1e-5,
+            "layers": len(ref.layers())}
+
+
 def cpu_baseline(wl, target_s=12.0):
     """The CPU oracle (single-threaded port of the reference path, -O3 no -march: the reference's
     Release flags) timed on this host on a bounded sample of the same workload."""
@@ -232,7 +261,8 @@ def cpu_baseline(wl, target_s=12.0):
         native = n * it2 / rn.time_integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, poses, it2, **kw) / 1e6
     except Exception:
         pass
-    return {"value": n * iters / dt / 1e6, "unit": "Mpts/s", "cores": 1, "kind": "port",
+    return {"parity": parity_gate(wl, R),
+            "value": n * iters / dt / 1e6, "unit": "Mpts/s", "cores": 1, "kind": "port",
             "march_native_value": native,
             "ms_per_scan": dt / iters * 1e3,
             "ms_per_scan_median": samples[len(samples) // 2] * 1e3,
