@@ -129,7 +129,11 @@ int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* 
   F.min_valid = cfg->min_valid_neighbors;
   F.n_entries = int(reg.size());
   const unsigned fblocks = unsigned((e->ncell + kFusionThreads - 1) / kFusionThreads);
-  if (int(reg.size()) <= kFusionLdsEntries) {  // sample lists in LDS
+  if (reg.size() <= 32 && !(e->dbg_ray & 1024)) {  // samples sorted in registers (the default radius: 29 cells)
+    hipLaunchKernelGGL(k_fusion_net32, dim3(fblocks), dim3(kFusionThreads), 0, e->stream, e->G, e->d_state,
+                       int(e->scan_no & 3), e->d_region, F, e->d_tmp, e->d_tmp2, lptr(e, *up), lstride(e, *up),
+                       lptr(e, *lo), lstride(e, *lo), unsigned(e->ncell));
+  } else if (int(reg.size()) <= kFusionLdsEntries) {  // sample lists in LDS
     const size_t lds = size_t(4) * reg.size() * kFusionThreads * sizeof(float);
     static bool raised = false;
     if (!raised) {
@@ -180,11 +184,22 @@ int fdm_engine_apply_feature_extraction(fdm_engine* e, float radius, int min_val
   const int need_lo = nmax > 0 ? static_cast<int>(lo_pct * float(nmax - 1)) + 1 : 1;
   const int need_hi = nmax > 0 ? (nmax - 1) - static_cast<int>(hi_pct * float(nmax - 1)) + 1 : 1;
   const bool pct_ok = lo_pct >= 0.0f && hi_pct <= 1.0f && lo_pct <= 1.0f && hi_pct >= 0.0f;
+  // the stencil reads ~113 neighbours per cell: from a cell-record field (64 B stride) every one of them
+  // is its own cache line — a dense copy of the layer first (C4: 0.82 -> see DESIGN.md §7)
+  const float* elev_p = lptr(e, *elev);
+  int elev_s = lstride(e, *elev);
+  if (elev_s != 1) {
+    if ((rc = ensure_tmp(e))) return rc;
+    if ((rc = copy_strided(e, e->d_tmp, 1, elev_p, elev_s))) return rc;
+    elev_p = e->d_tmp;
+    elev_s = 1;
+  }
   auto launch_feat = [&](auto kern) {
     hipLaunchKernelGGL(kern, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state, int(e->scan_no & 3),
-                       e->d_region, F, lptr(e, *elev), lstride(e, *elev), O, unsigned(e->ncell));
+                       e->d_region, F, elev_p, elev_s, O, unsigned(e->ncell));
   };
-  if (pct_ok && need_lo <= 16 && need_hi <= 16) launch_feat(k_features<16>);
+  if (pct_ok && need_lo <= 8 && need_hi <= 8) launch_feat(k_features<8>);  // defaults: 6 from the bottom, 7 from the top
+  else if (pct_ok && need_lo <= 16 && need_hi <= 16) launch_feat(k_features<16>);
   else launch_feat(k_features<0>);
   HIPCK(hipGetLastError());
   return FDM_OK;

@@ -190,6 +190,99 @@ __global__ __launch_bounds__(kFusionThreads) void k_fusion(const GeomConst G, co
   }
 }
 
+// Regions of up to 32 cells (the default radius: 29): no lists in memory at all.  A sample is one
+// 64-bit register, ord(value) << 32 | entry index, so that ties keep the entry order the insertion
+// sort above gives them; a fixed 191-step merge-exchange network (fdm_sortnet32.inc) sorts the
+// lower and the upper samples in registers, and the weights — shared by both lists — sit in LDS by
+// entry index.  The list kernel holds one wave per SIMD (59 KB of LDS per 128 threads) and walks a
+// dependent chain of ~1900 LDS operations per cell; this one is straight-line ALU code.
+#include "fdm_sortnet32.inc"
+#define FDM_E32(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) \
+  X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
+// One list (lower or upper bounds) of one cell: gather, sort, weighted quantile.  The two lists are
+// done one after the other so that only 32 samples are live (2 x 32 x 64 bit would hold the kernel
+// at one wave per SIMD); the second pass re-reads the neighbours from L2 and the weights from LDS.
+template <bool UPPER>
+__device__ __forceinline__ float fusion_list32(const PostGeom& p, int lr, int lc, const RegionEntry* __restrict__ reg,
+                                               const FusionParams& F, const float* __restrict__ up_in,
+                                               const float* __restrict__ lo_in, float (*s_w)[kFusionThreads],
+                                               int& valid) {
+  constexpr unsigned long long kNone = ~0ull;  // sorts behind every sample
+  int n = 0;
+  valid = 0;
+#define FDM_DECL(e) unsigned long long a##e = kNone;
+  FDM_E32(FDM_DECL)
+#undef FDM_DECL
+#define FDM_GATHER(e)                                                                         \
+  if (e < F.n_entries) {                                                                       \
+    const RegionEntry re = reg[e];                                                             \
+    if (post_inside(p, lr + re.dr, lc + re.dc)) {                                              \
+      const size_t ni = post_index(p, lr + re.dr, lc + re.dc);                                 \
+      const float nu_v = up_in[ni], nl_v = lo_in[ni];                                          \
+      if (isfinite(nu_v) && isfinite(nl_v)) {                                                  \
+        const float weight = re.w * (1.0f / ((nu_v - nl_v) + 1e-4f));                          \
+        if (weight > 1e-6f) {                                                                  \
+          if (!UPPER) s_w[e][threadIdx.x] = weight;                                            \
+          const float v = UPPER ? nu_v : nl_v;                                                 \
+          a##e = ((unsigned long long)ord(v == 0.0f ? 0.0f : v) << 32) | unsigned(e);          \
+          ++n;                                                                                 \
+        }                                                                                      \
+        ++valid;                                                                               \
+      }                                                                                        \
+    }                                                                                          \
+  }
+  FDM_E32(FDM_GATHER)
+#undef FDM_GATHER
+  if (valid < F.min_valid) return __uint_as_float(0x7FC00000u);
+#define FDM_CE(i, j) { const bool sw = a##i > a##j; const unsigned long long lo_ = sw ? a##j : a##i; a##j = sw ? a##i : a##j; a##i = lo_; }
+  FDM_NET32(FDM_CE)
+#undef FDM_CE
+  // SimpleWeightedECDF::quantile over the sorted samples (uncertainty_fusion.cpp:63-91)
+  float q = __uint_as_float(0x7FC00000u);
+  if (n == 1) {
+    q = unord(uint32_t(a0 >> 32));
+  } else if (n > 1) {
+    float total = 0.0f;
+#define FDM_TOTAL(k) if (k < n) total += s_w[a##k & 31u][threadIdx.x];
+    FDM_E32(FDM_TOTAL)
+#undef FDM_TOTAL
+    if (total > 0.0f) {
+      const float target = (UPPER ? F.q_upper : F.q_lower) * total;
+      float cum = 0.0f;
+      bool found = false;
+#define FDM_Q(k) if (k < n && !found) { cum += s_w[a##k & 31u][threadIdx.x]; q = unord(uint32_t(a##k >> 32)); found = cum >= target; }
+      FDM_E32(FDM_Q)
+#undef FDM_Q
+    }
+  }
+  return q;
+}
+
+__global__ __launch_bounds__(kFusionThreads) void k_fusion_net32(const GeomConst G, const DevState* __restrict__ st,
+                                                                 int slot, const RegionEntry* __restrict__ reg,
+                                                                 const FusionParams F, const float* __restrict__ up_in,
+                                                                 const float* __restrict__ lo_in,
+                                                                 float* __restrict__ up_out, int up_stride,
+                                                                 float* __restrict__ lo_out, int lo_stride,
+                                                                 unsigned ncell) {
+  __shared__ float s_w[32][kFusionThreads];
+  const unsigned t = blockIdx.x * unsigned(kFusionThreads) + threadIdx.x;
+  if (t >= ncell) return;
+  const PostGeom p = post_geom(st, slot, G);
+  const int lc = int(t / unsigned(p.rows)), lr = int(t - unsigned(lc) * unsigned(p.rows));
+  const size_t ci = post_index(p, lr, lc);
+  if (!isfinite(up_in[ci]) || !isfinite(lo_in[ci])) return;
+  int valid = 0;
+  const float lower = fusion_list32<false>(p, lr, lc, reg, F, up_in, lo_in, s_w, valid);
+  if (valid < F.min_valid) return;
+  const float upper = fusion_list32<true>(p, lr, lc, reg, F, up_in, lo_in, s_w, valid);
+  if (isfinite(lower) && isfinite(upper)) {
+    up_out[ci * up_stride] = upper;
+    lo_out[ci * lo_stride] = lower;
+  }
+}
+#undef FDM_E32
+
 // ---- Eigen::SelfAdjointEigenSolver<Matrix3f>::computeDirect (Eigen 3.4, 3x3 closed form) ----
 // transcendental steps are evaluated in double and rounded (closest to the host libm's float results)
 __device__ __forceinline__ void eig3_cross(const float* a, const float* b, float* o) {
