@@ -240,6 +240,21 @@ __global__ __launch_bounds__(256) void k_ray_compact(const RayParams Q, const Ge
   }
 }
 
+// Minimum over the 64 lanes with DPP row operations (VALU rate; a __shfl butterfly is six trips through
+// the LDS crossbar).  gfx9 encodings: quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror =
+// 0x141, row_mirror = 0x140, row_bcast15 = 0x142 (rows 1,3), row_bcast31 = 0x143 (rows 2,3).
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  constexpr int kId = -1;  // 0xFFFFFFFF: identity of the unsigned minimum, kept by lanes a step does not write
+  uint32_t o;
+  o = uint32_t(__builtin_amdgcn_update_dpp(kId, int(v), 0xB1, 0xF, 0xF, false)); v = o < v ? o : v;
+  o = uint32_t(__builtin_amdgcn_update_dpp(kId, int(v), 0x4E, 0xF, 0xF, false)); v = o < v ? o : v;
+  o = uint32_t(__builtin_amdgcn_update_dpp(kId, int(v), 0x141, 0xF, 0xF, false)); v = o < v ? o : v;
+  o = uint32_t(__builtin_amdgcn_update_dpp(kId, int(v), 0x140, 0xF, 0xF, false)); v = o < v ? o : v;
+  o = uint32_t(__builtin_amdgcn_update_dpp(kId, int(v), 0x142, 0xA, 0xF, false)); v = o < v ? o : v;
+  o = uint32_t(__builtin_amdgcn_update_dpp(kId, int(v), 0x143, 0xC, 0xF, false)); v = o < v ? o : v;
+  return uint32_t(__builtin_amdgcn_readlane(int(v), 63));
+}
+
 // processScan, second half — traceRay (raycasting.cpp:46-140) for the queued rays, one per lane.
 // SEG > 1 (small scans: a few hundred wavefronts, each a chain of ~L/8 dependent L2 round trips):
 // a ray is walked by SEG lanes, lane k covering steps [k*S, (k+1)*S) (the last one to the end).  The
@@ -374,17 +389,29 @@ __global__ __launch_bounds__(256) void k_ray(const RayParams Q, const GeomConst 
 #pragma unroll
     for (int j = 0; j < kRayBatch; ++j) {
       const bool need = cell[j] >= 0 && hh[j] < seen[j];
-      if (__ballot(need) == 0ull) continue;  // wave-uniform: nobody lowers anything at this step
-      uint32_t v = cell[j] >= 0 ? hh[j] : 0xFFFFFFFFu;
+      unsigned long long todo = __ballot(need);  // wave-uniform loop: one round per distinct cell that gets lowered
+      if (SEG == 16) {  // small scans keep the segmented shuffle scan (C2: 70 vs 75 us; C3 / C4: 275 -> 244 us, 1.64 -> 1.58 ms the other way)
+        if (todo == 0ull) continue;
+        uint32_t v = cell[j] >= 0 ? hh[j] : 0xFFFFFFFFu;
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int ocell = __shfl_up(cell[j], d);
-        const uint32_t ov = __shfl_up(v, d);
-        if (lane >= d && ocell == cell[j]) v = ov < v ? ov : v;
+        for (int d = 1; d < 64; d <<= 1) {
+          const int ocell = __shfl_up(cell[j], d);
+          const uint32_t ov = __shfl_up(v, d);
+          if (lane >= d && ocell == cell[j]) v = ov < v ? ov : v;
+        }
+        const int ncell = __shfl_down(cell[j], 1);
+        const bool tail = cell[j] >= 0 && (lane == 63 || ncell != cell[j]);
+        if (tail && v < seen[j] && Q.dbg != 1) atomicMin(&rc_min[cell[j]], v);
+        continue;
       }
-      const int ncell = __shfl_down(cell[j], 1);
-      const bool tail = cell[j] >= 0 && (lane == 63 || ncell != cell[j]);
-      if (tail && v < seen[j] && Q.dbg != 1) atomicMin(&rc_min[cell[j]], v);
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int c = __builtin_amdgcn_readlane(cell[j], leader);
+        const bool mine = cell[j] == c;  // every lane standing in that cell joins the minimum
+        const uint32_t v = wave_min_u32(mine ? hh[j] : 0xFFFFFFFFu);
+        if (lane == leader && Q.dbg != 1) atomicMin(&rc_min[c], v);
+        todo &= ~__ballot(mine);
+      }
     }
   }
 }
