@@ -32,6 +32,7 @@ done
 cd $R
 # the widened rows: stage timings + kernel traces
 for W in c2 c3 c4; do python scripts/ray_bench.py $W --steps 20 --cpu-iters 2 >> $O/ray_bench.jsonl 2>> $O/ray_bench.err; done
+for W in c2 c4; do python scripts/stage_bench.py $W --iters 20 --cpu-iters 1 2>> $O/stage_bench.err | grep '^{' >> $O/stage_bench.jsonl; done  # unprofiled wall times
 bash scripts/prof_ray.sh c2 c4 > $O/prof_ray.txt 2>&1
 bash scripts/prof_stages.sh c2 c4 > $O/prof_stages.txt 2>&1
 for W in c2 c4; do
