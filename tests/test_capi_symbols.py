@@ -68,3 +68,11 @@ def test_product_never_references_the_oracle():
                 if re.search(r"fdm_ref|fdmref|oracle/", txt):
                     bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_generated_sorting_network_is_current():
+    """fastdem_amd/csrc/fdm_sortnet32.inc is the verbatim output of scripts/gen_sortnet.py (which also
+    verifies the network on sampled 0-1 inputs and permutations)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.run([sys.executable, os.path.join(root, "scripts", "gen_sortnet.py"), "--check"]).returncode == 0
