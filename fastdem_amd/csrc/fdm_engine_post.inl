@@ -93,9 +93,13 @@ int fdm_engine_apply_spatial_smoothing(fdm_engine* e, const char* layer, int ker
   if (!l || l->pending) return FDM_OK;  // spatial_smoothing.hpp:42
   if ((rc = ensure_tmp(e))) return rc;
   if ((rc = copy_strided(e, e->d_tmp, 1, lptr(e, *l), lstride(e, *l)))) return rc;  // the double buffer
-  hipLaunchKernelGGL(k_median, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state,
-                     int(e->scan_no & 3), e->d_tmp, lptr(e, *l), lstride(e, *l), kernel_size, min_valid,
-                     unsigned(e->ncell));
+  if (kernel_size == 3)
+    hipLaunchKernelGGL(k_median3, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state,
+                       int(e->scan_no & 3), e->d_tmp, lptr(e, *l), lstride(e, *l), min_valid, unsigned(e->ncell));
+  else
+    hipLaunchKernelGGL(k_median, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state,
+                       int(e->scan_no & 3), e->d_tmp, lptr(e, *l), lstride(e, *l), kernel_size, min_valid,
+                       unsigned(e->ncell));
   HIPCK(hipGetLastError());
   if (std::strcmp(layer, "obstacle") == 0) e->obst_dense_pending = true;
   return FDM_OK;
