@@ -713,7 +713,19 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     if (e->profile) HIPCK(hipEventRecord(e->ev_ray[0], e->stream));
     const float origin[3] = {P.ray_ox, P.ray_oy, P.ray_oz};
     // cropRange keeps d^2 <= range_max^2 around the BASE origin, i.e. around T_world_base's translation
-    const double box[4] = {P.base_x, P.base_y, P.base_z, double(e->cfg.range_max)};
+    // ... and cropZ keeps z_base in [z_min, z_max]: z_map = R20 x + R21 y + R22 z + t_z with |R20 x + R21 y|
+    // <= hypot(R20, R21) * range_max (column-major Twb: R2j = Twb[4 j + 2])
+    double zlo = NAN, zhi = NAN;
+    if (std::isfinite(double(e->cfg.z_min)) && std::isfinite(double(e->cfg.z_max)) &&
+        std::fabs(double(e->cfg.z_min)) < 1e6 && std::fabs(double(e->cfg.z_max)) < 1e6 &&
+        std::isfinite(double(e->cfg.range_max)) && double(e->cfg.range_max) < 1e6) {
+      const double r20 = double(P.Twb[2]), r21 = double(P.Twb[6]), r22 = double(P.Twb[10]);
+      const double tilt = std::hypot(r20, r21) * double(e->cfg.range_max);
+      const double a = r22 * double(e->cfg.z_min), b = r22 * double(e->cfg.z_max);
+      zlo = P.base_z + std::min(a, b) - tilt;
+      zhi = P.base_z + std::max(a, b) + tilt;
+    }
+    const double box[6] = {P.base_x, P.base_y, P.base_z, double(e->cfg.range_max), zlo, zhi};
     int key_mode = 0;
     if ((rc = enqueue_voxel_sort(e, P.n, static_cast<float>(e->G.res), P.slot, e->S.cap_x, e->S.cap_y,
                                  e->S.cap_z, box, &key_mode)))

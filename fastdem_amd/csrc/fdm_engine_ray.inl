@@ -56,27 +56,41 @@ int ensure_voxel_buffers(fdm_engine* e, size_t n) {
 }
 
 // keys -> stable sort: vkeys[1] / vidx[1] hold the voxel-ordered scan afterwards.
-// `box` (nullable): centre + half extent [m] of a box that holds every finite point of the cloud;
+// `box` (nullable): centre (3) + half extent [m] of a box that holds every finite point of the cloud, then the
+// map-frame z interval [lo, hi] they lie in (NaN, NaN if unknown);
 // with it the compact 32-bit key is used when 3 * bits <= 31.  *key_mode tells what the buffers hold:
 // 0 = sorted uint64 keys, 1 = sorted uint32 compact keys.
 int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slot, const float* dx,
                        const float* dy, const float* dz, const double* box, int* key_mode) {
   if (int rc = ensure_voxel_buffers(e, n)) return rc;
   const float inv = 1.0f / voxel_size;  // voxel_grid_impl.hpp:46
-  VoxelCompact C{0, 0, 0, 0};
+  VoxelCompact C{0, 0, 0, 0, 0};
   if (box && std::isfinite(box[3]) && box[3] > 0.0 && box[3] * double(inv) < 4.0e6) {
     const double half = box[3] + 2.0 * double(voxel_size);  // 2-cell margin for the float transforms
     const int span = int(std::ceil(2.0 * half * double(inv))) + 4;
     int bits = 1;
     while ((1 << bits) < span) ++bits;
     if (3 * bits <= 62 && bits <= 21) {
-      C.bits = bits;
+      C.bits = C.zbits = bits;
       C.x0 = int(std::floor((box[0] - half) * double(inv))) - 1;
       C.y0 = int(std::floor((box[1] - half) * double(inv))) - 1;
       C.z0 = int(std::floor((box[2] - half) * double(inv))) - 1;
+      // box[4..5] (optional): map-frame z interval the crops leave (cropZ slab tilted by T_world_base)
+      if (std::isfinite(box[4]) && std::isfinite(box[5]) && box[5] > box[4]) {
+        const double zlo = std::max(box[4], box[2] - half) - 2.0 * double(voxel_size);
+        const double zhi = std::min(box[5], box[2] + half) + 2.0 * double(voxel_size);
+        const int zspan = int(std::ceil((zhi - zlo) * double(inv))) + 4;
+        int zb = 1;
+        while ((1 << zb) < zspan) ++zb;
+        if (zb < bits) {
+          C.zbits = zb;
+          C.z0 = int(std::floor(zlo * double(inv))) - 1;
+        }
+      }
     }
   }
-  const bool compact = C.bits > 0 && 3 * C.bits <= 31;  // true: the sorted buffer holds uint32 keys
+  const int key_bits = 2 * C.bits + C.zbits;
+  const bool compact = C.bits > 0 && key_bits <= 31;  // true: the sorted buffer holds uint32 keys
   *key_mode = compact ? 1 : 0;
   size_t bytes = e->sort_tmp_bytes;
   if (compact) {
@@ -88,13 +102,13 @@ int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slo
     // bits 3*bits .. 31 are zero in every valid key and one in the invalid key (all ones): sorting
     // one bit past the fields is enough to keep the dropped points behind every voxel
     HIPCK(rocprim::radix_sort_pairs(e->sort_tmp, bytes, k0, k1, e->vidx[0], e->vidx[1], size_t(n), 0,
-                                    unsigned(3 * C.bits + 1), e->stream));
+                                    unsigned(key_bits + 1), e->stream));
   } else {
     hipLaunchKernelGGL(k_voxel_keys<unsigned long long>, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, inv,
                        flag_slot, C, e->d_state, dx, dy, dz, e->vkeys[0], e->vidx[0], e->vsel);
     HIPCK(hipGetLastError());
     HIPCK(rocprim::radix_sort_pairs(e->sort_tmp, bytes, e->vkeys[0], e->vkeys[1], e->vidx[0], e->vidx[1],
-                                    size_t(n), 0, C.bits > 0 ? unsigned(3 * C.bits + 1) : 64u, e->stream));
+                                    size_t(n), 0, C.bits > 0 ? unsigned(key_bits + 1) : 64u, e->stream));
   }
   return FDM_OK;
 }

@@ -67,16 +67,17 @@ __device__ __forceinline__ uint64_t voxel_pack(float x, float y, float z, float 
 // use the same packing in a uint64 and still sort only 3*bits + 1 bits.
 struct VoxelCompact {
   int x0, y0, z0;  // voxel index of the box corner
-  int bits;        // per axis; 0 = use the full 63-bit key
+  int bits;        // per horizontal axis; 0 = use the full 63-bit key
+  int zbits;       // vertical axis: the z crop usually bounds it far tighter than the range ball does
 };
 constexpr uint32_t kInvalidVoxel32 = 0xFFFFFFFFu;
 template <typename KEY>
 __device__ __forceinline__ KEY voxel_pack_compact(float x, float y, float z, float inv, const VoxelCompact& C) {
-  const int hi = (1 << C.bits) - 1;
+  const int hi = (1 << C.bits) - 1, hiz = (1 << C.zbits) - 1;
   int fx = cvt_x86(floorf(x * inv)) - C.x0, fy = cvt_x86(floorf(y * inv)) - C.y0, fz = cvt_x86(floorf(z * inv)) - C.z0;
   fx = fx < 0 ? 0 : (fx > hi ? hi : fx);  // cannot trigger inside the box the host derived (2-cell margin)
   fy = fy < 0 ? 0 : (fy > hi ? hi : fy);
-  fz = fz < 0 ? 0 : (fz > hi ? hi : fz);
+  fz = fz < 0 ? 0 : (fz > hiz ? hiz : fz);
   return (KEY(fz) << (2 * C.bits)) | (KEY(fy) << C.bits) | KEY(fx);
 }
 template <typename KEY>

@@ -255,6 +255,26 @@ def plant_ghost_block(o):
 
 
 class TestIntegrateWithRaycasting:
+    def test_tilted_base_keeps_the_compact_voxel_key_exact(self, gpu, R):
+        """The compact sort key bounds z by the cropZ slab pushed through T_world_base (roll / pitch
+        widen it by hypot(R20, R21) * range_max): a tilted, lifted robot must give the oracle's voxels."""
+        wl = gpu.synth.vlp16(n_scans=4)
+
+        def fill(cfg):
+            wl.apply_to(cfg)
+            return ray_cfg()(cfg)
+        eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, fill)
+        for k in range(4):
+            a, b = np.deg2rad(9.0 * (k + 1) / 4), np.deg2rad(-6.0)
+            Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+            Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+            T = wl.pose(k).copy()
+            T[:3, :3] = T[:3, :3] @ Rx @ Ry
+            T[2, 3] += 0.35 * k
+            run_both(eng, ref, wl.scan(k), wl.T_base_sensor, T)
+            assert_layers_equal(eng, ref)
+        assert ref.last_ray_stats()["n_rays"] > 1000
+
     def test_c2_vlp16_kalman_local(self, gpu, R):
         wl = gpu.synth.vlp16(n_scans=8)
         eng, ref, cleared = run_ray_workload(gpu, R, wl, 8, ghosts=plant_ghost_block,
