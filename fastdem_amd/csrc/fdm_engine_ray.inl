@@ -168,13 +168,25 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float
     else
       hipLaunchKernelGGL(k_voxel_mark<unsigned long long>, dim3(blocks), dim3(256), 0, e->stream, Q.n,
                          e->vkeys[1], e->vidx[1], e->vsel);
+  }
+  // large scans: queue sorted by (wedge, length) before the walk (see k_ray_compact)
+  const bool sort_queue = Q.n >= (1u << 20) && !(e->dbg_ray & 2048);
+  uint32_t* ray_key = sort_queue ? reinterpret_cast<uint32_t*>(e->vkeys[0]) : nullptr;
+  if (sort_queue) HIPCK(hipMemsetAsync(ray_key, 0xFF, size_t(Q.n) * sizeof(uint32_t), e->stream));  // unused slots sort last
+  if (voxel) {
     hipLaunchKernelGGL(k_ray_compact<true>, dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx,
-                       dy, dz, e->vsel, e->rc_cnt, ray_list);
+                       dy, dz, e->vsel, e->rc_cnt, ray_list, ray_key);
   } else {
     hipLaunchKernelGGL(k_ray_compact<false>, dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx,
-                       dy, dz, static_cast<const uint32_t*>(nullptr), e->rc_cnt, ray_list);
+                       dy, dz, static_cast<const uint32_t*>(nullptr), e->rc_cnt, ray_list, ray_key);
   }
   HIPCK(hipGetLastError());
+  if (sort_queue) {
+    size_t bytes = e->sort_tmp_bytes;
+    HIPCK(rocprim::radix_sort_pairs(e->sort_tmp, bytes, ray_key, reinterpret_cast<uint32_t*>(e->vkeys[1]), e->vidx[0],
+                                    e->vidx[1], size_t(Q.n), 0, 21, e->stream));
+    ray_list = e->vidx[1];
+  }
   const bool tiled = e->G.o_rows != e->G.rows || e->G.o_cols != e->G.cols || e->G.s_rows != e->G.rows ||
                      e->G.s_cols != e->G.cols;
   auto launch_ray = [&](auto kern, unsigned seg) {

@@ -18,9 +18,10 @@ ap.add_argument("workload")
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--cpu-iters", type=int, default=5)
 ap.add_argument("--dbg-ray", type=int, default=0)
+ap.add_argument("--order", default="azimuth", choices=["azimuth", "ring"])
 a = ap.parse_args()
 
-wl = synth.make(a.workload)
+wl = synth.make(a.workload, **({"order": a.order} if a.workload in ("c2", "c4") else {}))
 
 
 def run(raycast):

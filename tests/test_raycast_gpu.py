@@ -301,6 +301,13 @@ class TestIntegrateWithRaycasting:
         wl = gpu.synth.lidar128(n_scans=3, n_az=2048)
         run_ray_workload(gpu, R, wl, 3, ghosts=plant_ghost_block, rc_log_odds_ghost=1.2)
 
+    @pytest.mark.parametrize("order", ["azimuth", "ring"])
+    def test_c4_lidar128_full_size_sorted_ray_queue(self, gpu, R, order):
+        """configs[3] at full size (2.1 M points): from 2^20 points up the ray queue is sorted by
+        (direction wedge, length) before the walk — the result must not depend on the queue's order."""
+        wl = gpu.synth.lidar128(n_scans=2, order=order)
+        run_ray_workload(gpu, R, wl, 2, ghosts=plant_ghost_block, rc_log_odds_ghost=1.2)
+
     def test_per_layer_storage(self, gpu, R):
         wl = gpu.synth.vlp16(n_scans=4)
 
