@@ -506,7 +506,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     e->S.key = e->key2[parity];
     e->S.aux = e->aux2[parity];
   }
-  const bool plain = e->overlap && e->key2[1] && e->S.dense && !ray_on && !e->cap_pre &&
+  const bool plain = e->overlap && e->key2[1] && !ray_on && !e->cap_pre &&
                      !e->cap_ras && !e->obst_dense_pending;
 
   // k_bin4 (4 consecutive points per thread, float4 loads) needs 16-byte aligned channels
@@ -615,9 +615,14 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     const Scratch Su = e->S;
     const auto Lu = layers;
     e->upd_alone = [e, Pu, Su, Lu, in_u, upd_blocks]() -> int {
-      hipLaunchKernelGGL(k_update<POLICY>, dim3(upd_blocks), dim3(256), 0, e->stream, Pu, e->G, e->d_state, Lu,
-                         e->d_layer_ptrs, e->n_layer_ptrs, Su, in_u.x, in_u.y, in_u.z, in_u.intensity, in_u.rgb,
-                         in_u.var, unsigned(e->ncell));
+      if (Su.dense)
+        hipLaunchKernelGGL(k_update<POLICY>, dim3(upd_blocks), dim3(256), 0, e->stream, Pu, e->G, e->d_state, Lu,
+                           e->d_layer_ptrs, e->n_layer_ptrs, Su, in_u.x, in_u.y, in_u.z, in_u.intensity, in_u.rgb,
+                           in_u.var, unsigned(e->ncell));
+      else
+        hipLaunchKernelGGL(k_update_stamped<POLICY>, dim3((upd_blocks + kStampTiles - 1) / kStampTiles), dim3(256), 0,
+                           e->stream, Pu, e->G, e->d_state, Lu, e->d_layer_ptrs, e->n_layer_ptrs, Su, in_u.x, in_u.y,
+                           in_u.z, in_u.intensity, in_u.rgb, in_u.var, unsigned(e->ncell));
       HIPCK(hipGetLastError());
       return FDM_OK;
     };
@@ -627,7 +632,9 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
                                                      int32_t* ids_b, unsigned bin_blocks_b,
                                                      fdm_engine::BinVariant bv) -> int {
       auto go = [&](auto kern, unsigned threads) {
-        const unsigned ub = (upd_blocks + threads / 256u - 1u) / (threads / 256u);  // tiles per update block
+        // tiles per update block: threads / 256, times kStampTiles slots on stamp-gated maps
+        const unsigned per = (threads / 256u) * (Su.dense ? 1u : kStampTiles);
+        const unsigned ub = (upd_blocks + per - 1u) / per;
         hipLaunchKernelGGL(kern, dim3(ub + bin_blocks_b), dim3(threads), 0, e->stream, Pu, e->G, e->d_state, Lu,
                            e->d_layer_ptrs, e->n_layer_ptrs, Su, in_u, unsigned(e->ncell), ub, Pb, Sb, Ib, ids_b);
       };
@@ -1046,7 +1053,7 @@ static int create_impl(const fdm_geometry* g, const fdm_config* cfg, const fdm_t
   HCK(hipMalloc(reinterpret_cast<void**>(&e->S.tile_stamp), e->n_tiles * sizeof(uint32_t)));
   e->key2[0] = e->S.key;
   e->aux2[0] = e->S.aux;
-  if (e->S.dense) {  // second scratch set: scan t+1 bins while scan t still updates (24 B/cell, <= 100 MB)
+  {  // second scratch set: scan t+1 bins while scan t still updates (24 B/cell: 100 MB at 4 M cells, 1.5 GB at 64 M)
     HCK(hipMalloc(reinterpret_cast<void**>(&e->key2[1]), e->ncell * sizeof(unsigned long long)));
     HCK(hipMalloc(reinterpret_cast<void**>(&e->aux2[1]), e->ncell * sizeof(uint4)));
     const int blocks2 = int(std::min<size_t>((e->ncell + 255) / 256, 4096));

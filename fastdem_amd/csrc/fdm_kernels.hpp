@@ -580,7 +580,10 @@ __device__ __forceinline__ void make_ctx(const ScanParams& P, DevState* __restri
     u.obst_tile = u.do_update;
   } else {
     const unsigned stamp = tile_ok ? S.tile_stamp[tile] : 0xFFFFFFFEu;
-    u.cur = u.do_update && stamp == P.scan_no;
+    // (stamp == scan_no + 1: the NEXT scan's bin kernel, which shares a launch with this held-back
+    // update, re-stamped the tile — it may or may not hold cells of this scan or of the last updating
+    // one, so it is swept; untouched cells have an empty key and cost nothing but the sweep)
+    u.cur = u.do_update && (stamp == P.scan_no || stamp == P.scan_no + 1u);
     u.obst_tile = u.do_update && (u.cur || stamp == ob_scan);
   }
   u.strips = u.applied && (u.C.shr != 0 || u.C.shc != 0);
@@ -848,13 +851,15 @@ __global__ __launch_bounds__(256) void k_update(
 // tile stamp alone and runs the update body only for the live ones (and always for tile 0, which
 // commits the geometry ring).
 constexpr unsigned kStampTiles = 32;  // <= 64: one lane of the first wave per tile (16: 62 us, 32: 60 us, 64: 73 us at C5)
-template <typename POLICY>
-__global__ __launch_bounds__(256) void k_update_stamped(
-    const ScanParams P, const GeomConst G, DevState* __restrict__ st,
-    const typename POLICY::Layers L, float* const* __restrict__ all_layers, int n_layers,
-    const Scratch S, const float* __restrict__ px, const float* __restrict__ py,
-    const float* __restrict__ pz, const float* __restrict__ /*pint*/,
-    const uint32_t* __restrict__ prgb, const float* __restrict__ pvar, unsigned ncell) {
+// BLOCK threads look at kStampTiles SLOTS of BLOCK/256 consecutive tiles each.
+template <typename POLICY, int BLOCK>
+__device__ __forceinline__ void update_stamped_body(
+    const ScanParams& P, const GeomConst& G, DevState* __restrict__ st,
+    const typename POLICY::Layers& L, float* const* __restrict__ all_layers, int n_layers,
+    const Scratch& S, const float* __restrict__ px, const float* __restrict__ py,
+    const float* __restrict__ pz, const uint32_t* __restrict__ prgb, const float* __restrict__ pvar,
+    unsigned ncell, const unsigned bid) {
+  constexpr unsigned kPer = unsigned(BLOCK) / 256u;
   const int slot = P.slot;
   const bool do_update = st->flags[slot].any_inside != 0u;
   const bool applied = P.do_move && (!P.gate_on_filter || st->flags[slot].any_pass != 0u);
@@ -862,15 +867,26 @@ __global__ __launch_bounds__(256) void k_update_stamped(
   const bool strips = applied && (shr != 0 || shc != 0);  // a move: every tile may hold vacated cells
   const unsigned ob_scan = st->obst[slot].scan;
   const unsigned n_tiles = (ncell + 255u) >> 8;
-  // all kStampTiles stamps in ONE round trip: lane q of the first wave looks at tile q
+  // all stamps in ONE round trip: lane q of the first wave looks at slot q
   __shared__ unsigned long long s_live;
   if (threadIdx.x < 64u) {
-    const unsigned tile = blockIdx.x * kStampTiles + threadIdx.x;
     bool live = false;
-    if (threadIdx.x < kStampTiles && tile < n_tiles) {
-      const unsigned stamp = S.tile_stamp[tile];
-      live = tile == 0u || strips || (do_update && (stamp == P.scan_no || stamp == ob_scan));
-      if (!live) S.upd_part[tile] = 0u;
+    if (threadIdx.x < kStampTiles) {
+      const unsigned first = (bid * kStampTiles + threadIdx.x) * kPer;
+#pragma unroll
+      for (unsigned k = 0; k < kPer; ++k) {
+        const unsigned tile = first + k;
+        if (tile < n_tiles) {
+          const unsigned stamp = S.tile_stamp[tile];
+          live = live || tile == 0u || strips ||
+                 (do_update && (stamp == P.scan_no || stamp == P.scan_no + 1u || stamp == ob_scan));  // see make_ctx
+        }
+      }
+      if (!live) {
+#pragma unroll
+        for (unsigned k = 0; k < kPer; ++k)
+          if (first + k < n_tiles) S.upd_part[first + k] = 0u;
+      }
     }
     const unsigned long long m = __ballot(live);
     if (threadIdx.x == 0) s_live = m;
@@ -880,10 +896,20 @@ __global__ __launch_bounds__(256) void k_update_stamped(
   while (live_mask) {  // block-uniform
     const unsigned q = unsigned(__ffsll((long long)live_mask)) - 1u;
     live_mask &= live_mask - 1ull;
-    update_body<POLICY, 256>(P, G, st, L, all_layers, n_layers, S, px, py, pz, prgb, pvar, ncell,
-                             blockIdx.x * kStampTiles + q);
-    __syncthreads();  // the body's shared counters are reused by the next live tile
+    update_body<POLICY, BLOCK>(P, G, st, L, all_layers, n_layers, S, px, py, pz, prgb, pvar, ncell,
+                               bid * kStampTiles + q);
+    __syncthreads();  // the body's shared counters are reused by the next live slot
   }
+}
+
+template <typename POLICY>
+__global__ __launch_bounds__(256) void k_update_stamped(
+    const ScanParams P, const GeomConst G, DevState* __restrict__ st,
+    const typename POLICY::Layers L, float* const* __restrict__ all_layers, int n_layers,
+    const Scratch S, const float* __restrict__ px, const float* __restrict__ py,
+    const float* __restrict__ pz, const float* __restrict__ /*pint*/,
+    const uint32_t* __restrict__ prgb, const float* __restrict__ pvar, unsigned ncell) {
+  update_stamped_body<POLICY, 256>(P, G, st, L, all_layers, n_layers, S, px, py, pz, prgb, pvar, ncell, blockIdx.x);
 }
 
 // Scan statistics for the synchronous entry points (fdm_scan_stats): the per-block / per-tile
@@ -966,7 +992,11 @@ __global__ __launch_bounds__(THREADS) void k_update_bin4(
   const unsigned u0 = unsigned((blockIdx.x * (unsigned long long)upd_blocks) / total);
   const unsigned u1 = unsigned(((blockIdx.x + 1ull) * (unsigned long long)upd_blocks) / total);
   if (u1 > u0) {
-    update_body<POLICY, THREADS>(Pu, G, st, L, all_layers, n_layers, Su, Iu.x, Iu.y, Iu.z, Iu.rgb, Iu.var, ncell, u0);
+    if (Su.dense)
+      update_body<POLICY, THREADS>(Pu, G, st, L, all_layers, n_layers, Su, Iu.x, Iu.y, Iu.z, Iu.rgb, Iu.var, ncell, u0);
+    else  // stamp-gated maps: an update block is kStampTiles slots
+      update_stamped_body<POLICY, THREADS>(Pu, G, st, L, all_layers, n_layers, Su, Iu.x, Iu.y, Iu.z, Iu.rgb, Iu.var,
+                                           ncell, u0);
   } else {
     bin4_body<HAS_INT, HAS_COL, THREADS>(Pb, G, st, Ib.x, Ib.y, Ib.z, Ib.intensity, Sb, cell_ids,
                                          blockIdx.x - u0);
@@ -980,8 +1010,12 @@ __global__ __launch_bounds__(256) void k_update_bin(
     unsigned upd_blocks, const ScanParams Pb, const Scratch Sb, const ScanInputs Ib,
     int32_t* __restrict__ cell_ids) {
   if (blockIdx.x < upd_blocks) {
-    update_body<POLICY>(Pu, G, st, L, all_layers, n_layers, Su, Iu.x, Iu.y, Iu.z, Iu.rgb, Iu.var, ncell,
-                        blockIdx.x);
+    if (Su.dense)
+      update_body<POLICY>(Pu, G, st, L, all_layers, n_layers, Su, Iu.x, Iu.y, Iu.z, Iu.rgb, Iu.var, ncell,
+                          blockIdx.x);
+    else
+      update_stamped_body<POLICY, 256>(Pu, G, st, L, all_layers, n_layers, Su, Iu.x, Iu.y, Iu.z, Iu.rgb, Iu.var,
+                                       ncell, blockIdx.x);
   } else {
     bin_body<WAVE_MERGE>(Pb, G, st, Ib.x, Ib.y, Ib.z, Ib.intensity, Sb, cell_ids, blockIdx.x - upd_blocks);
   }

@@ -48,6 +48,33 @@ def test_chain_equals_oracle(gpu, R, name, overlap):
     assert eng.geometry().start_row != 0
 
 
+@pytest.mark.parametrize("name", ["vlp16", "lidar128"])
+def test_chain_on_a_stamp_gated_map(gpu, R, name):
+    """Non-dense (stamp-gated) maps hold the update back too: the fused launch sweeps the tiles stamped
+    by scan t, by scan t+1 (the bin kernel sharing the launch may already have re-stamped them) or by the
+    last updating scan.  Moving window, scans that land nowhere and re-landing in between."""
+    wl = gpu.synth.vlp16(n_scans=10) if name == "vlp16" else gpu.synth.lidar128(n_scans=5, n_az=1024)
+    eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
+    eng.set_option("dense", 0)
+    keep = []
+    n = len(wl.scans)
+    for k in range(n):
+        s = wl.scan(k)
+        T = wl.pose(k).copy()
+        if k in (3, 4):  # two scans far away: nothing lands, the obstacle cells of scan 2 must survive them
+            T[0, 3] += 500.0
+        d = dev(s)
+        keep.append(d)
+        enqueue(eng, d, wl.T_base_sensor, T)
+        ref_step(ref, s, wl.T_base_sensor, T)
+        if k == n // 2:
+            assert_layers_equal(eng, ref)
+    rc, st = eng.last_stats()
+    assert rc == 0
+    assert_layers_equal(eng, ref)
+    assert same_geometry(eng.geometry(), ref.geometry())
+
+
 def test_chain_with_interleaved_calls(gpu, R):
     """Reads, writes, config changes and layer additions in the middle of a chain flush the
     held-back update first; the chain then restarts from the committed geometry."""
