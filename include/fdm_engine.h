@@ -126,7 +126,7 @@ int fdm_engine_integrate(fdm_engine* e, uint64_t n, const float* x, const float*
 /* Same, inputs already resident in HBM; enqueue-only (no host sync).  The skip
  * decisions of fastdem.cpp:125-138 are taken on the device; read them back with
  * fdm_engine_last_stats().
- * On maps <= 4 M cells the map update of the scan is
+ * The map update of the scan is
  * HELD BACK and leaves in the same launch as the next scan's bin kernel (one launch per scan
  * instead of two); every other entry point — fdm_engine_sync() included — first launches a held-back
  * update, so the map is always current when it is read through this API.  A caller that reads
