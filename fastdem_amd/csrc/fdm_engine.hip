@@ -639,14 +639,19 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
                            e->d_layer_ptrs, e->n_layer_ptrs, Su, in_u, unsigned(e->ncell), ub, Pb, Sb, Ib, ids_b);
       };
       if (!bv.bin4) {
-        bv.wave_merge ? go(k_update_bin<POLICY, true>, 256u) : go(k_update_bin<POLICY, false>, 256u);
+        if (Su.dense) bv.wave_merge ? go(k_update_bin<POLICY, true>, 256u) : go(k_update_bin<POLICY, false>, 256u);
+        else bv.wave_merge ? go(k_update_bin<POLICY, true, true>, 256u) : go(k_update_bin<POLICY, false, true>, 256u);
       } else if constexpr (kRec) {
-#define FDM_FUSED4(T)                                                              \
-        if (bv.has_int && bv.has_col) go(k_update_bin4<POLICY, true, true, T>, T);   \
-        else if (bv.has_int) go(k_update_bin4<POLICY, true, false, T>, T);           \
-        else if (bv.has_col) go(k_update_bin4<POLICY, false, true, T>, T);           \
-        else go(k_update_bin4<POLICY, false, false, T>, T);
-        if (bv.threads == 512u) { FDM_FUSED4(512) } else { FDM_FUSED4(256) }
+#define FDM_FUSED4(T, ST)                                                              \
+        if (bv.has_int && bv.has_col) go(k_update_bin4<POLICY, true, true, T, ST>, T);   \
+        else if (bv.has_int) go(k_update_bin4<POLICY, true, false, T, ST>, T);           \
+        else if (bv.has_col) go(k_update_bin4<POLICY, false, true, T, ST>, T);           \
+        else go(k_update_bin4<POLICY, false, false, T, ST>, T);
+        if (Su.dense) {
+          if (bv.threads == 512u) { FDM_FUSED4(512, false) } else { FDM_FUSED4(256, false) }
+        } else {
+          if (bv.threads == 512u) { FDM_FUSED4(512, true) } else { FDM_FUSED4(256, true) }
+        }
 #undef FDM_FUSED4
       } else {
         return fail(FDM_ERR_INVALID, "internal: k_bin4 fused with a per-layer policy");

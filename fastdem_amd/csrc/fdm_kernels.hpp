@@ -979,7 +979,9 @@ struct ScanInputs {
   const uint32_t* rgb;
   const float* var;
 };
-template <typename POLICY, bool HAS_INT, bool HAS_COL, int THREADS>
+// STAMPED (stamp-gated maps) is a template parameter, not a branch on Su.dense: carrying both update bodies
+// in one kernel cost the dense configs[2] launch 4 % (14.9 -> 15.4 us).
+template <typename POLICY, bool HAS_INT, bool HAS_COL, int THREADS, bool STAMPED = false>
 __global__ __launch_bounds__(THREADS) void k_update_bin4(
     const ScanParams Pu, const GeomConst G, DevState* __restrict__ st, const typename POLICY::Layers L,
     float* const* __restrict__ all_layers, int n_layers, const Scratch Su, const ScanInputs Iu, unsigned ncell,
@@ -992,7 +994,7 @@ __global__ __launch_bounds__(THREADS) void k_update_bin4(
   const unsigned u0 = unsigned((blockIdx.x * (unsigned long long)upd_blocks) / total);
   const unsigned u1 = unsigned(((blockIdx.x + 1ull) * (unsigned long long)upd_blocks) / total);
   if (u1 > u0) {
-    if (Su.dense)
+    if (!STAMPED)
       update_body<POLICY, THREADS>(Pu, G, st, L, all_layers, n_layers, Su, Iu.x, Iu.y, Iu.z, Iu.rgb, Iu.var, ncell, u0);
     else  // stamp-gated maps: an update block is kStampTiles slots
       update_stamped_body<POLICY, THREADS>(Pu, G, st, L, all_layers, n_layers, Su, Iu.x, Iu.y, Iu.z, Iu.rgb, Iu.var,
@@ -1003,14 +1005,14 @@ __global__ __launch_bounds__(THREADS) void k_update_bin4(
   }
 }
 
-template <typename POLICY, bool WAVE_MERGE>
+template <typename POLICY, bool WAVE_MERGE, bool STAMPED = false>
 __global__ __launch_bounds__(256) void k_update_bin(
     const ScanParams Pu, const GeomConst G, DevState* __restrict__ st, const typename POLICY::Layers L,
     float* const* __restrict__ all_layers, int n_layers, const Scratch Su, const ScanInputs Iu, unsigned ncell,
     unsigned upd_blocks, const ScanParams Pb, const Scratch Sb, const ScanInputs Ib,
     int32_t* __restrict__ cell_ids) {
   if (blockIdx.x < upd_blocks) {
-    if (Su.dense)
+    if (!STAMPED)
       update_body<POLICY>(Pu, G, st, L, all_layers, n_layers, Su, Iu.x, Iu.y, Iu.z, Iu.rgb, Iu.var, ncell,
                           blockIdx.x);
     else
