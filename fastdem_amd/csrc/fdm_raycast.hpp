@@ -29,6 +29,7 @@
 namespace fdm {
 
 constexpr uint32_t kRayEmpty = 0xFFFFFFFFu;       // ord() of no float that can occur (NaN pattern)
+constexpr int kRayBatchLarge = 32;
 constexpr int kRayBatch = 8;                      // cells a ray walks between two rounds of loads
 constexpr uint64_t kInvalidVoxel = ~0ull;         // voxel::INVALID_KEY: sorts behind every real key
 
@@ -287,6 +288,9 @@ __global__ __launch_bounds__(256) void k_ray(const RayParams Q, const GeomConst 
                                              const float* __restrict__ z,
                                              const uint32_t* __restrict__ ray_list,
                                              uint32_t* __restrict__ rc_min) {
+  // large scans (one lane per ray, queue sorted by wedge and length) walk 32 cells between two rounds of
+  // loads (C4 stage: 8 cells 1.16 ms, 16: 1.10, 32: 1.05, 64: 1.16); the segmented small-scan variants stay at 8
+  constexpr int kB = SEG == 1 ? kRayBatchLarge : kRayBatch;
   const unsigned n_rays = st->ray_count;
   const unsigned gid = blockIdx.x * 256u + threadIdx.x;
   const unsigned n_pad = (n_rays + 63u) & ~63u;  // whole wavefronts per segment
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(256) void k_ray(const RayParams Q, const GeomConst 
     t_delta_c = float(step_c) / dc;
   }
   // The walk: a step is straight-line predicated code (in-map test by unsigned compare, wrap by one
-  // conditional subtract, DDA advance by selects).  kRayBatch cells are walked in registers, their
+  // conditional subtract, DDA advance by selects).  kB cells are walked in registers, their
   // loads go out together (one L2 round trip), then the atomics — which are what this kernel costs
   // (memory-side, ~1 ns each when lanes hit one address):
   //   * rc_min only ever decreases, so a value read from L2 that is already <= h settles the visit
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(256) void k_ray(const RayParams Q, const GeomConst 
     const float est_f = fabsf(floorf(gr1) - float(r)) + fabsf(floorf(gc1) - float(c)) + 2.0f;
     const int est = est_f < float(max_steps) ? int(est_f) : max_steps;
     int seg_len = (est + SEG - 1) / SEG;
-    seg_len = (seg_len + kRayBatch - 1) / kRayBatch * kRayBatch;
+    seg_len = (seg_len + kB - 1) / kB * kB;
     const int s_begin = int(seg) * seg_len;
     if (int(seg) != SEG - 1) s_end = s_begin + seg_len;
     for (; s < s_begin && alive; ++s) {  // replay: the walk without the visits
@@ -369,10 +373,10 @@ __global__ __launch_bounds__(256) void k_ray(const RayParams Q, const GeomConst 
     alive = alive && s == s_begin && s < s_end;
   }
   while (__ballot(alive)) {
-    int cell[kRayBatch];
-    uint32_t hh[kRayBatch];
+    int cell[kB];
+    uint32_t hh[kB];
 #pragma unroll
-    for (int j = 0; j < kRayBatch; ++j) {
+    for (int j = 0; j < kB; ++j) {
       const bool row = t_max_r < t_max_c;
       // == std::min(t_max_r, t_max_c): on a tie both hold the same value
       const float t_exit = row ? t_max_r : t_max_c;
@@ -395,16 +399,16 @@ __global__ __launch_bounds__(256) void k_ray(const RayParams Q, const GeomConst 
       t_max_r = row ? t_max_r + t_delta_r : t_max_r;
       t_max_c = row ? t_max_c : t_max_c + t_delta_c;
     }
-    s += kRayBatch;
+    s += kB;
     // (the loads are unconditional — a masked step reads cell 0 — so that nothing but the loads
     // sits between them and they leave back to back)
-    uint32_t seen[kRayBatch];
+    uint32_t seen[kB];
 #pragma unroll
-    for (int j = 0; j < kRayBatch; ++j)
+    for (int j = 0; j < kB; ++j)
       seen[j] = __hip_atomic_load(&rc_min[cell[j] >= 0 ? cell[j] : 0], __ATOMIC_RELAXED,
                                   __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-    for (int j = 0; j < kRayBatch; ++j) {
+    for (int j = 0; j < kB; ++j) {
       const bool need = cell[j] >= 0 && hh[j] < seen[j];
       unsigned long long todo = __ballot(need);  // wave-uniform loop: one round per distinct cell that gets lowered
       if (SEG == 16) {  // small scans keep the segmented shuffle scan (C2: 70 vs 75 us; C3 / C4: 275 -> 244 us, 1.64 -> 1.58 ms the other way)
