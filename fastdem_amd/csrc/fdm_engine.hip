@@ -570,7 +570,11 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
       hipLaunchKernelGGL(kern, dim3(bin_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state, dx, dy,
                          dz, dint, e->S, ids);
     };
-    e->wave_merge ? launch_bin(k_bin<true>) : launch_bin(k_bin<false>);
+    if (!e->wave_merge) launch_bin(k_bin<false>);
+    else if (P.has_intensity && P.has_color) launch_bin(k_bin<true, 3>);
+    else if (P.has_color) launch_bin(k_bin<true, 2>);
+    else if (P.has_intensity) launch_bin(k_bin<true, 1>);
+    else launch_bin(k_bin<true, 0>);
   }
   HIPCK(hipGetLastError());
   if (e->profile) HIPCK(hipEventRecord(e->ev[1], e->stream));
@@ -639,8 +643,19 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
                            e->d_layer_ptrs, e->n_layer_ptrs, Su, in_u, unsigned(e->ncell), ub, Pb, Sb, Ib, ids_b);
       };
       if (!bv.bin4) {
-        if (Su.dense) bv.wave_merge ? go(k_update_bin<POLICY, true>, 256u) : go(k_update_bin<POLICY, false>, 256u);
-        else bv.wave_merge ? go(k_update_bin<POLICY, true, true>, 256u) : go(k_update_bin<POLICY, false, true>, 256u);
+        if (!Su.dense) {
+          bv.wave_merge ? go(k_update_bin<POLICY, true, true>, 256u) : go(k_update_bin<POLICY, false, true>, 256u);
+        } else if (!bv.wave_merge) {
+          go(k_update_bin<POLICY, false>, 256u);
+        } else if (bv.has_int && bv.has_col) {  // the bin half's channel tests folded at compile time
+          go(k_update_bin<POLICY, true, false, 3>, 256u);
+        } else if (bv.has_col) {
+          go(k_update_bin<POLICY, true, false, 2>, 256u);
+        } else if (bv.has_int) {
+          go(k_update_bin<POLICY, true, false, 1>, 256u);
+        } else {
+          go(k_update_bin<POLICY, true, false, 0>, 256u);
+        }
       } else if constexpr (kRec) {
 #define FDM_FUSED4(T, ST)                                                              \
         if (bv.has_int && bv.has_col) go(k_update_bin4<POLICY, true, true, T, ST>, T);   \
