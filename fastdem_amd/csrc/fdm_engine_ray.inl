@@ -26,6 +26,12 @@ int ensure_ray_cells(fdm_engine* e) {
   return FDM_OK;
 }
 
+// rocPRIM switches radix_sort_pairs to a merge sort below 1 M items: 18 launches (114 us) for a 272 K-point
+// RGB-D scan, 8 (41 us) for a VLP-16 sweep.  This config keeps the onesweep radix sort; used from 64 K
+// items up (C3 stage 246 -> 231 us; at 28.8 K items the radix passes lose: 148 vs 70 us).
+using RadixAlways = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                               rocprim::default_config, 4096>;
+
 int ensure_voxel_buffers(fdm_engine* e, size_t n) {
   if (n <= e->vcap) return FDM_OK;
   if (int rc_sync = sync_all(e)) return rc_sync;
@@ -49,6 +55,11 @@ int ensure_voxel_buffers(fdm_engine* e, size_t n) {
     HIPCK(rocprim::radix_sort_pairs(nullptr, b32, reinterpret_cast<uint32_t*>(e->vkeys[0]),
                                     reinterpret_cast<uint32_t*>(e->vkeys[1]), e->vidx[0], e->vidx[1], e->vcap, 0,
                                     32, e->stream));
+    e->sort_tmp_bytes = std::max(e->sort_tmp_bytes, b32);
+    b32 = 0;
+    HIPCK(rocprim::radix_sort_pairs<RadixAlways>(nullptr, b32, reinterpret_cast<uint32_t*>(e->vkeys[0]),
+                                                 reinterpret_cast<uint32_t*>(e->vkeys[1]), e->vidx[0], e->vidx[1],
+                                                 e->vcap, 0, 32, e->stream));
     e->sort_tmp_bytes = std::max(e->sort_tmp_bytes, b32);
   }
   HIPCK(hipMalloc(&e->sort_tmp, e->sort_tmp_bytes ? e->sort_tmp_bytes : 16));
@@ -101,8 +112,12 @@ int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slo
     HIPCK(hipGetLastError());
     // bits 3*bits .. 31 are zero in every valid key and one in the invalid key (all ones): sorting
     // one bit past the fields is enough to keep the dropped points behind every voxel
-    HIPCK(rocprim::radix_sort_pairs(e->sort_tmp, bytes, k0, k1, e->vidx[0], e->vidx[1], size_t(n), 0,
-                                    unsigned(key_bits + 1), e->stream));
+    if (n < (1u << 16))
+      HIPCK(rocprim::radix_sort_pairs(e->sort_tmp, bytes, k0, k1, e->vidx[0], e->vidx[1], size_t(n), 0,
+                                      unsigned(key_bits + 1), e->stream));
+    else
+      HIPCK(rocprim::radix_sort_pairs<RadixAlways>(e->sort_tmp, bytes, k0, k1, e->vidx[0], e->vidx[1], size_t(n), 0,
+                                                   unsigned(key_bits + 1), e->stream));
   } else {
     hipLaunchKernelGGL(k_voxel_keys<unsigned long long>, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, inv,
                        flag_slot, C, e->d_state, dx, dy, dz, e->vkeys[0], e->vidx[0], e->vsel);
