@@ -146,7 +146,7 @@ struct fdm_engine {
   bool overlap = true;          // option "overlap"
   bool chain = false;           // an update is held back: the next bin derives its geometry from the previous slot
   std::function<int()> upd_alone;   // launches the held-back update on its own
-  struct BinVariant { bool bin4, has_int, has_col, wave_merge; unsigned threads; };
+  struct BinVariant { bool bin4, has_int, has_col, wave_merge; unsigned threads; bool lean; };
   std::function<int(const ScanParams&, const Scratch&, const ScanInputs&, int32_t*, unsigned, BinVariant)> upd_fused;
   bool upd_fuses_bin4 = false;  // the held-back update can ride with a k_bin4 launch (record policies only)
   int last_do_move = 0, last_gate = 0;
@@ -548,7 +548,9 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     e->upd_fused = nullptr;
     e->upd_alone = nullptr;
     e->chain = false;
-    const fdm_engine::BinVariant bv{use_bin4, P.has_intensity != 0, P.has_color != 0, e->wave_merge, bin_threads};
+    // a scan that asks for nothing optional takes the LEAN bin body (fdm_kernels.hpp)
+    const bool lean = !ids && !e->S.wt_x && !e->S.cap_x && !P.drop_nonfinite && !P.dbg_no_atomics;
+    const fdm_engine::BinVariant bv{use_bin4, P.has_intensity != 0, P.has_color != 0, e->wave_merge, bin_threads, lean};
     if ((rc = fused(P, e->S, in_b, ids, bin_blocks, bv))) return rc;
   } else if (use_bin4) {
     const bool hi = P.has_intensity != 0, hc = P.has_color != 0;
@@ -647,6 +649,11 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
           bv.wave_merge ? go(k_update_bin<POLICY, true, true>, 256u) : go(k_update_bin<POLICY, false, true>, 256u);
         } else if (!bv.wave_merge) {
           go(k_update_bin<POLICY, false>, 256u);
+        } else if (bv.lean) {  // channel tests folded at compile time, optional work compiled out
+          if (bv.has_int && bv.has_col) go(k_update_bin<POLICY, true, false, 3, true>, 256u);
+          else if (bv.has_col) go(k_update_bin<POLICY, true, false, 2, true>, 256u);
+          else if (bv.has_int) go(k_update_bin<POLICY, true, false, 1, true>, 256u);
+          else go(k_update_bin<POLICY, true, false, 0, true>, 256u);
         } else if (bv.has_int && bv.has_col) {  // the bin half's channel tests folded at compile time
           go(k_update_bin<POLICY, true, false, 3>, 256u);
         } else if (bv.has_col) {
@@ -657,16 +664,18 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
           go(k_update_bin<POLICY, true, false, 0>, 256u);
         }
       } else if constexpr (kRec) {
-#define FDM_FUSED4(T, ST)                                                              \
-        if (bv.has_int && bv.has_col) go(k_update_bin4<POLICY, true, true, T, ST>, T);   \
-        else if (bv.has_int) go(k_update_bin4<POLICY, true, false, T, ST>, T);           \
-        else if (bv.has_col) go(k_update_bin4<POLICY, false, true, T, ST>, T);           \
-        else go(k_update_bin4<POLICY, false, false, T, ST>, T);
+#define FDM_FUSED4(T, ST, LN)                                                              \
+        if (bv.has_int && bv.has_col) go(k_update_bin4<POLICY, true, true, T, ST, LN>, T);   \
+        else if (bv.has_int) go(k_update_bin4<POLICY, true, false, T, ST, LN>, T);           \
+        else if (bv.has_col) go(k_update_bin4<POLICY, false, true, T, ST, LN>, T);           \
+        else go(k_update_bin4<POLICY, false, false, T, ST, LN>, T);
+#define FDM_FUSED4L(T, ST) if (bv.lean) { FDM_FUSED4(T, ST, true) } else { FDM_FUSED4(T, ST, false) }
         if (Su.dense) {
-          if (bv.threads == 512u) { FDM_FUSED4(512, false) } else { FDM_FUSED4(256, false) }
+          if (bv.threads == 512u) { FDM_FUSED4L(512, false) } else { FDM_FUSED4L(256, false) }
         } else {
-          if (bv.threads == 512u) { FDM_FUSED4(512, true) } else { FDM_FUSED4(256, true) }
+          if (bv.threads == 512u) { FDM_FUSED4L(512, true) } else { FDM_FUSED4L(256, true) }
         }
+#undef FDM_FUSED4L
 #undef FDM_FUSED4
       } else {
         return fail(FDM_ERR_INVALID, "internal: k_bin4 fused with a per-layer policy");

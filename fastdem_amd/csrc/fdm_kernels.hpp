@@ -192,12 +192,20 @@ __device__ __forceinline__ DevCand block_candidate(const ScanParams& P, const Ge
 // four CONSECUTIVE points per thread (dwordx4 loads).
 constexpr uint32_t kEmptyCell = 0xFFFFFFFFu;
 
-template <bool HAS_INT, bool HAS_COL, int THREADS>
+template <bool HAS_INT, bool HAS_COL, int THREADS, bool LEAN = false>
 __device__ __forceinline__ void bin4_body(const ScanParams& P, const GeomConst& G,
                                           DevState* __restrict__ st, const float* __restrict__ px,
                                           const float* __restrict__ py, const float* __restrict__ pz,
                                           const float* __restrict__ pint, const Scratch& S,
                                           int32_t* __restrict__ cell_ids, const unsigned bid) {
+  // LEAN (the fused launches of a plain scan): captures, write-through, cell ids, the non-finite filter and
+  // the measurement switches are compiled out — dormant, they still cost 3-7 % of the launch
+  float* const cap_x = LEAN ? nullptr : S.cap_x;
+  float* const cap_var = LEAN ? nullptr : S.cap_var;
+  float* const wt_x = LEAN ? nullptr : S.wt_x;
+  int32_t* const ids = LEAN ? nullptr : cell_ids;
+  const int dbg_na = LEAN ? 0 : P.dbg_no_atomics;
+  const bool drop_nf = LEAN ? false : P.drop_nonfinite != 0;
   constexpr int kHashSlots = THREADS * 4;  // == points per block: room for every point in its own cell
   __shared__ unsigned long long h_key[kHashSlots];
   __shared__ uint32_t h_cell[kHashSlots];
@@ -234,11 +242,11 @@ __device__ __forceinline__ void bin4_body(const ScanParams& P, const GeomConst& 
     }
   }
 
-  if (S.wt_x) {  // leave the raw scan in HBM for the update kernel (see Scratch::wt_x)
+  if (wt_x) {  // leave the raw scan in HBM for the update kernel (see Scratch::wt_x)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (i0 + j >= P.n) break;
-      S.wt_x[i0 + j] = xs[j]; S.wt_y[i0 + j] = ys[j]; S.wt_z[i0 + j] = zs[j];
+      wt_x[i0 + j] = xs[j]; S.wt_y[i0 + j] = ys[j]; S.wt_z[i0 + j] = zs[j];
       if (S.wt_var) S.wt_var[i0 + j] = S.wt_src_var[i0 + j];
       if (S.wt_rgb) S.wt_rgb[i0 + j] = S.wt_src_rgb[i0 + j];
     }
@@ -258,25 +266,25 @@ __device__ __forceinline__ void bin4_body(const ScanParams& P, const GeomConst& 
   bool any_glob = false;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if (P.dbg_no_atomics >= 3) {  // measurement only: loads without the arithmetic
+    if (dbg_na >= 3) {  // measurement only: loads without the arithmetic
       cells[j] = (xs[j] + ys[j] + zs[j] == 12345.f) ? 0 : -1;
       continue;
     }
     const bool live = i0 + j < P.n;
     float cvar = 0.f;
-    if (S.cap_var && live && P.integrate_mode) cvar = sigma_z2(P, xs[j], ys[j], zs[j]);
-    const bool exists = live && (!P.drop_nonfinite || (isfinite(xs[j]) && isfinite(ys[j]) && isfinite(zs[j])));
+    if (cap_var && live && P.integrate_mode) cvar = sigma_z2(P, xs[j], ys[j], zs[j]);
+    const bool exists = live && (!drop_nf || (isfinite(xs[j]) && isfinite(ys[j]) && isfinite(zs[j])));
     const bool pass = preprocess_point(P, xs[j], ys[j], zs[j]) && exists;
-    if (S.cap_x && live) {
-      S.cap_x[i0 + j] = (S.cap_drop_nan && !pass) ? __uint_as_float(0x7FC00000u) : xs[j];
+    if (cap_x && live) {
+      cap_x[i0 + j] = (S.cap_drop_nan && !pass) ? __uint_as_float(0x7FC00000u) : xs[j];
       S.cap_y[i0 + j] = ys[j]; S.cap_z[i0 + j] = zs[j];
-      if (S.cap_var) S.cap_var[i0 + j] = cvar;
+      if (cap_var) cap_var[i0 + j] = cvar;
     }
     cells[j] = pass ? owned_cell(xs[j], ys[j], cand, G) : -1;
     n_pass += pass ? 1u : 0u;
     n_in += cells[j] >= 0 ? 1u : 0u;
     any_glob = any_glob || (pass && cells[j] != -1);
-    if (cell_ids && live) cell_ids[i0 + j] = cells[j] >= 0 ? cells[j] : (!pass ? -1 : (cells[j] == -2 ? -3 : -2));
+    if (ids && live) ids[i0 + j] = cells[j] >= 0 ? cells[j] : (!pass ? -1 : (cells[j] == -2 ? -3 : -2));
   }
 
   // phase 2: merge runs of equal cell in registers, fold each run into the block's LDS table
@@ -284,7 +292,7 @@ __device__ __forceinline__ void bin4_body(const ScanParams& P, const GeomConst& 
   unsigned long long run_key = kEmptyKey;
   uint32_t run_zmx = 0, run_imx = 0, run_fst = kNoIdx, run_lst = 0;
   auto fold_run = [&]() {
-    if (run_cell < 0 || P.dbg_no_atomics >= 2) return;
+    if (run_cell < 0 || dbg_na >= 2) return;
     uint32_t h = uint32_t(run_cell) & (kHashSlots - 1);
     while (true) {
       const uint32_t seen = h_cell[h];
@@ -336,7 +344,7 @@ __device__ __forceinline__ void bin4_body(const ScanParams& P, const GeomConst& 
   __syncthreads();  // every run of the block is in the table
 
   // phase 3: one global atomic set per unique cell of the block
-  if (!P.dbg_no_atomics) {
+  if (!dbg_na) {
 #pragma unroll
     for (int q = 0; q < kHashSlots / THREADS; ++q) {
       const int k = threadIdx.x + q * THREADS;
@@ -373,12 +381,20 @@ __global__ __launch_bounds__(THREADS) void k_bin4(const ScanParams P, const Geom
 // CH: the scan's optional channels as a compile-time constant (bit 0 intensity, bit 1 colour) or -1 = read
 // them from ScanParams.  A VLP-16 scan is launch/latency-bound: with the channel tests folded away the fused
 // launch of configs[1] takes 5.95 instead of 6.35 us.
-template <bool WAVE_MERGE, int CH = -1>
+template <bool WAVE_MERGE, int CH = -1, bool LEAN = false>
 __device__ __forceinline__ void bin_body(const ScanParams& P, const GeomConst& G,
                                          DevState* __restrict__ st, const float* __restrict__ px,
                                          const float* __restrict__ py, const float* __restrict__ pz,
                                          const float* __restrict__ pint, const Scratch& S,
                                          int32_t* __restrict__ cell_ids, const unsigned bid) {
+  // LEAN (the fused launches of a plain scan): captures, write-through, cell ids, the non-finite filter and
+  // the measurement switches are compiled out — dormant, they still cost 3-7 % of the launch
+  float* const cap_x = LEAN ? nullptr : S.cap_x;
+  float* const cap_var = LEAN ? nullptr : S.cap_var;
+  float* const wt_x = LEAN ? nullptr : S.wt_x;
+  int32_t* const ids = LEAN ? nullptr : cell_ids;
+  const int dbg_na = LEAN ? 0 : P.dbg_no_atomics;
+  const bool drop_nf = LEAN ? false : P.drop_nonfinite != 0;
   const bool has_int = CH < 0 ? P.has_intensity != 0 : (CH & 1) != 0;
   const bool has_col = CH < 0 ? P.has_color != 0 : (CH & 2) != 0;
   __shared__ DevCand s_cand;
@@ -402,8 +418,8 @@ __device__ __forceinline__ void bin_body(const ScanParams& P, const GeomConst& G
     y = py[i];
     z = pz[i];
     if (has_int) vint = pint[i];
-    if (S.wt_x) {  // leave the raw scan in HBM for the update kernel (see Scratch::wt_x)
-      S.wt_x[i] = x; S.wt_y[i] = y; S.wt_z[i] = z;
+    if (wt_x) {  // leave the raw scan in HBM for the update kernel (see Scratch::wt_x)
+      wt_x[i] = x; S.wt_y[i] = y; S.wt_z[i] = z;
       if (S.wt_var) S.wt_var[i] = S.wt_src_var[i];
       if (S.wt_rgb) S.wt_rgb[i] = S.wt_src_rgb[i];
     }
@@ -414,16 +430,16 @@ __device__ __forceinline__ void bin_body(const ScanParams& P, const GeomConst& G
   int cell = -1;
   if (i < P.n) {
     float cvar = 0.f;
-    if (S.cap_var && P.integrate_mode) cvar = sigma_z2(P, x, y, z);
-    const bool exists = !P.drop_nonfinite || (isfinite(x) && isfinite(y) && isfinite(z));
+    if (cap_var && P.integrate_mode) cvar = sigma_z2(P, x, y, z);
+    const bool exists = !drop_nf || (isfinite(x) && isfinite(y) && isfinite(z));
     pass = preprocess_point(P, x, y, z) && exists;
-    if (S.cap_x) {
-      S.cap_x[i] = (S.cap_drop_nan && !pass) ? __uint_as_float(0x7FC00000u) : x;
+    if (cap_x) {
+      cap_x[i] = (S.cap_drop_nan && !pass) ? __uint_as_float(0x7FC00000u) : x;
       S.cap_y[i] = y; S.cap_z[i] = z;
-      if (S.cap_var) S.cap_var[i] = cvar;
+      if (cap_var) cap_var[i] = cvar;
     }
     if (pass) cell = owned_cell(x, y, cand, G);
-    if (cell_ids) cell_ids[i] = cell >= 0 ? cell : (!pass ? -1 : (cell == -2 ? -3 : -2));
+    if (ids) ids[i] = cell >= 0 ? cell : (!pass ? -1 : (cell == -2 ? -3 : -2));
   }
   const bool inside = cell >= 0;
   const bool glob = pass && cell != -1;
@@ -487,7 +503,7 @@ __device__ __forceinline__ void bin_body(const ScanParams& P, const GeomConst& G
       }
       if (has_col) atomicMax(&t_lst[h], lst);
     }
-  } else if (commit && !P.dbg_no_atomics) {
+  } else if (commit && !dbg_na) {
     if (has_int && has_col)
       scratch_merge<true, true>(S, P.scan_no, cell, key, zmx, imx, fst, lst);
     else if (has_int)
@@ -505,7 +521,7 @@ __device__ __forceinline__ void bin_body(const ScanParams& P, const GeomConst& G
     if (mg) st->flags[P.slot].any_inside = 1u;
   }
   __syncthreads();
-  if (P.bin_table && !P.dbg_no_atomics) {  // one slot per thread
+  if (P.bin_table && !dbg_na) {  // one slot per thread
     const uint32_t tc = t_cell[threadIdx.x];
     if (tc != kEmptyCell) {
       const unsigned long long tk = t_key[threadIdx.x];
@@ -986,7 +1002,7 @@ struct ScanInputs {
 };
 // STAMPED (stamp-gated maps) is a template parameter, not a branch on Su.dense: carrying both update bodies
 // in one kernel cost the dense configs[2] launch 4 % (14.9 -> 15.4 us).
-template <typename POLICY, bool HAS_INT, bool HAS_COL, int THREADS, bool STAMPED = false>
+template <typename POLICY, bool HAS_INT, bool HAS_COL, int THREADS, bool STAMPED = false, bool LEAN = false>
 __global__ __launch_bounds__(THREADS) void k_update_bin4(
     const ScanParams Pu, const GeomConst G, DevState* __restrict__ st, const typename POLICY::Layers L,
     float* const* __restrict__ all_layers, int n_layers, const Scratch Su, const ScanInputs Iu, unsigned ncell,
@@ -1005,12 +1021,12 @@ __global__ __launch_bounds__(THREADS) void k_update_bin4(
       update_stamped_body<POLICY, THREADS>(Pu, G, st, L, all_layers, n_layers, Su, Iu.x, Iu.y, Iu.z, Iu.rgb, Iu.var,
                                            ncell, u0);
   } else {
-    bin4_body<HAS_INT, HAS_COL, THREADS>(Pb, G, st, Ib.x, Ib.y, Ib.z, Ib.intensity, Sb, cell_ids,
+    bin4_body<HAS_INT, HAS_COL, THREADS, LEAN>(Pb, G, st, Ib.x, Ib.y, Ib.z, Ib.intensity, Sb, cell_ids,
                                          blockIdx.x - u0);
   }
 }
 
-template <typename POLICY, bool WAVE_MERGE, bool STAMPED = false, int CH = -1>
+template <typename POLICY, bool WAVE_MERGE, bool STAMPED = false, int CH = -1, bool LEAN = false>
 __global__ __launch_bounds__(256) void k_update_bin(
     const ScanParams Pu, const GeomConst G, DevState* __restrict__ st, const typename POLICY::Layers L,
     float* const* __restrict__ all_layers, int n_layers, const Scratch Su, const ScanInputs Iu, unsigned ncell,
@@ -1024,7 +1040,7 @@ __global__ __launch_bounds__(256) void k_update_bin(
       update_stamped_body<POLICY, 256>(Pu, G, st, L, all_layers, n_layers, Su, Iu.x, Iu.y, Iu.z, Iu.rgb, Iu.var,
                                        ncell, blockIdx.x);
   } else {
-    bin_body<WAVE_MERGE, CH>(Pb, G, st, Ib.x, Ib.y, Ib.z, Ib.intensity, Sb, cell_ids, blockIdx.x - upd_blocks);
+    bin_body<WAVE_MERGE, CH, LEAN>(Pb, G, st, Ib.x, Ib.y, Ib.z, Ib.intensity, Sb, cell_ids, blockIdx.x - upd_blocks);
   }
 }
 

@@ -25,12 +25,17 @@ def ref_step(ref, s, Tbs, Twb):
     return ref.integrate(s["x"], s["y"], s["z"], Tbs, Twb, **kw)
 
 
+@pytest.mark.parametrize("lean", [0, 1])
 @pytest.mark.parametrize("overlap", [1, 0])
 @pytest.mark.parametrize("name", ["vlp16", "rgbd_small"])
-def test_chain_equals_oracle(gpu, R, name, overlap):
+def test_chain_equals_oracle(gpu, R, name, overlap, lean):
+    """lean = 1: nothing optional is asked of the bin kernel (no cell ids), which selects the LEAN fused
+    kernels — the ones bench.py times."""
     wl = gpu.synth.vlp16(n_scans=12) if name == "vlp16" else gpu.synth.rgbd(n_scans=6)
     eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
     eng.set_option("overlap", overlap)
+    if lean:
+        eng.enable_cell_ids(False)
     keep = []
     for k in range(12):
         s = wl.scan(k)
@@ -56,6 +61,8 @@ def test_chain_on_a_stamp_gated_map(gpu, R, name):
     wl = gpu.synth.vlp16(n_scans=10) if name == "vlp16" else gpu.synth.lidar128(n_scans=5, n_az=1024)
     eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
     eng.set_option("dense", 0)
+    if name == "lidar128":
+        eng.enable_cell_ids(False)  # LEAN stamped k_update_bin4
     keep = []
     n = len(wl.scans)
     for k in range(n):
@@ -191,12 +198,15 @@ def test_destroy_with_a_held_back_update(gpu, R):
     eng.close()  # nothing read back: the held-back closure is dropped with the engine
 
 
+@pytest.mark.parametrize("lean", [0, 1])
 @pytest.mark.parametrize("n_az,scans", [(2048, 6), (16384, 3)])
-def test_chain_of_large_scans(gpu, R, n_az, scans):
+def test_chain_of_large_scans(gpu, R, n_az, scans, lean):
     """k_bin4 launches (256-thread blocks below 1 M points, 512-thread blocks above) carrying the
     previous scan's update, with an 8-cell rolling shift per scan."""
     wl = gpu.synth.lidar128(n_scans=scans, n_az=n_az)
     eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
+    if lean:
+        eng.enable_cell_ids(False)
     keep = []
     for k in range(scans):
         d = dev(wl.scan(k))
@@ -209,10 +219,13 @@ def test_chain_of_large_scans(gpu, R, n_az, scans):
     assert same_geometry(eng.geometry(), ref.geometry())
 
 
-def test_chain_rgbd_p2_colour_large(gpu, R):
+@pytest.mark.parametrize("lean", [0, 1])
+def test_chain_rgbd_p2_colour_large(gpu, R, lean):
     """configs[2] through the chain: P2 cell records (128 B), colour channel, k_bin4<false,true,256>."""
     wl = gpu.synth.rgbd(n_scans=5)
     eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
+    if lean:
+        eng.enable_cell_ids(False)
     keep = []
     for k in range(5):
         d = dev(wl.scan(k))
