@@ -213,8 +213,15 @@ def parity_gate(wl, R):
         if k + 1 in (1, 2, 10):
             worst = max(worst, compare_layers(eng, ref))  # asserts NaN pattern + tolerance
             checked.append(k + 1)
+    # ... and the path that was TIMED: scans resident in HBM, enqueue-only, one fused launch per scan with the
+    # LEAN bin half (no cell ids asked for), against the same oracle state after the 10 scans
+    import torch
+    res = Resident(wl, torch.cuda.current_device())
+    for k in range(10):
+        res.step(k)
+    worst_timed_path = compare_layers(res.eng, ref)
     return {"after_scans": checked, "cell_ids": "bit-exact", "layers_max_rel_err": worst, "rtol": 1e-5,
-            "layers": len(ref.layers())}
+            "layers": len(ref.layers()), "timed_path_after_10_scans_max_rel_err": worst_timed_path}
 
 
 def cpu_baseline(wl, target_s=12.0):
