@@ -29,6 +29,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+# distinct 2 M-point scans of the configs[3] legs: 9 x 33.5 MB = 302 MB of input cycle through the
+# timed region, more than the 256 MiB Infinity Cache can hold, so the read stream comes from HBM
+LARGE_SCANS = 9
 
 
 def parse():
@@ -38,6 +41,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--order", default="azimuth", choices=["azimuth", "ring"])
+    ap.add_argument("--scans", type=int, default=0,
+                    help="distinct synthetic scans resident in HBM (0 = per workload: enough that the 2 M-point "
+                         "workloads stream > 256 MiB of input, i.e. cannot sit in the Infinity Cache)")
     ap.add_argument("--host-legs", action="store_true",
                     help="also time the PCIe-inclusive host entry points (reported beside `value`, never as it)")
     ap.add_argument("--profile-steps", type=int, default=200)
@@ -301,6 +307,8 @@ def main():
         result = tiling.bench_global(args, rank, local_rank, world)
     else:
         kw = {"order": args.order} if args.workload in ("c2", "c4") else {}
+        if args.scans or args.workload == "c4":
+            kw["n_scans"] = args.scans or LARGE_SCANS
         wl = synth.make(args.workload, **kw)
         res = Resident(wl, local_rank, args.wave_merge, args.overlap)
         for kv in args.set:
@@ -405,7 +413,9 @@ def main():
                 res.eng.sync()
                 result["host_stream_pinned_ms_per_scan"] = (time.perf_counter() - t0) / 200 * 1e3
             if world == 1 and not args.no_large and args.workload != "c4":
-                big = Resident(synth.lidar128(n_scans=2), local_rank, args.wave_merge, args.overlap)
+                big = Resident(synth.lidar128(n_scans=LARGE_SCANS), local_rank, args.wave_merge, args.overlap)
+                for kv in args.set:
+                    big.eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
                 for i in range(10):
                     big.step(i)
                 big.eng.sync()

@@ -60,6 +60,8 @@ struct DevState {
 
 struct GeomConst {
   double len_x, len_y, half_x, half_y, res, inv_res;
+  double inv_res_k;                    // 2^idx_shift / res (fixed-point index estimate of axis_fast)
+  int idx_shift, idx_pad;              // as many fraction bits as the map size leaves in an int32 (<= 20)
   int rows, cols;                      // global buffer size
   int s_r0, s_c0, s_rows, s_cols;      // stored window (tile incl. halo)
   int o_r0, o_c0, o_rows, o_cols;      // owned window (cells this engine updates)
@@ -184,6 +186,35 @@ __device__ __forceinline__ bool cell_of(float xf, float yf, const DevCand& g, co
   const bool okr = axis_index(double(xf), g.px, G.half_x, G.len_x, G.res, G.inv_res, g.sr, any_start, G.rows, r);
   const bool okc = axis_index(double(yf), g.py, G.half_y, G.len_y, G.res, G.inv_res, g.sc, any_start, G.cols, c);
   return okr && okc;
+}
+
+// The same getIndex, split for branch-lean callers (k_tbin evaluates four points per thread):
+//   axis_fast  : k = trunc of a fixed-point estimate of -v/res with `shift` fraction bits.  `sure` when the
+//                estimate lies at least 2^-shift cell away from a cell edge and one cell away from the map
+//                border: the estimate is off by ~1e-12 cells at most, so trunc(-(v/res)) is k.
+//   axis_exact : the reference arithmetic (inside test + IEEE divide) for the lanes that were not sure.
+//   axis_wrap  : start index + circular wrap (getBufferIndexFromIndex), range check.
+__device__ __forceinline__ int axis_fast(double pos, double center, double half, double inv_res_k, int shift,
+                                         int size, bool& sure) {
+  const double v = (pos - half) - center;
+  const int ki = static_cast<int>(-v * inv_res_k);  // saturating convert; NaN -> 0
+  const int mask = (1 << shift) - 1;
+  const int k = ki >> shift, fr = ki & mask;
+  sure = fr != 0 && fr != mask && k >= 1 && k < size - 1;
+  return k;
+}
+__device__ __forceinline__ bool axis_exact(double pos, double center, double half, double len, double res,
+                                           int& k) {
+  const double tt = -((pos - center) - half);
+  if (!(tt >= 0.0 && tt < len)) return false;
+  const double v = (pos - half) - center;
+  k = static_cast<int>(-(v / res));
+  return true;
+}
+__device__ __forceinline__ bool axis_wrap(int& k, int start, bool any_start, int size) {
+  k += start;
+  if (any_start && k >= size) k -= size;
+  return k >= 0 && k < size;
 }
 
 // is buffer index `b` on `axis` inside the strip GridMap::move vacates? (E = geometry

@@ -13,8 +13,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
-#include <functional>
 #include <limits>
 #include <mutex>
 #include <string>
@@ -25,6 +25,7 @@
 #include <rocprim/device/device_radix_sort.hpp>  // stable (key, index) sort of the voxel filter
 
 #include "fdm_kernels.hpp"
+#include "fdm_tiled.hpp"
 #include "fdm_raycast.hpp"
 #include "fdm_egress.hpp"
 #include "fdm_ingest.hpp"
@@ -145,10 +146,31 @@ struct fdm_engine {
   uint4* aux2[2] = {nullptr, nullptr};
   bool overlap = true;          // option "overlap"
   bool chain = false;           // an update is held back: the next bin derives its geometry from the previous slot
-  std::function<int()> upd_alone;   // launches the held-back update on its own
   struct BinVariant { bool bin4, has_int, has_col, wave_merge; unsigned threads; bool lean; };
-  std::function<int(const ScanParams&, const Scratch&, const ScanInputs&, int32_t*, unsigned, BinVariant)> upd_fused;
-  bool upd_fuses_bin4 = false;  // the held-back update can ride with a k_bin4 launch (record policies only)
+  // the held-back update (plain data: the layer set cannot change while it is pending, every entry
+  // point that could change it flushes first)
+  struct PendingUpdate {
+    bool tiled = false;     // large-scan pipeline (fdm_tiled.hpp) or the per-cell scratch one
+    ScanParams P;
+    Scratch S;              // scratch pipeline: the key / aux set of the scan's parity, captures
+    ScanInputs in;          // scratch pipeline: where the winning points are gathered from
+    TilePool Q;             // tiled pipeline: the record pool of the scan's parity
+    TileAux A;
+    unsigned upd_blocks = 0;
+  } pend;
+  // ---- tiled pipeline state (allocated when the first large scan arrives) ----
+  int tiled = 1;                    // option "tiled": large scans go through per-tile record pools
+  unsigned tiled_min = 65536;       // ... from this many points up
+  int tiled_threads = 0;            // 0 = by scan size, 256 / 512
+  TileGrid TG{};
+  TilePool pool[2] = {};            // by scan parity
+  size_t pool_cap = 0;              // records per pool
+  unsigned desc_stride = 0;
+  uint32_t* tile_stamp32 = nullptr;
+  uint32_t* upd_part32 = nullptr;
+  unsigned last_upd_tiles = 0;      // length of the per-tile statistics of the last scan
+  uint32_t* last_upd_part = nullptr;
+  int last_kind = -1;               // pipeline of the last scan (0 scratch, 1 tiled)
   int last_do_move = 0, last_gate = 0;
   // stencil post-processing (fdm_post.hpp)
   RegionEntry* d_region = nullptr;   // kMaxRegion entries
@@ -171,15 +193,11 @@ namespace {
 
 // Launch the held-back update kernel, if any.  Called at the top of every entry point that is not
 // the next scan of the chain, and before anything that syncs or reallocates.
+int launch_update_alone(fdm_engine* e, const fdm_engine::PendingUpdate& u);
 int join_streams(fdm_engine* e) {
   if (e->chain) {
     e->chain = false;
-    std::function<int()> f = std::move(e->upd_alone);
-    e->upd_alone = nullptr;
-    e->upd_fused = nullptr;
-    if (f) {
-      if (int rc = f()) return rc;
-    }
+    if (int rc = launch_update_alone(e, e->pend)) return rc;
   }
   return FDM_OK;
 }
@@ -415,6 +433,276 @@ RayParams make_ray_params(fdm_engine* e, const fdm_raycast_config& c, const floa
 int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float* dx, const float* dy,
                       const float* dz, int key_mode = 0);
 
+// ---- launch helpers -------------------------------------------------------------------------
+P2Params p2_params(const fdm_config& c) {  // P2Quantile ctor (quantile_estimation.hpp:84-95): clamp, then monotone dn
+  P2Params p2{};
+  auto clamp01 = [](float v) { return v < 0.f ? 0.f : (1.f < v ? 1.f : v); };
+  for (int k = 0; k < 5; ++k) p2.dn[k] = clamp01(c.p2_dn[k]);
+  for (int k = 1; k < 5; ++k) p2.dn[k] = std::max(p2.dn[k], p2.dn[k - 1]);
+  p2.marker = std::min(std::max(c.p2_elevation_marker, 0), 4);
+  p2.max_count = std::max(c.p2_max_sample_count, 0.0f);
+  return p2;
+}
+
+// f(policy tag, layer set) for the engine's estimator and layer layout
+template <typename F>
+int with_policy(fdm_engine* e, F&& f) {
+  const bool p2mode = e->cfg.estimation_type == 1;
+  if (e->rec_kind >= 0) {  // cell records
+    if (p2mode) {
+      P2RecLayers Lr{};
+      Lr.rec = e->d_rec; Lr.obstacle = L(e, "obstacle"); Lr.intensity = L(e, "intensity"); Lr.color = L(e, "color");
+      Lr.p = p2_params(e->cfg);
+      return f(P2RecPolicy{}, Lr);
+    }
+    KalmanRecLayers Lr{};
+    Lr.rec = e->d_rec; Lr.obstacle = L(e, "obstacle"); Lr.intensity = L(e, "intensity"); Lr.color = L(e, "color");
+    Lr.min_var = e->cfg.kalman_min_variance; Lr.max_var = e->cfg.kalman_max_variance;
+    Lr.q = e->cfg.kalman_process_noise;
+    return f(KalmanRecPolicy{}, Lr);
+  }
+  if (p2mode) {
+    P2Layers Lp{};
+    Lp.elevation = L(e, "elevation");
+    Lp.elevation_min = L(e, "elevation_min");
+    Lp.elevation_max = L(e, "elevation_max");
+    Lp.variance = L(e, "variance");
+    Lp.n_points = L(e, "n_points");
+    Lp.upper = L(e, "upper_bound");
+    Lp.lower = L(e, "lower_bound");
+    Lp.obstacle = L(e, "obstacle");
+    Lp.intensity = L(e, "intensity");
+    Lp.color = L(e, "color");
+    for (int k = 0; k < 5; ++k) {
+      Lp.q[k] = L(e, kP2Q[k]);
+      Lp.n[k] = L(e, kP2N[k]);
+    }
+    Lp.p = p2_params(e->cfg);
+    return f(P2Policy{}, Lp);
+  }
+  KalmanLayers Lk{};
+  Lk.elevation = L(e, "elevation");
+  Lk.elevation_min = L(e, "elevation_min");
+  Lk.elevation_max = L(e, "elevation_max");
+  Lk.variance = L(e, "variance");
+  Lk.n_points = L(e, "n_points");
+  Lk.kalman_p = L(e, "_kalman_p");
+  Lk.sample_mean = L(e, "_sample_mean");
+  Lk.sample_m2 = L(e, "_sample_m2");
+  Lk.upper = L(e, "upper_bound");
+  Lk.lower = L(e, "lower_bound");
+  Lk.obstacle = L(e, "obstacle");
+  Lk.intensity = L(e, "intensity");
+  Lk.color = L(e, "color");
+  Lk.min_var = e->cfg.kalman_min_variance;
+  Lk.max_var = e->cfg.kalman_max_variance;
+  Lk.q = e->cfg.kalman_process_noise;
+  return f(KalmanPolicy{}, Lk);
+}
+template <typename POLICY>
+constexpr bool is_rec_policy = std::is_same<POLICY, KalmanRecPolicy>::value || std::is_same<POLICY, P2RecPolicy>::value;
+
+// kernels with more than 64 KB of dynamic LDS need the attribute once
+template <typename K>
+int allow_lds(K kern, unsigned bytes) {
+  static std::mutex mu;
+  static std::unordered_map<const void*, unsigned> seen;
+  if (bytes <= 65536u) return FDM_OK;
+  const void* f = reinterpret_cast<const void*>(kern);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = seen.find(f);
+  if (it != seen.end() && it->second >= bytes) return FDM_OK;
+  HIPCK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
+  seen[f] = bytes;
+  return FDM_OK;
+}
+
+// tiles per 256-thread group of k_tupdate: 1 while the tile count keeps the chip busy by itself, 32 on
+// very large maps (nearly every tile idle: one wavefront looks at 32 chunk counts in one round trip)
+unsigned tile_span(const fdm_engine* e) { return e->TG.n_tiles <= 16384u ? 1u : 32u; }
+
+// The record pools of the tiled pipeline: `records` per pool, `blocks` chunk slots per tile.
+int ensure_tile_pool(fdm_engine* e, size_t records, unsigned blocks, bool has_int, bool has_col) {
+  if (!e->tile_stamp32) {
+    e->TG.tiles_r = (e->G.s_rows + kTS - 1) / kTS;
+    e->TG.tiles_c = (e->G.s_cols + kTS - 1) / kTS;
+    e->TG.n_tiles = unsigned(e->TG.tiles_r) * unsigned(e->TG.tiles_c);
+    if (e->TG.n_tiles >= (1u << 21)) return fail(FDM_ERR_INVALID, "tiled pipeline: more than 2^21 map tiles");
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->tile_stamp32), e->TG.n_tiles * sizeof(uint32_t)));
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->upd_part32), e->TG.n_tiles * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_fill_u32, dim3(64), dim3(256), 0, e->stream, e->tile_stamp32, 0xFFFFFFFEu, size_t(e->TG.n_tiles));
+    hipLaunchKernelGGL(k_fill_u32, dim3(64), dim3(256), 0, e->stream, e->upd_part32, 0u, size_t(e->TG.n_tiles));
+    HIPCK(hipGetLastError());
+  }
+  const bool grow_rec = records > e->pool_cap;
+  const bool need_int = has_int && !e->pool[0].imax, need_col = has_col && !e->pool[0].rgb;
+  const bool grow_desc = blocks + 1u > e->desc_stride;
+  if (!grow_rec && !need_int && !need_col && !grow_desc) return FDM_OK;
+  if (int rc_sync = sync_all(e)) return rc_sync;  // (every chunk list is consumed: the row counts are all zero)
+  if (grow_rec) {
+    e->pool_cap = records + records / 4 + 8192;
+    if (e->pool_cap >= 0x7FFFFFF0ull) return fail(FDM_ERR_INVALID, "tiled pipeline: scan too large");
+  }
+  if (grow_desc) e->desc_stride = blocks + blocks / 4 + 16;  // (+1: word 0 of a row is its chunk count)
+  for (auto& q : e->pool) {
+    auto re = [&](auto*& ptr, size_t bytes) -> int {
+      if (ptr) HIPCK(hipFree(ptr));
+      ptr = nullptr;
+      HIPCK(hipMalloc(reinterpret_cast<void**>(&ptr), bytes));
+      return FDM_OK;
+    };
+    int rc;
+    if (grow_rec) {
+      if ((rc = re(q.key, e->pool_cap * 8)) || (rc = re(q.zmax, e->pool_cap * 8)) ||
+          (rc = re(q.cell, e->pool_cap * 4)) || (rc = re(q.var, e->pool_cap * 4)))
+        return rc;
+    }
+    if ((has_int || q.imax) && (grow_rec || need_int) && (rc = re(q.imax, e->pool_cap * 8))) return rc;
+    if ((has_col || q.rgb) && (grow_rec || need_col) && (rc = re(q.rgb, e->pool_cap * 4))) return rc;
+    if (grow_desc) {
+      if ((rc = re(q.desc, size_t(e->TG.n_tiles) * e->desc_stride * 8))) return rc;
+      HIPCK(hipMemsetAsync(q.desc, 0, size_t(e->TG.n_tiles) * e->desc_stride * 8, e->stream));
+    }
+    q.stride = e->desc_stride;
+  }
+  return FDM_OK;
+}
+
+int launch_tbin(fdm_engine* e, const ScanParams& P, const ScanInputs& in, const TilePool& Q, int32_t* ids,
+                unsigned bin_blocks, fdm_engine::BinVariant bv) {
+  const unsigned lds = tbin_lds_bytes(bv.has_int, bv.has_col, bv.threads);
+  int rc = FDM_OK;
+  auto go = [&](auto kern) {
+    if ((rc = allow_lds(kern, lds))) return;
+    hipLaunchKernelGGL(kern, dim3(bin_blocks), dim3(bv.threads), lds, e->stream, P, e->G, e->TG, e->d_state, in, e->S,
+                       Q, ids);
+  };
+#define FDM_TBIN(T, LN)                                           \
+  if (bv.has_int && bv.has_col) go(k_tbin<true, true, T, LN>);    \
+  else if (bv.has_int) go(k_tbin<true, false, T, LN>);            \
+  else if (bv.has_col) go(k_tbin<false, true, T, LN>);            \
+  else go(k_tbin<false, false, T, LN>);
+  if (bv.threads == 512u) { if (bv.lean) { FDM_TBIN(512, true) } else { FDM_TBIN(512, false) } }
+  else { if (bv.lean) { FDM_TBIN(256, true) } else { FDM_TBIN(256, false) } }
+#undef FDM_TBIN
+  if (rc) return rc;
+  HIPCK(hipGetLastError());
+  return FDM_OK;
+}
+
+// The held-back (or just enqueued) update on its own.
+int launch_update_alone(fdm_engine* e, const fdm_engine::PendingUpdate& u) {
+  return with_policy(e, [&](auto tag, const auto& layers) -> int {
+    using POLICY = decltype(tag);
+    if (u.tiled) {
+      if constexpr (is_rec_policy<POLICY>) {
+        const unsigned span = tile_span(e);
+        const unsigned blocks = (e->TG.n_tiles + span - 1u) / span;
+        const unsigned lds = tile_lds_bytes(u.P.has_intensity != 0, u.P.has_color != 0);
+        hipLaunchKernelGGL(k_tupdate<POLICY>, dim3(blocks), dim3(256), lds, e->stream, u.P, e->G, e->TG, e->d_state,
+                           layers, e->d_layer_ptrs, e->n_layer_ptrs, u.Q, u.A, span);
+      } else {
+        return fail(FDM_ERR_INVALID, "internal: tiled update with a per-layer policy");
+      }
+    } else if (u.S.dense) {
+      hipLaunchKernelGGL(k_update<POLICY>, dim3(u.upd_blocks), dim3(256), 0, e->stream, u.P, e->G, e->d_state, layers,
+                         e->d_layer_ptrs, e->n_layer_ptrs, u.S, u.in.x, u.in.y, u.in.z, u.in.intensity, u.in.rgb,
+                         u.in.var, unsigned(e->ncell));
+    } else {  // stamp-gated: kStampTiles tiles per block, idle tiles cost one scalar load
+      hipLaunchKernelGGL(k_update_stamped<POLICY>, dim3((u.upd_blocks + kStampTiles - 1) / kStampTiles), dim3(256), 0,
+                         e->stream, u.P, e->G, e->d_state, layers, e->d_layer_ptrs, e->n_layer_ptrs, u.S, u.in.x,
+                         u.in.y, u.in.z, u.in.intensity, u.in.rgb, u.in.var, unsigned(e->ncell));
+    }
+    HIPCK(hipGetLastError());
+    return FDM_OK;
+  });
+}
+
+// The held-back update of scan t and the bin of scan t+1 in one launch.
+int launch_update_fused(fdm_engine* e, const fdm_engine::PendingUpdate& u, const ScanParams& Pb,
+                        const ScanInputs& Ib, const TilePool& Qb, int32_t* ids_b, unsigned bin_blocks_b,
+                        fdm_engine::BinVariant bv) {
+  const Scratch Sb = e->S;
+  return with_policy(e, [&](auto tag, const auto& layers) -> int {
+    using POLICY = decltype(tag);
+    constexpr bool kRec = is_rec_policy<POLICY>;
+    if (u.tiled) {
+      if constexpr (kRec) {
+        const unsigned span = tile_span(e);
+        const unsigned groups = bv.threads / 256u;
+        const unsigned ub = (e->TG.n_tiles + span * groups - 1u) / (span * groups);
+        const unsigned lds = std::max(groups * tile_lds_bytes(u.P.has_intensity != 0, u.P.has_color != 0),
+                                      tbin_lds_bytes(bv.has_int, bv.has_col, bv.threads));
+        int rc = FDM_OK;
+        auto go = [&](auto kern) {
+          if ((rc = allow_lds(kern, lds))) return;
+          hipLaunchKernelGGL(kern, dim3(ub + bin_blocks_b), dim3(bv.threads), lds, e->stream, u.P, e->G, e->TG,
+                             e->d_state, layers, e->d_layer_ptrs, e->n_layer_ptrs, u.Q, u.A, span, ub, Pb, Ib, Sb, Qb,
+                             ids_b);
+        };
+#define FDM_TF(T, LN)                                                              \
+        if (bv.has_int && bv.has_col) go(k_tupdate_tbin<POLICY, true, true, T, LN>);   \
+        else if (bv.has_int) go(k_tupdate_tbin<POLICY, true, false, T, LN>);           \
+        else if (bv.has_col) go(k_tupdate_tbin<POLICY, false, true, T, LN>);           \
+        else go(k_tupdate_tbin<POLICY, false, false, T, LN>);
+        if (bv.threads == 512u) { if (bv.lean) { FDM_TF(512, true) } else { FDM_TF(512, false) } }
+        else { if (bv.lean) { FDM_TF(256, true) } else { FDM_TF(256, false) } }
+#undef FDM_TF
+        if (rc) return rc;
+      } else {
+        return fail(FDM_ERR_INVALID, "internal: tiled update with a per-layer policy");
+      }
+      HIPCK(hipGetLastError());
+      return FDM_OK;
+    }
+    auto go = [&](auto kern, unsigned threads) {
+      // tiles per update block: threads / 256, times kStampTiles slots on stamp-gated maps
+      const unsigned per = (threads / 256u) * (u.S.dense ? 1u : kStampTiles);
+      const unsigned ub = (u.upd_blocks + per - 1u) / per;
+      hipLaunchKernelGGL(kern, dim3(ub + bin_blocks_b), dim3(threads), 0, e->stream, u.P, e->G, e->d_state, layers,
+                         e->d_layer_ptrs, e->n_layer_ptrs, u.S, u.in, unsigned(e->ncell), ub, Pb, Sb, Ib, ids_b);
+    };
+    if (!bv.bin4) {
+      if (!u.S.dense) {
+        bv.wave_merge ? go(k_update_bin<POLICY, true, true>, 256u) : go(k_update_bin<POLICY, false, true>, 256u);
+      } else if (!bv.wave_merge) {
+        go(k_update_bin<POLICY, false>, 256u);
+      } else if (bv.lean) {  // channel tests folded at compile time, optional work compiled out
+        if (bv.has_int && bv.has_col) go(k_update_bin<POLICY, true, false, 3, true>, 256u);
+        else if (bv.has_col) go(k_update_bin<POLICY, true, false, 2, true>, 256u);
+        else if (bv.has_int) go(k_update_bin<POLICY, true, false, 1, true>, 256u);
+        else go(k_update_bin<POLICY, true, false, 0, true>, 256u);
+      } else if (bv.has_int && bv.has_col) {  // the bin half's channel tests folded at compile time
+        go(k_update_bin<POLICY, true, false, 3>, 256u);
+      } else if (bv.has_col) {
+        go(k_update_bin<POLICY, true, false, 2>, 256u);
+      } else if (bv.has_int) {
+        go(k_update_bin<POLICY, true, false, 1>, 256u);
+      } else {
+        go(k_update_bin<POLICY, true, false, 0>, 256u);
+      }
+    } else if constexpr (kRec) {
+#define FDM_FUSED4(T, ST, LN)                                                              \
+      if (bv.has_int && bv.has_col) go(k_update_bin4<POLICY, true, true, T, ST, LN>, T);   \
+      else if (bv.has_int) go(k_update_bin4<POLICY, true, false, T, ST, LN>, T);           \
+      else if (bv.has_col) go(k_update_bin4<POLICY, false, true, T, ST, LN>, T);           \
+      else go(k_update_bin4<POLICY, false, false, T, ST, LN>, T);
+#define FDM_FUSED4L(T, ST) if (bv.lean) { FDM_FUSED4(T, ST, true) } else { FDM_FUSED4(T, ST, false) }
+      if (u.S.dense) {
+        if (bv.threads == 512u) { FDM_FUSED4L(512, false) } else { FDM_FUSED4L(256, false) }
+      } else {
+        if (bv.threads == 512u) { FDM_FUSED4L(512, true) } else { FDM_FUSED4L(256, true) }
+      }
+#undef FDM_FUSED4L
+#undef FDM_FUSED4
+    } else {
+      return fail(FDM_ERR_INVALID, "internal: k_bin4 fused with a per-layer policy");
+    }
+    HIPCK(hipGetLastError());
+    return FDM_OK;
+  });
+}
+
 // One scan = k_bin + k_update on the stream.  All pointers are device pointers.
 // `gather` (nullable): where the UPDATE kernel reads the winning points from.  Set when dx..dvar are
 // pinned host arrays seen through PCIe: the bin kernel then writes the scan through to these HBM
@@ -497,11 +785,19 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     e->S.ras_z = e->d_ras;
   }
 
-  // ---- launch plan.  Small scans are launch/latency-bound (two dependent launches of ~100 blocks),
-  // so the update of scan t is held back and leaves together with the bin of scan t+1 in one launch
-  // (k_update_bin): they share nothing — the scratch is double-buffered by scan parity and a
-  // chained bin derives its base geometry from slot t (ScanParams::chain_prev).
+  // ---- launch plan.  One scan = bin + update.  The update of a plain scan is held back and leaves
+  // together with the bin of the next scan in ONE launch (k_update_bin / k_tupdate_tbin): the two
+  // halves share nothing — the per-scan scratch (or record pool) is double-buffered by scan parity
+  // and a chained bin derives its base geometry from slot t (ScanParams::chain_prev).
   const int parity = int(e->scan_no & 1);
+  // float4 loads need 16-byte aligned channels
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  const bool aligned = al16(dx) && al16(dy) && al16(dz) && al16(dint);
+  // large scans: per-tile record pools (fdm_tiled.hpp); needs the cell-record layout
+  const bool tiled = e->tiled && e->rec_kind >= 0 && n >= e->tiled_min && aligned && n < 0x7FFF0000ull &&
+                     e->bin_variant != 1;
+  if (e->last_kind >= 0 && e->last_kind != int(tiled)) e->obst_dense_pending = true;  // the pipelines keep
+  e->last_kind = int(tiled);                                // separate books on which tiles hold obstacle cells
   if (e->key2[1]) {  // the scratch set of this scan's parity
     e->S.key = e->key2[parity];
     e->S.aux = e->aux2[parity];
@@ -509,16 +805,15 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   const bool plain = e->overlap && e->key2[1] && !ray_on && !e->cap_pre &&
                      !e->cap_ras && !e->obst_dense_pending;
 
-  // k_bin4 (4 consecutive points per thread, float4 loads) needs 16-byte aligned channels
-  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
   // k_bin4 trades latency for fewer memory-side atomics: worth it from ~64 K points up
   const bool want4 = e->bin_variant == 4 || (e->bin_variant == 0 && n >= 65536);
-  const bool use_bin4 = want4 && al16(dx) && al16(dy) && al16(dz) && al16(dint);
-  // k_bin4 block size: 0 = by scan size.  2048-point blocks (512 threads) merge ~20 % more cells on
-  // chip for firing-order LiDAR scans (C4: 50 -> 40 us); smaller scans keep more blocks in flight.
-  const int bt = e->bin_threads ? e->bin_threads : (n >= (1u << 20) ? 512 : 256);
-  const unsigned bin_threads = use_bin4 ? unsigned(bt) : 256u;
-  const unsigned per_block = use_bin4 ? bin_threads * 4u : 256u;
+  const bool use_bin4 = !tiled && want4 && aligned;
+  // block size of the 4-points-per-thread kernels: 0 = by scan size.  2048-point blocks (512 threads) merge
+  // ~20 % more cells on chip for firing-order LiDAR scans; smaller scans keep more blocks in flight.
+  const int bt_opt = tiled ? e->tiled_threads : e->bin_threads;
+  const int bt = bt_opt ? bt_opt : (n >= (1u << 20) ? 512 : 256);
+  const unsigned bin_threads = (use_bin4 || tiled) ? unsigned(bt) : 256u;
+  const unsigned per_block = (use_bin4 || tiled) ? bin_threads * 4u : 256u;
   const unsigned bin_blocks = n ? unsigned((n + per_block - 1) / per_block) : 1u;
   if (bin_blocks > e->bin_part_cap) {
     if (int rc_sync = sync_all(e)) return rc_sync;
@@ -526,32 +821,38 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     e->bin_part_cap = bin_blocks + bin_blocks / 4 + 64;
     HIPCK(hipMalloc(reinterpret_cast<void**>(&e->S.bin_part), e->bin_part_cap * sizeof(unsigned long long)));
   }
+  if (tiled && (rc = ensure_tile_pool(e, size_t(bin_blocks) * per_block, bin_blocks * (kTbinSlotsPerThread < 4 ? 2u : 1u),
+                                      P.has_intensity != 0,
+                                      P.has_color != 0)))
+    return rc;
   e->last_bin_blocks = bin_blocks;
   P.dbg_no_atomics = e->dbg_no_atomics;
   P.bin_table = e->bin_table;
   P.dbg_upd = e->dbg_upd;
   P.drop_nonfinite = e->next_drop_nonfinite;
   e->next_drop_nonfinite = 0;
-  // a held-back update leaves now: fused with this bin if this scan is a plain small one, alone otherwise
-  const bool bin4_fusable = use_bin4 && (bin_threads == 256 || bin_threads == 512) && e->upd_fuses_bin4;
-  const bool fuse_now = e->chain && plain && (!use_bin4 || bin4_fusable) && e->upd_fused;
+  int32_t* ids = e->want_ids ? e->d_cell_ids : nullptr;
+  const ScanInputs in_b{dx, dy, dz, dint, drgb, dvar};
+  // a scan that asks for nothing optional takes the LEAN bin body (fdm_kernels.hpp)
+  const bool lean = !ids && !e->S.wt_x && !e->S.cap_x && !P.drop_nonfinite && !P.dbg_no_atomics;
+  const fdm_engine::BinVariant bv{use_bin4, P.has_intensity != 0, P.has_color != 0, e->wave_merge, bin_threads, lean};
+  // a held-back update leaves now: fused with this bin if the two belong to the same pipeline and
+  // this scan is a plain one, alone otherwise
+  const bool fusable = tiled ? (bin_threads == 256 || bin_threads == 512)
+                             : (!use_bin4 || ((bin_threads == 256 || bin_threads == 512) && e->rec_kind >= 0));
+  const bool fuse_now = e->chain && plain && fusable && e->pend.tiled == tiled;
   if (e->chain && !fuse_now && (rc = join_streams(e))) return rc;
   P.chain_prev = 0;
   if (e->profile) HIPCK(hipEventRecord(e->ev[0], e->stream));
-  int32_t* ids = e->want_ids ? e->d_cell_ids : nullptr;
   if (fuse_now) {  // the held-back update of the previous scan + this scan's bin, one launch
     P.chain_prev = 1;
     P.prev_do_move = e->last_do_move;
     P.prev_gate = e->last_gate;
-    const ScanInputs in_b{dx, dy, dz, dint, drgb, dvar};
-    auto fused = std::move(e->upd_fused);
-    e->upd_fused = nullptr;
-    e->upd_alone = nullptr;
     e->chain = false;
-    // a scan that asks for nothing optional takes the LEAN bin body (fdm_kernels.hpp)
-    const bool lean = !ids && !e->S.wt_x && !e->S.cap_x && !P.drop_nonfinite && !P.dbg_no_atomics;
-    const fdm_engine::BinVariant bv{use_bin4, P.has_intensity != 0, P.has_color != 0, e->wave_merge, bin_threads, lean};
-    if ((rc = fused(P, e->S, in_b, ids, bin_blocks, bv))) return rc;
+    if ((rc = launch_update_fused(e, e->pend, P, in_b, tiled ? e->pool[parity] : TilePool{}, ids, bin_blocks, bv)))
+      return rc;
+  } else if (tiled) {
+    if ((rc = launch_tbin(e, P, in_b, e->pool[parity], ids, bin_blocks, bv))) return rc;
   } else if (use_bin4) {
     const bool hi = P.has_intensity != 0, hc = P.has_color != 0;
     auto launch4 = [&](auto kern) {
@@ -588,158 +889,31 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     HIPCK(hipGetLastError());
     e->obst_dense_pending = false;
   }
-  const unsigned upd_blocks = e->n_tiles;  // one block per map tile
-  // P2Quantile ctor (quantile_estimation.hpp:84-95): clamp, then enforce monotone dn
-  P2Params p2{};
-  {
-    auto clamp01 = [](float v) { return v < 0.f ? 0.f : (1.f < v ? 1.f : v); };
-    for (int k = 0; k < 5; ++k) p2.dn[k] = clamp01(e->cfg.p2_dn[k]);
-    for (int k = 1; k < 5; ++k) p2.dn[k] = std::max(p2.dn[k], p2.dn[k - 1]);
-    p2.marker = std::min(std::max(e->cfg.p2_elevation_marker, 0), 4);
-    p2.max_count = std::max(e->cfg.p2_max_sample_count, 0.0f);
+  // this scan's update: held back (the next scan's launch or a flush carries it) or launched now
+  fdm_engine::PendingUpdate& u = e->pend;
+  u.tiled = tiled;
+  u.P = P;
+  u.S = e->S;
+  u.in = (gather && n) ? ScanInputs{gather->x, gather->y, gather->z, nullptr, drgb ? gather->rgb : nullptr,
+                                    dvar ? gather->var : nullptr}
+                       : in_b;
+  u.upd_blocks = e->n_tiles;
+  if (tiled) {
+    u.Q = e->pool[parity];
+    u.A = TileAux{e->tile_stamp32, e->upd_part32, e->S.ras_z};
+    e->last_upd_tiles = e->TG.n_tiles;
+    e->last_upd_part = e->upd_part32;
+  } else {
+    e->last_upd_tiles = e->n_tiles;
+    e->last_upd_part = e->S.upd_part;
   }
-  // the next scan's launch (or a flush) carries this update
-  const bool hold = plain;
-  const ScanInputs in_u = (gather && n) ? ScanInputs{gather->x, gather->y, gather->z, nullptr,
-                                                     drgb ? gather->rgb : nullptr, dvar ? gather->var : nullptr}
-                                        : ScanInputs{dx, dy, dz, dint, drgb, dvar};
-  auto launch_upd = [&](auto policy_tag, const auto& layers) {
-    using POLICY = decltype(policy_tag);
-    if (!hold) {
-      if (!e->S.dense) {  // stamp-gated: 16 tiles per block, idle tiles cost one scalar load
-        hipLaunchKernelGGL(k_update_stamped<POLICY>, dim3((upd_blocks + kStampTiles - 1) / kStampTiles), dim3(256),
-                           0, e->stream, P, e->G, e->d_state, layers, e->d_layer_ptrs, e->n_layer_ptrs, e->S,
-                           in_u.x, in_u.y, in_u.z, in_u.intensity, in_u.rgb, in_u.var, unsigned(e->ncell));
-        return;
-      }
-      hipLaunchKernelGGL(k_update<POLICY>, dim3(upd_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state,
-                         layers, e->d_layer_ptrs, e->n_layer_ptrs, e->S, in_u.x, in_u.y, in_u.z, in_u.intensity,
-                         in_u.rgb, in_u.var, unsigned(e->ncell));
-      return;
-    }
-    const ScanParams Pu = P;
-    const Scratch Su = e->S;
-    const auto Lu = layers;
-    e->upd_alone = [e, Pu, Su, Lu, in_u, upd_blocks]() -> int {
-      if (Su.dense)
-        hipLaunchKernelGGL(k_update<POLICY>, dim3(upd_blocks), dim3(256), 0, e->stream, Pu, e->G, e->d_state, Lu,
-                           e->d_layer_ptrs, e->n_layer_ptrs, Su, in_u.x, in_u.y, in_u.z, in_u.intensity, in_u.rgb,
-                           in_u.var, unsigned(e->ncell));
-      else
-        hipLaunchKernelGGL(k_update_stamped<POLICY>, dim3((upd_blocks + kStampTiles - 1) / kStampTiles), dim3(256), 0,
-                           e->stream, Pu, e->G, e->d_state, Lu, e->d_layer_ptrs, e->n_layer_ptrs, Su, in_u.x, in_u.y,
-                           in_u.z, in_u.intensity, in_u.rgb, in_u.var, unsigned(e->ncell));
-      HIPCK(hipGetLastError());
-      return FDM_OK;
-    };
-    constexpr bool kRec = std::is_same<POLICY, KalmanRecPolicy>::value || std::is_same<POLICY, P2RecPolicy>::value;
-    e->upd_fuses_bin4 = kRec;
-    e->upd_fused = [e, Pu, Su, Lu, in_u, upd_blocks](const ScanParams& Pb, const Scratch& Sb, const ScanInputs& Ib,
-                                                     int32_t* ids_b, unsigned bin_blocks_b,
-                                                     fdm_engine::BinVariant bv) -> int {
-      auto go = [&](auto kern, unsigned threads) {
-        // tiles per update block: threads / 256, times kStampTiles slots on stamp-gated maps
-        const unsigned per = (threads / 256u) * (Su.dense ? 1u : kStampTiles);
-        const unsigned ub = (upd_blocks + per - 1u) / per;
-        hipLaunchKernelGGL(kern, dim3(ub + bin_blocks_b), dim3(threads), 0, e->stream, Pu, e->G, e->d_state, Lu,
-                           e->d_layer_ptrs, e->n_layer_ptrs, Su, in_u, unsigned(e->ncell), ub, Pb, Sb, Ib, ids_b);
-      };
-      if (!bv.bin4) {
-        if (!Su.dense) {
-          bv.wave_merge ? go(k_update_bin<POLICY, true, true>, 256u) : go(k_update_bin<POLICY, false, true>, 256u);
-        } else if (!bv.wave_merge) {
-          go(k_update_bin<POLICY, false>, 256u);
-        } else if (bv.lean) {  // channel tests folded at compile time, optional work compiled out
-          if (bv.has_int && bv.has_col) go(k_update_bin<POLICY, true, false, 3, true>, 256u);
-          else if (bv.has_col) go(k_update_bin<POLICY, true, false, 2, true>, 256u);
-          else if (bv.has_int) go(k_update_bin<POLICY, true, false, 1, true>, 256u);
-          else go(k_update_bin<POLICY, true, false, 0, true>, 256u);
-        } else if (bv.has_int && bv.has_col) {  // the bin half's channel tests folded at compile time
-          go(k_update_bin<POLICY, true, false, 3>, 256u);
-        } else if (bv.has_col) {
-          go(k_update_bin<POLICY, true, false, 2>, 256u);
-        } else if (bv.has_int) {
-          go(k_update_bin<POLICY, true, false, 1>, 256u);
-        } else {
-          go(k_update_bin<POLICY, true, false, 0>, 256u);
-        }
-      } else if constexpr (kRec) {
-#define FDM_FUSED4(T, ST, LN)                                                              \
-        if (bv.has_int && bv.has_col) go(k_update_bin4<POLICY, true, true, T, ST, LN>, T);   \
-        else if (bv.has_int) go(k_update_bin4<POLICY, true, false, T, ST, LN>, T);           \
-        else if (bv.has_col) go(k_update_bin4<POLICY, false, true, T, ST, LN>, T);           \
-        else go(k_update_bin4<POLICY, false, false, T, ST, LN>, T);
-#define FDM_FUSED4L(T, ST) if (bv.lean) { FDM_FUSED4(T, ST, true) } else { FDM_FUSED4(T, ST, false) }
-        if (Su.dense) {
-          if (bv.threads == 512u) { FDM_FUSED4L(512, false) } else { FDM_FUSED4L(256, false) }
-        } else {
-          if (bv.threads == 512u) { FDM_FUSED4L(512, true) } else { FDM_FUSED4L(256, true) }
-        }
-#undef FDM_FUSED4L
-#undef FDM_FUSED4
-      } else {
-        return fail(FDM_ERR_INVALID, "internal: k_bin4 fused with a per-layer policy");
-      }
-      HIPCK(hipGetLastError());
-      return FDM_OK;
-    };
+  if (plain) {
     e->chain = true;
     e->last_do_move = P.do_move;
     e->last_gate = P.gate_on_filter;
-  };
-  const bool p2mode = e->cfg.estimation_type == 1;
-  if (e->rec_kind >= 0) {  // cell records
-    if (p2mode) {
-      P2RecLayers Lr{};
-      Lr.rec = e->d_rec; Lr.obstacle = L(e, "obstacle"); Lr.intensity = L(e, "intensity"); Lr.color = L(e, "color");
-      Lr.p = p2;
-      launch_upd(P2RecPolicy{}, Lr);
-    } else {
-      KalmanRecLayers Lr{};
-      Lr.rec = e->d_rec; Lr.obstacle = L(e, "obstacle"); Lr.intensity = L(e, "intensity"); Lr.color = L(e, "color");
-      Lr.min_var = e->cfg.kalman_min_variance; Lr.max_var = e->cfg.kalman_max_variance;
-      Lr.q = e->cfg.kalman_process_noise;
-      launch_upd(KalmanRecPolicy{}, Lr);
-    }
-  } else if (p2mode) {
-    P2Layers Lp{};
-    Lp.elevation = L(e, "elevation");
-    Lp.elevation_min = L(e, "elevation_min");
-    Lp.elevation_max = L(e, "elevation_max");
-    Lp.variance = L(e, "variance");
-    Lp.n_points = L(e, "n_points");
-    Lp.upper = L(e, "upper_bound");
-    Lp.lower = L(e, "lower_bound");
-    Lp.obstacle = L(e, "obstacle");
-    Lp.intensity = L(e, "intensity");
-    Lp.color = L(e, "color");
-    for (int k = 0; k < 5; ++k) {
-      Lp.q[k] = L(e, kP2Q[k]);
-      Lp.n[k] = L(e, kP2N[k]);
-    }
-    Lp.p = p2;
-    launch_upd(P2Policy{}, Lp);
-  } else {
-    KalmanLayers Lk{};
-    Lk.elevation = L(e, "elevation");
-    Lk.elevation_min = L(e, "elevation_min");
-    Lk.elevation_max = L(e, "elevation_max");
-    Lk.variance = L(e, "variance");
-    Lk.n_points = L(e, "n_points");
-    Lk.kalman_p = L(e, "_kalman_p");
-    Lk.sample_mean = L(e, "_sample_mean");
-    Lk.sample_m2 = L(e, "_sample_m2");
-    Lk.upper = L(e, "upper_bound");
-    Lk.lower = L(e, "lower_bound");
-    Lk.obstacle = L(e, "obstacle");
-    Lk.intensity = L(e, "intensity");
-    Lk.color = L(e, "color");
-    Lk.min_var = e->cfg.kalman_min_variance;
-    Lk.max_var = e->cfg.kalman_max_variance;
-    Lk.q = e->cfg.kalman_process_noise;
-    launch_upd(KalmanPolicy{}, Lk);
+  } else if ((rc = launch_update_alone(e, u))) {
+    return rc;
   }
-  HIPCK(hipGetLastError());
   if (e->profile) {
     HIPCK(hipEventRecord(e->ev[2], e->stream));
     HIPCK(hipEventRecord(e->ev[3], e->stream));  // back-to-back pair: the event-to-event overhead
@@ -910,10 +1084,10 @@ int read_stats(fdm_engine* e, fdm_scan_stats* out, int* status) {
     return FDM_OK;
   }
   {  // sum the partial counts behind the scan's kernels; the result lands in pinned host memory
-    const unsigned work = std::max<unsigned>(e->last_bin_blocks, unsigned(e->n_tiles));
+    const unsigned work = std::max<unsigned>(e->last_bin_blocks, e->last_upd_tiles);
     const unsigned blocks = std::min(64u, std::max(1u, (work + 4095u) / 4096u));
     hipLaunchKernelGGL(k_collect_stats, dim3(blocks), dim3(256), 0, e->stream, e->S.bin_part, e->last_bin_blocks,
-                       e->S.upd_part, unsigned(e->n_tiles), e->pack_counts, e->ingest_blocks, e->d_state,
+                       e->last_upd_part, e->last_upd_tiles, e->pack_counts, e->ingest_blocks, e->d_state,
                        int((e->scan_no - 1) & 3), e->d_stats_acc, e->h_stats_dev);
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(e->stream));
@@ -1004,6 +1178,13 @@ static int create_impl(const fdm_geometry* g, const fdm_config* cfg, const fdm_t
   }
   G.res = g->resolution;
   G.inv_res = 1.0 / G.res;  // fast-path only; the exact divide decides near cell edges
+  {  // fraction bits of the fixed-point index estimate: whatever an int32 has left beside the map size
+    int bits = 1;
+    while ((1 << bits) < std::max(G.rows, G.cols) + 2 && bits < 30) ++bits;
+    G.idx_shift = std::max(1, std::min(20, 30 - bits));
+    G.idx_pad = 0;
+    G.inv_res_k = std::ldexp(1.0, G.idx_shift) / G.res;
+  }
   G.len_x = double(G.rows) * G.res;
   G.len_y = double(G.cols) * G.res;
   G.half_x = 0.5 * G.len_x;
@@ -1028,6 +1209,9 @@ static int create_impl(const fdm_geometry* g, const fdm_config* cfg, const fdm_t
     G.s_r0 = G.s_c0 = G.o_r0 = G.o_c0 = 0;
     G.s_rows = G.o_rows = G.rows;
     G.s_cols = G.o_cols = G.cols;
+  }
+  if (const char* v = std::getenv("FDM_TILED_MIN")) {  // test switch: push every scan of at least this many points
+    e->tiled_min = unsigned(std::strtoul(v, nullptr, 10));  // through the large-scan pipeline
   }
   e->ncell = size_t(G.s_rows) * size_t(G.s_cols);
   if (e->ncell >= 0xFFFFFFFFull) {
@@ -1135,13 +1319,22 @@ void fdm_engine_destroy(fdm_engine* e) {
   if (e->d_rec) (void)hipFree(e->d_rec);
   if (e->d_tmp) (void)hipFree(e->d_tmp);
   if (e->d_layer_ptrs) (void)hipFree(e->d_layer_ptrs);
-  e->upd_alone = nullptr;
-  e->upd_fused = nullptr;
   if (e->key2[0]) (void)hipFree(e->key2[0]);
   if (e->aux2[0]) (void)hipFree(e->aux2[0]);
   if (e->key2[1]) (void)hipFree(e->key2[1]);
   if (e->aux2[1]) (void)hipFree(e->aux2[1]);
 
+  for (auto& q : e->pool) {
+    if (q.key) (void)hipFree(q.key);
+    if (q.zmax) (void)hipFree(q.zmax);
+    if (q.imax) (void)hipFree(q.imax);
+    if (q.cell) (void)hipFree(q.cell);
+    if (q.var) (void)hipFree(q.var);
+    if (q.rgb) (void)hipFree(q.rgb);
+    if (q.desc) (void)hipFree(q.desc);
+  }
+  if (e->tile_stamp32) (void)hipFree(e->tile_stamp32);
+  if (e->upd_part32) (void)hipFree(e->upd_part32);
   if (e->S.bin_part) (void)hipFree(e->S.bin_part);
   if (e->S.upd_part) (void)hipFree(e->S.upd_part);
   if (e->S.tile_stamp) (void)hipFree(e->S.tile_stamp);
@@ -1720,6 +1913,20 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
     if (value != 0 && value != 128 && value != 256 && value != 512)
       return fail(FDM_ERR_INVALID, "bin_threads must be 0 (auto), 128, 256 or 512");
     e->bin_threads = value;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "tiled") == 0) {  // large scans through per-tile record pools (1, default) or the per-cell scratch (0)
+    e->tiled = value != 0;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "tiled_min") == 0) {
+    if (value < 0) return fail(FDM_ERR_INVALID, "tiled_min: a point count");
+    e->tiled_min = unsigned(value);
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "tiled_threads") == 0) {
+    if (value != 0 && value != 256 && value != 512) return fail(FDM_ERR_INVALID, "tiled_threads must be 0 (auto), 256 or 512");
+    e->tiled_threads = value;
     return FDM_OK;
   }
   if (std::strcmp(key, "bin_variant") == 0) {

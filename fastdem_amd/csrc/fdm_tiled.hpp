@@ -1,0 +1,907 @@
+// fdm_tiled.hpp — the large-scan pipeline: per-tile observation buckets instead of per-cell atomics.
+//
+// Why (profiles/r01): the first large-scan pipeline reduced every cell through
+// memory-side atomics (k_bin4 -> key/aux scratch -> k_update).  On configs[3] that was ~240 K
+// (block, cell) pairs x 4 atomics ~ 1 M fabric operations per scan at ~26 Gop/s = the whole 39 us of
+// the bin kernel, plus a dense 8 B/cell key sweep and a 3-sector point gather in the update kernel
+// (160 MB of traffic for 52 MB of algorithmic bytes).  Nothing in this pipeline reduces through memory:
+//
+//   k_tbin   : a block of 4*THREADS consecutive points runs preprocessScan + getIndex, merges
+//              same-cell points in registers and in a per-block LDS table (as before), then SORTS its
+//              unique cells by 32x32-cell map tile in LDS and writes them as observation records —
+//              plain coalesced stores into the block's own region of a record pool.  Per (block, tile)
+//              ONE returning atomic appends a chunk descriptor {first record, count} to the tile's list
+//              (configs[3]: ~16 per block, 16 K per scan, instead of ~1 M).  A record carries
+//              everything the update needs (min z + its sigma_z^2, max z, intensity, colour), so the
+//              update kernel never looks at the scan again: the caller's arrays are dead as soon as
+//              this kernel has run.
+//   k_tupdate: one block per 32x32 tile.  It reads the tile's chunk list, folds the records into an
+//              LDS image of the tile (LDS atomics), and then walks the tile's cells in memory order:
+//              estimator step, min/max, obstacle, intensity, colour, move() strips.  Only touched
+//              cells read and write their 64 B / 128 B record; there is no per-cell scratch in memory.
+//
+// Order rules (elevation_mapping.cpp:62-92) carried through both levels without a point index:
+//   * records of one cell are ordered by pool position = (bin block, ...) = scan order of their
+//     blocks, and each block contributes at most one record per cell, so "first point wins a tie"
+//     is "lowest position wins";
+//   * the minimum is ONE 64-bit reduction word  ord(z) << 32 | order << 1 | (z is -0): the lowest z,
+//     among equals the first point — "strict z < min_z, first point wins" — and the winner's order
+//     leads to its sigma_z^2.  -0 and +0 compare equal in the reference, so every value is reduced
+//     with zeros canonicalised; for the maxima (32-bit words) the sign of the FIRST zero-valued
+//     point of a cell rides along in a separate min-reduced word.  min_z / max_z / intensity come
+//     out bit-identical to the reference's first-seen zero.
+//
+// Algorithmic bytes are unchanged: 12 B/point (+4 intensity, +4 colour), 72 / 124 B
+// per touched cell, 4 B per map cell per scan for the obstacle clear.
+#pragma once
+
+#include "fdm_kernels.hpp"
+
+namespace fdm {
+
+constexpr int kTS = 32;                 // tile edge in cells
+constexpr int kTSShift = 5;
+constexpr unsigned kTileCells = 1024u;  // kTS * kTS
+constexpr uint32_t kNoWinner = 0xFFFFFFFFu;
+constexpr uint32_t kOrdZero = 0x80000000u;  // ord(+0.0f)
+constexpr int kTbinSlotsPerThread = 4;  // k_tbin: LDS table slots per thread (2: half-size table + overflow passes; 4: one slot per point)
+constexpr int kRecBatch = 4;    // k_tupdate: records per thread whose loads are in flight together
+constexpr int kCellBatch = 2;   // ... and touched cells
+
+// flags beside the cell-in-tile number (10 bits) of a record
+constexpr uint32_t kRecNanFirst = 1u << 10;  // the cell's first point has a NaN intensity
+constexpr uint32_t kRecZZero = 1u << 11;     // some point of the cell has z == +-0 ...
+constexpr uint32_t kRecZNeg = 1u << 12;      // ... and the first such point is -0
+constexpr uint32_t kRecIZero = 1u << 13;     // the same for the intensity
+constexpr uint32_t kRecINeg = 1u << 14;
+
+// The record pool of one scan parity (bin of scan t+1 runs beside the update of scan t).
+struct TilePool {
+  unsigned long long* key;    // [cap]  ord(min z) << 32 | pos << 1 | (that z is -0)   (low word kNoWinner: no finite z)
+  uint32_t* zmax;             // [cap]  ord(max z), 0 = none
+  uint32_t* imax;             // [cap]  ord(max intensity), 0 = none (intensity scans only)
+  uint32_t* cell;             // [cap]  cell inside the tile | kRec* flags
+  float* var;                 // [cap]  sigma_z^2 of the min-z point
+  uint32_t* rgb;              // [cap]  colour of the block's last point in the cell (colour scans only)
+  unsigned long long* desc;   // [n_tiles][stride]  row of a tile: word 0 = number of chunks (put back to 0 by the update
+                              // kernel), then one word per chunk: first record | count << 32
+  unsigned stride;            // > bin blocks of the scan: a block appends at most one chunk per tile
+};
+
+struct TileGrid {
+  int tiles_r, tiles_c;  // tiles over the stored window (rows, cols)
+  unsigned n_tiles;
+};
+
+struct TileAux {           // what the update kernel keeps per tile between scans
+  uint32_t* stamp;         // [n_tiles] last scan that touched a cell of the tile
+  uint32_t* upd_part;      // [n_tiles] cells touched by the last scan (statistics)
+  float* ras_z;            // [ncell] optional capture (onScanRasterized), NaN-filled by the host
+};
+
+// value of a canonicalised ord word; `neg`: the first zero seen was -0 (only looked at for a zero)
+__device__ __forceinline__ float signed_value(uint32_t ordv, uint32_t neg) {
+  return (ordv == kOrdZero && neg) ? -0.0f : unord(ordv);
+}
+// ord with -0 folded onto +0 (they tie in every comparison of the reference)
+__device__ __forceinline__ uint32_t ord_canon(float v) { return ord(v == 0.0f ? 0.0f : v); }
+
+// point -> (tile << 10 | cell in tile) of this engine's owned window; -1 outside the (global) map,
+// -2 inside the map but owned by another engine tile (see owned_cell).  lin = storage-linear id.
+__device__ __forceinline__ int owned_tcell(float x, float y, const DevCand& cand, const GeomConst& G,
+                                           const TileGrid& TG, int& lin) {
+  int r, c;
+  lin = -1;
+  if (!cell_of(x, y, cand, G, r, c)) return -1;
+  const int lr = r - G.o_r0, lc = c - G.o_c0;
+  lin = -2;
+  if (lr < 0 || lc < 0 || lr >= G.o_rows || lc >= G.o_cols) return -2;
+  const int sr = r - G.s_r0, sc = c - G.s_c0;
+  lin = sc * G.s_rows + sr;
+  const int tile = (sc >> kTSShift) * TG.tiles_r + (sr >> kTSShift);
+  return (tile << 10) | ((sc & (kTS - 1)) << kTSShift) | (sr & (kTS - 1));
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tbin.  Dynamic LDS: kSlots-sized u32 arrays cell | zmin | widx | zmax | zs [| imax | izs | first]
+// [| last], then the compaction list (u16).
+__host__ __device__ constexpr unsigned tbin_lds_bytes(bool has_int, bool has_col, unsigned threads) {
+  return threads * unsigned(kTbinSlotsPerThread) * (20u + (has_int ? 12u : 0u) + (has_col ? 4u : 0u) + 2u);
+}
+
+template <bool HAS_INT, bool HAS_COL, int THREADS, bool LEAN>
+__device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& G, const TileGrid& TG,
+                                          DevState* __restrict__ st, const ScanInputs& I,
+                                          const Scratch& S, const TilePool& Q,
+                                          int32_t* __restrict__ cell_ids, unsigned char* lds,
+                                          const unsigned bid) {
+  float* const cap_x = LEAN ? nullptr : S.cap_x;
+  float* const cap_var = LEAN ? nullptr : S.cap_var;
+  int32_t* const ids = LEAN ? nullptr : cell_ids;
+  const bool drop_nf = LEAN ? false : P.drop_nonfinite != 0;
+  const int dbg = LEAN ? 0 : P.dbg_no_atomics;  // measurement only: leave the kernel after a phase (results are wrong)
+  constexpr int kSPT = kTbinSlotsPerThread;  // table slots per thread (4 points per thread)
+  constexpr int kPts = THREADS * 4;          // points per block = the block's region of the record pool
+  constexpr int kSlots = THREADS * kSPT;
+  constexpr int kSlotBits = (THREADS == 512 ? 9 : (THREADS == 256 ? 8 : 7)) + (kSPT == 4 ? 2 : 1);
+  static_assert((1 << kSlotBits) == kSlots && (kSPT == 2 || kSPT == 4), "block size");
+  constexpr int kWaves = THREADS / 64;
+  uint32_t* const h_cell = reinterpret_cast<uint32_t*>(lds);
+  // ord(min z) << 32 | order in block << 1 | z is -0, min-reduced: the lowest z, among equals the first point
+  unsigned long long* const h_key = reinterpret_cast<unsigned long long*>(h_cell + kSlots);
+  uint32_t* const h_zmax = h_cell + 3 * kSlots;  // ord(max z), 0 = none
+  uint32_t* const h_zs = h_zmax + kSlots;      // (order << 1 | is -0) of the first point with z == +-0
+  uint32_t* const h_imax = h_zs + kSlots;      // (HAS_INT) like zmax / zs for the intensity
+  uint32_t* const h_izs = h_imax + kSlots;
+  uint32_t* const h_first = h_izs + kSlots;    //           (order << 1 | intensity is NaN) of the first point
+  uint32_t* const h_last = h_zs + (HAS_INT ? 4 : 1) * kSlots;  // (HAS_COL) order + 1 of the last point
+  uint16_t* const s_list = reinterpret_cast<uint16_t*>(h_zs + (1 + (HAS_INT ? 3 : 0) + (HAS_COL ? 1 : 0)) * kSlots);
+  __shared__ DevCand s_cand;
+  __shared__ unsigned s_cnt[kWaves];
+  __shared__ unsigned s_wsum[kWaves];
+  __shared__ unsigned s_ovf;
+
+  const float* __restrict__ px = I.x;
+  const float* __restrict__ py = I.y;
+  const float* __restrict__ pz = I.z;
+  const float* __restrict__ pint = I.intensity;
+
+  // the point loads go out first: they are in flight while the table is initialised and
+  // thread 0 works out the post-move geometry
+  const unsigned b0 = bid * unsigned(kPts);
+  const unsigned l0 = threadIdx.x * 4u;
+  const unsigned i0 = b0 + l0;
+  float xs[4], ys[4], zs[4], vs[4];
+  if (i0 + 3 < P.n) {
+    const float4 a = *reinterpret_cast<const float4*>(px + i0);
+    const float4 b = *reinterpret_cast<const float4*>(py + i0);
+    const float4 c = *reinterpret_cast<const float4*>(pz + i0);
+    xs[0] = a.x; xs[1] = a.y; xs[2] = a.z; xs[3] = a.w;
+    ys[0] = b.x; ys[1] = b.y; ys[2] = b.z; ys[3] = b.w;
+    zs[0] = c.x; zs[1] = c.y; zs[2] = c.z; zs[3] = c.w;
+    if (HAS_INT) {
+      const float4 d = *reinterpret_cast<const float4*>(pint + i0);
+      vs[0] = d.x; vs[1] = d.y; vs[2] = d.z; vs[3] = d.w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = i0 + j < P.n;
+      xs[j] = ok ? px[i0 + j] : 0.f;
+      ys[j] = ok ? py[i0 + j] : 0.f;
+      zs[j] = ok ? pz[i0 + j] : 0.f;
+      if (HAS_INT) vs[j] = ok ? pint[i0 + j] : 0.f;
+    }
+  }
+  for (int k = threadIdx.x; k < kSlots; k += THREADS) {
+    h_cell[k] = kEmptyCell;
+    h_key[k] = kEmptyKey;
+    h_zmax[k] = 0u;
+    h_zs[k] = 0xFFFFFFFFu;
+    if (HAS_INT) { h_imax[k] = 0u; h_izs[k] = 0xFFFFFFFFu; h_first[k] = kNoIdx; }
+    if (HAS_COL) h_last[k] = 0u;
+  }
+  if (threadIdx.x == 0) s_ovf = 0u;
+  const DevCand cand = block_candidate(P, G, st, &s_cand, bid);  // contains the __syncthreads
+
+  // phase 1: all four points through the arithmetic.  Branch-lean on purpose (the first version spent as many
+  // issue slots on exec-mask bookkeeping as on arithmetic): the transforms and the fixed-point index
+  // estimate run for all four points without a branch; the reference's exact index arithmetic is one
+  // shared, rarely taken branch for the lanes whose estimate sits within 1/1024 cell of a cell edge.
+  int cells[4];
+  bool pass[4];
+  unsigned n_pass = 0, n_in = 0;
+  bool any_glob = false;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bool live = i0 + j < P.n;
+    float cvar = 0.f;
+    if (cap_var && live && P.integrate_mode) cvar = sigma_z2(P, xs[j], ys[j], zs[j]);
+    const bool exists = live && (!drop_nf || (isfinite(xs[j]) && isfinite(ys[j]) && isfinite(zs[j])));
+    pass[j] = preprocess_point(P, xs[j], ys[j], zs[j]) && exists;
+    if (cap_x && live) {
+      cap_x[i0 + j] = (S.cap_drop_nan && !pass[j]) ? __uint_as_float(0x7FC00000u) : xs[j];
+      S.cap_y[i0 + j] = ys[j]; S.cap_z[i0 + j] = zs[j];
+      if (cap_var) cap_var[i0 + j] = cvar;
+    }
+    n_pass += pass[j] ? 1u : 0u;
+  }
+  {
+    const bool any_start = cand.sr != 0 || cand.sc != 0;
+    int kr[4], kc[4];
+    bool sure_r[4], sure_c[4], inside[4];
+    bool unsure = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      kr[j] = axis_fast(double(xs[j]), cand.px, G.half_x, G.inv_res_k, G.idx_shift, G.rows, sure_r[j]);
+      kc[j] = axis_fast(double(ys[j]), cand.py, G.half_y, G.inv_res_k, G.idx_shift, G.cols, sure_c[j]);
+      inside[j] = pass[j];
+      unsure = unsure || (pass[j] && !(sure_r[j] && sure_c[j]));
+    }
+    if (__ballot(unsure)) {  // wave-uniform; a few percent of the wavefronts
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (pass[j] && !sure_r[j]) inside[j] = axis_exact(double(xs[j]), cand.px, G.half_x, G.len_x, G.res, kr[j]);
+        if (inside[j] && !sure_c[j]) inside[j] = axis_exact(double(ys[j]), cand.py, G.half_y, G.len_y, G.res, kc[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int r = kr[j], c = kc[j];
+      const bool okr = axis_wrap(r, cand.sr, any_start, G.rows);  // (both axes are evaluated, as getIndex does)
+      const bool okc = axis_wrap(c, cand.sc, any_start, G.cols);
+      const bool in_map = inside[j] && okr && okc;
+      const int lr = r - G.o_r0, lc = c - G.o_c0;
+      const bool owned = in_map && lr >= 0 && lc >= 0 && lr < G.o_rows && lc < G.o_cols;
+      const int sr = r - G.s_r0, sc = c - G.s_c0;
+      const int tile = (sc >> kTSShift) * TG.tiles_r + (sr >> kTSShift);
+      const int tcell = (tile << 10) | ((sc & (kTS - 1)) << kTSShift) | (sr & (kTS - 1));
+      cells[j] = owned ? tcell : (in_map ? -2 : -1);
+      n_in += owned ? 1u : 0u;
+      any_glob = any_glob || in_map;
+      if (ids && i0 + j < P.n)
+        ids[i0 + j] = owned ? sc * G.s_rows + sr : (!pass[j] ? -1 : (in_map ? -3 : -2));
+    }
+  }
+  if (dbg == 2) {
+    S.bin_part[bid] = (cells[0] + cells[1] + cells[2] + cells[3] == 0x7FFFFFF1) ? 1ull : 0x100000001ull;
+    return;
+  }
+
+  unsigned v = n_pass | (n_in << 16);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = v;
+  if (__ballot(any_glob) && (threadIdx.x & 63) == 0) st->flags[P.slot].any_inside = 1u;
+  bool zero_here = false;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) zero_here = zero_here || (cells[j] >= 0 && (zs[j] == 0.0f || (HAS_INT && vs[j] == 0.0f)));
+  const bool zero_seen = __ballot(zero_here) != 0ull;  // wave-uniform: some lane holds a +-0 value (rare outside synthetic data)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  // The table has kSlots = kSPT * THREADS slots for 4 * THREADS points.  With kSPT < 4 a block whose points
+  // fall into more than kSlots distinct cells cannot be folded in one go: pass 0 (everything) then reports
+  // an overflow and the block is redone as two halves of its threads (passes 1 and 2: at most
+  // 2 * THREADS points each), each with its own flush.  Pool positions stay in scan order.
+  unsigned rec_base = 0;  // records written by the block's earlier passes
+#pragma unroll 1
+  for (int pass = 0; pass < 3; ++pass) {
+    if (pass > 0) {
+      for (int k = threadIdx.x; k < kSlots; k += THREADS) {
+        h_cell[k] = kEmptyCell;
+        h_key[k] = kEmptyKey;
+        h_zmax[k] = 0u;
+        h_zs[k] = 0xFFFFFFFFu;
+        if (HAS_INT) { h_imax[k] = 0u; h_izs[k] = 0xFFFFFFFFu; h_first[k] = kNoIdx; }
+        if (HAS_COL) h_last[k] = 0u;
+      }
+      if (threadIdx.x == 0) s_ovf = 0u;
+      __syncthreads();
+    }
+    // phase 2: merge runs of equal cell in registers, fold each run into the block's LDS table
+    if (pass == 0 || (threadIdx.x >= THREADS / 2) == (pass == 2)) {
+      int run_cell = -1;
+      unsigned long long run_key = kEmptyKey;
+      uint32_t run_zmx = 0u, run_zs = 0xFFFFFFFFu, run_imx = 0u, run_izs = 0xFFFFFFFFu, run_fst = kNoIdx, run_lst = 0u;
+      auto fold_run = [&]() {
+        if (run_cell < 0) return;
+        // (multiplicative hash: the low bits of tile << 10 | cell repeat from tile to tile along a wedge, and
+        // linear probing through such clusters cost 49 of the first version's 65 us)
+        uint32_t h = (uint32_t(run_cell) * 2654435761u) >> (32 - kSlotBits);
+        unsigned tries = 0;
+        while (true) {  // claim-or-find in ONE LDS operation per probe
+          const uint32_t prev = atomicCAS(&h_cell[h], kEmptyCell, uint32_t(run_cell));
+          if (prev == kEmptyCell || prev == uint32_t(run_cell)) break;
+          h = (h + 1) & (kSlots - 1);
+          if (kSPT < 4 && ++tries >= unsigned(kSlots)) { s_ovf = 1u; return; }  // table full
+        }
+        // (no-op operands instead of branches: max with 0, min with all-ones)
+        atomicMin(&h_key[h], run_key);
+        atomicMax(&h_zmax[h], run_zmx);
+        if (HAS_INT) {
+          atomicMax(&h_imax[h], run_imx);
+          atomicMin(&h_first[h], run_fst);
+        }
+        if (HAS_COL) atomicMax(&h_last[h], run_lst);
+        if (zero_seen) {
+          atomicMin(&h_zs[h], run_zs);
+          if (HAS_INT) atomicMin(&h_izs[h], run_izs);
+        }
+      };
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (cells[j] < 0) continue;
+        const uint32_t li = l0 + j;  // order inside the block
+        const float z = zs[j];
+        const uint32_t zneg = __float_as_uint(z) == 0x80000000u ? 1u : 0u;
+        const uint32_t oz = ord_canon(z);
+        // strict "z < min_z" from FLT_MAX / "z > max_z" from lowest(): NaN, FLT_MAX and beyond never win
+        const unsigned long long key = (z < kFltMax) ? ((unsigned long long)oz << 32) | (li << 1) | zneg
+                                                     : ((unsigned long long)ord(kFltMax) << 32) | kNoWinner;
+        const uint32_t zmx = (z > -kFltMax) ? oz : 0u;
+        const uint32_t zz = (z == 0.0f) ? ((li << 1) | zneg) : 0xFFFFFFFFu;
+        uint32_t imx = 0u, iz = 0xFFFFFFFFu;
+        bool vnan = false;
+        if (HAS_INT) {
+          const float vv = vs[j];
+          vnan = isnan(vv);
+          imx = vnan ? 0u : ord_canon(vv);
+          if (vv == 0.0f) iz = (li << 1) | (__float_as_uint(vv) == 0x80000000u ? 1u : 0u);
+        }
+        if (cells[j] != run_cell) {
+          fold_run();
+          run_cell = cells[j];
+          run_key = key;
+          run_zmx = zmx;
+          run_zs = zz;
+          run_imx = imx;
+          run_izs = iz;
+          run_fst = (li << 1) | (vnan ? 1u : 0u);
+        } else {
+          run_key = key < run_key ? key : run_key;
+          run_zmx = zmx > run_zmx ? zmx : run_zmx;
+          run_zs = zz < run_zs ? zz : run_zs;
+          run_imx = imx > run_imx ? imx : run_imx;
+          run_izs = iz < run_izs ? iz : run_izs;
+        }
+        run_lst = li + 1u;
+      }
+      fold_run();
+    }
+    __syncthreads();  // every run of the pass is in the table
+    if (threadIdx.x == 0 && pass == 0) {
+      unsigned np = 0, ni = 0;
+      for (int w = 0; w < kWaves; ++w) { np += s_cnt[w] & 0xFFFFu; ni += s_cnt[w] >> 16; }
+      if (np) st->flags[P.slot].any_pass = 1u;
+      S.bin_part[bid] = (unsigned long long)np | ((unsigned long long)ni << 32);
+    }
+    if (kSPT < 4 && pass == 0 && s_ovf != 0u) continue;  // block-uniform
+
+    // ---- flush: the pass's unique cells become observation records, grouped by map tile ----
+    // (a) compact the occupied slots: record j of the pass is slot s_list[j]
+    unsigned n_rec;
+    {
+      uint32_t cc[kSPT];
+#pragma unroll
+      for (int q = 0; q < kSPT; ++q) cc[q] = h_cell[threadIdx.x * kSPT + q];
+      unsigned mine = 0;
+#pragma unroll
+      for (int q = 0; q < kSPT; ++q) mine += cc[q] != kEmptyCell ? 1u : 0u;
+      unsigned inc = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+      }
+      if (lane == 63) s_wsum[wave] = inc;
+      __syncthreads();
+      unsigned base = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) {
+        const unsigned ws = s_wsum[w];
+        base += w < wave ? ws : 0u;
+        total += ws;
+      }
+      n_rec = total;
+      unsigned p = base + inc - mine;
+#pragma unroll
+      for (int q = 0; q < kSPT; ++q)
+        if (cc[q] != kEmptyCell) s_list[p++] = uint16_t(threadIdx.x * kSPT + q);
+    }
+    __syncthreads();
+    // (b) record j = threadIdx.x + q * THREADS leaves the table for registers; its sigma_z^2 is evaluated
+    // from the winning point (re-read from L2: the block loaded it a few microseconds ago)
+    uint32_t c_[kSPT], kz_[kSPT], kw_[kSPT], zm_[kSPT], im_[kSPT], fl_[kSPT], col_[kSPT];
+    float var_[kSPT];
+#pragma unroll
+    for (int q = 0; q < kSPT; ++q) {
+      c_[q] = kEmptyCell; kz_[q] = 0u; kw_[q] = kNoWinner; zm_[q] = 0u; im_[q] = 0u; var_[q] = 0.0f; fl_[q] = 0u; col_[q] = 0u;
+      if (unsigned(q * THREADS) >= n_rec) continue;  // block-uniform
+      const unsigned j = threadIdx.x + unsigned(q * THREADS);
+      if (j >= n_rec) continue;
+      const unsigned slot = s_list[j];
+      c_[q] = h_cell[slot];  // tile << 10 | cell in tile
+      const unsigned long long k64 = h_key[slot];
+      kz_[q] = uint32_t(k64 >> 32);
+      kw_[q] = uint32_t(k64);
+      zm_[q] = h_zmax[slot];
+      const uint32_t zsw = h_zs[slot];
+      uint32_t fl = 0u;
+      if (zsw != 0xFFFFFFFFu) fl |= kRecZZero | ((zsw & 1u) ? kRecZNeg : 0u);
+      if (HAS_INT) {
+        im_[q] = h_imax[slot];
+        const uint32_t izw = h_izs[slot];
+        if (izw != 0xFFFFFFFFu) fl |= kRecIZero | ((izw & 1u) ? kRecINeg : 0u);
+        if (h_first[slot] & 1u) fl |= kRecNanFirst;
+      }
+      fl_[q] = fl;
+      if (HAS_COL) col_[q] = I.rgb[b0 + h_last[slot] - 1u];
+      const uint32_t wl = kw_[q];           // winner: order << 1 | sign, or kNoWinner
+      if (wl != kNoWinner) {                // (else: CellObservation default 0, elevation_mapping.hpp:26-34)
+        const unsigned gi = b0 + (wl >> 1);
+        if (P.has_var) var_[q] = I.var[gi];
+        else if (P.integrate_mode) var_[q] = sigma_z2(P, px[gi], py[gi], pz[gi]);
+      }
+    }
+    __syncthreads();
+    // (c) the table's memory becomes the block's TILE table: tile id -> how many of the pass's cells
+    uint32_t* const t_tile = h_cell + kSlots;      // [kSlots]
+    uint32_t* const t_cnt = h_cell + 2 * kSlots;   // [kSlots]
+    uint32_t* const t_off = h_zmax;                // [kSlots]
+    for (int k = threadIdx.x; k < kSlots; k += THREADS) {
+      t_tile[k] = kEmptyCell;
+      t_cnt[k] = 0u;
+    }
+    __syncthreads();
+    uint32_t th_[kSPT], rk_[kSPT];
+#pragma unroll
+    for (int q = 0; q < kSPT; ++q) {
+      th_[q] = 0u; rk_[q] = 0u;
+      if (c_[q] == kEmptyCell) continue;
+      const uint32_t tile = c_[q] >> 10;
+      uint32_t h = (tile * 2654435761u) >> (32 - kSlotBits);
+      while (true) {  // (at most n_rec <= kSlots distinct tiles: always terminates)
+        const uint32_t prev = atomicCAS(&t_tile[h], kEmptyCell, tile);
+        if (prev == kEmptyCell || prev == tile) break;
+        h = (h + 1) & (kSlots - 1);
+      }
+      th_[q] = h;
+      rk_[q] = atomicAdd(&t_cnt[h], 1u);
+    }
+    __syncthreads();
+    // (d) exclusive scan of the tile counts; thread t owns entries t, t + THREADS, ... (neighbouring
+    // tiles of a wedge go to different threads), appends one chunk per occupied entry to the tile's row
+    {
+      uint32_t nn[kSPT], tt[kSPT];
+      unsigned mine = 0;
+#pragma unroll
+      for (int k = 0; k < kSPT; ++k) {
+        nn[k] = t_cnt[threadIdx.x + k * THREADS];
+        tt[k] = t_tile[threadIdx.x + k * THREADS];
+        mine += nn[k];
+      }
+      unsigned slot[kSPT];
+#pragma unroll
+      for (int k = 0; k < kSPT; ++k) {  // the returning atomics leave together, ahead of the scan
+        slot[k] = 0u;
+        if (nn[k])
+          slot[k] = atomicAdd(reinterpret_cast<unsigned*>(Q.desc + size_t(tt[k]) * Q.stride), 1u);
+      }
+      unsigned inc = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+      }
+      __syncthreads();  // ((a)'s readers of s_wsum are long done)
+      if (lane == 63) s_wsum[wave] = inc;
+      __syncthreads();
+      unsigned p = inc - mine;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) p += w < wave ? s_wsum[w] : 0u;
+#pragma unroll
+      for (int k = 0; k < kSPT; ++k) {
+        if (nn[k]) {
+          t_off[threadIdx.x + k * THREADS] = p;
+          Q.desc[size_t(tt[k]) * Q.stride + 1u + slot[k]] =
+              (unsigned long long)(b0 + rec_base + p) | ((unsigned long long)nn[k] << 32);
+          p += nn[k];
+        }
+      }
+    }
+    __syncthreads();
+    // (e) the records, grouped by tile, into the block's own region of the pool
+#pragma unroll
+    for (int q = 0; q < kSPT; ++q) {
+      if (c_[q] == kEmptyCell) continue;
+      const uint32_t pos = b0 + rec_base + t_off[th_[q]] + rk_[q];
+      const uint32_t wl = kw_[q];
+      Q.key[pos] = ((unsigned long long)kz_[q] << 32) | (wl != kNoWinner ? (pos << 1) | (wl & 1u) : kNoWinner);
+      Q.zmax[pos] = zm_[q];
+      Q.var[pos] = var_[q];
+      if (HAS_INT) Q.imax[pos] = im_[q];
+      Q.cell[pos] = (c_[q] & 1023u) | fl_[q];
+      if (HAS_COL) Q.rgb[pos] = col_[q];
+    }
+    if (kSPT == 4 || pass == 0 || pass == 2) break;
+    rec_base += n_rec;
+    __syncthreads();  // the tile table is re-initialised by the next pass
+  }
+}
+
+template <bool HAS_INT, bool HAS_COL, int THREADS, bool LEAN>
+__global__ __launch_bounds__(THREADS) void k_tbin(const ScanParams P, const GeomConst G, const TileGrid TG,
+                                                  DevState* __restrict__ st, const ScanInputs I,
+                                                  const Scratch S, const TilePool Q,
+                                                  int32_t* __restrict__ cell_ids) {
+  extern __shared__ __align__(16) unsigned char dyn_lds[];
+  tbin_body<HAS_INT, HAS_COL, THREADS, LEAN>(P, G, TG, st, I, S, Q, cell_ids, dyn_lds, blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tupdate — 256 threads per tile.  LDS image of the tile (dynamic shared memory, per 256-thread
+// group), 1024-entry arrays: key u64 | zmax | zs | descriptors u64[256] | offsets u32[260]
+// [| imax | izs | first] [| last].
+__host__ __device__ constexpr unsigned tile_lds_bytes(bool has_int, bool has_col) {
+  return 1024u * (16u + (has_int ? 12u : 0u) + (has_col ? 4u : 0u)) + 260u * 4u + 256u * 8u;
+}
+
+struct TileCtx {
+  bool applied, do_update, strips;
+  unsigned ob_scan;
+  DevGeom E;
+  DevCand C;
+};
+
+__device__ __forceinline__ void make_tile_ctx(const ScanParams& P, DevState* __restrict__ st, TileCtx& u,
+                                              bool committer) {
+  const int slot = P.slot;
+  const bool any_pass = st->flags[slot].any_pass != 0u;
+  u.do_update = st->flags[slot].any_inside != 0u;
+  u.applied = P.do_move && (!P.gate_on_filter || any_pass);
+  u.ob_scan = st->obst[slot].scan;
+  u.E = st->geom[slot];
+  u.C = st->cand[slot];
+  if (committer) {  // commit geometry + ring bookkeeping (see make_ctx)
+    const int nxt = (slot + 1) & 3, nn = (slot + 2) & 3;
+    DevGeom g = u.E;
+    if (u.applied) { g.px = u.C.px; g.py = u.C.py; g.sr = u.C.sr; g.sc = u.C.sc; }
+    st->geom[nxt] = g;
+    st->obst[nxt].scan = u.do_update ? P.scan_no : u.ob_scan;
+    st->flags[nn].any_pass = 0u;
+    st->flags[nn].any_inside = 0u;
+    st->flags[nn].ray_any = 0u;
+    if (u.do_update) {
+      if (P.has_intensity && st->vis_int == 0u) st->vis_int = 3u * P.scan_no + 2u;
+      if (P.has_color && st->vis_col == 0u) st->vis_col = 3u * P.scan_no + 2u;
+    }
+  }
+  u.strips = u.applied && (u.C.shr != 0 || u.C.shc != 0);
+}
+
+// One tile by one 256-thread group (`lt` = thread inside the group).  Block-uniform control flow
+// around the barriers: `n_chunks_max` is the largest chunk count among the block's groups.
+// `d0` = word `lt` of the tile's descriptor row, already loaded by the caller (word 0 is the count).
+template <typename POLICY, int BLOCK>
+__device__ __forceinline__ void tupdate_tile(
+    const ScanParams& P, const GeomConst& G, const TileGrid& TG, const TileCtx& u,
+    const typename POLICY::Layers& L, float* const* __restrict__ all_layers, int n_layers,
+    const TilePool& Q, const TileAux& A, unsigned char* lds, const unsigned tile, const bool tile_ok,
+    const unsigned n_chunks, const unsigned n_chunks_max, const unsigned long long d0, const bool obst_tile,
+    const unsigned lt) {
+  const float nanv = __uint_as_float(0x7FC00000u);
+  const bool has_int = P.has_intensity != 0, has_col = P.has_color != 0;
+  unsigned long long* const s_key = reinterpret_cast<unsigned long long*>(lds);  // min of the records' keys
+  uint32_t* const s_zmax = reinterpret_cast<uint32_t*>(s_key + 1024);
+  uint32_t* const s_zs = s_zmax + 1024;     // (pos << 1 | is -0) of the first record holding a zero z
+  unsigned long long* const s_desc = reinterpret_cast<unsigned long long*>(s_zs + 1024);  // [256]
+  uint32_t* const s_off = reinterpret_cast<uint32_t*>(s_desc + 256);                      // [260]
+  uint32_t* const s_imax = s_off + 260;     // (intensity scans)
+  uint32_t* const s_izs = s_imax + 1024;
+  uint32_t* const s_first = s_izs + 1024;
+  uint32_t* const s_last = s_off + 260 + (has_int ? 3072 : 0);  // (colour scans)
+  const unsigned long long* const row = Q.desc + size_t(tile_ok ? tile : 0u) * Q.stride;
+
+  if (P.dbg_upd == 1) {
+    if (d0 == 0x7FFFFFF1ull) A.upd_part[0] = 1u;
+    if (lt == 0 && tile_ok && n_chunks) Q.desc[size_t(tile) * Q.stride] = 0ull;
+    return;
+  }
+  if (n_chunks_max) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned k = lt + q * 256u;
+      s_key[k] = kEmptyKey;
+      s_zmax[k] = 0u;
+      s_zs[k] = 0xFFFFFFFFu;
+      if (has_int) { s_imax[k] = 0u; s_izs[k] = 0xFFFFFFFFu; s_first[k] = kNoIdx; }
+      if (has_col) s_last[k] = 0u;
+    }
+    // ---- fold the tile's records into the LDS image, 256 row words (255 chunks) at a time ----
+    for (unsigned c0 = 0; c0 <= n_chunks_max; c0 += 256u) {
+      unsigned long long d = 0ull;
+      if (c0 == 0u) d = lt ? d0 : 0ull;                      // (word 0 is the count)
+      else if (c0 + lt <= n_chunks) d = row[c0 + lt];
+      if (c0 + lt > n_chunks) d = 0ull;                      // beyond the list: whatever an earlier scan left
+      const unsigned cnt = unsigned(d >> 32);
+      // inclusive scan of the chunk sizes over the group's four wavefronts
+      unsigned inc = cnt;
+      const unsigned lane = lt & 63u;
+#pragma unroll
+      for (int dd = 1; dd < 64; dd <<= 1) {
+        const unsigned o = __shfl_up(inc, dd);
+        if (lane >= unsigned(dd)) inc += o;
+      }
+      __syncthreads();  // (the previous batch's readers of s_off / s_desc are done)
+      if (lane == 63u) s_off[256u + (lt >> 6)] = inc;
+      __syncthreads();
+      unsigned base = 0;
+      for (unsigned w = 0; w < (lt >> 6); ++w) base += s_off[256u + w];
+      s_off[lt] = base + inc - cnt;  // exclusive
+      s_desc[lt] = d;
+      __syncthreads();
+      const unsigned total = s_off[256u] + s_off[257u] + s_off[258u] + s_off[259u];
+      // kRecBatch records per thread and pass: all their loads are in flight before the first LDS atomic
+      for (unsigned r0 = lt; r0 < total; r0 += 256u * kRecBatch) {
+        unsigned pos_[kRecBatch];
+        uint32_t cw_[kRecBatch], zm_[kRecBatch], im_[kRecBatch];
+        unsigned long long k_[kRecBatch];
+#pragma unroll
+        for (int b = 0; b < kRecBatch; ++b) {
+          const unsigned r = r0 + unsigned(b) * 256u;
+          pos_[b] = 0xFFFFFFFFu; cw_[b] = 0u; zm_[b] = 0u; im_[b] = 0u; k_[b] = 0ull;
+          if (r >= total) continue;
+          // which chunk holds record r: the last one whose offset is <= r (real chunks are never empty;
+          // the batch's unused lanes sit at offset == total, its leading count word at offset 0 with
+          // size 0 — the search takes the LAST lane with offset <= r, never that one)
+          unsigned lo = 0, hi = 255u;
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const unsigned mid = (lo + hi + 1u) >> 1;
+            const bool le = s_off[mid] <= r;
+            lo = le ? mid : lo;
+            hi = le ? hi : mid - 1u;
+          }
+          const unsigned pos = unsigned(s_desc[lo]) + (r - s_off[lo]);
+          pos_[b] = pos;
+          cw_[b] = Q.cell[pos];
+          k_[b] = Q.key[pos];
+          zm_[b] = Q.zmax[pos];
+          if (has_int) im_[b] = Q.imax[pos];
+        }
+#pragma unroll
+        for (int b = 0; b < kRecBatch; ++b) {
+          if (pos_[b] == 0xFFFFFFFFu) continue;
+          const unsigned pos = pos_[b];
+          const uint32_t cw = cw_[b], lc = cw & 1023u;
+          atomicMin(&s_key[lc], k_[b]);
+          if (zm_[b]) atomicMax(&s_zmax[lc], zm_[b]);
+          if (cw & kRecZZero) atomicMin(&s_zs[lc], (pos << 1) | ((cw & kRecZNeg) ? 1u : 0u));
+          if (has_int) {
+            if (im_[b]) atomicMax(&s_imax[lc], im_[b]);
+            if (cw & kRecIZero) atomicMin(&s_izs[lc], (pos << 1) | ((cw & kRecINeg) ? 1u : 0u));
+            atomicMin(&s_first[lc], (pos << 1) | ((cw & kRecNanFirst) ? 1u : 0u));
+          }
+          if (has_col) atomicMax(&s_last[lc], pos + 1u);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (P.dbg_upd == 2) {
+    if (lt == 0 && tile_ok && n_chunks) Q.desc[size_t(tile) * Q.stride] = 0ull;
+    return;  // measurement only (block-uniform)
+  }
+  // ---- the tile's cells.  Untouched ones (most) only ever need stores — the obstacle clear, the strips
+  // move() vacates — and are walked in memory order, four per thread (a wavefront = two columns x 32
+  // rows).  The touched ones are compacted into a list first, so that each is one thread's only cell and
+  // all their record / sigma loads are ONE round trip instead of four dependent ones. ----
+  const unsigned tr = tile % unsigned(TG.tiles_r), tc = tile / unsigned(TG.tiles_r);
+  uint16_t* const s_tlist = reinterpret_cast<uint16_t*>(s_desc);  // [1024] (the descriptors are consumed)
+  const bool work = tile_ok && (n_chunks || obst_tile || u.strips);
+  unsigned n_touched = 0;  // of the whole tile (group-uniform)
+  if (n_chunks_max) {      // block-uniform: barriers inside
+    unsigned long long tm[4];
+    unsigned mine = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned lc = lt + unsigned(q) * 256u;
+      const bool t = work && n_chunks && u.do_update && s_key[lc] != kEmptyKey &&
+                     int(tr * kTS + (lc & 31u)) < G.s_rows && int(tc * kTS + (lc >> 5)) < G.s_cols;
+      tm[q] = __ballot(t);
+      mine += unsigned(__popcll(tm[q]));  // (wave total)
+    }
+    if ((lt & 63u) == 0u) s_off[256u + (lt >> 6)] = mine;
+    __syncthreads();
+    unsigned base = 0;
+    for (unsigned w = 0; w < (lt >> 6); ++w) base += s_off[256u + w];
+    n_touched = s_off[256u] + s_off[257u] + s_off[258u] + s_off[259u];
+    const unsigned long long below = (1ull << (lt & 63u)) - 1ull;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if ((tm[q] >> (lt & 63u)) & 1ull) s_tlist[base + unsigned(__popcll(tm[q] & below))] = uint16_t(lt + unsigned(q) * 256u);
+      base += unsigned(__popcll(tm[q]));
+    }
+    __syncthreads();
+  }
+  if (work) {
+    // touched cells: one per thread (kCellBatch per pass when the tile holds more than 256)
+    for (unsigned j0 = lt; j0 < n_touched; j0 += 256u * kCellBatch) {
+      unsigned o_[kCellBatch];
+      bool on_[kCellBatch], strip_[kCellBatch];
+      unsigned long long key_[kCellBatch];
+      uint32_t zm_[kCellBatch], zsw_[kCellBatch], im_[kCellBatch], izw_[kCellBatch], fst_[kCellBatch], rgb_[kCellBatch];
+      float var_[kCellBatch], sint_[kCellBatch];
+      typename POLICY::State stt_[kCellBatch];
+#pragma unroll
+      for (int b = 0; b < kCellBatch; ++b) {
+        const unsigned j = j0 + unsigned(b) * 256u;
+        on_[b] = j < n_touched;
+        o_[b] = 0u; strip_[b] = false; key_[b] = kEmptyKey; zm_[b] = 0u; zsw_[b] = 0u; im_[b] = 0u; izw_[b] = 0u;
+        fst_[b] = 0u; rgb_[b] = 0u; var_[b] = 0.0f; sint_[b] = nanv;  // (CellObservation defaults: var 0)
+        if (!on_[b]) continue;
+        const unsigned lc = s_tlist[j];
+        const int sr = int(tr * kTS + (lc & 31u)), sc = int(tc * kTS + (lc >> 5));
+        o_[b] = unsigned(sc) * unsigned(G.s_rows) + unsigned(sr);
+        strip_[b] = u.strips && (in_cleared_strip(sr + G.s_r0, u.E.sr, u.C.shr, G.rows) ||
+                                 in_cleared_strip(sc + G.s_c0, u.E.sc, u.C.shc, G.cols));
+        key_[b] = s_key[lc];
+        zm_[b] = s_zmax[lc];
+        zsw_[b] = s_zs[lc];
+        if (has_int) { im_[b] = s_imax[lc]; izw_[b] = s_izs[lc]; fst_[b] = s_first[lc]; }
+        const uint32_t wl = uint32_t(key_[b]);
+        if (wl != kNoWinner) var_[b] = Q.var[wl >> 1];
+        if (has_col) rgb_[b] = Q.rgb[s_last[lc] - 1u];
+        if (strip_[b]) {
+          POLICY::set_nan(stt_[b]);
+        } else {
+          POLICY::load(L, o_[b], stt_[b]);
+          if (has_int) sint_[b] = L.intensity[o_[b]];
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < kCellBatch; ++b) {
+        if (!on_[b]) continue;
+        const unsigned o = o_[b];
+        if (strip_[b]) {  // NaN in EVERY layer (GridMap::move); the estimator's record is rewritten below
+          for (int l0 = 0; l0 < n_layers; l0 += 8) {
+            float* p[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) p[k] = all_layers[min(l0 + k, n_layers - 1)];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+              if (l0 + k < n_layers) p[k][o] = nanv;
+          }
+          POLICY::clear_cell(L, o);
+        }
+        const uint32_t wl = uint32_t(key_[b]);
+        const float min_z = wl != kNoWinner ? signed_value(uint32_t(key_[b] >> 32), wl & 1u) : kFltMax;
+        const float max_z = zm_[b] ? signed_value(zm_[b], zsw_[b] & 1u) : -kFltMax;
+        if (A.ras_z) A.ras_z[o] = min_z;
+        POLICY::update(L, o, stt_[b], min_z, var_[b], max_z);
+        L.obstacle[o] = (max_z > min_z) ? max_z : nanv;
+        if (has_int) {
+          const float obs = (fst_[b] & 1u) ? nanv  // first point NaN -> stays NaN (elevation_mapping.cpp:73-79)
+                                           : signed_value(im_[b], izw_[b] & 1u);
+          if (isnan(sint_[b]) || obs > sint_[b]) L.intensity[o] = obs;
+        }
+        if (has_col) reinterpret_cast<uint32_t*>(L.color)[o] = rgb_[b] & 0x00FFFFFFu;
+      }
+    }
+    // untouched cells: stores only
+    if (obst_tile || u.strips) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned lc = lt + unsigned(q) * 256u;
+        const int sr = int(tr * kTS + (lc & 31u)), sc = int(tc * kTS + (lc >> 5));
+        if (sr >= G.s_rows || sc >= G.s_cols) continue;
+        if (n_chunks && u.do_update && s_key[lc] != kEmptyKey) continue;  // touched: done above
+        const unsigned o = unsigned(sc) * unsigned(G.s_rows) + unsigned(sr);
+        bool in_strip = false;
+        if (u.strips) {
+          in_strip = in_cleared_strip(sr + G.s_r0, u.E.sr, u.C.shr, G.rows) ||
+                     in_cleared_strip(sc + G.s_c0, u.E.sc, u.C.shc, G.cols);
+          if (in_strip) {
+            for (int l0 = 0; l0 < n_layers; l0 += 8) {
+              float* p[8];
+#pragma unroll
+              for (int k = 0; k < 8; ++k) p[k] = all_layers[min(l0 + k, n_layers - 1)];
+#pragma unroll
+              for (int k = 0; k < 8; ++k)
+                if (l0 + k < n_layers) p[k][o] = nanv;
+            }
+            POLICY::clear_cell(L, o);
+          }
+        }
+        if (obst_tile && !in_strip) L.obstacle[o] = nanv;  // map_.clear(obstacle), elevation_mapping.cpp:144-146
+      }
+    }
+  }
+  // bookkeeping: the chunk list is consumed, the tile remembers who touched it last
+  if (lt == 0 && tile_ok) {
+    A.upd_part[tile] = n_touched;
+    if (n_chunks) {
+      Q.desc[size_t(tile) * Q.stride] = 0ull;
+      if (u.do_update) A.stamp[tile] = P.scan_no;
+    }
+  }
+}
+
+// A block of BLOCK threads = BLOCK/256 groups; every group looks after `span` consecutive tiles
+// (span = 1 on maps whose tile count fills the chip by itself — the group then reads its tile's whole
+// descriptor row, count included, in ONE round trip — and 32 on very large maps where nearly every tile
+// is idle: the group's first wavefront reads the 32 chunk counts / stamps in one round trip and only the
+// live tiles are visited).
+template <typename POLICY, int BLOCK>
+__device__ __forceinline__ void tupdate_body(
+    const ScanParams& P, const GeomConst& G, const TileGrid& TG, DevState* __restrict__ st,
+    const typename POLICY::Layers& L, float* const* __restrict__ all_layers, int n_layers,
+    const TilePool& Q, const TileAux& A, const unsigned span, unsigned char* dyn_lds, const unsigned bid) {
+  constexpr unsigned kGroups = unsigned(BLOCK) / 256u;
+  __shared__ unsigned long long s_live[kGroups], s_ob[kGroups];
+  __shared__ unsigned s_nch[kGroups][64];
+  const unsigned g = threadIdx.x >> 8, lt = threadIdx.x & 255u;
+  unsigned char* const lds = dyn_lds + size_t(g) * tile_lds_bytes(P.has_intensity != 0, P.has_color != 0);
+  const unsigned first = (bid * kGroups + g) * span;
+
+  // round trip 1: the tile's descriptor row (span 1) or the chunk counts of the group's tiles, the
+  // stamps, and the scan context
+  unsigned long long d0 = 0ull;
+  if (span == 1u && first < TG.n_tiles && lt < Q.stride) d0 = Q.desc[size_t(first) * Q.stride + lt];
+  TileCtx u;
+  make_tile_ctx(P, st, u, bid == 0 && threadIdx.x == 0);
+  if (lt < 64u) {
+    bool live = false, ob = false;
+    unsigned nch = 0;
+    if (lt < span) {
+      const unsigned tile = first + lt;
+      if (tile < TG.n_tiles) {
+        nch = span == 1u ? unsigned(d0) : unsigned(Q.desc[size_t(tile) * Q.stride]);
+        const unsigned stamp = A.stamp[tile];
+        ob = u.do_update && (nch != 0u || stamp == u.ob_scan);
+        live = nch != 0u || u.strips || ob;
+        if (!live) A.upd_part[tile] = 0u;
+      }
+      s_nch[g][lt] = nch;
+    }
+    const unsigned long long m = __ballot(live), mo = __ballot(ob);
+    if (lt == 0) { s_live[g] = m; s_ob[g] = mo; }
+  }
+  __syncthreads();
+  // block-uniform walk over the union of the groups' live slots
+  unsigned long long any = 0ull;
+#pragma unroll
+  for (unsigned k = 0; k < kGroups; ++k) any |= s_live[k];
+  while (any) {
+    const unsigned q = unsigned(__ffsll((long long)any)) - 1u;
+    any &= any - 1ull;
+    const bool mine = (s_live[g] >> q) & 1ull;
+    const unsigned tile = first + q;
+    const unsigned nch = mine ? s_nch[g][q] : 0u;
+    unsigned nmax = 0u;  // the block's groups walk the barriers of tupdate_tile together
+#pragma unroll
+    for (unsigned k = 0; k < kGroups; ++k) {
+      const unsigned nk = ((s_live[k] >> q) & 1ull) ? s_nch[k][q] : 0u;
+      nmax = nk > nmax ? nk : nmax;
+    }
+    unsigned long long dq = d0;
+    if (span != 1u) {
+      dq = 0ull;
+      if (mine && lt <= nch && lt < Q.stride) dq = Q.desc[size_t(tile) * Q.stride + lt];
+    }
+    const bool obst_tile = mine && ((s_ob[g] >> q) & 1ull);
+    tupdate_tile<POLICY, BLOCK>(P, G, TG, u, L, all_layers, n_layers, Q, A, lds, tile,
+                                mine && tile < TG.n_tiles, nch, nmax, dq, obst_tile, lt);
+    __syncthreads();
+  }
+}
+
+template <typename POLICY>
+__global__ __launch_bounds__(256) void k_tupdate(
+    const ScanParams P, const GeomConst G, const TileGrid TG, DevState* __restrict__ st,
+    const typename POLICY::Layers L, float* const* __restrict__ all_layers, int n_layers,
+    const TilePool Q, const TileAux A, unsigned span) {
+  extern __shared__ __align__(16) unsigned char dyn_lds[];
+  tupdate_body<POLICY, 256>(P, G, TG, st, L, all_layers, n_layers, Q, A, span, dyn_lds, blockIdx.x);
+}
+
+// update of scan t + bin of scan t+1 in one launch (the pools are double-buffered by scan parity)
+template <typename POLICY, bool HAS_INT, bool HAS_COL, int THREADS, bool LEAN>
+__global__ __launch_bounds__(THREADS) void k_tupdate_tbin(
+    const ScanParams Pu, const GeomConst G, const TileGrid TG, DevState* __restrict__ st,
+    const typename POLICY::Layers L, float* const* __restrict__ all_layers, int n_layers,
+    const TilePool Qu, const TileAux A, unsigned span, unsigned upd_blocks, const ScanParams Pb,
+    const ScanInputs Ib, const Scratch Sb, const TilePool Qb, int32_t* __restrict__ cell_ids) {
+  // the two kinds of block interleaved in proportion over the grid (see k_update_bin4)
+  extern __shared__ __align__(16) unsigned char dyn_lds[];
+  const unsigned long long total = gridDim.x;
+  const unsigned u0 = unsigned((blockIdx.x * (unsigned long long)upd_blocks) / total);
+  const unsigned u1 = unsigned(((blockIdx.x + 1ull) * (unsigned long long)upd_blocks) / total);
+  if (u1 > u0)
+    tupdate_body<POLICY, THREADS>(Pu, G, TG, st, L, all_layers, n_layers, Qu, A, span, dyn_lds, u0);
+  else
+    tbin_body<HAS_INT, HAS_COL, THREADS, LEAN>(Pb, G, TG, st, Ib, Sb, Qb, cell_ids, dyn_lds, blockIdx.x - u0);
+}
+
+}  // namespace fdm

@@ -21,11 +21,18 @@ def R():
     return fdm_ref_py
 
 
-@pytest.fixture(scope="session")
-def gpu():
-    """fastdem_amd with a usable device; loading fails loudly if the HIP library is missing."""
+@pytest.fixture(scope="session", params=["default", "tiled_all"])
+def gpu(request):
+    """fastdem_amd with a usable device; loading fails loudly if the HIP library is missing.
+    Every GPU test runs twice: with the engine's own choice of pipeline by scan size, and with every
+    scan pushed through the large-scan (per-tile record pool) pipeline (FDM_TILED_MIN=1)."""
     import torch
     assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
     import fastdem_amd
     fastdem_amd.capi.load()
-    return fastdem_amd
+    if request.param == "tiled_all":
+        os.environ["FDM_TILED_MIN"] = "1"
+    else:
+        os.environ.pop("FDM_TILED_MIN", None)
+    yield fastdem_amd
+    os.environ.pop("FDM_TILED_MIN", None)

@@ -560,3 +560,42 @@ def test_per_layer_layout_equals_cell_records(gpu, R, est):
     assert_layers_equal(a, ref)
     for n in a.layers():
         assert_arrays_close(a.layer(n), b.layer(n), n, 0.0, 0.0)
+
+
+# ------------------------------------------------------------ large-scan (tiled) pipeline ----
+@pytest.mark.parametrize("colour", [False, True])
+def test_tiled_pipeline_sparse_cloud_overflows_the_block_table(gpu, R, colour):
+    """A cloud whose consecutive points all fall into different cells: every block of the large-scan bin
+    kernel holds more distinct cells than its LDS table has slots, so it takes the overflow route (the
+    block redone as two halves, two chunks per tile).  Ties, +-0 and NaN intensities ride along."""
+    def fill(c):
+        c.mode = 1
+        c.kalman_max_variance = 1.0
+
+    eng, ref = pair(gpu, R, 120.0, 120.0, 0.1, fill)
+    rng = np.random.default_rng(11)
+    n = 70000  # >= the engine's own threshold for the large-scan pipeline
+    for k in range(3):
+        s = {"x": rng.uniform(-55, 55, n).astype(F32), "y": rng.uniform(-55, 55, n).astype(F32),
+             "z": rng.choice(np.array([0.25, -0.0, 0.0, 0.5, 1.5, -1.0], F32), n).astype(F32),
+             "intensity": rng.choice(np.array([0.0, -0.0, 0.3, np.nan, 7.0], F32), n).astype(F32)}
+        if colour:
+            s["rgb"] = rng.integers(0, 1 << 24, n, dtype=np.uint32)
+        if k == 2:  # a dense patch on top: blocks with few distinct cells next to overflowing ones
+            s["x"][:20000] = rng.uniform(-1, 1, 20000).astype(F32)
+            s["y"][:20000] = rng.uniform(-1, 1, 20000).astype(F32)
+        run_both(eng, ref, s, T(z=0.3), T(0.4 * k, -0.2 * k, yaw=0.1 * k))
+        assert_layers_equal(eng, ref, rtol=0.0)
+
+
+def test_tiled_and_scratch_pipelines_interleave(gpu, R):
+    """Small scans (per-cell scratch pipeline) and large ones (per-tile record pools) on the same map: the
+    obstacle layer's whole-layer clear has to hold across the switch, in LOCAL mode with moves."""
+    eng, ref = pair(gpu, R, 30.0, 30.0, 0.1)
+    rng = np.random.default_rng(5)
+    for k, n in enumerate([3000, 80000, 2000, 90000, 70000, 500]):
+        s = {"x": rng.normal(0.5 * k, 4.0, n).astype(F32), "y": rng.normal(0, 4.0, n).astype(F32),
+             "z": rng.normal(0, 0.5, n).astype(F32), "intensity": rng.random(n, dtype=F32)}
+        run_both(eng, ref, s, T(z=0.5), T(0.37 * k, 0.11 * k, yaw=0.05 * k))
+        assert_layers_equal(eng, ref, rtol=0.0)
+    assert same_geometry(eng.geometry(), ref.geometry())
