@@ -45,8 +45,8 @@ constexpr unsigned kTileCells = 1024u;  // kTS * kTS
 constexpr uint32_t kNoWinner = 0xFFFFFFFFu;
 constexpr uint32_t kOrdZero = 0x80000000u;  // ord(+0.0f)
 constexpr int kTbinSlotsPerThread = 4;  // k_tbin: LDS table slots per thread (2: half-size table + overflow passes; 4: one slot per point)
-constexpr int kRecBatch = 4;    // k_tupdate: records per thread whose loads are in flight together
-constexpr int kCellBatch = 2;   // ... and touched cells
+constexpr int kRecBatch = 2;    // k_tupdate: records per thread whose loads are in flight together
+constexpr int kCellBatch = 1;   // ... and touched cells
 
 // flags beside the cell-in-tile number (10 bits) of a record
 constexpr uint32_t kRecNanFirst = 1u << 10;  // the cell's first point has a NaN intensity
@@ -893,11 +893,12 @@ __global__ __launch_bounds__(THREADS) void k_tupdate_tbin(
     const typename POLICY::Layers L, float* const* __restrict__ all_layers, int n_layers,
     const TilePool Qu, const TileAux A, unsigned span, unsigned upd_blocks, const ScanParams Pb,
     const ScanInputs Ib, const Scratch Sb, const TilePool Qb, int32_t* __restrict__ cell_ids) {
-  // the two kinds of block interleaved in proportion over the grid (see k_update_bin4)
   extern __shared__ __align__(16) unsigned char dyn_lds[];
-  const unsigned long long total = gridDim.x;
-  const unsigned u0 = unsigned((blockIdx.x * (unsigned long long)upd_blocks) / total);
-  const unsigned u1 = unsigned(((blockIdx.x + 1ull) * (unsigned long long)upd_blocks) / total);
+  // Update blocks first: they are short chains of dependent memory round trips that barely use the
+  // vector units, so they get going at once and the bin blocks (arithmetic-bound) fill the chip behind
+  // them (C4: 42.4 us against 44.9 with the two kinds interleaved in proportion, 49.5 as two launches).
+  const unsigned u0 = blockIdx.x < upd_blocks ? blockIdx.x : upd_blocks;
+  const unsigned u1 = blockIdx.x < upd_blocks ? blockIdx.x + 1u : upd_blocks;
   if (u1 > u0)
     tupdate_body<POLICY, THREADS>(Pu, G, TG, st, L, all_layers, n_layers, Qu, A, span, dyn_lds, u0);
   else

@@ -592,6 +592,7 @@ def test_tiled_and_scratch_pipelines_interleave(gpu, R):
     """Small scans (per-cell scratch pipeline) and large ones (per-tile record pools) on the same map: the
     obstacle layer's whole-layer clear has to hold across the switch, in LOCAL mode with moves."""
     eng, ref = pair(gpu, R, 30.0, 30.0, 0.1)
+    eng.set_option("tiled_min", 60000)  # (by itself the engine keeps a map of 88 tiles on the scratch pipeline)
     rng = np.random.default_rng(5)
     for k, n in enumerate([3000, 80000, 2000, 90000, 70000, 500]):
         s = {"x": rng.normal(0.5 * k, 4.0, n).astype(F32), "y": rng.normal(0, 4.0, n).astype(F32),
