@@ -44,8 +44,10 @@ def parse():
     ap.add_argument("--scans", type=int, default=0,
                     help="distinct synthetic scans resident in HBM (0 = per workload: enough that the 2 M-point "
                          "workloads stream > 256 MiB of input, i.e. cannot sit in the Infinity Cache)")
-    ap.add_argument("--host-legs", action="store_true",
-                    help="also time the PCIe-inclusive host entry points (reported beside `value`, never as it)")
+    ap.add_argument("--no-host-legs", action="store_true",
+                    help="skip the PCIe-inclusive host entry points (reported beside `value`, never as it): they launch "
+                         "the same kernels on host memory, which pulls a rocprofv3 per-kernel average of this "
+                         "command away from the timed region")
     ap.add_argument("--profile-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large", action="store_true")
@@ -96,6 +98,20 @@ class Resident:
             raise RuntimeError(f"integrate_device failed: {rc}")
         return a[0]
 
+    def batch(self, k0, count):
+        """`count` consecutive steps k0.. as one fdm_device_scan array (built outside any timed region)."""
+        from fastdem_amd import capi
+        arr = (capi.FdmDeviceScan * count)()
+        vp = lambda p: None if p is None else p.value  # noqa: E731
+        for i in range(count):
+            a = self.args[(k0 + i) % len(self.args)]
+            d = arr[i]
+            d.n = a[0]
+            d.x, d.y, d.z, d.intensity, d.rgb, d.sigma_z2 = vp(a[1]), vp(a[2]), vp(a[3]), vp(a[4]), vp(a[5]), None
+            d.T_base_sensor = self.tbs
+            d.T_world_base = self.pose(k0 + i)
+        return arr, sum(self.args[(k0 + i) % len(self.args)][0] for i in range(count))
+
     def bytes_per_point(self):
         s = self.wl.scans[0]
         return 12 + (4 if s["intensity"] is not None else 0) + (4 if s["rgb"] is not None else 0)
@@ -107,26 +123,25 @@ class Resident:
 
 
 class HipEvents:
-    """A start/stop pair of HIP events recorded on the ENGINE's stream (torch.cuda.Event only sees
-    torch's current stream)."""
+    """A start/stop pair of HIP events recorded on the ENGINE's stream (a plain torch.cuda.Event().record()
+    only sees torch's current stream).  The events are torch's, recorded on the engine's stream wrapped as
+    an ExternalStream: the same HIP runtime the engine library is bound to, no second dlopen."""
 
     def __init__(self, stream):
-        self.hip = C.CDLL("libamdhip64.so")
-        self.stream = C.c_void_p(stream)
-        self.a, self.b = C.c_void_p(), C.c_void_p()
-        assert self.hip.hipEventCreate(C.byref(self.a)) == 0 and self.hip.hipEventCreate(C.byref(self.b)) == 0
+        import torch
+        self.ext = torch.cuda.ExternalStream(int(stream))
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
 
     def start(self):
-        assert self.hip.hipEventRecord(self.a, self.stream) == 0
+        self.a.record(self.ext)
 
     def stop(self):
-        assert self.hip.hipEventRecord(self.b, self.stream) == 0
+        self.b.record(self.ext)
 
     def elapsed_ms(self):
-        assert self.hip.hipEventSynchronize(self.b) == 0
-        ms = C.c_float(0)
-        assert self.hip.hipEventElapsedTime(C.byref(ms), self.a, self.b) == 0
-        return float(ms.value)
+        self.b.synchronize()
+        return float(self.a.elapsed_time(self.b))
 
 
 def measure_kernels(res, k0, steps, tag=None, overlap=1):
@@ -268,6 +283,10 @@ def cpu_baseline(wl, target_s=12.0):
     # courtesy row: the same source built with -march=native
     native = None
     try:
+        # -march=native means THIS host: rebuild the library here (8 s of g++), never trust a shipped one
+        import subprocess
+        subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(ROOT, "oracle"), "_build/libfdm_ref_native.so"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
         rn = R.RefEngine(wl.width, wl.height, wl.resolution, wl.apply_to(R.default_config()), native=True)
         rn.time_integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, poses, 5, **kw)
         it2 = max(5, iters // 4)
@@ -276,7 +295,7 @@ def cpu_baseline(wl, target_s=12.0):
         pass
     return {"parity": parity_gate(wl, R),
             "value": n * iters / dt / 1e6, "unit": "Mpts/s", "cores": 1, "kind": "port",
-            "march_native_value": native,
+            "march_native_value": native,  # same source, -march=native, built on this host just now (None: no g++)
             "ms_per_scan": dt / iters * 1e3,
             "ms_per_scan_median": samples[len(samples) // 2] * 1e3,
             "ms_per_scan_ci95": 1.96 * sd / len(samples) ** 0.5 * 1e3,
@@ -328,19 +347,23 @@ def main():
         for _ in range(args.warmup):
             res.step(k)
             k += 1
+        # the K timed steps leave as ONE call across the language boundary (fdm_engine_integrate_device_batch:
+        # K x fdm_engine_integrate_device in C++): with a Python / ctypes call per 6 us scan the timed region
+        # would measure the interpreter, not the engine
+        batch, pts = res.batch(k, args.steps)
         barrier()
         ev = HipEvents(res.eng.stream())
         t0 = time.perf_counter()
         ev.start()
-        pts = 0
-        for _ in range(args.steps):
-            pts += res.step(k)
-            k += 1
+        rc = res.eng.integrate_device_batch(batch)
         res.eng.flush()  # the last scan's held-back update belongs to the timed region
         ev.stop()
         res.eng.sync()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if rc != 0:
+            raise RuntimeError(f"integrate_device_batch failed: {rc}")
+        k += args.steps
         timed_launch_us = ev.elapsed_ms() / args.steps * 1e3  # HIP events on the engine's stream
         if world > 1:
             dist.barrier()
@@ -354,6 +377,9 @@ def main():
             "metric": "M points/s integrated into ElevationMap",
             "value": total_pts / dt / 1e6, "unit": "Mpts/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            # the same K steps by the GPU's own clock (HIP events on the engine's stream around the region);
+            # `value` is the host wall clock incl. the final sync — for very short regions it is launch-bound
+            "device_value": pts / (timed_launch_us * args.steps * 1e-6) / 1e6,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl.name, "points_per_scan": wl.n_points,
@@ -377,9 +403,7 @@ def main():
             result["roofline"] = roof
             result["kernels"] = kern
             result["timed_region_us_per_scan_hip_events"] = timed_launch_us
-            if args.host_legs:
-                # (opt-in: these launches read pinned HOST memory through the same kernels, which would
-                # pull the rocprofv3 per-kernel average of the default command away from the timed region)
+            if not args.no_host_legs:
                 # end-to-end with host staging (PCIe-inclusive) for DESIGN.md — never `value`
                 s = wl.scan(0)
                 t0 = time.perf_counter()

@@ -95,6 +95,15 @@ class FdmScanStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class FdmDeviceScan(C.Structure):  # fdm_device_scan (include/fdm_engine.h)
+    _fields_ = [
+        ("n", C.c_uint64),
+        ("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p), ("intensity", C.c_void_p),
+        ("rgb", C.c_void_p), ("sigma_z2", C.c_void_p),
+        ("T_base_sensor", C.c_double * 16), ("T_world_base", C.c_double * 16),
+    ]
+
+
 SENSOR_CONSTANT, SENSOR_LIDAR, SENSOR_RGBD = 0, 1, 2
 MODE_LOCAL, MODE_GLOBAL = 0, 1
 EST_KALMAN, EST_P2 = 0, 1
@@ -119,6 +128,7 @@ PROTOTYPES = {
     "fdm_engine_integrate": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, _D, _D,
                                        C.POINTER(FdmScanStats)]),
     "fdm_engine_integrate_device": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, _D, _D]),
+    "fdm_engine_integrate_device_batch": (C.c_int, [_P, C.c_uint32, _P]),
     "fdm_engine_integrate_async": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_double),
                                              C.POINTER(C.c_double)]),
     "fdm_engine_update": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, C.c_double,
@@ -131,6 +141,8 @@ PROTOTYPES = {
     "fdm_host_is_pinned": (C.c_int, [_P]),
     "fdm_engine_flush": (C.c_int, [_P]),
     "fdm_engine_stream": (_P, [_P]),
+    "fdm_engine_record_event": (C.c_int, [_P, _P]),
+    "fdm_engine_wait_event": (C.c_int, [_P, _P]),
     "fdm_engine_sync": (C.c_int, [_P]),
     "fdm_engine_last_stats": (C.c_int, [_P, C.POINTER(FdmScanStats)]),
     "fdm_engine_move": (C.c_int, [_P, C.c_double, C.c_double]),

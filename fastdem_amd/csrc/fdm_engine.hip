@@ -146,7 +146,7 @@ struct fdm_engine {
   uint4* aux2[2] = {nullptr, nullptr};
   bool overlap = true;          // option "overlap"
   bool chain = false;           // an update is held back: the next bin derives its geometry from the previous slot
-  struct BinVariant { bool bin4, has_int, has_col, wave_merge; unsigned threads; bool lean; };
+  struct BinVariant { bool bin4, has_int, has_col, wave_merge; unsigned threads; int lean; };  // lean: see bin4_body
   // the held-back update (plain data: the layer set cannot change while it is pending, every entry
   // point that could change it flushes first)
   struct PendingUpdate {
@@ -159,6 +159,7 @@ struct fdm_engine {
     unsigned upd_blocks = 0;
   } pend;
   // ---- tiled pipeline state (allocated when the first large scan arrives) ----
+  bool borrow_inputs = false;       // option "borrow_inputs": a held-back update gathers from the CALLER's device arrays
   int tiled = 1;                    // option "tiled": large scans go through per-tile record pools
   unsigned tiled_min = 65536;       // ... from this many points up
   bool tiled_forced = false;        // tiled_min was set by hand (option / FDM_TILED_MIN): no map-size condition
@@ -583,8 +584,8 @@ int launch_tbin(fdm_engine* e, const ScanParams& P, const ScanInputs& in, const 
   else if (bv.has_int) go(k_tbin<true, false, T, LN>);            \
   else if (bv.has_col) go(k_tbin<false, true, T, LN>);            \
   else go(k_tbin<false, false, T, LN>);
-  if (bv.threads == 512u) { if (bv.lean) { FDM_TBIN(512, true) } else { FDM_TBIN(512, false) } }
-  else { if (bv.lean) { FDM_TBIN(256, true) } else { FDM_TBIN(256, false) } }
+  if (bv.threads == 512u) { if (bv.lean == 1) { FDM_TBIN(512, true) } else { FDM_TBIN(512, false) } }
+  else { if (bv.lean == 1) { FDM_TBIN(256, true) } else { FDM_TBIN(256, false) } }
 #undef FDM_TBIN
   if (rc) return rc;
   HIPCK(hipGetLastError());
@@ -646,8 +647,8 @@ int launch_update_fused(fdm_engine* e, const fdm_engine::PendingUpdate& u, const
         else if (bv.has_int) go(k_tupdate_tbin<POLICY, true, false, T, LN>);           \
         else if (bv.has_col) go(k_tupdate_tbin<POLICY, false, true, T, LN>);           \
         else go(k_tupdate_tbin<POLICY, false, false, T, LN>);
-        if (bv.threads == 512u) { if (bv.lean) { FDM_TF(512, true) } else { FDM_TF(512, false) } }
-        else { if (bv.lean) { FDM_TF(256, true) } else { FDM_TF(256, false) } }
+        if (bv.threads == 512u) { if (bv.lean == 1) { FDM_TF(512, true) } else { FDM_TF(512, false) } }
+        else { if (bv.lean == 1) { FDM_TF(256, true) } else { FDM_TF(256, false) } }
 #undef FDM_TF
         if (rc) return rc;
       } else {
@@ -668,11 +669,16 @@ int launch_update_fused(fdm_engine* e, const fdm_engine::PendingUpdate& u, const
         bv.wave_merge ? go(k_update_bin<POLICY, true, true>, 256u) : go(k_update_bin<POLICY, false, true>, 256u);
       } else if (!bv.wave_merge) {
         go(k_update_bin<POLICY, false>, 256u);
-      } else if (bv.lean) {  // channel tests folded at compile time, optional work compiled out
-        if (bv.has_int && bv.has_col) go(k_update_bin<POLICY, true, false, 3, true>, 256u);
-        else if (bv.has_col) go(k_update_bin<POLICY, true, false, 2, true>, 256u);
-        else if (bv.has_int) go(k_update_bin<POLICY, true, false, 1, true>, 256u);
-        else go(k_update_bin<POLICY, true, false, 0, true>, 256u);
+      } else if (bv.lean == 1) {  // channel tests folded at compile time, optional work compiled out
+        if (bv.has_int && bv.has_col) go(k_update_bin<POLICY, true, false, 3, 1>, 256u);
+        else if (bv.has_col) go(k_update_bin<POLICY, true, false, 2, 1>, 256u);
+        else if (bv.has_int) go(k_update_bin<POLICY, true, false, 1, 1>, 256u);
+        else go(k_update_bin<POLICY, true, false, 0, 1>, 256u);
+      } else if (bv.lean == 2) {  // ... but x / y / z written through to the engine's staging block
+        if (bv.has_int && bv.has_col) go(k_update_bin<POLICY, true, false, 3, 2>, 256u);
+        else if (bv.has_col) go(k_update_bin<POLICY, true, false, 2, 2>, 256u);
+        else if (bv.has_int) go(k_update_bin<POLICY, true, false, 1, 2>, 256u);
+        else go(k_update_bin<POLICY, true, false, 0, 2>, 256u);
       } else if (bv.has_int && bv.has_col) {  // the bin half's channel tests folded at compile time
         go(k_update_bin<POLICY, true, false, 3>, 256u);
       } else if (bv.has_col) {
@@ -688,7 +694,7 @@ int launch_update_fused(fdm_engine* e, const fdm_engine::PendingUpdate& u, const
       else if (bv.has_int) go(k_update_bin4<POLICY, true, false, T, ST, LN>, T);           \
       else if (bv.has_col) go(k_update_bin4<POLICY, false, true, T, ST, LN>, T);           \
       else go(k_update_bin4<POLICY, false, false, T, ST, LN>, T);
-#define FDM_FUSED4L(T, ST) if (bv.lean) { FDM_FUSED4(T, ST, true) } else { FDM_FUSED4(T, ST, false) }
+#define FDM_FUSED4L(T, ST) if (bv.lean == 1) { FDM_FUSED4(T, ST, 1) } else if (bv.lean == 2) { FDM_FUSED4(T, ST, 2) } else { FDM_FUSED4(T, ST, 0) }
       if (u.S.dense) {
         if (bv.threads == 512u) { FDM_FUSED4L(512, false) } else { FDM_FUSED4L(256, false) }
       } else {
@@ -703,6 +709,9 @@ int launch_update_fused(fdm_engine* e, const fdm_engine::PendingUpdate& u, const
     return FDM_OK;
   });
 }
+
+constexpr int kStageSlots = 3;  // rotating staging blocks (see ensure_stage)
+int ensure_stage(fdm_engine* e, size_t n);
 
 // One scan = k_bin + k_update on the stream.  All pointers are device pointers.
 // `gather` (nullable): where the UPDATE kernel reads the winning points from.  Set when dx..dvar are
@@ -808,6 +817,26 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   }
   const bool plain = e->overlap && e->key2[1] && !ray_on && !e->cap_pre &&
                      !e->cap_ras && !e->obst_dense_pending;
+  // A held-back update of the scratch pipeline gathers the winning points AFTER this call has returned and
+  // the next scan has been enqueued.  Device arrays handed to the enqueue-only entry points are therefore
+  // written through to the engine's rotating staging block by the bin kernel (12 B/point), and the update
+  // gathers from that copy: the caller's arrays are free as soon as the bin kernel has run, which is the
+  // ordinary stream contract.  (The tiled pipeline never looks at a scan twice.)
+  ScanInputs auto_gather{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (!tiled && plain && !gather && n && !e->borrow_inputs) {
+    if ((rc = ensure_stage(e, n))) return rc;
+    e->stage_rr = (e->stage_rr + 1) % kStageSlots;
+    float* base = e->d_stage + size_t(e->stage_rr) * 6 * e->stage_cap;
+    const size_t cap = e->stage_cap;
+    auto_gather = ScanInputs{base, base + cap, base + cap * 2, nullptr,
+                             reinterpret_cast<const uint32_t*>(base + cap * 4), base + cap * 5};
+    gather = &auto_gather;
+    e->S.wt_x = base;
+    e->S.wt_y = base + cap;
+    e->S.wt_z = base + cap * 2;
+    if (dvar) { e->S.wt_var = base + cap * 5; e->S.wt_src_var = dvar; }
+    if (drgb) { e->S.wt_rgb = reinterpret_cast<uint32_t*>(base + cap * 4); e->S.wt_src_rgb = drgb; }
+  }
 
   // k_bin4 trades latency for fewer memory-side atomics: worth it from ~64 K points up
   const bool want4 = e->bin_variant == 4 || (e->bin_variant == 0 && n >= 65536);
@@ -840,7 +869,9 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   int32_t* ids = e->want_ids ? e->d_cell_ids : nullptr;
   const ScanInputs in_b{dx, dy, dz, dint, drgb, dvar};
   // a scan that asks for nothing optional takes the LEAN bin body (fdm_kernels.hpp)
-  const bool lean = !ids && !e->S.wt_x && !e->S.cap_x && !P.drop_nonfinite && !P.dbg_no_atomics;
+  // (2: lean, but x / y / z written through for the held-back update's gather)
+  const int lean = (ids || e->S.cap_x || P.drop_nonfinite || P.dbg_no_atomics || e->S.wt_var || e->S.wt_rgb) ? 0
+                   : (e->S.wt_x ? 2 : 1);
   const fdm_engine::BinVariant bv{use_bin4, P.has_intensity != 0, P.has_color != 0, e->wave_merge, bin_threads, lean};
   // a held-back update leaves now: fused with this bin if the two belong to the same pipeline and
   // this scan is a plain one, alone otherwise
@@ -1003,8 +1034,6 @@ void fill_update_params(fdm_engine* e, ScanParams& P, double rx, double ry, bool
 // Staging for host-array entry points: kStageSlots rotating blocks of 6 channels.  A block is reused
 // three scans later, when the update that gathers from it (held back by at most one scan) has long
 // been launched ahead of the new copy on the same stream.
-constexpr int kStageSlots = 3;
-
 int ensure_stage(fdm_engine* e, size_t n) {
   if (n <= e->stage_cap) return FDM_OK;
   if (int rc_sync = sync_all(e)) return rc_sync;
@@ -1420,6 +1449,17 @@ int fdm_engine_integrate_device(fdm_engine* e, uint64_t n, const float* dx, cons
   return enqueue_scan(e, P, n, dx, dy, dz, dint, drgb, dvar);
 }
 
+int fdm_engine_integrate_device_batch(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) {
+  if (!e || (count && !scans)) return fail(FDM_ERR_INVALID, "null argument");
+  for (uint32_t k = 0; k < count; ++k) {
+    const fdm_device_scan& s = scans[k];
+    if (int rc = fdm_engine_integrate_device(e, s.n, s.x, s.y, s.z, s.intensity, s.rgb, s.sigma_z2,
+                                             s.T_base_sensor, s.T_world_base))
+      return rc;
+  }
+  return FDM_OK;
+}
+
 int fdm_engine_integrate(fdm_engine* e, uint64_t n, const float* x, const float* y, const float* z,
                          const float* intensity, const uint32_t* rgb, const float* sigma_z2,
                          const double Tbs[16], const double Twb[16], fdm_scan_stats* out) {
@@ -1582,6 +1622,19 @@ int fdm_engine_flush(fdm_engine* e) {
 }
 
 void* fdm_engine_stream(fdm_engine* e) { return e ? static_cast<void*>(e->stream) : nullptr; }
+
+int fdm_engine_record_event(fdm_engine* e, void* hip_event) {
+  if (!e || !hip_event) return fail(FDM_ERR_INVALID, "null argument");
+  if (int rc = join_streams(e)) return rc;  // the map is current behind this event
+  HIPCK(hipEventRecord(static_cast<hipEvent_t>(hip_event), e->stream));
+  return FDM_OK;
+}
+
+int fdm_engine_wait_event(fdm_engine* e, void* hip_event) {
+  if (!e || !hip_event) return fail(FDM_ERR_INVALID, "null argument");
+  HIPCK(hipStreamWaitEvent(e->stream, static_cast<hipEvent_t>(hip_event), 0));
+  return FDM_OK;
+}
 
 int fdm_engine_sync(fdm_engine* e) {
   if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
@@ -1924,6 +1977,10 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
   }
   if (std::strcmp(key, "tiled") == 0) {  // large scans through per-tile record pools (1, default) or the per-cell scratch (0)
     e->tiled = value != 0;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "borrow_inputs") == 0) {  // 1: device arrays of enqueue-only scans stay untouched by the caller
+    e->borrow_inputs = value != 0;              //    until the NEXT-BUT-ONE scan is enqueued (or a flush): no staging copy
     return FDM_OK;
   }
   if (std::strcmp(key, "tiled_min") == 0) {

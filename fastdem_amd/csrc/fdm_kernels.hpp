@@ -192,17 +192,19 @@ __device__ __forceinline__ DevCand block_candidate(const ScanParams& P, const Ge
 // four CONSECUTIVE points per thread (dwordx4 loads).
 constexpr uint32_t kEmptyCell = 0xFFFFFFFFu;
 
-template <bool HAS_INT, bool HAS_COL, int THREADS, bool LEAN = false>
+template <bool HAS_INT, bool HAS_COL, int THREADS, int LEAN = 0>
 __device__ __forceinline__ void bin4_body(const ScanParams& P, const GeomConst& G,
                                           DevState* __restrict__ st, const float* __restrict__ px,
                                           const float* __restrict__ py, const float* __restrict__ pz,
                                           const float* __restrict__ pint, const Scratch& S,
                                           int32_t* __restrict__ cell_ids, const unsigned bid) {
   // LEAN (the fused launches of a plain scan): captures, write-through, cell ids, the non-finite filter and
-  // the measurement switches are compiled out — dormant, they still cost 3-7 % of the launch
+  // the measurement switches are compiled out — dormant, they still cost 3-7 % of the launch.
+  // LEAN == 2 keeps the write-through of x / y / z (a held-back update gathers from the engine's copy, so
+  // the caller's arrays are free as soon as this kernel has run).
   float* const cap_x = LEAN ? nullptr : S.cap_x;
   float* const cap_var = LEAN ? nullptr : S.cap_var;
-  float* const wt_x = LEAN ? nullptr : S.wt_x;
+  float* const wt_x = LEAN == 1 ? nullptr : S.wt_x;
   int32_t* const ids = LEAN ? nullptr : cell_ids;
   const int dbg_na = LEAN ? 0 : P.dbg_no_atomics;
   const bool drop_nf = LEAN ? false : P.drop_nonfinite != 0;
@@ -247,8 +249,8 @@ __device__ __forceinline__ void bin4_body(const ScanParams& P, const GeomConst& 
     for (int j = 0; j < 4; ++j) {
       if (i0 + j >= P.n) break;
       wt_x[i0 + j] = xs[j]; S.wt_y[i0 + j] = ys[j]; S.wt_z[i0 + j] = zs[j];
-      if (S.wt_var) S.wt_var[i0 + j] = S.wt_src_var[i0 + j];
-      if (S.wt_rgb) S.wt_rgb[i0 + j] = S.wt_src_rgb[i0 + j];
+      if (LEAN != 2 && S.wt_var) S.wt_var[i0 + j] = S.wt_src_var[i0 + j];
+      if (LEAN != 2 && S.wt_rgb) S.wt_rgb[i0 + j] = S.wt_src_rgb[i0 + j];
     }
   }
   for (int k = threadIdx.x; k < kHashSlots; k += THREADS) {
@@ -381,17 +383,19 @@ __global__ __launch_bounds__(THREADS) void k_bin4(const ScanParams P, const Geom
 // CH: the scan's optional channels as a compile-time constant (bit 0 intensity, bit 1 colour) or -1 = read
 // them from ScanParams.  A VLP-16 scan is launch/latency-bound: with the channel tests folded away the fused
 // launch of configs[1] takes 5.95 instead of 6.35 us.
-template <bool WAVE_MERGE, int CH = -1, bool LEAN = false>
+template <bool WAVE_MERGE, int CH = -1, int LEAN = 0>
 __device__ __forceinline__ void bin_body(const ScanParams& P, const GeomConst& G,
                                          DevState* __restrict__ st, const float* __restrict__ px,
                                          const float* __restrict__ py, const float* __restrict__ pz,
                                          const float* __restrict__ pint, const Scratch& S,
                                          int32_t* __restrict__ cell_ids, const unsigned bid) {
   // LEAN (the fused launches of a plain scan): captures, write-through, cell ids, the non-finite filter and
-  // the measurement switches are compiled out — dormant, they still cost 3-7 % of the launch
+  // the measurement switches are compiled out — dormant, they still cost 3-7 % of the launch.
+  // LEAN == 2 keeps the write-through of x / y / z (a held-back update gathers from the engine's copy, so
+  // the caller's arrays are free as soon as this kernel has run).
   float* const cap_x = LEAN ? nullptr : S.cap_x;
   float* const cap_var = LEAN ? nullptr : S.cap_var;
-  float* const wt_x = LEAN ? nullptr : S.wt_x;
+  float* const wt_x = LEAN == 1 ? nullptr : S.wt_x;
   int32_t* const ids = LEAN ? nullptr : cell_ids;
   const int dbg_na = LEAN ? 0 : P.dbg_no_atomics;
   const bool drop_nf = LEAN ? false : P.drop_nonfinite != 0;
@@ -420,8 +424,8 @@ __device__ __forceinline__ void bin_body(const ScanParams& P, const GeomConst& G
     if (has_int) vint = pint[i];
     if (wt_x) {  // leave the raw scan in HBM for the update kernel (see Scratch::wt_x)
       wt_x[i] = x; S.wt_y[i] = y; S.wt_z[i] = z;
-      if (S.wt_var) S.wt_var[i] = S.wt_src_var[i];
-      if (S.wt_rgb) S.wt_rgb[i] = S.wt_src_rgb[i];
+      if (LEAN != 2 && S.wt_var) S.wt_var[i] = S.wt_src_var[i];
+      if (LEAN != 2 && S.wt_rgb) S.wt_rgb[i] = S.wt_src_rgb[i];
     }
   }
   const DevCand cand = block_candidate(P, G, st, &s_cand, bid);
@@ -1002,7 +1006,7 @@ struct ScanInputs {
 };
 // STAMPED (stamp-gated maps) is a template parameter, not a branch on Su.dense: carrying both update bodies
 // in one kernel cost the dense configs[2] launch 4 % (14.9 -> 15.4 us).
-template <typename POLICY, bool HAS_INT, bool HAS_COL, int THREADS, bool STAMPED = false, bool LEAN = false>
+template <typename POLICY, bool HAS_INT, bool HAS_COL, int THREADS, bool STAMPED = false, int LEAN = 0>
 __global__ __launch_bounds__(THREADS) void k_update_bin4(
     const ScanParams Pu, const GeomConst G, DevState* __restrict__ st, const typename POLICY::Layers L,
     float* const* __restrict__ all_layers, int n_layers, const Scratch Su, const ScanInputs Iu, unsigned ncell,
@@ -1026,7 +1030,7 @@ __global__ __launch_bounds__(THREADS) void k_update_bin4(
   }
 }
 
-template <typename POLICY, bool WAVE_MERGE, bool STAMPED = false, int CH = -1, bool LEAN = false>
+template <typename POLICY, bool WAVE_MERGE, bool STAMPED = false, int CH = -1, int LEAN = 0>
 __global__ __launch_bounds__(256) void k_update_bin(
     const ScanParams Pu, const GeomConst G, DevState* __restrict__ st, const typename POLICY::Layers L,
     float* const* __restrict__ all_layers, int n_layers, const Scratch Su, const ScanInputs Iu, unsigned ncell,

@@ -144,9 +144,33 @@ class Engine:
             C.byref(st)))
         return rc, st.as_dict()
 
+    def wait_torch(self):
+        """Order the engine's stream behind torch's current stream (an event + hipStreamWaitEvent): tensors
+        produced by asynchronous torch work (copy_, kernels, NCCL results) are complete before the engine
+        reads them.  The tensor-taking enqueue-only entry points call this themselves."""
+        import torch
+        if getattr(self, "_ev_in", None) is None:
+            self._ev_in = torch.cuda.Event()
+        self._ev_in.record()
+        _ck(self._lib.fdm_engine_wait_event(self._h, C.c_void_p(self._ev_in.cuda_event)))
+
+    def torch_wait(self):
+        """Order torch's current stream behind the engine: launches a held-back map update, then makes
+        torch's stream wait for everything the engine has enqueued (the map is current, the input arrays
+        of every enqueued scan are free)."""
+        import torch
+        if getattr(self, "_ev_out", None) is None:
+            self._ev_out = torch.cuda.Event()
+            self._ev_out.record()  # (creates the HIP event)
+        _ck(self._lib.fdm_engine_record_event(self._h, C.c_void_p(self._ev_out.cuda_event)))
+        torch.cuda.current_stream().wait_event(self._ev_out)
+
     def integrate_device(self, x, y, z, T_base_sensor, T_world_base, intensity=None, rgb=None,
                          sigma_z2=None):
-        """torch device tensors in, enqueue only (no sync)."""
+        """torch device tensors in, enqueue only (no sync).  The engine's stream is ordered behind torch's
+        current stream first; the tensors may be reused once the enqueued work has run (torch_wait(), sync())
+        — the held-back map update does not read them."""
+        self.wait_torch()
         tbs, twb = _colmajor16(T_base_sensor), _colmajor16(T_world_base)
         _ck(self._lib.fdm_engine_integrate_device(
             self._h, x.numel(), _dptr(x), _dptr(y), _dptr(z), _dptr(intensity), _dptr(rgb),
@@ -172,6 +196,11 @@ class Engine:
         return self._lib.fdm_engine_integrate_device(self._h, n, dx, dy, dz, dint, drgb, dvar,
                                                      tbs16, twb16)
 
+    def integrate_device_batch(self, scans, count=None):
+        """`scans`: a ctypes array of capi.FdmDeviceScan — `count` device-resident scans enqueued by ONE call
+        across the language boundary."""
+        return self._lib.fdm_engine_integrate_device_batch(self._h, len(scans) if count is None else count, scans)
+
     def update(self, x, y, z, robot_xy=(0.0, 0.0), z_var=None, intensity=None, rgb=None):
         x, y, z = _f32(x), _f32(y), _f32(z)
         v, a, c = _f32(z_var), _f32(intensity), _u32(rgb)
@@ -192,6 +221,7 @@ class Engine:
 
     def update_device(self, x, y, z, robot_xy=(0.0, 0.0), z_var=None, intensity=None, rgb=None):
         """ElevationMapping::update on torch device tensors (map-frame cloud), enqueue only."""
+        self.wait_torch()
         _ck(self._lib.fdm_engine_update_device(self._h, x.numel(), _dptr(x), _dptr(y), _dptr(z), _dptr(z_var),
                                                _dptr(intensity), _dptr(rgb), float(robot_xy[0]),
                                                float(robot_xy[1])))

@@ -126,17 +126,33 @@ int fdm_engine_integrate(fdm_engine* e, uint64_t n, const float* x, const float*
 /* Same, inputs already resident in HBM; enqueue-only (no host sync).  The skip
  * decisions of fastdem.cpp:125-138 are taken on the device; read them back with
  * fdm_engine_last_stats().
- * The map update of the scan is
- * HELD BACK and leaves in the same launch as the next scan's bin kernel (one launch per scan
- * instead of two); every other entry point — fdm_engine_sync() included — first launches a held-back
- * update, so the map is always current when it is read through this API.  A caller that reads
- * layers through raw device pointers on its own stream must call fdm_engine_sync() (or any entry
- * point) first; the input arrays must stay valid until then.  fdm_engine_set_option(e, "overlap", 0)
- * turns the hold-back off. */
+ * The map update of the scan is HELD BACK and leaves in the same launch as the next scan's bin kernel
+ * (one launch per scan instead of two); every other entry point — fdm_engine_sync() included — first
+ * launches a held-back update, so the map is always current when it is read through this API.
+ * A caller that reads layers through raw device pointers on its own stream orders itself behind
+ * fdm_engine_record_event() (which launches the held-back update first).
+ * Input arrays follow the ordinary stream contract: they may be reused as soon as the work this call
+ * enqueued has run (an event from fdm_engine_record_event, or fdm_engine_sync) — the held-back update
+ * never reads them (the bin kernel leaves what it needs in engine-owned memory).  Producers on another
+ * stream hand the arrays over with fdm_engine_wait_event().
+ * fdm_engine_set_option(e, "overlap", 0) turns the hold-back off. */
 int fdm_engine_integrate_device(fdm_engine* e, uint64_t n, const float* d_x, const float* d_y,
                                 const float* d_z, const float* d_intensity, const uint32_t* d_rgb,
                                 const float* d_sigma_z2, const double T_base_sensor[16],
                                 const double T_world_base[16]);
+
+/* A batch of device-resident scans in ONE call (a bag replay, a driver that queues ahead): exactly
+ * `count` consecutive fdm_engine_integrate_device calls, without the per-call crossing of the language
+ * boundary (ctypes / JNI / cgo cost more than the 6 us a small scan takes on the device). */
+typedef struct fdm_device_scan {
+  uint64_t n;
+  const float *x, *y, *z, *intensity; /* device pointers; intensity nullable */
+  const uint32_t* rgb;                /* nullable */
+  const float* sigma_z2;              /* nullable */
+  double T_base_sensor[16];           /* column-major */
+  double T_world_base[16];
+} fdm_device_scan;
+int fdm_engine_integrate_device_batch(fdm_engine* e, uint32_t count, const fdm_device_scan* scans);
 
 /* Same, HOST arrays, enqueue-only; nothing waits.  For a stream of scans from host memory (bag replay,
  * a ROS callback).
@@ -168,6 +184,14 @@ int fdm_engine_flush(fdm_engine* e);
 /* The HIP stream (hipStream_t) the engine launches on: for callers that bracket engine work with
  * their own HIP events or order their own kernels after it. */
 void* fdm_engine_stream(fdm_engine* e);
+/* Order a consumer behind the engine: launches a held-back update, then records `hip_event`
+ * (hipEvent_t) on the engine's stream — everything enqueued so far, the map update of the last scan
+ * included, is complete when the event fires (the reference's callers hold a shared_mutex around
+ * integrate() for this, fastdem.hpp:48-53). */
+int fdm_engine_record_event(fdm_engine* e, void* hip_event);
+/* Order the engine behind a producer: work enqueued after this call waits for `hip_event`
+ * (hipStreamWaitEvent), e.g. the kernel or copy that fills the next scan's device arrays. */
+int fdm_engine_wait_event(fdm_engine* e, void* hip_event);
 int fdm_engine_sync(fdm_engine* e);
 /* Waits for the stream, returns the status (0/1/2) and stats of the last enqueued scan. */
 int fdm_engine_last_stats(fdm_engine* e, fdm_scan_stats* out);

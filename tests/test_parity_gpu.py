@@ -600,3 +600,32 @@ def test_tiled_and_scratch_pipelines_interleave(gpu, R):
         run_both(eng, ref, s, T(z=0.5), T(0.37 * k, 0.11 * k, yaw=0.05 * k))
         assert_layers_equal(eng, ref, rtol=0.0)
     assert same_geometry(eng.geometry(), ref.geometry())
+
+
+@pytest.mark.parametrize("n_pts", [28800, 100000])
+def test_held_back_update_never_reads_the_callers_arrays(gpu, R, n_pts):
+    """The streaming pattern of a real caller: ONE set of device buffers, refilled for every scan by
+    asynchronous torch copies.  The update of scan t is still held back when the buffers are overwritten
+    with scan t+1 (here: with garbage first) — it must gather from the engine's own copy."""
+    import torch
+    wl = gpu.synth.vlp16(n_scans=4) if n_pts < 50000 else gpu.synth.lidar128(n_scans=4, n_az=n_pts // 128)
+    a = gpu.Engine(wl.width, wl.height, wl.resolution, wl.apply_to(gpu.capi.default_config()))
+    b = gpu.Engine(wl.width, wl.height, wl.resolution, wl.apply_to(gpu.capi.default_config()))
+    n = wl.n_points
+    buf = {c: torch.empty(n, dtype=torch.float32, device="cuda") for c in ("x", "y", "z", "intensity")}
+    for k in range(6):
+        s = wl.scan(k)
+        a.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k), intensity=s["intensity"])
+        for c in buf:
+            buf[c].copy_(torch.from_numpy(s[c]), non_blocking=True)   # torch's stream ...
+        b.integrate_device(buf["x"], buf["y"], buf["z"], wl.T_base_sensor, wl.pose(k),
+                           intensity=buf["intensity"])               # ... the engine orders itself behind it
+        torch.cuda.synchronize()  # the bin kernel has run; the map update of this scan is still held back
+        for c in buf:
+            buf[c].fill_(float("nan") if c != "intensity" else 1e9)
+        torch.cuda.synchronize()
+    rc, st = b.last_stats()
+    assert rc == 0 and st == a.last_stats()[1]
+    for name in a.layers():
+        assert_arrays_close(a.layer(name), b.layer(name), name, 0.0, 0.0)
+    assert same_geometry(a.geometry(), b.geometry())
