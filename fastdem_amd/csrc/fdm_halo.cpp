@@ -1,0 +1,164 @@
+// fdm_halo.cpp — libfdm_halo.so: tile plan + RCCL scan broadcast / halo exchange on the engine's stream
+// (include/fdm_halo.h).  Host code only; the HIP pack / unpack kernels are libfdm_engine.so's
+// fdm_engine_region_pack / _unpack.
+#include "../../include/fdm_halo.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+
+namespace {
+thread_local std::string g_err;
+int fail(int code, const std::string& m) {
+  g_err = m;
+  return code;
+}
+
+void grid_for(int world, int& pr, int& pc) {
+  pr = int(std::floor(std::sqrt(double(world))));
+  while (world % pr) --pr;
+  pc = world / pr;
+}
+// Python's round(): half to even (fastdem_amd/tiling.py::_split uses it)
+long round_half_even(double v) {
+  const double f = std::floor(v), d = v - f;
+  if (d > 0.5) return long(f) + 1;
+  if (d < 0.5) return long(f);
+  return (long(f) % 2 == 0) ? long(f) : long(f) + 1;
+}
+void split(int n, int parts, int i, int& start, int& len) {
+  const long a = round_half_even(double(i) * n / parts), b = round_half_even(double(i + 1) * n / parts);
+  start = int(a);
+  len = int(b - a);
+}
+fdm_rect owned_rect(int rank, int world, int rows, int cols) {
+  int pr, pc;
+  grid_for(world, pr, pc);
+  const int i = rank / pc, j = rank % pc;
+  fdm_rect r;
+  split(rows, pr, i, r.r0, r.nr);
+  split(cols, pc, j, r.c0, r.nc);
+  return r;
+}
+fdm_rect stored_rect(const fdm_rect& o, int rows, int cols, int halo) {
+  const int r0 = std::max(0, o.r0 - halo), c0 = std::max(0, o.c0 - halo);
+  const int r1 = std::min(rows, o.r0 + o.nr + halo), c1 = std::min(cols, o.c0 + o.nc + halo);
+  return fdm_rect{r0, c0, r1 - r0, c1 - c0};
+}
+fdm_rect intersect(const fdm_rect& a, const fdm_rect& b) {
+  const int r0 = std::max(a.r0, b.r0), c0 = std::max(a.c0, b.c0);
+  const int r1 = std::min(a.r0 + a.nr, b.r0 + b.nr), c1 = std::min(a.c0 + a.nc, b.c0 + b.nc);
+  return fdm_rect{r0, c0, std::max(0, r1 - r0), std::max(0, c1 - c0)};
+}
+}  // namespace
+
+extern "C" {
+
+const char* fdm_halo_last_error(void) { return g_err.c_str(); }
+
+int fdm_tile_plan_make(int32_t rank, int32_t world, int32_t rows, int32_t cols, int32_t halo, fdm_tile_plan* out) {
+  if (!out) return fail(FDM_ERR_INVALID, "null plan");
+  if (world <= 0 || rank < 0 || rank >= world || rows <= 0 || cols <= 0 || halo < 0)
+    return fail(FDM_ERR_INVALID, "bad rank / world / size / halo");
+  fdm_tile_plan p{};
+  p.rank = rank; p.world = world; p.rows = rows; p.cols = cols; p.halo = halo;
+  grid_for(world, p.grid_rows, p.grid_cols);
+  p.owned = owned_rect(rank, world, rows, cols);
+  p.stored = stored_rect(p.owned, rows, cols, halo);
+  if (p.owned.nr <= 0 || p.owned.nc <= 0) return fail(FDM_ERR_INVALID, "more tiles than cells along an axis");
+  for (int other = 0; other < world; ++other) {
+    if (other == rank) continue;
+    const fdm_rect theirs = owned_rect(other, world, rows, cols);
+    const fdm_rect theirs_st = stored_rect(theirs, rows, cols, halo);
+    const fdm_rect s = intersect(p.owned, theirs_st), r = intersect(theirs, p.stored);
+    if (s.nr > 0 && s.nc > 0) {
+      if (p.n_sends >= FDM_MAX_NEIGHBOURS) return fail(FDM_ERR_INVALID, "halo wider than a tile: more than 8 neighbours");
+      p.send_rank[p.n_sends] = other;
+      p.send_rect[p.n_sends++] = s;
+    }
+    if (r.nr > 0 && r.nc > 0) {
+      if (p.n_recvs >= FDM_MAX_NEIGHBOURS) return fail(FDM_ERR_INVALID, "halo wider than a tile: more than 8 neighbours");
+      p.recv_rank[p.n_recvs] = other;
+      p.recv_rect[p.n_recvs++] = r;
+    }
+  }
+  *out = p;
+  return FDM_OK;
+}
+
+void fdm_tile_plan_tile(const fdm_tile_plan* p, fdm_tile* t) {
+  if (!p || !t) return;
+  t->row0 = p->stored.r0; t->col0 = p->stored.c0; t->rows = p->stored.nr; t->cols = p->stored.nc;
+  t->own_row0 = p->owned.r0; t->own_col0 = p->owned.c0; t->own_rows = p->owned.nr; t->own_cols = p->owned.nc;
+}
+
+uint64_t fdm_halo_workspace_bytes(const fdm_tile_plan* p, int32_t n_layers) {
+  if (!p || n_layers <= 0) return 0;
+  uint64_t cells = 0;
+  for (int k = 0; k < p->n_sends; ++k) cells += uint64_t(p->send_rect[k].nr) * uint64_t(p->send_rect[k].nc);
+  for (int k = 0; k < p->n_recvs; ++k) cells += uint64_t(p->recv_rect[k].nr) * uint64_t(p->recv_rect[k].nc);
+  return cells * uint64_t(n_layers) * sizeof(float);
+}
+
+int fdm_halo_broadcast_scan(fdm_engine* e, void* nccl_comm, float* d_packed, uint64_t count, int32_t root) {
+  if (!e || !nccl_comm || !d_packed) return fail(FDM_ERR_INVALID, "null argument");
+  hipStream_t stream = static_cast<hipStream_t>(fdm_engine_stream(e));
+  const ncclResult_t r = ncclBroadcast(d_packed, d_packed, size_t(count), ncclFloat, root,
+                                       static_cast<ncclComm_t>(nccl_comm), stream);
+  if (r != ncclSuccess) return fail(FDM_ERR_HIP, std::string("ncclBroadcast: ") + ncclGetErrorString(r));
+  return FDM_OK;
+}
+
+int64_t fdm_halo_exchange(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p, const char* const* names,
+                          int32_t n_names, float* d_ws, uint64_t ws_bytes) {
+  if (!e || !p || !names) return fail(FDM_ERR_INVALID, "null argument");
+  if (p->world == 1 || n_names <= 0) return 0;
+  if (!nccl_comm || !d_ws) return fail(FDM_ERR_INVALID, "null communicator / workspace");
+  if (ws_bytes < fdm_halo_workspace_bytes(p, n_names)) return fail(FDM_ERR_INVALID, "workspace too small");
+  hipStream_t stream = static_cast<hipStream_t>(fdm_engine_stream(e));
+  ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);
+  // pack (the first region call launches a held-back update: the map is current)
+  float* cur = d_ws;
+  float* send_buf[FDM_MAX_NEIGHBOURS];
+  float* recv_buf[FDM_MAX_NEIGHBOURS];
+  int64_t sent = 0;
+  for (int k = 0; k < p->n_sends; ++k) {
+    const fdm_rect& r = p->send_rect[k];
+    send_buf[k] = cur;
+    cur += size_t(r.nr) * size_t(r.nc) * size_t(n_names);
+    if (int rc = fdm_engine_region_pack(e, r.r0 - p->stored.r0, r.c0 - p->stored.c0, r.nr, r.nc, names, n_names,
+                                        send_buf[k]))
+      return fail(rc, std::string("region_pack: ") + fdm_last_error());
+    sent += int64_t(r.nr) * r.nc * n_names * int64_t(sizeof(float));
+  }
+  for (int k = 0; k < p->n_recvs; ++k) {
+    const fdm_rect& r = p->recv_rect[k];
+    recv_buf[k] = cur;
+    cur += size_t(r.nr) * size_t(r.nc) * size_t(n_names);
+  }
+  // one group: xGMI is point-to-point, a strip is ~10^2 KB — latency-bound, so everything leaves together
+  ncclResult_t r = ncclGroupStart();
+  for (int k = 0; r == ncclSuccess && k < p->n_recvs; ++k) {
+    const fdm_rect& q = p->recv_rect[k];
+    r = ncclRecv(recv_buf[k], size_t(q.nr) * size_t(q.nc) * size_t(n_names), ncclFloat, p->recv_rank[k], comm, stream);
+  }
+  for (int k = 0; r == ncclSuccess && k < p->n_sends; ++k) {
+    const fdm_rect& q = p->send_rect[k];
+    r = ncclSend(send_buf[k], size_t(q.nr) * size_t(q.nc) * size_t(n_names), ncclFloat, p->send_rank[k], comm, stream);
+  }
+  const ncclResult_t r2 = ncclGroupEnd();
+  if (r != ncclSuccess || r2 != ncclSuccess)
+    return fail(FDM_ERR_HIP, std::string("nccl send/recv: ") + ncclGetErrorString(r != ncclSuccess ? r : r2));
+  for (int k = 0; k < p->n_recvs; ++k) {
+    const fdm_rect& q = p->recv_rect[k];
+    if (int rc = fdm_engine_region_unpack(e, q.r0 - p->stored.r0, q.c0 - p->stored.c0, q.nr, q.nc, names, n_names,
+                                          recv_buf[k]))
+      return fail(rc, std::string("region_unpack: ") + fdm_last_error());
+  }
+  return sent;
+}
+
+}  // extern "C"

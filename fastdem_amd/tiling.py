@@ -128,35 +128,74 @@ def visible_layers(names: Sequence[str]) -> List[str]:
 
 
 class EngineTile:
-    """Tile backend over a live engine: packs / unpacks with HIP kernels into torch buffers."""
+    """Tile backend over a live engine: packs / unpacks with HIP kernels into torch buffers that live as
+    long as the tile (one pair per neighbour, reused by every exchange: nothing is allocated per scan and
+    no buffer can be recycled by torch's allocator while a kernel on the ENGINE's stream still uses it).
+    Ordering between the engine's stream and torch's (the collective's) is by events, never by the host."""
 
     def __init__(self, engine, plan: TilePlan, device):
         import torch
         self.eng, self.plan, self.device, self.torch = engine, plan, device, torch
+        self._bufs = {}
+
+    def _buf(self, kind, rect: Rect, names: Sequence[str]):
+        key = (kind, rect, len(names))
+        if key not in self._bufs:
+            self._bufs[key] = self.torch.empty(len(names) * rect.nr * rect.nc, dtype=self.torch.float32,
+                                               device=self.device)
+        return self._bufs[key]
 
     def pack(self, rect: Rect, names: Sequence[str]):
         loc = rect.local_to(self.plan.stored)
-        buf = self.torch.empty(len(names) * rect.nr * rect.nc, dtype=self.torch.float32,
-                               device=self.device)
+        buf = self._buf("send", rect, names)
         self.eng.region_pack(loc.r0, loc.c0, loc.nr, loc.nc, list(names), buf.data_ptr())
         return buf
 
     def recv_buffer(self, rect: Rect, names: Sequence[str]):
-        return self.torch.empty(len(names) * rect.nr * rect.nc, dtype=self.torch.float32,
-                                device=self.device)
+        return self._buf("recv", rect, names)
 
     def unpack(self, rect: Rect, names: Sequence[str], buf):
         loc = rect.local_to(self.plan.stored)
         self.eng.region_unpack(loc.r0, loc.c0, loc.nr, loc.nc, list(names), buf.data_ptr())
 
     def fence(self):
-        """Packed buffers are produced on the engine's stream, consumed by the collective."""
-        self.eng.sync()
+        """The pack kernels run on the engine's stream, the collective on torch's: torch's stream waits for
+        the engine (an event; the host does not).  Also orders this exchange's receives behind the previous
+        exchange's unpack kernels, which read the same buffers."""
+        self.eng.torch_wait()
 
     def after_comm(self):
-        """NCCL/RCCL `wait()` orders the CURRENT TORCH STREAM after the transfer, not the host and
-        not the engine's stream: drain it before the unpack kernels are enqueued on the engine."""
-        self.torch.cuda.current_stream().synchronize()
+        """`req.wait()` has ordered torch's current stream behind the transfers; the unpack kernels go to the
+        engine's stream, which waits for torch's stream here (again an event)."""
+        self.eng.wait_torch()
+
+
+class HostStagedTile:
+    """The same tile over a backend that only moves HOST memory (gloo): buffers are staged through the host
+    around the real HIP pack / unpack kernels.  Used by the one-GPU multi-process test (RCCL refuses two ranks
+    on one device) — the plan, the pack / unpack code and the exchange loop are the ones the RCCL path runs."""
+
+    def __init__(self, inner: "EngineTile"):
+        self.inner = inner
+        self._recv = {}
+
+    def pack(self, rect, names):
+        buf = self.inner.pack(rect, names)
+        self.inner.eng.sync()
+        return buf.cpu()
+
+    def recv_buffer(self, rect, names):
+        t = self.inner.torch.empty(len(names) * rect.nr * rect.nc, dtype=self.inner.torch.float32)
+        return t
+
+    def unpack(self, rect, names, buf):
+        dev = self.inner.recv_buffer(rect, names)
+        dev.copy_(buf)
+        self.inner.torch.cuda.current_stream().synchronize()
+        self.inner.unpack(rect, names, dev)
+
+    def fence(self):
+        pass
 
 
 def exchange_halos(tile, plan: TilePlan, names: Sequence[str], dist, group=None):
@@ -204,34 +243,32 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
                  tile=plan.fdm_tile() if world > 1 else None, device=local_rank)
     tile = EngineTile(eng, plan, dev)
     names = ["elevation", "variance", "elevation_min", "elevation_max", "upper_bound",
-             "lower_bound", "n_points", "obstacle"]
-    scans = []
-    for s in wl.scans:
-        if rank == 0:
-            scans.append({k: torch.from_numpy(s[k]).to(dev) for k in ("x", "y", "z")})
-        else:
-            scans.append({k: torch.empty(s[k].size, dtype=torch.float32, device=dev)
-                          for k in ("x", "y", "z")})
+             "lower_bound", "n_points", "obstacle", "intensity"]
+    chans = ("x", "y", "z", "intensity")
+    n_pts = wl.n_points
+    # rank 0 holds the scans; every rank has ONE packed [4, N] receive buffer (one broadcast per scan, not
+    # one per channel), double-buffered so that scan k+1 can be distributed while scan k is integrated
+    src = [torch.stack([torch.from_numpy(s[c]) for c in chans]).to(dev) for s in wl.scans] if rank == 0 else None
+    staged = [torch.empty((4, n_pts), dtype=torch.float32, device=dev) for _ in range(2)]
     tbs = (C.c_double * 16)(*np.ascontiguousarray(wl.T_base_sensor.T).reshape(16).tolist())
-    staged = {k: torch.empty_like(scans[0][k]) for k in ("x", "y", "z")}
+    steps, warm = min(args.steps, 200), min(args.warmup, 20)
+    poses = [(C.c_double * 16)(*np.ascontiguousarray(wl.pose(k).T).reshape(16).tolist())
+             for k in range(steps + warm)]
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 
     def step(k):
-        src = scans[k % len(scans)]
         if world > 1:
-            for ch in ("x", "y", "z"):
-                if rank == 0:
-                    staged[ch].copy_(src[ch])
-                dist.broadcast(staged[ch], 0)
-            cur = staged
-            torch.cuda.current_stream().synchronize()
+            cur = staged[k & 1]
+            if rank == 0:
+                cur.copy_(src[k % len(src)])
+            dist.broadcast(cur, 0)   # on torch's stream ...
+            eng.wait_torch()         # ... which the engine's stream waits for (an event, no host sync)
         else:
-            cur = src
-        twb = (C.c_double * 16)(*np.ascontiguousarray(wl.pose(k).T).reshape(16).tolist())
-        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-        rc = eng.integrate_device_raw(cur["x"].numel(), p(cur["x"]), p(cur["y"]), p(cur["z"]), tbs, twb)
+            cur = src[k % len(src)]
+        rc = eng.integrate_device_raw(n_pts, p(cur[0]), p(cur[1]), p(cur[2]), tbs, poses[k], p(cur[3]))
         assert rc == 0, rc
         exchange_halos(tile, plan, names, dist)
-        return int(cur["x"].numel())
+        return n_pts
 
     def barrier():
         eng.sync()
@@ -239,7 +276,6 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
         if world > 1:
             dist.barrier()
 
-    steps, warm = min(args.steps, 200), min(args.warmup, 20)
     k = 0
     for _ in range(warm):
         step(k)
@@ -268,7 +304,7 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl.name, "points_per_scan": wl.n_points, "map_cells": rows * cols,
                    "parallelism": f"spatial tiles {grid_for(world)[0]}x{grid_for(world)[1]}, halo {DEFAULT_HALO} cells, "
-                                  "scan broadcast + p2p halo exchange per scan",
-                   "inputs": "SoA float32 resident in HBM on rank 0"},
+                                  "one packed scan broadcast + p2p halo exchange per scan, stream-ordered by events",
+                   "inputs": "SoA float32 (x, y, z, intensity) resident in HBM on rank 0"},
         "rank0_last_scan": st,
     }

@@ -1,0 +1,69 @@
+/* fdm_halo.h — C ABI for driving the spatial tiling of ONE global map from a C++ host with RCCL.
+ *
+ * The reference has no multi-GPU path; its callers that would need one keep a single very large GLOBAL map
+ * (ros1/config/global_mapping.yaml:14-17, driven by ros1/src/fastdem_ros_node.cpp:171-182).  This library
+ * (libfdm_halo.so, links librccl; libfdm_engine.so itself has no RCCL dependency) gives such a host the
+ * three things it needs: the tile plan, the scan distribution and the halo exchange — all enqueued on the
+ * ENGINE's stream, so there is no host synchronisation and no cross-stream event anywhere:
+ *
+ *     fdm_tile_plan plan;  fdm_tile tile;
+ *     fdm_tile_plan_make(rank, world, rows, cols, FDM_DEFAULT_HALO, &plan);
+ *     fdm_tile_plan_tile(&plan, &tile);
+ *     fdm_engine_create(&geometry, &config, &tile, device, &engine);          // GLOBAL mode
+ *     per scan:
+ *       fdm_halo_broadcast_scan(engine, comm, d_packed, channels * n, root);  // [channels][n] float32
+ *       fdm_engine_integrate_device(engine, n, d_packed, d_packed + n, d_packed + 2 * n, ...);
+ *       fdm_halo_exchange(engine, comm, &plan, names, n_names, d_workspace, workspace_bytes);
+ *
+ * fastdem_amd/tiling.py is the same plan / exchange over torch.distributed; tests/test_halo_capi.py checks
+ * the two plans against each other.
+ */
+#ifndef FDM_HALO_H
+#define FDM_HALO_H
+
+#include "fdm_engine.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDM_DEFAULT_HALO 6 /* cells: feature extraction reaches ceil(0.3 m / 0.05 m) (config/postprocess.hpp:45) */
+#define FDM_MAX_NEIGHBOURS 8
+
+typedef struct fdm_rect {
+  int32_t r0, c0, nr, nc; /* GLOBAL cell coordinates */
+} fdm_rect;
+
+typedef struct fdm_tile_plan {
+  int32_t rank, world, rows, cols, halo;
+  int32_t grid_rows, grid_cols; /* pr x pc tiles, pr * pc == world, as square as possible, pr <= pc */
+  fdm_rect owned, stored;       /* stored = owned + halo ring, clamped at the map border */
+  int32_t n_sends, n_recvs;
+  int32_t send_rank[FDM_MAX_NEIGHBOURS];
+  fdm_rect send_rect[FDM_MAX_NEIGHBOURS]; /* my owned cells inside that neighbour's halo ring */
+  int32_t recv_rank[FDM_MAX_NEIGHBOURS];
+  fdm_rect recv_rect[FDM_MAX_NEIGHBOURS]; /* that neighbour's owned cells inside my halo ring */
+} fdm_tile_plan;
+
+/* The plan of `rank` (needs halo < every tile's extent, i.e. at most 8 neighbours). */
+int fdm_tile_plan_make(int32_t rank, int32_t world, int32_t rows, int32_t cols, int32_t halo, fdm_tile_plan* out);
+void fdm_tile_plan_tile(const fdm_tile_plan* plan, fdm_tile* out);
+/* Bytes of device workspace fdm_halo_exchange needs for `n_layers` layers (send + receive buffers). */
+uint64_t fdm_halo_workspace_bytes(const fdm_tile_plan* plan, int32_t n_layers);
+
+/* Scan distribution: ncclBroadcast of `count` floats (the packed SoA channels) from `root`, on the engine's
+ * stream.  `nccl_comm` is the host application's ncclComm_t. */
+int fdm_halo_broadcast_scan(fdm_engine* e, void* nccl_comm, float* d_packed, uint64_t count, int32_t root);
+
+/* One halo exchange on the engine's stream: HIP pack of every send rectangle, ONE ncclGroup of
+ * ncclSend / ncclRecv with the (at most 8) neighbours, HIP unpack.  Launches a held-back map update first.
+ * Returns the number of bytes sent, or a negative FDM_ERR_*. */
+int64_t fdm_halo_exchange(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* plan, const char* const* names,
+                          int32_t n_names, float* d_workspace, uint64_t workspace_bytes);
+
+const char* fdm_halo_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

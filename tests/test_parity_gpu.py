@@ -629,3 +629,43 @@ def test_held_back_update_never_reads_the_callers_arrays(gpu, R, n_pts):
     for name in a.layers():
         assert_arrays_close(a.layer(name), b.layer(name), name, 0.0, 0.0)
     assert same_geometry(a.geometry(), b.geometry())
+
+
+# ------------------------------------------------------------ configs[4] as BASELINE.json states it ----
+def test_c5_stated_size_engine_vs_oracle_and_2x4_tiles(gpu, R):
+    """configs[4] at its stated size: GLOBAL 400x400 m @ 0.05 m map (8000x8000 cells), 2 097 152-point scans.
+    (a) the untiled engine against the oracle — cell ids of every point bit-exact, every layer bit-identical;
+    (b) the 2x4 spatial tiling of the 8-GPU configuration (tiling.make_plan: owned window + 6-cell halo per
+        tile), all eight tile engines on this one GPU, each fed the whole scan: every OWNED window equals
+        the untiled map bit for bit (the halo ring is filled by the exchange, tests/test_tiling_gpu.py)."""
+    from fastdem_amd import tiling
+    wl = gpu.synth.global_map(n_scans=2)
+    assert wl.n_points == 128 * 16384
+    eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
+    assert (eng.rows, eng.cols) == (8000, 8000)
+    for k in range(2):
+        rc, st = run_both(eng, ref, wl.scan(k), wl.T_base_sensor, wl.pose(k))
+        assert rc == 0 and st["n_in_map"] > 500000
+    names = eng.layers()
+    assert sorted(names) == sorted(ref.layers())
+    whole = {}
+    for name in names:
+        whole[name] = eng.layer(name)
+        assert_arrays_close(whole[name], ref.layer(name), name, 0.0, 0.0)
+    del ref
+    for rank in range(8):
+        plan = tiling.make_plan(rank, 8, 8000, 8000, tiling.DEFAULT_HALO)
+        t = gpu.Engine(wl.width, wl.height, wl.resolution, wl.apply_to(gpu.capi.default_config()),
+                       tile=plan.fdm_tile())
+        for k in range(2):
+            s = wl.scan(k)
+            t.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k), intensity=s["intensity"])
+        o, st_ = plan.owned, plan.stored
+        for name in names:
+            want = whole[name][o.r0:o.r1, o.c0:o.c1]
+            if not t.exists(name):  # a lazily created layer no point of this tile carried
+                assert np.isnan(want).all(), (rank, name)
+                continue
+            got = t.layer(name)[o.r0 - st_.r0:o.r1 - st_.r0, o.c0 - st_.c0:o.c1 - st_.c0]
+            assert_arrays_close(got, want, f"tile {rank} {name}", 0.0, 0.0)
+        t.close()

@@ -1,0 +1,98 @@
+"""The N>1 path of the spatial tiling on ONE GPU: 2 and 4 processes share device 0, each owns a tile
+engine (fdm_tile: owned window + halo ring), the scan is broadcast, every rank integrates it and the halo
+exchange runs through the real plan / HIP pack / HIP unpack code of fastdem_amd.tiling — over gloo with
+host-staged buffers, because RCCL refuses two ranks on one device.  Every STORED window (owned cells and
+the exchanged halo ring) must equal the untiled engine's map bit for bit.
+Run on the GPU box:  python -m pytest tests -m gpu
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        sys.path.insert(0, ROOT)
+        import torch
+        import torch.distributed as dist
+        from fastdem_amd import Engine, capi, synth, tiling
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        wl = synth.global_map(n_scans=3, size_m=100.0, n_az=2048, radius=30.0)
+        rows = cols = 2000
+        plan = tiling.make_plan(rank, world, rows, cols, tiling.DEFAULT_HALO)
+        eng = Engine(wl.width, wl.height, wl.resolution, wl.apply_to(capi.default_config()),
+                     tile=plan.fdm_tile(), device=0)
+        assert (eng.rows, eng.cols) == (rows, cols)
+        tile = tiling.HostStagedTile(tiling.EngineTile(eng, plan, "cuda:0"))
+        whole = Engine(wl.width, wl.height, wl.resolution, wl.apply_to(capi.default_config()), device=0)
+        names = None
+        for k in range(3):
+            # scan distribution as tiling.bench_global does it: one packed [4, N] tensor from rank 0
+            s = wl.scan(k)
+            n = s["x"].size
+            packed = torch.empty((4, n), dtype=torch.float32)
+            if rank == 0:
+                for i, c in enumerate(("x", "y", "z", "intensity")):
+                    packed[i] = torch.from_numpy(s[c])
+            dist.broadcast(packed, 0)
+            d = packed.cuda()
+            eng.integrate_device(d[0], d[1], d[2], wl.T_base_sensor, wl.pose(k), intensity=d[3])
+            names = [nm for nm in tiling.visible_layers(eng.layers())]
+            # (lazily created layers exist on every rank or on none only if every tile saw the channel;
+            # exchange the intersection all ranks agree on)
+            have = [None] * world
+            dist.all_gather_object(have, names)
+            names = [nm for nm in names if all(nm in h for h in have)]
+            tiling.exchange_halos(tile, plan, names, dist)
+            whole.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k), intensity=s["intensity"])
+        st = plan.stored
+        bad = []
+        for nm in names:
+            got = eng.layer(nm)
+            want = whole.layer(nm)[st.r0:st.r1, st.c0:st.c1]
+            same = np.array_equal(got.view(np.uint32), want.view(np.uint32))
+            if not same:
+                nan_ok = np.array_equal(np.isnan(got), np.isnan(want))
+                bad.append((nm, int((got.view(np.uint32) != want.view(np.uint32)).sum()), nan_ok))
+        q.put((rank, bad, len(names)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, [("exception", traceback.format_exc(), str(e))], 0))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_tile_engines_with_halo_exchange_equal_the_untiled_map(world):
+    import torch
+    assert torch.cuda.is_available()
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, bad, n_names in sorted(results):
+        assert not bad, f"rank {rank}: {bad}"
+        assert n_names >= 8
