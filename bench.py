@@ -321,12 +321,12 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     from fastdem_amd import synth
 
-    if args.workload == "c5":
+    if args.workload == "c5" and world > 1:
         from fastdem_amd import tiling
         result = tiling.bench_global(args, rank, local_rank, world)
     else:
         kw = {"order": args.order} if args.workload in ("c2", "c4") else {}
-        if args.scans or args.workload == "c4":
+        if args.scans or args.workload in ("c4", "c5"):
             kw["n_scans"] = args.scans or LARGE_SCANS
         wl = synth.make(args.workload, **kw)
         res = Resident(wl, local_rank, args.wave_merge, args.overlap)

@@ -106,7 +106,6 @@ struct fdm_engine {
   int zero_copy = 1 << 30;
   int dbg_no_atomics = 0;
   int dbg_upd = 0;
-  int bin_threads = 0;               // k_bin4 block size (0 = auto, 128 / 256 / 512): 4 points per thread
   int bin_variant = 0;  // 0 = by scan size, 4 = k_bin4 (LDS-staged), 1 = k_bin (one point/thread)
   size_t bin_part_cap = 0;   // blocks
   unsigned last_bin_blocks = 0;
@@ -163,7 +162,6 @@ struct fdm_engine {
   int tiled = 1;                    // option "tiled": large scans go through per-tile record pools
   unsigned tiled_min = 65536;       // ... from this many points up
   bool tiled_forced = false;        // tiled_min was set by hand (option / FDM_TILED_MIN): no map-size condition
-  int tiled_threads = 0;            // 0 = by scan size, 256 / 512
   TileGrid TG{};
   TilePool pool[2] = {};            // by scan parity
   size_t pool_cap = 0;              // records per pool
@@ -579,13 +577,12 @@ int launch_tbin(fdm_engine* e, const ScanParams& P, const ScanInputs& in, const 
     hipLaunchKernelGGL(kern, dim3(bin_blocks), dim3(bv.threads), lds, e->stream, P, e->G, e->TG, e->d_state, in, e->S,
                        Q, ids);
   };
-#define FDM_TBIN(T, LN)                                           \
-  if (bv.has_int && bv.has_col) go(k_tbin<true, true, T, LN>);    \
-  else if (bv.has_int) go(k_tbin<true, false, T, LN>);            \
-  else if (bv.has_col) go(k_tbin<false, true, T, LN>);            \
-  else go(k_tbin<false, false, T, LN>);
-  if (bv.threads == 512u) { if (bv.lean == 1) { FDM_TBIN(512, true) } else { FDM_TBIN(512, false) } }
-  else { if (bv.lean == 1) { FDM_TBIN(256, true) } else { FDM_TBIN(256, false) } }
+#define FDM_TBIN(LN)                                               \
+  if (bv.has_int && bv.has_col) go(k_tbin<true, true, 256, LN>);    \
+  else if (bv.has_int) go(k_tbin<true, false, 256, LN>);            \
+  else if (bv.has_col) go(k_tbin<false, true, 256, LN>);            \
+  else go(k_tbin<false, false, 256, LN>);
+  if (bv.lean == 1) { FDM_TBIN(true) } else { FDM_TBIN(false) }
 #undef FDM_TBIN
   if (rc) return rc;
   HIPCK(hipGetLastError());
@@ -642,13 +639,12 @@ int launch_update_fused(fdm_engine* e, const fdm_engine::PendingUpdate& u, const
                              e->d_state, layers, e->d_layer_ptrs, e->n_layer_ptrs, u.Q, u.A, span, ub, Pb, Ib, Sb, Qb,
                              ids_b);
         };
-#define FDM_TF(T, LN)                                                              \
-        if (bv.has_int && bv.has_col) go(k_tupdate_tbin<POLICY, true, true, T, LN>);   \
-        else if (bv.has_int) go(k_tupdate_tbin<POLICY, true, false, T, LN>);           \
-        else if (bv.has_col) go(k_tupdate_tbin<POLICY, false, true, T, LN>);           \
-        else go(k_tupdate_tbin<POLICY, false, false, T, LN>);
-        if (bv.threads == 512u) { if (bv.lean == 1) { FDM_TF(512, true) } else { FDM_TF(512, false) } }
-        else { if (bv.lean == 1) { FDM_TF(256, true) } else { FDM_TF(256, false) } }
+#define FDM_TF(LN)                                                                  \
+        if (bv.has_int && bv.has_col) go(k_tupdate_tbin<POLICY, true, true, 256, LN>);   \
+        else if (bv.has_int) go(k_tupdate_tbin<POLICY, true, false, 256, LN>);           \
+        else if (bv.has_col) go(k_tupdate_tbin<POLICY, false, true, 256, LN>);           \
+        else go(k_tupdate_tbin<POLICY, false, false, 256, LN>);
+        if (bv.lean == 1) { FDM_TF(true) } else { FDM_TF(false) }
 #undef FDM_TF
         if (rc) return rc;
       } else {
@@ -665,42 +661,33 @@ int launch_update_fused(fdm_engine* e, const fdm_engine::PendingUpdate& u, const
                          e->d_layer_ptrs, e->n_layer_ptrs, u.S, u.in, unsigned(e->ncell), ub, Pb, Sb, Ib, ids_b);
     };
     if (!bv.bin4) {
-      if (!u.S.dense) {
-        bv.wave_merge ? go(k_update_bin<POLICY, true, true>, 256u) : go(k_update_bin<POLICY, false, true>, 256u);
-      } else if (!bv.wave_merge) {
-        go(k_update_bin<POLICY, false>, 256u);
-      } else if (bv.lean == 1) {  // channel tests folded at compile time, optional work compiled out
-        if (bv.has_int && bv.has_col) go(k_update_bin<POLICY, true, false, 3, 1>, 256u);
-        else if (bv.has_col) go(k_update_bin<POLICY, true, false, 2, 1>, 256u);
-        else if (bv.has_int) go(k_update_bin<POLICY, true, false, 1, 1>, 256u);
-        else go(k_update_bin<POLICY, true, false, 0, 1>, 256u);
-      } else if (bv.lean == 2) {  // ... but x / y / z written through to the engine's staging block
-        if (bv.has_int && bv.has_col) go(k_update_bin<POLICY, true, false, 3, 2>, 256u);
-        else if (bv.has_col) go(k_update_bin<POLICY, true, false, 2, 2>, 256u);
-        else if (bv.has_int) go(k_update_bin<POLICY, true, false, 1, 2>, 256u);
-        else go(k_update_bin<POLICY, true, false, 0, 2>, 256u);
-      } else if (bv.has_int && bv.has_col) {  // the bin half's channel tests folded at compile time
-        go(k_update_bin<POLICY, true, false, 3>, 256u);
-      } else if (bv.has_col) {
-        go(k_update_bin<POLICY, true, false, 2>, 256u);
-      } else if (bv.has_int) {
-        go(k_update_bin<POLICY, true, false, 1>, 256u);
-      } else {
-        go(k_update_bin<POLICY, true, false, 0>, 256u);
+      if (!u.S.dense) {  // stamp-gated maps: one generic variant
+        go(k_update_bin<POLICY, true, true>, 256u);
+      } else if (kRec && bv.lean == 1) {  // channel tests folded at compile time, optional work compiled out
+        if constexpr (kRec) {
+          if (bv.has_int && bv.has_col) go(k_update_bin<POLICY, true, false, 3, 1>, 256u);
+          else if (bv.has_col) go(k_update_bin<POLICY, true, false, 2, 1>, 256u);
+          else if (bv.has_int) go(k_update_bin<POLICY, true, false, 1, 1>, 256u);
+          else go(k_update_bin<POLICY, true, false, 0, 1>, 256u);
+        }
+      } else if (kRec && bv.lean == 2) {  // ... but x / y / z written through to the engine's staging block
+        if constexpr (kRec) {
+          if (bv.has_int && bv.has_col) go(k_update_bin<POLICY, true, false, 3, 2>, 256u);
+          else if (bv.has_col) go(k_update_bin<POLICY, true, false, 2, 2>, 256u);
+          else if (bv.has_int) go(k_update_bin<POLICY, true, false, 1, 2>, 256u);
+          else go(k_update_bin<POLICY, true, false, 0, 2>, 256u);
+        }
+      } else {  // everything else (captures, cell ids, per-layer layout ...): channels read from ScanParams
+        go(k_update_bin<POLICY, true, false>, 256u);
       }
     } else if constexpr (kRec) {
-#define FDM_FUSED4(T, ST, LN)                                                              \
-      if (bv.has_int && bv.has_col) go(k_update_bin4<POLICY, true, true, T, ST, LN>, T);   \
-      else if (bv.has_int) go(k_update_bin4<POLICY, true, false, T, ST, LN>, T);           \
-      else if (bv.has_col) go(k_update_bin4<POLICY, false, true, T, ST, LN>, T);           \
-      else go(k_update_bin4<POLICY, false, false, T, ST, LN>, T);
-#define FDM_FUSED4L(T, ST) if (bv.lean == 1) { FDM_FUSED4(T, ST, 1) } else if (bv.lean == 2) { FDM_FUSED4(T, ST, 2) } else { FDM_FUSED4(T, ST, 0) }
-      if (u.S.dense) {
-        if (bv.threads == 512u) { FDM_FUSED4L(512, false) } else { FDM_FUSED4L(256, false) }
-      } else {
-        if (bv.threads == 512u) { FDM_FUSED4L(512, true) } else { FDM_FUSED4L(256, true) }
-      }
-#undef FDM_FUSED4L
+      if (!u.S.dense) return fail(FDM_ERR_INVALID, "internal: k_bin4 fused with a stamp-gated update");
+#define FDM_FUSED4(LN)                                                                       \
+      if (bv.has_int && bv.has_col) go(k_update_bin4<POLICY, true, true, 256, false, LN>, 256u);   \
+      else if (bv.has_int) go(k_update_bin4<POLICY, true, false, 256, false, LN>, 256u);           \
+      else if (bv.has_col) go(k_update_bin4<POLICY, false, true, 256, false, LN>, 256u);           \
+      else go(k_update_bin4<POLICY, false, false, 256, false, LN>, 256u);
+      if (bv.lean == 1) { FDM_FUSED4(1) } else if (bv.lean == 2) { FDM_FUSED4(2) } else { FDM_FUSED4(0) }
 #undef FDM_FUSED4
     } else {
       return fail(FDM_ERR_INVALID, "internal: k_bin4 fused with a per-layer policy");
@@ -841,13 +828,10 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   // k_bin4 trades latency for fewer memory-side atomics: worth it from ~64 K points up
   const bool want4 = e->bin_variant == 4 || (e->bin_variant == 0 && n >= 65536);
   const bool use_bin4 = !tiled && want4 && aligned;
-  // block size of the 4-points-per-thread kernels: 0 = by scan size.  2048-point blocks (512 threads) merge
-  // ~20 % more cells on chip for firing-order LiDAR scans; smaller scans keep more blocks in flight.
-  const int bt_opt = tiled ? e->tiled_threads : e->bin_threads;
-  // (the tiled kernels: 256-thread blocks throughout — four resident blocks per CU instead of two, C4 fused
-  // launch 44.9 against 46.4 us)
-  const int bt = bt_opt ? bt_opt : (!tiled && n >= (1u << 20) ? 512 : 256);
-  const unsigned bin_threads = (use_bin4 || tiled) ? unsigned(bt) : 256u;
+  // 4-points-per-thread kernels: 256-thread blocks (1024 points).  (2048-point blocks merged ~20 % more cells on
+  // chip when every merged cell still cost memory-side atomics; with the record pools four resident blocks per
+  // CU beat two: C4 fused launch 44.9 against 46.4 us.)
+  const unsigned bin_threads = 256u;
   const unsigned per_block = (use_bin4 || tiled) ? bin_threads * 4u : 256u;
   const unsigned bin_blocks = n ? unsigned((n + per_block - 1) / per_block) : 1u;
   if (bin_blocks > e->bin_part_cap) {
@@ -870,13 +854,11 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   const ScanInputs in_b{dx, dy, dz, dint, drgb, dvar};
   // a scan that asks for nothing optional takes the LEAN bin body (fdm_kernels.hpp)
   // (2: lean, but x / y / z written through for the held-back update's gather)
-  const int lean = (ids || e->S.cap_x || P.drop_nonfinite || P.dbg_no_atomics || e->S.wt_var || e->S.wt_rgb) ? 0
-                   : (e->S.wt_x ? 2 : 1);
+  const int lean = (ids || e->S.cap_x || P.drop_nonfinite || P.dbg_no_atomics) ? 0 : (e->S.wt_x ? 2 : 1);
   const fdm_engine::BinVariant bv{use_bin4, P.has_intensity != 0, P.has_color != 0, e->wave_merge, bin_threads, lean};
   // a held-back update leaves now: fused with this bin if the two belong to the same pipeline and
   // this scan is a plain one, alone otherwise
-  const bool fusable = tiled ? (bin_threads == 256 || bin_threads == 512)
-                             : (!use_bin4 || ((bin_threads == 256 || bin_threads == 512) && e->rec_kind >= 0));
+  const bool fusable = tiled || ((!use_bin4 || (e->rec_kind >= 0 && e->S.dense)) && e->wave_merge);
   const bool fuse_now = e->chain && plain && fusable && e->pend.tiled == tiled;
   if (e->chain && !fuse_now && (rc = join_streams(e))) return rc;
   P.chain_prev = 0;
@@ -896,15 +878,10 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
       hipLaunchKernelGGL(kern, dim3(bin_blocks), dim3(bin_threads), 0, e->stream, P, e->G, e->d_state, dx,
                          dy, dz, dint, e->S, ids);
     };
-#define FDM_BIN4(T)                                         \
-    if (hi && hc) launch4(k_bin4<true, true, T>);           \
-    else if (hi) launch4(k_bin4<true, false, T>);           \
-    else if (hc) launch4(k_bin4<false, true, T>);           \
-    else launch4(k_bin4<false, false, T>);
-    if (bin_threads == 128) { FDM_BIN4(128) }
-    else if (bin_threads == 512) { FDM_BIN4(512) }
-    else { FDM_BIN4(256) }
-#undef FDM_BIN4
+    if (hi && hc) launch4(k_bin4<true, true, 256>);
+    else if (hi) launch4(k_bin4<true, false, 256>);
+    else if (hc) launch4(k_bin4<false, true, 256>);
+    else launch4(k_bin4<false, false, 256>);
   } else {
     auto launch_bin = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(bin_blocks), dim3(256), 0, e->stream, P, e->G, e->d_state, dx, dy,
@@ -1969,12 +1946,6 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
     e->dbg_ray = value;
     return FDM_OK;
   }
-  if (std::strcmp(key, "bin_threads") == 0) {
-    if (value != 0 && value != 128 && value != 256 && value != 512)
-      return fail(FDM_ERR_INVALID, "bin_threads must be 0 (auto), 128, 256 or 512");
-    e->bin_threads = value;
-    return FDM_OK;
-  }
   if (std::strcmp(key, "tiled") == 0) {  // large scans through per-tile record pools (1, default) or the per-cell scratch (0)
     e->tiled = value != 0;
     return FDM_OK;
@@ -1987,11 +1958,6 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
     if (value < 0) return fail(FDM_ERR_INVALID, "tiled_min: a point count");
     e->tiled_min = unsigned(value);
     e->tiled_forced = true;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "tiled_threads") == 0) {
-    if (value != 0 && value != 256 && value != 512) return fail(FDM_ERR_INVALID, "tiled_threads must be 0 (auto), 256 or 512");
-    e->tiled_threads = value;
     return FDM_OK;
   }
   if (std::strcmp(key, "bin_variant") == 0) {

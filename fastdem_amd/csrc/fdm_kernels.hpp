@@ -200,8 +200,8 @@ __device__ __forceinline__ void bin4_body(const ScanParams& P, const GeomConst& 
                                           int32_t* __restrict__ cell_ids, const unsigned bid) {
   // LEAN (the fused launches of a plain scan): captures, write-through, cell ids, the non-finite filter and
   // the measurement switches are compiled out — dormant, they still cost 3-7 % of the launch.
-  // LEAN == 2 keeps the write-through of x / y / z (a held-back update gathers from the engine's copy, so
-  // the caller's arrays are free as soon as this kernel has run).
+  // LEAN == 2 keeps the write-through (a held-back update gathers from the engine's copy, so the caller's
+  // arrays are free as soon as this kernel has run).
   float* const cap_x = LEAN ? nullptr : S.cap_x;
   float* const cap_var = LEAN ? nullptr : S.cap_var;
   float* const wt_x = LEAN == 1 ? nullptr : S.wt_x;
@@ -249,8 +249,8 @@ __device__ __forceinline__ void bin4_body(const ScanParams& P, const GeomConst& 
     for (int j = 0; j < 4; ++j) {
       if (i0 + j >= P.n) break;
       wt_x[i0 + j] = xs[j]; S.wt_y[i0 + j] = ys[j]; S.wt_z[i0 + j] = zs[j];
-      if (LEAN != 2 && S.wt_var) S.wt_var[i0 + j] = S.wt_src_var[i0 + j];
-      if (LEAN != 2 && S.wt_rgb) S.wt_rgb[i0 + j] = S.wt_src_rgb[i0 + j];
+      if (S.wt_var) S.wt_var[i0 + j] = S.wt_src_var[i0 + j];
+      if (S.wt_rgb) S.wt_rgb[i0 + j] = S.wt_src_rgb[i0 + j];
     }
   }
   for (int k = threadIdx.x; k < kHashSlots; k += THREADS) {
@@ -391,8 +391,8 @@ __device__ __forceinline__ void bin_body(const ScanParams& P, const GeomConst& G
                                          int32_t* __restrict__ cell_ids, const unsigned bid) {
   // LEAN (the fused launches of a plain scan): captures, write-through, cell ids, the non-finite filter and
   // the measurement switches are compiled out — dormant, they still cost 3-7 % of the launch.
-  // LEAN == 2 keeps the write-through of x / y / z (a held-back update gathers from the engine's copy, so
-  // the caller's arrays are free as soon as this kernel has run).
+  // LEAN == 2 keeps the write-through (a held-back update gathers from the engine's copy, so the caller's
+  // arrays are free as soon as this kernel has run).
   float* const cap_x = LEAN ? nullptr : S.cap_x;
   float* const cap_var = LEAN ? nullptr : S.cap_var;
   float* const wt_x = LEAN == 1 ? nullptr : S.wt_x;
@@ -424,8 +424,8 @@ __device__ __forceinline__ void bin_body(const ScanParams& P, const GeomConst& G
     if (has_int) vint = pint[i];
     if (wt_x) {  // leave the raw scan in HBM for the update kernel (see Scratch::wt_x)
       wt_x[i] = x; S.wt_y[i] = y; S.wt_z[i] = z;
-      if (LEAN != 2 && S.wt_var) S.wt_var[i] = S.wt_src_var[i];
-      if (LEAN != 2 && S.wt_rgb) S.wt_rgb[i] = S.wt_src_rgb[i];
+      if (S.wt_var) S.wt_var[i] = S.wt_src_var[i];
+      if (S.wt_rgb) S.wt_rgb[i] = S.wt_src_rgb[i];
     }
   }
   const DevCand cand = block_candidate(P, G, st, &s_cand, bid);

@@ -823,7 +823,11 @@ __device__ __forceinline__ void tupdate_body(
   __shared__ unsigned s_nch[kGroups][64];
   const unsigned g = threadIdx.x >> 8, lt = threadIdx.x & 255u;
   unsigned char* const lds = dyn_lds + size_t(g) * tile_lds_bytes(P.has_intensity != 0, P.has_color != 0);
-  const unsigned first = (bid * kGroups + g) * span;
+  // slot q of group i is tile i + q * n_groups: the tiles a scan touches are neighbours in the map (and in tile
+  // order), so consecutive slots would put all of them into a few groups that then walk them one after the
+  // other (configs[4] on one GPU: 209 us); strided, the live tiles spread over all groups
+  const unsigned n_groups = (TG.n_tiles + span - 1u) / span;
+  const unsigned first = bid * kGroups + g;
 
   // round trip 1: the tile's descriptor row (span 1) or the chunk counts of the group's tiles, the
   // stamps, and the scan context
@@ -835,8 +839,8 @@ __device__ __forceinline__ void tupdate_body(
     bool live = false, ob = false;
     unsigned nch = 0;
     if (lt < span) {
-      const unsigned tile = first + lt;
-      if (tile < TG.n_tiles) {
+      const unsigned tile = first + lt * n_groups;
+      if (first < n_groups && tile < TG.n_tiles) {  // (a surplus group of the grid's last block owns nothing)
         nch = span == 1u ? unsigned(d0) : unsigned(Q.desc[size_t(tile) * Q.stride]);
         const unsigned stamp = A.stamp[tile];
         ob = u.do_update && (nch != 0u || stamp == u.ob_scan);
@@ -857,7 +861,7 @@ __device__ __forceinline__ void tupdate_body(
     const unsigned q = unsigned(__ffsll((long long)any)) - 1u;
     any &= any - 1ull;
     const bool mine = (s_live[g] >> q) & 1ull;
-    const unsigned tile = first + q;
+    const unsigned tile = first + q * n_groups;
     const unsigned nch = mine ? s_nch[g][q] : 0u;
     unsigned nmax = 0u;  // the block's groups walk the barriers of tupdate_tile together
 #pragma unroll
