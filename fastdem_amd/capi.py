@@ -163,6 +163,7 @@ PROTOTYPES = {
                                            C.POINTER(C.c_char_p), C.c_int, _P]),
     "fdm_engine_capture": (C.c_int, [_P, C.c_int, C.c_int]),
     "fdm_engine_last_preprocessed": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, C.POINTER(C.c_uint64)]),
+    "fdm_engine_last_preprocessed_cov": (C.c_int, [_P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
     "fdm_engine_last_rasterized": (C.c_int, [_P, C.c_uint64, _P, _P, _P, C.POINTER(C.c_uint64)]),
     "fdm_engine_apply_raycasting": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _F, C.POINTER(FdmRaycastConfig)]),
     "fdm_engine_apply_raycasting_device": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _F,

@@ -226,15 +226,18 @@ class FastDEM {
     detail::ck(rc, "fdm_engine_integrate");
     map_.invalidateHost();
     if (rc != FDM_OK) return false;  // FDM_SKIP_ALL_FILTERED == `if (points.empty()) return false`
-    if (on_preprocessed_) on_preprocessed_(fetch(true, cloud.size()));              // fastdem.cpp:139-141
+    if (on_preprocessed_) {                                                         // fastdem.cpp:139-141
+      R_last_ = (T_world_base * T_base_sensor).rotation().cast<float>();
+      on_preprocessed_(fetch(true, cloud.size(), &cloud));
+    }
     if (on_rasterized_ && last_.n_cells_touched > 0) on_rasterized_(fetch(false, last_.n_cells_touched));  // :148-150
     return true;
   }
   void syncCapture() {
-    detail::ck(fdm_engine_capture(map_.engine(), on_preprocessed_ ? 1 : 0, on_rasterized_ ? 1 : 0),
+    detail::ck(fdm_engine_capture(map_.engine(), on_preprocessed_ ? 2 : 0, on_rasterized_ ? 1 : 0),
                "fdm_engine_capture");
   }
-  PointCloud fetch(bool preprocessed, size_t cap) {
+  PointCloud fetch(bool preprocessed, size_t cap, const PointCloud* src = nullptr) {
     std::vector<float> x(cap), y(cap), z(cap);
     uint64_t n = 0;
     if (preprocessed)
@@ -246,6 +249,30 @@ class FastDEM {
     PointCloud out;
     out.reserve(n);
     for (uint64_t i = 0; i < n && i < cap; ++i) out.add(x[i], y[i], z[i]);
+    if (preprocessed) {  // the reference's preprocessed cloud carries the rotated covariances (fastdem.cpp:182-187)
+      out.useCovariance();
+      SensorType builtin;
+      if (!sensor_model_ || sensor_model_->builtin(builtin)) {
+        uint64_t nc = 0;
+        detail::ck(fdm_engine_last_preprocessed_cov(map_.engine(), out.size(), out.covarianceData(), &nc),
+                   "fdm_engine_last_preprocessed_cov");
+      } else if (src) {
+        // user SensorModel subclass: the device only ever saw sigma_z^2; R * Sigma * R^T of the surviving
+        // points is evaluated here, in the reference's order (M = R * Sigma, then M * R^T)
+        std::vector<int32_t> ids(src->size());
+        detail::ck(fdm_engine_last_cell_ids(map_.engine(), ids.data(), ids.size()), "fdm_engine_last_cell_ids");
+        const Eigen::Matrix3f Rt = R_last_.transpose();
+        size_t w = 0;
+        float* dst = out.covarianceData();
+        for (size_t i = 0; i < src->size() && w < out.size(); ++i) {
+          if (ids[i] == -1) continue;  // dropped by cropRange / cropZ
+          const Eigen::Matrix3f C = (R_last_ * sensor_model_->computeCovariance(src->point(i))) * Rt;
+          for (int c = 0; c < 3; ++c)
+            for (int r = 0; r < 3; ++r) dst[w * 9 + size_t(c) * 3 + size_t(r)] = C(r, c);
+          ++w;
+        }
+      }
+    }
     out.setFrameId(map_.getFrameId());
     return out;
   }
@@ -258,6 +285,7 @@ class FastDEM {
   std::shared_ptr<Odometry> odometry_;
   CloudCallback on_preprocessed_, on_rasterized_;
   std::vector<float> sigma_;
+  Eigen::Matrix3f R_last_;
   fdm_scan_stats last_{};
 };
 

@@ -73,6 +73,7 @@ class PointCloud {
     x_.resize(n); y_.resize(n); z_.resize(n);
     if (use_intensity_) intensity_.resize(n);
     if (use_color_) rgb_.resize(n);
+    if (use_cov_) cov_.resize(n * 9);
   }
   void clear() { resize(0); }
 
@@ -80,6 +81,7 @@ class PointCloud {
     x_.push_back(x); y_.push_back(y); z_.push_back(z);
     if (use_intensity_) intensity_.push_back(0.0f);
     if (use_color_) rgb_.push_back(0u);
+    if (use_cov_) cov_.resize(cov_.size() + 9, 0.0f);
   }
   void add(float x, float y, float z, Intensity i) {
     if (!use_intensity_) useIntensity();
@@ -99,6 +101,18 @@ class PointCloud {
   void useIntensity() { use_intensity_ = true; intensity_.resize(size(), 0.0f); }
   float& intensity(size_t i) { return intensity_[i]; }
   float intensity(size_t i) const { return intensity_[i]; }
+
+  // covariance channel (nanopcl/core/point_cloud.hpp:126-147): the cloud the preprocessed-scan callback
+  // receives carries R * Sigma_sensor * R^T per point
+  bool hasCovariance() const { return use_cov_; }
+  void useCovariance() { use_cov_ = true; cov_.resize(size() * 9, 0.0f); }
+  Eigen::Matrix3f covariance(size_t i) const {
+    Eigen::Matrix3f m;
+    for (int c = 0; c < 3; ++c)
+      for (int r = 0; r < 3; ++r) m(r, c) = cov_[i * 9 + size_t(c) * 3 + size_t(r)];
+    return m;
+  }
+  float* covarianceData() { return use_cov_ ? cov_.data() : nullptr; }  // [n][9], column-major 3x3 per point
 
   bool hasColor() const { return use_color_; }
   void useColor() { use_color_ = true; rgb_.resize(size(), 0u); }
@@ -121,9 +135,10 @@ class PointCloud {
   static uint32_t pack(const Color& c) { return (uint32_t(c.r) << 16) | (uint32_t(c.g) << 8) | uint32_t(c.b); }
   HostVector<float> x_, y_, z_, intensity_;
   HostVector<uint32_t> rgb_;  // 0x00RRGGBB
+  std::vector<float> cov_;
   std::string frame_id_;
   uint64_t timestamp_ns_ = 0;
-  bool use_intensity_ = false, use_color_ = false;
+  bool use_intensity_ = false, use_color_ = false, use_cov_ = false;
 };
 
 }  // namespace nanopcl

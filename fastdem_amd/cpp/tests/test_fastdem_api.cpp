@@ -234,11 +234,20 @@ TEST(FastDEMIntegration, ScanCallbacksFire) {  // :320-353
   bool pre = false, ras = false;
   size_t n_pre = 0, n_ras = 0;
   float z_ras = 0.f;
-  mapper.onScanPreprocessed([&](const PointCloud& c) { pre = true; n_pre = c.size(); });
+  bool has_cov = false;
+  float c22 = -1.f, c00 = -1.f;
+  mapper.onScanPreprocessed([&](const PointCloud& c) {
+    pre = true; n_pre = c.size();
+    has_cov = c.hasCovariance();                       // fastdem.cpp:182-187: the cloud carries R Sigma R^T
+    if (has_cov && c.size()) { c22 = c.covariance(0)(2, 2); c00 = c.covariance(0)(0, 0); }
+  });
   mapper.onScanRasterized([&](const PointCloud& c) { ras = true; n_ras = c.size(); z_ras = c.point(0)[2]; });
   mapper.integrate(makeGroundCloud(1.0f), f.T_base_sensor, f.T_world_base);
   EXPECT_TRUE(pre);
   EXPECT_EQ(n_pre, size_t(49));
+  EXPECT_TRUE(has_cov);
+  EXPECT_GT(c22, 0.0f);
+  EXPECT_GT(c00, 0.0f);
   EXPECT_TRUE(ras);
   EXPECT_EQ(n_ras, size_t(mapper.lastStats().n_cells_touched));
   EXPECT_GT(n_ras, 0u);

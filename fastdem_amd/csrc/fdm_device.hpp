@@ -230,9 +230,8 @@ __device__ __forceinline__ bool in_cleared_strip(int b, int start, int sh, int s
   return d < n;
 }
 
-// sigma_z^2 = (R * Sigma_sensor * R^T)(2,2) for one point in the SENSOR frame.
-__device__ __forceinline__ float sigma_z2(const ScanParams& P, float x, float y, float z) {
-  float S[9];  // column-major
+// Sigma_sensor of one point in the SENSOR frame (column-major 3x3): SensorModel::computeCovariance.
+__device__ __forceinline__ void sensor_cov(const ScanParams& P, float x, float y, float z, float* S) {
   if (P.sensor_type == 1) {  // LiDAR, lidar_model.hpp:64-89
     const float dist_sq = sum3(x * x, y * y, z * z);
     if (dist_sq < 1e-6f) {
@@ -281,6 +280,12 @@ __device__ __forceinline__ float sigma_z2(const ScanParams& P, float x, float y,
     for (int k = 0; k < 9; ++k) S[k] = 0.0f * v;
     S[0] = v; S[4] = v; S[8] = v;
   }
+}
+
+// sigma_z^2 = (R * Sigma_sensor * R^T)(2,2) for one point in the SENSOR frame.
+__device__ __forceinline__ float sigma_z2(const ScanParams& P, float x, float y, float z) {
+  float S[9];  // column-major
+  sensor_cov(P, x, y, z, S);
   // M = R*S (row 2 only), out(2,2) = M(2,:) . R(2,:)   — 3-term dots a0b0 + (a1b1 + a2b2)
   const float* R = P.R;
   float M2[3];
@@ -288,6 +293,25 @@ __device__ __forceinline__ float sigma_z2(const ScanParams& P, float x, float y,
   for (int j = 0; j < 3; ++j)
     M2[j] = sum3(R[0 * 3 + 2] * S[j * 3 + 0], R[1 * 3 + 2] * S[j * 3 + 1], R[2 * 3 + 2] * S[j * 3 + 2]);
   return sum3(M2[0] * R[0 * 3 + 2], M2[1] * R[1 * 3 + 2], M2[2] * R[2 * 3 + 2]);
+}
+
+// The whole R * Sigma_sensor * R^T (column-major), fastdem.cpp:182-187: M = R*Sigma to a temporary, then
+// M*R^T, every coefficient a 3-term dot a0b0 + (a1b1 + a2b2).  Only evaluated for the preprocessed-scan
+// callback's cloud, which carries the covariance channel (nanopcl/core/point_cloud.hpp:126-147).
+__device__ __forceinline__ void cov_full(const ScanParams& P, float x, float y, float z, float* out) {
+  float S[9], M[9];
+  sensor_cov(P, x, y, z, S);
+  const float* R = P.R;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      M[j * 3 + i] = sum3(R[0 * 3 + i] * S[j * 3 + 0], R[1 * 3 + i] * S[j * 3 + 1], R[2 * 3 + i] * S[j * 3 + 2]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      out[j * 3 + i] = sum3(M[0 * 3 + i] * R[0 * 3 + j], M[1 * 3 + i] * R[1 * 3 + j], M[2 * 3 + i] * R[2 * 3 + j]);
 }
 
 // ---- estimators (one update per touched cell) ----

@@ -120,6 +120,7 @@ struct fdm_engine {
   int rec_floats = 0;
   float* d_tmp = nullptr;           // ncell floats: contiguous staging for strided layer transfers
   bool cap_pre = false, cap_ras = false;  // scan-callback captures
+  bool cap_cov = false;                   // ... the preprocessed cloud with its 3x3 covariance channel
   float* d_cap = nullptr;            // 4 channels x cap_cap points
   size_t cap_cap = 0;
   float* d_ras = nullptr;            // ncell
@@ -750,7 +751,8 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   if ((rc = refresh_layer_ptrs(e))) return rc;
   if ((rc = ensure_ids(e, n))) return rc;
   // scan-callback captures (off unless fdm_engine_capture enabled them)
-  e->S.cap_x = e->S.cap_y = e->S.cap_z = e->S.cap_var = nullptr;
+  e->S.cap_x = e->S.cap_y = e->S.cap_z = e->S.cap_var = e->S.cap_cov = nullptr;
+  e->S.cap_stride = 0;
   e->S.ras_z = nullptr;
   e->S.cap_drop_nan = ray_on ? 1 : 0;
   e->S.wt_x = e->S.wt_y = e->S.wt_z = e->S.wt_var = nullptr;
@@ -769,12 +771,13 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
       if (int rc_sync = sync_all(e)) return rc_sync;
       if (e->d_cap) HIPCK(hipFree(e->d_cap));
       e->cap_cap = n + n / 4 + 1024;
-      HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_cap), e->cap_cap * 4 * sizeof(float)));
+      HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_cap), e->cap_cap * 13 * sizeof(float)));  // x y z var + 9 cov
     }
     e->S.cap_x = e->d_cap;
     e->S.cap_y = e->d_cap + e->cap_cap;
     e->S.cap_z = e->d_cap + 2 * e->cap_cap;
     if (e->cap_pre) e->S.cap_var = e->d_cap + 3 * e->cap_cap;
+    if (e->cap_pre && e->cap_cov) { e->S.cap_cov = e->d_cap + 4 * e->cap_cap; e->S.cap_stride = e->cap_cap; }
   }
   if (e->cap_ras) {
     if (!e->d_ras) HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_ras), e->ncell * sizeof(float)));
@@ -1815,6 +1818,7 @@ int fdm_engine_capture(fdm_engine* e, int preprocessed, int rasterized) {
   if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
   e->cap_pre = preprocessed != 0;
+  e->cap_cov = preprocessed == 2;
   e->cap_ras = rasterized != 0;
   if (e->cap_pre) e->want_ids = true;  // the per-point pass flag rides on the cell-id buffer
   return FDM_OK;
@@ -1843,6 +1847,30 @@ int fdm_engine_last_preprocessed(fdm_engine* e, uint64_t cap, float* x, float* y
       if (z) z[w] = h[2 * n + i];
       if (sigma_z2) sigma_z2[w] = h[3 * n + i];
     }
+    ++w;
+  }
+  *n_out = w;
+  return FDM_OK;
+}
+
+int fdm_engine_last_preprocessed_cov(fdm_engine* e, uint64_t cap, float* cov9, uint64_t* n_out) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
+  if (!e || !n_out || !cov9) return fail(FDM_ERR_INVALID, "null argument");
+  *n_out = 0;
+  if (!e->cap_pre || !e->cap_cov) return fail(FDM_ERR_INVALID, "covariance capture is off (fdm_engine_capture(e, 2, ..))");
+  const size_t n = e->last_n;
+  if (!e->have_scan || n == 0 || !e->d_cap || !e->d_cell_ids) return FDM_OK;
+  if (int rc_sync = sync_all(e)) return rc_sync;
+  std::vector<float> h(9 * n);
+  std::vector<int32_t> ids(n);
+  for (int c = 0; c < 9; ++c)
+    HIPCK(hipMemcpy(h.data() + c * n, e->d_cap + (4 + c) * e->cap_cap, n * sizeof(float), hipMemcpyDeviceToHost));
+  HIPCK(hipMemcpy(ids.data(), e->d_cell_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  uint64_t w = 0;
+  for (size_t i = 0; i < n; ++i) {  // the same order-preserving compaction as fdm_engine_last_preprocessed
+    if (ids[i] == -1) continue;
+    if (w < cap)
+      for (int c = 0; c < 9; ++c) cov9[w * 9 + c] = h[c * n + i];
     ++w;
   }
   *n_out = w;

@@ -58,6 +58,8 @@ struct Scratch {
   float* cap_y;
   float* cap_z;
   float* cap_var;                // [n] sigma_z^2 of every input point (nullable on its own)
+  float* cap_cov;                // [9][cap_stride] full R Sigma R^T of every input point (nullable on its own)
+  size_t cap_stride;
   int cap_drop_nan;              // 1: a point the crops dropped is stored with x = NaN (ray stage input)
   float* ras_z;                  // [cells] min z observed by this scan (NaN = not observed)
   // optional write-through (fdm_engine_integrate_async on PINNED host arrays): the bin kernel reads
@@ -275,6 +277,12 @@ __device__ __forceinline__ void bin4_body(const ScanParams& P, const GeomConst& 
     const bool live = i0 + j < P.n;
     float cvar = 0.f;
     if (cap_var && live && P.integrate_mode) cvar = sigma_z2(P, xs[j], ys[j], zs[j]);
+    if (!LEAN && cap_var && S.cap_cov && live && P.integrate_mode) {
+      float c9[9];
+      cov_full(P, xs[j], ys[j], zs[j], c9);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) S.cap_cov[size_t(k) * S.cap_stride + i0 + j] = c9[k];
+    }
     const bool exists = live && (!drop_nf || (isfinite(xs[j]) && isfinite(ys[j]) && isfinite(zs[j])));
     const bool pass = preprocess_point(P, xs[j], ys[j], zs[j]) && exists;
     if (cap_x && live) {
@@ -435,6 +443,12 @@ __device__ __forceinline__ void bin_body(const ScanParams& P, const GeomConst& G
   if (i < P.n) {
     float cvar = 0.f;
     if (cap_var && P.integrate_mode) cvar = sigma_z2(P, x, y, z);
+    if (!LEAN && cap_var && S.cap_cov && P.integrate_mode) {
+      float c9[9];
+      cov_full(P, x, y, z, c9);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) S.cap_cov[size_t(k) * S.cap_stride + i] = c9[k];
+    }
     const bool exists = !drop_nf || (isfinite(x) && isfinite(y) && isfinite(z));
     pass = preprocess_point(P, x, y, z) && exists;
     if (cap_x) {

@@ -197,6 +197,12 @@ __device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& 
     const bool live = i0 + j < P.n;
     float cvar = 0.f;
     if (cap_var && live && P.integrate_mode) cvar = sigma_z2(P, xs[j], ys[j], zs[j]);
+    if (!LEAN && cap_var && S.cap_cov && live && P.integrate_mode) {
+      float c9[9];
+      cov_full(P, xs[j], ys[j], zs[j], c9);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) S.cap_cov[size_t(k) * S.cap_stride + i0 + j] = c9[k];
+    }
     const bool exists = live && (!drop_nf || (isfinite(xs[j]) && isfinite(ys[j]) && isfinite(zs[j])));
     pass[j] = preprocess_point(P, xs[j], ys[j], zs[j]) && exists;
     if (cap_x && live) {

@@ -418,6 +418,13 @@ class Engine:
         _ck(self._lib.fdm_engine_last_preprocessed(self._h, cap, *[_ptr(v) for v in a], C.byref(n)))
         return [v[:n.value] for v in a]
 
+    def last_preprocessed_cov(self, cap):
+        """(n, 3, 3) covariance channel of the preprocessed cloud (capture(preprocessed=2))."""
+        a = np.empty((cap, 9), dtype=np.float32)
+        n = C.c_uint64(0)
+        _ck(self._lib.fdm_engine_last_preprocessed_cov(self._h, cap, _ptr(a), C.byref(n)))
+        return a[:n.value].reshape(-1, 3, 3).transpose(0, 2, 1)  # column-major 3x3 per point
+
     def last_rasterized(self, cap):
         a = [np.empty(cap, dtype=np.float32) for _ in range(3)]
         n = C.c_uint64(0)

@@ -230,8 +230,14 @@ int fdm_engine_region_unpack(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, 
  *   last_rasterized:   the cloud handed to onScanRasterized — one point per observed cell at the
  *     cell centre (GridMap::getPosition) with z = min_z (fastdem.cpp:200-214); order unspecified,
  *     as in the reference (hash-map iteration order).
- * Both return the number of points through n_out; `cap` is the capacity of the output arrays. */
+ * Both return the number of points through n_out; `cap` is the capacity of the output arrays.
+ * preprocessed == 2 also keeps the cloud's covariance channel (the reference's preprocessed cloud carries the
+ * rotated 3x3 covariance of every point, nanopcl/core/point_cloud.hpp:126-147). */
 int fdm_engine_capture(fdm_engine* e, int preprocessed, int rasterized);
+/* The covariance channel of the preprocessed cloud: R * Sigma_sensor * R^T per surviving point
+ * (fastdem.cpp:182-187), 9 floats per point, column-major like Eigen::Matrix3f, same order as
+ * fdm_engine_last_preprocessed.  Needs fdm_engine_capture(e, 2, ..). */
+int fdm_engine_last_preprocessed_cov(fdm_engine* e, uint64_t cap, float* cov9, uint64_t* n_out);
 int fdm_engine_last_preprocessed(fdm_engine* e, uint64_t cap, float* x, float* y, float* z,
                                  float* sigma_z2, uint64_t* n_out);
 int fdm_engine_last_rasterized(fdm_engine* e, uint64_t cap, float* x, float* y, float* z,

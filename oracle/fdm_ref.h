@@ -93,6 +93,8 @@ int fdmref_last_cell_ids(void* e, int32_t* out, uint64_t n);
 /* scan callbacks: keep the preprocessed cloud / rasterized observations of the last integrate() */
 void fdmref_keep_scan(void* e, int on);
 uint64_t fdmref_last_preprocessed(void* e, uint64_t cap, float* x, float* y, float* z, float* var);
+/* the covariance channel of that cloud, 9 floats per point, column-major */
+uint64_t fdmref_last_preprocessed_cov(void* e, uint64_t cap, float* cov9);
 uint64_t fdmref_last_rasterized(void* e, uint64_t cap, float* x, float* y, float* z);
 
 /* raycasting stage (fdm_ref_raycast.hpp).  stats5 = {n_rays, n_observed, n_ray_cells, n_conflicts,

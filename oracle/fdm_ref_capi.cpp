@@ -211,6 +211,12 @@ uint64_t fdmref_last_preprocessed(void* e, uint64_t cap, float* x, float* y, flo
   }
   return c.size();
 }
+uint64_t fdmref_last_preprocessed_cov(void* e, uint64_t cap, float* cov9) {
+  const Cloud& c = E(e)->last_preprocessed;
+  for (uint64_t i = 0; i < c.size() && i < cap; ++i)
+    for (int k = 0; k < 9; ++k) cov9[i * 9 + k] = c.cov[i][k];
+  return c.size();
+}
 uint64_t fdmref_last_rasterized(void* e, uint64_t cap, float* x, float* y, float* z) {
   const auto& r = E(e)->last_rasterized;
   for (uint64_t i = 0; i < r.size() && i < cap; ++i) {

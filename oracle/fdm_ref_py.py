@@ -125,6 +125,8 @@ def load(native=False):
     lib.fdmref_keep_scan.argtypes = [P, C.c_int]
     lib.fdmref_last_preprocessed.restype = C.c_uint64
     lib.fdmref_last_preprocessed.argtypes = [P, C.c_uint64, P, P, P, P]
+    lib.fdmref_last_preprocessed_cov.restype = C.c_uint64
+    lib.fdmref_last_preprocessed_cov.argtypes = [P, C.c_uint64, P]
     lib.fdmref_last_rasterized.restype = C.c_uint64
     lib.fdmref_last_rasterized.argtypes = [P, C.c_uint64, P, P, P]
     lib.fdmref_apply_inpainting.argtypes = [P, C.c_int, C.c_int, C.c_int]
@@ -312,6 +314,11 @@ class RefEngine:
         a = [np.empty(cap, dtype=np.float32) for _ in range(4)]
         n = self._lib.fdmref_last_preprocessed(self._h, cap, *[_ptr(v) for v in a])
         return [v[:n] for v in a]
+
+    def last_preprocessed_cov(self, cap):
+        a = np.empty((cap, 9), dtype=np.float32)
+        n = self._lib.fdmref_last_preprocessed_cov(self._h, cap, _ptr(a))
+        return a[:n].reshape(-1, 3, 3).transpose(0, 2, 1)
 
     def last_rasterized(self, cap):
         a = [np.empty(cap, dtype=np.float32) for _ in range(3)]

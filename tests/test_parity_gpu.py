@@ -474,11 +474,11 @@ def test_tiled_engines_with_halo_exchange_match_single_map(gpu, R):
 @pytest.mark.parametrize("big", [False, True])
 def test_scan_callback_clouds_match_the_reference(gpu, R, big):
     """onScanPreprocessed / onScanRasterized payloads (fastdem.cpp:139-150, 200-214): the
-    preprocessed cloud is bit-identical in input order incl. cov(2,2); the rasterized cloud is the
+    preprocessed cloud is bit-identical in input order incl. its 3x3 covariance channel; the rasterized cloud is the
     same SET of (cell centre, min_z) points (the reference's order is hash-map order)."""
     wl = gpu.synth.lidar128(n_scans=3, n_az=1024) if big else gpu.synth.vlp16(n_scans=3)
     eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
-    eng.capture(True, True)
+    eng.capture(2, True)  # 2: the preprocessed cloud with its 3x3 covariance channel, as the reference hands it over
     ref.capture(True)
     for k in range(3):
         run_both(eng, ref, wl.scan(k), wl.T_base_sensor, wl.pose(k))
@@ -487,6 +487,10 @@ def test_scan_callback_clouds_match_the_reference(gpu, R, big):
         assert pe[0].size == pr[0].size > 0
         for a, b, name in zip(pe, pr, "xyzv"):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"preprocessed {name} differs"
+        ce, cr = eng.last_preprocessed_cov(n), ref.last_preprocessed_cov(n)
+        assert ce.shape == cr.shape == (pe[0].size, 3, 3)
+        assert np.array_equal(ce.view(np.uint32), cr.view(np.uint32)), "R Sigma R^T differs"
+        assert np.array_equal(ce[:, 2, 2].view(np.uint32), pe[3].view(np.uint32))
         re_, rr = eng.last_rasterized(eng.rows * eng.cols), ref.last_rasterized(eng.rows * eng.cols)
         assert re_[0].size == rr[0].size == eng.last_stats()[1]["n_cells_touched"]
         se = sorted(zip(*[v.tolist() for v in re_]))
