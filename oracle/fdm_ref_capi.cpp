@@ -243,7 +243,7 @@ int64_t fdmref_pack_cloud(void* e, const char* elevation_layer, int sub_r0, int 
     for (size_t k = 0; k < pc.fields.size(); ++k) joined += (k ? "\n" : "") + pc.fields[k];
     std::snprintf(fields_buf, fields_cap, "%s", joined.c_str());
   }
-  if (data && cap_bytes >= pc.data.size()) std::memcpy(data, pc.data.data(), pc.data.size());
+  if (data && !pc.data.empty() && cap_bytes >= pc.data.size()) std::memcpy(data, pc.data.data(), pc.data.size());
   return int64_t(pc.n_points);
 }
 
@@ -319,7 +319,7 @@ int64_t fdmref_voxel_any(uint64_t n, const float* x, const float* y, const float
   for (uint64_t i = 0; i < n; ++i) pts[i] = {x[i], y[i], z[i], 1.0f};
   try {
     const auto sel = voxelGridAny(pts, voxel_size, stable != 0);
-    std::memcpy(out_idx, sel.data(), sel.size() * sizeof(uint32_t));
+    if (!sel.empty()) std::memcpy(out_idx, sel.data(), sel.size() * sizeof(uint32_t));  // (memcpy(_, nullptr, 0) is UB)
     return int64_t(sel.size());
   } catch (const std::invalid_argument&) {
     return -1;

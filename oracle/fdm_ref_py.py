@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "libfdm_ref.so")
+LIB_PATH = os.environ.get("FDM_REF_LIB") or os.path.join(_HERE, "_build", "libfdm_ref.so")  # (FDM_REF_LIB: the sanitizer build)
 LIB_NATIVE_PATH = os.path.join(_HERE, "_build", "libfdm_ref_native.so")
 
 
