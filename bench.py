@@ -188,20 +188,25 @@ def measure_kernels(res, k0, steps, tag=None, overlap=1):
         dom = "k_update_bin"
     eng.enable_profile(False)
     eng.set_option("overlap", overlap)
-    names = {"k_update_bin": "k_update_bin (one launch: update of scan t + bin of scan t+1)"}
-    roof = {"bound": "hbm", "kernel": names.get(dom, dom), "achieved": out[dom]["GBps"], "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": out[dom]["GBps"] / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(tag, dom),
+    tiled = eng.last_pipeline() == 1  # scans of >= 64 K points on maps of >= 512 tiles: k_tbin / k_tupdate
+    real = {"k_bin": "k_tbin", "k_update": "k_tupdate", "k_update_bin": "k_tupdate_tbin"} if tiled else {}
+    out["kernel_names"] = {k: real.get(k, k) for k in ("k_bin", "k_update", "k_update_bin") if k in out}
+    names = {"k_update_bin": "k_update_bin (one launch: update of scan t + bin of scan t+1)",
+             "k_tupdate_tbin": "k_tupdate_tbin (one launch: update of scan t + bin of scan t+1, per-tile record pools)"}
+    roof = {"bound": "hbm", "kernel": names.get(real.get(dom, dom), real.get(dom, dom)), "achieved": out[dom]["GBps"],
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": out[dom]["GBps"] / HBM_PEAK_GBS,
+            "traffic": pmc_traffic(tag, real.get(dom, dom)),
             "avg_kernel_us": out[dom]["ms"] * 1e3,
             "alg_bytes_per_launch": out[dom]["alg_bytes"]}
     return out, roof
 
 
 def pmc_traffic(tag, kernel):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json,
-    made by scripts/gpu_round.sh + scripts/pmc_traffic.py: (2*FETCH_SIZE + WRITE_SIZE) KiB, the
-    gfx950 read-side correction of MI355X_MICROARCH.md).  PMC cannot be collected from inside this
-    process, so this is null when no profile of the workload has been committed."""
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, made by
+    scripts/r02_profile.sh + scripts/pmc_traffic.py: read bytes from the request-size counters
+    128 * RDREQ_128B + 64 * RDREQ_64B + 32 * RDREQ_32B — calibrated on known-byte kernels,
+    profiles/r02/pmc_calibration.json — plus WRITE_SIZE).  PMC cannot be collected from inside this process,
+    so this is null when no profile of the workload has been committed."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         return d[tag][kernel]["hbm_bytes_per_launch"]

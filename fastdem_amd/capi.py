@@ -141,6 +141,7 @@ PROTOTYPES = {
     "fdm_host_is_pinned": (C.c_int, [_P]),
     "fdm_engine_flush": (C.c_int, [_P]),
     "fdm_engine_stream": (_P, [_P]),
+    "fdm_engine_last_pipeline": (C.c_int, [_P]),
     "fdm_engine_record_event": (C.c_int, [_P, _P]),
     "fdm_engine_wait_event": (C.c_int, [_P, _P]),
     "fdm_engine_sync": (C.c_int, [_P]),

@@ -536,9 +536,9 @@ int ensure_tile_pool(fdm_engine* e, size_t records, unsigned blocks, bool has_in
     HIPCK(hipGetLastError());
   }
   const bool grow_rec = records > e->pool_cap;
-  const bool need_int = has_int && !e->pool[0].imax, need_col = has_col && !e->pool[0].rgb;
+  (void)has_int; (void)has_col;
   const bool grow_desc = blocks + 1u > e->desc_stride;
-  if (!grow_rec && !need_int && !need_col && !grow_desc) return FDM_OK;
+  if (!grow_rec && !grow_desc) return FDM_OK;
   if (int rc_sync = sync_all(e)) return rc_sync;  // (every chunk list is consumed: the row counts are all zero)
   if (grow_rec) {
     e->pool_cap = records + records / 4 + 8192;
@@ -553,13 +553,7 @@ int ensure_tile_pool(fdm_engine* e, size_t records, unsigned blocks, bool has_in
       return FDM_OK;
     };
     int rc;
-    if (grow_rec) {
-      if ((rc = re(q.key, e->pool_cap * 8)) || (rc = re(q.zmax, e->pool_cap * 8)) ||
-          (rc = re(q.cell, e->pool_cap * 4)) || (rc = re(q.var, e->pool_cap * 4)))
-        return rc;
-    }
-    if ((has_int || q.imax) && (grow_rec || need_int) && (rc = re(q.imax, e->pool_cap * 8))) return rc;
-    if ((has_col || q.rgb) && (grow_rec || need_col) && (rc = re(q.rgb, e->pool_cap * 4))) return rc;
+    if (grow_rec && (rc = re(q.rec, e->pool_cap * sizeof(TileRec)))) return rc;
     if (grow_desc) {
       if ((rc = re(q.desc, size_t(e->TG.n_tiles) * e->desc_stride * 8))) return rc;
       HIPCK(hipMemsetAsync(q.desc, 0, size_t(e->TG.n_tiles) * e->desc_stride * 8, e->stream));
@@ -1341,12 +1335,7 @@ void fdm_engine_destroy(fdm_engine* e) {
   if (e->aux2[1]) (void)hipFree(e->aux2[1]);
 
   for (auto& q : e->pool) {
-    if (q.key) (void)hipFree(q.key);
-    if (q.zmax) (void)hipFree(q.zmax);
-    if (q.imax) (void)hipFree(q.imax);
-    if (q.cell) (void)hipFree(q.cell);
-    if (q.var) (void)hipFree(q.var);
-    if (q.rgb) (void)hipFree(q.rgb);
+    if (q.rec) (void)hipFree(q.rec);
     if (q.desc) (void)hipFree(q.desc);
   }
   if (e->tile_stamp32) (void)hipFree(e->tile_stamp32);
@@ -1602,6 +1591,8 @@ int fdm_engine_flush(fdm_engine* e) {
 }
 
 void* fdm_engine_stream(fdm_engine* e) { return e ? static_cast<void*>(e->stream) : nullptr; }
+
+int fdm_engine_last_pipeline(fdm_engine* e) { return e ? e->last_kind : -1; }
 
 int fdm_engine_record_event(fdm_engine* e, void* hip_event) {
   if (!e || !hip_event) return fail(FDM_ERR_INVALID, "null argument");

@@ -55,14 +55,21 @@ constexpr uint32_t kRecZNeg = 1u << 12;      // ... and the first such point is 
 constexpr uint32_t kRecIZero = 1u << 13;     // the same for the intensity
 constexpr uint32_t kRecINeg = 1u << 14;
 
+// One observation record: what a bin block knows about one cell (32 B, two 16 B words; a chunk's records are
+// contiguous, so a tile's update reads them as whole 128 B lines — as five separate arrays the same records
+// cost 18 MB of fetches for 6.7 MB of payload at configs[3]).
+struct __align__(16) TileRec {
+  unsigned long long key;  // ord(min z) << 32 | pos << 1 | (that z is -0)   (low word kNoWinner: no finite z)
+  uint32_t zmax;           // ord(max z), 0 = none
+  uint32_t imax;           // ord(max intensity), 0 = none
+  uint32_t cell;           // cell inside the tile | kRec* flags
+  float var;               // sigma_z^2 of the min-z point
+  uint32_t rgb;            // colour of the block's last point in the cell
+  uint32_t pad;
+};
 // The record pool of one scan parity (bin of scan t+1 runs beside the update of scan t).
 struct TilePool {
-  unsigned long long* key;    // [cap]  ord(min z) << 32 | pos << 1 | (that z is -0)   (low word kNoWinner: no finite z)
-  uint32_t* zmax;             // [cap]  ord(max z), 0 = none
-  uint32_t* imax;             // [cap]  ord(max intensity), 0 = none (intensity scans only)
-  uint32_t* cell;             // [cap]  cell inside the tile | kRec* flags
-  float* var;                 // [cap]  sigma_z^2 of the min-z point
-  uint32_t* rgb;              // [cap]  colour of the block's last point in the cell (colour scans only)
+  TileRec* rec;               // [cap]
   unsigned long long* desc;   // [n_tiles][stride]  row of a tile: word 0 = number of chunks (put back to 0 by the update
                               // kernel), then one word per chunk: first record | count << 32
   unsigned stride;            // > bin blocks of the scan: a block appends at most one chunk per tile
@@ -502,12 +509,18 @@ __device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& 
       if (c_[q] == kEmptyCell) continue;
       const uint32_t pos = b0 + rec_base + t_off[th_[q]] + rk_[q];
       const uint32_t wl = kw_[q];
-      Q.key[pos] = ((unsigned long long)kz_[q] << 32) | (wl != kNoWinner ? (pos << 1) | (wl & 1u) : kNoWinner);
-      Q.zmax[pos] = zm_[q];
-      Q.var[pos] = var_[q];
-      if (HAS_INT) Q.imax[pos] = im_[q];
-      Q.cell[pos] = (c_[q] & 1023u) | fl_[q];
-      if (HAS_COL) Q.rgb[pos] = col_[q];
+      TileRec r;
+      r.key = ((unsigned long long)kz_[q] << 32) | (wl != kNoWinner ? (pos << 1) | (wl & 1u) : kNoWinner);
+      r.zmax = zm_[q];
+      r.imax = HAS_INT ? im_[q] : 0u;
+      r.cell = (c_[q] & 1023u) | fl_[q];
+      r.var = var_[q];
+      r.rgb = HAS_COL ? col_[q] : 0u;
+      r.pad = 0u;
+      uint4* const dst = reinterpret_cast<uint4*>(Q.rec + pos);
+      const uint4* const src = reinterpret_cast<const uint4*>(&r);
+      dst[0] = src[0];
+      dst[1] = src[1];
     }
     if (kSPT == 4 || pass == 0 || pass == 2) break;
     rec_base += n_rec;
@@ -650,10 +663,11 @@ __device__ __forceinline__ void tupdate_tile(
           }
           const unsigned pos = unsigned(s_desc[lo]) + (r - s_off[lo]);
           pos_[b] = pos;
-          cw_[b] = Q.cell[pos];
-          k_[b] = Q.key[pos];
-          zm_[b] = Q.zmax[pos];
-          if (has_int) im_[b] = Q.imax[pos];
+          const uint4 w0 = reinterpret_cast<const uint4*>(Q.rec + pos)[0];  // key | zmax | imax
+          cw_[b] = Q.rec[pos].cell;
+          k_[b] = (unsigned long long)w0.x | ((unsigned long long)w0.y << 32);
+          zm_[b] = w0.z;
+          im_[b] = w0.w;
         }
 #pragma unroll
         for (int b = 0; b < kRecBatch; ++b) {
@@ -737,8 +751,8 @@ __device__ __forceinline__ void tupdate_tile(
         zsw_[b] = s_zs[lc];
         if (has_int) { im_[b] = s_imax[lc]; izw_[b] = s_izs[lc]; fst_[b] = s_first[lc]; }
         const uint32_t wl = uint32_t(key_[b]);
-        if (wl != kNoWinner) var_[b] = Q.var[wl >> 1];
-        if (has_col) rgb_[b] = Q.rgb[s_last[lc] - 1u];
+        if (wl != kNoWinner) var_[b] = Q.rec[wl >> 1].var;
+        if (has_col) rgb_[b] = Q.rec[s_last[lc] - 1u].rgb;
         if (strip_[b]) {
           POLICY::set_nan(stt_[b]);
         } else {

@@ -211,6 +211,10 @@ class Engine:
                                         C.byref(st)))
         return st.as_dict()
 
+    def last_pipeline(self):
+        """0 = per-cell scratch pipeline, 1 = per-tile record pools (large scans), -1 = no scan yet."""
+        return self._lib.fdm_engine_last_pipeline(self._h)
+
     def flush(self):
         """Launch a held-back map update (no wait)."""
         _ck(self._lib.fdm_engine_flush(self._h))

@@ -184,6 +184,9 @@ int fdm_engine_flush(fdm_engine* e);
 /* The HIP stream (hipStream_t) the engine launches on: for callers that bracket engine work with
  * their own HIP events or order their own kernels after it. */
 void* fdm_engine_stream(fdm_engine* e);
+/* Which pipeline the last scan took: 0 = per-cell scratch (k_bin / k_update), 1 = per-tile record pools
+ * (k_tbin / k_tupdate: scans of >= 64 K points on maps of >= 512 tiles), -1 = no scan yet.  Diagnostic. */
+int fdm_engine_last_pipeline(fdm_engine* e);
 /* Order a consumer behind the engine: launches a held-back update, then records `hip_event`
  * (hipEvent_t) on the engine's stream — everything enqueued so far, the map update of the last scan
  * included, is complete when the event fires (the reference's callers hold a shared_mutex around
