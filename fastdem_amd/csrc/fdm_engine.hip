@@ -169,6 +169,7 @@ struct fdm_engine {
   unsigned desc_stride = 0;
   uint32_t* tile_stamp32 = nullptr;
   uint32_t* upd_part32 = nullptr;
+  uint32_t* tile_rare = nullptr;    // k_tupdate's rare-path scratch, 12 KB per update group
   unsigned last_upd_tiles = 0;      // length of the per-tile statistics of the last scan
   uint32_t* last_upd_part = nullptr;
   int last_kind = -1;               // pipeline of the last scan (0 scratch, 1 tiled)
@@ -533,6 +534,12 @@ int ensure_tile_pool(fdm_engine* e, size_t records, unsigned blocks, bool has_in
     HIPCK(hipMalloc(reinterpret_cast<void**>(&e->upd_part32), e->TG.n_tiles * sizeof(uint32_t)));
     hipLaunchKernelGGL(k_fill_u32, dim3(64), dim3(256), 0, e->stream, e->tile_stamp32, 0xFFFFFFFEu, size_t(e->TG.n_tiles));
     hipLaunchKernelGGL(k_fill_u32, dim3(64), dim3(256), 0, e->stream, e->upd_part32, 0u, size_t(e->TG.n_tiles));
+    {
+      const unsigned span = tile_span(e);
+      const size_t groups = (e->TG.n_tiles + span - 1u) / span + 2u;
+      HIPCK(hipMalloc(reinterpret_cast<void**>(&e->tile_rare), groups * 3072u * sizeof(uint32_t)));
+      for (auto& q : e->pool) q.rare = e->tile_rare;
+    }
     HIPCK(hipGetLastError());
   }
   const bool grow_rec = records > e->pool_cap;
@@ -592,9 +599,16 @@ int launch_update_alone(fdm_engine* e, const fdm_engine::PendingUpdate& u) {
       if constexpr (is_rec_policy<POLICY>) {
         const unsigned span = tile_span(e);
         const unsigned blocks = (e->TG.n_tiles + span - 1u) / span;
-        const unsigned lds = tile_lds_bytes(u.P.has_intensity != 0, u.P.has_color != 0);
-        hipLaunchKernelGGL(k_tupdate<POLICY>, dim3(blocks), dim3(256), lds, e->stream, u.P, e->G, e->TG, e->d_state,
-                           layers, e->d_layer_ptrs, e->n_layer_ptrs, u.Q, u.A, span);
+        const bool hi = u.P.has_intensity != 0, hc = u.P.has_color != 0;
+        const unsigned lds = tile_lds_bytes(hi, hc);
+        auto go = [&](auto kern) {
+          hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, e->stream, u.P, e->G, e->TG, e->d_state, layers,
+                             e->d_layer_ptrs, e->n_layer_ptrs, u.Q, u.A, span);
+        };
+        if (hi && hc) go(k_tupdate<POLICY, true, true>);
+        else if (hi) go(k_tupdate<POLICY, true, false>);
+        else if (hc) go(k_tupdate<POLICY, false, true>);
+        else go(k_tupdate<POLICY, false, false>);
       } else {
         return fail(FDM_ERR_INVALID, "internal: tiled update with a per-layer policy");
       }
@@ -625,7 +639,7 @@ int launch_update_fused(fdm_engine* e, const fdm_engine::PendingUpdate& u, const
         const unsigned span = tile_span(e);
         const unsigned groups = bv.threads / 256u;
         const unsigned ub = (e->TG.n_tiles + span * groups - 1u) / (span * groups);
-        const unsigned lds = std::max(groups * tile_lds_bytes(u.P.has_intensity != 0, u.P.has_color != 0),
+        const unsigned lds = std::max(groups * tile_lds_bytes(bv.has_int, bv.has_col),
                                       tbin_lds_bytes(bv.has_int, bv.has_col, bv.threads));
         int rc = FDM_OK;
         auto go = [&](auto kern) {
@@ -837,7 +851,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     e->bin_part_cap = bin_blocks + bin_blocks / 4 + 64;
     HIPCK(hipMalloc(reinterpret_cast<void**>(&e->S.bin_part), e->bin_part_cap * sizeof(unsigned long long)));
   }
-  if (tiled && (rc = ensure_tile_pool(e, size_t(bin_blocks) * per_block, bin_blocks * (kTbinSlotsPerThread < 4 ? 2u : 1u),
+  if (tiled && (rc = ensure_tile_pool(e, size_t(bin_blocks) * per_block, bin_blocks,
                                       P.has_intensity != 0,
                                       P.has_color != 0)))
     return rc;
@@ -856,7 +870,9 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   // a held-back update leaves now: fused with this bin if the two belong to the same pipeline and
   // this scan is a plain one, alone otherwise
   const bool fusable = tiled || ((!use_bin4 || (e->rec_kind >= 0 && e->S.dense)) && e->wave_merge);
-  const bool fuse_now = e->chain && plain && fusable && e->pend.tiled == tiled;
+  // (the fused tiled launch compiles the channels in once, for both halves)
+  const bool same_channels = !tiled || (e->pend.P.has_intensity == P.has_intensity && e->pend.P.has_color == P.has_color);
+  const bool fuse_now = e->chain && plain && fusable && e->pend.tiled == tiled && same_channels;
   if (e->chain && !fuse_now && (rc = join_streams(e))) return rc;
   P.chain_prev = 0;
   if (e->profile) HIPCK(hipEventRecord(e->ev[0], e->stream));
@@ -1340,6 +1356,7 @@ void fdm_engine_destroy(fdm_engine* e) {
   }
   if (e->tile_stamp32) (void)hipFree(e->tile_stamp32);
   if (e->upd_part32) (void)hipFree(e->upd_part32);
+  if (e->tile_rare) (void)hipFree(e->tile_rare);
   if (e->S.bin_part) (void)hipFree(e->S.bin_part);
   if (e->S.upd_part) (void)hipFree(e->S.upd_part);
   if (e->S.tile_stamp) (void)hipFree(e->S.tile_stamp);

@@ -44,16 +44,22 @@ constexpr int kTSShift = 5;
 constexpr unsigned kTileCells = 1024u;  // kTS * kTS
 constexpr uint32_t kNoWinner = 0xFFFFFFFFu;
 constexpr uint32_t kOrdZero = 0x80000000u;  // ord(+0.0f)
-constexpr int kTbinSlotsPerThread = 4;  // k_tbin: LDS table slots per thread (2: half-size table + overflow passes; 4: one slot per point)
-constexpr int kRecBatch = 2;    // k_tupdate: records per thread whose loads are in flight together
+#ifndef FDM_UPD_WAVES
+#define FDM_UPD_WAVES 6  // min waves per SIMD the tile kernels are compiled for (<= 72 VGPRs): LDS lets 7-8 blocks per CU in
+#endif
+#ifndef FDM_REC_BATCH
+#define FDM_REC_BATCH 2
+#endif
+constexpr int kRecBatch = FDM_REC_BATCH;    // k_tupdate: records per thread whose loads are in flight together
 constexpr int kCellBatch = 1;   // ... and touched cells
 
 // flags beside the cell-in-tile number (10 bits) of a record
-constexpr uint32_t kRecNanFirst = 1u << 10;  // the cell's first point has a NaN intensity
-constexpr uint32_t kRecZZero = 1u << 11;     // some point of the cell has z == +-0 ...
-constexpr uint32_t kRecZNeg = 1u << 12;      // ... and the first such point is -0
-constexpr uint32_t kRecIZero = 1u << 13;     // the same for the intensity
-constexpr uint32_t kRecINeg = 1u << 14;
+// (rare: set only by a block that met a -0.0 or a NaN intensity; "the cell holds a zero" needs no flag — a
+// zero only matters when it is the cell's maximum, and then the record's zmax / imax IS ord(0))
+constexpr uint32_t kRecNanFirst = 1u << 10;  // the block's first point in the cell has a NaN intensity
+constexpr uint32_t kRecZNeg = 1u << 12;      // the block's first zero-valued z in the cell is -0
+constexpr uint32_t kRecINeg = 1u << 14;      // the same for the intensity
+constexpr uint32_t kRecRare = kRecNanFirst | kRecZNeg | kRecINeg;
 
 // One observation record: what a bin block knows about one cell (32 B, two 16 B words; a chunk's records are
 // contiguous, so a tile's update reads them as whole 128 B lines — as five separate arrays the same records
@@ -73,6 +79,7 @@ struct TilePool {
   unsigned long long* desc;   // [n_tiles][stride]  row of a tile: word 0 = number of chunks (put back to 0 by the update
                               // kernel), then one word per chunk: first record | count << 32
   unsigned stride;            // > bin blocks of the scan: a block appends at most one chunk per tile
+  uint32_t* rare;             // [update groups][3][1024] scratch of k_tupdate's rare path (first-occurrence words)
 };
 
 struct TileGrid {
@@ -110,101 +117,44 @@ __device__ __forceinline__ int owned_tcell(float x, float y, const DevCand& cand
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_tbin.  Dynamic LDS: kSlots-sized u32 arrays cell | zmin | widx | zmax | zs [| imax | izs | first]
-// [| last], then the compaction list (u16).
+// k_tbin.  Dynamic LDS: 4*THREADS-slot arrays cell u32 | key u64 | zmax u32 [| imax u32] [| last u32], then
+// the compaction list (u16): 18-26 B per point.  The RARE-EVENT words of a cell — the sign of its first
+// zero-valued z / intensity, whether its first point's intensity is NaN — are not in the table: a block
+// that meets no -0.0 and no NaN (every block of a real scan) never needs them, and keeping 12 B per slot for
+// them cost three resident blocks per CU (configs[3]: 27 -> 22 us).  A block that does meet one re-walks
+// its points after the main fold, into table arrays that are dead by then (rare path, exact).
 __host__ __device__ constexpr unsigned tbin_lds_bytes(bool has_int, bool has_col, unsigned threads) {
-  return threads * unsigned(kTbinSlotsPerThread) * (20u + (has_int ? 12u : 0u) + (has_col ? 4u : 0u) + 2u);
+  return threads * 4u * (16u + (has_int ? 4u : 0u) + (has_col ? 4u : 0u) + 2u);
 }
 
-template <bool HAS_INT, bool HAS_COL, int THREADS, bool LEAN>
-__device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& G, const TileGrid& TG,
-                                          DevState* __restrict__ st, const ScanInputs& I,
-                                          const Scratch& S, const TilePool& Q,
-                                          int32_t* __restrict__ cell_ids, unsigned char* lds,
-                                          const unsigned bid) {
-  float* const cap_x = LEAN ? nullptr : S.cap_x;
-  float* const cap_var = LEAN ? nullptr : S.cap_var;
-  int32_t* const ids = LEAN ? nullptr : cell_ids;
+// Loads + phase 1 of one block: the four points of this thread through T_base_sensor, the crops,
+// T_world_base and getIndex.  cells[j] = tile << 10 | cell in tile of an owned cell, -1 outside the map
+// (or dropped by the crops), -2 inside the map but owned by another engine tile.  zs[] = map-frame z,
+// vs[] = intensity.  SIDE: also the captures, cell ids and statistics (the block's first walk only).
+template <bool HAS_INT, int THREADS, bool LEAN, bool SIDE>
+__device__ __forceinline__ void tbin_points(const ScanParams& P, const GeomConst& G, const TileGrid& TG,
+                                            const ScanInputs& I, const Scratch& S, int32_t* __restrict__ cell_ids,
+                                            const DevCand& cand, const unsigned bid, const float (&xin)[4],
+                                            const float (&yin)[4], const float (&zin)[4], int (&cells)[4],
+                                            float (&zs)[4], unsigned& n_pass, unsigned& n_in, bool& any_glob) {
+  float* const cap_x = (LEAN || !SIDE) ? nullptr : S.cap_x;
+  float* const cap_var = (LEAN || !SIDE) ? nullptr : S.cap_var;
+  int32_t* const ids = (LEAN || !SIDE) ? nullptr : cell_ids;
   const bool drop_nf = LEAN ? false : P.drop_nonfinite != 0;
-  const int dbg = LEAN ? 0 : P.dbg_no_atomics;  // measurement only: leave the kernel after a phase (results are wrong)
-  constexpr int kSPT = kTbinSlotsPerThread;  // table slots per thread (4 points per thread)
-  constexpr int kPts = THREADS * 4;          // points per block = the block's region of the record pool
-  constexpr int kSlots = THREADS * kSPT;
-  constexpr int kSlotBits = (THREADS == 512 ? 9 : (THREADS == 256 ? 8 : 7)) + (kSPT == 4 ? 2 : 1);
-  static_assert((1 << kSlotBits) == kSlots && (kSPT == 2 || kSPT == 4), "block size");
-  constexpr int kWaves = THREADS / 64;
-  uint32_t* const h_cell = reinterpret_cast<uint32_t*>(lds);
-  // ord(min z) << 32 | order in block << 1 | z is -0, min-reduced: the lowest z, among equals the first point
-  unsigned long long* const h_key = reinterpret_cast<unsigned long long*>(h_cell + kSlots);
-  uint32_t* const h_zmax = h_cell + 3 * kSlots;  // ord(max z), 0 = none
-  uint32_t* const h_zs = h_zmax + kSlots;      // (order << 1 | is -0) of the first point with z == +-0
-  uint32_t* const h_imax = h_zs + kSlots;      // (HAS_INT) like zmax / zs for the intensity
-  uint32_t* const h_izs = h_imax + kSlots;
-  uint32_t* const h_first = h_izs + kSlots;    //           (order << 1 | intensity is NaN) of the first point
-  uint32_t* const h_last = h_zs + (HAS_INT ? 4 : 1) * kSlots;  // (HAS_COL) order + 1 of the last point
-  uint16_t* const s_list = reinterpret_cast<uint16_t*>(h_zs + (1 + (HAS_INT ? 3 : 0) + (HAS_COL ? 1 : 0)) * kSlots);
-  __shared__ DevCand s_cand;
-  __shared__ unsigned s_cnt[kWaves];
-  __shared__ unsigned s_wsum[kWaves];
-  __shared__ unsigned s_ovf;
-
-  const float* __restrict__ px = I.x;
-  const float* __restrict__ py = I.y;
-  const float* __restrict__ pz = I.z;
-  const float* __restrict__ pint = I.intensity;
-
-  // the point loads go out first: they are in flight while the table is initialised and
-  // thread 0 works out the post-move geometry
-  const unsigned b0 = bid * unsigned(kPts);
-  const unsigned l0 = threadIdx.x * 4u;
-  const unsigned i0 = b0 + l0;
-  float xs[4], ys[4], zs[4], vs[4];
-  if (i0 + 3 < P.n) {
-    const float4 a = *reinterpret_cast<const float4*>(px + i0);
-    const float4 b = *reinterpret_cast<const float4*>(py + i0);
-    const float4 c = *reinterpret_cast<const float4*>(pz + i0);
-    xs[0] = a.x; xs[1] = a.y; xs[2] = a.z; xs[3] = a.w;
-    ys[0] = b.x; ys[1] = b.y; ys[2] = b.z; ys[3] = b.w;
-    zs[0] = c.x; zs[1] = c.y; zs[2] = c.z; zs[3] = c.w;
-    if (HAS_INT) {
-      const float4 d = *reinterpret_cast<const float4*>(pint + i0);
-      vs[0] = d.x; vs[1] = d.y; vs[2] = d.z; vs[3] = d.w;
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bool ok = i0 + j < P.n;
-      xs[j] = ok ? px[i0 + j] : 0.f;
-      ys[j] = ok ? py[i0 + j] : 0.f;
-      zs[j] = ok ? pz[i0 + j] : 0.f;
-      if (HAS_INT) vs[j] = ok ? pint[i0 + j] : 0.f;
-    }
-  }
-  for (int k = threadIdx.x; k < kSlots; k += THREADS) {
-    h_cell[k] = kEmptyCell;
-    h_key[k] = kEmptyKey;
-    h_zmax[k] = 0u;
-    h_zs[k] = 0xFFFFFFFFu;
-    if (HAS_INT) { h_imax[k] = 0u; h_izs[k] = 0xFFFFFFFFu; h_first[k] = kNoIdx; }
-    if (HAS_COL) h_last[k] = 0u;
-  }
-  if (threadIdx.x == 0) s_ovf = 0u;
-  const DevCand cand = block_candidate(P, G, st, &s_cand, bid);  // contains the __syncthreads
-
-  // phase 1: all four points through the arithmetic.  Branch-lean on purpose (the first version spent as many
-  // issue slots on exec-mask bookkeeping as on arithmetic): the transforms and the fixed-point index
-  // estimate run for all four points without a branch; the reference's exact index arithmetic is one
-  // shared, rarely taken branch for the lanes whose estimate sits within 1/1024 cell of a cell edge.
-  int cells[4];
+  const unsigned i0 = bid * unsigned(THREADS * 4) + threadIdx.x * 4u;
+  float xs[4], ys[4];
   bool pass[4];
-  unsigned n_pass = 0, n_in = 0;
-  bool any_glob = false;
+  // Branch-lean on purpose (the first version spent as many issue slots on exec-mask bookkeeping as on
+  // arithmetic): the transforms and the fixed-point index estimate run for all four points without a branch;
+  // the reference's exact index arithmetic is one shared, rarely taken branch for the lanes whose estimate
+  // sits within 2^-shift cell of a cell edge.
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
+    xs[j] = xin[j]; ys[j] = yin[j]; zs[j] = zin[j];
     const bool live = i0 + j < P.n;
     float cvar = 0.f;
     if (cap_var && live && P.integrate_mode) cvar = sigma_z2(P, xs[j], ys[j], zs[j]);
-    if (!LEAN && cap_var && S.cap_cov && live && P.integrate_mode) {
+    if (!LEAN && SIDE && cap_var && S.cap_cov && live && P.integrate_mode) {
       float c9[9];
       cov_full(P, xs[j], ys[j], zs[j], c9);
 #pragma unroll
@@ -219,43 +169,119 @@ __device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& 
     }
     n_pass += pass[j] ? 1u : 0u;
   }
-  {
-    const bool any_start = cand.sr != 0 || cand.sc != 0;
-    int kr[4], kc[4];
-    bool sure_r[4], sure_c[4], inside[4];
-    bool unsure = false;
+  const bool any_start = cand.sr != 0 || cand.sc != 0;
+  int kr[4], kc[4];
+  bool sure_r[4], sure_c[4], inside[4];
+  bool unsure = false;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    kr[j] = axis_fast(double(xs[j]), cand.px, G.half_x, G.inv_res_k, G.idx_shift, G.rows, sure_r[j]);
+    kc[j] = axis_fast(double(ys[j]), cand.py, G.half_y, G.inv_res_k, G.idx_shift, G.cols, sure_c[j]);
+    inside[j] = pass[j];
+    unsure = unsure || (pass[j] && !(sure_r[j] && sure_c[j]));
+  }
+  if (__ballot(unsure)) {  // wave-uniform; well under a percent of the wavefronts
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      kr[j] = axis_fast(double(xs[j]), cand.px, G.half_x, G.inv_res_k, G.idx_shift, G.rows, sure_r[j]);
-      kc[j] = axis_fast(double(ys[j]), cand.py, G.half_y, G.inv_res_k, G.idx_shift, G.cols, sure_c[j]);
-      inside[j] = pass[j];
-      unsure = unsure || (pass[j] && !(sure_r[j] && sure_c[j]));
-    }
-    if (__ballot(unsure)) {  // wave-uniform; a few percent of the wavefronts
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (pass[j] && !sure_r[j]) inside[j] = axis_exact(double(xs[j]), cand.px, G.half_x, G.len_x, G.res, kr[j]);
-        if (inside[j] && !sure_c[j]) inside[j] = axis_exact(double(ys[j]), cand.py, G.half_y, G.len_y, G.res, kc[j]);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int r = kr[j], c = kc[j];
-      const bool okr = axis_wrap(r, cand.sr, any_start, G.rows);  // (both axes are evaluated, as getIndex does)
-      const bool okc = axis_wrap(c, cand.sc, any_start, G.cols);
-      const bool in_map = inside[j] && okr && okc;
-      const int lr = r - G.o_r0, lc = c - G.o_c0;
-      const bool owned = in_map && lr >= 0 && lc >= 0 && lr < G.o_rows && lc < G.o_cols;
-      const int sr = r - G.s_r0, sc = c - G.s_c0;
-      const int tile = (sc >> kTSShift) * TG.tiles_r + (sr >> kTSShift);
-      const int tcell = (tile << 10) | ((sc & (kTS - 1)) << kTSShift) | (sr & (kTS - 1));
-      cells[j] = owned ? tcell : (in_map ? -2 : -1);
-      n_in += owned ? 1u : 0u;
-      any_glob = any_glob || in_map;
-      if (ids && i0 + j < P.n)
-        ids[i0 + j] = owned ? sc * G.s_rows + sr : (!pass[j] ? -1 : (in_map ? -3 : -2));
+      if (pass[j] && !sure_r[j]) inside[j] = axis_exact(double(xs[j]), cand.px, G.half_x, G.len_x, G.res, kr[j]);
+      if (inside[j] && !sure_c[j]) inside[j] = axis_exact(double(ys[j]), cand.py, G.half_y, G.len_y, G.res, kc[j]);
     }
   }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int r = kr[j], c = kc[j];
+    const bool okr = axis_wrap(r, cand.sr, any_start, G.rows);  // (both axes are evaluated, as getIndex does)
+    const bool okc = axis_wrap(c, cand.sc, any_start, G.cols);
+    const bool in_map = inside[j] && okr && okc;
+    const int lr = r - G.o_r0, lc = c - G.o_c0;
+    const bool owned = in_map && lr >= 0 && lc >= 0 && lr < G.o_rows && lc < G.o_cols;
+    const int sr = r - G.s_r0, sc = c - G.s_c0;
+    const int tile = (sc >> kTSShift) * TG.tiles_r + (sr >> kTSShift);
+    const int tcell = (tile << 10) | ((sc & (kTS - 1)) << kTSShift) | (sr & (kTS - 1));
+    cells[j] = owned ? tcell : (in_map ? -2 : -1);
+    n_in += owned ? 1u : 0u;
+    any_glob = any_glob || in_map;
+    if (ids && i0 + j < P.n)
+      ids[i0 + j] = owned ? sc * G.s_rows + sr : (!pass[j] ? -1 : (in_map ? -3 : -2));
+  }
+  (void)I;
+}
+
+template <bool HAS_INT, bool HAS_COL, int THREADS, bool LEAN>
+__device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& G, const TileGrid& TG,
+                                          DevState* __restrict__ st, const ScanInputs& I,
+                                          const Scratch& S, const TilePool& Q,
+                                          int32_t* __restrict__ cell_ids, unsigned char* lds,
+                                          const unsigned bid) {
+  const int dbg = LEAN ? 0 : P.dbg_no_atomics;  // measurement only: leave the kernel after a phase (results are wrong)
+  constexpr int kSlots = THREADS * 4;  // == points per block: room for every point in its own cell
+  constexpr int kSlotBits = THREADS == 512 ? 11 : (THREADS == 256 ? 10 : 9);
+  static_assert((1 << kSlotBits) == kSlots, "block size");
+  constexpr int kWaves = THREADS / 64;
+  uint32_t* const h_cell = reinterpret_cast<uint32_t*>(lds);
+  // ord(min z) << 32 | order in block << 1 | z is -0, min-reduced: the lowest z, among equals the first point
+  unsigned long long* const h_key = reinterpret_cast<unsigned long long*>(h_cell + kSlots);
+  uint32_t* const h_zmax = h_cell + 3 * kSlots;  // ord(max z), 0 = none
+  uint32_t* const h_imax = h_zmax + kSlots;      // (HAS_INT) ord(max intensity), 0 = none
+  uint32_t* const h_last = h_zmax + (HAS_INT ? 2 : 1) * kSlots;  // (HAS_COL) order + 1 of the last point
+  uint16_t* const s_list = reinterpret_cast<uint16_t*>(h_zmax + (1 + (HAS_INT ? 1 : 0) + (HAS_COL ? 1 : 0)) * kSlots);
+  __shared__ DevCand s_cand;
+  __shared__ unsigned s_cnt[kWaves];
+  __shared__ unsigned s_wsum[kWaves];
+  __shared__ unsigned s_rare;
+
+  const float* __restrict__ px = I.x;
+  const float* __restrict__ py = I.y;
+  const float* __restrict__ pz = I.z;
+  const float* __restrict__ pint = I.intensity;
+
+  // the point loads go out first: they are in flight while the table is initialised and
+  // thread 0 works out the post-move geometry
+  const unsigned b0 = bid * unsigned(kSlots);
+  const unsigned l0 = threadIdx.x * 4u;
+  const unsigned i0 = b0 + l0;
+  float xs[4], ys[4], zin[4], vs[4];
+  auto load_points = [&]() {
+    if (i0 + 3 < P.n) {
+      const float4 a = *reinterpret_cast<const float4*>(px + i0);
+      const float4 b = *reinterpret_cast<const float4*>(py + i0);
+      const float4 c = *reinterpret_cast<const float4*>(pz + i0);
+      xs[0] = a.x; xs[1] = a.y; xs[2] = a.z; xs[3] = a.w;
+      ys[0] = b.x; ys[1] = b.y; ys[2] = b.z; ys[3] = b.w;
+      zin[0] = c.x; zin[1] = c.y; zin[2] = c.z; zin[3] = c.w;
+      if (HAS_INT) {
+        const float4 d = *reinterpret_cast<const float4*>(pint + i0);
+        vs[0] = d.x; vs[1] = d.y; vs[2] = d.z; vs[3] = d.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = i0 + j < P.n;
+        xs[j] = ok ? px[i0 + j] : 0.f;
+        ys[j] = ok ? py[i0 + j] : 0.f;
+        zin[j] = ok ? pz[i0 + j] : 0.f;
+        if (HAS_INT) vs[j] = ok ? pint[i0 + j] : 0.f;
+      }
+    }
+  };
+  load_points();
+  for (int k = threadIdx.x; k < kSlots; k += THREADS) {
+    h_cell[k] = kEmptyCell;
+    h_key[k] = kEmptyKey;
+    h_zmax[k] = 0u;
+    if (HAS_INT) h_imax[k] = 0u;
+    if (HAS_COL) h_last[k] = 0u;
+  }
+  if (threadIdx.x == 0) s_rare = 0u;
+  const DevCand cand = block_candidate(P, G, st, &s_cand, bid);  // contains the __syncthreads
+
+  // phase 1: all four points through the arithmetic
+  int cells[4];
+  float zs[4];
+  unsigned n_pass = 0, n_in = 0;
+  bool any_glob = false;
+  tbin_points<HAS_INT, THREADS, LEAN, true>(P, G, TG, I, S, cell_ids, cand, bid, xs, ys, zin, cells, zs, n_pass, n_in,
+                                            any_glob);
   if (dbg == 2) {
     S.bin_part[bid] = (cells[0] + cells[1] + cells[2] + cells[3] == 0x7FFFFFF1) ? 1ull : 0x100000001ull;
     return;
@@ -266,265 +292,263 @@ __device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& 
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
   if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = v;
   if (__ballot(any_glob) && (threadIdx.x & 63) == 0) st->flags[P.slot].any_inside = 1u;
-  bool zero_here = false;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) zero_here = zero_here || (cells[j] >= 0 && (zs[j] == 0.0f || (HAS_INT && vs[j] == 0.0f)));
-  const bool zero_seen = __ballot(zero_here) != 0ull;  // wave-uniform: some lane holds a +-0 value (rare outside synthetic data)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-  // The table has kSlots = kSPT * THREADS slots for 4 * THREADS points.  With kSPT < 4 a block whose points
-  // fall into more than kSlots distinct cells cannot be folded in one go: pass 0 (everything) then reports
-  // an overflow and the block is redone as two halves of its threads (passes 1 and 2: at most
-  // 2 * THREADS points each), each with its own flush.  Pool positions stay in scan order.
-  unsigned rec_base = 0;  // records written by the block's earlier passes
-#pragma unroll 1
-  for (int pass = 0; pass < 3; ++pass) {
-    if (pass > 0) {
-      for (int k = threadIdx.x; k < kSlots; k += THREADS) {
-        h_cell[k] = kEmptyCell;
-        h_key[k] = kEmptyKey;
-        h_zmax[k] = 0u;
-        h_zs[k] = 0xFFFFFFFFu;
-        if (HAS_INT) { h_imax[k] = 0u; h_izs[k] = 0xFFFFFFFFu; h_first[k] = kNoIdx; }
-        if (HAS_COL) h_last[k] = 0u;
-      }
-      if (threadIdx.x == 0) s_ovf = 0u;
-      __syncthreads();
+  // probe of the block's cell table: claim-or-find in ONE LDS operation per step.  (Multiplicative hash: the low
+  // bits of tile << 10 | cell repeat from tile to tile along a wedge, and linear probing through such clusters
+  // cost 49 of the first version's 65 us.)
+  auto find_slot = [&](uint32_t cell) -> uint32_t {
+    uint32_t h = (cell * 2654435761u) >> (32 - kSlotBits);
+    while (true) {
+      const uint32_t prev = atomicCAS(&h_cell[h], kEmptyCell, cell);
+      if (prev == kEmptyCell || prev == cell) return h;
+      h = (h + 1) & (kSlots - 1);
     }
-    // phase 2: merge runs of equal cell in registers, fold each run into the block's LDS table
-    if (pass == 0 || (threadIdx.x >= THREADS / 2) == (pass == 2)) {
-      int run_cell = -1;
-      unsigned long long run_key = kEmptyKey;
-      uint32_t run_zmx = 0u, run_zs = 0xFFFFFFFFu, run_imx = 0u, run_izs = 0xFFFFFFFFu, run_fst = kNoIdx, run_lst = 0u;
-      auto fold_run = [&]() {
-        if (run_cell < 0) return;
-        // (multiplicative hash: the low bits of tile << 10 | cell repeat from tile to tile along a wedge, and
-        // linear probing through such clusters cost 49 of the first version's 65 us)
-        uint32_t h = (uint32_t(run_cell) * 2654435761u) >> (32 - kSlotBits);
-        unsigned tries = 0;
-        while (true) {  // claim-or-find in ONE LDS operation per probe
-          const uint32_t prev = atomicCAS(&h_cell[h], kEmptyCell, uint32_t(run_cell));
-          if (prev == kEmptyCell || prev == uint32_t(run_cell)) break;
-          h = (h + 1) & (kSlots - 1);
-          if (kSPT < 4 && ++tries >= unsigned(kSlots)) { s_ovf = 1u; return; }  // table full
-        }
-        // (no-op operands instead of branches: max with 0, min with all-ones)
-        atomicMin(&h_key[h], run_key);
-        atomicMax(&h_zmax[h], run_zmx);
-        if (HAS_INT) {
-          atomicMax(&h_imax[h], run_imx);
-          atomicMin(&h_first[h], run_fst);
-        }
-        if (HAS_COL) atomicMax(&h_last[h], run_lst);
-        if (zero_seen) {
-          atomicMin(&h_zs[h], run_zs);
-          if (HAS_INT) atomicMin(&h_izs[h], run_izs);
-        }
-      };
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (cells[j] < 0) continue;
-        const uint32_t li = l0 + j;  // order inside the block
-        const float z = zs[j];
-        const uint32_t zneg = __float_as_uint(z) == 0x80000000u ? 1u : 0u;
-        const uint32_t oz = ord_canon(z);
-        // strict "z < min_z" from FLT_MAX / "z > max_z" from lowest(): NaN, FLT_MAX and beyond never win
-        const unsigned long long key = (z < kFltMax) ? ((unsigned long long)oz << 32) | (li << 1) | zneg
-                                                     : ((unsigned long long)ord(kFltMax) << 32) | kNoWinner;
-        const uint32_t zmx = (z > -kFltMax) ? oz : 0u;
-        const uint32_t zz = (z == 0.0f) ? ((li << 1) | zneg) : 0xFFFFFFFFu;
-        uint32_t imx = 0u, iz = 0xFFFFFFFFu;
-        bool vnan = false;
-        if (HAS_INT) {
-          const float vv = vs[j];
-          vnan = isnan(vv);
-          imx = vnan ? 0u : ord_canon(vv);
-          if (vv == 0.0f) iz = (li << 1) | (__float_as_uint(vv) == 0x80000000u ? 1u : 0u);
-        }
-        if (cells[j] != run_cell) {
-          fold_run();
-          run_cell = cells[j];
-          run_key = key;
-          run_zmx = zmx;
-          run_zs = zz;
-          run_imx = imx;
-          run_izs = iz;
-          run_fst = (li << 1) | (vnan ? 1u : 0u);
-        } else {
-          run_key = key < run_key ? key : run_key;
-          run_zmx = zmx > run_zmx ? zmx : run_zmx;
-          run_zs = zz < run_zs ? zz : run_zs;
-          run_imx = imx > run_imx ? imx : run_imx;
-          run_izs = iz < run_izs ? iz : run_izs;
-        }
-        run_lst = li + 1u;
-      }
-      fold_run();
-    }
-    __syncthreads();  // every run of the pass is in the table
-    if (threadIdx.x == 0 && pass == 0) {
-      unsigned np = 0, ni = 0;
-      for (int w = 0; w < kWaves; ++w) { np += s_cnt[w] & 0xFFFFu; ni += s_cnt[w] >> 16; }
-      if (np) st->flags[P.slot].any_pass = 1u;
-      S.bin_part[bid] = (unsigned long long)np | ((unsigned long long)ni << 32);
-    }
-    if (kSPT < 4 && pass == 0 && s_ovf != 0u) continue;  // block-uniform
+  };
 
-    // ---- flush: the pass's unique cells become observation records, grouped by map tile ----
-    // (a) compact the occupied slots: record j of the pass is slot s_list[j]
-    unsigned n_rec;
-    {
-      uint32_t cc[kSPT];
+  // phase 2: merge runs of equal cell in registers, fold each run into the table
+  uint32_t pflags = 0u;  // 8 bits per point, see below
+  {
+    int run_cell = -1;
+    unsigned long long run_key = kEmptyKey;
+    uint32_t run_zmx = 0u, run_imx = 0u, run_lst = 0u;
+    auto fold_run = [&]() {
+      if (run_cell < 0) return;
+      const uint32_t h = find_slot(uint32_t(run_cell));
+      // (no-op operands instead of branches: max with 0)
+      atomicMin(&h_key[h], run_key);
+      atomicMax(&h_zmax[h], run_zmx);
+      if (HAS_INT) atomicMax(&h_imax[h], run_imx);
+      if (HAS_COL) atomicMax(&h_last[h], run_lst);
+    };
 #pragma unroll
-      for (int q = 0; q < kSPT; ++q) cc[q] = h_cell[threadIdx.x * kSPT + q];
-      unsigned mine = 0;
-#pragma unroll
-      for (int q = 0; q < kSPT; ++q) mine += cc[q] != kEmptyCell ? 1u : 0u;
-      unsigned inc = mine;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const unsigned o = __shfl_up(inc, d);
-        if (lane >= d) inc += o;
+    for (int j = 0; j < 4; ++j) {
+      if (cells[j] < 0) continue;
+      const uint32_t li = l0 + j;  // order inside the block
+      const float z = zs[j];
+      const uint32_t zneg = __float_as_uint(z) == 0x80000000u ? 1u : 0u;
+      const uint32_t oz = ord_canon(z);
+      // strict "z < min_z" from FLT_MAX / "z > max_z" from lowest(): NaN, FLT_MAX and beyond never win
+      const unsigned long long key = (z < kFltMax) ? ((unsigned long long)oz << 32) | (li << 1) | zneg
+                                                   : ((unsigned long long)ord(kFltMax) << 32) | kNoWinner;
+      const uint32_t zmx = (z > -kFltMax) ? oz : 0u;
+      uint32_t imx = 0u;
+      // what the rare path needs of this point, 5 bits: z is a zero / is -0, intensity is a zero / is -0 / is NaN
+      uint32_t pf = (z == 0.0f ? 1u : 0u) | (zneg << 1);
+      if (HAS_INT) {
+        const float vv = vs[j];
+        const bool vnan = isnan(vv);
+        imx = vnan ? 0u : ord_canon(vv);
+        pf |= (vv == 0.0f ? 4u : 0u) | (__float_as_uint(vv) == 0x80000000u ? 8u : 0u) | (vnan ? 16u : 0u);
       }
-      if (lane == 63) s_wsum[wave] = inc;
-      __syncthreads();
-      unsigned base = 0, total = 0;
-#pragma unroll
-      for (int w = 0; w < kWaves; ++w) {
-        const unsigned ws = s_wsum[w];
-        base += w < wave ? ws : 0u;
-        total += ws;
+      pflags |= pf << (8 * j);
+      if (cells[j] != run_cell) {
+        fold_run();
+        run_cell = cells[j];
+        run_key = key;
+        run_zmx = zmx;
+        run_imx = imx;
+      } else {
+        run_key = key < run_key ? key : run_key;
+        run_zmx = zmx > run_zmx ? zmx : run_zmx;
+        run_imx = imx > run_imx ? imx : run_imx;
       }
-      n_rec = total;
-      unsigned p = base + inc - mine;
+      run_lst = li + 1u;
+    }
+    fold_run();
+    // a -0.0 or a NaN intensity among the block's points: the order of first occurrences matters
+    if (__ballot((pflags & 0x1A1A1A1Au) != 0u) && lane == 0) s_rare = 1u;
+  }
+  __syncthreads();  // every run of the block is in the table
+  if (threadIdx.x == 0) {
+    unsigned np = 0, ni = 0;
+    for (int w = 0; w < kWaves; ++w) { np += s_cnt[w] & 0xFFFFu; ni += s_cnt[w] >> 16; }
+    if (np) st->flags[P.slot].any_pass = 1u;
+    S.bin_part[bid] = (unsigned long long)np | ((unsigned long long)ni << 32);
+  }
+  const bool rare_block = s_rare != 0u;  // block-uniform
+
+  // ---- flush: the block's unique cells become observation records, grouped by map tile ----
+  // (a) compact the occupied slots: record j of the block is slot s_list[j]
+  unsigned n_rec;
+  {
+    const uint4 c4 = *reinterpret_cast<const uint4*>(h_cell + l0);  // the thread's 4 consecutive slots
+    const uint32_t cc[4] = {c4.x, c4.y, c4.z, c4.w};
+    unsigned mine = 0;
 #pragma unroll
-      for (int q = 0; q < kSPT; ++q)
-        if (cc[q] != kEmptyCell) s_list[p++] = uint16_t(threadIdx.x * kSPT + q);
+    for (int q = 0; q < 4; ++q) mine += cc[q] != kEmptyCell ? 1u : 0u;
+    unsigned inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned o = __shfl_up(inc, d);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    unsigned base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+      const unsigned ws = s_wsum[w];
+      base += w < wave ? ws : 0u;
+      total += ws;
+    }
+    n_rec = total;
+    unsigned p = base + inc - mine;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (cc[q] != kEmptyCell) s_list[p++] = uint16_t(l0 + q);
+  }
+  __syncthreads();
+  // (b) record j = threadIdx.x + q * THREADS leaves the table for registers; its sigma_z^2 is evaluated
+  // from the winning point (re-read from L2: the block loaded it a few microseconds ago)
+  constexpr int kRounds = 4;
+  uint32_t c_[kRounds], kz_[kRounds], kw_[kRounds], zm_[kRounds], im_[kRounds], fl_[kRounds], col_[kRounds];
+  float var_[kRounds];
+#pragma unroll
+  for (int q = 0; q < kRounds; ++q) {
+    c_[q] = kEmptyCell; kz_[q] = 0u; kw_[q] = kNoWinner; zm_[q] = 0u; im_[q] = 0u; var_[q] = 0.0f; fl_[q] = 0u; col_[q] = 0u;
+    if (unsigned(q * THREADS) >= n_rec) continue;  // block-uniform
+    const unsigned j = threadIdx.x + unsigned(q * THREADS);
+    if (j >= n_rec) continue;
+    const unsigned slot = s_list[j];
+    c_[q] = h_cell[slot];  // tile << 10 | cell in tile
+    const unsigned long long k64 = h_key[slot];
+    kz_[q] = uint32_t(k64 >> 32);
+    kw_[q] = uint32_t(k64);
+    zm_[q] = h_zmax[slot];
+    if (HAS_INT) im_[q] = h_imax[slot];
+    if (HAS_COL) col_[q] = I.rgb[b0 + h_last[slot] - 1u];
+    const uint32_t wl = kw_[q];           // winner: order << 1 | sign, or kNoWinner
+    if (wl != kNoWinner) {                // (else: CellObservation default 0, elevation_mapping.hpp:26-34)
+      const unsigned gi = b0 + (wl >> 1);
+      if (P.has_var) var_[q] = I.var[gi];
+      else if (P.integrate_mode) var_[q] = sigma_z2(P, px[gi], py[gi], pz[gi]);
+    }
+  }
+  __syncthreads();
+  if (rare_block) {
+    // Rare path: some point of the block is a -0.0 or has a NaN intensity, so the order of first occurrences
+    // matters.  The points are walked once more (their cells and five flag bits each stayed in registers) into
+    // three table arrays that are dead now: per slot the (order << 1 | is -0) of the first zero-valued z, of
+    // the first zero-valued intensity, and (order << 1 | is NaN) of the first point.
+    uint32_t* const r_zs = h_cell + kSlots;      // (the key's memory)
+    uint32_t* const r_izs = h_cell + 2 * kSlots;
+    uint32_t* const r_first = h_zmax;
+    for (int k = threadIdx.x; k < kSlots; k += THREADS) {
+      r_zs[k] = 0xFFFFFFFFu; r_izs[k] = 0xFFFFFFFFu; r_first[k] = 0xFFFFFFFFu;
     }
     __syncthreads();
-    // (b) record j = threadIdx.x + q * THREADS leaves the table for registers; its sigma_z^2 is evaluated
-    // from the winning point (re-read from L2: the block loaded it a few microseconds ago)
-    uint32_t c_[kSPT], kz_[kSPT], kw_[kSPT], zm_[kSPT], im_[kSPT], fl_[kSPT], col_[kSPT];
-    float var_[kSPT];
 #pragma unroll
-    for (int q = 0; q < kSPT; ++q) {
-      c_[q] = kEmptyCell; kz_[q] = 0u; kw_[q] = kNoWinner; zm_[q] = 0u; im_[q] = 0u; var_[q] = 0.0f; fl_[q] = 0u; col_[q] = 0u;
-      if (unsigned(q * THREADS) >= n_rec) continue;  // block-uniform
-      const unsigned j = threadIdx.x + unsigned(q * THREADS);
-      if (j >= n_rec) continue;
-      const unsigned slot = s_list[j];
-      c_[q] = h_cell[slot];  // tile << 10 | cell in tile
-      const unsigned long long k64 = h_key[slot];
-      kz_[q] = uint32_t(k64 >> 32);
-      kw_[q] = uint32_t(k64);
-      zm_[q] = h_zmax[slot];
-      const uint32_t zsw = h_zs[slot];
-      uint32_t fl = 0u;
-      if (zsw != 0xFFFFFFFFu) fl |= kRecZZero | ((zsw & 1u) ? kRecZNeg : 0u);
+    for (int j = 0; j < 4; ++j) {
+      if (cells[j] < 0) continue;
+      const uint32_t li = l0 + j, pf = pflags >> (8 * j);
+      const uint32_t h = find_slot(uint32_t(cells[j]));  // (present: the main fold put it there)
+      if (pf & 1u) atomicMin(&r_zs[h], (li << 1) | ((pf >> 1) & 1u));
       if (HAS_INT) {
-        im_[q] = h_imax[slot];
-        const uint32_t izw = h_izs[slot];
-        if (izw != 0xFFFFFFFFu) fl |= kRecIZero | ((izw & 1u) ? kRecINeg : 0u);
-        if (h_first[slot] & 1u) fl |= kRecNanFirst;
+        if (pf & 4u) atomicMin(&r_izs[h], (li << 1) | ((pf >> 3) & 1u));
+        atomicMin(&r_first[h], (li << 1) | ((pf >> 4) & 1u));
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kRounds; ++q) {
+      if (c_[q] == kEmptyCell) continue;
+      const unsigned slot = s_list[threadIdx.x + unsigned(q * THREADS)];
+      uint32_t fl = 0u;
+      const uint32_t zsw = r_zs[slot];
+      if (zsw != 0xFFFFFFFFu && (zsw & 1u)) fl |= kRecZNeg;
+      if (HAS_INT) {
+        const uint32_t izw = r_izs[slot];
+        if (izw != 0xFFFFFFFFu && (izw & 1u)) fl |= kRecINeg;
+        if (r_first[slot] & 1u) fl |= kRecNanFirst;
       }
       fl_[q] = fl;
-      if (HAS_COL) col_[q] = I.rgb[b0 + h_last[slot] - 1u];
-      const uint32_t wl = kw_[q];           // winner: order << 1 | sign, or kNoWinner
-      if (wl != kNoWinner) {                // (else: CellObservation default 0, elevation_mapping.hpp:26-34)
-        const unsigned gi = b0 + (wl >> 1);
-        if (P.has_var) var_[q] = I.var[gi];
-        else if (P.integrate_mode) var_[q] = sigma_z2(P, px[gi], py[gi], pz[gi]);
-      }
     }
     __syncthreads();
-    // (c) the table's memory becomes the block's TILE table: tile id -> how many of the pass's cells
-    uint32_t* const t_tile = h_cell + kSlots;      // [kSlots]
-    uint32_t* const t_cnt = h_cell + 2 * kSlots;   // [kSlots]
-    uint32_t* const t_off = h_zmax;                // [kSlots]
-    for (int k = threadIdx.x; k < kSlots; k += THREADS) {
-      t_tile[k] = kEmptyCell;
-      t_cnt[k] = 0u;
+  }
+  // (c) the table's memory becomes the block's TILE table: tile id -> how many of the block's cells
+  uint32_t* const t_tile = h_cell + kSlots;      // [kSlots]
+  uint32_t* const t_cnt = h_cell + 2 * kSlots;   // [kSlots]
+  uint32_t* const t_off = h_zmax;                // [kSlots]
+  for (int k = threadIdx.x; k < kSlots; k += THREADS) {
+    t_tile[k] = kEmptyCell;
+    t_cnt[k] = 0u;
+  }
+  __syncthreads();
+  uint32_t th_[kRounds], rk_[kRounds];
+#pragma unroll
+  for (int q = 0; q < kRounds; ++q) {
+    th_[q] = 0u; rk_[q] = 0u;
+    if (c_[q] == kEmptyCell) continue;
+    const uint32_t tile = c_[q] >> 10;
+    uint32_t h = (tile * 2654435761u) >> (32 - kSlotBits);
+    while (true) {  // (at most n_rec <= kSlots distinct tiles: always terminates)
+      const uint32_t prev = atomicCAS(&t_tile[h], kEmptyCell, tile);
+      if (prev == kEmptyCell || prev == tile) break;
+      h = (h + 1) & (kSlots - 1);
     }
+    th_[q] = h;
+    rk_[q] = atomicAdd(&t_cnt[h], 1u);
+  }
+  __syncthreads();
+  // (d) exclusive scan of the tile counts; thread t owns entries t, t + THREADS, ... (neighbouring
+  // tiles of a wedge go to different threads), appends one chunk per occupied entry to the tile's row
+  {
+    uint32_t nn[4], tt[4];
+    unsigned mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      nn[k] = t_cnt[threadIdx.x + k * THREADS];
+      tt[k] = t_tile[threadIdx.x + k * THREADS];
+      mine += nn[k];
+    }
+    unsigned slot[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // the returning atomics leave together, ahead of the scan
+      slot[k] = 0u;
+      if (nn[k])
+        slot[k] = atomicAdd(reinterpret_cast<unsigned*>(Q.desc + size_t(tt[k]) * Q.stride), 1u);
+    }
+    unsigned inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned o = __shfl_up(inc, d);
+      if (lane >= d) inc += o;
+    }
+    __syncthreads();  // ((a)'s readers of s_wsum are long done)
+    if (lane == 63) s_wsum[wave] = inc;
     __syncthreads();
-    uint32_t th_[kSPT], rk_[kSPT];
+    unsigned p = inc - mine;
 #pragma unroll
-    for (int q = 0; q < kSPT; ++q) {
-      th_[q] = 0u; rk_[q] = 0u;
-      if (c_[q] == kEmptyCell) continue;
-      const uint32_t tile = c_[q] >> 10;
-      uint32_t h = (tile * 2654435761u) >> (32 - kSlotBits);
-      while (true) {  // (at most n_rec <= kSlots distinct tiles: always terminates)
-        const uint32_t prev = atomicCAS(&t_tile[h], kEmptyCell, tile);
-        if (prev == kEmptyCell || prev == tile) break;
-        h = (h + 1) & (kSlots - 1);
-      }
-      th_[q] = h;
-      rk_[q] = atomicAdd(&t_cnt[h], 1u);
-    }
-    __syncthreads();
-    // (d) exclusive scan of the tile counts; thread t owns entries t, t + THREADS, ... (neighbouring
-    // tiles of a wedge go to different threads), appends one chunk per occupied entry to the tile's row
-    {
-      uint32_t nn[kSPT], tt[kSPT];
-      unsigned mine = 0;
+    for (int w = 0; w < kWaves; ++w) p += w < wave ? s_wsum[w] : 0u;
 #pragma unroll
-      for (int k = 0; k < kSPT; ++k) {
-        nn[k] = t_cnt[threadIdx.x + k * THREADS];
-        tt[k] = t_tile[threadIdx.x + k * THREADS];
-        mine += nn[k];
-      }
-      unsigned slot[kSPT];
-#pragma unroll
-      for (int k = 0; k < kSPT; ++k) {  // the returning atomics leave together, ahead of the scan
-        slot[k] = 0u;
-        if (nn[k])
-          slot[k] = atomicAdd(reinterpret_cast<unsigned*>(Q.desc + size_t(tt[k]) * Q.stride), 1u);
-      }
-      unsigned inc = mine;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const unsigned o = __shfl_up(inc, d);
-        if (lane >= d) inc += o;
-      }
-      __syncthreads();  // ((a)'s readers of s_wsum are long done)
-      if (lane == 63) s_wsum[wave] = inc;
-      __syncthreads();
-      unsigned p = inc - mine;
-#pragma unroll
-      for (int w = 0; w < kWaves; ++w) p += w < wave ? s_wsum[w] : 0u;
-#pragma unroll
-      for (int k = 0; k < kSPT; ++k) {
-        if (nn[k]) {
-          t_off[threadIdx.x + k * THREADS] = p;
-          Q.desc[size_t(tt[k]) * Q.stride + 1u + slot[k]] =
-              (unsigned long long)(b0 + rec_base + p) | ((unsigned long long)nn[k] << 32);
-          p += nn[k];
-        }
+    for (int k = 0; k < 4; ++k) {
+      if (nn[k]) {
+        t_off[threadIdx.x + k * THREADS] = p;
+        Q.desc[size_t(tt[k]) * Q.stride + 1u + slot[k]] = (unsigned long long)(b0 + p) | ((unsigned long long)nn[k] << 32);
+        p += nn[k];
       }
     }
-    __syncthreads();
-    // (e) the records, grouped by tile, into the block's own region of the pool
+  }
+  __syncthreads();
+  // (e) the records, grouped by tile, into the block's own region of the pool
 #pragma unroll
-    for (int q = 0; q < kSPT; ++q) {
-      if (c_[q] == kEmptyCell) continue;
-      const uint32_t pos = b0 + rec_base + t_off[th_[q]] + rk_[q];
-      const uint32_t wl = kw_[q];
-      TileRec r;
-      r.key = ((unsigned long long)kz_[q] << 32) | (wl != kNoWinner ? (pos << 1) | (wl & 1u) : kNoWinner);
-      r.zmax = zm_[q];
-      r.imax = HAS_INT ? im_[q] : 0u;
-      r.cell = (c_[q] & 1023u) | fl_[q];
-      r.var = var_[q];
-      r.rgb = HAS_COL ? col_[q] : 0u;
-      r.pad = 0u;
-      uint4* const dst = reinterpret_cast<uint4*>(Q.rec + pos);
-      const uint4* const src = reinterpret_cast<const uint4*>(&r);
-      dst[0] = src[0];
-      dst[1] = src[1];
-    }
-    if (kSPT == 4 || pass == 0 || pass == 2) break;
-    rec_base += n_rec;
-    __syncthreads();  // the tile table is re-initialised by the next pass
+  for (int q = 0; q < kRounds; ++q) {
+    if (c_[q] == kEmptyCell) continue;
+    const uint32_t pos = b0 + t_off[th_[q]] + rk_[q];
+    const uint32_t wl = kw_[q];
+    TileRec r;
+    r.key = ((unsigned long long)kz_[q] << 32) | (wl != kNoWinner ? (pos << 1) | (wl & 1u) : kNoWinner);
+    r.zmax = zm_[q];
+    r.imax = HAS_INT ? im_[q] : 0u;
+    r.cell = (c_[q] & 1023u) | fl_[q];
+    r.var = var_[q];
+    r.rgb = HAS_COL ? col_[q] : 0u;
+    r.pad = 0u;
+    uint4* const dst = reinterpret_cast<uint4*>(Q.rec + pos);
+    const uint4* const src = reinterpret_cast<const uint4*>(&r);
+    dst[0] = src[0];
+    dst[1] = src[1];
   }
 }
 
@@ -539,11 +563,15 @@ __global__ __launch_bounds__(THREADS) void k_tbin(const ScanParams P, const Geom
 
 // ---------------------------------------------------------------------------------------------
 // k_tupdate — 256 threads per tile.  LDS image of the tile (dynamic shared memory, per 256-thread
-// group), 1024-entry arrays: key u64 | zmax | zs | descriptors u64[256] | offsets u32[260]
+// group), 1024-entry arrays: key u64 | zmax | descriptors u64[256] | offsets u32[260]
 // [| imax | izs | first] [| last].
 __host__ __device__ constexpr unsigned tile_lds_bytes(bool has_int, bool has_col) {
-  return 1024u * (16u + (has_int ? 12u : 0u) + (has_col ? 4u : 0u)) + 260u * 4u + 256u * 8u;
+  return 1024u * (12u + (has_int ? 4u : 0u) + (has_col ? 4u : 0u)) + 260u * 4u + 256u * 8u;
 }
+
+// uniform value that came out of LDS / a ballot: tell the compiler (everything derived from it — tile number,
+// row pointer, loop bounds — then lives in scalar registers instead of one vector register each)
+__device__ __forceinline__ unsigned uni(unsigned v) { return unsigned(__builtin_amdgcn_readfirstlane(int(v))); }
 
 struct TileCtx {
   bool applied, do_update, strips;
@@ -581,24 +609,26 @@ __device__ __forceinline__ void make_tile_ctx(const ScanParams& P, DevState* __r
 // One tile by one 256-thread group (`lt` = thread inside the group).  Block-uniform control flow
 // around the barriers: `n_chunks_max` is the largest chunk count among the block's groups.
 // `d0` = word `lt` of the tile's descriptor row, already loaded by the caller (word 0 is the count).
-template <typename POLICY, int BLOCK>
+template <typename POLICY, int BLOCK, bool HAS_INT, bool HAS_COL>
 __device__ __forceinline__ void tupdate_tile(
     const ScanParams& P, const GeomConst& G, const TileGrid& TG, const TileCtx& u,
     const typename POLICY::Layers& L, float* const* __restrict__ all_layers, int n_layers,
     const TilePool& Q, const TileAux& A, unsigned char* lds, const unsigned tile, const bool tile_ok,
     const unsigned n_chunks, const unsigned n_chunks_max, const unsigned long long d0, const bool obst_tile,
-    const unsigned lt) {
+    const unsigned lt, const unsigned rare_slot, unsigned* s_rare /* one word per block */) {
   const float nanv = __uint_as_float(0x7FC00000u);
-  const bool has_int = P.has_intensity != 0, has_col = P.has_color != 0;
+  constexpr bool has_int = HAS_INT, has_col = HAS_COL;  // (compile-time: the LDS layout and a dozen uniform values fold away)
   unsigned long long* const s_key = reinterpret_cast<unsigned long long*>(lds);  // min of the records' keys
   uint32_t* const s_zmax = reinterpret_cast<uint32_t*>(s_key + 1024);
-  uint32_t* const s_zs = s_zmax + 1024;     // (pos << 1 | is -0) of the first record holding a zero z
-  unsigned long long* const s_desc = reinterpret_cast<unsigned long long*>(s_zs + 1024);  // [256]
+  unsigned long long* const s_desc = reinterpret_cast<unsigned long long*>(s_zmax + 1024);  // [256]
   uint32_t* const s_off = reinterpret_cast<uint32_t*>(s_desc + 256);                      // [260]
-  uint32_t* const s_imax = s_off + 260;     // (intensity scans)
-  uint32_t* const s_izs = s_imax + 1024;
-  uint32_t* const s_first = s_izs + 1024;
-  uint32_t* const s_last = s_off + 260 + (has_int ? 3072 : 0);  // (colour scans)
+  uint32_t* const s_imax = s_off + 260;                            // (intensity scans)
+  uint32_t* const s_last = s_off + 260 + (has_int ? 1024 : 0);     // (colour scans)
+  // rare-event words of the tile's cells (see k_tbin): global scratch of this group, only ever touched by a tile
+  // that holds a record flagged kRecRare
+  uint32_t* const g_zs = Q.rare + size_t(rare_slot) * 3072u;  // (pos << 1 | is -0) of the first record whose zmax is a zero
+  uint32_t* const g_izs = g_zs + 1024;
+  uint32_t* const g_first = g_zs + 2048;                       // (pos << 1 | first intensity is NaN) of the first record
   const unsigned long long* const row = Q.desc + size_t(tile_ok ? tile : 0u) * Q.stride;
 
   if (P.dbg_upd == 1) {
@@ -606,87 +636,106 @@ __device__ __forceinline__ void tupdate_tile(
     if (lt == 0 && tile_ok && n_chunks) Q.desc[size_t(tile) * Q.stride] = 0ull;
     return;
   }
+  bool rare_tile = false;  // block-uniform
   if (n_chunks_max) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const unsigned k = lt + q * 256u;
       s_key[k] = kEmptyKey;
       s_zmax[k] = 0u;
-      s_zs[k] = 0xFFFFFFFFu;
-      if (has_int) { s_imax[k] = 0u; s_izs[k] = 0xFFFFFFFFu; s_first[k] = kNoIdx; }
+      if (has_int) s_imax[k] = 0u;
       if (has_col) s_last[k] = 0u;
     }
-    // ---- fold the tile's records into the LDS image, 256 row words (255 chunks) at a time ----
-    for (unsigned c0 = 0; c0 <= n_chunks_max; c0 += 256u) {
-      unsigned long long d = 0ull;
-      if (c0 == 0u) d = lt ? d0 : 0ull;                      // (word 0 is the count)
-      else if (c0 + lt <= n_chunks) d = row[c0 + lt];
-      if (c0 + lt > n_chunks) d = 0ull;                      // beyond the list: whatever an earlier scan left
-      const unsigned cnt = unsigned(d >> 32);
-      // inclusive scan of the chunk sizes over the group's four wavefronts
-      unsigned inc = cnt;
-      const unsigned lane = lt & 63u;
+    // ---- fold the tile's records into the LDS image, 256 row words (255 chunks) at a time.  step 0: the
+    // values; step 1 (only a tile holding a record flagged kRecRare): the order of first occurrences, into the
+    // group's global scratch ----
+    bool rare_seen = false;
+#pragma unroll 1
+    for (int step = 0; step < 2; ++step) {
+#pragma unroll 1
+      for (unsigned c0 = 0; c0 <= n_chunks_max; c0 += 256u) {
+        unsigned long long d = 0ull;
+        if (c0 == 0u) d = lt ? d0 : 0ull;                      // (word 0 is the count)
+        else if (c0 + lt <= n_chunks) d = row[c0 + lt];
+        if (c0 + lt > n_chunks) d = 0ull;                      // beyond the list: whatever an earlier scan left
+        const unsigned cnt = unsigned(d >> 32);
+        // inclusive scan of the chunk sizes over the group's four wavefronts
+        unsigned inc = cnt;
+        const unsigned lane = lt & 63u;
 #pragma unroll
-      for (int dd = 1; dd < 64; dd <<= 1) {
-        const unsigned o = __shfl_up(inc, dd);
-        if (lane >= unsigned(dd)) inc += o;
-      }
-      __syncthreads();  // (the previous batch's readers of s_off / s_desc are done)
-      if (lane == 63u) s_off[256u + (lt >> 6)] = inc;
-      __syncthreads();
-      unsigned base = 0;
-      for (unsigned w = 0; w < (lt >> 6); ++w) base += s_off[256u + w];
-      s_off[lt] = base + inc - cnt;  // exclusive
-      s_desc[lt] = d;
-      __syncthreads();
-      const unsigned total = s_off[256u] + s_off[257u] + s_off[258u] + s_off[259u];
-      // kRecBatch records per thread and pass: all their loads are in flight before the first LDS atomic
-      for (unsigned r0 = lt; r0 < total; r0 += 256u * kRecBatch) {
-        unsigned pos_[kRecBatch];
-        uint32_t cw_[kRecBatch], zm_[kRecBatch], im_[kRecBatch];
-        unsigned long long k_[kRecBatch];
-#pragma unroll
-        for (int b = 0; b < kRecBatch; ++b) {
-          const unsigned r = r0 + unsigned(b) * 256u;
-          pos_[b] = 0xFFFFFFFFu; cw_[b] = 0u; zm_[b] = 0u; im_[b] = 0u; k_[b] = 0ull;
-          if (r >= total) continue;
-          // which chunk holds record r: the last one whose offset is <= r (real chunks are never empty;
-          // the batch's unused lanes sit at offset == total, its leading count word at offset 0 with
-          // size 0 — the search takes the LAST lane with offset <= r, never that one)
-          unsigned lo = 0, hi = 255u;
-#pragma unroll
-          for (int it = 0; it < 8; ++it) {
-            const unsigned mid = (lo + hi + 1u) >> 1;
-            const bool le = s_off[mid] <= r;
-            lo = le ? mid : lo;
-            hi = le ? hi : mid - 1u;
-          }
-          const unsigned pos = unsigned(s_desc[lo]) + (r - s_off[lo]);
-          pos_[b] = pos;
-          const uint4 w0 = reinterpret_cast<const uint4*>(Q.rec + pos)[0];  // key | zmax | imax
-          cw_[b] = Q.rec[pos].cell;
-          k_[b] = (unsigned long long)w0.x | ((unsigned long long)w0.y << 32);
-          zm_[b] = w0.z;
-          im_[b] = w0.w;
+        for (int dd = 1; dd < 64; dd <<= 1) {
+          const unsigned o = __shfl_up(inc, dd);
+          if (lane >= unsigned(dd)) inc += o;
         }
+        __syncthreads();  // (the previous batch's readers of s_off / s_desc are done)
+        if (lane == 63u) s_off[256u + (lt >> 6)] = inc;
+        __syncthreads();
+        unsigned base = 0;
+        for (unsigned w = 0; w < (lt >> 6); ++w) base += s_off[256u + w];
+        s_off[lt] = base + inc - cnt;  // exclusive
+        s_desc[lt] = d;
+        __syncthreads();
+        const unsigned total = uni(s_off[256u] + s_off[257u] + s_off[258u] + s_off[259u]);
+        // kRecBatch records per thread and pass: all their loads are in flight before the first atomic
+#pragma unroll 1
+        for (unsigned r0 = lt; r0 < total; r0 += 256u * kRecBatch) {
+          unsigned pos_[kRecBatch];
+          uint32_t cw_[kRecBatch], zm_[kRecBatch], im_[kRecBatch];
+          unsigned long long k_[kRecBatch];
 #pragma unroll
-        for (int b = 0; b < kRecBatch; ++b) {
-          if (pos_[b] == 0xFFFFFFFFu) continue;
-          const unsigned pos = pos_[b];
-          const uint32_t cw = cw_[b], lc = cw & 1023u;
-          atomicMin(&s_key[lc], k_[b]);
-          if (zm_[b]) atomicMax(&s_zmax[lc], zm_[b]);
-          if (cw & kRecZZero) atomicMin(&s_zs[lc], (pos << 1) | ((cw & kRecZNeg) ? 1u : 0u));
-          if (has_int) {
-            if (im_[b]) atomicMax(&s_imax[lc], im_[b]);
-            if (cw & kRecIZero) atomicMin(&s_izs[lc], (pos << 1) | ((cw & kRecINeg) ? 1u : 0u));
-            atomicMin(&s_first[lc], (pos << 1) | ((cw & kRecNanFirst) ? 1u : 0u));
+          for (int b = 0; b < kRecBatch; ++b) {
+            const unsigned r = r0 + unsigned(b) * 256u;
+            pos_[b] = 0xFFFFFFFFu; cw_[b] = 0u; zm_[b] = 0u; im_[b] = 0u; k_[b] = 0ull;
+            if (r >= total) continue;
+            // which chunk holds record r: the last one whose offset is <= r (real chunks are never empty;
+            // the batch's unused lanes sit at offset == total, its leading count word at offset 0 with
+            // size 0 — the search takes the LAST lane with offset <= r, never that one)
+            unsigned lo = 0, hi = 255u;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+              const unsigned mid = (lo + hi + 1u) >> 1;
+              const bool le = s_off[mid] <= r;
+              lo = le ? mid : lo;
+              hi = le ? hi : mid - 1u;
+            }
+            const unsigned pos = unsigned(s_desc[lo]) + (r - s_off[lo]);
+            pos_[b] = pos;
+            const uint4 w0 = reinterpret_cast<const uint4*>(Q.rec + pos)[0];  // key | zmax | imax
+            cw_[b] = Q.rec[pos].cell;
+            k_[b] = (unsigned long long)w0.x | ((unsigned long long)w0.y << 32);
+            zm_[b] = w0.z;
+            im_[b] = w0.w;
           }
-          if (has_col) atomicMax(&s_last[lc], pos + 1u);
+#pragma unroll
+          for (int b = 0; b < kRecBatch; ++b) {
+            if (pos_[b] == 0xFFFFFFFFu) continue;
+            const unsigned pos = pos_[b];
+            const uint32_t cw = cw_[b], lc = cw & 1023u;
+            if (step == 0) {
+              atomicMin(&s_key[lc], k_[b]);
+              atomicMax(&s_zmax[lc], zm_[b]);  // (max with 0: no-op)
+              if (has_int) atomicMax(&s_imax[lc], im_[b]);
+              if (has_col) atomicMax(&s_last[lc], pos + 1u);
+              rare_seen = rare_seen || (cw & kRecRare) != 0u;
+            } else {
+              if (zm_[b] == kOrdZero) atomicMin(&g_zs[lc], (pos << 1) | ((cw & kRecZNeg) ? 1u : 0u));
+              if (has_int) {
+                if (im_[b] == kOrdZero) atomicMin(&g_izs[lc], (pos << 1) | ((cw & kRecINeg) ? 1u : 0u));
+                atomicMin(&g_first[lc], (pos << 1) | ((cw & kRecNanFirst) ? 1u : 0u));
+              }
+            }
+          }
         }
       }
+      if (step == 0) {
+        if (__ballot(rare_seen) && (lt & 63u) == 0u) *s_rare = 1u;
+        __syncthreads();
+        rare_tile = uni(*s_rare) != 0u;
+        if (!rare_tile) break;
+        for (unsigned k = lt; k < 3072u; k += 256u) g_zs[k] = 0xFFFFFFFFu;  // (zs | izs | first)
+      }
+      __syncthreads();  // step 0: the image is complete / the scratch is initialised; step 1: every atomic has landed
     }
-    __syncthreads();
   }
 
   if (P.dbg_upd == 2) {
@@ -716,7 +765,7 @@ __device__ __forceinline__ void tupdate_tile(
     __syncthreads();
     unsigned base = 0;
     for (unsigned w = 0; w < (lt >> 6); ++w) base += s_off[256u + w];
-    n_touched = s_off[256u] + s_off[257u] + s_off[258u] + s_off[259u];
+    n_touched = uni(s_off[256u] + s_off[257u] + s_off[258u] + s_off[259u]);
     const unsigned long long below = (1ull << (lt & 63u)) - 1ull;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -727,6 +776,7 @@ __device__ __forceinline__ void tupdate_tile(
   }
   if (work) {
     // touched cells: one per thread (kCellBatch per pass when the tile holds more than 256)
+#pragma unroll 1
     for (unsigned j0 = lt; j0 < n_touched; j0 += 256u * kCellBatch) {
       unsigned o_[kCellBatch];
       bool on_[kCellBatch], strip_[kCellBatch];
@@ -748,8 +798,14 @@ __device__ __forceinline__ void tupdate_tile(
                                  in_cleared_strip(sc + G.s_c0, u.E.sc, u.C.shc, G.cols));
         key_[b] = s_key[lc];
         zm_[b] = s_zmax[lc];
-        zsw_[b] = s_zs[lc];
-        if (has_int) { im_[b] = s_imax[lc]; izw_[b] = s_izs[lc]; fst_[b] = s_first[lc]; }
+        if (has_int) im_[b] = s_imax[lc];
+        if (rare_tile) {  // (written by memory-side atomics of this block: read past the L1 / L2 copies)
+          zsw_[b] = __hip_atomic_load(&g_zs[lc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (has_int) {
+            izw_[b] = __hip_atomic_load(&g_izs[lc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fst_[b] = __hip_atomic_load(&g_first[lc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
         const uint32_t wl = uint32_t(key_[b]);
         if (wl != kNoWinner) var_[b] = Q.rec[wl >> 1].var;
         if (has_col) rgb_[b] = Q.rec[s_last[lc] - 1u].rgb;
@@ -828,28 +884,27 @@ __device__ __forceinline__ void tupdate_tile(
   }
 }
 
-// A block of BLOCK threads = BLOCK/256 groups; every group looks after `span` consecutive tiles
-// (span = 1 on maps whose tile count fills the chip by itself — the group then reads its tile's whole
-// descriptor row, count included, in ONE round trip — and 32 on very large maps where nearly every tile
-// is idle: the group's first wavefront reads the 32 chunk counts / stamps in one round trip and only the
-// live tiles are visited).
-template <typename POLICY, int BLOCK>
+// One 256-thread block looks after `span` tiles (span = 1 on maps whose tile count fills the chip by itself —
+// the block then reads its tile's whole descriptor row, count included, in ONE round trip — and 32 on very
+// large maps where nearly every tile is idle: the first wavefront reads the 32 chunk counts / stamps in one
+// round trip and only the live tiles are visited).
+template <typename POLICY, int BLOCK, bool HAS_INT, bool HAS_COL>
 __device__ __forceinline__ void tupdate_body(
     const ScanParams& P, const GeomConst& G, const TileGrid& TG, DevState* __restrict__ st,
     const typename POLICY::Layers& L, float* const* __restrict__ all_layers, int n_layers,
     const TilePool& Q, const TileAux& A, const unsigned span, unsigned char* dyn_lds, const unsigned bid) {
-  constexpr unsigned kGroups = unsigned(BLOCK) / 256u;
-  __shared__ unsigned long long s_live[kGroups], s_ob[kGroups];
-  __shared__ unsigned s_nch[kGroups][64];
-  const unsigned g = threadIdx.x >> 8, lt = threadIdx.x & 255u;
-  unsigned char* const lds = dyn_lds + size_t(g) * tile_lds_bytes(P.has_intensity != 0, P.has_color != 0);
-  // slot q of group i is tile i + q * n_groups: the tiles a scan touches are neighbours in the map (and in tile
-  // order), so consecutive slots would put all of them into a few groups that then walk them one after the
-  // other (configs[4] on one GPU: 209 us); strided, the live tiles spread over all groups
+  static_assert(BLOCK == 256, "one tile group per block");
+  __shared__ unsigned long long s_live, s_ob;
+  __shared__ unsigned s_nch[64];
+  __shared__ unsigned s_rare;
+  const unsigned lt = threadIdx.x;
+  // slot q of block i is tile i + q * n_groups: the tiles a scan touches are neighbours in the map (and in tile
+  // order), so consecutive slots would put all of them into a few blocks that then walk them one after the
+  // other (configs[4] on one GPU: 209 us); strided, the live tiles spread over all blocks
   const unsigned n_groups = (TG.n_tiles + span - 1u) / span;
-  const unsigned first = bid * kGroups + g;
+  const unsigned first = bid;
 
-  // round trip 1: the tile's descriptor row (span 1) or the chunk counts of the group's tiles, the
+  // round trip 1: the tile's descriptor row (span 1) or the chunk counts of the block's tiles, the
   // stamps, and the scan context
   unsigned long long d0 = 0ull;
   if (span == 1u && first < TG.n_tiles && lt < Q.stride) d0 = Q.desc[size_t(first) * Q.stride + lt];
@@ -860,59 +915,51 @@ __device__ __forceinline__ void tupdate_body(
     unsigned nch = 0;
     if (lt < span) {
       const unsigned tile = first + lt * n_groups;
-      if (first < n_groups && tile < TG.n_tiles) {  // (a surplus group of the grid's last block owns nothing)
+      if (first < n_groups && tile < TG.n_tiles) {  // (a surplus block of the grid owns nothing)
         nch = span == 1u ? unsigned(d0) : unsigned(Q.desc[size_t(tile) * Q.stride]);
         const unsigned stamp = A.stamp[tile];
         ob = u.do_update && (nch != 0u || stamp == u.ob_scan);
         live = nch != 0u || u.strips || ob;
         if (!live) A.upd_part[tile] = 0u;
       }
-      s_nch[g][lt] = nch;
+      s_nch[lt] = nch;
     }
     const unsigned long long m = __ballot(live), mo = __ballot(ob);
-    if (lt == 0) { s_live[g] = m; s_ob[g] = mo; }
+    if (lt == 0) { s_live = m; s_ob = mo; s_rare = 0u; }
   }
   __syncthreads();
-  // block-uniform walk over the union of the groups' live slots
-  unsigned long long any = 0ull;
-#pragma unroll
-  for (unsigned k = 0; k < kGroups; ++k) any |= s_live[k];
-  while (any) {
-    const unsigned q = unsigned(__ffsll((long long)any)) - 1u;
-    any &= any - 1ull;
-    const bool mine = (s_live[g] >> q) & 1ull;
+  unsigned live_lo = uni(unsigned(s_live)), live_hi = uni(unsigned(s_live >> 32));
+  const unsigned ob_lo = uni(unsigned(s_ob)), ob_hi = uni(unsigned(s_ob >> 32));
+  while (live_lo | live_hi) {  // block-uniform walk over the live slots
+    const unsigned q = live_lo ? unsigned(__ffs(int(live_lo))) - 1u : 32u + unsigned(__ffs(int(live_hi))) - 1u;
+    if (q < 32u) live_lo &= live_lo - 1u; else live_hi &= live_hi - 1u;
     const unsigned tile = first + q * n_groups;
-    const unsigned nch = mine ? s_nch[g][q] : 0u;
-    unsigned nmax = 0u;  // the block's groups walk the barriers of tupdate_tile together
-#pragma unroll
-    for (unsigned k = 0; k < kGroups; ++k) {
-      const unsigned nk = ((s_live[k] >> q) & 1ull) ? s_nch[k][q] : 0u;
-      nmax = nk > nmax ? nk : nmax;
-    }
+    const unsigned nch = uni(s_nch[q]);
     unsigned long long dq = d0;
     if (span != 1u) {
       dq = 0ull;
-      if (mine && lt <= nch && lt < Q.stride) dq = Q.desc[size_t(tile) * Q.stride + lt];
+      if (lt <= nch && lt < Q.stride) dq = Q.desc[size_t(tile) * Q.stride + lt];
     }
-    const bool obst_tile = mine && ((s_ob[g] >> q) & 1ull);
-    tupdate_tile<POLICY, BLOCK>(P, G, TG, u, L, all_layers, n_layers, Q, A, lds, tile,
-                                mine && tile < TG.n_tiles, nch, nmax, dq, obst_tile, lt);
+    const bool obst_tile = ((q < 32u ? ob_lo >> q : ob_hi >> (q - 32u)) & 1u) != 0u;
+    tupdate_tile<POLICY, BLOCK, HAS_INT, HAS_COL>(P, G, TG, u, L, all_layers, n_layers, Q, A, dyn_lds, tile, true, nch,
+                                                  nch, dq, obst_tile, lt, first, &s_rare);
     __syncthreads();
+    if (lt == 0) s_rare = 0u;  // (read only behind barriers inside tupdate_tile)
   }
 }
 
-template <typename POLICY>
-__global__ __launch_bounds__(256) void k_tupdate(
+template <typename POLICY, bool HAS_INT, bool HAS_COL>
+__global__ __launch_bounds__(256, FDM_UPD_WAVES) void k_tupdate(
     const ScanParams P, const GeomConst G, const TileGrid TG, DevState* __restrict__ st,
     const typename POLICY::Layers L, float* const* __restrict__ all_layers, int n_layers,
     const TilePool Q, const TileAux A, unsigned span) {
   extern __shared__ __align__(16) unsigned char dyn_lds[];
-  tupdate_body<POLICY, 256>(P, G, TG, st, L, all_layers, n_layers, Q, A, span, dyn_lds, blockIdx.x);
+  tupdate_body<POLICY, 256, HAS_INT, HAS_COL>(P, G, TG, st, L, all_layers, n_layers, Q, A, span, dyn_lds, blockIdx.x);
 }
 
 // update of scan t + bin of scan t+1 in one launch (the pools are double-buffered by scan parity)
 template <typename POLICY, bool HAS_INT, bool HAS_COL, int THREADS, bool LEAN>
-__global__ __launch_bounds__(THREADS) void k_tupdate_tbin(
+__global__ __launch_bounds__(THREADS, FDM_UPD_WAVES) void k_tupdate_tbin(
     const ScanParams Pu, const GeomConst G, const TileGrid TG, DevState* __restrict__ st,
     const typename POLICY::Layers L, float* const* __restrict__ all_layers, int n_layers,
     const TilePool Qu, const TileAux A, unsigned span, unsigned upd_blocks, const ScanParams Pb,
@@ -924,7 +971,7 @@ __global__ __launch_bounds__(THREADS) void k_tupdate_tbin(
   const unsigned u0 = blockIdx.x < upd_blocks ? blockIdx.x : upd_blocks;
   const unsigned u1 = blockIdx.x < upd_blocks ? blockIdx.x + 1u : upd_blocks;
   if (u1 > u0)
-    tupdate_body<POLICY, THREADS>(Pu, G, TG, st, L, all_layers, n_layers, Qu, A, span, dyn_lds, u0);
+    tupdate_body<POLICY, THREADS, HAS_INT, HAS_COL>(Pu, G, TG, st, L, all_layers, n_layers, Qu, A, span, dyn_lds, u0);
   else
     tbin_body<HAS_INT, HAS_COL, THREADS, LEAN>(Pb, G, TG, st, Ib, Sb, Qb, cell_ids, dyn_lds, blockIdx.x - u0);
 }

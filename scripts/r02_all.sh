@@ -10,7 +10,7 @@ import json
 try:
     d=json.loads(open("gpurun_out/all_$W.json").read().strip().splitlines()[-1])
     k=d.get("kernels",{})
-    print("$W rc=$rc", "Mpts/s", round(d["value"]), "us/step", round(d["ms_per_step"]*1e3,2), "frac", round(d.get("roofline",{}).get("frac") or 0,4), {a:round(v["ms"]*1e3,2) for a,v in k.items() if isinstance(v,dict)})
+    print("$W rc=$rc", "Mpts/s", round(d["value"]), "us/step", round(d["ms_per_step"]*1e3,2), "frac", round(d.get("roofline",{}).get("frac") or 0,4), {a:round(v["ms"]*1e3,2) for a,v in k.items() if isinstance(v,dict) and "ms" in v})
 except Exception as e: print("$W rc=$rc parse fail", e); print(open("gpurun_out/all_$W.err").read()[-600:])
 PY
 done

@@ -10,7 +10,7 @@ import json
 try:
     d=json.loads(open("gpurun_out/d_$name.json").read().strip().splitlines()[-1])
     k=d.get("kernels",{})
-    print("$name", "rc=$rc", "step us", round(d["ms_per_step"]*1e3,2), {a:round(v["ms"]*1e3,2) for a,v in k.items() if isinstance(v,dict)})
+    print("$name", "rc=$rc", "step us", round(d["ms_per_step"]*1e3,2), {a:round(v["ms"]*1e3,2) for a,v in k.items() if isinstance(v,dict) and "ms" in v})
 except Exception as e: print("$name rc=$rc parse fail", e); print(open("gpurun_out/d_$name.err").read()[-400:])
 PY
 }

@@ -12,7 +12,7 @@ import json
 try:
     d=json.loads(open("gpurun_out/c4_$name.json").read().strip().splitlines()[-1])
     print("  value", round(d["value"]), "us/step", round(d["ms_per_step"]*1e3,2), "roof us", d.get("roofline",{}).get("avg_kernel_us"), "frac", d.get("roofline",{}).get("frac"))
-    print("  ", {k:(round(v["ms"]*1e3,2) if isinstance(v,dict) else v) for k,v in d.get("kernels",{}).items() if isinstance(v,dict)})
+    print("  ", {k:(round(v["ms"]*1e3,2) if isinstance(v,dict) else v) for k,v in d.get("kernels",{}).items() if isinstance(v,dict) and "ms" in v})
 except Exception as e: print("parse fail", e)
 PY
 }
