@@ -265,12 +265,14 @@ __device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& 
     }
   };
   load_points();
-  for (int k = threadIdx.x; k < kSlots; k += THREADS) {
-    h_cell[k] = kEmptyCell;
-    h_key[k] = kEmptyKey;
-    h_zmax[k] = 0u;
-    if (HAS_INT) h_imax[k] = 0u;
-    if (HAS_COL) h_last[k] = 0u;
+  {  // table initialisation, 16 bytes per LDS store (4 slots per thread and array)
+    const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu), zero = make_uint4(0u, 0u, 0u, 0u);
+    reinterpret_cast<uint4*>(h_cell)[threadIdx.x] = ones;                  // kEmptyCell
+    reinterpret_cast<uint4*>(h_key)[2 * threadIdx.x] = ones;               // kEmptyKey (two keys per store)
+    reinterpret_cast<uint4*>(h_key)[2 * threadIdx.x + 1] = ones;
+    reinterpret_cast<uint4*>(h_zmax)[threadIdx.x] = zero;
+    if (HAS_INT) reinterpret_cast<uint4*>(h_imax)[threadIdx.x] = zero;
+    if (HAS_COL) reinterpret_cast<uint4*>(h_last)[threadIdx.x] = zero;
   }
   if (threadIdx.x == 0) s_rare = 0u;
   const DevCand cand = block_candidate(P, G, st, &s_cand, bid);  // contains the __syncthreads
@@ -307,7 +309,7 @@ __device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& 
   };
 
   // phase 2: merge runs of equal cell in registers, fold each run into the table
-  uint32_t pflags = 0u;  // 8 bits per point, see below
+  bool rare = false;  // a -0.0 or a NaN intensity among this thread's points
   {
     int run_cell = -1;
     unsigned long long run_key = kEmptyKey;
@@ -333,15 +335,14 @@ __device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& 
                                                    : ((unsigned long long)ord(kFltMax) << 32) | kNoWinner;
       const uint32_t zmx = (z > -kFltMax) ? oz : 0u;
       uint32_t imx = 0u;
-      // what the rare path needs of this point, 5 bits: z is a zero / is -0, intensity is a zero / is -0 / is NaN
-      uint32_t pf = (z == 0.0f ? 1u : 0u) | (zneg << 1);
+      rare = rare || zneg != 0u;
       if (HAS_INT) {
         const float vv = vs[j];
-        const bool vnan = isnan(vv);
+        const uint32_t vb = __float_as_uint(vv);
+        const bool vnan = (vb & 0x7FFFFFFFu) > 0x7F800000u;
         imx = vnan ? 0u : ord_canon(vv);
-        pf |= (vv == 0.0f ? 4u : 0u) | (__float_as_uint(vv) == 0x80000000u ? 8u : 0u) | (vnan ? 16u : 0u);
+        rare = rare || vnan || vb == 0x80000000u;
       }
-      pflags |= pf << (8 * j);
       if (cells[j] != run_cell) {
         fold_run();
         run_cell = cells[j];
@@ -357,7 +358,7 @@ __device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& 
     }
     fold_run();
     // a -0.0 or a NaN intensity among the block's points: the order of first occurrences matters
-    if (__ballot((pflags & 0x1A1A1A1Au) != 0u) && lane == 0) s_rare = 1u;
+    if (__ballot(rare) && lane == 0) s_rare = 1u;
   }
   __syncthreads();  // every run of the block is in the table
   if (threadIdx.x == 0) {
@@ -428,7 +429,7 @@ __device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& 
   __syncthreads();
   if (rare_block) {
     // Rare path: some point of the block is a -0.0 or has a NaN intensity, so the order of first occurrences
-    // matters.  The points are walked once more (their cells and five flag bits each stayed in registers) into
+    // matters.  The points are walked once more (their cells, z and intensity stayed in registers) into
     // three table arrays that are dead now: per slot the (order << 1 | is -0) of the first zero-valued z, of
     // the first zero-valued intensity, and (order << 1 | is NaN) of the first point.
     uint32_t* const r_zs = h_cell + kSlots;      // (the key's memory)
@@ -441,12 +442,13 @@ __device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (cells[j] < 0) continue;
-      const uint32_t li = l0 + j, pf = pflags >> (8 * j);
+      const uint32_t li = l0 + j;
       const uint32_t h = find_slot(uint32_t(cells[j]));  // (present: the main fold put it there)
-      if (pf & 1u) atomicMin(&r_zs[h], (li << 1) | ((pf >> 1) & 1u));
+      if (zs[j] == 0.0f) atomicMin(&r_zs[h], (li << 1) | (__float_as_uint(zs[j]) == 0x80000000u ? 1u : 0u));
       if (HAS_INT) {
-        if (pf & 4u) atomicMin(&r_izs[h], (li << 1) | ((pf >> 3) & 1u));
-        atomicMin(&r_first[h], (li << 1) | ((pf >> 4) & 1u));
+        const float vv = vs[j];
+        if (vv == 0.0f) atomicMin(&r_izs[h], (li << 1) | (__float_as_uint(vv) == 0x80000000u ? 1u : 0u));
+        atomicMin(&r_first[h], (li << 1) | (isnan(vv) ? 1u : 0u));
       }
     }
     __syncthreads();
@@ -966,8 +968,10 @@ __global__ __launch_bounds__(THREADS, FDM_UPD_WAVES) void k_tupdate_tbin(
     const ScanInputs Ib, const Scratch Sb, const TilePool Qb, int32_t* __restrict__ cell_ids) {
   extern __shared__ __align__(16) unsigned char dyn_lds[];
   // Update blocks first: they are short chains of dependent memory round trips that barely use the
-  // vector units, so they get going at once and the bin blocks (arithmetic-bound) fill the chip behind
-  // them (C4: 42.4 us against 44.9 with the two kinds interleaved in proportion, 49.5 as two launches).
+  // vector units, so they get going at once and the bin blocks (arithmetic-bound) fill the chip behind them
+  // (C4, final kernels: 35.3 us against 39.5 with the two kinds interleaved in proportion, and 37.7-40.1 with a
+  // heavy-tiles-first square ahead of an interleaved rest — bin blocks that start early slow the latency-bound
+  // tile chains down by more than they gain).
   const unsigned u0 = blockIdx.x < upd_blocks ? blockIdx.x : upd_blocks;
   const unsigned u1 = blockIdx.x < upd_blocks ? blockIdx.x + 1u : upd_blocks;
   if (u1 > u0)
