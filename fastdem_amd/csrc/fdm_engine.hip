@@ -527,7 +527,7 @@ unsigned tile_span(const fdm_engine* e) { return e->TG.n_tiles <= 16384u ? 1u : 
 int ensure_tile_pool(fdm_engine* e, size_t records, unsigned blocks, bool has_int, bool has_col) {
   if (!e->tile_stamp32) {
     e->TG.tiles_r = (e->G.s_rows + kTS - 1) / kTS;
-    e->TG.tiles_c = (e->G.s_cols + kTS - 1) / kTS;
+    e->TG.tiles_c = (e->G.s_cols + kTC - 1) / kTC;
     e->TG.n_tiles = unsigned(e->TG.tiles_r) * unsigned(e->TG.tiles_c);
     if (e->TG.n_tiles >= (1u << 21)) return fail(FDM_ERR_INVALID, "tiled pipeline: more than 2^21 map tiles");
     HIPCK(hipMalloc(reinterpret_cast<void**>(&e->tile_stamp32), e->TG.n_tiles * sizeof(uint32_t)));
@@ -537,7 +537,7 @@ int ensure_tile_pool(fdm_engine* e, size_t records, unsigned blocks, bool has_in
     {
       const unsigned span = tile_span(e);
       const size_t groups = (e->TG.n_tiles + span - 1u) / span + 2u;
-      HIPCK(hipMalloc(reinterpret_cast<void**>(&e->tile_rare), groups * 3072u * sizeof(uint32_t)));
+      HIPCK(hipMalloc(reinterpret_cast<void**>(&e->tile_rare), groups * 3u * kTileCells * sizeof(uint32_t)));
       for (auto& q : e->pool) q.rare = e->tile_rare;
     }
     HIPCK(hipGetLastError());
@@ -804,7 +804,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   // large scans: per-tile record pools (fdm_tiled.hpp); needs the cell-record layout
   // ... and a map with enough 32x32 tiles to keep the chip busy with one block per tile (configs[2], 49 tiles:
   // 31 us against 13.8 us through the per-cell scratch; configs[3], 1444 tiles: 40.7 against 51.3 us)
-  const bool enough_tiles = e->tiled_forced || (e->ncell >> 10) >= 512;
+  const bool enough_tiles = e->tiled_forced || e->ncell / kTileCells >= 512;
   const bool tiled = e->tiled && e->rec_kind >= 0 && n >= e->tiled_min && aligned && n < 0x7FFF0000ull &&
                      e->bin_variant != 1 && enough_tiles;
   if (e->last_kind >= 0 && e->last_kind != int(tiled)) e->obst_dense_pending = true;  // the pipelines keep

@@ -39,9 +39,16 @@
 
 namespace fdm {
 
-constexpr int kTS = 32;                 // tile edge in cells
+#ifndef FDM_TILE_COL_SHIFT
+#define FDM_TILE_COL_SHIFT 5
+#endif
+constexpr int kTS = 32;                 // tile height: 32 consecutive rows of a column = 128 B of every layer
 constexpr int kTSShift = 5;
-constexpr unsigned kTileCells = 1024u;  // kTS * kTS
+constexpr int kTCShift = FDM_TILE_COL_SHIFT;   // tile width: 32 columns (16: the update alone 21.9 -> 18.7 us, but twice the tile
+                                               // blocks ahead of the bin blocks: fused launch 34.2 -> 37.5 us)
+constexpr int kTC = 1 << kTCShift;
+constexpr unsigned kTileCells = unsigned(kTS * kTC);
+constexpr int kCellsPerThread = int(kTileCells) / 256;
 constexpr uint32_t kNoWinner = 0xFFFFFFFFu;
 constexpr uint32_t kOrdZero = 0x80000000u;  // ord(+0.0f)
 #ifndef FDM_UPD_WAVES
@@ -112,8 +119,8 @@ __device__ __forceinline__ int owned_tcell(float x, float y, const DevCand& cand
   if (lr < 0 || lc < 0 || lr >= G.o_rows || lc >= G.o_cols) return -2;
   const int sr = r - G.s_r0, sc = c - G.s_c0;
   lin = sc * G.s_rows + sr;
-  const int tile = (sc >> kTSShift) * TG.tiles_r + (sr >> kTSShift);
-  return (tile << 10) | ((sc & (kTS - 1)) << kTSShift) | (sr & (kTS - 1));
+  const int tile = (sc >> kTCShift) * TG.tiles_r + (sr >> kTSShift);
+  return (tile << 10) | ((sc & (kTC - 1)) << kTSShift) | (sr & (kTS - 1));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -196,8 +203,8 @@ __device__ __forceinline__ void tbin_points(const ScanParams& P, const GeomConst
     const int lr = r - G.o_r0, lc = c - G.o_c0;
     const bool owned = in_map && lr >= 0 && lc >= 0 && lr < G.o_rows && lc < G.o_cols;
     const int sr = r - G.s_r0, sc = c - G.s_c0;
-    const int tile = (sc >> kTSShift) * TG.tiles_r + (sr >> kTSShift);
-    const int tcell = (tile << 10) | ((sc & (kTS - 1)) << kTSShift) | (sr & (kTS - 1));
+    const int tile = (sc >> kTCShift) * TG.tiles_r + (sr >> kTSShift);
+    const int tcell = (tile << 10) | ((sc & (kTC - 1)) << kTSShift) | (sr & (kTS - 1));
     cells[j] = owned ? tcell : (in_map ? -2 : -1);
     n_in += owned ? 1u : 0u;
     any_glob = any_glob || in_map;
@@ -568,7 +575,7 @@ __global__ __launch_bounds__(THREADS) void k_tbin(const ScanParams P, const Geom
 // group), 1024-entry arrays: key u64 | zmax | descriptors u64[256] | offsets u32[260]
 // [| imax | izs | first] [| last].
 __host__ __device__ constexpr unsigned tile_lds_bytes(bool has_int, bool has_col) {
-  return 1024u * (12u + (has_int ? 4u : 0u) + (has_col ? 4u : 0u)) + 260u * 4u + 256u * 8u;
+  return kTileCells * (12u + (has_int ? 4u : 0u) + (has_col ? 4u : 0u)) + 260u * 4u + 256u * 8u;
 }
 
 // uniform value that came out of LDS / a ballot: tell the compiler (everything derived from it — tile number,
@@ -621,16 +628,16 @@ __device__ __forceinline__ void tupdate_tile(
   const float nanv = __uint_as_float(0x7FC00000u);
   constexpr bool has_int = HAS_INT, has_col = HAS_COL;  // (compile-time: the LDS layout and a dozen uniform values fold away)
   unsigned long long* const s_key = reinterpret_cast<unsigned long long*>(lds);  // min of the records' keys
-  uint32_t* const s_zmax = reinterpret_cast<uint32_t*>(s_key + 1024);
-  unsigned long long* const s_desc = reinterpret_cast<unsigned long long*>(s_zmax + 1024);  // [256]
+  uint32_t* const s_zmax = reinterpret_cast<uint32_t*>(s_key + kTileCells);
+  unsigned long long* const s_desc = reinterpret_cast<unsigned long long*>(s_zmax + kTileCells);  // [256]
   uint32_t* const s_off = reinterpret_cast<uint32_t*>(s_desc + 256);                      // [260]
   uint32_t* const s_imax = s_off + 260;                            // (intensity scans)
-  uint32_t* const s_last = s_off + 260 + (has_int ? 1024 : 0);     // (colour scans)
+  uint32_t* const s_last = s_off + 260 + (has_int ? kTileCells : 0u);     // (colour scans)
   // rare-event words of the tile's cells (see k_tbin): global scratch of this group, only ever touched by a tile
   // that holds a record flagged kRecRare
-  uint32_t* const g_zs = Q.rare + size_t(rare_slot) * 3072u;  // (pos << 1 | is -0) of the first record whose zmax is a zero
-  uint32_t* const g_izs = g_zs + 1024;
-  uint32_t* const g_first = g_zs + 2048;                       // (pos << 1 | first intensity is NaN) of the first record
+  uint32_t* const g_zs = Q.rare + size_t(rare_slot) * (3u * kTileCells);  // (pos << 1 | is -0) of the first record whose zmax is a zero
+  uint32_t* const g_izs = g_zs + kTileCells;
+  uint32_t* const g_first = g_zs + 2u * kTileCells;                       // (pos << 1 | first intensity is NaN) of the first record
   const unsigned long long* const row = Q.desc + size_t(tile_ok ? tile : 0u) * Q.stride;
 
   if (P.dbg_upd == 1) {
@@ -641,7 +648,7 @@ __device__ __forceinline__ void tupdate_tile(
   bool rare_tile = false;  // block-uniform
   if (n_chunks_max) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < kCellsPerThread; ++q) {
       const unsigned k = lt + q * 256u;
       s_key[k] = kEmptyKey;
       s_zmax[k] = 0u;
@@ -734,7 +741,7 @@ __device__ __forceinline__ void tupdate_tile(
         __syncthreads();
         rare_tile = uni(*s_rare) != 0u;
         if (!rare_tile) break;
-        for (unsigned k = lt; k < 3072u; k += 256u) g_zs[k] = 0xFFFFFFFFu;  // (zs | izs | first)
+        for (unsigned k = lt; k < 3u * kTileCells; k += 256u) g_zs[k] = 0xFFFFFFFFu;  // (zs | izs | first)
       }
       __syncthreads();  // step 0: the image is complete / the scratch is initialised; step 1: every atomic has landed
     }
@@ -749,17 +756,17 @@ __device__ __forceinline__ void tupdate_tile(
   // rows).  The touched ones are compacted into a list first, so that each is one thread's only cell and
   // all their record / sigma loads are ONE round trip instead of four dependent ones. ----
   const unsigned tr = tile % unsigned(TG.tiles_r), tc = tile / unsigned(TG.tiles_r);
-  uint16_t* const s_tlist = reinterpret_cast<uint16_t*>(s_desc);  // [1024] (the descriptors are consumed)
+  uint16_t* const s_tlist = reinterpret_cast<uint16_t*>(s_desc);  // [kTileCells] (the descriptors are consumed)
   const bool work = tile_ok && (n_chunks || obst_tile || u.strips);
   unsigned n_touched = 0;  // of the whole tile (group-uniform)
   if (n_chunks_max) {      // block-uniform: barriers inside
-    unsigned long long tm[4];
+    unsigned long long tm[kCellsPerThread];
     unsigned mine = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < kCellsPerThread; ++q) {
       const unsigned lc = lt + unsigned(q) * 256u;
       const bool t = work && n_chunks && u.do_update && s_key[lc] != kEmptyKey &&
-                     int(tr * kTS + (lc & 31u)) < G.s_rows && int(tc * kTS + (lc >> 5)) < G.s_cols;
+                     int(tr * kTS + (lc & 31u)) < G.s_rows && int(tc * kTC + (lc >> 5)) < G.s_cols;
       tm[q] = __ballot(t);
       mine += unsigned(__popcll(tm[q]));  // (wave total)
     }
@@ -770,7 +777,7 @@ __device__ __forceinline__ void tupdate_tile(
     n_touched = uni(s_off[256u] + s_off[257u] + s_off[258u] + s_off[259u]);
     const unsigned long long below = (1ull << (lt & 63u)) - 1ull;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < kCellsPerThread; ++q) {
       if ((tm[q] >> (lt & 63u)) & 1ull) s_tlist[base + unsigned(__popcll(tm[q] & below))] = uint16_t(lt + unsigned(q) * 256u);
       base += unsigned(__popcll(tm[q]));
     }
@@ -794,7 +801,7 @@ __device__ __forceinline__ void tupdate_tile(
         fst_[b] = 0u; rgb_[b] = 0u; var_[b] = 0.0f; sint_[b] = nanv;  // (CellObservation defaults: var 0)
         if (!on_[b]) continue;
         const unsigned lc = s_tlist[j];
-        const int sr = int(tr * kTS + (lc & 31u)), sc = int(tc * kTS + (lc >> 5));
+        const int sr = int(tr * kTS + (lc & 31u)), sc = int(tc * kTC + (lc >> 5));
         o_[b] = unsigned(sc) * unsigned(G.s_rows) + unsigned(sr);
         strip_[b] = u.strips && (in_cleared_strip(sr + G.s_r0, u.E.sr, u.C.shr, G.rows) ||
                                  in_cleared_strip(sc + G.s_c0, u.E.sc, u.C.shc, G.cols));
@@ -850,9 +857,9 @@ __device__ __forceinline__ void tupdate_tile(
     // untouched cells: stores only
     if (obst_tile || u.strips) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < kCellsPerThread; ++q) {
         const unsigned lc = lt + unsigned(q) * 256u;
-        const int sr = int(tr * kTS + (lc & 31u)), sc = int(tc * kTS + (lc >> 5));
+        const int sr = int(tr * kTS + (lc & 31u)), sc = int(tc * kTC + (lc >> 5));
         if (sr >= G.s_rows || sc >= G.s_cols) continue;
         if (n_chunks && u.do_update && s_key[lc] != kEmptyKey) continue;  // touched: done above
         const unsigned o = unsigned(sc) * unsigned(G.s_rows) + unsigned(sr);
