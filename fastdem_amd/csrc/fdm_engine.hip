@@ -144,6 +144,7 @@ struct fdm_engine {
   // double-buffered by scan parity.
   unsigned long long* key2[2] = {nullptr, nullptr};  // scratch of even / odd scans ([0] == the original allocation)
   uint4* aux2[2] = {nullptr, nullptr};
+  uint2* zs2[2] = {nullptr, nullptr};
   bool overlap = true;          // option "overlap"
   bool chain = false;           // an update is held back: the next bin derives its geometry from the previous slot
   struct BinVariant { bool bin4, has_int, has_col, wave_merge; unsigned threads; int lean; };  // lean: see bin4_body
@@ -718,7 +719,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
                  const float* dz, const float* dint, const uint32_t* drgb, const float* dvar,
                  const ScanInputs* gather = nullptr) {
   if (n >= 0xFFFFFFFEull) return fail(FDM_ERR_INVALID, "point count exceeds 2^32-2");
-  if (dint && n >= 0x7FFFFFFFull) return fail(FDM_ERR_INVALID, "point count exceeds 2^31-1 (intensity channel)");
+  if (n >= 0x7FFFFFFFull) return fail(FDM_ERR_INVALID, "point count exceeds 2^31-1");
   int rc;
   P.n = uint32_t(n);
   P.scan_no = uint32_t(e->scan_no);
@@ -812,6 +813,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   if (e->key2[1]) {  // the scratch set of this scan's parity
     e->S.key = e->key2[parity];
     e->S.aux = e->aux2[parity];
+    e->S.zs = e->zs2[parity];
   }
   const bool plain = e->overlap && e->key2[1] && !ray_on && !e->cap_pre &&
                      !e->cap_ras && !e->obst_dense_pending;
@@ -1292,6 +1294,11 @@ static int create_impl(const fdm_geometry* g, const fdm_config* cfg, const fdm_t
   HCK(hipMalloc(reinterpret_cast<void**>(&e->S.tile_stamp), e->n_tiles * sizeof(uint32_t)));
   e->key2[0] = e->S.key;
   e->aux2[0] = e->S.aux;
+  for (int k = 0; k < 2; ++k) {
+    HCK(hipMalloc(reinterpret_cast<void**>(&e->zs2[k]), e->ncell * sizeof(uint2)));
+    HCK(hipMemsetAsync(e->zs2[k], 0xFF, e->ncell * sizeof(uint2), e->stream));
+  }
+  e->S.zs = e->zs2[0];
   {  // second scratch set: scan t+1 bins while scan t still updates (24 B/cell: 100 MB at 4 M cells, 1.5 GB at 64 M)
     HCK(hipMalloc(reinterpret_cast<void**>(&e->key2[1]), e->ncell * sizeof(unsigned long long)));
     HCK(hipMalloc(reinterpret_cast<void**>(&e->aux2[1]), e->ncell * sizeof(uint4)));
@@ -1349,6 +1356,7 @@ void fdm_engine_destroy(fdm_engine* e) {
   if (e->aux2[0]) (void)hipFree(e->aux2[0]);
   if (e->key2[1]) (void)hipFree(e->key2[1]);
   if (e->aux2[1]) (void)hipFree(e->aux2[1]);
+  for (auto* z : e->zs2) if (z) (void)hipFree(z);
 
   for (auto& q : e->pool) {
     if (q.rec) (void)hipFree(q.rec);

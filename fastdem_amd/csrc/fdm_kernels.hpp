@@ -53,6 +53,11 @@ struct Scratch {
   //         sticks (elevation_mapping.cpp:73-79); kNoIdx = none
   //   last  highest point index in the cell (colour = last point wins)
   uint4* aux;
+  // zs[cell] = {(lowest index of a point with z == +-0) << 1 | that z is -0, the same for the intensity}; all-ones =
+  // none.  -0 and +0 tie in the reference's comparisons and the FIRST one seen stays (elevation_mapping.cpp:65-79), so
+  // when a cell's max z / max intensity is a zero its sign is the first zero-valued point's.  Touched only by
+  // zero-valued points (bin) and read with the aux group (update): free for real scans, exact for synthetic ones.
+  uint2* zs;
   // optional captures for the scan callbacks (null unless fdm_engine_capture enabled them)
   float* cap_x;                  // [n] map-frame coordinates of every input point
   float* cap_y;
@@ -158,6 +163,15 @@ __device__ __forceinline__ void scratch_merge(const Scratch& S, unsigned scan_no
   }
   if (HAS_COL) atomicMax(a + 3, lst);
   if (!S.dense) S.tile_stamp[cell >> kTileShift] = scan_no;  // benign race: all writers store the same value
+}
+
+// a zero-valued z / intensity of point i in `cell`: remember the first one and its sign (see Scratch::zs)
+template <bool HAS_INT>
+__device__ __forceinline__ void note_zeros(const Scratch& S, uint32_t cell, unsigned i, float z, float v) {
+  if (z == 0.0f)
+    atomicMin(reinterpret_cast<uint32_t*>(S.zs) + size_t(cell) * 2, (i << 1) | (__float_as_uint(z) >> 31));
+  if (HAS_INT && v == 0.0f)
+    atomicMin(reinterpret_cast<uint32_t*>(S.zs) + size_t(cell) * 2 + 1, (i << 1) | (__float_as_uint(v) >> 31));
 }
 
 __device__ __forceinline__ DevCand block_candidate(const ScanParams& P, const GeomConst& G,
@@ -325,6 +339,7 @@ __device__ __forceinline__ void bin4_body(const ScanParams& P, const GeomConst& 
   for (int j = 0; j < 4; ++j) {
     if (cells[j] < 0) continue;
     const unsigned i = i0 + j;
+    if (zs[j] == 0.0f || (HAS_INT && vs[j] == 0.0f)) note_zeros<HAS_INT>(S, uint32_t(cells[j]), i, zs[j], HAS_INT ? vs[j] : 1.0f);
     const unsigned long long key = make_key(zs[j], i);
     const uint32_t zmx = make_zmax(zs[j]);
     uint32_t imx = 0;
@@ -465,6 +480,10 @@ __device__ __forceinline__ void bin_body(const ScanParams& P, const GeomConst& G
   unsigned long long key = kEmptyKey;
   uint32_t zmx = 0, imx = 0, fst = kNoIdx, lst = 0;
   if (inside) {
+    if (z == 0.0f || (has_int && vint == 0.0f)) {
+      if (has_int) note_zeros<true>(S, uint32_t(cell), i, z, vint);
+      else note_zeros<false>(S, uint32_t(cell), i, z, 1.0f);
+    }
     key = make_key(z, i);
     zmx = make_zmax(z);
     if (has_int) {
@@ -829,6 +848,7 @@ __device__ __forceinline__ void update_body(
         if (P.has_var) gvar = pvar[idx];
       }
       const uint4 ax = S.aux[o];
+      const uint2 zsw = S.zs[o];
       const uint32_t zm = ax.x, imx = ax.y, fst = ax.z, lst = ax.w;
       float sint = nanv;
       typename POLICY::State stt;
@@ -851,17 +871,20 @@ __device__ __forceinline__ void update_body(
         preprocess_point(P, x, y, z);
         min_z = z;
       }
-      const float max_z = zm ? unord(zm) : -kFltMax;
+      // (a zero maximum takes the sign of the first zero-valued point, see Scratch::zs)
+      const float max_z = zm ? ((zm == 0x80000000u && (zsw.x & 1u)) ? -0.0f : unord(zm)) : -kFltMax;
       if (S.ras_z) S.ras_z[o] = min_z;
       POLICY::update(L, o, stt, min_z, min_z_var, max_z);
       L.obstacle[o] = (max_z > min_z) ? max_z : nanv;
       if (P.has_intensity) {
-        const float obs = (fst & 1u) ? nanv : unord(imx);  // first point NaN -> NaN (see Scratch)
+        const float obs = (fst & 1u) ? nanv  // first point NaN -> NaN (see Scratch)
+                                     : ((imx == 0x80000000u && (zsw.y & 1u)) ? -0.0f : unord(imx));
         if (isnan(sint) || obs > sint) L.intensity[o] = obs;
       }
       if (P.has_color) reinterpret_cast<uint32_t*>(L.color)[o] = rgb & 0x00FFFFFFu;
       S.key[o] = kEmptyKey;  // scratch is clean again for the next scan
       S.aux[o] = make_uint4(0u, 0u, kNoIdx, 0u);
+      if ((zsw.x & zsw.y) != 0xFFFFFFFFu) S.zs[o] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
     }
   }
   // per-tile touched-cell count (plain store; summed by the host on demand)

@@ -41,6 +41,21 @@ def assert_arrays_close(a, b, name="", rtol=RTOL, atol=ATOL):
     return float(err.max())
 
 
+def assert_layers_bit_identical(a_eng, b_ref, names=None):
+    """Every non-NaN value bit for bit (the SIGN OF A ZERO included), NaN pattern identical."""
+    na, nb = a_eng.layers(), b_ref.layers()
+    assert sorted(na) == sorted(nb), (na, nb)
+    for name in (names or nb):
+        a, b = a_eng.layer(name), b_ref.layer(name)
+        nan_a, nan_b = np.isnan(a), np.isnan(b)
+        if name == "color":
+            nan_a, nan_b = np.zeros_like(nan_a), np.zeros_like(nan_b)
+        assert np.array_equal(nan_a, nan_b), f"{name}: NaN pattern differs"
+        ia, ib = a.view(np.uint32)[~nan_a], b.view(np.uint32)[~nan_b]
+        bad = ia != ib
+        assert not bad.any(), f"{name}: {int(bad.sum())} values differ in their bits, e.g. {ia[bad][:3]} vs {ib[bad][:3]}"
+
+
 def same_geometry(ge, gr):
     return (ge.position_x, ge.position_y, ge.start_row, ge.start_col, ge.rows, ge.cols,
             ge.resolution, ge.length_x, ge.length_y) == \

@@ -8,7 +8,8 @@ Run on the GPU box:  python -m pytest tests -m gpu
 import numpy as np
 import pytest
 
-from helpers import assert_arrays_close, assert_layers_equal, pair, run_both, same_geometry
+from helpers import (assert_arrays_close, assert_layers_bit_identical, assert_layers_equal, pair, run_both,
+                     same_geometry)
 
 pytestmark = pytest.mark.gpu
 F32 = np.float32
@@ -673,3 +674,29 @@ def test_c5_stated_size_engine_vs_oracle_and_2x4_tiles(gpu, R):
             got = t.layer(name)[o.r0 - st_.r0:o.r1 - st_.r0, o.c0 - st_.c0:o.c1 - st_.c0]
             assert_arrays_close(got, want, f"tile {rank} {name}", 0.0, 0.0)
         t.close()
+
+
+@pytest.mark.parametrize("n", [6000, 90000])
+def test_first_seen_signed_zero_is_kept_bit_for_bit(gpu, R, n):
+    """-0.0 and +0.0 compare equal in the reference, so the FIRST zero a cell sees stays in min_z / max_z /
+    max_intensity (elevation_mapping.cpp:65-79) and from there in elevation_min / _max / obstacle / intensity.
+    Clouds of zeros and negatives in a few hundred cells, in both orders, through both pipelines: every layer
+    bit-identical, the sign of every zero included."""
+    def fill(c):
+        c.mode = 1
+        c.kalman_max_variance = 1.0
+
+    eng, ref = pair(gpu, R, 40.0, 40.0, 0.1, fill)
+    if n >= 65536:
+        eng.set_option("tiled_min", 65536)  # (400x400 cells = 157 tiles: the engine would not pick the pipeline itself)
+    rng = np.random.default_rng(3)
+    for k in range(4):
+        x = rng.uniform(-1.5, 1.5, n).astype(F32)
+        y = rng.uniform(-1.5, 1.5, n).astype(F32)
+        z = rng.choice(np.array([-0.0, 0.0, -0.5, -1.0, 0.0, -0.0], F32), n).astype(F32)
+        v = rng.choice(np.array([-0.0, 0.0, -2.0, 0.0, -0.0, np.nan], F32), n).astype(F32)
+        if k == 3:  # positive maxima overwrite zeros; zeros no longer decide
+            z[::7] = 0.75
+            v[::5] = 3.0
+        run_both(eng, ref, {"x": x, "y": y, "z": z, "intensity": v}, T(), T(0.05 * k, 0.0))
+        assert_layers_bit_identical(eng, ref)
