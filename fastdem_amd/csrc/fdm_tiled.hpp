@@ -615,6 +615,24 @@ __device__ __forceinline__ void make_tile_ctx(const ScanParams& P, DevState* __r
   u.strips = u.applied && (u.C.shr != 0 || u.C.shc != 0);
 }
 
+// Does the run of buffer indices [b0, b0 + len) on one axis meet the strip GridMap::move vacates there?
+// (in_cleared_strip for a whole tile edge: the strip is [index, index + n) modulo size)
+__device__ __forceinline__ bool span_hits_strip(int b0, int len, int start, int sh, int size) {
+  if (sh == 0) return false;
+  const int n = sh > 0 ? sh : -sh;
+  if (n >= size) return true;
+  int index = sh > 0 ? start : start + sh;
+  wrap_index(index, size);
+  int d = b0 - index;  // distance of the span's first index behind the strip's first index, modulo size
+  if (d < 0) d += size;
+  return d < n || d + len > size;  // starts inside the strip, or wraps around into its start
+}
+__device__ __forceinline__ bool tile_hits_strips(const TileCtx& u, const GeomConst& G, const TileGrid& TG, unsigned tile) {
+  const int tr = int(tile % unsigned(TG.tiles_r)), tc = int(tile / unsigned(TG.tiles_r));
+  return span_hits_strip(tr * kTS + G.s_r0, kTS, u.E.sr, u.C.shr, G.rows) ||
+         span_hits_strip(tc * kTC + G.s_c0, kTC, u.E.sc, u.C.shc, G.cols);
+}
+
 // One tile by one 256-thread group (`lt` = thread inside the group).  Block-uniform control flow
 // around the barriers: `n_chunks_max` is the largest chunk count among the block's groups.
 // `d0` = word `lt` of the tile's descriptor row, already loaded by the caller (word 0 is the count).
@@ -757,7 +775,9 @@ __device__ __forceinline__ void tupdate_tile(
   // all their record / sigma loads are ONE round trip instead of four dependent ones. ----
   const unsigned tr = tile % unsigned(TG.tiles_r), tc = tile / unsigned(TG.tiles_r);
   uint16_t* const s_tlist = reinterpret_cast<uint16_t*>(s_desc);  // [kTileCells] (the descriptors are consumed)
-  const bool work = tile_ok && (n_chunks || obst_tile || u.strips);
+  // (a move vacates a few rows / columns: only the tiles they cross look at their cells for it)
+  const bool strips = u.strips && tile_hits_strips(u, G, TG, tile);
+  const bool work = tile_ok && (n_chunks || obst_tile || strips);
   unsigned n_touched = 0;  // of the whole tile (group-uniform)
   if (n_chunks_max) {      // block-uniform: barriers inside
     unsigned long long tm[kCellsPerThread];
@@ -803,7 +823,7 @@ __device__ __forceinline__ void tupdate_tile(
         const unsigned lc = s_tlist[j];
         const int sr = int(tr * kTS + (lc & 31u)), sc = int(tc * kTC + (lc >> 5));
         o_[b] = unsigned(sc) * unsigned(G.s_rows) + unsigned(sr);
-        strip_[b] = u.strips && (in_cleared_strip(sr + G.s_r0, u.E.sr, u.C.shr, G.rows) ||
+        strip_[b] = strips && (in_cleared_strip(sr + G.s_r0, u.E.sr, u.C.shr, G.rows) ||
                                  in_cleared_strip(sc + G.s_c0, u.E.sc, u.C.shc, G.cols));
         key_[b] = s_key[lc];
         zm_[b] = s_zmax[lc];
@@ -855,7 +875,7 @@ __device__ __forceinline__ void tupdate_tile(
       }
     }
     // untouched cells: stores only
-    if (obst_tile || u.strips) {
+    if (obst_tile || strips) {
 #pragma unroll
       for (int q = 0; q < kCellsPerThread; ++q) {
         const unsigned lc = lt + unsigned(q) * 256u;
@@ -864,7 +884,7 @@ __device__ __forceinline__ void tupdate_tile(
         if (n_chunks && u.do_update && s_key[lc] != kEmptyKey) continue;  // touched: done above
         const unsigned o = unsigned(sc) * unsigned(G.s_rows) + unsigned(sr);
         bool in_strip = false;
-        if (u.strips) {
+        if (strips) {
           in_strip = in_cleared_strip(sr + G.s_r0, u.E.sr, u.C.shr, G.rows) ||
                      in_cleared_strip(sc + G.s_c0, u.E.sc, u.C.shc, G.cols);
           if (in_strip) {
@@ -928,7 +948,7 @@ __device__ __forceinline__ void tupdate_body(
         nch = span == 1u ? unsigned(d0) : unsigned(Q.desc[size_t(tile) * Q.stride]);
         const unsigned stamp = A.stamp[tile];
         ob = u.do_update && (nch != 0u || stamp == u.ob_scan);
-        live = nch != 0u || u.strips || ob;
+        live = nch != 0u || ob || (u.strips && tile_hits_strips(u, G, TG, tile));
         if (!live) A.upd_part[tile] = 0u;
       }
       s_nch[lt] = nch;
