@@ -130,6 +130,7 @@ struct fdm_engine {
   // raycasting stage (fdm_raycast.hpp)
   uint32_t* rc_cnt = nullptr;        // [ncell] ray-scan points observed in the cell this frame
   uint32_t* rc_min = nullptr;        // [ncell] ord(min ray height), kRayEmpty = not traversed
+  uint32_t* ray_bins = nullptr;      // large scans: ray-queue bucket counts | offsets | block sums (fdm_raycast.hpp)
   unsigned long long* vkeys[2] = {nullptr, nullptr};  // voxel keys: unsorted / sorted
   uint32_t* vidx[2] = {nullptr, nullptr};             // point indices: unsorted / sorted
   uint32_t* vsel = nullptr;          // voxel_any output staging
@@ -1388,6 +1389,7 @@ void fdm_engine_destroy(fdm_engine* e) {
   if (e->d_pack) (void)hipFree(e->d_pack);
   if (e->rc_cnt) (void)hipFree(e->rc_cnt);
   if (e->rc_min) (void)hipFree(e->rc_min);
+  if (e->ray_bins) (void)hipFree(e->ray_bins);
   for (int k = 0; k < 2; ++k) {
     if (e->vkeys[k]) (void)hipFree(e->vkeys[k]);
     if (e->vidx[k]) (void)hipFree(e->vidx[k]);

@@ -22,6 +22,10 @@ int ensure_ray_cells(fdm_engine* e) {
   const int blocks = int(std::min<size_t>((e->ncell + 255) / 256, 4096));
   hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, e->stream, e->rc_cnt, 0u, e->ncell);
   hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, e->stream, e->rc_min, kRayEmpty, e->ncell);
+  // bucket counts (kept at zero between scans by k_ray_bin_scan) | bucket offsets | per-block sums
+  const size_t bin_words = 2u * size_t(kRayBins) + kRayBins / kRayBinBlock;
+  HIPCK(hipMalloc(reinterpret_cast<void**>(&e->ray_bins), bin_words * sizeof(uint32_t)));
+  HIPCK(hipMemsetAsync(e->ray_bins, 0, bin_words * sizeof(uint32_t), e->stream));
   HIPCK(hipGetLastError());
   return FDM_OK;
 }
@@ -184,24 +188,37 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float
       hipLaunchKernelGGL(k_voxel_mark<unsigned long long>, dim3(blocks), dim3(256), 0, e->stream, Q.n,
                          e->vkeys[1], e->vidx[1], e->vsel);
   }
-  // large scans: queue sorted by (wedge, length) before the walk (see k_ray_compact)
+  // large scans: queue bucketed by (wedge, length class) before the walk (see k_ray_compact)
   const bool sort_queue = Q.n >= (1u << 20) && !(e->dbg_ray & 2048);
-  uint32_t* ray_key = sort_queue ? reinterpret_cast<uint32_t*>(e->vkeys[0]) : nullptr;
-  if (sort_queue) HIPCK(hipMemsetAsync(ray_key, 0xFF, size_t(Q.n) * sizeof(uint32_t), e->stream));  // unused slots sort last
-  if (voxel) {
-    hipLaunchKernelGGL(k_ray_compact<true>, dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx,
-                       dy, dz, e->vsel, e->rc_cnt, ray_list, ray_key);
+  uint32_t* ray_key = sort_queue ? reinterpret_cast<uint32_t*>(e->vkeys[0]) : nullptr;       // vkeys hold 2 x vcap uint32
+  uint32_t* ray_rank = sort_queue ? reinterpret_cast<uint32_t*>(e->vkeys[0]) + e->vcap : nullptr;
+  uint32_t* bin_cnt = sort_queue ? e->ray_bins : nullptr;
+  if (sort_queue) {
+    constexpr unsigned kPts = 8;
+    const unsigned cblocks = (Q.n + 256u * kPts - 1u) / (256u * kPts);
+    if (voxel)
+      hipLaunchKernelGGL((k_ray_compact<true, kPts>), dim3(cblocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx,
+                         dy, dz, e->vsel, e->rc_cnt, ray_list, ray_key, ray_rank, bin_cnt);
+    else
+      hipLaunchKernelGGL((k_ray_compact<false, kPts>), dim3(cblocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx,
+                         dy, dz, static_cast<const uint32_t*>(nullptr), e->rc_cnt, ray_list, ray_key, ray_rank, bin_cnt);
+    uint32_t* bin_start = e->ray_bins + kRayBins;
+    uint32_t* bin_part = e->ray_bins + 2u * kRayBins;
+    hipLaunchKernelGGL(k_ray_bin_sum, dim3(kRayBins / kRayBinBlock), dim3(256), 0, e->stream, Q, e->G, e->d_state,
+                       bin_cnt, bin_part);
+    hipLaunchKernelGGL(k_ray_bin_scan, dim3(kRayBins / kRayBinBlock), dim3(256), 0, e->stream, Q, e->G, e->d_state,
+                       bin_cnt, bin_part, bin_start);
+    hipLaunchKernelGGL(k_ray_scatter, dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, ray_list, ray_key,
+                       ray_rank, bin_start, e->vidx[1]);
+    ray_list = e->vidx[1];
+  } else if (voxel) {
+    hipLaunchKernelGGL((k_ray_compact<true, 1>), dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx,
+                       dy, dz, e->vsel, e->rc_cnt, ray_list, ray_key, ray_rank, bin_cnt);
   } else {
-    hipLaunchKernelGGL(k_ray_compact<false>, dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx,
-                       dy, dz, static_cast<const uint32_t*>(nullptr), e->rc_cnt, ray_list, ray_key);
+    hipLaunchKernelGGL((k_ray_compact<false, 1>), dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx,
+                       dy, dz, static_cast<const uint32_t*>(nullptr), e->rc_cnt, ray_list, ray_key, ray_rank, bin_cnt);
   }
   HIPCK(hipGetLastError());
-  if (sort_queue) {
-    size_t bytes = e->sort_tmp_bytes;
-    HIPCK(rocprim::radix_sort_pairs(e->sort_tmp, bytes, ray_key, reinterpret_cast<uint32_t*>(e->vkeys[1]), e->vidx[0],
-                                    e->vidx[1], size_t(Q.n), 0, 21, e->stream));
-    ray_list = e->vidx[1];
-  }
   const bool tiled = e->G.o_rows != e->G.rows || e->G.o_cols != e->G.cols || e->G.s_rows != e->G.rows ||
                      e->G.s_cols != e->G.cols;
   auto launch_ray = [&](auto kern, unsigned seg) {

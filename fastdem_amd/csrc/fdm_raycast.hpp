@@ -17,7 +17,7 @@
 //   * ghost resolution: one independent decision per traversed cell, after both of the above.
 // Pipeline (one stream, no host round trip):
 //   k_voxel_keys -> stable radix sort of (key, point index) -> k_voxel_mark -> k_ray_compact
-//   -> k_ray -> k_ray_resolve
+//   (-> k_ray_bin_sum -> k_ray_bin_scan -> k_ray_scatter for large scans) -> k_ray -> k_ray_resolve
 // VoxelMode::ANY picks idx[start + (count*7 + start*13) % count] of each voxel's run in the sorted
 // array.  The reference sorts with std::sort on the key only (unstable: the order inside a voxel is
 // whatever that libstdc++'s introsort leaves); the engine sorts stably, i.e. ties in original point
@@ -200,7 +200,21 @@ __global__ __launch_bounds__(256) void k_voxel_mark(unsigned n, const KEY* __res
 // Observed evidence is counted here; the downward rays are queued DENSELY for k_ray (order inside a
 // block = scan order, blocks land in whatever order their atomicAdd does — the result is order-free),
 // so k_ray's wavefronts are full and neighbouring lanes hold neighbouring rays of the scan.
-template <bool VOXEL>
+// PTS points per thread: the queue tail is ONE same-address returning atomic per block, and those
+// serialise in L2 (8192 blocks of 256 points took 100 us at C4 for this reason alone).
+//
+// Large scans (bin_cnt != nullptr) bucket the queue by (direction wedge of 0.18 deg, length class) before
+// the walk.  k_ray's loop runs until the longest ray of a wavefront ends; 64 beams of one firing step reach
+// from 1.5 m to the far wall (lanes ~40 % busy), 64 rays of one wedge and similar length end together and
+// still stand in the same few cells at every step.  The direction is a diamond angle (monotone in the
+// azimuth, no atan2), the length the Manhattan cell count in classes of 16 cells.  The order INSIDE a bucket
+// is irrelevant (every step of the stage is order-free), so this is a counting sort without a sort: the
+// returning atomic that counts the bucket is the ray's rank in it; k_ray_bin_sum / k_ray_bin_scan turn
+// the counts into offsets and k_ray_scatter places the rays.
+constexpr unsigned kRayWedges = 2048u, kRayLenClasses = 128u, kRayBins = kRayWedges * kRayLenClasses;
+constexpr unsigned kRayBinBlock = 1024u;  // bins per block of the two scan kernels
+
+template <bool VOXEL, int PTS>
 __global__ __launch_bounds__(256) void k_ray_compact(const RayParams Q, const GeomConst G,
                                                      DevState* __restrict__ st,
                                                      const float* __restrict__ x,
@@ -209,53 +223,140 @@ __global__ __launch_bounds__(256) void k_ray_compact(const RayParams Q, const Ge
                                                      const uint32_t* __restrict__ sel,
                                                      uint32_t* __restrict__ rc_cnt,
                                                      uint32_t* __restrict__ ray_list,
-                                                     uint32_t* __restrict__ ray_key) {
-  __shared__ unsigned s_wave[4];
+                                                     uint32_t* __restrict__ ray_key,
+                                                     uint32_t* __restrict__ ray_rank,
+                                                     uint32_t* __restrict__ bin_cnt) {
+  __shared__ unsigned s_wave[PTS][4];
   __shared__ unsigned s_base;
   const DevGeom g = st->geom[Q.slot];
   if (!ray_stage_runs(Q, st, g, G)) return;
-  const unsigned i = blockIdx.x * 256u + threadIdx.x;
-  if (i == 0 && st->vis_ray == 0u) st->vis_ray = Q.vis_stamp;  // the three layers become visible (raycasting.cpp:223-226)
-  bool ray = false;
-  if (i < Q.n && (!VOXEL || sel[i] != 0u)) {
-    const float ex = x[i], ey = y[i], ez = z[i];
-    if (VOXEL || (isfinite(ex) && isfinite(ey) && isfinite(ez))) {
-      DevCand c;  // observed evidence: the point's own cell (nanoGrid getIndex, fp64)
-      c.px = g.px; c.py = g.py; c.sr = g.sr; c.sc = g.sc; c.shr = 0; c.shc = 0;
-      const int o = owned_cell(ex, ey, c, G);
-      if (o >= 0) atomicAdd(&rc_cnt[o], 1u);
-      ray = ez < Q.oz;  // upward rays are skipped (raycasting.cpp:168)
-    }
-  }
-  const unsigned long long m = __ballot(ray);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && st->vis_ray == 0u)
+    st->vis_ray = Q.vis_stamp;  // the three layers become visible (raycasting.cpp:223-226)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 0) s_wave[w] = unsigned(__popcll(m));
+  unsigned idx[PTS], key[PTS], rank[PTS];
+  unsigned long long mask[PTS];
+#pragma unroll
+  for (int k = 0; k < PTS; ++k) {
+    const unsigned i = (blockIdx.x * unsigned(PTS) + unsigned(k)) * 256u + threadIdx.x;
+    idx[k] = i;
+    key[k] = 0u;
+    rank[k] = 0u;
+    bool ray = false;
+    if (i < Q.n && (!VOXEL || sel[i] != 0u)) {
+      const float ex = x[i], ey = y[i], ez = z[i];
+      if (VOXEL || (isfinite(ex) && isfinite(ey) && isfinite(ez))) {
+        DevCand c;  // observed evidence: the point's own cell (nanoGrid getIndex, fp64)
+        c.px = g.px; c.py = g.py; c.sr = g.sr; c.sc = g.sc; c.shr = 0; c.shc = 0;
+        const int o = owned_cell(ex, ey, c, G);
+        if (o >= 0) atomicAdd(&rc_cnt[o], 1u);
+        ray = ez < Q.oz;  // upward rays are skipped (raycasting.cpp:168)
+        if (ray && bin_cnt) {
+          const float dx = ex - Q.ox, dy = ey - Q.oy;
+          const float ax = fabsf(dx), ay = fabsf(dy), sum = ax + ay;
+          const float p = sum > 0.0f ? dy / sum : 0.0f;                        // [-1, 1]
+          const float a = dx >= 0.0f ? (dy >= 0.0f ? p : 4.0f + p) : 2.0f - p;  // [0, 4)
+          // (2048 wedges; 1024: +1 %, 512: +20 %; length classes of 2..16 cells measured the same)
+          const unsigned wedge = min(kRayWedges - 1u, unsigned(a * float(kRayWedges / 4u)));
+          const unsigned len = min(kRayLenClasses - 1u, unsigned(sum / Q.resolution) >> 4);
+          key[k] = wedge * kRayLenClasses + len;
+          rank[k] = atomicAdd(&bin_cnt[key[k]], 1u);
+        }
+      }
+    }
+    mask[k] = __ballot(ray);
+    if (lane == 0) s_wave[k][w] = unsigned(__popcll(mask[k]));
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    unsigned tot = 0u;
+#pragma unroll
+    for (int k = 0; k < PTS; ++k) tot += s_wave[k][0] + s_wave[k][1] + s_wave[k][2] + s_wave[k][3];
     s_base = tot ? atomicAdd(&st->ray_count, tot) : 0u;
   }
   __syncthreads();
-  if (ray) {
-    unsigned off = s_base + unsigned(__popcll(m & ((1ull << lane) - 1ull)));
-    for (int k = 0; k < w; ++k) off += s_wave[k];
-    ray_list[off] = i;
-    if (ray_key) {
-      // Large scans: the queue is sorted by (direction wedge of 0.18 deg, length) before the walk.  k_ray's
-      // loop runs until the longest ray of a wavefront ends; 64 beams of one firing step reach from 1.5 m
-      // to the far wall (lanes ~40 % busy), 64 rays of one wedge and similar length end together and still
-      // stand in the same few cells at every step.  The direction is a diamond angle (monotone in the
-      // azimuth, no atan2), the length the Manhattan cell count in units of 8 cells.
-      const float dx = x[i] - Q.ox, dy = y[i] - Q.oy;
-      const float ax = fabsf(dx), ay = fabsf(dy), sum = ax + ay;
-      const float p = sum > 0.0f ? dy / sum : 0.0f;                     // [-1, 1]
-      const float a = dx >= 0.0f ? (dy >= 0.0f ? p : 4.0f + p) : 2.0f - p;  // [0, 4)
-      // (2048 wedges x 8-cell length classes; 1024 wedges: +1 %, 512: +20 %, length classes of 2..16 cells: same)
-      const unsigned wedge = min(2047u, unsigned(a * 512.0f));
-      const unsigned len = min(511u, unsigned(sum / Q.resolution) >> 3);
-      ray_key[off] = (wedge << 9) | len;
+  unsigned off = s_base;
+#pragma unroll
+  for (int k = 0; k < PTS; ++k) {
+    unsigned mine = off + unsigned(__popcll(mask[k] & ((1ull << lane) - 1ull)));
+    for (int v = 0; v < w; ++v) mine += s_wave[k][v];
+    if ((mask[k] >> lane) & 1ull) {
+      ray_list[mine] = idx[k];
+      if (bin_cnt) {
+        ray_key[mine] = key[k];
+        ray_rank[mine] = rank[k];
+      }
     }
+    off += s_wave[k][0] + s_wave[k][1] + s_wave[k][2] + s_wave[k][3];
   }
+}
+
+// bucket counts -> offsets, in two launches of kRayBins / kRayBinBlock blocks: per-block sums, then every block
+// adds up the sums in front of it and scans its own kRayBinBlock counts (4 per thread).  The counts are left
+// at zero for the next scan.
+__global__ __launch_bounds__(256) void k_ray_bin_sum(const RayParams Q, const GeomConst G,
+                                                     DevState* __restrict__ st,
+                                                     const uint32_t* __restrict__ bin_cnt,
+                                                     uint32_t* __restrict__ bin_part) {
+  __shared__ unsigned s_w[4];
+  const DevGeom g = st->geom[Q.slot];
+  if (!ray_stage_runs(Q, st, g, G)) return;
+  const uint4 c = reinterpret_cast<const uint4*>(bin_cnt)[blockIdx.x * 256u + threadIdx.x];
+  unsigned v = c.x + c.y + c.z + c.w;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) bin_part[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(256) void k_ray_bin_scan(const RayParams Q, const GeomConst G,
+                                                      DevState* __restrict__ st,
+                                                      uint32_t* __restrict__ bin_cnt,
+                                                      const uint32_t* __restrict__ bin_part,
+                                                      uint32_t* __restrict__ bin_start) {
+  __shared__ unsigned s_w[4], s_p[4];
+  const DevGeom g = st->geom[Q.slot];
+  if (!ray_stage_runs(Q, st, g, G)) return;
+  static_assert(kRayBins / kRayBinBlock == 256u, "one partial sum per thread");
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned pre = threadIdx.x < blockIdx.x ? bin_part[threadIdx.x] : 0u;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d);
+  uint4* cnt4 = reinterpret_cast<uint4*>(bin_cnt) + blockIdx.x * 256u + threadIdx.x;
+  const uint4 c = *cnt4;
+  *cnt4 = make_uint4(0u, 0u, 0u, 0u);
+  const unsigned mine = c.x + c.y + c.z + c.w;
+  unsigned inc = mine;  // inclusive scan over the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned o = __shfl_up(inc, d);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) s_w[w] = inc;
+  if (lane == 0) s_p[w] = pre;
+  __syncthreads();
+  unsigned base = s_p[0] + s_p[1] + s_p[2] + s_p[3] + inc - mine;
+  for (int v = 0; v < w; ++v) base += s_w[v];
+  uint4 o;
+  o.x = base;
+  o.y = o.x + c.x;
+  o.z = o.y + c.y;
+  o.w = o.z + c.z;
+  reinterpret_cast<uint4*>(bin_start)[blockIdx.x * 256u + threadIdx.x] = o;
+}
+
+__global__ __launch_bounds__(256) void k_ray_scatter(const RayParams Q, const GeomConst G,
+                                                     DevState* __restrict__ st,
+                                                     const uint32_t* __restrict__ ray_list,
+                                                     const uint32_t* __restrict__ ray_key,
+                                                     const uint32_t* __restrict__ ray_rank,
+                                                     const uint32_t* __restrict__ bin_start,
+                                                     uint32_t* __restrict__ ray_sorted) {
+  const DevGeom g = st->geom[Q.slot];
+  if (!ray_stage_runs(Q, st, g, G)) return;
+  const unsigned q = blockIdx.x * 256u + threadIdx.x;
+  if (q >= st->ray_count) return;
+  ray_sorted[bin_start[ray_key[q]] + ray_rank[q]] = ray_list[q];
 }
 
 // Minimum over the 64 lanes with DPP row operations (VALU rate; a __shfl butterfly is six trips through
@@ -403,10 +504,19 @@ __global__ __launch_bounds__(256) void k_ray(const RayParams Q, const GeomConst 
     // (the loads are unconditional — a masked step reads cell 0 — so that nothing but the loads
     // sits between them and they leave back to back)
     uint32_t seen[kB];
+    if (Q.dbg == 3) {  // measurement only: no loads, every visit settled
 #pragma unroll
-    for (int j = 0; j < kB; ++j)
-      seen[j] = __hip_atomic_load(&rc_min[cell[j] >= 0 ? cell[j] : 0], __ATOMIC_RELAXED,
-                                  __HIP_MEMORY_SCOPE_AGENT);
+      for (int j = 0; j < kB; ++j) seen[j] = uint32_t(cell[j] & 1);
+    } else {
+#pragma unroll
+      for (int j = 0; j < kB; ++j)
+        seen[j] = __hip_atomic_load(&rc_min[cell[j] >= 0 ? cell[j] : 0], __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT);
+      if (Q.dbg == 2) {  // measurement only: every visit settled by the read
+#pragma unroll
+        for (int j = 0; j < kB; ++j) seen[j] &= 1u;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < kB; ++j) {
       const bool need = cell[j] >= 0 && hh[j] < seen[j];
