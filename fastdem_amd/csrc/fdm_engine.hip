@@ -178,6 +178,8 @@ struct fdm_engine {
   int last_do_move = 0, last_gate = 0;
   // stencil post-processing (fdm_post.hpp)
   RegionEntry* d_region = nullptr;   // kMaxRegion entries
+  FeatEntry* d_feat_tab = nullptr;   // kMaxRegion entries: the region as k_features_tiled reads it
+  int dbg_post = 0;                  // measurement only: 1 = untiled feature kernel
   float* d_tmp2 = nullptr;           // second ncell staging array (fusion works on two layers)
   // ingest (fdm_ingest.hpp)
   uint8_t* d_blob = nullptr;         // raw message bytes
@@ -1382,6 +1384,7 @@ void fdm_engine_destroy(fdm_engine* e) {
   for (auto& ev : e->ev_ray)
     if (ev) (void)hipEventDestroy(ev);
   if (e->d_region) (void)hipFree(e->d_region);
+  if (e->d_feat_tab) (void)hipFree(e->d_feat_tab);
   if (e->d_tmp2) (void)hipFree(e->d_tmp2);
   if (e->d_blob) (void)hipFree(e->d_blob);
   if (e->d_in) (void)hipFree(e->d_in);
@@ -1986,6 +1989,10 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
   if (std::strcmp(key, "zero_copy") == 0) {
     if (value < 0) return fail(FDM_ERR_INVALID, "zero_copy: a point count (0 = off)");
     e->zero_copy = value;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "dbg_post") == 0) {
+    e->dbg_post = value;
     return FDM_OK;
   }
   if (std::strcmp(key, "dbg_ray") == 0) {

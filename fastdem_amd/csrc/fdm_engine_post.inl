@@ -171,10 +171,31 @@ int fdm_engine_apply_feature_extraction(fdm_engine* e, float radius, int min_val
     if (!find_layer(e, n) && (rc = add_layer(e, n, NAN, false))) return rc;
   std::vector<RegionEntry> reg;
   region_disc(e, radius, reg);
-  if ((rc = upload_region(e, reg))) return rc;
-  Layer* elev = find_layer(e, "elevation");
   FeatureParams F{};
   F.resf = static_cast<float>(e->G.res);
+  // the region as k_features_tiled reads it (fdm_post.hpp); uploaded ahead of upload_region's synchronisation
+  int halo = 0;
+  for (const RegionEntry& r : reg) halo = std::max(halo, std::max(std::abs(r.dr), std::abs(r.dc)));
+  std::vector<FeatEntry> tab;
+  if (halo <= kFeatHaloMax && reg.size() <= size_t(kMaxRegion)) {
+    const int pitch = kFeatTileR + 2 * halo;
+    tab.resize(reg.size());
+    for (size_t k = 0; k < reg.size(); ++k) {
+      FeatEntry& t = tab[k];
+      t.off = reg[k].dc * pitch + reg[k].dr;
+      t.d0 = static_cast<float>(-reg[k].dr) * F.resf;  // feature_extraction.cpp:74-76
+      t.d1 = static_cast<float>(-reg[k].dc) * F.resf;
+      t.p00 = t.d0 * t.d0;
+      t.p01 = t.d0 * t.d1;
+      t.p11 = t.d1 * t.d1;
+      t.pad0 = t.pad1 = 0;
+    }
+    if (!e->d_feat_tab) HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_feat_tab), kMaxRegion * sizeof(FeatEntry)));
+    if (!tab.empty())
+      HIPCK(hipMemcpyAsync(e->d_feat_tab, tab.data(), tab.size() * sizeof(FeatEntry), hipMemcpyHostToDevice, e->stream));
+  }
+  if ((rc = upload_region(e, reg))) return rc;
+  Layer* elev = find_layer(e, "elevation");
   F.lo_pct = lo_pct;
   F.hi_pct = hi_pct;
   F.min_valid = min_valid;
@@ -202,7 +223,18 @@ int fdm_engine_apply_feature_extraction(fdm_engine* e, float radius, int min_val
     hipLaunchKernelGGL(kern, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state, int(e->scan_no & 3),
                        e->d_region, F, elev_p, elev_s, O, unsigned(e->ncell));
   };
-  if (pct_ok && need_lo <= 8 && need_hi <= 8) launch_feat(k_features<8>);  // defaults: 6 from the bottom, 7 from the top
+  // dense layer + a region of bounded reach: LDS-tiled kernel fed from a pre-digested region table (fdm_post.hpp)
+  const bool tiled_ok = pct_ok && need_lo <= 16 && need_hi <= 16 && !tab.empty() && !(e->dbg_post & 1);
+  if (tiled_ok) {
+    const int rows = e->G.s_rows, cols = e->G.s_cols;
+    const unsigned blocks = unsigned((rows + kFeatTileR - 1) / kFeatTileR) * unsigned((cols + kFeatTileC - 1) / kFeatTileC);
+    auto launch_tiled = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, e->stream, e->G, e->d_state, int(e->scan_no & 3),
+                         e->d_feat_tab, F, halo, elev_p, O);
+    };
+    if (need_lo <= 8 && need_hi <= 8) launch_tiled(k_features_tiled<8>);  // defaults: 6 from the bottom, 7 from the top
+    else launch_tiled(k_features_tiled<16>);
+  } else if (pct_ok && need_lo <= 8 && need_hi <= 8) launch_feat(k_features<8>);
   else if (pct_ok && need_lo <= 16 && need_hi <= 16) launch_feat(k_features<16>);
   else launch_feat(k_features<0>);
   HIPCK(hipGetLastError());

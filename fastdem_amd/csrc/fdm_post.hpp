@@ -433,6 +433,30 @@ struct FeatureParams {
 struct FeatureOut {
   float *step, *slope, *roughness, *curvature, *nx, *ny, *nz;
 };
+// covariance -> PCA -> the seven layers (feature_extraction.cpp:85-116).  sum / sq are the accumulated
+// displacement sums in the reference's order; z_lo / z_hi come from the caller's order statistics.
+__device__ __forceinline__ bool features_cov(const float* sum, const float* sq, int count, float* cov, float* trace) {
+  const float inv_n = 1.0f / float(count);
+  const float mean[3] = {sum[0] * inv_n, sum[1] * inv_n, sum[2] * inv_n};
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) cov[c * 3 + r] = sq[c * 3 + r] * inv_n - mean[r] * mean[c];
+  *trace = cov[0] + cov[4] + cov[8];
+  return !(*trace < 1.1920929e-07f);  // computePCA: degenerate covariance
+}
+__device__ __forceinline__ void features_store(const FeatureOut& O, size_t ci, const float* val, float* normal,
+                                               float trace, float z_lo, float z_hi) {
+  if (normal[2] < 0.0f) { normal[0] = -normal[0]; normal[1] = -normal[1]; normal[2] = -normal[2]; }
+  O.step[ci] = z_hi - z_lo;
+  O.slope[ci] = static_cast<float>(acos(static_cast<double>(fabsf(normal[2])))) * 180.0f / 3.14159274101257324f;
+  O.roughness[ci] = sqrtf(val[0]);
+  O.curvature[ci] = (trace > 0.0f) ? fabsf(val[0] / trace) : 0.0f;
+  O.nx[ci] = normal[0];
+  O.ny[ci] = normal[1];
+  O.nz[ci] = normal[2];
+}
+
 // `step` needs two order statistics of the neighbourhood's heights (feature_extraction.cpp:100-103).
 // TOPK > 0: they are among the TOPK smallest / TOPK largest values, which are kept in registers by
 // unrolled compare-exchange chains (the host checks the percentiles make that true for the region);
@@ -488,19 +512,11 @@ __global__ __launch_bounds__(256) void k_features(const GeomConst G, const DevSt
     }
   }
   if (count < F.min_valid) return;
-  const float inv_n = 1.0f / float(count);
-  const float mean[3] = {sum[0] * inv_n, sum[1] * inv_n, sum[2] * inv_n};
-  float cov[9];
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-#pragma unroll
-    for (int r = 0; r < 3; ++r) cov[c * 3 + r] = sq[c * 3 + r] * inv_n - mean[r] * mean[c];
-  const float trace = cov[0] + cov[4] + cov[8];
-  if (trace < 1.1920929e-07f) return;  // computePCA: degenerate covariance
+  float cov[9], trace;
+  if (!features_cov(sum, sq, count, cov, &trace)) return;
   float val[3], normal[3];
   eig3_direct(cov, val, normal);
   if (val[1] < 1e-8f) return;  // kMinEigenvalue
-  if (normal[2] < 0.0f) { normal[0] = -normal[0]; normal[1] = -normal[1]; normal[2] = -normal[2]; }
   const int lo = static_cast<int>(F.lo_pct * float(count - 1));
   const int hi = static_cast<int>(F.hi_pct * float(count - 1));
   float z_lo, z_hi;
@@ -517,13 +533,120 @@ __global__ __launch_bounds__(256) void k_features(const GeomConst G, const DevSt
     z_lo = zs[lo];
     z_hi = zs[hi];
   }
-  O.step[ci] = z_hi - z_lo;
-  O.slope[ci] = static_cast<float>(acos(static_cast<double>(fabsf(normal[2])))) * 180.0f / 3.14159274101257324f;
-  O.roughness[ci] = sqrtf(val[0]);
-  O.curvature[ci] = (trace > 0.0f) ? fabsf(val[0] / trace) : 0.0f;
-  O.nx[ci] = normal[0];
-  O.ny[ci] = normal[1];
-  O.nz[ci] = normal[2];
+  features_store(O, ci, val, normal, trace, z_lo, z_hi);
+}
+
+// The same stage for dense layers (stride 1) and a region that reaches at most kFeatHaloMax cells: one block per
+// 32 x 8 cells (rows are the contiguous axis of the storage), the tile and its ring staged in LDS once — cells
+// outside the stored window as NaN, so "outside" and "no data" are one test.  The region table is pre-digested by the
+// host (`FeatEntry`: LDS offset of the neighbour, the two horizontal displacements and their three products — the
+// same float expressions the reference evaluates per neighbour, evaluated once): an entry is one scalar load, a
+// neighbour one LDS read.  The order statistics are kept by v_min / v_max chains (TOPK smallest, TOPK largest;
+// among zeros -0 orders before +0, where std::sort leaves the order of the two unspecified).  Per neighbour
+// ~14 + 4*TOPK vector instructions instead of ~130 (index arithmetic, a dependent L1/L2 gather and compare-select
+// chains) — the kernel is bound by instruction issue, not by its 46 MB of traffic.
+// v_min_f32 / v_max_f32 on values known to be finite: the builtins put a canonicalising v_max x, x in front of
+// every operand that was loaded rather than computed (IEEE mode), which doubles the chain.
+__device__ __forceinline__ float vmin_f32(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax_f32(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+constexpr int kFeatTileR = 32, kFeatTileC = 8, kFeatHaloMax = 16;
+struct FeatEntry { int off; float d0, d1, p00, p01, p11; int pad0, pad1; };  // 32 B: one s_load_dwordx8
+
+// keeps a table row's scalar loads where they are written (the compiler otherwise sinks them into the branch that
+// uses them, one dependent scalar-cache round trip per neighbour)
+__device__ __forceinline__ void pin_sgpr(const FeatEntry& f) {
+  asm volatile("" ::"s"(f.off), "s"(f.d0), "s"(f.d1), "s"(f.p00), "s"(f.p01), "s"(f.p11));
+}
+
+template <int TOPK>
+__global__ __launch_bounds__(256) void k_features_tiled(const GeomConst G, const DevState* __restrict__ st, int slot,
+                                                        const FeatEntry* __restrict__ tab, const FeatureParams F,
+                                                        int halo, const float* __restrict__ elev,
+                                                        const FeatureOut O) {
+  __shared__ float s_z[(kFeatTileR + 2 * kFeatHaloMax) * (kFeatTileC + 2 * kFeatHaloMax)];
+  const PostGeom p = post_geom(st, slot, G);
+  const int tiles_r = (p.rows + kFeatTileR - 1) / kFeatTileR;
+  const int tr = int(blockIdx.x) % tiles_r, tc = int(blockIdx.x) / tiles_r;
+  const int pitch = kFeatTileR + 2 * halo, width = kFeatTileC + 2 * halo;
+  const int r0 = tr * kFeatTileR - halo, c0 = tc * kFeatTileC - halo;
+  const float nanv = __uint_as_float(0x7FC00000u);
+  for (int k = int(threadIdx.x); k < pitch * width; k += 256) {
+    const int cc = k / pitch, rr = k - cc * pitch;
+    const int lr = r0 + rr, lc = c0 + cc;
+    s_z[k] = post_inside(p, lr, lc) ? elev[post_index(p, lr, lc)] : nanv;
+  }
+  __syncthreads();
+  const int lrl = int(threadIdx.x) & (kFeatTileR - 1), lcl = int(threadIdx.x) >> 5;
+  const int lr = tr * kFeatTileR + lrl, lc = tc * kFeatTileC + lcl;
+  if (!post_inside(p, lr, lc)) return;
+  const int base = (lcl + halo) * pitch + lrl + halo;
+  const float center_z = s_z[base];
+  if (!isfinite(center_z)) return;
+  const size_t ci = post_index(p, lr, lc);
+  float sum[3] = {0.f, 0.f, 0.f};
+  float s00 = 0.f, s01 = 0.f, s11 = 0.f, s02 = 0.f, s12 = 0.f, s22 = 0.f;
+  float small[TOPK], large[TOPK];
+#pragma unroll
+  for (int j = 0; j < TOPK; ++j) { small[j] = 3.402823466e+38f; large[j] = -3.402823466e+38f; }
+  int count = 0;
+  auto visit = [&](const FeatEntry& fe, float nz) {
+    if (!isfinite(nz)) return;
+    const float d2 = nz - center_z;
+    sum[0] += fe.d0;
+    sum[1] += fe.d1;
+    sum[2] += d2;
+    s00 += fe.p00;
+    s01 += fe.p01;
+    s11 += fe.p11;
+    s02 += fe.d0 * d2;
+    s12 += fe.d1 * d2;
+    s22 += d2 * d2;
+    float a = nz, b = nz;
+#pragma unroll
+    for (int j = 0; j < TOPK; ++j) {  // small[] ascending, large[] descending
+      const float lo_j = small[j], hi_j = large[j];
+      small[j] = vmin_f32(a, lo_j);
+      a = vmax_f32(a, lo_j);
+      large[j] = vmax_f32(b, hi_j);
+      b = vmin_f32(b, hi_j);
+    }
+    ++count;
+  };
+  int e = 0;
+  for (; e + 4 <= F.n_entries; e += 4) {  // four entries' scalar loads and LDS reads in flight together
+    const FeatEntry f0 = tab[e], f1 = tab[e + 1], f2 = tab[e + 2], f3 = tab[e + 3];
+    pin_sgpr(f0); pin_sgpr(f1); pin_sgpr(f2); pin_sgpr(f3);
+    const float z0 = s_z[base + f0.off], z1 = s_z[base + f1.off], z2 = s_z[base + f2.off], z3 = s_z[base + f3.off];
+    visit(f0, z0); visit(f1, z1); visit(f2, z2); visit(f3, z3);
+  }
+  for (; e < F.n_entries; ++e) {
+    const FeatEntry fe = tab[e];
+    visit(fe, s_z[base + fe.off]);
+  }
+  if (count < F.min_valid) return;
+  const float sq[9] = {s00, s01, s02, s01, s11, s12, s02, s12, s22};  // d[r] * d[c] is the same float either way round
+  float cov[9], trace;
+  if (!features_cov(sum, sq, count, cov, &trace)) return;
+  float val[3], normal[3];
+  eig3_direct(cov, val, normal);
+  if (val[1] < 1e-8f) return;  // kMinEigenvalue
+  const int lo = static_cast<int>(F.lo_pct * float(count - 1));
+  const int from_top = count - 1 - static_cast<int>(F.hi_pct * float(count - 1));
+  float z_lo = small[0], z_hi = large[0];
+#pragma unroll
+  for (int j = 1; j < TOPK; ++j) {
+    z_lo = lo == j ? small[j] : z_lo;
+    z_hi = from_top == j ? large[j] : z_hi;
+  }
+  features_store(O, ci, val, normal, trace, z_lo, z_hi);
 }
 
 }  // namespace fdm

@@ -142,6 +142,8 @@ void fdmref_apply_inpainting(void* e, int max_iterations, int min_valid_neighbor
 void fdmref_apply_spatial_smoothing(void* e, const char* layer, int kernel_size, int min_valid_neighbors);
 void fdmref_apply_uncertainty_fusion(void* e, int enabled, float search_radius, float spatial_sigma,
                                      float quantile_lower, float quantile_upper, int min_valid_neighbors);
+/* process-wide: 0 = platform float libm (default, the reference as built here), 1 = correctly rounded trig */
+void fdmref_set_trig_mode(int mode);
 void fdmref_apply_feature_extraction(void* e, float analysis_radius, int min_valid_neighbors,
                                      float step_lower_percentile, float step_upper_percentile);
 /* Eigen SelfAdjointEigenSolver<Matrix3f>::computeDirect restated: cov9 column-major -> val3 ascending, vec9 */

@@ -289,6 +289,8 @@ void fdmref_apply_uncertainty_fusion(void* e, int enabled, float r, float s, flo
   c.quantile_upper = qu; c.min_valid_neighbors = mv;
   applyUncertaintyFusion(E(e)->map(), c);
 }
+// 0 = the platform's float libm (the reference as built here), 1 = correctly rounded trig (fdm_ref_post.hpp)
+void fdmref_set_trig_mode(int mode) { fdmref::trig_mode() = mode ? 1 : 0; }
 void fdmref_apply_feature_extraction(void* e, float r, int mv, float lo, float hi) {
   applyFeatureExtraction(E(e)->map(), r, mv, lo, hi);
 }

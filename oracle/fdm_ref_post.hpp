@@ -237,6 +237,24 @@ inline void applyUncertaintyFusion(Grid& map, const FusionConfig& cfg) {
 // trigonometric roots, eigenvectors from cross-product kernels.  m is column-major, lower triangle read.
 struct Eig3 { float val[3]; float vec[9]; };  // vec column k = eigenvector of val[k], ascending
 
+// The reference calls the platform's float libm (atan2f / cosf / sinf / acosf).  Which float comes back for an
+// argument is a property of that libm: glibc 2.35 (this image) ships the fdlibm atan2f (errors up to ~1 ulp), glibc
+// >= 2.41 the correctly rounded CORE-MATH versions.  trig_mode() selects what the oracle restates:
+//   0  the platform's float functions — the reference as built on this machine (default);
+//   1  the function evaluated in double and rounded once to float, i.e. the correctly rounded result (up to
+//      double rounding) — what the device computes, and what a CORE-MATH libm returns.
+// Parity tests run both: mode 1 pins every OTHER float operation of the stage bit for bit, mode 0 bounds what
+// the libm's last-ulp differences become after the cancellation in the roots.
+inline int& trig_mode() { static int mode = 0; return mode; }
+namespace trig {
+inline float atan2_(float y, float x) {
+  return trig_mode() ? static_cast<float>(std::atan2(static_cast<double>(y), static_cast<double>(x))) : std::atan2(y, x);
+}
+inline float cos_(float v) { return trig_mode() ? static_cast<float>(std::cos(static_cast<double>(v))) : std::cos(v); }
+inline float sin_(float v) { return trig_mode() ? static_cast<float>(std::sin(static_cast<double>(v))) : std::sin(v); }
+inline float acos_(float v) { return trig_mode() ? static_cast<float>(std::acos(static_cast<double>(v))) : std::acos(v); }
+}  // namespace trig
+
 namespace eig3 {
 inline float& M(float* m, int r, int c) { return m[c * 3 + r]; }
 inline void cross(const float* a, const float* b, float* o) {
@@ -260,8 +278,8 @@ inline void computeRoots(const float* m, float* roots) {
   float q = a_over_3 * a_over_3 * a_over_3 - half_b * half_b;
   q = std::max(q, 0.0f);
   const float rho = std::sqrt(a_over_3);
-  const float theta = std::atan2(std::sqrt(q), half_b) * s_inv3;
-  const float cos_theta = std::cos(theta), sin_theta = std::sin(theta);
+  const float theta = trig::atan2_(std::sqrt(q), half_b) * s_inv3;
+  const float cos_theta = trig::cos_(theta), sin_theta = trig::sin_(theta);
   roots[0] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
   roots[1] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
   roots[2] = c2_over_3 + 2.0f * rho * cos_theta;
@@ -392,7 +410,7 @@ inline void applyFeatureExtraction(Grid& map, float analysis_radius, int min_val
       const int lo = static_cast<int>(step_lower_percentile * static_cast<float>(count - 1));
       const int hi = static_cast<int>(step_upper_percentile * static_cast<float>(count - 1));
       step_mat[ci] = z_vals[hi] - z_vals[lo];
-      slope_mat[ci] = std::acos(std::abs(normal[2])) * 180.0f / static_cast<float>(M_PI);
+      slope_mat[ci] = trig::acos_(std::abs(normal[2])) * 180.0f / static_cast<float>(M_PI);
       rough_mat[ci] = std::sqrt(pca.val[0]);
       curv_mat[ci] = (trace > 0.0f) ? std::abs(pca.val[0] / trace) : 0.0f;
       nx_mat[ci] = normal[0];

@@ -133,6 +133,7 @@ def load(native=False):
     lib.fdmref_apply_spatial_smoothing.argtypes = [P, C.c_char_p, C.c_int, C.c_int]
     lib.fdmref_apply_uncertainty_fusion.argtypes = [P, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]
     lib.fdmref_apply_feature_extraction.argtypes = [P, C.c_float, C.c_int, C.c_float, C.c_float]
+    lib.fdmref_set_trig_mode.argtypes = [C.c_int]
     lib.fdmref_eig3.argtypes = [P, P, P]
     lib.fdmref_from_cloud2.restype = C.c_uint64
     lib.fdmref_from_cloud2.argtypes = [P, C.c_uint64, C.POINTER(RefCloud2Layout), P, P, P, P, P]
@@ -397,6 +398,12 @@ class RefEngine:
 
 
 # ---- unit-level helpers for the reference's known-answer tests ----
+def set_trig_mode(mode):
+    """0 = platform float libm (the reference as built on this machine), 1 = correctly rounded trig
+    (fdm_ref_post.hpp `trig_mode`).  Process-wide."""
+    load().fdmref_set_trig_mode(int(mode))
+
+
 def voxel_any(x, y, z, voxel_size, stable=True):
     """filters::voxelGrid(..., VoxelMode::ANY): original indices of the kept points, output order."""
     x, y, z = _f32(x), _f32(y), _f32(z)

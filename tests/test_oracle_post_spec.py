@@ -165,6 +165,36 @@ class TestFeatureExtraction:
         assert not np.isfinite(cv) or 0.0 <= cv <= 1.0
 
 
+def test_trig_modes_agree_within_the_conditioning_bound(R):
+    """trig_mode 1 (correctly rounded atan2 / cos / sin / acos, what the device computes) against trig_mode 0
+    (this machine's float libm): same NaN pattern, eigen layers within 2e-6 absolute, `step` identical —
+    the bound tests/test_post_gpu.py asserts for the engine against mode 0."""
+    rng = np.random.default_rng(5)
+    r, c = np.meshgrid(np.arange(160), np.arange(160), indexing="ij")
+    el = (0.4 * np.sin(r * 0.11) * np.cos(c * 0.07) + 0.002 * r + rng.normal(0, 0.01, r.shape)).astype(F32)
+    el[rng.uniform(size=el.shape) < 0.15] = np.nan
+    out = []
+    try:
+        for mode in (0, 1):
+            R.set_trig_mode(mode)
+            m = R.RefEngine(8.0, 8.0, 0.05)
+            m.set_layer("elevation", el)
+            m.apply_feature_extraction(0.3, 4, 0.05, 0.95)
+            out.append({n: m.layer(n) for n in TestFeatureExtraction.NAMES})
+    finally:
+        R.set_trig_mode(0)
+    a, b = out
+    assert np.array_equal(a["step"], b["step"], equal_nan=True)
+    differ = 0
+    for n in ("roughness", "curvature", "_normal_x", "_normal_y", "_normal_z"):
+        assert np.array_equal(np.isnan(a[n]), np.isnan(b[n])), n
+        ok = np.isfinite(a[n])
+        assert ok.sum() > 10000
+        assert np.abs(a[n][ok].astype(np.float64) - b[n][ok]).max() <= 2e-6, n
+        differ += int((a[n][ok] != b[n][ok]).sum())
+    assert differ > 0  # the two libm behaviours are really different on this machine (glibc 2.35)
+
+
 def test_eig3_against_lapack(R):
     rng = np.random.default_rng(1)
     for _ in range(200):

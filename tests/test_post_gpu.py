@@ -3,10 +3,10 @@
 Tolerances (stated per stage):
   inpainting / median smoothing / uncertainty fusion: bit-exact (same float operation order; the
     fusion's exp() is evaluated in double on the device and agrees with libm's expf);
-  feature extraction: the closed-form 3x3 eigen-solver goes through atan2 / cos / sin / acos, whose
-    last-ulp differences between the device and the host libm are amplified by the cancellation in
-    the roots; eigen-derived layers are compared with atol 2e-4 (+ rtol 1e-4), slope in degrees with
-    atol 0.05 (acos is ill-conditioned at normal_z -> 1); `step` (order statistics) is bit-exact.
+  feature extraction: bit-exact in all seven layers once both sides use correctly rounded atan2 / cos / sin /
+    acos (the device does; the oracle's trig_mode 1); against this machine's float libm the eigen-derived
+    layers are bounded at 2e-6 absolute and slope by its acos conditioning (see the two tests);
+    `step` (order statistics) is bit-exact either way.
 """
 import numpy as np
 import pytest
@@ -129,22 +129,57 @@ def test_uncertainty_fusion_parity(gpu, R):
     assert not np.array_equal(eng.layer("upper_bound"), el + half, equal_nan=True)
 
 
-def test_feature_extraction_parity(gpu, R):
-    rng = np.random.default_rng(24)
-    eng, ref, shape = rolled_pair(gpu, R, rng, size=20.0, res=0.05)
+EIGEN_LAYERS = ("roughness", "curvature", "_normal_x", "_normal_y", "_normal_z", "slope")
+
+
+def _feature_pair(gpu, R, seed, size, radius):
+    rng = np.random.default_rng(seed)
+    eng, ref, shape = rolled_pair(gpu, R, rng, size=size, res=0.05)
     el = terrain(rng, shape, holes=0.15, noise=0.01)
     el[:, shape[1] // 2:] += F32(0.3)  # a step edge
-    both((eng, ref), lambda o: (o.set_layer("elevation", el), o.apply_feature_extraction(0.3, 4, 0.05, 0.95)))
+    both((eng, ref), lambda o: (o.set_layer("elevation", el), o.apply_feature_extraction(radius, 4, 0.05, 0.95)))
     assert sorted(eng.layers()) == sorted(ref.layers())
+    assert np.isfinite(eng.layer("slope")).sum() > 0.5 * el.size
+    return eng, ref
+
+
+@pytest.mark.parametrize("seed,size,radius", [(24, 20.0, 0.3), (7, 30.0, 0.35)])
+def test_feature_extraction_bit_exact_with_correctly_rounded_trig(gpu, R, seed, size, radius):
+    """The device evaluates atan2 / cos / sin / acos in double and rounds once, i.e. the correctly rounded float.
+    With the oracle doing the same (trig_mode 1; glibc >= 2.41's CORE-MATH float functions return exactly
+    that) every other float operation of the stage is pinned: all seven layers bit for bit."""
+    R.set_trig_mode(1)
+    try:
+        eng, ref = _feature_pair(gpu, R, seed, size, radius)
+        for n in ("step",) + EIGEN_LAYERS:
+            assert_arrays_close(eng.layer(n), ref.layer(n), n, 0.0, 0.0)
+    finally:
+        R.set_trig_mode(0)
+
+
+def test_feature_extraction_against_platform_libm(gpu, R):
+    """Oracle on this machine's float libm (glibc 2.35: fdlibm atan2f, <= 1 ulp off the rounded value in ~3 % of the
+    calls).  One ulp in theta moves the scaled roots by <= ~2 eps; the eigenvalues carry that as an ABSOLUTE error of
+    a few eps * scale (scale = max |cov - mean| <= ~1e-1 here), so the bound is absolute, not relative:
+      roughness, curvature, normals: 2e-6 (measured max 4.3e-7 over 1.7 M cells; the bar was 2e-4);
+      slope = acos(|nz|) in degrees: (180/pi) * 3 ulp(1) / sqrt(1 - nz^2), floor 1e-5 — acos is ill-conditioned
+      towards nz = 1 (0.03 deg there, 7e-5 deg at nz = 0.99; measured max 4.8e-4 deg);
+      step (order statistics): bit-exact."""
+    eng, ref = _feature_pair(gpu, R, 24, 20.0, 0.3)
     assert_arrays_close(eng.layer("step"), ref.layer("step"), "step", 0.0, 0.0)
-    for n, atol, rtol in (("roughness", 2e-4, 1e-4), ("curvature", 2e-4, 1e-4), ("_normal_x", 2e-4, 1e-4),
-                          ("_normal_y", 2e-4, 1e-4), ("_normal_z", 2e-4, 1e-4), ("slope", 0.05, 1e-4)):
+    nz = ref.layer("_normal_z").astype(np.float64)
+    for n in EIGEN_LAYERS:
         a, b = eng.layer(n), ref.layer(n)
         assert np.array_equal(np.isnan(a), np.isnan(b)), f"{n}: NaN pattern differs in {(np.isnan(a) != np.isnan(b)).sum()}"
         ok = np.isfinite(b)
-        err = np.abs(a[ok].astype(np.float64) - b[ok]) - rtol * np.abs(b[ok])
-        assert err.max() <= atol, f"{n}: max abs err {err.max():.3e}"
-    assert np.isfinite(eng.layer("slope")).sum() > 0.5 * el.size
+        err = np.abs(a[ok].astype(np.float64) - b[ok])
+        if n == "slope":
+            tol = np.degrees(3.0 * 2.0 ** -24 / np.sqrt(np.maximum(1.0 - nz[ok] ** 2, 2.0 ** -23))) + 1e-5
+        else:
+            tol = 2e-6
+        assert (err <= tol).all(), f"{n}: max abs err {err.max():.3e}, {(err > tol).sum()} cells over the bound"
+        same = a.view(np.uint32)[ok] == b.view(np.uint32)[ok]
+        assert same.mean() > 0.9, f"{n}: only {same.mean():.3f} of the cells bit-identical"
 
 
 def test_after_real_scans_with_records(gpu, R):
