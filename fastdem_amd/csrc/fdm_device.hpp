@@ -194,13 +194,14 @@ __device__ __forceinline__ bool cell_of(float xf, float yf, const DevCand& g, co
 //                border: the estimate is off by ~1e-12 cells at most, so trunc(-(v/res)) is k.
 //   axis_exact : the reference arithmetic (inside test + IEEE divide) for the lanes that were not sure.
 //   axis_wrap  : start index + circular wrap (getBufferIndexFromIndex), range check.
-__device__ __forceinline__ int axis_fast(double pos, double center, double half, double inv_res_k, int shift,
-                                         int size, bool& sure) {
-  const double v = (pos - half) - center;
-  const int ki = static_cast<int>(-v * inv_res_k);  // saturating convert; NaN -> 0
+__device__ __forceinline__ int axis_fast(double pos, double off_k, double inv_res_k, int shift, int size,
+                                         bool& sure) {
+  // -((pos - half) - center) * 2^shift / res in ONE rounding: off_k = (half + center) * inv_res_k per block
+  const int ki = static_cast<int>(fma(pos, -inv_res_k, off_k));  // saturating convert; NaN -> 0
   const int mask = (1 << shift) - 1;
   const int k = ki >> shift, fr = ki & mask;
-  sure = fr != 0 && fr != mask && k >= 1 && k < size - 1;
+  // fr in [1, mask - 1] and k in [1, size - 2], one unsigned compare each
+  sure = unsigned(fr - 1) < unsigned(mask - 1) && unsigned(k - 1) < unsigned(size - 2);
   return k;
 }
 __device__ __forceinline__ bool axis_exact(double pos, double center, double half, double len, double res,
@@ -214,7 +215,7 @@ __device__ __forceinline__ bool axis_exact(double pos, double center, double hal
 __device__ __forceinline__ bool axis_wrap(int& k, int start, bool any_start, int size) {
   k += start;
   if (any_start && k >= size) k -= size;
-  return k >= 0 && k < size;
+  return unsigned(k) < unsigned(size);
 }
 
 // is buffer index `b` on `axis` inside the strip GridMap::move vacates? (E = geometry

@@ -180,10 +180,11 @@ __device__ __forceinline__ void tbin_points(const ScanParams& P, const GeomConst
   int kr[4], kc[4];
   bool sure_r[4], sure_c[4], inside[4];
   bool unsure = false;
+  const double off_r = (G.half_x + cand.px) * G.inv_res_k, off_c = (G.half_y + cand.py) * G.inv_res_k;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    kr[j] = axis_fast(double(xs[j]), cand.px, G.half_x, G.inv_res_k, G.idx_shift, G.rows, sure_r[j]);
-    kc[j] = axis_fast(double(ys[j]), cand.py, G.half_y, G.inv_res_k, G.idx_shift, G.cols, sure_c[j]);
+    kr[j] = axis_fast(double(xs[j]), off_r, G.inv_res_k, G.idx_shift, G.rows, sure_r[j]);
+    kc[j] = axis_fast(double(ys[j]), off_c, G.inv_res_k, G.idx_shift, G.cols, sure_c[j]);
     inside[j] = pass[j];
     unsure = unsure || (pass[j] && !(sure_r[j] && sure_c[j]));
   }
@@ -201,7 +202,7 @@ __device__ __forceinline__ void tbin_points(const ScanParams& P, const GeomConst
     const bool okc = axis_wrap(c, cand.sc, any_start, G.cols);
     const bool in_map = inside[j] && okr && okc;
     const int lr = r - G.o_r0, lc = c - G.o_c0;
-    const bool owned = in_map && lr >= 0 && lc >= 0 && lr < G.o_rows && lc < G.o_cols;
+    const bool owned = in_map && unsigned(lr) < unsigned(G.o_rows) && unsigned(lc) < unsigned(G.o_cols);
     const int sr = r - G.s_r0, sc = c - G.s_c0;
     const int tile = (sc >> kTCShift) * TG.tiles_r + (sr >> kTSShift);
     const int tcell = (tile << 10) | ((sc & (kTC - 1)) << kTSShift) | (sr & (kTS - 1));
