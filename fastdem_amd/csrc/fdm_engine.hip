@@ -180,6 +180,10 @@ struct fdm_engine {
   RegionEntry* d_region = nullptr;   // kMaxRegion entries
   FeatEntry* d_feat_tab = nullptr;   // kMaxRegion entries: the region as k_features_tiled reads it
   int dbg_post = 0;                  // measurement only: 1 = untiled feature kernel
+  int dbg_span = 0;                  // measurement only: tiles per update group (0 = automatic)
+  unsigned long long* d_timeline = nullptr;  // measurement only: {start, end} ticks per block of the last fused launch
+  unsigned timeline_cap = 0;         // blocks the buffer holds
+  unsigned timeline_blocks = 0, timeline_upd = 0;  // grid of the last fused launch, its update blocks
   float* d_tmp2 = nullptr;           // second ncell staging array (fusion works on two layers)
   // ingest (fdm_ingest.hpp)
   uint8_t* d_blob = nullptr;         // raw message bytes
@@ -525,7 +529,10 @@ int allow_lds(K kern, unsigned bytes) {
 
 // tiles per 256-thread group of k_tupdate: 1 while the tile count keeps the chip busy by itself, 32 on
 // very large maps (nearly every tile idle: one wavefront looks at 32 chunk counts in one round trip)
-unsigned tile_span(const fdm_engine* e) { return e->TG.n_tiles <= 16384u ? 1u : 32u; }
+unsigned tile_span(const fdm_engine* e) {
+  if (e->dbg_span > 0) return unsigned(e->dbg_span);  // measurement only
+  return e->TG.n_tiles <= 16384u ? 1u : 32u;
+}
 
 // The record pools of the tiled pipeline: `records` per pool, `blocks` chunk slots per tile.
 int ensure_tile_pool(fdm_engine* e, size_t records, unsigned blocks, bool has_int, bool has_col) {
@@ -648,8 +655,12 @@ int launch_update_fused(fdm_engine* e, const fdm_engine::PendingUpdate& u, const
         int rc = FDM_OK;
         auto go = [&](auto kern) {
           if ((rc = allow_lds(kern, lds))) return;
+          TileAux A = u.A;
+          if (ub + bin_blocks_b > e->timeline_cap) A.timeline = nullptr;
+          e->timeline_blocks = A.timeline ? ub + bin_blocks_b : 0u;
+          e->timeline_upd = ub;
           hipLaunchKernelGGL(kern, dim3(ub + bin_blocks_b), dim3(bv.threads), lds, e->stream, u.P, e->G, e->TG,
-                             e->d_state, layers, e->d_layer_ptrs, e->n_layer_ptrs, u.Q, u.A, span, ub, Pb, Ib, Sb, Qb,
+                             e->d_state, layers, e->d_layer_ptrs, e->n_layer_ptrs, u.Q, A, span, ub, Pb, Ib, Sb, Qb,
                              ids_b);
         };
 #define FDM_TF(LN)                                                                  \
@@ -932,7 +943,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   u.upd_blocks = e->n_tiles;
   if (tiled) {
     u.Q = e->pool[parity];
-    u.A = TileAux{e->tile_stamp32, e->upd_part32, e->S.ras_z};
+    u.A = TileAux{e->tile_stamp32, e->upd_part32, e->S.ras_z, e->d_timeline};
     e->last_upd_tiles = e->TG.n_tiles;
     e->last_upd_part = e->upd_part32;
   } else {
@@ -1385,6 +1396,7 @@ void fdm_engine_destroy(fdm_engine* e) {
     if (ev) (void)hipEventDestroy(ev);
   if (e->d_region) (void)hipFree(e->d_region);
   if (e->d_feat_tab) (void)hipFree(e->d_feat_tab);
+  if (e->d_timeline) (void)hipFree(e->d_timeline);
   if (e->d_tmp2) (void)hipFree(e->d_tmp2);
   if (e->d_blob) (void)hipFree(e->d_blob);
   if (e->d_in) (void)hipFree(e->d_in);
@@ -1623,6 +1635,19 @@ int fdm_engine_flush(fdm_engine* e) {
 void* fdm_engine_stream(fdm_engine* e) { return e ? static_cast<void*>(e->stream) : nullptr; }
 
 int fdm_engine_last_pipeline(fdm_engine* e) { return e ? e->last_kind : -1; }
+
+int fdm_engine_debug_timeline(fdm_engine* e, uint64_t* ticks, uint64_t cap_blocks, uint32_t* n_blocks,
+                              uint32_t* n_update_blocks) {
+  if (!e || !ticks || !n_blocks || !n_update_blocks) return fail(FDM_ERR_INVALID, "null argument");
+  if (!e->d_timeline) return fail(FDM_ERR_INVALID, "option dbg_timeline is off");
+  HIPCK(hipSetDevice(e->device));
+  HIPCK(hipStreamSynchronize(e->stream));  // (no flush: a held-back update stays held back)
+  *n_blocks = e->timeline_blocks;
+  *n_update_blocks = e->timeline_upd;
+  const uint64_t n = std::min<uint64_t>(cap_blocks, e->timeline_blocks);
+  if (n) HIPCK(hipMemcpy(ticks, e->d_timeline, n * 16, hipMemcpyDeviceToHost));
+  return FDM_OK;
+}
 
 int fdm_engine_record_event(fdm_engine* e, void* hip_event) {
   if (!e || !hip_event) return fail(FDM_ERR_INVALID, "null argument");
@@ -1989,6 +2014,21 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
   if (std::strcmp(key, "zero_copy") == 0) {
     if (value < 0) return fail(FDM_ERR_INVALID, "zero_copy: a point count (0 = off)");
     e->zero_copy = value;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "dbg_timeline") == 0) {  // measurement only: block start / end ticks of the fused tiled launches
+    if (int rc_sync = sync_all(e)) return rc_sync;
+    if (e->d_timeline) { (void)hipFree(e->d_timeline); e->d_timeline = nullptr; }
+    e->timeline_cap = 0;
+    if (value > 0) {
+      e->timeline_cap = 1u << 16;
+      HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_timeline), size_t(e->timeline_cap) * 16));
+      HIPCK(hipMemset(e->d_timeline, 0, size_t(e->timeline_cap) * 16));
+    }
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "dbg_span") == 0) {
+    e->dbg_span = value;
     return FDM_OK;
   }
   if (std::strcmp(key, "dbg_post") == 0) {

@@ -98,6 +98,7 @@ struct TileAux {           // what the update kernel keeps per tile between scan
   uint32_t* stamp;         // [n_tiles] last scan that touched a cell of the tile
   uint32_t* upd_part;      // [n_tiles] cells touched by the last scan (statistics)
   float* ras_z;            // [ncell] optional capture (onScanRasterized), NaN-filled by the host
+  unsigned long long* timeline;  // measurement only (nullable): per block of a fused launch {start, end} in 100 MHz ticks
 };
 
 // value of a canonicalised ord word; `neg`: the first zero seen was -0 (only looked at for a zero)
@@ -1002,10 +1003,15 @@ __global__ __launch_bounds__(THREADS, FDM_UPD_WAVES) void k_tupdate_tbin(
   // tile chains down by more than they gain).
   const unsigned u0 = blockIdx.x < upd_blocks ? blockIdx.x : upd_blocks;
   const unsigned u1 = blockIdx.x < upd_blocks ? blockIdx.x + 1u : upd_blocks;
+  const unsigned long long t0 = A.timeline ? wall_clock64() : 0ull;
   if (u1 > u0)
     tupdate_body<POLICY, THREADS, HAS_INT, HAS_COL>(Pu, G, TG, st, L, all_layers, n_layers, Qu, A, span, dyn_lds, u0);
   else
     tbin_body<HAS_INT, HAS_COL, THREADS, LEAN>(Pb, G, TG, st, Ib, Sb, Qb, cell_ids, dyn_lds, blockIdx.x - u0);
+  if (A.timeline && threadIdx.x == 0) {  // (thread 0's view of the block; bench A/B tool, see scripts/timeline.py)
+    A.timeline[2u * blockIdx.x] = t0;
+    A.timeline[2u * blockIdx.x + 1u] = wall_clock64();
+  }
 }
 
 }  // namespace fdm

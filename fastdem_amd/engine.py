@@ -215,6 +215,15 @@ class Engine:
         """0 = per-cell scratch pipeline, 1 = per-tile record pools (large scans), -1 = no scan yet."""
         return self._lib.fdm_engine_last_pipeline(self._h)
 
+    def debug_timeline(self, cap_blocks=1 << 16):
+        """(option dbg_timeline=1) -> (ticks[n_blocks, 2] uint64 of the 100 MHz clock, n_update_blocks) of the
+        last fused large-scan launch."""
+        buf = np.zeros((cap_blocks, 2), dtype=np.uint64)
+        nb, nu = C.c_uint32(0), C.c_uint32(0)
+        _ck(self._lib.fdm_engine_debug_timeline(self._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), cap_blocks,
+                                                C.byref(nb), C.byref(nu)))
+        return buf[:nb.value], nu.value
+
     def flush(self):
         """Launch a held-back map update (no wait)."""
         _ck(self._lib.fdm_engine_flush(self._h))

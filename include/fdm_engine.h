@@ -187,6 +187,11 @@ void* fdm_engine_stream(fdm_engine* e);
 /* Which pipeline the last scan took: 0 = per-cell scratch (k_bin / k_update), 1 = per-tile record pools
  * (k_tbin / k_tupdate: scans of >= 64 K points on maps of >= 512 tiles), -1 = no scan yet.  Diagnostic. */
 int fdm_engine_last_pipeline(fdm_engine* e);
+/* Measurement tool (engine option "dbg_timeline" = 1): start / end time of every block of the last fused
+ * large-scan launch, in ticks of the 100 MHz constant clock — ticks[2*b], ticks[2*b + 1] for block b; blocks
+ * [0, *n_update_blocks) are tile-update groups of scan t, the rest bin blocks of scan t+1.  Waits for the stream. */
+int fdm_engine_debug_timeline(fdm_engine* e, uint64_t* ticks, uint64_t cap_blocks, uint32_t* n_blocks,
+                              uint32_t* n_update_blocks);
 /* Order a consumer behind the engine: launches a held-back update, then records `hip_event`
  * (hipEvent_t) on the engine's stream — everything enqueued so far, the map update of the last scan
  * included, is complete when the event fires (the reference's callers hold a shared_mutex around
