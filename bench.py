@@ -448,17 +448,35 @@ def main():
                 big = Resident(synth.lidar128(n_scans=LARGE_SCANS), local_rank, args.wave_merge, args.overlap)
                 for kv in args.set:
                     big.eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
-                for i in range(10):
+                # the same protocol as the headline: warm-up, then ONE batch call timed by the wall clock and by HIP
+                # events on the engine's stream; the roofline of the fused launch from that region
+                n_big = 300
+                for i in range(30):
                     big.step(i)
                 big.eng.sync()
+                bb, bpts = big.batch(30, n_big)
+                evb = HipEvents(big.eng.stream())
                 t0 = time.perf_counter()
-                for i in range(40):
-                    big.step(10 + i)
+                evb.start()
+                rcb = big.eng.integrate_device_batch(bb)
+                big.eng.flush()
+                evb.stop()
                 big.eng.sync()
                 dtb = time.perf_counter() - t0
-                kb, rb = measure_kernels(big, 50, 20, "c4")
-                result["large"] = {"workload": big.wl.name, "value": big.n * 40 / dtb / 1e6,
-                                   "unit": "Mpts/s", "ms_per_step": dtb / 40 * 1e3,
+                if rcb != 0:
+                    raise RuntimeError(f"integrate_device_batch (large leg) failed: {rcb}")
+                big_us = evb.elapsed_ms() / n_big * 1e3
+                kb, rb = measure_kernels(big, 30 + n_big, 20, "c4")
+                if "k_update_bin" in kb:
+                    kb["k_update_bin"]["ms_isolated"] = kb["k_update_bin"]["ms"]
+                    kb["k_update_bin"]["ms"] = big_us * 1e-3
+                    gb = kb["k_update_bin"]["alg_bytes"] / (big_us * 1e-6) / 1e9
+                    kb["k_update_bin"]["GBps"] = gb
+                    rb.update({"achieved": gb, "frac": gb / HBM_PEAK_GBS, "avg_kernel_us": big_us,
+                               "measured": "HIP events on the engine stream around the timed region / steps"})
+                result["large"] = {"workload": big.wl.name, "value": bpts / dtb / 1e6, "steps": n_big,
+                                   "device_value": bpts / (big_us * n_big * 1e-6) / 1e6,
+                                   "unit": "Mpts/s", "ms_per_step": dtb / n_big * 1e3,
                                    "roofline": rb, "kernels": kb}
                 del big
             if world == 1 and not args.no_cpu_baseline:
