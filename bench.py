@@ -450,11 +450,12 @@ def main():
                     big.eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
                 # the same protocol as the headline: warm-up, then ONE batch call timed by the wall clock and by HIP
                 # events on the engine's stream; the roofline of the fused launch from that region
-                n_big = 300
-                for i in range(30):
-                    big.step(i)
+                n_big, n_warm = 1000, 200
+                wb, _ = big.batch(0, n_warm)
+                if big.eng.integrate_device_batch(wb) != 0:
+                    raise RuntimeError("integrate_device_batch (large leg warm-up) failed")
                 big.eng.sync()
-                bb, bpts = big.batch(30, n_big)
+                bb, bpts = big.batch(n_warm, n_big)
                 evb = HipEvents(big.eng.stream())
                 t0 = time.perf_counter()
                 evb.start()
@@ -466,7 +467,7 @@ def main():
                 if rcb != 0:
                     raise RuntimeError(f"integrate_device_batch (large leg) failed: {rcb}")
                 big_us = evb.elapsed_ms() / n_big * 1e3
-                kb, rb = measure_kernels(big, 30 + n_big, 20, "c4")
+                kb, rb = measure_kernels(big, n_warm + n_big, 20, "c4")
                 if "k_update_bin" in kb:
                     kb["k_update_bin"]["ms_isolated"] = kb["k_update_bin"]["ms"]
                     kb["k_update_bin"]["ms"] = big_us * 1e-3
