@@ -19,6 +19,7 @@ ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--cpu-iters", type=int, default=5)
 ap.add_argument("--dbg-ray", type=int, default=0)
 ap.add_argument("--order", default="azimuth", choices=["azimuth", "ring"])
+ap.add_argument("--set", action="append", default=[])
 a = ap.parse_args()
 
 wl = synth.make(a.workload, **({"order": a.order} if a.workload in ("c2", "c4") else {}))
@@ -30,6 +31,8 @@ def run(raycast):
     cfg.raycast_enabled = raycast
     res.eng.set_config(cfg)
     res.eng.set_option("dbg_ray", a.dbg_ray)
+    for kv in a.set:
+        res.eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     for k in range(10):
         res.step(k)
     res.eng.sync()
