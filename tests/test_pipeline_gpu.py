@@ -2,6 +2,8 @@
 launch per scan (update of scan t fused with the bin of scan t+1, k_update_bin).  Everything the
 reference decides per scan (rolling move, "all filtered" / "nothing landed" gates, lazy layers) must
 come out exactly as with one scan at a time, whatever is interleaved with the chain."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -216,6 +218,33 @@ def test_chain_of_large_scans(gpu, R, n_az, scans, lean):
     rc, st = eng.last_stats()
     assert rc == rc_r and st == st_r and st["shift_rows"] == -8
     assert_layers_equal(eng, ref)
+    assert same_geometry(eng.geometry(), ref.geometry())
+
+
+def test_long_chain_of_large_scans_through_the_batch_entry(gpu, R):
+    """48 scans of 262 K points in ONE fdm_engine_integrate_device_batch call (what bench.py times): the record
+    pools alternate 24 times, the window rolls by 8 cells per scan until it has wrapped around, every update is
+    held back into the next scan's launch — compared with the oracle at the end, bit for bit."""
+    scans, distinct = 48, 6
+    wl = gpu.synth.lidar128(n_scans=distinct, n_az=2048)
+    eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
+    eng.enable_cell_ids(False)
+    devs = [dev(wl.scan(k)) for k in range(distinct)]
+    arr = (gpu.capi.FdmDeviceScan * scans)()
+    for k in range(scans):
+        d, a = devs[k % distinct], arr[k]
+        a.n = wl.n_points
+        a.x, a.y, a.z, a.intensity = (d[c].data_ptr() for c in ("x", "y", "z", "intensity"))
+        a.rgb, a.sigma_z2 = None, None
+        # (the ABI takes 4x4 matrices column-major, as Eigen stores them)
+        a.T_base_sensor = (C.c_double * 16)(*np.asarray(wl.T_base_sensor, dtype=np.float64).T.ravel())
+        a.T_world_base = (C.c_double * 16)(*np.asarray(wl.pose(k), dtype=np.float64).T.ravel())
+    assert eng.integrate_device_batch(arr) == 0
+    for k in range(scans):
+        rc_r, st_r = ref_step(ref, wl.scan(k % distinct), wl.T_base_sensor, wl.pose(k))
+    rc, st = eng.last_stats()
+    assert rc == rc_r and st == st_r
+    assert_layers_equal(eng, ref, rtol=0.0)
     assert same_geometry(eng.geometry(), ref.geometry())
 
 
