@@ -122,28 +122,6 @@ class Resident:
         return b + (8 if s["intensity"] is not None else 0) + (4 if s["rgb"] is not None else 0)
 
 
-class HipEvents:
-    """A start/stop pair of HIP events recorded on the ENGINE's stream (a plain torch.cuda.Event().record()
-    only sees torch's current stream).  The events are torch's, recorded on the engine's stream wrapped as
-    an ExternalStream: the same HIP runtime the engine library is bound to, no second dlopen."""
-
-    def __init__(self, stream):
-        import torch
-        self.ext = torch.cuda.ExternalStream(int(stream))
-        self.a = torch.cuda.Event(enable_timing=True)
-        self.b = torch.cuda.Event(enable_timing=True)
-
-    def start(self):
-        self.a.record(self.ext)
-
-    def stop(self):
-        self.b.record(self.ext)
-
-    def elapsed_ms(self):
-        self.b.synchronize()
-        return float(self.a.elapsed_time(self.b))
-
-
 def measure_kernels(res, k0, steps, tag=None, overlap=1):
     """HIP-event durations of the launches (events recorded on the engine's stream around each
     launch), averaged over `steps` scans, plus the algorithmic bytes each launch moves.
@@ -360,19 +338,17 @@ def main():
         # would measure the interpreter, not the engine
         batch, pts = res.batch(k, args.steps)
         barrier()
-        ev = HipEvents(res.eng.stream())
         t0 = time.perf_counter()
-        ev.start()
+        res.eng.timer_start()  # HIP event on the engine's stream (fdm_engine_timer_*)
         rc = res.eng.integrate_device_batch(batch)
-        res.eng.flush()  # the last scan's held-back update belongs to the timed region
-        ev.stop()
+        res.eng.timer_stop()   # launches the last scan's held-back update — it belongs to the timed region — and marks
         res.eng.sync()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if rc != 0:
             raise RuntimeError(f"integrate_device_batch failed: {rc}")
         k += args.steps
-        timed_launch_us = ev.elapsed_ms() / args.steps * 1e3  # HIP events on the engine's stream
+        timed_launch_us = res.eng.timer_ms() / args.steps * 1e3  # HIP events on the engine's stream
         if world > 1:
             dist.barrier()
             t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -456,17 +432,15 @@ def main():
                     raise RuntimeError("integrate_device_batch (large leg warm-up) failed")
                 big.eng.sync()
                 bb, bpts = big.batch(n_warm, n_big)
-                evb = HipEvents(big.eng.stream())
                 t0 = time.perf_counter()
-                evb.start()
+                big.eng.timer_start()
                 rcb = big.eng.integrate_device_batch(bb)
-                big.eng.flush()
-                evb.stop()
+                big.eng.timer_stop()
                 big.eng.sync()
                 dtb = time.perf_counter() - t0
                 if rcb != 0:
                     raise RuntimeError(f"integrate_device_batch (large leg) failed: {rcb}")
-                big_us = evb.elapsed_ms() / n_big * 1e3
+                big_us = big.eng.timer_ms() / n_big * 1e3
                 kb, rb = measure_kernels(big, n_warm + n_big, 20, "c4")
                 if "k_update_bin" in kb:
                     kb["k_update_bin"]["ms_isolated"] = kb["k_update_bin"]["ms"]

@@ -138,6 +138,7 @@ struct fdm_engine {
   void* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   hipEvent_t ev_ray[2] = {nullptr, nullptr};
+  hipEvent_t ev_timer[2] = {nullptr, nullptr};  // fdm_engine_timer_start / _stop
   bool ray_timed = false;
   int dbg_ray = 0;
   // update(t) || bin(t+1) in ONE launch (k_update_bin): the update of the last small scan is held back
@@ -1281,6 +1282,7 @@ static int create_impl(const fdm_geometry* g, const fdm_config* cfg, const fdm_t
   HCK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   for (auto& ev : e->ev) HCK(hipEventCreate(&ev));
   for (auto& ev : e->ev_ray) HCK(hipEventCreate(&ev));
+  for (auto& ev : e->ev_timer) HCK(hipEventCreate(&ev));
   HCK(hipMalloc(reinterpret_cast<void**>(&e->d_state), sizeof(DevState)));
   HCK(hipHostMalloc(reinterpret_cast<void**>(&e->h_state), sizeof(DevState)));
   std::memset(e->h_state, 0, sizeof(DevState));
@@ -1393,6 +1395,8 @@ void fdm_engine_destroy(fdm_engine* e) {
   for (auto& ev : e->ev)
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : e->ev_ray)
+    if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : e->ev_timer)
     if (ev) (void)hipEventDestroy(ev);
   if (e->d_region) (void)hipFree(e->d_region);
   if (e->d_feat_tab) (void)hipFree(e->d_feat_tab);
@@ -1635,6 +1639,27 @@ int fdm_engine_flush(fdm_engine* e) {
 void* fdm_engine_stream(fdm_engine* e) { return e ? static_cast<void*>(e->stream) : nullptr; }
 
 int fdm_engine_last_pipeline(fdm_engine* e) { return e ? e->last_kind : -1; }
+
+int fdm_engine_timer_start(fdm_engine* e) {
+  if (!e) return fail(FDM_ERR_INVALID, "null engine");
+  if (int rc = join_streams(e)) return rc;  // a held-back update belongs to what came before the mark
+  HIPCK(hipEventRecord(e->ev_timer[0], e->stream));
+  return FDM_OK;
+}
+
+int fdm_engine_timer_stop(fdm_engine* e) {
+  if (!e) return fail(FDM_ERR_INVALID, "null engine");
+  if (int rc = join_streams(e)) return rc;  // the last scan's update is part of the timed work
+  HIPCK(hipEventRecord(e->ev_timer[1], e->stream));
+  return FDM_OK;
+}
+
+int fdm_engine_timer_ms(fdm_engine* e, float* ms) {
+  if (!e || !ms) return fail(FDM_ERR_INVALID, "null argument");
+  if (int rc = sync_all(e)) return rc;
+  HIPCK(hipEventElapsedTime(ms, e->ev_timer[0], e->ev_timer[1]));
+  return FDM_OK;
+}
 
 int fdm_engine_debug_timeline(fdm_engine* e, uint64_t* ticks, uint64_t cap_blocks, uint32_t* n_blocks,
                               uint32_t* n_update_blocks) {

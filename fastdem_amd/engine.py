@@ -215,6 +215,19 @@ class Engine:
         """0 = per-cell scratch pipeline, 1 = per-tile record pools (large scans), -1 = no scan yet."""
         return self._lib.fdm_engine_last_pipeline(self._h)
 
+    def timer_start(self):
+        """Mark the start of a timed run of enqueue-only calls on the engine's stream."""
+        _ck(self._lib.fdm_engine_timer_start(self._h))
+
+    def timer_stop(self):
+        """Launch the last scan's held-back update and mark the end."""
+        _ck(self._lib.fdm_engine_timer_stop(self._h))
+
+    def timer_ms(self):
+        ms = C.c_float(0.0)
+        _ck(self._lib.fdm_engine_timer_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
     def debug_timeline(self, cap_blocks=1 << 16):
         """(option dbg_timeline=1) -> (ticks[n_blocks, 2] uint64 of the 100 MHz clock, n_update_blocks) of the
         last fused large-scan launch."""

@@ -187,6 +187,13 @@ void* fdm_engine_stream(fdm_engine* e);
 /* Which pipeline the last scan took: 0 = per-cell scratch (k_bin / k_update), 1 = per-tile record pools
  * (k_tbin / k_tupdate: scans of >= 64 K points on maps of >= 512 tiles), -1 = no scan yet.  Diagnostic. */
 int fdm_engine_last_pipeline(fdm_engine* e);
+/* Device-side stopwatch on the engine's stream (two engine-owned HIP events): _start marks "everything enqueued so
+ * far" (a held-back update is launched first), _stop launches the last scan's held-back update and marks its end,
+ * _ms waits for the stop mark and returns the time between the two.  For callers without HIP of their own that
+ * want the GPU's view of a run of enqueue-only calls (bench.py's `device_value`). */
+int fdm_engine_timer_start(fdm_engine* e);
+int fdm_engine_timer_stop(fdm_engine* e);
+int fdm_engine_timer_ms(fdm_engine* e, float* ms);
 /* Measurement tool (engine option "dbg_timeline" = 1): start / end time of every block of the last fused
  * large-scan launch, in ticks of the 100 MHz constant clock — ticks[2*b], ticks[2*b + 1] for block b; blocks
  * [0, *n_update_blocks) are tile-update groups of scan t, the rest bin blocks of scan t+1.  Waits for the stream. */
@@ -391,6 +398,7 @@ int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2);
  *   "bin_table"   0/1   : k_bin folds poorly merged waves into a per-block LDS cell table before the atomics
  *   "zero_copy"   n     : host entry points read PINNED input arrays of up to n points in place (0 = always copy)
  *   "overlap"     0/1   : hold the update of a small scan back and fuse it with the next scan's bin launch
+ *   "tiled" 0/1, "tiled_min" n : large-scan pipeline (per-tile record pools) on/off, its point-count threshold
  *   "dbg_*"             : measurement-only switches used by scripts/ab_kernels.py */
 int fdm_engine_set_option(fdm_engine* e, const char* key, int value);
 

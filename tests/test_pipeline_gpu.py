@@ -383,3 +383,21 @@ def test_fused_launch_timeline_tool(gpu):
     assert 1.0 < span_us < 5000.0
     eng.set_option("dbg_timeline", 0)
     eng.sync()
+
+
+def test_engine_stopwatch(gpu):
+    """fdm_engine_timer_*: the device-side duration of a run of enqueue-only calls, the last scan's held-back
+    update included (what bench.py reports as `device_value`)."""
+    wl = gpu.synth.vlp16(n_scans=3)
+    eng = gpu.Engine(wl.width, wl.height, wl.resolution, wl.apply_to(gpu.capi.default_config()))
+    devs = [dev(wl.scan(k)) for k in range(3)]
+    for k in range(3):
+        enqueue(eng, devs[k], wl.T_base_sensor, wl.pose(k))
+    eng.timer_start()
+    for k in range(3, 43):
+        enqueue(eng, devs[k % 3], wl.T_base_sensor, wl.pose(k))
+    eng.timer_stop()
+    ms = eng.timer_ms()
+    assert 40 * 0.002 < ms < 40 * 0.2, ms  # 40 scans of a few microseconds each
+    rc, st = eng.last_stats()
+    assert rc == 0 and st["n_in_map"] > 0
