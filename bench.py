@@ -339,11 +339,9 @@ def main():
         batch, pts = res.batch(k, args.steps)
         barrier()
         t0 = time.perf_counter()
-        res.eng.timer_start()  # HIP event on the engine's stream (fdm_engine_timer_*)
-        rc = res.eng.integrate_device_batch(batch)
-        res.eng.timer_stop()   # launches the last scan's held-back update — it belongs to the timed region — and marks
-        res.eng.sync()
-        torch.cuda.synchronize()
+        # K scans + the last scan's held-back update between two HIP events on the engine's stream, ONE call
+        rc = res.eng.integrate_device_batch_timed(batch)
+        torch.cuda.synchronize()  # (device-wide: covers the engine's stream)
         dt = time.perf_counter() - t0
         if rc != 0:
             raise RuntimeError(f"integrate_device_batch failed: {rc}")
@@ -433,10 +431,8 @@ def main():
                 big.eng.sync()
                 bb, bpts = big.batch(n_warm, n_big)
                 t0 = time.perf_counter()
-                big.eng.timer_start()
-                rcb = big.eng.integrate_device_batch(bb)
-                big.eng.timer_stop()
-                big.eng.sync()
+                rcb = big.eng.integrate_device_batch_timed(bb)
+                torch.cuda.synchronize()
                 dtb = time.perf_counter() - t0
                 if rcb != 0:
                     raise RuntimeError(f"integrate_device_batch (large leg) failed: {rcb}")

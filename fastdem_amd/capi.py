@@ -129,6 +129,7 @@ PROTOTYPES = {
                                        C.POINTER(FdmScanStats)]),
     "fdm_engine_integrate_device": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, _D, _D]),
     "fdm_engine_integrate_device_batch": (C.c_int, [_P, C.c_uint32, _P]),
+    "fdm_engine_integrate_device_batch_timed": (C.c_int, [_P, C.c_uint32, _P]),
     "fdm_engine_integrate_async": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_double),
                                              C.POINTER(C.c_double)]),
     "fdm_engine_update": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, C.c_double,

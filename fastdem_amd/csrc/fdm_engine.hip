@@ -1468,11 +1468,17 @@ int fdm_engine_integrate_device_batch(fdm_engine* e, uint32_t count, const fdm_d
   if (!e || (count && !scans)) return fail(FDM_ERR_INVALID, "null argument");
   for (uint32_t k = 0; k < count; ++k) {
     const fdm_device_scan& s = scans[k];
-    if (int rc = fdm_engine_integrate_device(e, s.n, s.x, s.y, s.z, s.intensity, s.rgb, s.sigma_z2,
-                                             s.T_base_sensor, s.T_world_base))
-      return rc;
+    const int rc = fdm_engine_integrate_device(e, s.n, s.x, s.y, s.z, s.intensity, s.rgb, s.sigma_z2,
+                                               s.T_base_sensor, s.T_world_base);
+    if (rc < 0) return rc;  // (an empty cloud is skipped like the reference does, the batch goes on)
   }
   return FDM_OK;
+}
+
+int fdm_engine_integrate_device_batch_timed(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) {
+  if (int rc = fdm_engine_timer_start(e)) return rc;
+  if (int rc = fdm_engine_integrate_device_batch(e, count, scans)) return rc;
+  return fdm_engine_timer_stop(e);
 }
 
 int fdm_engine_integrate(fdm_engine* e, uint64_t n, const float* x, const float* y, const float* z,

@@ -201,6 +201,10 @@ class Engine:
         across the language boundary."""
         return self._lib.fdm_engine_integrate_device_batch(self._h, len(scans) if count is None else count, scans)
 
+    def integrate_device_batch_timed(self, scans, count=None):
+        """The same between timer_start() and timer_stop(): timer_ms() afterwards is the batch's device time."""
+        return self._lib.fdm_engine_integrate_device_batch_timed(self._h, len(scans) if count is None else count, scans)
+
     def update(self, x, y, z, robot_xy=(0.0, 0.0), z_var=None, intensity=None, rgb=None):
         x, y, z = _f32(x), _f32(y), _f32(z)
         v, a, c = _f32(z_var), _f32(intensity), _u32(rgb)

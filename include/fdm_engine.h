@@ -153,6 +153,10 @@ typedef struct fdm_device_scan {
   double T_world_base[16];
 } fdm_device_scan;
 int fdm_engine_integrate_device_batch(fdm_engine* e, uint32_t count, const fdm_device_scan* scans);
+/* Returns FDM_OK or the first error (< 0); an empty cloud in the batch is skipped and the batch goes on.
+ * _timed: the same between fdm_engine_timer_start and fdm_engine_timer_stop (below), i.e. the held-back update of the
+ * last scan is launched and fdm_engine_timer_ms returns the device-side duration of the whole batch. */
+int fdm_engine_integrate_device_batch_timed(fdm_engine* e, uint32_t count, const fdm_device_scan* scans);
 
 /* Same, HOST arrays, enqueue-only; nothing waits.  For a stream of scans from host memory (bag replay,
  * a ROS callback).
