@@ -853,8 +853,10 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     if (drgb) { e->S.wt_rgb = reinterpret_cast<uint32_t*>(base + cap * 4); e->S.wt_src_rgb = drgb; }
   }
 
-  // k_bin4 trades latency for fewer memory-side atomics: worth it from ~64 K points up
-  const bool want4 = e->bin_variant == 4 || (e->bin_variant == 0 && n >= 65536);
+  // k_bin4 (1024-point blocks, 16 B loads) needs enough blocks to hide a block's latency chain: since k_bin folds
+  // its runs through the same per-block LDS table, it wins up to ~400 K points (4 x the blocks; RGB-D 272 K: 13.0
+  // vs 15.9 us, 128-beam 262 K: 33.8 vs 39.8; 524 K: 51.1 vs 39.6 the other way)
+  const bool want4 = e->bin_variant == 4 || (e->bin_variant == 0 && n >= 393216);
   const bool use_bin4 = !tiled && want4 && aligned;
   // 4-points-per-thread kernels: 256-thread blocks (1024 points).  (2048-point blocks merged ~20 % more cells on
   // chip when every merged cell still cost memory-side atomics; with the record pools four resident blocks per

@@ -160,7 +160,7 @@ def test_chain_mixes_small_and_large_scans(gpu, R):
     """k_bin (fusable) and k_bin4 (not) alternate: the held-back update leaves alone before a large scan."""
     small = gpu.synth.vlp16(n_scans=3)
     eng, ref = pair(gpu, R, 60.0, 60.0, 0.1, small.apply_to)
-    big = gpu.synth.lidar128(n_scans=2, n_az=1024)   # 131 K points -> k_bin4
+    big = gpu.synth.lidar128(n_scans=2, n_az=4096)   # 524 K points -> k_bin4 (the engine's choice from ~400 K up)
     keep = []
     for k in range(6):
         wl, idx = (small, k // 2) if k % 2 == 0 else (big, k // 2 % 2)
@@ -201,12 +201,13 @@ def test_destroy_with_a_held_back_update(gpu, R):
 
 
 @pytest.mark.parametrize("lean", [0, 1])
-@pytest.mark.parametrize("n_az,scans", [(2048, 6), (16384, 3)])
-def test_chain_of_large_scans(gpu, R, n_az, scans, lean):
-    """k_bin4 launches (256-thread blocks below 1 M points, 512-thread blocks above) carrying the
-    previous scan's update, with an 8-cell rolling shift per scan."""
+@pytest.mark.parametrize("n_az,scans,variant", [(2048, 6, 0), (2048, 6, 4), (16384, 3, 0)])
+def test_chain_of_large_scans(gpu, R, n_az, scans, lean, variant):
+    """Bin launches of large scans (k_bin by the engine's choice at 262 K points, k_bin4 forced; the per-tile
+    pipeline at 2 M) carrying the previous scan's update, with an 8-cell rolling shift per scan."""
     wl = gpu.synth.lidar128(n_scans=scans, n_az=n_az)
     eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
+    eng.set_option("bin_variant", variant)
     if lean:
         eng.enable_cell_ids(False)
     keep = []
@@ -248,11 +249,14 @@ def test_long_chain_of_large_scans_through_the_batch_entry(gpu, R):
     assert same_geometry(eng.geometry(), ref.geometry())
 
 
+@pytest.mark.parametrize("variant", [0, 4])
 @pytest.mark.parametrize("lean", [0, 1])
-def test_chain_rgbd_p2_colour_large(gpu, R, lean):
-    """configs[2] through the chain: P2 cell records (128 B), colour channel, k_bin4<false,true,256>."""
+def test_chain_rgbd_p2_colour_large(gpu, R, lean, variant):
+    """configs[2] through the chain: P2 cell records (128 B), colour channel; k_bin (the engine's choice at
+    272 K points) and k_bin4<false,true,256> (forced)."""
     wl = gpu.synth.rgbd(n_scans=5)
     eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
+    eng.set_option("bin_variant", variant)
     if lean:
         eng.enable_cell_ids(False)
     keep = []
@@ -298,11 +302,13 @@ def test_host_streaming_pageable_arrays_are_staged(gpu, R):
     assert_layers_equal(eng, ref)
 
 
-def test_host_streaming_rgbd_in_place(gpu, R):
-    """configs[2] from pinned memory: k_bin4 reads x/y/z in place, the colour channel (which only the
-    update kernel consumes) is copied through by the bin kernel as well."""
+@pytest.mark.parametrize("variant", [0, 4])
+def test_host_streaming_rgbd_in_place(gpu, R, variant):
+    """configs[2] from pinned memory: the bin kernel (k_bin by choice, k_bin4 forced) reads x/y/z in place, the
+    colour channel (which only the update kernel consumes) is copied through by the bin kernel as well."""
     wl = gpu.synth.rgbd(n_scans=4)
     eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
+    eng.set_option("bin_variant", variant)
     pinned = []
     for k in range(4):
         s = wl.scan(k)
