@@ -169,7 +169,7 @@ def measure_kernels(res, k0, steps, tag=None, overlap=1):
         dom = "k_update_bin"
     eng.enable_profile(False)
     eng.set_option("overlap", overlap)
-    tiled = eng.last_pipeline() == 1  # maps of >= 512 tiles: k_tbin / k_tupdate
+    tiled = eng.last_pipeline() == 1  # maps of >= 240 tiles: k_tbin / k_tupdate
     real = {"k_bin": "k_tbin", "k_update": "k_tupdate", "k_update_bin": "k_tupdate_tbin"} if tiled else {}
     out["kernel_names"] = {k: real.get(k, k) for k in ("k_bin", "k_update", "k_update_bin") if k in out}
     names = {"k_update_bin": "k_update_bin (one launch: update of scan t + bin of scan t+1)",

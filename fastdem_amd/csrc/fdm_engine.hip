@@ -820,8 +820,11 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   const bool aligned = al16(dx) && al16(dy) && al16(dz) && al16(dint);
   // large scans: per-tile record pools (fdm_tiled.hpp); needs the cell-record layout
   // ... and a map with enough 32x32 tiles to keep the chip busy with one block per tile (configs[2], 49 tiles:
-  // 31 us against 13.8 us through the per-cell scratch; configs[3], 1444 tiles: 40.7 against 51.3 us)
-  const bool enough_tiles = e->tiled_forced || e->ncell / kTileCells >= 512;
+  // 31 us against 13.8 us through the per-cell scratch; configs[3], 1444 tiles: 40.7 against 51.3 us).  Measured
+  // crossover (128-beam scans of 32 K / 262 K points): 100 tiles 11.9 vs 7.4 / 15.3 vs 13.2 us (scratch wins),
+  // 169 tiles 11.8 vs 7.7 / 15.0 vs 19.3, 256 tiles 12.6 vs 15.5 / 15.3 vs 24.4, 625 tiles 13.7 vs 14.4 / 16.6 vs 25.5
+  const size_t kt = e->ncell / kTileCells;
+  const bool enough_tiles = e->tiled_forced || kt >= 240 || (kt >= 160 && n >= 100000);
   const bool tiled = e->tiled && e->rec_kind >= 0 && n >= e->tiled_min && aligned && n < 0x7FFF0000ull &&
                      e->bin_variant != 1 && enough_tiles;
   if (e->last_kind >= 0 && e->last_kind != int(tiled)) e->obst_dense_pending = true;  // the pipelines keep

@@ -189,7 +189,7 @@ int fdm_engine_flush(fdm_engine* e);
  * their own HIP events or order their own kernels after it. */
 void* fdm_engine_stream(fdm_engine* e);
 /* Which pipeline the last scan took: 0 = per-cell scratch (k_bin / k_update), 1 = per-tile record pools
- * (k_tbin / k_tupdate: maps of >= 512 tiles of 32 x 32 cells, scans of >= 2 K points), -1 = no scan yet.  Diagnostic. */
+ * (k_tbin / k_tupdate: maps of >= 240 tiles of 32 x 32 cells, scans of >= 2 K points), -1 = no scan yet.  Diagnostic. */
 int fdm_engine_last_pipeline(fdm_engine* e);
 /* Device-side stopwatch on the engine's stream (two engine-owned HIP events): _start marks "everything enqueued so
  * far" (a held-back update is launched first), _stop launches the last scan's held-back update and marks its end,

@@ -160,6 +160,7 @@ def test_chain_mixes_small_and_large_scans(gpu, R):
     """k_bin (fusable) and k_bin4 (not) alternate: the held-back update leaves alone before a large scan."""
     small = gpu.synth.vlp16(n_scans=3)
     eng, ref = pair(gpu, R, 60.0, 60.0, 0.1, small.apply_to)
+    eng.set_option("tiled", 0)  # (a 600 x 600 map would go through the per-tile pipeline by itself)
     big = gpu.synth.lidar128(n_scans=2, n_az=4096)   # 524 K points -> k_bin4 (the engine's choice from ~400 K up)
     keep = []
     for k in range(6):
