@@ -189,7 +189,8 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float
                          e->vkeys[1], e->vidx[1], e->vsel);
   }
   // large scans: queue bucketed by (wedge, length class) before the walk (see k_ray_compact)
-  const bool sort_queue = Q.n >= (1u << 20) && !(e->dbg_ray & 2048);
+  const bool large = Q.n >= unsigned(e->ray_large_min);  // one lane per ray, queue bucketed by (wedge, length)
+  const bool sort_queue = large && !(e->dbg_ray & 2048);
   uint32_t* ray_key = sort_queue ? reinterpret_cast<uint32_t*>(e->vkeys[0]) : nullptr;       // vkeys hold 2 x vcap uint32
   uint32_t* ray_rank = sort_queue ? reinterpret_cast<uint32_t*>(e->vkeys[0]) + e->vcap : nullptr;
   uint32_t* bin_cnt = sort_queue ? e->ray_bins : nullptr;
@@ -229,9 +230,9 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float
   };
   // small scans are a few hundred wavefronts of dependent round trips: 16 / 8 lanes share a ray
   // (C2: k_ray 60 -> 25 (8) -> 16 us (16)); the point count bounds the ray count from above
-  if (Q.n < (1u << 16)) {
+  if (Q.n < (1u << 16) && !large) {
     tiled ? launch_ray(k_ray<true, 16>, 16u) : launch_ray(k_ray<false, 16>, 16u);
-  } else if (Q.n < (1u << 20)) {
+  } else if (!large) {
     tiled ? launch_ray(k_ray<true, 8>, 8u) : launch_ray(k_ray<false, 8>, 8u);
   } else {
     tiled ? launch_ray(k_ray<true, 1>, 1u) : launch_ray(k_ray<false, 1>, 1u);
