@@ -133,7 +133,16 @@ int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* 
   F.min_valid = cfg->min_valid_neighbors;
   F.n_entries = int(reg.size());
   const unsigned fblocks = unsigned((e->ncell + kFusionThreads - 1) / kFusionThreads);
-  if (reg.size() <= 32 && !(e->dbg_ray & 1024)) {  // samples sorted in registers (the default radius: 29 cells)
+  int halo = 0;
+  for (const RegionEntry& r : reg) halo = std::max(halo, std::max(std::abs(r.dr), std::abs(r.dc)));
+  if (reg.size() <= 32 && halo <= kFusHaloMax && !(e->dbg_ray & 1024) && !(e->dbg_post & 2)) {
+    // samples sorted in registers (the default radius: 29 cells), neighbourhood staged in LDS
+    const unsigned tblocks = unsigned((e->G.s_rows + kFusTileR - 1) / kFusTileR) *
+                             unsigned((e->G.s_cols + kFusTileC - 1) / kFusTileC);
+    hipLaunchKernelGGL(k_fusion_net32_tiled, dim3(tblocks), dim3(kFusionThreads), 0, e->stream, e->G, e->d_state,
+                       int(e->scan_no & 3), e->d_region, F, halo, e->d_tmp, e->d_tmp2, lptr(e, *up), lstride(e, *up),
+                       lptr(e, *lo), lstride(e, *lo));
+  } else if (reg.size() <= 32 && !(e->dbg_ray & 1024)) {  // the same from L2
     hipLaunchKernelGGL(k_fusion_net32, dim3(fblocks), dim3(kFusionThreads), 0, e->stream, e->G, e->d_state,
                        int(e->scan_no & 3), e->d_region, F, e->d_tmp, e->d_tmp2, lptr(e, *up), lstride(e, *up),
                        lptr(e, *lo), lstride(e, *lo), unsigned(e->ncell));

@@ -236,7 +236,9 @@ __global__ __launch_bounds__(kFusionThreads) void k_fusion(const GeomConst G, co
 // One list (lower or upper bounds) of one cell: gather, sort, weighted quantile.  The two lists are
 // done one after the other so that only 32 samples are live (2 x 32 x 64 bit would hold the kernel
 // at one wave per SIMD); the second pass re-reads the neighbours from L2 and the weights from LDS.
-template <bool UPPER>
+// TILED: up_in / lo_in are the block's LDS tiles (cells outside the stored window hold NaN), `lr` is the thread's
+// cell inside them and `lc` the tile pitch — a neighbour is one scalar multiply-add and two LDS reads.
+template <bool UPPER, bool TILED = false>
 __device__ __forceinline__ float fusion_list32(const PostGeom& p, int lr, int lc, const RegionEntry* __restrict__ reg,
                                                const FusionParams& F, const float* __restrict__ up_in,
                                                const float* __restrict__ lo_in, float (*s_w)[kFusionThreads],
@@ -250,8 +252,8 @@ __device__ __forceinline__ float fusion_list32(const PostGeom& p, int lr, int lc
 #define FDM_GATHER(e)                                                                         \
   if (e < F.n_entries) {                                                                       \
     const RegionEntry re = reg[e];                                                             \
-    if (post_inside(p, lr + re.dr, lc + re.dc)) {                                              \
-      const size_t ni = post_index(p, lr + re.dr, lc + re.dc);                                 \
+    if (TILED || post_inside(p, lr + re.dr, lc + re.dc)) {                                     \
+      const size_t ni = TILED ? size_t(lr + re.dc * lc + re.dr) : post_index(p, lr + re.dr, lc + re.dc); \
       const float nu_v = up_in[ni], nl_v = lo_in[ni];                                          \
       if (isfinite(nu_v) && isfinite(nl_v)) {                                                  \
         const float weight = re.w * (1.0f / ((nu_v - nl_v) + 1e-4f));                          \
@@ -310,6 +312,49 @@ __global__ __launch_bounds__(kFusionThreads) void k_fusion_net32(const GeomConst
   const float lower = fusion_list32<false>(p, lr, lc, reg, F, up_in, lo_in, s_w, valid);
   if (valid < F.min_valid) return;
   const float upper = fusion_list32<true>(p, lr, lc, reg, F, up_in, lo_in, s_w, valid);
+  if (isfinite(lower) && isfinite(upper)) {
+    up_out[ci * up_stride] = upper;
+    lo_out[ci * lo_stride] = lower;
+  }
+}
+// The same with the neighbourhood staged in LDS: one block per 32 x 4 cells, both layers' tiles with a ring of
+// `halo` cells (NaN outside the stored window, so "outside" and "no data" are one test).  The two passes (lower
+// list, then upper) re-read LDS instead of L2, and a neighbour costs no 64-bit index arithmetic.
+constexpr int kFusTileR = 32, kFusTileC = kFusionThreads / kFusTileR, kFusHaloMax = 8;
+__global__ __launch_bounds__(kFusionThreads) void k_fusion_net32_tiled(const GeomConst G, const DevState* __restrict__ st,
+                                                                       int slot, const RegionEntry* __restrict__ reg,
+                                                                       const FusionParams F, int halo,
+                                                                       const float* __restrict__ up_in,
+                                                                       const float* __restrict__ lo_in,
+                                                                       float* __restrict__ up_out, int up_stride,
+                                                                       float* __restrict__ lo_out, int lo_stride) {
+  __shared__ float s_w[32][kFusionThreads];
+  __shared__ float s_up[(kFusTileR + 2 * kFusHaloMax) * (kFusTileC + 2 * kFusHaloMax)];
+  __shared__ float s_lo[(kFusTileR + 2 * kFusHaloMax) * (kFusTileC + 2 * kFusHaloMax)];
+  const PostGeom p = post_geom(st, slot, G);
+  const int tiles_r = (p.rows + kFusTileR - 1) / kFusTileR;
+  const int tr = int(blockIdx.x) % tiles_r, tc = int(blockIdx.x) / tiles_r;
+  const int pitch = kFusTileR + 2 * halo, width = kFusTileC + 2 * halo;
+  const int r0 = tr * kFusTileR - halo, c0 = tc * kFusTileC - halo;
+  const float nanv = __uint_as_float(0x7FC00000u);
+  for (int k = int(threadIdx.x); k < pitch * width; k += kFusionThreads) {
+    const int cc = k / pitch, rr = k - cc * pitch;
+    const bool in = post_inside(p, r0 + rr, c0 + cc);
+    const size_t gi = in ? post_index(p, r0 + rr, c0 + cc) : 0;
+    s_up[k] = in ? up_in[gi] : nanv;
+    s_lo[k] = in ? lo_in[gi] : nanv;
+  }
+  __syncthreads();
+  const int lrl = int(threadIdx.x) & (kFusTileR - 1), lcl = int(threadIdx.x) / kFusTileR;
+  const int lr = tr * kFusTileR + lrl, lc = tc * kFusTileC + lcl;
+  if (!post_inside(p, lr, lc)) return;
+  const int base = (lcl + halo) * pitch + lrl + halo;
+  if (!isfinite(s_up[base]) || !isfinite(s_lo[base])) return;
+  const size_t ci = post_index(p, lr, lc);
+  int valid = 0;
+  const float lower = fusion_list32<false, true>(p, base, pitch, reg, F, s_up, s_lo, s_w, valid);
+  if (valid < F.min_valid) return;
+  const float upper = fusion_list32<true, true>(p, base, pitch, reg, F, s_up, s_lo, s_w, valid);
   if (isfinite(lower) && isfinite(upper)) {
     up_out[ci * up_stride] = upper;
     lo_out[ci * lo_stride] = lower;
