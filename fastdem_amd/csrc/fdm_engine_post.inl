@@ -36,6 +36,9 @@ void region_disc(const fdm_engine* e, float radius, std::vector<RegionEntry>& re
     }
 }
 unsigned cell_blocks(const fdm_engine* e) { return unsigned((e->ncell + 255) / 256); }
+unsigned tile3_blocks(const fdm_engine* e) {  // 32 x 8-cell tiles of the 3x3 stencils (fdm_post.hpp)
+  return unsigned((e->G.s_rows + kS3R - 1) / kS3R) * unsigned((e->G.s_cols + kS3C - 1) / kS3C);
+}
 int ensure_tmp2(fdm_engine* e) {
   if (!e->d_tmp2) HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_tmp2), e->ncell * sizeof(float)));
   return FDM_OK;
@@ -71,9 +74,13 @@ int fdm_engine_apply_inpainting(fdm_engine* e, int max_iterations, int min_valid
   }
   bool in_layer = start_in_layer;
   for (int it = 0; it < iters; ++it) {
-    hipLaunchKernelGGL(k_inpaint_pass, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state, slot,
-                       in_layer ? A : B, in_layer ? As : 1, in_layer ? B : A, in_layer ? 1 : As, min_valid,
-                       unsigned(e->ncell));
+    if (e->dbg_post & 4)
+      hipLaunchKernelGGL(k_inpaint_pass, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state, slot,
+                         in_layer ? A : B, in_layer ? As : 1, in_layer ? B : A, in_layer ? 1 : As, min_valid,
+                         unsigned(e->ncell));
+    else
+      hipLaunchKernelGGL(k_inpaint_pass_tiled, dim3(tile3_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state, slot,
+                         in_layer ? A : B, in_layer ? As : 1, in_layer ? B : A, in_layer ? 1 : As, min_valid);
     in_layer = !in_layer;
   }
   HIPCK(hipGetLastError());
@@ -93,7 +100,10 @@ int fdm_engine_apply_spatial_smoothing(fdm_engine* e, const char* layer, int ker
   if (!l || l->pending) return FDM_OK;  // spatial_smoothing.hpp:42
   if ((rc = ensure_tmp(e))) return rc;
   if ((rc = copy_strided(e, e->d_tmp, 1, lptr(e, *l), lstride(e, *l)))) return rc;  // the double buffer
-  if (kernel_size == 3)
+  if (kernel_size == 3 && !(e->dbg_post & 4))
+    hipLaunchKernelGGL(k_median3_tiled, dim3(tile3_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state,
+                       int(e->scan_no & 3), e->d_tmp, lptr(e, *l), lstride(e, *l), min_valid);
+  else if (kernel_size == 3)
     hipLaunchKernelGGL(k_median3, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state,
                        int(e->scan_no & 3), e->d_tmp, lptr(e, *l), lstride(e, *l), min_valid, unsigned(e->ncell));
   else

@@ -139,6 +139,86 @@ __global__ __launch_bounds__(256) void k_median3(const GeomConst G, const DevSta
   out[ci * out_stride] = m == 0 ? w0 : (m == 1 ? w1 : (m == 2 ? w2 : (m == 3 ? w3 : w4)));
 }
 
+// ---- the two 3x3 stencils with the neighbourhood staged in LDS: one block per 32 x 8 cells, a ring of one cell,
+// cells outside the stored window as NaN ("outside" and "no data" are one test), neighbours visited in the
+// reference's order ----
+constexpr int kS3R = 32, kS3C = 8, kS3Pitch = kS3R + 2, kS3Width = kS3C + 2;
+__device__ __forceinline__ void stage_tile3(const PostGeom& p, const float* __restrict__ in, int in_stride, int tr,
+                                            int tc, float* __restrict__ s_t) {
+  const int r0 = tr * kS3R - 1, c0 = tc * kS3C - 1;
+  for (int k = int(threadIdx.x); k < kS3Pitch * kS3Width; k += 256) {
+    const int cc = k / kS3Pitch, rr = k - cc * kS3Pitch;
+    s_t[k] = post_inside(p, r0 + rr, c0 + cc) ? in[post_index(p, r0 + rr, c0 + cc) * size_t(in_stride)]
+                                              : __uint_as_float(0x7FC00000u);
+  }
+  __syncthreads();
+}
+__global__ __launch_bounds__(256) void k_inpaint_pass_tiled(const GeomConst G, const DevState* __restrict__ st, int slot,
+                                                            const float* __restrict__ in, int in_stride,
+                                                            float* __restrict__ out, int out_stride, int min_valid) {
+  __shared__ float s_t[kS3Pitch * kS3Width];
+  const PostGeom p = post_geom(st, slot, G);
+  const int tiles_r = (p.rows + kS3R - 1) / kS3R;
+  const int tr = int(blockIdx.x) % tiles_r, tc = int(blockIdx.x) / tiles_r;
+  stage_tile3(p, in, in_stride, tr, tc, s_t);
+  const int lrl = int(threadIdx.x) & (kS3R - 1), lcl = int(threadIdx.x) >> 5;
+  const int lr = tr * kS3R + lrl, lc = tc * kS3C + lcl;
+  if (!post_inside(p, lr, lc)) return;
+  const int base = (lcl + 1) * kS3Pitch + lrl + 1;
+  float v = s_t[base];
+  if (isnan(v)) {
+    float sum = 0.0f;
+    int count = 0;
+#pragma unroll
+    for (int dr = -1; dr <= 1; ++dr)
+#pragma unroll
+      for (int dc = -1; dc <= 1; ++dc) {
+        if (dr == 0 && dc == 0) continue;
+        const float n = s_t[base + dc * kS3Pitch + dr];
+        if (isfinite(n)) {
+          sum += n;
+          ++count;
+        }
+      }
+    if (count >= min_valid) v = sum / float(count);
+  }
+  out[post_index(p, lr, lc) * size_t(out_stride)] = v;
+}
+__global__ __launch_bounds__(256) void k_median3_tiled(const GeomConst G, const DevState* __restrict__ st, int slot,
+                                                       const float* __restrict__ in, float* __restrict__ out,
+                                                       int out_stride, int min_valid) {
+  __shared__ float s_t[kS3Pitch * kS3Width];
+  const PostGeom p = post_geom(st, slot, G);
+  const int tiles_r = (p.rows + kS3R - 1) / kS3R;
+  const int tr = int(blockIdx.x) % tiles_r, tc = int(blockIdx.x) / tiles_r;
+  stage_tile3(p, in, 1, tr, tc, s_t);
+  const int lrl = int(threadIdx.x) & (kS3R - 1), lcl = int(threadIdx.x) >> 5;
+  const int lr = tr * kS3R + lrl, lc = tc * kS3C + lcl;
+  if (!post_inside(p, lr, lc)) return;
+  const int base = (lcl + 1) * kS3Pitch + lrl + 1;
+  if (!isfinite(s_t[base])) return;
+  constexpr float kInf = __builtin_huge_valf();
+  int n = 0;
+#define FDM_W(k, dr, dc)                                   \
+  float w##k = kInf;                                       \
+  {                                                        \
+    const float v = s_t[base + (dc) * kS3Pitch + (dr)];    \
+    if (isfinite(v)) { w##k = v; ++n; }                    \
+  }
+  FDM_W(0, -1, -1) FDM_W(1, -1, 0) FDM_W(2, -1, 1) FDM_W(3, 0, -1) FDM_W(4, 0, 0) FDM_W(5, 0, 1)
+  FDM_W(6, 1, -1) FDM_W(7, 1, 0) FDM_W(8, 1, 1)
+#undef FDM_W
+  if (n < min_valid) return;
+#define FDM_CE(i, j) { const float lo_ = fminf(w##i, w##j); w##j = fmaxf(w##i, w##j); w##i = lo_; }
+  FDM_CE(0, 3) FDM_CE(1, 7) FDM_CE(2, 5) FDM_CE(4, 8) FDM_CE(0, 7) FDM_CE(2, 4) FDM_CE(3, 8) FDM_CE(5, 6)
+  FDM_CE(0, 2) FDM_CE(1, 3) FDM_CE(4, 5) FDM_CE(7, 8) FDM_CE(1, 4) FDM_CE(3, 6) FDM_CE(5, 7) FDM_CE(0, 1)
+  FDM_CE(2, 4) FDM_CE(3, 5) FDM_CE(6, 8) FDM_CE(2, 3) FDM_CE(4, 5) FDM_CE(6, 7) FDM_CE(1, 2) FDM_CE(3, 4)
+  FDM_CE(5, 6)
+#undef FDM_CE
+  const int m = n / 2;  // nth_element(size/2): 0..4
+  out[post_index(p, lr, lc) * size_t(out_stride)] = m == 0 ? w0 : (m == 1 ? w1 : (m == 2 ? w2 : (m == 3 ? w3 : w4)));
+}
+
 // ---- uncertainty fusion (uncertainty_fusion.cpp:135-181); upper/lower are private copies ----
 struct FusionParams {
   float inv_2s2, q_lower, q_upper;
