@@ -367,7 +367,8 @@ def main():
             "config": {"workload": wl.name, "points_per_scan": wl.n_points,
                        "map_cells": res.eng.rows * res.eng.cols, "point_order": args.order,
                        "parallelism": "replicas only (LOCAL map does not shard)" if world > 1 else "1 gpu",
-                       "inputs": "SoA float32 resident in HBM", "wave_merge": args.wave_merge},
+                       "inputs": "SoA float32 resident in HBM", "wave_merge": args.wave_merge,
+                       "distinct_scans": len(wl.scans)},
         }
         if rank == 0:
             kern, roof = measure_kernels(res, k, args.profile_steps, args.workload, args.overlap)
