@@ -459,272 +459,7 @@ P2Params p2_params(const fdm_config& c) {  // P2Quantile ctor (quantile_estimati
   return p2;
 }
 
-// f(policy tag, layer set) for the engine's estimator and layer layout
-template <typename F>
-int with_policy(fdm_engine* e, F&& f) {
-  const bool p2mode = e->cfg.estimation_type == 1;
-  if (e->rec_kind >= 0) {  // cell records
-    if (p2mode) {
-      P2RecLayers Lr{};
-      Lr.rec = e->d_rec; Lr.obstacle = L(e, "obstacle"); Lr.intensity = L(e, "intensity"); Lr.color = L(e, "color");
-      Lr.p = p2_params(e->cfg);
-      return f(P2RecPolicy{}, Lr);
-    }
-    KalmanRecLayers Lr{};
-    Lr.rec = e->d_rec; Lr.obstacle = L(e, "obstacle"); Lr.intensity = L(e, "intensity"); Lr.color = L(e, "color");
-    Lr.min_var = e->cfg.kalman_min_variance; Lr.max_var = e->cfg.kalman_max_variance;
-    Lr.q = e->cfg.kalman_process_noise;
-    return f(KalmanRecPolicy{}, Lr);
-  }
-  if (p2mode) {
-    P2Layers Lp{};
-    Lp.elevation = L(e, "elevation");
-    Lp.elevation_min = L(e, "elevation_min");
-    Lp.elevation_max = L(e, "elevation_max");
-    Lp.variance = L(e, "variance");
-    Lp.n_points = L(e, "n_points");
-    Lp.upper = L(e, "upper_bound");
-    Lp.lower = L(e, "lower_bound");
-    Lp.obstacle = L(e, "obstacle");
-    Lp.intensity = L(e, "intensity");
-    Lp.color = L(e, "color");
-    for (int k = 0; k < 5; ++k) {
-      Lp.q[k] = L(e, kP2Q[k]);
-      Lp.n[k] = L(e, kP2N[k]);
-    }
-    Lp.p = p2_params(e->cfg);
-    return f(P2Policy{}, Lp);
-  }
-  KalmanLayers Lk{};
-  Lk.elevation = L(e, "elevation");
-  Lk.elevation_min = L(e, "elevation_min");
-  Lk.elevation_max = L(e, "elevation_max");
-  Lk.variance = L(e, "variance");
-  Lk.n_points = L(e, "n_points");
-  Lk.kalman_p = L(e, "_kalman_p");
-  Lk.sample_mean = L(e, "_sample_mean");
-  Lk.sample_m2 = L(e, "_sample_m2");
-  Lk.upper = L(e, "upper_bound");
-  Lk.lower = L(e, "lower_bound");
-  Lk.obstacle = L(e, "obstacle");
-  Lk.intensity = L(e, "intensity");
-  Lk.color = L(e, "color");
-  Lk.min_var = e->cfg.kalman_min_variance;
-  Lk.max_var = e->cfg.kalman_max_variance;
-  Lk.q = e->cfg.kalman_process_noise;
-  return f(KalmanPolicy{}, Lk);
-}
-template <typename POLICY>
-constexpr bool is_rec_policy = std::is_same<POLICY, KalmanRecPolicy>::value || std::is_same<POLICY, P2RecPolicy>::value;
-
-// kernels with more than 64 KB of dynamic LDS need the attribute once
-template <typename K>
-int allow_lds(K kern, unsigned bytes) {
-  static std::mutex mu;
-  static std::unordered_map<const void*, unsigned> seen;
-  if (bytes <= 65536u) return FDM_OK;
-  const void* f = reinterpret_cast<const void*>(kern);
-  std::lock_guard<std::mutex> lock(mu);
-  auto it = seen.find(f);
-  if (it != seen.end() && it->second >= bytes) return FDM_OK;
-  HIPCK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
-  seen[f] = bytes;
-  return FDM_OK;
-}
-
-// tiles per 256-thread group of k_tupdate: 1 while the tile count keeps the chip busy by itself, 32 on
-// very large maps (nearly every tile idle: one wavefront looks at 32 chunk counts in one round trip)
-unsigned tile_span(const fdm_engine* e) {
-  if (e->dbg_span > 0) return unsigned(e->dbg_span);  // measurement only
-  return e->TG.n_tiles <= 16384u ? 1u : 32u;
-}
-
-// The record pools of the tiled pipeline: `records` per pool, `blocks` chunk slots per tile.
-int ensure_tile_pool(fdm_engine* e, size_t records, unsigned blocks, bool has_int, bool has_col) {
-  if (!e->tile_stamp32) {
-    e->TG.tiles_r = (e->G.s_rows + kTS - 1) / kTS;
-    e->TG.tiles_c = (e->G.s_cols + kTC - 1) / kTC;
-    e->TG.n_tiles = unsigned(e->TG.tiles_r) * unsigned(e->TG.tiles_c);
-    if (e->TG.n_tiles >= (1u << 21)) return fail(FDM_ERR_INVALID, "tiled pipeline: more than 2^21 map tiles");
-    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->tile_stamp32), e->TG.n_tiles * sizeof(uint32_t)));
-    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->upd_part32), e->TG.n_tiles * sizeof(uint32_t)));
-    hipLaunchKernelGGL(k_fill_u32, dim3(64), dim3(256), 0, e->stream, e->tile_stamp32, 0xFFFFFFFEu, size_t(e->TG.n_tiles));
-    hipLaunchKernelGGL(k_fill_u32, dim3(64), dim3(256), 0, e->stream, e->upd_part32, 0u, size_t(e->TG.n_tiles));
-    {
-      const unsigned span = tile_span(e);
-      const size_t groups = (e->TG.n_tiles + span - 1u) / span + 2u;
-      HIPCK(hipMalloc(reinterpret_cast<void**>(&e->tile_rare), groups * 3u * kTileCells * sizeof(uint32_t)));
-      for (auto& q : e->pool) q.rare = e->tile_rare;
-    }
-    HIPCK(hipGetLastError());
-  }
-  const bool grow_rec = records > e->pool_cap;
-  (void)has_int; (void)has_col;
-  const bool grow_desc = blocks + 1u > e->desc_stride;
-  if (!grow_rec && !grow_desc) return FDM_OK;
-  if (int rc_sync = sync_all(e)) return rc_sync;  // (every chunk list is consumed: the row counts are all zero)
-  if (grow_rec) {
-    e->pool_cap = records + records / 4 + 8192;
-    if (e->pool_cap >= 0x7FFFFFF0ull) return fail(FDM_ERR_INVALID, "tiled pipeline: scan too large");
-  }
-  if (grow_desc) e->desc_stride = blocks + blocks / 4 + 16;  // (+1: word 0 of a row is its chunk count)
-  for (auto& q : e->pool) {
-    auto re = [&](auto*& ptr, size_t bytes) -> int {
-      if (ptr) HIPCK(hipFree(ptr));
-      ptr = nullptr;
-      HIPCK(hipMalloc(reinterpret_cast<void**>(&ptr), bytes));
-      return FDM_OK;
-    };
-    int rc;
-    if (grow_rec && (rc = re(q.rec, e->pool_cap * sizeof(TileRec)))) return rc;
-    if (grow_desc) {
-      if ((rc = re(q.desc, size_t(e->TG.n_tiles) * e->desc_stride * 8))) return rc;
-      HIPCK(hipMemsetAsync(q.desc, 0, size_t(e->TG.n_tiles) * e->desc_stride * 8, e->stream));
-    }
-    q.stride = e->desc_stride;
-  }
-  return FDM_OK;
-}
-
-int launch_tbin(fdm_engine* e, const ScanParams& P, const ScanInputs& in, const TilePool& Q, int32_t* ids,
-                unsigned bin_blocks, fdm_engine::BinVariant bv) {
-  const unsigned lds = tbin_lds_bytes(bv.has_int, bv.has_col, bv.threads);
-  int rc = FDM_OK;
-  auto go = [&](auto kern) {
-    if ((rc = allow_lds(kern, lds))) return;
-    hipLaunchKernelGGL(kern, dim3(bin_blocks), dim3(bv.threads), lds, e->stream, P, e->G, e->TG, e->d_state, in, e->S,
-                       Q, ids);
-  };
-#define FDM_TBIN(LN)                                               \
-  if (bv.has_int && bv.has_col) go(k_tbin<true, true, 256, LN>);    \
-  else if (bv.has_int) go(k_tbin<true, false, 256, LN>);            \
-  else if (bv.has_col) go(k_tbin<false, true, 256, LN>);            \
-  else go(k_tbin<false, false, 256, LN>);
-  if (bv.lean == 1) { FDM_TBIN(true) } else { FDM_TBIN(false) }
-#undef FDM_TBIN
-  if (rc) return rc;
-  HIPCK(hipGetLastError());
-  return FDM_OK;
-}
-
-// The held-back (or just enqueued) update on its own.
-int launch_update_alone(fdm_engine* e, const fdm_engine::PendingUpdate& u) {
-  return with_policy(e, [&](auto tag, const auto& layers) -> int {
-    using POLICY = decltype(tag);
-    if (u.tiled) {
-      if constexpr (is_rec_policy<POLICY>) {
-        const unsigned span = tile_span(e);
-        const unsigned blocks = (e->TG.n_tiles + span - 1u) / span;
-        const bool hi = u.P.has_intensity != 0, hc = u.P.has_color != 0;
-        const unsigned lds = tile_lds_bytes(hi, hc);
-        auto go = [&](auto kern) {
-          hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, e->stream, u.P, e->G, e->TG, e->d_state, layers,
-                             e->d_layer_ptrs, e->n_layer_ptrs, u.Q, u.A, span);
-        };
-        if (hi && hc) go(k_tupdate<POLICY, true, true>);
-        else if (hi) go(k_tupdate<POLICY, true, false>);
-        else if (hc) go(k_tupdate<POLICY, false, true>);
-        else go(k_tupdate<POLICY, false, false>);
-      } else {
-        return fail(FDM_ERR_INVALID, "internal: tiled update with a per-layer policy");
-      }
-    } else if (u.S.dense) {
-      hipLaunchKernelGGL(k_update<POLICY>, dim3(u.upd_blocks), dim3(256), 0, e->stream, u.P, e->G, e->d_state, layers,
-                         e->d_layer_ptrs, e->n_layer_ptrs, u.S, u.in.x, u.in.y, u.in.z, u.in.intensity, u.in.rgb,
-                         u.in.var, unsigned(e->ncell));
-    } else {  // stamp-gated: kStampTiles tiles per block, idle tiles cost one scalar load
-      hipLaunchKernelGGL(k_update_stamped<POLICY>, dim3((u.upd_blocks + kStampTiles - 1) / kStampTiles), dim3(256), 0,
-                         e->stream, u.P, e->G, e->d_state, layers, e->d_layer_ptrs, e->n_layer_ptrs, u.S, u.in.x,
-                         u.in.y, u.in.z, u.in.intensity, u.in.rgb, u.in.var, unsigned(e->ncell));
-    }
-    HIPCK(hipGetLastError());
-    return FDM_OK;
-  });
-}
-
-// The held-back update of scan t and the bin of scan t+1 in one launch.
-int launch_update_fused(fdm_engine* e, const fdm_engine::PendingUpdate& u, const ScanParams& Pb,
-                        const ScanInputs& Ib, const TilePool& Qb, int32_t* ids_b, unsigned bin_blocks_b,
-                        fdm_engine::BinVariant bv) {
-  const Scratch Sb = e->S;
-  return with_policy(e, [&](auto tag, const auto& layers) -> int {
-    using POLICY = decltype(tag);
-    constexpr bool kRec = is_rec_policy<POLICY>;
-    if (u.tiled) {
-      if constexpr (kRec) {
-        const unsigned span = tile_span(e);
-        const unsigned groups = bv.threads / 256u;
-        const unsigned ub = (e->TG.n_tiles + span * groups - 1u) / (span * groups);
-        const unsigned lds = std::max(groups * tile_lds_bytes(bv.has_int, bv.has_col),
-                                      tbin_lds_bytes(bv.has_int, bv.has_col, bv.threads));
-        int rc = FDM_OK;
-        auto go = [&](auto kern) {
-          if ((rc = allow_lds(kern, lds))) return;
-          TileAux A = u.A;
-          if (ub + bin_blocks_b > e->timeline_cap) A.timeline = nullptr;
-          e->timeline_blocks = A.timeline ? ub + bin_blocks_b : 0u;
-          e->timeline_upd = ub;
-          hipLaunchKernelGGL(kern, dim3(ub + bin_blocks_b), dim3(bv.threads), lds, e->stream, u.P, e->G, e->TG,
-                             e->d_state, layers, e->d_layer_ptrs, e->n_layer_ptrs, u.Q, A, span, ub, Pb, Ib, Sb, Qb,
-                             ids_b);
-        };
-#define FDM_TF(LN)                                                                  \
-        if (bv.has_int && bv.has_col) go(k_tupdate_tbin<POLICY, true, true, 256, LN>);   \
-        else if (bv.has_int) go(k_tupdate_tbin<POLICY, true, false, 256, LN>);           \
-        else if (bv.has_col) go(k_tupdate_tbin<POLICY, false, true, 256, LN>);           \
-        else go(k_tupdate_tbin<POLICY, false, false, 256, LN>);
-        if (bv.lean == 1) { FDM_TF(true) } else { FDM_TF(false) }
-#undef FDM_TF
-        if (rc) return rc;
-      } else {
-        return fail(FDM_ERR_INVALID, "internal: tiled update with a per-layer policy");
-      }
-      HIPCK(hipGetLastError());
-      return FDM_OK;
-    }
-    auto go = [&](auto kern, unsigned threads) {
-      // tiles per update block: threads / 256, times kStampTiles slots on stamp-gated maps
-      const unsigned per = (threads / 256u) * (u.S.dense ? 1u : kStampTiles);
-      const unsigned ub = (u.upd_blocks + per - 1u) / per;
-      hipLaunchKernelGGL(kern, dim3(ub + bin_blocks_b), dim3(threads), 0, e->stream, u.P, e->G, e->d_state, layers,
-                         e->d_layer_ptrs, e->n_layer_ptrs, u.S, u.in, unsigned(e->ncell), ub, Pb, Sb, Ib, ids_b);
-    };
-    if (!bv.bin4) {
-      if (!u.S.dense) {  // stamp-gated maps: one generic variant
-        go(k_update_bin<POLICY, true, true>, 256u);
-      } else if (kRec && bv.lean == 1) {  // channel tests folded at compile time, optional work compiled out
-        if constexpr (kRec) {
-          if (bv.has_int && bv.has_col) go(k_update_bin<POLICY, true, false, 3, 1>, 256u);
-          else if (bv.has_col) go(k_update_bin<POLICY, true, false, 2, 1>, 256u);
-          else if (bv.has_int) go(k_update_bin<POLICY, true, false, 1, 1>, 256u);
-          else go(k_update_bin<POLICY, true, false, 0, 1>, 256u);
-        }
-      } else if (kRec && bv.lean == 2) {  // ... but x / y / z written through to the engine's staging block
-        if constexpr (kRec) {
-          if (bv.has_int && bv.has_col) go(k_update_bin<POLICY, true, false, 3, 2>, 256u);
-          else if (bv.has_col) go(k_update_bin<POLICY, true, false, 2, 2>, 256u);
-          else if (bv.has_int) go(k_update_bin<POLICY, true, false, 1, 2>, 256u);
-          else go(k_update_bin<POLICY, true, false, 0, 2>, 256u);
-        }
-      } else {  // everything else (captures, cell ids, per-layer layout ...): channels read from ScanParams
-        go(k_update_bin<POLICY, true, false>, 256u);
-      }
-    } else if constexpr (kRec) {
-      if (!u.S.dense) return fail(FDM_ERR_INVALID, "internal: k_bin4 fused with a stamp-gated update");
-#define FDM_FUSED4(LN)                                                                       \
-      if (bv.has_int && bv.has_col) go(k_update_bin4<POLICY, true, true, 256, false, LN>, 256u);   \
-      else if (bv.has_int) go(k_update_bin4<POLICY, true, false, 256, false, LN>, 256u);           \
-      else if (bv.has_col) go(k_update_bin4<POLICY, false, true, 256, false, LN>, 256u);           \
-      else go(k_update_bin4<POLICY, false, false, 256, false, LN>, 256u);
-      if (bv.lean == 1) { FDM_FUSED4(1) } else if (bv.lean == 2) { FDM_FUSED4(2) } else { FDM_FUSED4(0) }
-#undef FDM_FUSED4
-    } else {
-      return fail(FDM_ERR_INVALID, "internal: k_bin4 fused with a per-layer policy");
-    }
-    HIPCK(hipGetLastError());
-    return FDM_OK;
-  });
-}
+#include "fdm_engine_launch.inl"  // with_policy, record pools, launch_tbin / launch_update_alone / launch_update_fused
 
 constexpr int kStageSlots = 3;  // rotating staging blocks (see ensure_stage)
 int ensure_stage(fdm_engine* e, size_t n);
