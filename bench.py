@@ -330,9 +330,11 @@ def main():
         for kk in range(args.warmup + args.steps + args.profile_steps + 8):
             res.pose(kk)
         k = 0
-        for _ in range(args.warmup):
-            res.step(k)
-            k += 1
+        if args.warmup > 0:  # the warm-up steps take the timed region's own entry point (its first call is not free)
+            wbatch, _ = res.batch(k, args.warmup)
+            if res.eng.integrate_device_batch_timed(wbatch) != 0:
+                raise RuntimeError("integrate_device_batch (warm-up) failed")
+            k += args.warmup
         # the K timed steps leave as ONE call across the language boundary (fdm_engine_integrate_device_batch:
         # K x fdm_engine_integrate_device in C++): with a Python / ctypes call per 6 us scan the timed region
         # would measure the interpreter, not the engine
