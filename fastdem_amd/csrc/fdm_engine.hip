@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdint>
@@ -83,6 +84,8 @@ struct fdm_engine {
   DevState* h_state = nullptr;  // pinned mirror for read-backs
   StatsOut* h_stats = nullptr;  // pinned + device-mapped: k_collect_stats writes here
   StatsOut* h_stats_dev = nullptr;  // the device's alias of h_stats
+  unsigned long long stats_seq = 0; // sequence number of the last statistics launch (StatsOut::seq)
+  int sync_spin_us = 150;           // read_stats polls the pinned block this long before a stream wait (option)
   StatsAcc* d_stats_acc = nullptr;
   uint64_t scan_no = 0;
   bool have_scan = false;
@@ -874,9 +877,24 @@ int read_stats(fdm_engine* e, fdm_scan_stats* out, int* status) {
     const unsigned blocks = std::min(64u, std::max(1u, (work + 4095u) / 4096u));
     hipLaunchKernelGGL(k_collect_stats, dim3(blocks), dim3(256), 0, e->stream, e->S.bin_part, e->last_bin_blocks,
                        e->last_upd_part, e->last_upd_tiles, e->pack_counts, e->ingest_blocks, e->d_state,
-                       int((e->scan_no - 1) & 3), e->d_stats_acc, e->h_stats_dev);
+                       int((e->scan_no - 1) & 3), e->d_stats_acc, e->h_stats_dev, ++e->stats_seq);
     HIPCK(hipGetLastError());
-    HIPCK(hipStreamSynchronize(e->stream));
+    // The statistics kernel is the last thing on the stream and ends with a system-scope store of its sequence
+    // number into the pinned block: the host polls that word for a while before it falls back to a stream wait
+    // (a thread sleeping in hipStreamSynchronize is woken some 10-20 us after the stream has drained — a third of
+    // what a synchronous integrate() of a VLP-16 scan takes end to end).
+    bool seen = false;
+    if (e->sync_spin_us > 0) {
+      const auto t0 = std::chrono::steady_clock::now();
+      const volatile unsigned long long* const w = &e->h_stats->seq;
+      for (;;) {
+        if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == e->stats_seq) { seen = true; break; }
+        if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >
+            e->sync_spin_us)
+          break;
+      }
+    }
+    if (!seen) HIPCK(hipStreamSynchronize(e->stream));
   }
   const uint64_t np = e->h_stats->n_pass, ni = e->h_stats->n_in, nt = e->h_stats->n_touched;
   if (e->ingest_blocks) {  // PointCloud2 scan: cloud.size() is the number of finite points (from_impl)
@@ -1800,6 +1818,10 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
       HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_timeline), size_t(e->timeline_cap) * 16));
       HIPCK(hipMemset(e->d_timeline, 0, size_t(e->timeline_cap) * 16));
     }
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "sync_spin_us") == 0) {
+    e->sync_spin_us = value < 0 ? 0 : value;
     return FDM_OK;
   }
   if (std::strcmp(key, "dbg_span") == 0) {

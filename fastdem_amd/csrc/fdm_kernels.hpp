@@ -985,12 +985,14 @@ struct StatsAcc {  // device
 struct StatsOut {  // pinned host memory, written by the last block
   unsigned long long n_pass, n_in, n_touched, n_finite;
   int shr, shc;
+  unsigned long long seq;  // written last (system scope): the host polls it instead of sleeping in a stream wait
 };
 __global__ __launch_bounds__(256) void k_collect_stats(const unsigned long long* __restrict__ bin_part,
                                                        unsigned n_bin, const uint32_t* __restrict__ upd_part,
                                                        unsigned n_tiles, const uint32_t* __restrict__ ingest_part,
                                                        unsigned n_ingest, const DevState* __restrict__ st, int slot,
-                                                       StatsAcc* __restrict__ acc, StatsOut* __restrict__ out) {
+                                                       StatsAcc* __restrict__ acc, StatsOut* __restrict__ out,
+                                                       unsigned long long seq) {
   unsigned long long np = 0, ni = 0, nt = 0, nf = 0;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n_ingest; i += gridDim.x * 256u) nf += ingest_part[i];
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n_bin; i += gridDim.x * 256u) {
@@ -1028,6 +1030,7 @@ __global__ __launch_bounds__(256) void k_collect_stats(const unsigned long long*
       out->shc = st->cand[slot].shc;
       acc->done = 0u;
       __threadfence_system();
+      __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }

@@ -402,6 +402,8 @@ int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2);
  *   "bin_table"   0/1   : k_bin folds poorly merged waves into a per-block LDS cell table before the atomics
  *   "zero_copy"   n     : host entry points read PINNED input arrays of up to n points in place (0 = always copy)
  *   "overlap"     0/1   : hold the update of a small scan back and fuse it with the next scan's bin launch
+ *   "sync_spin_us" n     : a synchronous call polls the pinned statistics block for up to n microseconds before it
+ *                         falls back to a stream wait (default 150; 0 = wait at once)
  *   "tiled" 0/1, "tiled_min" n : large-scan pipeline (per-tile record pools) on/off, its point-count threshold
  *   "dbg_*"             : measurement-only switches used by scripts/ab_kernels.py */
 int fdm_engine_set_option(fdm_engine* e, const char* key, int value);
