@@ -409,6 +409,18 @@ def main():
                 for i in range(3):  # first GPU touch of freshly pinned pages is not what is measured
                     res.eng.integrate(pn["x"], pn["y"], pn["z"], wl.T_base_sensor, wl.pose(k + 1000 + i),
                                       intensity=pn.get("intensity"), rgb=pn.get("rgb"))
+                # ... and on arrays from the engine's own pinned pool (fdm_host_alloc: what every channel of the C++
+                # mirror's nanopcl::PointCloud is made of): their device aliases come from the pool's table
+                from fastdem_amd import host_array
+                pool = {c: host_array(s[c], np.uint32 if c == "rgb" else np.float32)
+                        for c in ("x", "y", "z", "intensity", "rgb") if s.get(c) is not None}
+                pa = {c: h.array for c, h in pool.items()}
+                for i in range(3):
+                    res.eng.integrate(pa["x"], pa["y"], pa["z"], wl.T_base_sensor, wl.pose(k + 1000 + i),
+                                      intensity=pa.get("intensity"), rgb=pa.get("rgb"))
+                result["host_buffers_pool_ms_per_scan"] = median_ms(
+                    lambda i: res.eng.integrate(pa["x"], pa["y"], pa["z"], wl.T_base_sensor, wl.pose(k + 1000 + i),
+                                                intensity=pa.get("intensity"), rgb=pa.get("rgb")))
                 result["host_buffers_pinned_ms_per_scan"] = median_ms(
                     lambda i: res.eng.integrate(pn["x"], pn["y"], pn["z"], wl.T_base_sensor, wl.pose(k + 1000 + i),
                                                 intensity=pn.get("intensity"), rgb=pn.get("rgb")))

@@ -798,7 +798,11 @@ int ensure_stage(fdm_engine* e, size_t n) {
 }
 
 // Device-visible alias of a pinned (hipHostMalloc / hipHostRegister) host pointer; null for anything else.
+// Blocks of the engine's own pinned pool (fdm_host_alloc: every nanopcl::PointCloud channel of the C++ mirror) are
+// answered from the pool's table — hipPointerGetAttributes costs ~2.5 us a call, four to six calls per scan.
+const void* host_pool_alias(const void* p);  // (below, with the pool)
 const void* pinned_alias(const void* p) {
+  if (const void* known = host_pool_alias(p)) return known;
   hipPointerAttribute_t a{};
   if (hipPointerGetAttributes(&a, p) != hipSuccess) {
     (void)hipGetLastError();  // pageable memory is reported as an error by older runtimes: not ours to keep
@@ -1324,11 +1328,20 @@ struct HostPool {
   static constexpr int kMinShift = 12, kMaxShift = 30;  // 4 KiB .. 1 GiB classes; larger blocks are not pooled
   std::mutex mu;
   std::unordered_map<const void*, int> live;            // block -> class (>= 0 pinned, -1 pinned unpooled, -2 pageable)
+  std::unordered_map<const void*, const void*> alias;   // pinned block -> its device-visible address
   std::vector<void*> idle[kMaxShift + 1];
 };
 HostPool* host_pool() {
   static HostPool* pool = new HostPool;  // never destroyed: clouds with static storage may be freed after main()
   return pool;
+}
+const void* host_pool_alias(const void* p) {
+  HostPool& hp = *host_pool();
+  std::lock_guard<std::mutex> lock(hp.mu);
+  auto it = hp.live.find(p);
+  if (it == hp.live.end() || it->second == -2) return nullptr;
+  auto al = hp.alias.find(p);
+  return al == hp.alias.end() ? nullptr : al->second;
 }
 }  // namespace
 
@@ -1355,8 +1368,14 @@ void* fdm_host_alloc(uint64_t bytes) {
     tag = -2;
     if (!p) return nullptr;
   }
+  void* dev = nullptr;
+  if (tag != -2 && hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    dev = nullptr;  // (pinned_alias falls back to hipPointerGetAttributes)
+  }
   std::lock_guard<std::mutex> lock(hp.mu);
   hp.live[p] = tag;
+  if (dev) hp.alias[p] = dev;
   return p;
 }
 
@@ -1375,8 +1394,15 @@ void fdm_host_free(void* p) {
       return;
     }
   }
-  if (tag == -1) (void)hipHostFree(p);
-  else std::free(p);
+  if (tag == -1) {
+    {
+      std::lock_guard<std::mutex> lock(hp.mu);
+      hp.alias.erase(p);
+    }
+    (void)hipHostFree(p);
+  } else {
+    std::free(p);
+  }
 }
 
 void fdm_host_trim(void) {
@@ -1388,6 +1414,7 @@ void fdm_host_trim(void) {
       drop.insert(drop.end(), v.begin(), v.end());
       v.clear();
     }
+    for (void* p : drop) hp.alias.erase(p);
   }
   for (void* p : drop) (void)hipHostFree(p);
 }
