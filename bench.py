@@ -231,6 +231,19 @@ def parity_gate(wl, R):
             "layers": len(ref.layers()), "timed_path_after_10_scans_max_rel_err": worst_timed_path}
 
 
+PROFILER_VARS = ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY", "HSA_TOOLS_LIB", "ROCP_TOOL_LIB")
+
+
+def under_profiler():
+    """rocprofv3 preloads its tool library into this process (and into anything it spawns): a make -> sh -> g++
+    chain behind it is exactly the exec-behind-a-GPU-initialised-process pattern the pool forbids."""
+    return any(os.environ.get(v) for v in PROFILER_VARS) or any(k.startswith("ROCPROF") for k in os.environ)
+
+
+def clean_env():
+    return {k: v for k, v in os.environ.items() if k not in PROFILER_VARS and not k.startswith("ROCPROF")}
+
+
 def cpu_baseline(wl, target_s=12.0):
     """The CPU oracle (single-threaded port of the reference path, -O3 no -march: the reference's
     Release flags) timed on this host on a bounded sample of the same workload."""
@@ -271,8 +284,10 @@ def cpu_baseline(wl, target_s=12.0):
     try:
         # -march=native means THIS host: rebuild the library here (8 s of g++), never trust a shipped one
         import subprocess
+        if under_profiler():
+            raise RuntimeError("no child processes behind a profiler preload")
         subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(ROOT, "oracle"), "_build/libfdm_ref_native.so"],
-                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120, env=clean_env())
         rn = R.RefEngine(wl.width, wl.height, wl.resolution, wl.apply_to(R.default_config()), native=True)
         rn.time_integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, poses, 5, **kw)
         it2 = max(5, iters // 4)

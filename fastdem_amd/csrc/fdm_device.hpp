@@ -56,6 +56,8 @@ struct DevState {
   unsigned vis_int;
   unsigned ray_count;  // rays queued by k_ray_compact for k_ray; k_ray_resolve puts it back to 0
   unsigned vis_col, vis_ray;
+  unsigned fault;      // sticky: a device-side invariant failed (a batch's chain wait ran out of polls); reported by
+  unsigned pad_f[3];   // the next statistics read-back as FDM_ERR_HIP
 };
 
 struct GeomConst {
@@ -93,6 +95,10 @@ struct ScanParams {
 };
 
 // ---- helpers ----
+// uniform value that came out of LDS / a ballot: tell the compiler (everything derived from it — tile number,
+// row pointer, loop bounds — then lives in scalar registers instead of one vector register each)
+__device__ __forceinline__ unsigned uni(unsigned v) { return unsigned(__builtin_amdgcn_readfirstlane(int(v))); }
+
 __device__ __forceinline__ float sum3(float a0, float a1, float a2) { return a0 + (a1 + a2); }
 
 __device__ __forceinline__ void wrap_index(int& index, int size) {  // grid_map wrapIndexToRange
@@ -142,6 +148,40 @@ __device__ __forceinline__ DevCand move_candidate(const DevGeom& g, const GeomCo
   for (int i = 0; i < 2; ++i) {
     const double t = ps[i] / G.res;
     const int v = static_cast<int>(t + 0.5 * (t > 0 ? 1 : -1));
+    sh[i] = -v;
+  }
+  c.sr = g.sr + sh[0];
+  c.sc = g.sc + sh[1];
+  wrap_index(c.sr, G.rows);
+  wrap_index(c.sc, G.cols);
+  c.px = g.px + double(-sh[0]) * G.res;
+  c.py = g.py + double(-sh[1]) * G.res;
+  c.shr = sh[0];
+  c.shc = sh[1];
+  return c;
+}
+
+// The same move() arithmetic without the two IEEE fp64 divides on the common path (a batch of scans walks a chain
+// of up to kMaxBatch moves per block, fdm_multi.hpp): t = ps / res is estimated as ps * (1 / res); the estimate is
+// off by a few ulp, so trunc(t + 0.5 sign) can only differ from the reference where t + 0.5 sign lies within that
+// distance of an integer — those cases (and anything huge) take the exact divide.  Result bit-identical to
+// move_candidate.
+__device__ __forceinline__ DevCand move_candidate_fast(const DevGeom& g, const GeomConst& G, double x, double y) {
+  DevCand c;
+  const double ps[2] = {x - g.px, y - g.py};
+  int sh[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double te = ps[i] * G.inv_res;
+    const double ue = te + 0.5 * (te > 0 ? 1 : -1);
+    int v = static_cast<int>(ue);
+    const double f = fabs(ue - double(v));
+    // (te == 0 decides the sign of the half step: exact path; NaN / huge values fail the range test)
+    const bool sure = f > 1e-4 && f < 1.0 - 1e-4 && fabs(ue) < 1.0e6 && fabs(te) > 1e-4;
+    if (!sure) {
+      const double t = ps[i] / G.res;
+      v = static_cast<int>(t + 0.5 * (t > 0 ? 1 : -1));
+    }
     sh[i] = -v;
   }
   c.sr = g.sr + sh[0];
@@ -232,7 +272,9 @@ __device__ __forceinline__ bool in_cleared_strip(int b, int start, int sh, int s
 }
 
 // Sigma_sensor of one point in the SENSOR frame (column-major 3x3): SensorModel::computeCovariance.
-__device__ __forceinline__ void sensor_cov(const ScanParams& P, float x, float y, float z, float* S) {
+// (PT: ScanParams, or any view with the same member names — fdm_multi.hpp reads them from a device table)
+template <class PT>
+__device__ __forceinline__ void sensor_cov(const PT& P, float x, float y, float z, float* S) {
   if (P.sensor_type == 1) {  // LiDAR, lidar_model.hpp:64-89
     const float dist_sq = sum3(x * x, y * y, z * z);
     if (dist_sq < 1e-6f) {
@@ -284,7 +326,8 @@ __device__ __forceinline__ void sensor_cov(const ScanParams& P, float x, float y
 }
 
 // sigma_z^2 = (R * Sigma_sensor * R^T)(2,2) for one point in the SENSOR frame.
-__device__ __forceinline__ float sigma_z2(const ScanParams& P, float x, float y, float z) {
+template <class PT>
+__device__ __forceinline__ float sigma_z2(const PT& P, float x, float y, float z) {
   float S[9];  // column-major
   sensor_cov(P, x, y, z, S);
   // M = R*S (row 2 only), out(2,2) = M(2,:) . R(2,:)   — 3-term dots a0b0 + (a1b1 + a2b2)
@@ -299,7 +342,8 @@ __device__ __forceinline__ float sigma_z2(const ScanParams& P, float x, float y,
 // The whole R * Sigma_sensor * R^T (column-major), fastdem.cpp:182-187: M = R*Sigma to a temporary, then
 // M*R^T, every coefficient a 3-term dot a0b0 + (a1b1 + a2b2).  Only evaluated for the preprocessed-scan
 // callback's cloud, which carries the covariance channel (nanopcl/core/point_cloud.hpp:126-147).
-__device__ __forceinline__ void cov_full(const ScanParams& P, float x, float y, float z, float* out) {
+template <class PT>
+__device__ __forceinline__ void cov_full(const PT& P, float x, float y, float z, float* out) {
   float S[9], M[9];
   sensor_cov(P, x, y, z, S);
   const float* R = P.R;

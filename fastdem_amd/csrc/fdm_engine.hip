@@ -27,6 +27,7 @@
 
 #include "fdm_kernels.hpp"
 #include "fdm_tiled.hpp"
+#include "fdm_multi.hpp"
 #include "fdm_raycast.hpp"
 #include "fdm_egress.hpp"
 #include "fdm_ingest.hpp"
@@ -159,6 +160,9 @@ struct fdm_engine {
   // the held-back update (plain data: the layer set cannot change while it is pending, every entry
   // point that could change it flushes first)
   struct PendingUpdate {
+    bool multi = false;     // a whole batch (fdm_multi.hpp): MB / ch are what matters
+    MBatch MB;
+    int ch = 0;
     bool tiled = false;     // large-scan pipeline (fdm_tiled.hpp) or the per-cell scratch one
     ScanParams P;
     Scratch S;              // scratch pipeline: the key / aux set of the scan's parity, captures
@@ -172,7 +176,7 @@ struct fdm_engine {
   int tiled = 1;                    // option "tiled": large scans go through per-tile record pools
   unsigned tiled_min = 2048;        // ... from this many points up (on a map of >= 512 tiles the pipeline wins at every
                                     // size measured: 2 K points 13.1 vs 14.6 us, 32 K 16.6 vs 20.5, 262 K 18.9 vs 34.3)
-  bool tiled_forced = false;        // tiled_min was set by hand (option / FDM_TILED_MIN): no map-size condition
+  bool tiled_forced = false;        // tiled_min was set by hand (option "tiled_min"): no map-size condition
   TileGrid TG{};
   TilePool pool[2] = {};            // by scan parity
   size_t pool_cap = 0;              // records per pool
@@ -184,6 +188,21 @@ struct fdm_engine {
   uint32_t* last_upd_part = nullptr;
   int last_kind = -1;               // pipeline of the last scan (0 scratch, 1 tiled)
   int last_do_move = 0, last_gate = 0;
+  // ---- batch pipeline (fdm_multi.hpp): up to kMaxBatch small scans per launch, allocated by the first batch ----
+  int batch = 1;                     // option "batch": fdm_engine_integrate_device_batch groups eligible scans
+  int batch_max = kMaxBatch;         // option "batch_max": scans per launch (2 .. kMaxBatch)
+  unsigned long long* mkey[2] = {nullptr, nullptr};  // [kMaxBatch][ncell] per batch parity
+  uint4* maux[2] = {nullptr, nullptr};
+  uint2* mzs[2] = {nullptr, nullptr};
+  float2* mobs[2] = {nullptr, nullptr};              // [kMaxBatch][mobs_stride]
+  uint32_t* mcobs[2] = {nullptr, nullptr};
+  size_t mobs_stride = 0;
+  unsigned long long* mbin_part[2] = {nullptr, nullptr};
+  size_t mbin_cap = 0;
+  MState* mstate = nullptr;          // [2]
+  MScan* mscans = nullptr;           // [2][kMaxBatch]
+  int mparity = 0;
+  const unsigned long long* last_bin_part = nullptr;  // per-block statistics of the last scan (either pipeline)
   // stencil post-processing (fdm_post.hpp)
   RegionEntry* d_region = nullptr;   // kMaxRegion entries
   FeatEntry* d_feat_tab = nullptr;   // kMaxRegion entries: the region as k_features_tiled reads it
@@ -464,6 +483,25 @@ P2Params p2_params(const fdm_config& c) {  // P2Quantile ctor (quantile_estimati
 
 #include "fdm_engine_launch.inl"  // with_policy, record pools, launch_tbin / launch_update_alone / launch_update_fused
 
+// SensorModel parameters as the kernels take them (sensor_type 0 Constant, 1 LiDAR, 2 RGB-D)
+void sensor_params(const fdm_config& cfg, int& type, float* sp) {
+  type = cfg.sensor_type;
+  if (type == 2) {
+    sp[0] = cfg.rgbd_normal_a;
+    sp[1] = cfg.rgbd_normal_b;
+    sp[2] = cfg.rgbd_normal_c;
+    sp[3] = cfg.rgbd_lateral_factor;
+  } else if (type == 0) {
+    sp[0] = cfg.constant_uncertainty;
+    sp[1] = sp[2] = sp[3] = 0.f;
+  } else {  // LiDARSensorModel ctor takes |noise| (lidar_model.hpp:58-62); unknown -> LiDAR (sensor_model.cpp:34-38)
+    type = 1;
+    sp[0] = std::fabs(cfg.lidar_range_noise);
+    sp[1] = std::fabs(cfg.lidar_angular_noise);
+    sp[2] = sp[3] = 0.f;
+  }
+}
+
 constexpr int kStageSlots = 3;  // rotating staging blocks (see ensure_stage)
 int ensure_stage(fdm_engine* e, size_t n);
 
@@ -484,25 +522,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   P.has_intensity = dint != nullptr;
   P.has_color = drgb != nullptr;
   P.has_var = dvar != nullptr;
-  P.sensor_type = e->cfg.sensor_type;
-  if (P.sensor_type == 1) {  // LiDARSensorModel ctor takes |noise| (lidar_model.hpp:58-62)
-    P.sp[0] = std::fabs(e->cfg.lidar_range_noise);
-    P.sp[1] = std::fabs(e->cfg.lidar_angular_noise);
-    P.sp[2] = P.sp[3] = 0.f;
-  } else if (P.sensor_type == 2) {
-    P.sp[0] = e->cfg.rgbd_normal_a;
-    P.sp[1] = e->cfg.rgbd_normal_b;
-    P.sp[2] = e->cfg.rgbd_normal_c;
-    P.sp[3] = e->cfg.rgbd_lateral_factor;
-  } else if (P.sensor_type == 0) {
-    P.sp[0] = e->cfg.constant_uncertainty;
-    P.sp[1] = P.sp[2] = P.sp[3] = 0.f;
-  } else {  // unknown -> LiDAR (sensor_model.cpp:34-38)
-    P.sensor_type = 1;
-    P.sp[0] = std::fabs(e->cfg.lidar_range_noise);
-    P.sp[1] = std::fabs(e->cfg.lidar_angular_noise);
-    P.sp[2] = P.sp[3] = 0.f;
-  }
+  sensor_params(e->cfg, P.sensor_type, P.sp);
   if (!e->estimator_ready) {  // a bare map: behave as if FastDEM(map) had been constructed
     if ((rc = ensure_estimator_layers(e))) return rc;
     e->estimator_ready = true;
@@ -620,6 +640,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
                                       P.has_color != 0)))
     return rc;
   e->last_bin_blocks = bin_blocks;
+  e->last_bin_part = e->S.bin_part;
   P.dbg_no_atomics = e->dbg_no_atomics;
   P.bin_table = e->bin_table;
   P.dbg_upd = e->dbg_upd;
@@ -636,7 +657,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   const bool fusable = tiled || ((!use_bin4 || (e->rec_kind >= 0 && e->S.dense)) && e->wave_merge);
   // (the fused tiled launch compiles the channels in once, for both halves)
   const bool same_channels = !tiled || (e->pend.P.has_intensity == P.has_intensity && e->pend.P.has_color == P.has_color);
-  const bool fuse_now = e->chain && plain && fusable && e->pend.tiled == tiled && same_channels;
+  const bool fuse_now = e->chain && plain && fusable && !e->pend.multi && e->pend.tiled == tiled && same_channels;
   if (e->chain && !fuse_now && (rc = join_streams(e))) return rc;
   P.chain_prev = 0;
   if (e->profile) HIPCK(hipEventRecord(e->ev[0], e->stream));
@@ -682,6 +703,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   }
   // this scan's update: held back (the next scan's launch or a flush carries it) or launched now
   fdm_engine::PendingUpdate& u = e->pend;
+  u.multi = false;
   u.tiled = tiled;
   u.P = P;
   u.S = e->S;
@@ -785,6 +807,8 @@ void fill_update_params(fdm_engine* e, ScanParams& P, double rx, double ry, bool
   P.gate_on_filter = 0;
 }
 
+#include "fdm_engine_multi.inl"  // the batch pipeline's host side: eligibility, buffers, enqueue_multi
+
 // Staging for host-array entry points: kStageSlots rotating blocks of 6 channels.  A block is reused
 // three scans later, when the update that gathers from it (held back by at most one scan) has long
 // been launched ahead of the new copy on the same stream.
@@ -879,7 +903,7 @@ int read_stats(fdm_engine* e, fdm_scan_stats* out, int* status) {
   {  // sum the partial counts behind the scan's kernels; the result lands in pinned host memory
     const unsigned work = std::max<unsigned>(e->last_bin_blocks, e->last_upd_tiles);
     const unsigned blocks = std::min(64u, std::max(1u, (work + 4095u) / 4096u));
-    hipLaunchKernelGGL(k_collect_stats, dim3(blocks), dim3(256), 0, e->stream, e->S.bin_part, e->last_bin_blocks,
+    hipLaunchKernelGGL(k_collect_stats, dim3(blocks), dim3(256), 0, e->stream, e->last_bin_part, e->last_bin_blocks,
                        e->last_upd_part, e->last_upd_tiles, e->pack_counts, e->ingest_blocks, e->d_state,
                        int((e->scan_no - 1) & 3), e->d_stats_acc, e->h_stats_dev, ++e->stats_seq);
     HIPCK(hipGetLastError());
@@ -888,7 +912,8 @@ int read_stats(fdm_engine* e, fdm_scan_stats* out, int* status) {
     // (a thread sleeping in hipStreamSynchronize is woken some 10-20 us after the stream has drained — a third of
     // what a synchronous integrate() of a VLP-16 scan takes end to end).
     bool seen = false;
-    if (e->sync_spin_us > 0) {
+    // (a scan of more than ~100 K points keeps the device busy for longer than the poll window: sleep at once)
+    if (e->sync_spin_us > 0 && e->last_n <= 131072u && e->last_kind != 1) {
       const auto t0 = std::chrono::steady_clock::now();
       const volatile unsigned long long* const w = &e->h_stats->seq;
       for (;;) {
@@ -898,8 +923,18 @@ int read_stats(fdm_engine* e, fdm_scan_stats* out, int* status) {
           break;
       }
     }
-    if (!seen) HIPCK(hipStreamSynchronize(e->stream));
+    if (!seen) {
+      HIPCK(hipStreamSynchronize(e->stream));
+    } else {
+      // the sequence word says the stream has drained; a kernel fault is asynchronous and would otherwise go
+      // unnoticed until the next blocking call
+      const hipError_t q = hipStreamQuery(e->stream);
+      if (q != hipSuccess && q != hipErrorNotReady)
+        return fail(FDM_ERR_HIP, std::string("stream fault after the scan: ") + hipGetErrorString(q));
+      HIPCK(hipGetLastError());
+    }
   }
+  if (e->h_stats->fault) return fail(FDM_ERR_HIP, "device-side fault: a batch's geometry-chain wait ran out of polls");
   const uint64_t np = e->h_stats->n_pass, ni = e->h_stats->n_in, nt = e->h_stats->n_touched;
   if (e->ingest_blocks) {  // PointCloud2 scan: cloud.size() is the number of finite points (from_impl)
     e->last_n_input = uint32_t(e->h_stats->n_finite);
@@ -1017,10 +1052,6 @@ static int create_impl(const fdm_geometry* g, const fdm_config* cfg, const fdm_t
     G.s_r0 = G.s_c0 = G.o_r0 = G.o_c0 = 0;
     G.s_rows = G.o_rows = G.rows;
     G.s_cols = G.o_cols = G.cols;
-  }
-  if (const char* v = std::getenv("FDM_TILED_MIN")) {  // test switch: push every scan of at least this many points
-    e->tiled_min = unsigned(std::strtoul(v, nullptr, 10));  // through the large-scan pipeline
-    e->tiled_forced = true;
   }
   e->ncell = size_t(G.s_rows) * size_t(G.s_cols);
   if (e->ncell >= 0xFFFFFFFFull) {
@@ -1144,6 +1175,16 @@ void fdm_engine_destroy(fdm_engine* e) {
     if (q.rec) (void)hipFree(q.rec);
     if (q.desc) (void)hipFree(q.desc);
   }
+  for (int k = 0; k < 2; ++k) {
+    if (e->mkey[k]) (void)hipFree(e->mkey[k]);
+    if (e->maux[k]) (void)hipFree(e->maux[k]);
+    if (e->mzs[k]) (void)hipFree(e->mzs[k]);
+    if (e->mobs[k]) (void)hipFree(e->mobs[k]);
+    if (e->mcobs[k]) (void)hipFree(e->mcobs[k]);
+    if (e->mbin_part[k]) (void)hipFree(e->mbin_part[k]);
+  }
+  if (e->mstate) (void)hipFree(e->mstate);
+  if (e->mscans) (void)hipFree(e->mscans);
   if (e->tile_stamp32) (void)hipFree(e->tile_stamp32);
   if (e->upd_part32) (void)hipFree(e->upd_part32);
   if (e->tile_rare) (void)hipFree(e->tile_rare);
@@ -1233,6 +1274,13 @@ int fdm_engine_integrate_device(fdm_engine* e, uint64_t n, const float* dx, cons
 int fdm_engine_integrate_device_batch(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) {
   if (!e || (count && !scans)) return fail(FDM_ERR_INVALID, "null argument");
   for (uint32_t k = 0; k < count; ++k) {
+    // runs of small plain scans leave as batches: one bin launch + one update launch per kMaxBatch scans
+    if (const uint32_t run = multi_run(e, count - k, scans + k)) {
+      HIPCK(hipSetDevice(e->device));
+      if (int rc = enqueue_multi(e, run, scans + k)) return rc;
+      k += run - 1u;
+      continue;
+    }
     const fdm_device_scan& s = scans[k];
     const int rc = fdm_engine_integrate_device(e, s.n, s.x, s.y, s.z, s.intensity, s.rgb, s.sigma_z2,
                                                s.T_base_sensor, s.T_world_base);
@@ -1243,8 +1291,9 @@ int fdm_engine_integrate_device_batch(fdm_engine* e, uint32_t count, const fdm_d
 
 int fdm_engine_integrate_device_batch_timed(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) {
   if (int rc = fdm_engine_timer_start(e)) return rc;
-  if (int rc = fdm_engine_integrate_device_batch(e, count, scans)) return rc;
-  return fdm_engine_timer_stop(e);
+  const int rc_batch = fdm_engine_integrate_device_batch(e, count, scans);
+  const int rc_stop = fdm_engine_timer_stop(e);  // (also on the error path: fdm_engine_timer_ms must never see a stale mark)
+  return rc_batch ? rc_batch : rc_stop;
 }
 
 int fdm_engine_integrate(fdm_engine* e, uint64_t n, const float* x, const float* y, const float* z,
@@ -1831,6 +1880,15 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
     e->overlap = value != 0;
     return FDM_OK;
   }
+  if (std::strcmp(key, "batch") == 0) {  // fdm_engine_integrate_device_batch: group small scans into batch launches
+    e->batch = value != 0;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "batch_max") == 0) {
+    if (value < 2 || value > kMaxBatch) return fail(FDM_ERR_INVALID, "batch_max: 2 .. 16 scans per launch");
+    e->batch_max = value;
+    return FDM_OK;
+  }
   if (std::strcmp(key, "zero_copy") == 0) {
     if (value < 0) return fail(FDM_ERR_INVALID, "zero_copy: a point count (0 = off)");
     e->zero_copy = value;
@@ -1851,8 +1909,15 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
     e->sync_spin_us = value < 0 ? 0 : value;
     return FDM_OK;
   }
-  if (std::strcmp(key, "dbg_span") == 0) {
+  if (std::strcmp(key, "dbg_span") == 0) {  // measurement only: tiles per update group, 0 = automatic
+    if (value < 0 || value > 64) return fail(FDM_ERR_INVALID, "dbg_span: 0 (automatic) or 1..64 tiles per group");
+    if (int rc_sync = sync_all(e)) return rc_sync;
     e->dbg_span = value;
+    if (e->tile_rare) {  // sized per update group: the group count follows the span
+      HIPCK(hipFree(e->tile_rare));
+      e->tile_rare = nullptr;
+      for (auto& q : e->pool) q.rare = nullptr;
+    }
     return FDM_OK;
   }
   if (std::strcmp(key, "dbg_post") == 0) {

@@ -94,13 +94,13 @@ int ensure_tile_pool(fdm_engine* e, size_t records, unsigned blocks, bool has_in
     HIPCK(hipMalloc(reinterpret_cast<void**>(&e->upd_part32), e->TG.n_tiles * sizeof(uint32_t)));
     hipLaunchKernelGGL(k_fill_u32, dim3(64), dim3(256), 0, e->stream, e->tile_stamp32, 0xFFFFFFFEu, size_t(e->TG.n_tiles));
     hipLaunchKernelGGL(k_fill_u32, dim3(64), dim3(256), 0, e->stream, e->upd_part32, 0u, size_t(e->TG.n_tiles));
-    {
-      const unsigned span = tile_span(e);
-      const size_t groups = (e->TG.n_tiles + span - 1u) / span + 2u;
-      HIPCK(hipMalloc(reinterpret_cast<void**>(&e->tile_rare), groups * 3u * kTileCells * sizeof(uint32_t)));
-      for (auto& q : e->pool) q.rare = e->tile_rare;
-    }
     HIPCK(hipGetLastError());
+  }
+  if (!e->tile_rare) {  // k_tupdate's rare-path scratch: 12 KB per update group of the CURRENT span (see "dbg_span")
+    const unsigned span = tile_span(e);
+    const size_t groups = (e->TG.n_tiles + span - 1u) / span + 2u;
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->tile_rare), groups * 3u * kTileCells * sizeof(uint32_t)));
+    for (auto& q : e->pool) q.rare = e->tile_rare;
   }
   const bool grow_rec = records > e->pool_cap;
   (void)has_int; (void)has_col;
@@ -152,7 +152,9 @@ int launch_tbin(fdm_engine* e, const ScanParams& P, const ScanInputs& in, const 
 }
 
 // The held-back (or just enqueued) update on its own.
+int launch_multi_update(fdm_engine* e, const fdm_engine::PendingUpdate& u);  // a whole batch (fdm_engine_multi.inl)
 int launch_update_alone(fdm_engine* e, const fdm_engine::PendingUpdate& u) {
+  if (u.multi) return launch_multi_update(e, u);
   return with_policy(e, [&](auto tag, const auto& layers) -> int {
     using POLICY = decltype(tag);
     if (u.tiled) {

@@ -115,7 +115,8 @@ struct P2RecLayers {
 };
 
 // Bring one input point into the map frame; returns whether it survived the crops.
-__device__ __forceinline__ bool preprocess_point(const ScanParams& P, float& x, float& y, float& z) {
+template <class PT>
+__device__ __forceinline__ bool preprocess_point(const PT& P, float& x, float& y, float& z) {
   if (!P.integrate_mode) return true;
   float w = 1.0f;
   transform4(P.Tbs, x, y, z, w);
@@ -713,6 +714,19 @@ struct KalmanRecPolicy {  // cell records
     r[1] = make_float4(t.s.count, t.s.P, t.s.mean, t.s.m2);
     reinterpret_cast<float2*>(r + 2)[0] = make_float2(t.s.upper, t.s.lower);
   }
+  // the same update split in two for a cell that takes SEVERAL observations in one kernel (fdm_multi.hpp): step()
+  // keeps everything in registers, store() writes the record once at the end
+  static __device__ __forceinline__ void step(const Layers& L, State& t, float min_z, float var, float max_z) {
+    kalman_step(t.s, min_z, var, L.min_var, L.max_var, L.q);
+    t.smin = (isnan(t.smin) || min_z < t.smin) ? min_z : t.smin;
+    t.smax = (isnan(t.smax) || max_z > t.smax) ? max_z : t.smax;
+  }
+  static __device__ __forceinline__ void store(const Layers& L, unsigned o, const State& t) {
+    float4* r = reinterpret_cast<float4*>(L.rec + size_t(o) * kKalmanRec);
+    r[0] = make_float4(t.s.x, t.smin, t.smax, t.s.var);
+    r[1] = make_float4(t.s.count, t.s.P, t.s.mean, t.s.m2);
+    reinterpret_cast<float2*>(r + 2)[0] = make_float2(t.s.upper, t.s.lower);
+  }
 };
 
 struct P2Policy {  // one array per layer
@@ -783,6 +797,19 @@ struct P2RecPolicy {  // cell records
     const float nmax = (isnan(t.smax) || max_z > t.smax) ? max_z : t.smax;
     float4* r = reinterpret_cast<float4*>(L.rec + size_t(o) * kP2Rec);
     r[0] = make_float4(t.s.elevation, nmin, nmax, t.s.variance);
+    r[1] = make_float4(t.s.count, t.s.q[0], t.s.q[1], t.s.q[2]);
+    r[2] = make_float4(t.s.q[3], t.s.q[4], t.s.n[0], t.s.n[1]);
+    r[3] = make_float4(t.s.n[2], t.s.n[3], t.s.n[4], t.s.upper);
+    r[4].x = t.s.lower;
+  }
+  static __device__ __forceinline__ void step(const Layers& L, State& t, float min_z, float /*var*/, float max_z) {
+    p2_step(t.s, min_z, L.p);
+    t.smin = (isnan(t.smin) || min_z < t.smin) ? min_z : t.smin;
+    t.smax = (isnan(t.smax) || max_z > t.smax) ? max_z : t.smax;
+  }
+  static __device__ __forceinline__ void store(const Layers& L, unsigned o, const State& t) {
+    float4* r = reinterpret_cast<float4*>(L.rec + size_t(o) * kP2Rec);
+    r[0] = make_float4(t.s.elevation, t.smin, t.smax, t.s.variance);
     r[1] = make_float4(t.s.count, t.s.q[0], t.s.q[1], t.s.q[2]);
     r[2] = make_float4(t.s.q[3], t.s.q[4], t.s.n[0], t.s.n[1]);
     r[3] = make_float4(t.s.n[2], t.s.n[3], t.s.n[4], t.s.upper);
@@ -985,6 +1012,7 @@ struct StatsAcc {  // device
 struct StatsOut {  // pinned host memory, written by the last block
   unsigned long long n_pass, n_in, n_touched, n_finite;
   int shr, shc;
+  unsigned fault, pad;     // DevState::fault
   unsigned long long seq;  // written last (system scope): the host polls it instead of sleeping in a stream wait
 };
 __global__ __launch_bounds__(256) void k_collect_stats(const unsigned long long* __restrict__ bin_part,
@@ -1028,6 +1056,7 @@ __global__ __launch_bounds__(256) void k_collect_stats(const unsigned long long*
       out->n_finite = atomicExch(&acc->n_finite, 0ull);
       out->shr = st->cand[slot].shr;
       out->shc = st->cand[slot].shc;
+      out->fault = st->fault;
       acc->done = 0u;
       __threadfence_system();
       __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -580,9 +580,6 @@ __host__ __device__ constexpr unsigned tile_lds_bytes(bool has_int, bool has_col
   return kTileCells * (12u + (has_int ? 4u : 0u) + (has_col ? 4u : 0u)) + 260u * 4u + 256u * 8u;
 }
 
-// uniform value that came out of LDS / a ballot: tell the compiler (everything derived from it — tile number,
-// row pointer, loop bounds — then lives in scalar registers instead of one vector register each)
-__device__ __forceinline__ unsigned uni(unsigned v) { return unsigned(__builtin_amdgcn_readfirstlane(int(v))); }
 
 struct TileCtx {
   bool applied, do_update, strips;

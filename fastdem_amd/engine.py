@@ -77,6 +77,10 @@ def host_array(values, dtype=np.float32):
 
 
 class Engine:
+    # engine options (fdm_engine_set_option) every new Engine receives right after creation; the GPU test
+    # suite uses it to run each test on both scan pipelines (tests/conftest.py)
+    default_options = {}
+
     def __init__(self, width, height, resolution, cfg=None, position=(0.0, 0.0), tile=None,
                  device=0):
         self._lib = capi.load()
@@ -100,6 +104,8 @@ class Engine:
         self.rows, self.cols = geo.rows, geo.cols
         self.s_rows = self._tile.rows if self._tile else self.rows
         self.s_cols = self._tile.cols if self._tile else self.cols
+        for key, value in type(self).default_options.items():
+            self.set_option(key, value)
 
     # -- lifetime --
     def close(self):

@@ -15,8 +15,11 @@
  *     (fastdem/include/fastdem/bridge/ros/impl.hpp:117-119)
  *   - one engine = one device + one HIP stream; not thread-safe, caller serialises
  *     (same contract as fastdem.hpp:48-53)
- *   - host pointers are borrowed for the duration of the call only; device pointers
- *     passed to the *_device entry points must stay valid until fdm_engine_sync()
+ *   - host pointers are borrowed for the duration of the call only (pinned arrays handed to the
+ *     enqueue-only fdm_engine_integrate_async: until the work that call enqueued has run); device
+ *     pointers passed to the *_device entry points follow the ordinary stream contract — free to
+ *     reuse once the work the call enqueued has run (fdm_engine_record_event / fdm_engine_sync);
+ *     a held-back map update never reads them (see fdm_engine_integrate_device)
  */
 #ifndef FDM_ENGINE_H
 #define FDM_ENGINE_H

@@ -12,7 +12,7 @@ python bench.py --workload c3 --no-large --no-cpu-baseline --steps 1000 --warmup
 python bench.py --workload c5 --steps 100 --warmup 10 > $O/bench_c5.json 2> $O/bench_c5.err
 # PCIe-inclusive host entry points (opt-in legs; separate runs so the default command's kernel averages stay clean)
 for W in c2 c3 c4; do
-  python bench.py --workload $W --steps 200 --no-large --no-cpu-baseline --steps 200 --warmup 20 2> $O/bench_host_$W.err | python -c "
+  python bench.py --workload $W --no-large --no-cpu-baseline --steps 200 --warmup 20 2> $O/bench_host_$W.err | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(json.dumps({'workload': '$W', 'points_per_scan': d['config']['points_per_scan'], **{k: round(v, 4) for k, v in d.items() if k.startswith('host_')}}))" >> $O/bench_host.jsonl

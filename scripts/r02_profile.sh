@@ -7,7 +7,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # (1) kernel-trace stats of the default bench command (without the PCIe legs: they launch the same kernels on
 #     pinned host memory and would pull the per-kernel average away from the timed region) and of configs[3]
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_c2 -o c2 -- python3 $R/bench.py --no-host-legs > $O/rocprof_c2.json 2> $O/rocprof_c2.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_c2 -o c2 -- python3 $R/bench.py --no-host-legs --no-cpu-baseline > $O/rocprof_c2.json 2> $O/rocprof_c2.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_c4 -o c4 -- python3 $R/bench.py --workload c4 --no-host-legs --no-cpu-baseline --steps 2000 --warmup 200 > $O/rocprof_c4.json 2> $O/rocprof_c4.err
 # (2) traffic counters
 SETS=("TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "TCC_EA0_ATOMIC_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_REQ_sum")

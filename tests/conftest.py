@@ -25,14 +25,14 @@ def R():
 def gpu(request):
     """fastdem_amd with a usable device; loading fails loudly if the HIP library is missing.
     Every GPU test runs twice: with the engine's own choice of pipeline by scan size, and with every
-    scan pushed through the large-scan (per-tile record pool) pipeline (FDM_TILED_MIN=1)."""
+    scan pushed through the large-scan (per-tile record pool) pipeline — an ENGINE option
+    (`tiled_min` = 1) that every Engine the tests construct receives through `Engine.default_options`;
+    nothing process-wide, nothing the product reads from the environment."""
     import torch
     assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
     import fastdem_amd
     fastdem_amd.capi.load()
-    if request.param == "tiled_all":
-        os.environ["FDM_TILED_MIN"] = "1"
-    else:
-        os.environ.pop("FDM_TILED_MIN", None)
+    saved = dict(fastdem_amd.Engine.default_options)
+    fastdem_amd.Engine.default_options = {"tiled_min": 1} if request.param == "tiled_all" else {}
     yield fastdem_amd
-    os.environ.pop("FDM_TILED_MIN", None)
+    fastdem_amd.Engine.default_options = saved

@@ -571,8 +571,9 @@ def test_per_layer_layout_equals_cell_records(gpu, R, est):
 @pytest.mark.parametrize("colour", [False, True])
 def test_tiled_pipeline_sparse_cloud_overflows_the_block_table(gpu, R, colour):
     """A cloud whose consecutive points all fall into different cells: every block of the large-scan bin
-    kernel holds more distinct cells than its LDS table has slots, so it takes the overflow route (the
-    block redone as two halves, two chunks per tile).  Ties, +-0 and NaN intensities ride along."""
+    kernel fills its LDS cell table to the brim (one slot per point: the table has exactly as many slots as
+    the block has points, so it cannot overflow) and writes one record per point, spread over many map
+    tiles.  Ties, +-0 and NaN intensities ride along."""
     def fill(c):
         c.mode = 1
         c.kalman_max_variance = 1.0
