@@ -143,6 +143,7 @@ PROTOTYPES = {
     "fdm_engine_flush": (C.c_int, [_P]),
     "fdm_engine_stream": (_P, [_P]),
     "fdm_engine_last_pipeline": (C.c_int, [_P]),
+    "fdm_engine_last_batch": (C.c_int, [_P]),
     "fdm_engine_timer_start": (C.c_int, [_P]),
     "fdm_engine_timer_stop": (C.c_int, [_P]),
     "fdm_engine_timer_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),

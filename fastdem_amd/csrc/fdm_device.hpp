@@ -173,14 +173,19 @@ __device__ __forceinline__ DevCand move_candidate_fast(const DevGeom& g, const G
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const double te = ps[i] * G.inv_res;
-    const double ue = te + 0.5 * (te > 0 ? 1 : -1);
-    int v = static_cast<int>(ue);
-    const double f = fabs(ue - double(v));
-    // (te == 0 decides the sign of the half step: exact path; NaN / huge values fail the range test)
-    const bool sure = f > 1e-4 && f < 1.0 - 1e-4 && fabs(ue) < 1.0e6 && fabs(te) > 1e-4;
-    if (!sure) {
-      const double t = ps[i] / G.res;
-      v = static_cast<int>(t + 0.5 * (t > 0 ? 1 : -1));
+    int v = 0;
+    // |t| < ~1e-4 of a cell (an axis the robot does not move along): t +- 0.5 truncates to 0 whatever the sign of
+    // t — no divide, no sign question.  Otherwise sign(te) == sign(t) and the half-step estimate decides unless it
+    // lies within 1e-4 of an integer (or is huge / NaN): those take the exact divide.
+    if (!(fabs(te) <= 1e-4)) {
+      const double ue = te + 0.5 * (te > 0 ? 1 : -1);
+      v = static_cast<int>(ue);
+      const double f = fabs(ue - double(v));
+      const bool sure = f > 1e-4 && f < 1.0 - 1e-4 && fabs(ue) < 1.0e6;
+      if (!sure) {
+        const double t = ps[i] / G.res;
+        v = static_cast<int>(t + 0.5 * (t > 0 ? 1 : -1));
+      }
     }
     sh[i] = -v;
   }

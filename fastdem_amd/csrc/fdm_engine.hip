@@ -160,8 +160,8 @@ struct fdm_engine {
   // the held-back update (plain data: the layer set cannot change while it is pending, every entry
   // point that could change it flushes first)
   struct PendingUpdate {
-    bool multi = false;     // a whole batch (fdm_multi.hpp): MB / ch are what matters
-    MBatch MB;
+    bool multi = false;     // a whole batch (fdm_multi.hpp): MU / ch are what matters
+    MUpd MU;
     int ch = 0;
     bool tiled = false;     // large-scan pipeline (fdm_tiled.hpp) or the per-cell scratch one
     ScanParams P;
@@ -191,6 +191,7 @@ struct fdm_engine {
   // ---- batch pipeline (fdm_multi.hpp): up to kMaxBatch small scans per launch, allocated by the first batch ----
   int batch = 1;                     // option "batch": fdm_engine_integrate_device_batch groups eligible scans
   int batch_max = kMaxBatch;         // option "batch_max": scans per launch (2 .. kMaxBatch)
+  int batch_fuse = 1;                // option "batch_fuse": hold a batch's update back for the next batch's bin launch
   unsigned long long* mkey[2] = {nullptr, nullptr};  // [kMaxBatch][ncell] per batch parity
   uint4* maux[2] = {nullptr, nullptr};
   uint2* mzs[2] = {nullptr, nullptr};
@@ -199,9 +200,16 @@ struct fdm_engine {
   size_t mobs_stride = 0;
   unsigned long long* mbin_part[2] = {nullptr, nullptr};
   size_t mbin_cap = 0;
-  MState* mstate = nullptr;          // [2]
-  MScan* mscans = nullptr;           // [2][kMaxBatch]
-  int mparity = 0;
+  uint32_t* mupd_part = nullptr;     // [update blocks] touched cells of a batch's last scan
+  MState* mstate = nullptr;          // [kMStates] ring, slot = batch number % kMStates
+  unsigned mseq = 0;                 // batches enqueued so far
+  int last_batch_n = 0;              // scans of the batch launch the last scan left in (0: it took the single-scan path)
+  int dbg_batch = 0;                 // measurement only (option "dbg_batch")
+  int batch_crop = 1;                // option "batch_crop": evaluate the next batch's crops one launch ahead
+  bool pre_valid = false;            // the last launch carried the crop pass of the batch (pre_scans, pre_count) = number pre_seq
+  const fdm_device_scan* pre_scans = nullptr;
+  uint32_t pre_count = 0;
+  unsigned pre_seq = 0;
   const unsigned long long* last_bin_part = nullptr;  // per-block statistics of the last scan (either pipeline)
   // stencil post-processing (fdm_post.hpp)
   RegionEntry* d_region = nullptr;   // kMaxRegion entries
@@ -211,6 +219,7 @@ struct fdm_engine {
   unsigned long long* d_timeline = nullptr;  // measurement only: {start, end} ticks per block of the last fused launch
   unsigned timeline_cap = 0;         // blocks the buffer holds
   unsigned timeline_blocks = 0, timeline_upd = 0;  // grid of the last fused launch, its update blocks
+  unsigned timeline_bin = 0;         // ... its bin blocks (batch launches: the rest are crop blocks)
   float* d_tmp2 = nullptr;           // second ncell staging array (fusion works on two layers)
   // ingest (fdm_ingest.hpp)
   uint8_t* d_blob = nullptr;         // raw message bytes
@@ -761,6 +770,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     }
   }
   e->scan_no++;
+  e->last_batch_n = 0;
   e->have_scan = true;
   e->last_n = uint32_t(n);
   e->last_n_input = uint32_t(n);
@@ -1184,7 +1194,7 @@ void fdm_engine_destroy(fdm_engine* e) {
     if (e->mbin_part[k]) (void)hipFree(e->mbin_part[k]);
   }
   if (e->mstate) (void)hipFree(e->mstate);
-  if (e->mscans) (void)hipFree(e->mscans);
+  if (e->mupd_part) (void)hipFree(e->mupd_part);
   if (e->tile_stamp32) (void)hipFree(e->tile_stamp32);
   if (e->upd_part32) (void)hipFree(e->upd_part32);
   if (e->tile_rare) (void)hipFree(e->tile_rare);
@@ -1277,7 +1287,9 @@ int fdm_engine_integrate_device_batch(fdm_engine* e, uint32_t count, const fdm_d
     // runs of small plain scans leave as batches: one bin launch + one update launch per kMaxBatch scans
     if (const uint32_t run = multi_run(e, count - k, scans + k)) {
       HIPCK(hipSetDevice(e->device));
-      if (int rc = enqueue_multi(e, run, scans + k)) return rc;
+      // (look-ahead: the batch after this one, whose crops ride in this launch)
+      const uint32_t next = k + run < count ? multi_run(e, count - k - run, scans + k + run) : 0u;
+      if (int rc = enqueue_multi(e, run, scans + k, next)) return rc;
       k += run - 1u;
       continue;
     }
@@ -1483,6 +1495,8 @@ int fdm_engine_flush(fdm_engine* e) {
 void* fdm_engine_stream(fdm_engine* e) { return e ? static_cast<void*>(e->stream) : nullptr; }
 
 int fdm_engine_last_pipeline(fdm_engine* e) { return e ? e->last_kind : -1; }
+
+int fdm_engine_last_batch(fdm_engine* e) { return e ? e->last_batch_n : 0; }
 
 int fdm_engine_timer_start(fdm_engine* e) {
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
@@ -1882,6 +1896,18 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
   }
   if (std::strcmp(key, "batch") == 0) {  // fdm_engine_integrate_device_batch: group small scans into batch launches
     e->batch = value != 0;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "dbg_batch") == 0) {
+    e->dbg_batch = value;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "batch_crop") == 0) {
+    e->batch_crop = value != 0;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "batch_fuse") == 0) {
+    e->batch_fuse = value != 0;
     return FDM_OK;
   }
   if (std::strcmp(key, "batch_max") == 0) {

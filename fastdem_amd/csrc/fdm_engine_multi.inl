@@ -10,7 +10,8 @@ bool affine_last_row(const double* T) { return T[3] == 0.0 && T[7] == 0.0 && T[1
 
 // How many of the leading `count` scans can leave as ONE batch (0 or 1: take the single-scan path).
 // A batch is a run of plain small scans — exactly the scans the single-scan path would hold back and fuse
-// (enqueue_scan's `plain`), on the per-cell scratch pipeline with the one-point-per-thread bin kernel.
+// (enqueue_scan's `plain`), on the per-cell scratch pipeline with the one-point-per-thread bin kernel, from ONE
+// sensor (same T_base_sensor) and with the same optional channels.
 uint32_t multi_run(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) {
   if (!e->batch || count < 2u || !e->overlap || !e->wave_merge || e->bin_variant == 4) return 0u;
   if (!e->estimator_ready || e->rec_kind < 0 || !e->S.dense || e->ncell > kBatchMaxCells) return 0u;
@@ -32,6 +33,7 @@ uint32_t multi_run(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) 
         (s.sigma_z2 != nullptr) != (f.sigma_z2 != nullptr))
       break;
     if (!affine_last_row(s.T_base_sensor) || !affine_last_row(s.T_world_base)) break;
+    if (std::memcmp(s.T_base_sensor, f.T_base_sensor, 16 * sizeof(double)) != 0) break;
   }
   return run >= 2u ? run : 0u;
 }
@@ -49,9 +51,9 @@ int ensure_multi(fdm_engine* e, size_t max_n, size_t blocks) {
       HIPCK(hipGetLastError());
       HIPCK(hipMemsetAsync(e->mzs[k], 0xFF, slots * sizeof(uint2), e->stream));
     }
-    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->mstate), 2 * sizeof(MState)));
-    HIPCK(hipMemsetAsync(e->mstate, 0, 2 * sizeof(MState), e->stream));
-    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->mscans), 2 * sizeof(MScanBlock)));
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->mupd_part), ((e->ncell + kUpdCells - 1u) / kUpdCells) * sizeof(uint32_t)));
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->mstate), kMStates * sizeof(MState)));
+    HIPCK(hipMemsetAsync(e->mstate, 0, kMStates * sizeof(MState), e->stream));
   }
   if (max_n > e->mobs_stride) {
     if (int rc_sync = sync_all(e)) return rc_sync;  // (a held-back batch update reads the old arrays)
@@ -87,27 +89,52 @@ int with_channels(int ch, F&& f) {
   }
 }
 
-// The held-back update of a batch on its own (launch_update_alone forwards here).
-int launch_multi_update(fdm_engine* e, const fdm_engine::PendingUpdate& u) {
+// One k_mbatch launch: [ update U | bin B | crop Cn ], any of which may be empty (count == 0).
+int launch_mbatch(fdm_engine* e, int ch, const MUpd& U, const MBin& B, const MCrop& Cn, const MCommon& K) {
+  static_assert(sizeof(MUpd) + sizeof(MBin) + sizeof(MCrop) + sizeof(MCommon) + sizeof(GeomConst) + 160 <= 4096,
+                "k_mbatch: kernel arguments beyond 4 KB");
+  const unsigned ub = U.count ? unsigned((e->ncell + kUpdCells - 1u) / kUpdCells) : 0u;
+  // rows as wide as the widest scan; the update's blocks fill as many leading rows as they need
+  unsigned gx = 0u;
+  for (unsigned k = 0; k < B.count; ++k) gx = std::max(gx, (B.n[k] + kMBlock - 1u) / kMBlock);
+  for (unsigned k = 0; k < Cn.count; ++k) gx = std::max(gx, (Cn.n[k] + kMBlock - 1u) / kMBlock);
+  if (gx == 0u) gx = std::min(ub, 64u);
+  if (gx == 0u) return FDM_OK;
+  const unsigned urows = (ub + gx - 1u) / gx, rows = urows + B.count + Cn.count;
+  MCommon Kt = K;
+  Kt.timeline = (e->d_timeline && gx * rows <= e->timeline_cap && B.count) ? e->d_timeline : nullptr;
+  if (Kt.timeline) { e->timeline_blocks = gx * rows; e->timeline_upd = gx; e->timeline_bin = urows; }
   return with_policy(e, [&](auto tag, const auto& layers) -> int {
     using POLICY = decltype(tag);
     if constexpr (is_rec_policy<POLICY>) {
-      return with_channels(u.ch, [&](auto chc) -> int {
+      return with_channels(ch, [&](auto chc) -> int {
         constexpr int CH = decltype(chc)::value;
-        hipLaunchKernelGGL((k_mupdate<POLICY, CH>), dim3(e->n_tiles), dim3(256), 0, e->stream, u.MB, e->G, e->d_state,
-                           layers, e->d_layer_ptrs, e->n_layer_ptrs, unsigned(e->ncell));
+        hipLaunchKernelGGL((k_mbatch<POLICY, CH>), dim3(gx, rows), dim3(256), 0, e->stream, U, B, Cn, Kt, e->G,
+                           e->d_state, layers, e->d_layer_ptrs, e->n_layer_ptrs, unsigned(e->ncell), ub, urows);
         HIPCK(hipGetLastError());
         return FDM_OK;
       });
     } else {
-      return fail(FDM_ERR_INVALID, "internal: batch update with a per-layer policy");
+      return fail(FDM_ERR_INVALID, "internal: batch launch with a per-layer policy");
     }
   });
 }
 
-// `count` (2 .. kMaxBatch) scans that multi_run() accepted: parameter upload, then the bin launch of this batch —
-// fused with the held-back update of the previous batch when there is one.  This batch's update is held back.
-int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) {
+// The held-back update of a batch on its own (launch_update_alone forwards here).
+int launch_multi_update(fdm_engine* e, const fdm_engine::PendingUpdate& u) {
+  MBin B;
+  MCrop Cn;
+  MCommon K;
+  std::memset(&B, 0, sizeof(B));
+  std::memset(&Cn, 0, sizeof(Cn));
+  std::memset(&K, 0, sizeof(K));
+  return launch_mbatch(e, u.ch, u.MU, B, Cn, K);
+}
+
+// `count` (2 .. kMaxBatch) scans that multi_run() accepted leave as ONE launch: the held-back update of the previous
+// batch (when there is one), this batch's bin, and — `next_count` > 0 — the crop pass of the batch the caller will
+// enqueue next (scans[count .. count + next_count)).  This batch's update is held back.
+int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, uint32_t next_count) {
   int rc;
   const fdm_device_scan& f = scans[0];
   const bool hi = f.intensity != nullptr, hc = f.rgb != nullptr, hv = f.sigma_z2 != nullptr;
@@ -117,106 +144,118 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) {
   // a held-back update of another kind (single scan, other channels) leaves first
   if (e->chain && !(e->pend.multi && e->pend.ch == ch) && (rc = join_streams(e))) return rc;
 
-  MScanBlock blk;
-  MBatch B;
-  std::memset(&blk, 0, sizeof(blk));
+  MBin B;
+  MCrop Cn;
+  MCommon K;
+  MUpd U;
   std::memset(&B, 0, sizeof(B));
+  std::memset(&Cn, 0, sizeof(Cn));
+  std::memset(&K, 0, sizeof(K));
+  std::memset(&U, 0, sizeof(U));
   size_t max_n = 0;
   unsigned blocks = 0;
   ScanParams P;
   for (uint32_t k = 0; k < count; ++k) {
     const fdm_device_scan& s = scans[k];
     fill_integrate_params(e, P, s.T_base_sensor, s.T_world_base);
-    MScan& m = blk.s[k];
-    std::memcpy(m.Tbs, P.Tbs, sizeof(m.Tbs));
-    std::memcpy(m.Twb, P.Twb, sizeof(m.Twb));
-    std::memcpy(m.R, P.R, sizeof(m.R));
-    m.n = uint32_t(s.n);
-    m.robot_x = P.robot_x;
-    m.robot_y = P.robot_y;
-    m.x = s.x; m.y = s.y; m.z = s.z; m.intensity = s.intensity; m.rgb = s.rgb; m.var = s.sigma_z2;
-    m.scan_no = uint32_t(e->scan_no + k);
+    for (int c = 0; c < 4; ++c)
+      for (int r = 0; r < 3; ++r) B.t[k].Twb[c * 3 + r] = P.Twb[c * 4 + r];
+    std::memcpy(B.t[k].R, P.R, sizeof(P.R));
+    B.n[k] = uint32_t(s.n);
+    B.px[k] = s.x; B.py[k] = s.y; B.pz[k] = s.z; B.pint[k] = s.intensity; B.prgb[k] = s.rgb; B.pvar[k] = s.sigma_z2;
     B.first_block[k] = blocks;
     B.robot_x[k] = P.robot_x;
     B.robot_y[k] = P.robot_y;
-    blocks += unsigned((s.n + 255u) / 256u);
+    blocks += unsigned((s.n + kMBlock - 1u) / kMBlock);
     max_n = std::max<size_t>(max_n, s.n);
   }
   for (uint32_t k = count; k <= uint32_t(kMaxBatch); ++k) B.first_block[k] = blocks;
   if ((rc = ensure_multi(e, max_n, blocks))) return rc;
 
-  const int par = e->mparity;
-  e->mparity ^= 1;
+  K.min_sq = P.min_sq; K.max_sq = P.max_sq; K.z_min = P.z_min; K.z_max = P.z_max;
+  sensor_params(e->cfg, K.sensor_type, K.sp);
+  std::memcpy(K.Tbs, P.Tbs, sizeof(K.Tbs));
+  K.integrate_mode = 1;
+  K.do_move = P.do_move;
+  K.gate_on_filter = P.gate_on_filter;
+  K.has_var = hv ? 1 : 0;
+  K.bin_table = e->bin_table;
+  K.dbg = e->dbg_batch;
+
+  const unsigned seq = e->mseq++;
+  const int slot = int(seq % unsigned(kMStates)), par = int(seq & 1u);
+  // the crop pass that ran one launch ahead left this batch's pass bits in its state word — if it was for THIS batch
+  const bool pre = e->pre_valid && e->pre_scans == scans && e->pre_count == count && e->pre_seq == seq;
+  if (e->pre_valid && !pre)  // (bits of a batch that never came: not expected inside one call)
+    HIPCK(hipMemsetAsync(e->mstate[slot].flags, 0, sizeof(unsigned) * kLineWords, e->stream));
+  e->pre_valid = false;
   B.count = count;
   B.scan_no0 = uint32_t(e->scan_no);
-  B.scans = e->mscans + size_t(par) * kMaxBatch;
-  B.ms = e->mstate + par;
+  B.ms = e->mstate + slot;
   const bool fuse = e->chain && e->pend.multi;  // (same channels: checked above)
-  B.prev = fuse ? e->pend.MB.ms : nullptr;
-  B.prev_count = fuse ? e->pend.MB.count : 0u;
+  B.prev = fuse ? e->pend.MU.ms : nullptr;
+  B.prev_count = fuse ? e->pend.MU.count : 0u;
   B.obs_stride = unsigned(e->mobs_stride);
+  B.pre = pre ? 1u : 0u;
   B.key = e->mkey[par];
   B.aux = e->maux[par];
   B.zs = e->mzs[par];
   B.obs = e->mobs[par];
   B.cobs = e->mcobs[par];
   B.bin_part = e->mbin_part[par];
-  B.upd_part = e->S.upd_part;
-  B.min_sq = P.min_sq; B.max_sq = P.max_sq; B.z_min = P.z_min; B.z_max = P.z_max;
-  sensor_params(e->cfg, B.sensor_type, B.sp);
-  B.integrate_mode = 1;
-  B.do_move = P.do_move;
-  B.gate_on_filter = P.gate_on_filter;
-  B.has_var = hv ? 1 : 0;
-  B.bin_table = e->bin_table;
+  if (fuse) U = e->pend.MU;
 
-  hipLaunchKernelGGL(k_mput, dim3(1), dim3(256), 0, e->stream, blk, const_cast<MScan*>(B.scans), count, B.ms);
-  HIPCK(hipGetLastError());
-  if (fuse) {
-    const fdm_engine::PendingUpdate& u = e->pend;
-    e->chain = false;
-    rc = with_policy(e, [&](auto tag, const auto& layers) -> int {
-      using POLICY = decltype(tag);
-      if constexpr (is_rec_policy<POLICY>) {
-        return with_channels(ch, [&](auto chc) -> int {
-          constexpr int CH = decltype(chc)::value;
-          hipLaunchKernelGGL((k_mupdate_mbin<POLICY, CH>), dim3(e->n_tiles + blocks), dim3(256), 0, e->stream, u.MB,
-                             e->G, e->d_state, layers, e->d_layer_ptrs, e->n_layer_ptrs, unsigned(e->ncell),
-                             e->n_tiles, B);
-          HIPCK(hipGetLastError());
-          return FDM_OK;
-        });
-      } else {
-        return fail(FDM_ERR_INVALID, "internal: batch update with a per-layer policy");
-      }
-    });
-    if (rc) return rc;
-  } else {
-    rc = with_channels(ch, [&](auto chc) -> int {
-      constexpr int CH = decltype(chc)::value;
-      hipLaunchKernelGGL((k_mbin<CH>), dim3(blocks), dim3(256), 0, e->stream, B, e->G, e->d_state, unsigned(e->ncell));
-      HIPCK(hipGetLastError());
-      return FDM_OK;
-    });
-    if (rc) return rc;
+  // crop pass for the batch after this one (only a gated LOCAL-mode chain depends on it)
+  if (next_count >= 2u && K.do_move && K.gate_on_filter && e->batch_crop &&
+      std::memcmp(scans[count].T_base_sensor, f.T_base_sensor, 16 * sizeof(double)) == 0) {
+    unsigned cb = 0;
+    for (uint32_t k = 0; k < next_count; ++k) {
+      const fdm_device_scan& s = scans[count + k];
+      Cn.first_block[k] = cb;
+      Cn.n[k] = uint32_t(s.n);
+      Cn.px[k] = s.x; Cn.py[k] = s.y; Cn.pz[k] = s.z;
+      cb += unsigned((s.n + kMBlock - 1u) / kMBlock);
+    }
+    for (uint32_t k = next_count; k <= uint32_t(kMaxBatch); ++k) Cn.first_block[k] = cb;
+    Cn.count = next_count;
+    Cn.ms = e->mstate + int((seq + 1u) % unsigned(kMStates));
+    e->pre_valid = true;
+    e->pre_scans = scans + count;
+    e->pre_count = next_count;
+    e->pre_seq = seq + 1u;
   }
-  // this batch's update is held back
+  e->chain = false;
+  if ((rc = launch_mbatch(e, ch, U, B, Cn, K))) return rc;
+
+  // this batch's update is held back (option "batch_fuse" 0: launched at once, for per-kernel measurements)
+  MUpd& N = e->pend.MU;
+  std::memset(&N, 0, sizeof(N));
+  N.count = count;
+  N.scan_no0 = B.scan_no0;
+  N.obs_stride = B.obs_stride;
+  N.do_move = K.do_move;
+  N.gate_on_filter = K.gate_on_filter;
+  N.ms = B.ms;
+  N.rearm = e->mstate + int((seq + 3u) % unsigned(kMStates));
+  N.key = B.key; N.aux = B.aux; N.zs = B.zs; N.obs = B.obs; N.cobs = B.cobs;
+  N.upd_part = e->mupd_part;
   e->pend.multi = true;
-  e->pend.MB = B;
   e->pend.ch = ch;
   e->pend.tiled = false;
   e->chain = true;
   e->last_do_move = P.do_move;
   e->last_gate = P.gate_on_filter;
+  if (!e->batch_fuse && (rc = join_streams(e))) return rc;
   // bookkeeping as enqueue_scan leaves it after the batch's last scan
   const fdm_device_scan& l = scans[count - 1u];
   e->last_kind = 0;
   e->last_bin_blocks = blocks - B.first_block[count - 1u];
   e->last_bin_part = B.bin_part + B.first_block[count - 1u];
-  e->last_upd_tiles = e->n_tiles;
-  e->last_upd_part = e->S.upd_part;
+  e->last_upd_tiles = unsigned((e->ncell + kUpdCells - 1u) / kUpdCells);
+  e->last_upd_part = e->mupd_part;
   e->ray_timed = false;
   e->scan_no += count;
+  e->last_batch_n = int(count);
   e->have_scan = true;
   e->last_n = uint32_t(l.n);
   e->last_n_input = uint32_t(l.n);

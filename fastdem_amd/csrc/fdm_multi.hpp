@@ -1,38 +1,43 @@
-// fdm_multi.hpp — a BATCH of small scans in two launches instead of one launch per scan.
+// fdm_multi.hpp — a BATCH of small scans in ONE launch instead of one launch per scan.
 //
 // Why: a VLP-16 scan (28.8 K points, 113 bin blocks, 88 update blocks) is launch- and
-// latency-bound: one fused launch per scan costs ~6 us of which ~3 us is the queue's own per-kernel floor.
-// fdm_engine_integrate_device_batch sees its scans up front, so up to kMaxBatch of them are binned by ONE
-// launch into per-scan scratch sets, and ONE update launch lets every cell thread apply the batch's
-// observations in scan order.  Per cell the reference only fixes the order of the scans
-// (elevation_mapping.cpp:94-125: one independent update per observed cell and scan; GridMap::move strips and
-// the obstacle-layer clear happen between scans), and that order is kept exactly — the map after the batch is
-// bit-identical to integrating the scans one by one.  As in the single-scan path the update of batch b is held
-// back and shares its launch with the bin of batch b+1 (k_mupdate_mbin).
+// latency-bound: one fused launch per scan costs ~6 us — ~3 us of it the queue's own per-kernel floor, the rest
+// two or three dependent memory round trips of ~3 us each under load.  fdm_engine_integrate_device_batch sees its
+// scans up front, so up to kMaxBatch of them are binned by one launch into per-scan scratch sets and every cell
+// thread of the update applies the batch's observations in scan order.  Per cell the reference only fixes the
+// order of the scans (elevation_mapping.cpp:94-125: one independent update per observed cell and scan;
+// GridMap::move strips and the obstacle-layer clear happen between scans), and that order is kept exactly — the
+// map after the batch is bit-identical to integrating the scans one by one.
 //
-//   k_mput          the per-scan parameters (transforms, pose, array pointers) travel as kernel arguments of a
-//                   one-block kernel that stores them into a device table: no copy command on the stream.
-//   mbin_body       k_bin's body (one point per thread, wave-merge + per-block LDS cell table, memory-side atomics
-//                   on the block's unique cells) for scan k of the batch.  Two things are new:
-//                   * the geometry chain.  Scan k is binned against the map geometry AFTER the LOCAL-mode moves of
-//                     scans 0..k, and whether scan j moved the map depends on whether any of its points survived
-//                     the crops (fastdem.cpp:138).  Every wavefront-0 of a block publishes "my block is past
-//                     the crops, it had / had no surviving point" with one atomic on done[k] and then waits for
-//                     the blocks of scans < k (a block only ever waits for blocks with a LOWER block index, which
-//                     the dispatcher started earlier and which never wait before publishing: no deadlock; the
-//                     spin is bounded and raises MState::err instead of hanging).  Thread 0 then walks the chain
-//                     of k moves (move_candidate_fast: no fp64 divide on the common path).
-//                   * no second look at the scan.  The thread that merges a block-local minimum into the scratch
-//                     also evaluates that point's sigma_z^2 (the block keeps its points' sensor-frame coordinates
-//                     in LDS) and stores {map-frame z, sigma_z^2} at the POINT's index in an observation array;
-//                     likewise the colour of a block-local last point.  The update finds the winner's entry through
-//                     the index in the reduced key — one 8-byte gather, no transforms, no per-scan parameters —
-//                     and the caller's arrays are dead as soon as the bin launch has run.
-//   mupdate_body    one thread per cell, one block per 256-cell tile (memory order).  Round trip 1: the cell's
-//                   keys of all scans, its estimator record, the per-scan geometry.  Then a per-lane event loop
-//                   over the scans that touched the cell: {obs, aux, zs} loads, strips vacated since the previous
-//                   event, estimator step in registers.  One record store at the end.
+// One launch per batch, k_mbatch = [ update of batch b-1 | bin of batch b | crop pass of batch b+1 ]:
 //
+//   crop half    Scan k is binned against the map geometry AFTER the LOCAL-mode moves of scans 0..k, and whether
+//                scan j moved the map depends on whether any of its points survived the crops (fastdem.cpp:138) —
+//                device-side data.  The crops need no geometry, so they are evaluated ONE LAUNCH AHEAD: a light
+//                pass over the next batch's points (first transform + cropRange + cropZ, the same float
+//                operations the bin half will run) ORs "scan k has a surviving point" into the next batch's
+//                state word; the kernel boundary is the barrier.  It also pulls the next batch's points into the
+//                cache.  Without a look-ahead (the first batch of a call, a lone batch) the bin half falls back to
+//                an in-launch protocol: every block publishes with one atomic on its scan's own cache line, the
+//                block that completes a scan raises its bits in the state word, later scans' blocks poll that ONE
+//                word (a block only ever waits for blocks with a lower index, which never wait before publishing:
+//                no deadlock; the spin is bounded and raises MState::err instead of hanging).
+//   bin half     k_bin's body (one point per thread, wave-merge + per-block LDS cell table, memory-side atomics on
+//                the block's unique cells) for scan k of the batch; thread 0 walks the chain of k moves
+//                (move_candidate_fast: no fp64 divide on the common path) while the point loads are in flight.
+//                No second look at the scan: the thread that merges a block-local minimum into the scratch also
+//                evaluates that point's sigma_z^2 (the block keeps its points' sensor-frame coordinates in LDS) and
+//                stores {map-frame z, sigma_z^2} at the POINT's index in an observation array; likewise the colour
+//                of a block-local last point.  The update finds the winner's entry through the index in the
+//                reduced key, and the caller's arrays are dead as soon as the launch has run.
+//   update half  one thread per cell, one block per 256-cell tile (memory order).  Round trip 1: the cell's keys of
+//                all scans, its estimator record, the per-scan geometry.  The block's (cell, scan) events are then
+//                compacted into an LDS list and spread evenly over the threads: round trip 2 fetches {aux, zs,
+//                obs} of ALL events at once (a thread holds 2-3 of them whatever their distribution over the
+//                cells), the observations go back through LDS to the cell threads, which walk their events in scan
+//                order: strips vacated since the previous event, estimator step in registers, one record store.
+//
+// All per-batch parameters travel as kernel arguments (< 4 KB): no copy command, no upload kernel.
 // Algorithmic bytes are per scan what they were: 12 B/point (+4 intensity, +4 colour), 72 / 124 B per
 // touched cell, 4 B per map cell per scan for the obstacle clear.
 #pragma once
@@ -41,39 +46,47 @@
 
 namespace fdm {
 
-constexpr int kMaxBatch = 16;          // scans per launch: one k_mput argument block (16 x 240 B < 4 KB)
+constexpr int kMaxBatch = 16;            // scans per launch (one bit per scan in 16-bit halves of a state word)
 constexpr unsigned kSpinMax = 1u << 22;  // polls before a waiting block gives up (seconds; never reached in practice)
+constexpr int kLineWords = 32;           // a 128-byte line of 32-bit words
+#ifndef FDM_MB_WAVES
+#define FDM_MB_WAVES 6  // waves per SIMD k_mbatch is compiled for (<= 80 VGPRs; the LDS allows 6 blocks per CU): every block of a 16-scan VLP-16 batch resident at once
+#endif
+constexpr int kMStates = 4;              // ring of batch states: update b-1 | bin b | crop b+1 | being re-armed
 
-struct MScan {  // what is particular to one scan of a batch (240 B)
-  float Tbs[16], Twb[16], R[9];  // as ScanParams
-  unsigned n;
-  double robot_x, robot_y;
-  const float *x, *y, *z, *intensity;
-  const uint32_t* rgb;
-  const float* var;
-  unsigned scan_no, pad;
-};
-struct MScanBlock { MScan s[kMaxBatch]; };
-
-// Device-resident bookkeeping of one batch (double-buffered by batch parity).
+// Device-resident bookkeeping of one batch.  Every word other blocks poll or add to sits on its own 128-byte
+// line: pollers of `flags` must not queue up in front of the adds to `done`.
 struct MState {
   DevGeom E[kMaxBatch];        // geometry before scan k (written by the scan's first bin block)
   DevCand C[kMaxBatch];        // geometry after its move + the index shift
-  unsigned done[kMaxBatch];    // blocks of scan k past the crops (low 16 bits) | blocks with a surviving point << 16
+  unsigned done[kMaxBatch * kLineWords];  // [k * 32]: blocks of scan k past the crops | blocks with a surviving point << 16
+  unsigned flags[kLineWords];  // [0]: bit k = every block of scan k is past the crops, bit 16 + k = scan k has a surviving point
   unsigned inside[kMaxBatch];  // some point of scan k landed in the map (elevation_mapping.cpp:118)
   unsigned err;                // a waiting block ran out of polls
-  unsigned pad[3];
+  unsigned pad[15];
 };
 
-struct MBatch {  // kernel argument
-  unsigned count;                        // scans in the batch
-  unsigned scan_no0;                     // number of its first scan
+struct MCommon {  // what all scans of a batch share
+  float min_sq, max_sq, z_min, z_max;
+  float sp[4];
+  float Tbs[16];  // T_base_sensor (one sensor per batch: a scan with another extrinsic closes the batch)
+  int sensor_type, integrate_mode, do_move, gate_on_filter, has_var, bin_table;
+  int dbg, pad;                  // measurement only (results are wrong): 1 = no scratch atomics, 2 = no chain walk
+  unsigned long long* timeline;  // measurement only (nullable): {start, end} of every block in 100 MHz ticks
+};
+struct MScanT {   // per scan: T_world_base without its constant last row (0 0 0 1), column-major 3 x 4 | rotation of the product
+  float Twb[12], R[9];
+};
+struct MBin {     // bin half: batch b
+  unsigned count, scan_no0;
   unsigned first_block[kMaxBatch + 1];   // bin blocks before scan k
-  const MScan* scans;                    // device table (bin half only)
+  unsigned n[kMaxBatch];                 // points of scan k
   MState* ms;
-  const MState* prev;                    // bin half: the previous batch's state while its update is still held back
+  const MState* prev;                    // the previous batch's state while its update shares this launch (else null)
   unsigned prev_count;
   unsigned obs_stride;                   // points per scan slot of obs / cobs
+  unsigned pre;                          // 1: the crop pass of the previous launch left the batch's pass bits in ms->flags
+  unsigned pad;
   // per-scan scratch, slot k at + k * ncell (key, aux, zs as in Scratch)
   unsigned long long* key;
   uint4* aux;
@@ -81,144 +94,253 @@ struct MBatch {  // kernel argument
   float2* obs;                           // [count][obs_stride] {map-frame z, sigma_z^2} of block-local minima, by point index
   uint32_t* cobs;                        // [count][obs_stride] colour of block-local last points, by point index
   unsigned long long* bin_part;          // [bin blocks]
-  uint32_t* upd_part;                    // [tiles] of the batch's LAST scan
-  // what all scans of the batch share
-  float min_sq, max_sq, z_min, z_max;
-  float sp[4];
-  int sensor_type, integrate_mode, do_move, gate_on_filter, has_var, bin_table;
   double robot_x[kMaxBatch], robot_y[kMaxBatch];  // T_world_base translation of every scan (the chain of moves)
+  const float* px[kMaxBatch];
+  const float* py[kMaxBatch];
+  const float* pz[kMaxBatch];
+  const float* pint[kMaxBatch];
+  const uint32_t* prgb[kMaxBatch];
+  const float* pvar[kMaxBatch];
+  MScanT t[kMaxBatch];
+};
+struct MUpd {     // update half: batch b-1
+  unsigned count, scan_no0, obs_stride;
+  int do_move, gate_on_filter;
+  unsigned pad;
+  MState* ms;
+  MState* rearm;                         // the state of the batch after next: zeroed by the committing block
+  unsigned long long* key;
+  uint4* aux;
+  uint2* zs;
+  const float2* obs;
+  const uint32_t* cobs;
+  uint32_t* upd_part;                    // [update blocks] cells touched by the batch's LAST scan
+};
+struct MCrop {    // crop half: batch b+1 (count == 0: none)
+  unsigned count, pad;
+  unsigned first_block[kMaxBatch + 1];
+  unsigned n[kMaxBatch];
+  MState* ms;
+  const float* px[kMaxBatch];
+  const float* py[kMaxBatch];
+  const float* pz[kMaxBatch];
 };
 
-// The members preprocess_point / sigma_z2 read, by name (pointers only: an array member copied in device code is
-// spilled, see DevObst).
+// The members the arithmetic reads, by name (pointers only: an array member copied in device code is spilled,
+// see DevObst).
 struct MView {
   const float* Tbs;
-  const float* Twb;
+  const float* Twb12;
   const float* R;
   const float* sp;
   float min_sq, max_sq, z_min, z_max;
   int sensor_type, integrate_mode;
 };
 
-// Parameter upload + re-arm of the batch's counters (the set was last read by the update two launches ago).
-__global__ __launch_bounds__(256) void k_mput(const MScanBlock src, MScan* __restrict__ dst, unsigned count,
-                                              MState* __restrict__ ms) {
-  const uint32_t* s = reinterpret_cast<const uint32_t*>(&src);
-  uint32_t* d = reinterpret_cast<uint32_t*>(dst);
-  const unsigned words = count * unsigned(sizeof(MScan) / 4);
-  for (unsigned i = threadIdx.x; i < words; i += 256u) d[i] = s[i];
-  if (threadIdx.x < unsigned(kMaxBatch)) {
-    ms->done[threadIdx.x] = 0u;
-    ms->inside[threadIdx.x] = 0u;
+// p <- T * p for a T whose last row is (0 0 0 1), stored without it: the same products and sums, in the same
+// order, as transform4 on the full matrix (the row's coefficients are the literals 0 and 1).
+__device__ __forceinline__ void transform4_affine(const float* __restrict__ t12, float& x, float& y, float& z, float& w) {
+  float o[4];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    float acc = t12[0 + r] * x;
+    acc = t12[3 + r] * y + acc;
+    acc = t12[6 + r] * z + acc;
+    acc = t12[9 + r] * w + acc;
+    o[r] = acc;
   }
+  {
+    float acc = 0.0f * x;
+    acc = 0.0f * y + acc;
+    acc = 0.0f * z + acc;
+    acc = 1.0f * w + acc;
+    o[3] = acc;
+  }
+  x = o[0]; y = o[1]; z = o[2]; w = o[3];
+}
+// first half of preprocess_point (T_base_sensor, cropRange, cropZ): does the point survive?  w rides along.
+__device__ __forceinline__ bool mcrops(const MView& V, float& x, float& y, float& z, float& w) {
+  w = 1.0f;
+  transform4(V.Tbs, x, y, z, w);
+  const float d2 = sum3(x * x, y * y, z * z);
+  bool pass = (d2 >= V.min_sq) && (d2 <= V.max_sq);
+  pass = pass && (z >= V.z_min) && (z <= V.z_max);
+  return pass;
+}
+
+// LDS of one block: the bin half's cell table + point staging, or the update half's event exchange.
+constexpr int kEvCap = 512;  // (cell, scan) events of a 256-cell tile exchanged per round (two per thread)
+constexpr int kMPts = 2;                 // points per thread of the bin half: 512-point blocks — half the blocks (every block
+constexpr unsigned kMBlock = 256u * kMPts;  // of a 16-scan batch resident beside the update half) and ~20 % fewer (block, cell) pairs
+struct MBinLds {
+  unsigned long long t_key[kMBlock];
+  uint32_t t_cell[kMBlock], t_zmx[kMBlock], t_imx[kMBlock], t_fst[kMBlock], t_lst[kMBlock];
+  float4 s_pt[kMBlock];  // sensor-frame x, y, z | map-frame z of the block's points
+  uint16_t s_list[kMBlock];  // the occupied table slots, compacted for the flush
+  DevCand s_cand;
+  unsigned s_pass[4], s_in[4], s_occ[4 * kMPts];
+};
+struct MEvent { uint32_t idx; uint16_t cell, k; };  // winner's point index | cell in tile | scan
+struct MObs { float min_z, var, max_z, iobs; };
+template <bool COL>
+struct MUpdLds {
+  MEvent ev[kEvCap];
+  MObs ob[kEvCap];
+  uint32_t rgb[COL ? kEvCap : 1];
+  unsigned s_w[4], s_t[4];
+};
+template <bool COL>
+constexpr unsigned kMLdsBytes = sizeof(MUpdLds<COL>) > sizeof(MBinLds) ? sizeof(MUpdLds<COL>) : sizeof(MBinLds);
+
+// ---------------------------------------------------------------------------------------------
+// crop half: block `bid` of the NEXT batch's grid — kMBlock points per block, like its bin half will be.
+__device__ __forceinline__ void mcrop_body(const MCrop& Cn, const MCommon& K, const unsigned k, const unsigned lb,
+                                           unsigned* s_any) {
+  const unsigned lane = threadIdx.x & 63u;
+  MView V;
+  V.Tbs = K.Tbs; V.Twb12 = nullptr; V.R = nullptr; V.sp = K.sp;
+  V.min_sq = K.min_sq; V.max_sq = K.max_sq; V.z_min = K.z_min; V.z_max = K.z_max;
+  V.sensor_type = K.sensor_type; V.integrate_mode = K.integrate_mode;
+  bool pass = false;
+#pragma unroll
+  for (int h = 0; h < kMPts; ++h) {
+    const unsigned i = lb * kMBlock + unsigned(h) * 256u + threadIdx.x;
+    if (i < Cn.n[k]) {
+      float x = Cn.px[k][i], y = Cn.py[k][i], z = Cn.pz[k][i], w;
+      pass = mcrops(V, x, y, z, w) || pass;
+    }
+  }
+  // one OR per block is plenty: ~100 blocks per scan on one word, fire and forget
+  if (threadIdx.x == 0) *s_any = 0u;
+  __syncthreads();
+  if (__ballot(pass) && lane == 0u) *s_any = 1u;
+  __syncthreads();
+  if (threadIdx.x == 0 && *s_any) atomicOr(&Cn.ms->flags[0], 0x10000u << k);
 }
 
 // ---------------------------------------------------------------------------------------------
 // bin half: block `bid` of the batch's bin grid.  CH: bit 0 intensity, bit 1 colour (compile-time, as k_bin's).
 template <int CH>
-__device__ __forceinline__ void mbin_body(const MBatch& B, const GeomConst& G, DevState* __restrict__ st,
-                                          const unsigned ncell, const unsigned bid) {
+__device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const GeomConst& G,
+                                          DevState* __restrict__ st, const unsigned ncell, const unsigned k,
+                                          const unsigned lb, MBinLds& S) {
+  // (scan k of the batch and the block's number inside the scan come straight from the grid: nothing to look up
+  // before the point loads can leave)
   constexpr bool has_int = (CH & 1) != 0, has_col = (CH & 2) != 0;
-  __shared__ DevCand s_cand;
-  __shared__ unsigned s_pass[4], s_in[4];
-  __shared__ unsigned long long t_key[256];
-  __shared__ uint32_t t_cell[256], t_zmx[256], t_imx[256], t_fst[256], t_lst[256];
-  __shared__ float4 s_pt[256];  // sensor-frame x, y, z | map-frame z of the block's points
-
-  // which scan of the batch (block-uniform): lane j asks "does scan j start at or before this block?"
-  const unsigned k = uni(unsigned(__popcll(__ballot((threadIdx.x & 63u) < B.count &&
-                                                    bid >= B.first_block[threadIdx.x & 63u])))) - 1u;
-  const MScan* __restrict__ M = B.scans + k;
-  const unsigned lb = bid - B.first_block[k];
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   MState* const ms = B.ms;
   MView V;
-  V.Tbs = M->Tbs; V.Twb = M->Twb; V.R = M->R; V.sp = B.sp;
-  V.min_sq = B.min_sq; V.max_sq = B.max_sq; V.z_min = B.z_min; V.z_max = B.z_max;
-  V.sensor_type = B.sensor_type; V.integrate_mode = B.integrate_mode;
+  V.Tbs = K.Tbs; V.Twb12 = B.t[k].Twb; V.R = B.t[k].R; V.sp = K.sp;
+  V.min_sq = K.min_sq; V.max_sq = K.max_sq; V.z_min = K.z_min; V.z_max = K.z_max;
+  V.sensor_type = K.sensor_type; V.integrate_mode = K.integrate_mode;
+  const float* __restrict__ const px = B.px[k];
+  const float* __restrict__ const py = B.py[k];
+  const float* __restrict__ const pz = B.pz[k];
 
-  {
-    t_key[threadIdx.x] = kEmptyKey;
-    t_cell[threadIdx.x] = kEmptyCell;
-    t_zmx[threadIdx.x] = 0u; t_imx[threadIdx.x] = 0u; t_fst[threadIdx.x] = kNoIdx; t_lst[threadIdx.x] = 0u;
-  }
-  const unsigned n = M->n;
-  const unsigned i = lb * 256u + threadIdx.x;
-  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  float x = 0.f, y = 0.f, z = 0.f, vint = 0.f;
-  if (i < n) {
-    x = M->x[i];
-    y = M->y[i];
-    z = M->z[i];
-    if (has_int) vint = M->intensity[i];
-  }
-  // the crops need no geometry: run them first, publish, then wait for the earlier scans
-  const float sx = x, sy = y, sz = z;
-  bool pass = false;
-  if (i < n) pass = preprocess_point(V, x, y, z);
-  s_pt[threadIdx.x] = make_float4(sx, sy, sz, z);
-  {
-    const unsigned long long mp = __ballot(pass);
-    if (lane == 0u) s_pass[wave] = unsigned(__popcll(mp));
-  }
-  __syncthreads();  // table, s_pt, s_pass
-  const unsigned np = s_pass[0] + s_pass[1] + s_pass[2] + s_pass[3];
-  if (threadIdx.x < 64u) {
-    if (lane == 0u) atomicAdd(&ms->done[k], 1u | (np ? 0x10000u : 0u));
-    unsigned passmask = 0xFFFFFFFFu;
-    if (B.do_move && B.gate_on_filter && k > 0u) {
-      unsigned v = 0u, spins = 0u;
-      const unsigned want = lane < k ? B.first_block[lane + 1u] - B.first_block[lane] : 0u;
-      while (true) {
-        bool ok = true;
-        if (lane < k) {
-          v = __hip_atomic_load(&ms->done[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = (v & 0xFFFFu) == want;
-        }
-        if (__ballot(!ok) == 0ull) break;
-        if (++spins >= kSpinMax) {
-          if (lane == 0u) ms->err = 1u;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(2);  // (~128 clocks: keeps the pollers off the memory pipeline)
-      }
-      passmask = unsigned(__ballot(lane < k && (v >> 16) != 0u));
-    }
-    if (lane == 0u) {
-      DevGeom g;
-      if (B.prev) {  // what the held-back update of the previous batch is about to commit
-        const unsigned pk = B.prev_count - 1u;
-        g = B.prev->E[pk];
-        if (B.do_move && (!B.gate_on_filter || (B.prev->done[pk] >> 16) != 0u)) {
-          const DevCand pc = B.prev->C[pk];
-          g.px = pc.px; g.py = pc.py; g.sr = pc.sr; g.sc = pc.sc;
-        }
-      } else {
-        g = st->geom[B.scan_no0 & 3u];
-      }
-      if (B.do_move) {
-        for (unsigned j = 0; j < k; ++j) {
-          if (B.gate_on_filter && !((passmask >> j) & 1u)) continue;  // scan j returned before its move
-          const DevCand cj = move_candidate_fast(g, G, B.robot_x[j], B.robot_y[j]);
-          g.px = cj.px; g.py = cj.py; g.sr = cj.sr; g.sc = cj.sc;
-        }
-      }
-      DevCand c;
-      if (B.do_move) {
-        c = move_candidate_fast(g, G, B.robot_x[k], B.robot_y[k]);
-      } else {
-        c.px = g.px; c.py = g.py; c.sr = g.sr; c.sc = g.sc; c.shr = 0; c.shc = 0;
-      }
-      s_cand = c;
-      if (lb == 0u) { ms->E[k] = g; ms->C[k] = c; }
+  const unsigned n = B.n[k];
+  const unsigned i0 = lb * kMBlock + threadIdx.x;  // the thread's points: i0, i0 + 256 (two coalesced sweeps)
+  float xs[kMPts], ys[kMPts], zs[kMPts], vs[kMPts];
+#pragma unroll
+  for (int h = 0; h < kMPts; ++h) {  // the loads go out first
+    const unsigned i = i0 + unsigned(h) * 256u;
+    xs[h] = ys[h] = zs[h] = vs[h] = 0.f;
+    if (i < n) {
+      xs[h] = px[i];
+      ys[h] = py[i];
+      zs[h] = pz[i];
+      if (has_int) vs[h] = B.pint[k][i];
     }
   }
-  __syncthreads();
-  const DevCand cand = s_cand;
+#pragma unroll
+  for (int h = 0; h < kMPts; ++h) {
+    const unsigned t = threadIdx.x + unsigned(h) * 256u;
+    S.t_key[t] = kEmptyKey;
+    S.t_cell[t] = kEmptyCell;
+    S.t_zmx[t] = 0u; S.t_imx[t] = 0u; S.t_fst[t] = kNoIdx; S.t_lst[t] = 0u;
+  }
+  // the chain of moves up to this scan, given which of the earlier scans moved the map.  Lane j of the first
+  // wavefront holds scan j's pose, so that the walk (thread 0) never waits for memory between two moves.
+  double pose_x = 0.0, pose_y = 0.0;
+  if (threadIdx.x < 64u && lane <= k) { pose_x = B.robot_x[lane]; pose_y = B.robot_y[lane]; }
+  auto lane_f64 = [](double v, unsigned j) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), int(j));
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), int(j));
+    return __hiloint2double(hi, lo);
+  };
+  auto chain = [&](unsigned passmask) {
+    DevGeom g;
+    if (B.prev) {  // what the update of the previous batch (the other half of this launch) is about to commit
+      const unsigned pk = B.prev_count - 1u;
+      g = B.prev->E[pk];
+      if (K.do_move && (!K.gate_on_filter || ((B.prev->flags[0] >> (16u + pk)) & 1u) != 0u)) {
+        const DevCand pc = B.prev->C[pk];
+        g.px = pc.px; g.py = pc.py; g.sr = pc.sr; g.sc = pc.sc;
+      }
+    } else {
+      g = st->geom[B.scan_no0 & 3u];
+    }
+    if (K.do_move && K.dbg != 2) {
+      for (unsigned j = 0; j < k; ++j) {
+        if (K.gate_on_filter && !((passmask >> j) & 1u)) continue;  // scan j returned before its move
+        const DevCand cj = move_candidate_fast(g, G, lane_f64(pose_x, j), lane_f64(pose_y, j));
+        g.px = cj.px; g.py = cj.py; g.sr = cj.sr; g.sc = cj.sc;
+      }
+    }
+    DevCand c;
+    if (K.do_move) {
+      c = move_candidate_fast(g, G, lane_f64(pose_x, k), lane_f64(pose_y, k));
+    } else {
+      c.px = g.px; c.py = g.py; c.sr = g.sr; c.sc = g.sc; c.shr = 0; c.shc = 0;
+    }
+    S.s_cand = c;
+    if (lb == 0u) { ms->E[k] = g; ms->C[k] = c; }
+  };
+  const bool gated = K.do_move && K.gate_on_filter;
+  const bool must_wait = gated && k > 0u && !B.pre;  // block-uniform
+  if (threadIdx.x == 0 && !must_wait)  // the pass bits are known (or irrelevant): in the shadow of the point loads
+    chain((gated && k > 0u) ? (ms->flags[0] >> 16) : 0xFFFFu);
 
-  int cell = -1;
-  if (pass) cell = owned_cell(x, y, cand, G);
-  const bool inside = cell >= 0;
-  const bool glob = pass && cell != -1;
+  bool pass[kMPts];
+  unsigned npw = 0u;
+#pragma unroll
+  for (int h = 0; h < kMPts; ++h) {
+    const unsigned i = i0 + unsigned(h) * 256u;
+    const float sx = xs[h], sy = ys[h], sz = zs[h];
+    float w = 1.0f;
+    pass[h] = false;
+    if (i < n) pass[h] = mcrops(V, xs[h], ys[h], zs[h], w);
+    transform4_affine(V.Twb12, xs[h], ys[h], zs[h], w);
+    S.s_pt[threadIdx.x + unsigned(h) * 256u] = make_float4(sx, sy, sz, zs[h]);
+    npw += unsigned(__popcll(__ballot(pass[h])));
+  }
+  if (lane == 0u) S.s_pass[wave] = npw;
+  __syncthreads();  // table, s_pt, s_pass (and s_cand unless the block has to wait)
+  const unsigned np = S.s_pass[0] + S.s_pass[1] + S.s_pass[2] + S.s_pass[3];
+  if (!B.pre && gated) {  // no crop pass ran ahead of this batch: the blocks publish what they found
+    if (threadIdx.x == 0) {
+      // one add on the scan's own line; the block that completes the scan raises its two bits in `flags`
+      const unsigned mine = 1u | (np ? 0x10000u : 0u);
+      const unsigned tot = atomicAdd(&ms->done[k * kLineWords], mine) + mine;
+      if ((tot & 0xFFFFu) == B.first_block[k + 1u] - B.first_block[k])
+        atomicOr(&ms->flags[0], (1u << k) | ((tot >> 16) ? (0x10000u << k) : 0u));
+      if (must_wait) {  // ... and wait for the scans ahead: ONE word, ONE poller per block
+        const unsigned need = (1u << k) - 1u;
+        unsigned f = 0u, spins = 0u;
+        while (true) {
+          f = __hip_atomic_load(&ms->flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((f & need) == need) break;
+          if (++spins >= kSpinMax) {
+            ms->err = 1u;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(8);  // (~0.25 us: the pollers stay off the line the completing blocks write)
+        }
+        chain(f >> 16);
+      }
+    }
+    if (must_wait) __syncthreads();
+  }
+  const DevCand cand = S.s_cand;
 
   unsigned long long* const S_key = B.key + size_t(k) * ncell;
   uint32_t* const S_aux = reinterpret_cast<uint32_t*>(B.aux + size_t(k) * ncell);
@@ -229,6 +351,7 @@ __device__ __forceinline__ void mbin_body(const MBatch& B, const GeomConst& G, D
   // one cell's reduction goes to the scan's scratch; the merging thread also leaves what the update needs of the
   // block-local winner / last point at the POINT's index
   auto merge = [&](uint32_t c, unsigned long long key, uint32_t zmx, uint32_t imx, uint32_t fst, uint32_t lst) {
+    if (K.dbg == 1) return;
     atomicMin(&S_key[c], key);
     uint32_t* a = S_aux + size_t(c) * 4;
     if (zmx) atomicMax(a + 0, zmx);
@@ -238,165 +361,179 @@ __device__ __forceinline__ void mbin_body(const MBatch& B, const GeomConst& G, D
     }
     if (has_col) {
       atomicMax(a + 3, lst);
-      S_cobs[lst] = M->rgb[lst];
+      S_cobs[lst] = B.prgb[k][lst];
     }
     const uint32_t idx = uint32_t(key);
     if (idx != kNoIdx) {
-      const float4 p = s_pt[idx - lb * 256u];
+      const float4 p = S.s_pt[idx - lb * kMBlock];
       float var = 0.0f;  // CellObservation default (elevation_mapping.hpp:26-34)
-      if (B.has_var) var = M->var[idx];
-      else if (B.integrate_mode) var = sigma_z2(V, p.x, p.y, p.z);
+      if (K.has_var) var = B.pvar[k][idx];
+      else if (K.integrate_mode) var = sigma_z2(V, p.x, p.y, p.z);
       S_obs[idx] = make_float2(p.w, var);
     }
   };
 
-  unsigned long long key = kEmptyKey;
-  uint32_t zmx = 0, imx = 0, fst = kNoIdx, lst = 0;
-  if (inside) {
-    if (z == 0.0f) atomicMin(S_zs + size_t(cell) * 2, (i << 1) | (__float_as_uint(z) >> 31));
-    if (has_int && vint == 0.0f) atomicMin(S_zs + size_t(cell) * 2 + 1, (i << 1) | (__float_as_uint(vint) >> 31));
-    key = make_key(z, i);
-    zmx = make_zmax(z);
-    if (has_int) {
-      const bool vnan = isnan(vint);
-      imx = vnan ? 0u : ord(vint);
-      fst = (i << 1) | (vnan ? 1u : 0u);
-    }
-    lst = i;
-  }
-  // segmented scan over runs of equal cell in neighbouring lanes (see bin_body)
-  bool commit = inside;
-  {
+  // getIndex on a fixed-point estimate, the reference's fp64 arithmetic only for the lanes within 2^-shift cell of
+  // a cell edge (axis_fast / axis_exact, as k_tbin); every point then folds straight into the block's LDS cell
+  // table — LDS atomics are cheap, the cross-lane run merge of k_bin costs more instructions than it saves here
+  unsigned niw = 0u;
+  bool any_glob = false;
+  const bool any_start = cand.sr != 0 || cand.sc != 0;
+  const double off_r = (G.half_x + cand.px) * G.inv_res_k, off_c = (G.half_y + cand.py) * G.inv_res_k;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int ocell = __shfl_up(cell, d);
-      const unsigned long long okey = __shfl_up(key, d);
-      const uint32_t ozmx = __shfl_up(zmx, d);
-      const uint32_t oimx = __shfl_up(imx, d);
-      const uint32_t ofst = __shfl_up(fst, d);
-      if (int(lane) >= d && ocell == cell && inside) {
-        key = okey < key ? okey : key;
-        zmx = ozmx > zmx ? ozmx : zmx;
-        imx = oimx > imx ? oimx : imx;
-        fst = ofst < fst ? ofst : fst;
-      }
+  for (int h = 0; h < kMPts; ++h) {
+    const unsigned i = i0 + unsigned(h) * 256u;
+    const float x = xs[h], y = ys[h], z = zs[h], vint = vs[h];
+    bool sure_r, sure_c;
+    int kr = axis_fast(double(x), off_r, G.inv_res_k, G.idx_shift, G.rows, sure_r);
+    int kc = axis_fast(double(y), off_c, G.inv_res_k, G.idx_shift, G.cols, sure_c);
+    bool in = pass[h];
+    if (__ballot(pass[h] && !(sure_r && sure_c))) {  // wave-uniform; well under a percent of the wavefronts
+      if (pass[h] && !sure_r) in = axis_exact(double(x), cand.px, G.half_x, G.len_x, G.res, kr);
+      if (in && !sure_c) in = axis_exact(double(y), cand.py, G.half_y, G.len_y, G.res, kc);
     }
-    const int ncellv = __shfl_down(cell, 1);
-    commit = inside && (lane == 63u || ncellv != cell);
-  }
-  const bool use_table = B.bin_table && 2 * __popcll(__ballot(commit)) > __popcll(__ballot(inside));
-  if (use_table) {
-    if (commit) {
-      uint32_t h = uint32_t(cell) & 255u;
+    const bool okr = axis_wrap(kr, cand.sr, any_start, G.rows);  // (both axes are evaluated, as getIndex does)
+    const bool okc = axis_wrap(kc, cand.sc, any_start, G.cols);
+    const bool in_map = in && okr && okc;
+    const int lr = kr - G.o_r0, lc = kc - G.o_c0;
+    const bool inside = in_map && unsigned(lr) < unsigned(G.o_rows) && unsigned(lc) < unsigned(G.o_cols);
+    const int cell = (kc - G.s_c0) * G.s_rows + (kr - G.s_r0);
+    any_glob = any_glob || in_map;
+    if (inside) {
+      if (z == 0.0f) atomicMin(S_zs + size_t(cell) * 2, (i << 1) | (__float_as_uint(z) >> 31));
+      if (has_int && vint == 0.0f) atomicMin(S_zs + size_t(cell) * 2 + 1, (i << 1) | (__float_as_uint(vint) >> 31));
+      uint32_t hh = uint32_t(cell) & (kMBlock - 1u);
       while (true) {
-        const uint32_t seen = t_cell[h];
-        if (seen == uint32_t(cell)) break;
-        if (seen == kEmptyCell) {
-          const uint32_t prev = atomicCAS(&t_cell[h], kEmptyCell, uint32_t(cell));
-          if (prev == kEmptyCell || prev == uint32_t(cell)) break;
-        }
-        h = (h + 1) & 255u;
+        const uint32_t prev = atomicCAS(&S.t_cell[hh], kEmptyCell, uint32_t(cell));
+        if (prev == kEmptyCell || prev == uint32_t(cell)) break;
+        hh = (hh + 1) & (kMBlock - 1u);
       }
-      atomicMin(&t_key[h], key);
-      if (zmx) atomicMax(&t_zmx[h], zmx);
+      atomicMin(&S.t_key[hh], make_key(z, i));
+      atomicMax(&S.t_zmx[hh], make_zmax(z));  // (max with 0: no-op)
       if (has_int) {
-        if (imx) atomicMax(&t_imx[h], imx);
-        atomicMin(&t_fst[h], fst);
+        const bool vnan = isnan(vint);
+        atomicMax(&S.t_imx[hh], vnan ? 0u : ord(vint));
+        atomicMin(&S.t_fst[hh], (i << 1) | (vnan ? 1u : 0u));
       }
-      if (has_col) atomicMax(&t_lst[h], lst);
+      if (has_col) atomicMax(&S.t_lst[hh], i);
     }
-  } else if (commit) {
-    merge(uint32_t(cell), key, zmx, imx, fst, lst);
+    niw += unsigned(__popcll(__ballot(inside)));
   }
-
-  const unsigned long long mi = __ballot(inside), mg = __ballot(glob);
   if (lane == 0u) {
-    s_in[wave] = unsigned(__popcll(mi));
-    if (mg) ms->inside[k] = 1u;
+    S.s_in[wave] = niw;
+    if (__ballot(any_glob)) ms->inside[k] = 1u;
+  }
+  // ---- flush: the occupied slots are compacted first, so that the sigma_z^2 evaluation and the memory-side
+  // atomics of a block's ~100 cells keep two wavefronts busy instead of four, twice ----
+  __syncthreads();
+  uint32_t tc[kMPts];
+  unsigned before[kMPts];
+#pragma unroll
+  for (int h = 0; h < kMPts; ++h) {
+    tc[h] = S.t_cell[threadIdx.x + unsigned(h) * 256u];
+    const unsigned long long mo = __ballot(tc[h] != kEmptyCell);
+    before[h] = unsigned(__popcll(mo & ((1ull << lane) - 1ull)));
+    if (lane == 0u) S.s_occ[h * 4 + int(wave)] = unsigned(__popcll(mo));
   }
   __syncthreads();
-  if (B.bin_table) {  // one slot per thread
-    const uint32_t tc = t_cell[threadIdx.x];
-    if (tc != kEmptyCell)
-      merge(tc, t_key[threadIdx.x], t_zmx[threadIdx.x], t_imx[threadIdx.x], t_fst[threadIdx.x], t_lst[threadIdx.x]);
+  unsigned n_occ = 0u;
+#pragma unroll
+  for (int h = 0; h < kMPts; ++h) {
+    unsigned base = 0u;
+#pragma unroll
+    for (int q = 0; q < 4 * kMPts; ++q) {
+      const unsigned c = S.s_occ[q];
+      if (q < h * 4 + int(wave)) base += c;
+      if (h == 0) n_occ += c;
+    }
+    if (tc[h] != kEmptyCell) S.s_list[base + before[h]] = uint16_t(threadIdx.x + unsigned(h) * 256u);
+  }
+  __syncthreads();
+  for (unsigned j = threadIdx.x; j < n_occ; j += 256u) {
+    const unsigned t = S.s_list[j];
+    merge(S.t_cell[t], S.t_key[t], S.t_zmx[t], S.t_imx[t], S.t_fst[t], S.t_lst[t]);
   }
   if (threadIdx.x == 0) {
-    const unsigned ni = s_in[0] + s_in[1] + s_in[2] + s_in[3];
-    B.bin_part[bid] = (unsigned long long)np | ((unsigned long long)ni << 32);
+    const unsigned ni = S.s_in[0] + S.s_in[1] + S.s_in[2] + S.s_in[3];
+    B.bin_part[B.first_block[k] + lb] = (unsigned long long)np | ((unsigned long long)ni << 32);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// update half: 256 cells of the map, every scan of the batch.
+// update half: kUpdCells cells of the map (memory order), every scan of the batch.  Four threads per cell — thread
+// 4 c + q looks after cell c in scans 4 q .. 4 q + 3 — so that a block holds at most 1024 events (two rounds of
+// the exchange) and the densest corner of the map (every cell touched by every scan) is a chain as short as any
+// other; the cell's own thread (q == 0) applies the events.
+constexpr unsigned kUpdCells = 64u;
 template <typename POLICY, int CH>
-__device__ __forceinline__ void mupdate_body(const MBatch& B, const GeomConst& G, DevState* __restrict__ st,
+__device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, DevState* __restrict__ st,
                                              const typename POLICY::Layers& L,
                                              float* const* __restrict__ all_layers, int n_layers,
-                                             const unsigned ncell, const unsigned bid) {
+                                             const unsigned ncell, const unsigned bid,
+                                             MUpdLds<(CH & 2) != 0>& S) {
   constexpr bool has_int = (CH & 1) != 0, has_col = (CH & 2) != 0;
   const float nanv = __uint_as_float(0x7FC00000u);
-  __shared__ unsigned s_t[4];
-  const unsigned lt = threadIdx.x, lane = lt & 63u;
-  const unsigned o = bid * 256u + lt;
+  const unsigned lt = threadIdx.x, lane = lt & 63u, wave = lt >> 6;
+  const unsigned cq = lt & 3u, cl = lt >> 2;
+  const unsigned o = bid * kUpdCells + cl;
   const bool valid = o < ncell;
-  const unsigned count = B.count;
-  MState* const ms = B.ms;
+  const bool owner = valid && cq == 0u;  // the thread that applies the cell's events
+  const unsigned count = U.count;
+  MState* const ms = U.ms;
 
-  // ---- round trip 1: keys of every scan, the stored state, the per-scan geometry (lane j holds scan j's) ----
-  unsigned long long kk[kMaxBatch];
+  // ---- round trip 1: the thread's four keys, the per-scan geometry (lane j holds scan j's) ----
+  unsigned long long kk[4];
 #pragma unroll
-  for (int k = 0; k < kMaxBatch; ++k) {
-    kk[k] = kEmptyKey;
-    if (unsigned(k) < count && valid) kk[k] = B.key[size_t(k) * ncell + o];
-  }
-  typename POLICY::State stt;
-  POLICY::set_nan(stt);
-  float sint = nanv;
-  if (valid) {
-    POLICY::load(L, o, stt);
-    if (has_int) sint = L.intensity[o];
+  for (int j = 0; j < 4; ++j) {
+    const unsigned k = cq * 4u + unsigned(j);
+    kk[j] = kEmptyKey;
+    if (k < count && valid) kk[j] = U.key[size_t(k) * ncell + o];
   }
   int v_sr = 0, v_sc = 0, v_shr = 0, v_shc = 0;
-  unsigned v_done = 0u, v_in = 0u;
+  unsigned v_in = 0u;
   if (lane < count) {
     v_sr = ms->E[lane].sr; v_sc = ms->E[lane].sc;
     v_shr = ms->C[lane].shr; v_shc = ms->C[lane].shc;
-    v_done = ms->done[lane];
     v_in = ms->inside[lane];
   }
-  const bool v_applied = lane < count && B.do_move && (!B.gate_on_filter || (v_done >> 16) != 0u);
+  const unsigned passbits = uni(ms->flags[0]) >> 16;
+  const bool v_applied = lane < count && U.do_move && (!U.gate_on_filter || ((passbits >> lane) & 1u) != 0u);
   const unsigned umask = uni(unsigned(__ballot(lane < count && v_in != 0u)));                     // scans that observed a cell
   unsigned stripmask = uni(unsigned(__ballot(v_applied && (v_shr != 0 || v_shc != 0))));         // scans whose move vacated cells
 
   if (bid == 0 && lt == 0) {  // commit the geometry ring behind the batch (make_ctx does this per scan)
     const unsigned last = count - 1u;
-    const unsigned slot_next = (B.scan_no0 + count) & 3u;
+    const unsigned slot_next = (U.scan_no0 + count) & 3u;
     DevGeom g = ms->E[last];
-    const DevCand cl = ms->C[last];
-    const bool applied_last = B.do_move && (!B.gate_on_filter || (ms->done[last] >> 16) != 0u);
-    if (applied_last) { g.px = cl.px; g.py = cl.py; g.sr = cl.sr; g.sc = cl.sc; }
-    const unsigned ob_prev = st->obst[B.scan_no0 & 3u].scan;
+    const DevCand cl2 = ms->C[last];
+    const bool applied_last = U.do_move && (!U.gate_on_filter || ((passbits >> last) & 1u) != 0u);
+    if (applied_last) { g.px = cl2.px; g.py = cl2.py; g.sr = cl2.sr; g.sc = cl2.sc; }
+    const unsigned ob_prev = st->obst[U.scan_no0 & 3u].scan;
     st->geom[slot_next] = g;
-    st->cand[(B.scan_no0 + last) & 3u] = cl;   // (the synchronous statistics report the last scan's shift)
+    st->cand[(U.scan_no0 + last) & 3u] = cl2;   // (the synchronous statistics report the last scan's shift)
     // the last scan of the batch that observed a cell (umask: one bit per scan)
-    st->obst[slot_next].scan = umask ? B.scan_no0 + (31u - unsigned(__clz(int(umask)))) : ob_prev;
+    st->obst[slot_next].scan = umask ? U.scan_no0 + (31u - unsigned(__clz(int(umask)))) : ob_prev;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { st->flags[s].any_pass = 0u; st->flags[s].any_inside = 0u; st->flags[s].ray_any = 0u; }
+    for (int q = 0; q < 4; ++q) { st->flags[q].any_pass = 0u; st->flags[q].any_inside = 0u; st->flags[q].ray_any = 0u; }
     if (umask) {
-      const unsigned first_upd = B.scan_no0 + unsigned(__ffs(int(umask))) - 1u;
+      const unsigned first_upd = U.scan_no0 + unsigned(__ffs(int(umask))) - 1u;
       if (has_int && st->vis_int == 0u) st->vis_int = 3u * first_upd + 2u;
       if (has_col && st->vis_col == 0u) st->vis_col = 3u * first_upd + 2u;
     }
     if (ms->err) st->fault = 1u;
   }
-
-  unsigned tmask = 0u;
-  uint32_t idx[kMaxBatch];
-#pragma unroll
-  for (int k = 0; k < kMaxBatch; ++k) {
-    tmask |= (kk[k] != kEmptyKey) ? (1u << k) : 0u;
-    idx[k] = uint32_t(kk[k]);
+  if (bid == 0 && lt >= 64u && lt < 64u + unsigned(kMaxBatch)) {  // re-arm the state of the batch after next
+    U.rearm->done[(lt - 64u) * kLineWords] = 0u;
+    U.rearm->inside[lt - 64u] = 0u;
+    if (lt == 64u) U.rearm->flags[0] = 0u;
   }
+
+  unsigned nib = 0u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) nib |= (kk[j] != kEmptyKey) ? (1u << j) : 0u;
+  unsigned tmask = nib << (4u * cq);  // the cell's scans, all four threads of the cell
+  tmask |= unsigned(__shfl_xor(int(tmask), 1));
+  tmask |= unsigned(__shfl_xor(int(tmask), 2));
   // which scans' moves vacated THIS cell
   unsigned smask = 0u;
   if (stripmask) {
@@ -412,29 +549,100 @@ __device__ __forceinline__ void mupdate_body(const MBatch& B, const GeomConst& G
     if (!valid) smask = 0u;
   }
 
-  // ---- the cell's events, in scan order ----
-  unsigned m = tmask, lastp1 = 0u;
+  // ---- the block's (cell, scan) events, numbered cell-major / scan-minor (= thread order) ----
+  const unsigned mine = unsigned(__popc(nib));
+  unsigned inc = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned v = __shfl_up(inc, d);
+    if (int(lane) >= d) inc += v;
+  }
+  if (lane == 63u) S.s_w[wave] = inc;
+  __syncthreads();
+  unsigned base = inc - mine;
+  for (unsigned w2 = 0; w2 < wave; ++w2) base += S.s_w[w2];
+  const unsigned total = uni(S.s_w[0] + S.s_w[1] + S.s_w[2] + S.s_w[3]);
+
+  typename POLICY::State stt;
+  POLICY::set_nan(stt);
+  float sint = nanv;
+  unsigned lastp1 = 0u, m = owner ? tmask : 0u, e_next = base;  // (owner: the events still to be applied, the next one's number)
   bool evt = false, cleared = false, strip_any = false, obst_dirty = false;
   float obst = nanv;
   uint32_t colv = 0x7FC00000u;
-  while (__ballot(m != 0u)) {
-    const bool act = m != 0u;
-    const unsigned k = act ? unsigned(__ffs(int(m))) - 1u : 0u;
-    m &= m - 1u;
-    uint32_t id = idx[0];
+#pragma unroll 1
+  for (unsigned r0 = 0; r0 < total; r0 += unsigned(kEvCap)) {  // one round for all but the densest corners
+    const unsigned r1 = min(r0 + unsigned(kEvCap), total);
+    {  // every thread lists its (at most four) events of this round
+      unsigned e = base;
 #pragma unroll
-    for (int j = 1; j < kMaxBatch; ++j) id = (k == unsigned(j)) ? idx[j] : id;
-    float2 ob = make_float2(kFltMax, 0.0f);
-    uint4 ax = make_uint4(0u, 0u, kNoIdx, 0u);
-    uint2 zsw = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-    if (act) {
-      if (id != kNoIdx) ob = B.obs[size_t(k) * B.obs_stride + id];
-      ax = B.aux[size_t(k) * ncell + o];
-      zsw = B.zs[size_t(k) * ncell + o];
+      for (int j = 0; j < 4; ++j) {
+        if ((nib >> j) & 1u) {
+          if (e >= r0 && e < r1) {
+            MEvent ev;
+            ev.idx = uint32_t(kk[j]);
+            ev.cell = uint16_t(cl);
+            ev.k = uint16_t(cq * 4u + unsigned(j));
+            S.ev[e - r0] = ev;
+          }
+          ++e;
+        }
+      }
     }
-    uint32_t rgb = 0u;
-    if (has_col && act) rgb = B.cobs[size_t(k) * B.obs_stride + ax.w];
-    if (act) {
+    __syncthreads();
+    // round trip 2: every event of the round, spread evenly over the block (kEvCap / 256 per thread), and the
+    // cells' stored state
+    constexpr int kPer = kEvCap / 256;
+    MEvent ev_[kPer];
+    float2 ob_[kPer];
+    uint4 ax_[kPer];
+    uint2 zs_[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      const unsigned j = lt + unsigned(q) * 256u;
+      ob_[q] = make_float2(kFltMax, 0.0f);  // (no finite z: FLT_MAX, variance 0 — elevation_mapping.hpp:26-34)
+      ax_[q] = make_uint4(0u, 0u, kNoIdx, 0u);
+      zs_[q] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+      ev_[q].idx = kNoIdx; ev_[q].cell = 0; ev_[q].k = 0;
+      if (r0 + j < r1) {
+        ev_[q] = S.ev[j];
+        const size_t oc = size_t(ev_[q].k) * ncell + (bid * kUpdCells + ev_[q].cell);
+        if (ev_[q].idx != kNoIdx) ob_[q] = U.obs[size_t(ev_[q].k) * U.obs_stride + ev_[q].idx];
+        ax_[q] = U.aux[oc];
+        zs_[q] = U.zs[oc];
+      }
+    }
+    if (r0 == 0u && owner && tmask) {  // (the record joins the same round trip)
+      POLICY::load(L, o, stt);
+      if (has_int) sint = L.intensity[o];
+    }
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      const unsigned j = lt + unsigned(q) * 256u;
+      if (r0 + j >= r1) continue;
+      if (has_col) S.rgb[j] = U.cobs[size_t(ev_[q].k) * U.obs_stride + ax_[q].w];  // (one more dependent gather)
+      const uint32_t zm = ax_[q].x, imx = ax_[q].y, fst = ax_[q].z;
+      MObs ob;
+      ob.min_z = ob_[q].x;
+      ob.var = ob_[q].y;
+      // (a zero maximum takes the sign of the first zero-valued point, see Scratch::zs)
+      ob.max_z = zm ? ((zm == 0x80000000u && (zs_[q].x & 1u)) ? -0.0f : unord(zm)) : -kFltMax;
+      ob.iobs = 0.0f;
+      if (has_int) ob.iobs = (fst & 1u) ? nanv : ((imx == 0x80000000u && (zs_[q].y & 1u)) ? -0.0f : unord(imx));
+      S.ob[j] = ob;
+      const size_t oc = size_t(ev_[q].k) * ncell + (bid * kUpdCells + ev_[q].cell);
+      U.key[oc] = kEmptyKey;  // the scratch is clean again for the batch after next
+      U.aux[oc] = make_uint4(0u, 0u, kNoIdx, 0u);
+      if ((zs_[q].x & zs_[q].y) != 0xFFFFFFFFu) U.zs[oc] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    }
+    __syncthreads();
+    // the cells' own threads apply their events of this round, in scan order
+    while (m && e_next < r1) {
+      const unsigned k = unsigned(__ffs(int(m))) - 1u;
+      m &= m - 1u;
+      const MObs ob = S.ob[e_next - r0];
+      const uint32_t rgb = has_col ? S.rgb[e_next - r0] : 0u;
+      ++e_next;
       const unsigned upto = (2u << k) - 1u, from = (1u << lastp1) - 1u;  // scans lastp1 .. k
       if (smask & upto & ~from) {  // vacated since the last event: NaN in every layer (GridMap::move)
         POLICY::set_nan(stt);
@@ -442,32 +650,22 @@ __device__ __forceinline__ void mupdate_body(const MBatch& B, const GeomConst& G
         colv = 0x7FC00000u;
         strip_any = true;
       }
-      const float min_z = ob.x, min_z_var = ob.y;  // (no finite z: FLT_MAX, variance 0 — elevation_mapping.hpp:26-34)
-      const uint32_t zm = ax.x, imx = ax.y, fst = ax.z;
-      const float max_z = zm ? ((zm == 0x80000000u && (zsw.x & 1u)) ? -0.0f : unord(zm)) : -kFltMax;
-      POLICY::step(L, stt, min_z, min_z_var, max_z);
-      obst = (max_z > min_z) ? max_z : nanv;
+      POLICY::step(L, stt, ob.min_z, ob.var, ob.max_z);
+      obst = (ob.max_z > ob.min_z) ? ob.max_z : nanv;
       obst_dirty = true;
-      if (has_int) {
-        const float obs = (fst & 1u) ? nanv : ((imx == 0x80000000u && (zsw.y & 1u)) ? -0.0f : unord(imx));
-        if (isnan(sint) || obs > sint) sint = obs;
-      }
+      if (has_int && (isnan(sint) || ob.iobs > sint)) sint = ob.iobs;
       if (has_col) colv = rgb & 0x00FFFFFFu;
-      B.key[size_t(k) * ncell + o] = kEmptyKey;  // the scratch is clean again for the batch after next
-      B.aux[size_t(k) * ncell + o] = make_uint4(0u, 0u, kNoIdx, 0u);
-      if ((zsw.x & zsw.y) != 0xFFFFFFFFu) B.zs[size_t(k) * ncell + o] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
       evt = true;
-      cleared = false;
       lastp1 = k + 1u;
     }
+    __syncthreads();  // (the next round reuses the lists)
   }
   // the scans after the cell's last event
-  if (valid) {
-    const unsigned all = count >= 32u ? 0xFFFFFFFFu : (1u << count) - 1u, from = (1u << lastp1) - 1u;
+  if (owner) {
+    const unsigned all = (1u << count) - 1u, from = (1u << lastp1) - 1u;
     const unsigned tail = all & ~from;
     if (smask & tail) { strip_any = true; cleared = true; sint = nanv; colv = 0x7FC00000u; obst = nanv; obst_dirty = true; }
     if (umask & tail) { obst = nanv; obst_dirty = true; }  // map_.clear(obstacle), elevation_mapping.cpp:144-146
-    if (smask) strip_any = true;
     if (strip_any) {
       for (int l0 = 0; l0 < n_layers; l0 += 8) {
         float* p[8];
@@ -484,35 +682,48 @@ __device__ __forceinline__ void mupdate_body(const MBatch& B, const GeomConst& G
     if (has_int && (evt || strip_any)) L.intensity[o] = sint;
     if (has_col && (evt || strip_any)) reinterpret_cast<uint32_t*>(L.color)[o] = colv;
   }
-  // per-tile touched-cell count of the batch's last scan (what the synchronous statistics report)
-  const unsigned long long mt = __ballot(valid && ((tmask >> (count - 1u)) & 1u) != 0u);
-  if (lane == 0u) s_t[lt >> 6] = unsigned(__popcll(mt));
+  // touched-cell count of the batch's last scan (what the synchronous statistics report), per update block
+  const unsigned long long mt = __ballot(owner && ((tmask >> (count - 1u)) & 1u) != 0u);
+  if (lane == 0u) S.s_t[wave] = unsigned(__popcll(mt));
   __syncthreads();
-  if (lt == 0 && bid * 256u < ncell) B.upd_part[bid] = s_t[0] + s_t[1] + s_t[2] + s_t[3];
+  if (lt == 0 && bid * kUpdCells < ncell) U.upd_part[bid] = S.s_t[0] + S.s_t[1] + S.s_t[2] + S.s_t[3];
 }
+
+// [ update of batch b-1 | bin of batch b | crop pass of batch b+1 ] — any of the three may be empty.
+// Grid: blockIdx.x = block inside a scan (as wide as the widest scan of the two halves); blockIdx.y = first
+// `upd_rows` rows of update blocks (block = row * width + x), then one row per scan of the bin half, then one row per
+// scan of the crop half.  Surplus blocks leave at once.  Rows are dispatched in order: the update's chains first.
+// (the P2 estimator's 17-float state does not fit the 80 registers of 6 waves per SIMD without spilling: 5 there)
+template <typename POLICY> struct MBatchWaves { static constexpr int value = FDM_MB_WAVES; };
+template <> struct MBatchWaves<P2RecPolicy> { static constexpr int value = FDM_MB_WAVES - 1; };
+template <> struct MBatchWaves<P2Policy> { static constexpr int value = FDM_MB_WAVES - 1; };
 
 template <typename POLICY, int CH>
-__global__ __launch_bounds__(256) void k_mupdate(const MBatch Bu, const GeomConst G, DevState* __restrict__ st,
-                                                 const typename POLICY::Layers L,
-                                                 float* const* __restrict__ all_layers, int n_layers, unsigned ncell) {
-  mupdate_body<POLICY, CH>(Bu, G, st, L, all_layers, n_layers, ncell, blockIdx.x);
-}
-
-template <int CH>
-__global__ __launch_bounds__(256) void k_mbin(const MBatch Bb, const GeomConst G, DevState* __restrict__ st,
-                                              unsigned ncell) {
-  mbin_body<CH>(Bb, G, st, ncell, blockIdx.x);
-}
-
-// update of batch b + bin of batch b+1 in one launch (scratch sets, observation arrays and MState double-buffered
-// by batch parity)
-template <typename POLICY, int CH>
-__global__ __launch_bounds__(256) void k_mupdate_mbin(const MBatch Bu, const GeomConst G, DevState* __restrict__ st,
-                                                      const typename POLICY::Layers L,
-                                                      float* const* __restrict__ all_layers, int n_layers,
-                                                      unsigned ncell, unsigned upd_blocks, const MBatch Bb) {
-  if (blockIdx.x < upd_blocks) mupdate_body<POLICY, CH>(Bu, G, st, L, all_layers, n_layers, ncell, blockIdx.x);
-  else mbin_body<CH>(Bb, G, st, ncell, blockIdx.x - upd_blocks);
+__global__ __launch_bounds__(256, MBatchWaves<POLICY>::value) void k_mbatch(const MUpd U, const MBin B, const MCrop Cn, const MCommon K,
+                                                const GeomConst G, DevState* __restrict__ st,
+                                                const typename POLICY::Layers L,
+                                                float* const* __restrict__ all_layers, int n_layers,
+                                                unsigned ncell, unsigned upd_blocks, unsigned upd_rows) {
+  __shared__ __align__(16) unsigned char lds[kMLdsBytes<(CH & 2) != 0>];
+  const unsigned long long t0 = K.timeline ? wall_clock64() : 0ull;
+  const unsigned row = blockIdx.y, x = blockIdx.x;
+  if (row < upd_rows) {
+    const unsigned ub = row * gridDim.x + x;
+    if (ub < upd_blocks)
+      mupdate_body<POLICY, CH>(U, G, st, L, all_layers, n_layers, ncell, ub,
+                               *reinterpret_cast<MUpdLds<(CH & 2) != 0>*>(lds));
+  } else if (row < upd_rows + B.count) {
+    const unsigned k = row - upd_rows;
+    if (x < (B.n[k] + kMBlock - 1u) / kMBlock) mbin_body<CH>(B, K, G, st, ncell, k, x, *reinterpret_cast<MBinLds*>(lds));
+  } else {
+    const unsigned k = row - upd_rows - B.count;
+    if (x < (Cn.n[k] + kMBlock - 1u) / kMBlock) mcrop_body(Cn, K, k, x, reinterpret_cast<unsigned*>(lds));
+  }
+  if (K.timeline && threadIdx.x == 0) {  // (thread 0's view of the block; scripts/timeline_batch.py)
+    const unsigned b = blockIdx.y * gridDim.x + x;
+    K.timeline[2u * b] = t0;
+    K.timeline[2u * b + 1u] = wall_clock64();
+  }
 }
 
 }  // namespace fdm

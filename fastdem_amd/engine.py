@@ -225,6 +225,10 @@ class Engine:
         """0 = per-cell scratch pipeline, 1 = per-tile record pools (large scans), -1 = no scan yet."""
         return self._lib.fdm_engine_last_pipeline(self._h)
 
+    def last_batch(self):
+        """Scans of the batch launch the last scan left in (0: it took the single-scan path)."""
+        return self._lib.fdm_engine_last_batch(self._h)
+
     def timer_start(self):
         """Mark the start of a timed run of enqueue-only calls on the engine's stream."""
         _ck(self._lib.fdm_engine_timer_start(self._h))

@@ -144,9 +144,13 @@ int fdm_engine_integrate_device(fdm_engine* e, uint64_t n, const float* d_x, con
                                 const float* d_sigma_z2, const double T_base_sensor[16],
                                 const double T_world_base[16]);
 
-/* A batch of device-resident scans in ONE call (a bag replay, a driver that queues ahead): exactly
- * `count` consecutive fdm_engine_integrate_device calls, without the per-call crossing of the language
- * boundary (ctypes / JNI / cgo cost more than the 6 us a small scan takes on the device). */
+/* A batch of device-resident scans in ONE call (a bag replay, a driver that queues ahead): the map it leaves is
+ * exactly what `count` consecutive fdm_engine_integrate_device calls leave (every layer bit for bit), without the
+ * per-call crossing of the language boundary — and, because the engine sees the scans up front, without one launch
+ * per scan: runs of small plain scans of one sensor (same T_base_sensor, same optional channels, no captures / cell
+ * ids / raycasting, a map of at most 2^18 cells) are binned sixteen to a launch and applied cell by cell in scan
+ * order by the same launch's update half (fastdem_amd/csrc/fdm_multi.hpp; configs[1]: 1.2 us instead of 6 us per
+ * scan).  Scans that do not qualify take the single-scan path in place.  Options "batch" 0/1, "batch_max" 2..16. */
 typedef struct fdm_device_scan {
   uint64_t n;
   const float *x, *y, *z, *intensity; /* device pointers; intensity nullable */
@@ -194,6 +198,9 @@ void* fdm_engine_stream(fdm_engine* e);
 /* Which pipeline the last scan took: 0 = per-cell scratch (k_bin / k_update), 1 = per-tile record pools
  * (k_tbin / k_tupdate: maps of >= 240 tiles of 32 x 32 cells, scans of >= 2 K points), -1 = no scan yet.  Diagnostic. */
 int fdm_engine_last_pipeline(fdm_engine* e);
+/* Scans of the batch launch the last scan left in (fdm_engine_integrate_device_batch groups up to 16 small scans
+ * per launch, see below), 0 when it took the single-scan path.  Diagnostic. */
+int fdm_engine_last_batch(fdm_engine* e);
 /* Device-side stopwatch on the engine's stream (two engine-owned HIP events): _start marks "everything enqueued so
  * far" (a held-back update is launched first), _stop launches the last scan's held-back update and marks its end,
  * _ms waits for the stop mark and returns the time between the two.  For callers without HIP of their own that
@@ -405,6 +412,9 @@ int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2);
  *   "bin_table"   0/1   : k_bin folds poorly merged waves into a per-block LDS cell table before the atomics
  *   "zero_copy"   n     : host entry points read PINNED input arrays of up to n points in place (0 = always copy)
  *   "overlap"     0/1   : hold the update of a small scan back and fuse it with the next scan's bin launch
+ *   "batch" 0/1, "batch_max" n, "batch_crop" 0/1, "batch_fuse" 0/1 : fdm_engine_integrate_device_batch groups small
+ *                         scans into batch launches (default on, 16 per launch); evaluate the next batch's crops
+ *                         one launch ahead; hold a batch's update back for the next batch's launch
  *   "sync_spin_us" n     : a synchronous call polls the pinned statistics block for up to n microseconds before it
  *                         falls back to a stream wait (default 150; 0 = wait at once)
  *   "tiled" 0/1, "tiled_min" n : large-scan pipeline (per-tile record pools) on/off, its point-count threshold

@@ -11,7 +11,7 @@ Calibrated on known-byte kernels (scripts/ubench/pmc_calib.hip, profiles/r02/pmc
 usage: pmc_traffic.py <tag> <dir-with-p*/...counter_collection.csv> <out.json>"""
 import collections, csv, glob, json, sys
 tag, root, out = sys.argv[1:4]
-NAMES = [("fdm::k_tupdate_tbin", "k_tupdate_tbin"), ("fdm::k_tupdate", "k_tupdate"), ("fdm::k_tbin", "k_tbin"),
+NAMES = [("fdm::k_mbatch", "k_mbatch"), ("fdm::k_tupdate_tbin", "k_tupdate_tbin"), ("fdm::k_tupdate", "k_tupdate"), ("fdm::k_tbin", "k_tbin"),
          ("fdm::k_update_bin", "k_update_bin"), ("fdm::k_bin", "k_bin"), ("fdm::k_update", "k_update")]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/p*/*counter_collection.csv"):

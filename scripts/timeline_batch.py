@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Block timeline of the batch launch (k_mbatch = update | bin | crop): who runs when.
+   python scripts/timeline_batch.py [key=val ...]"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import bench  # noqa: E402
+from fastdem_amd import synth  # noqa: E402
+
+wl = synth.make("c2", n_scans=8)
+res = bench.Resident(wl, 0)
+res.eng.set_option("dbg_timeline", 1)
+for kv in sys.argv[1:]:
+    res.eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+for kk in range(400):
+    res.pose(kk)
+arr, _ = res.batch(0, 160)
+assert res.eng.integrate_device_batch(arr) == 0
+res.eng.sync()
+arr, _ = res.batch(160, 64)  # 4 batches: the timeline holds the LAST launch with a bin half (update 2 | bin 3 | no crop)
+arr2, _ = res.batch(160, 80)
+assert res.eng.integrate_device_batch(arr2) == 0   # 5 batches; last bin launch = update 3 | bin 4
+t, gx = res.eng.debug_timeline()   # rows of gx blocks: row 0 update tiles, then one row per scan (bin), then crop rows
+t = t.astype(np.int64)
+live = t[:, 1] > 0
+t0 = t[live, 0].min()
+s, e = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0
+d = e - s
+nrow = len(t) // gx
+def q(x): return [round(float(v), 2) for v in np.percentile(x, [0, 10, 50, 90, 99, 100])] if len(x) else []
+out = {"grid": [int(gx), int(nrow)], "span_us": round(float(e[live].max()), 2)}
+nb = (28800 + 511) // 512
+def role(rows, width):
+    idx = np.concatenate([np.arange(r * gx, r * gx + width) for r in rows]) if rows else np.array([], dtype=int)
+    idx = idx[live[idx]] if len(idx) else idx
+    return {"n": int(len(idx)), "start": q(s[idx]), "end": q(e[idx]), "dur": q(d[idx])}
+nu = (22500 + 63) // 64
+ur = (nu + gx - 1) // gx
+upd_idx = np.arange(0, nu)
+out["update"] = {"n": int(nu), "start": q(s[upd_idx]), "end": q(e[upd_idx]), "dur": q(d[upd_idx])}
+out["bin"] = role(list(range(ur, ur + 16)), nb)
+out["crop"] = role(list(range(ur + 16, nrow)), nb)
+out["bin_by_scan"] = [{"k": k, "start50": round(float(np.median(s[(ur + k) * gx:(ur + k) * gx + nb])), 2),
+                       "end50": round(float(np.median(e[(ur + k) * gx:(ur + k) * gx + nb])), 2)} for k in range(16)]
+print(json.dumps(out))

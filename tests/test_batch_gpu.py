@@ -99,9 +99,11 @@ def test_vlp16_stream_in_batches_equals_the_reference_scan_by_scan(gpu, R):
     assert "intensity" in eng.layers()
     # the stream goes on: single enqueue-only scans, then another batch, on the same map
     import torch
+    keep = []  # (device arrays stay alive until the engine has read them)
     for k in range(37, 40):
         s = wl.scan(k)
         d = {c: torch.from_numpy(s[c]).cuda() for c in ("x", "y", "z", "intensity")}
+        keep.append(d)
         eng.integrate_device(d["x"], d["y"], d["z"], wl.T_base_sensor, wl.pose(k), intensity=d["intensity"])
         ref.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k), intensity=s["intensity"])
     check_batch(gpu, R, eng, ref, [wl.scan(k) for k in range(40, 51)], wl.T_base_sensor, [wl.pose(k) for k in range(40, 51)])
@@ -155,6 +157,37 @@ def test_a_scan_with_every_point_filtered_does_not_move_the_map(gpu, R):
     check_batch(gpu, R, eng, ref, scans2, T(z=0.4), [T(9.0 + k, 1.0, 0.0) for k in range(5)])
     assert eng.last_stats()[0] == 2  # FDM_SKIP_ALL_FILTERED
     check_batch(gpu, R, eng, ref, scans[:7], T(z=0.4), [T(5.0 - k, 1.0, 0.0) for k in range(7)])
+
+
+def test_filtered_scans_deep_inside_a_long_call(gpu, R):
+    """60 scans in one call = four batches.  From the second batch on the crops were evaluated one launch AHEAD;
+    scans 21, 22, 37 and 59 have no surviving point, so they must not move the map and the scans behind them are
+    binned against the geometry that really resulted."""
+    def fill(c):
+        c.z_min, c.z_max, c.range_min, c.range_max = -1.0, 2.0, 0.5, 20.0
+
+    eng, ref = pair(gpu, R, 12.0, 9.0, 0.1, fill)
+    rng = np.random.default_rng(77)
+    scans, poses = [], []
+    for k in range(60):
+        s = cloud(rng, 2000 + 37 * (k % 9), 4.2, intensity=True)
+        if k in (21, 22, 37, 59):
+            s["z"] = (s["z"] + 40.0).astype(F32)
+        scans.append(s)
+        poses.append(T(0.27 * k, 0.15 * np.sin(0.4 * k) * k, 0.0, yaw=0.03 * k))
+    check_batch(gpu, R, eng, ref, scans, T(z=0.4), poses)
+    assert eng.last_stats()[0] == 2  # the last scan was filtered
+    # the same stream with the look-ahead switched off piece by piece leaves the same map
+    for opts in ({"batch_crop": 0}, {"batch_fuse": 0}):
+        e2, r2 = pair(gpu, R, 12.0, 9.0, 0.1, fill)
+        for key, v in opts.items():
+            e2.set_option(key, v)
+        b = DeviceBatch(gpu, scans, T(z=0.4), poses)
+        assert e2.integrate_device_batch(b.arr) == 0
+        e2.sync()
+        for n in eng.layers():
+            assert_arrays_close(e2.layer(n), eng.layer(n), n, 0.0, 0.0)
+        assert same_geometry(e2.geometry(), eng.geometry())
 
 
 def test_global_mode_p2_colour_intensity(gpu, R):
