@@ -95,6 +95,11 @@ class FdmScanStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class FdmRoutePlan(C.Structure):  # fdm_route_plan (include/fdm_engine.h)
+    _fields_ = [("world", C.c_int32), ("grid_rows", C.c_int32), ("grid_cols", C.c_int32), ("pad", C.c_int32),
+                ("row_edge", C.c_int32 * 17), ("col_edge", C.c_int32 * 17)]
+
+
 class FdmDeviceScan(C.Structure):  # fdm_device_scan (include/fdm_engine.h)
     _fields_ = [
         ("n", C.c_uint64),
@@ -132,6 +137,8 @@ PROTOTYPES = {
     "fdm_engine_integrate_device_batch_timed": (C.c_int, [_P, C.c_uint32, _P]),
     "fdm_engine_integrate_async": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_double),
                                              C.POINTER(C.c_double)]),
+    "fdm_engine_route_scan": (C.c_int, [_P, C.POINTER(FdmRoutePlan), C.c_uint64, _P, _P, _P, _P, _D, _D, _P, _P]),
+    "fdm_engine_integrate_points4_device": (C.c_int, [_P, C.c_uint64, _P, C.c_int, C.c_int, _D, _D]),
     "fdm_engine_update": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, C.c_double,
                                     C.c_double, C.POINTER(FdmScanStats)]),
     "fdm_engine_update_device": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, C.c_double,

@@ -92,7 +92,8 @@ struct ScanParams {
   int dbg_no_atomics;  // experiment switch (bench A/B only): skip the scratch atomics
   int drop_nonfinite;  // 1: a point with a non-finite coordinate does not exist (PointCloud2 ingest, from_impl)
   int dbg_upd;         // experiment switch: 1 = k_update returns after the context, 2 = after round 1
-};
+  int force_inside;    // 1: "some point of the scan landed in the map" holds whatever this engine's points say (a
+};                     //    routed slice of a larger scan: the fact is global, fdm_engine_integrate_points4_device)
 
 // ---- helpers ----
 // uniform value that came out of LDS / a ballot: tell the compiler (everything derived from it — tile number,

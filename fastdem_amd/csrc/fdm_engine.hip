@@ -28,6 +28,7 @@
 #include "fdm_kernels.hpp"
 #include "fdm_tiled.hpp"
 #include "fdm_multi.hpp"
+#include "fdm_route.hpp"
 #include "fdm_raycast.hpp"
 #include "fdm_egress.hpp"
 #include "fdm_ingest.hpp"
@@ -211,6 +212,10 @@ struct fdm_engine {
   uint32_t pre_count = 0;
   unsigned pre_seq = 0;
   const unsigned long long* last_bin_part = nullptr;  // per-block statistics of the last scan (either pipeline)
+  // scan routing (fdm_route.hpp)
+  uint8_t* d_route_owner = nullptr;  // [route_cap] owner rank of every point of the slice
+  uint32_t* d_route_cnt = nullptr;   // [route_blocks_cap][world + 2] block counts -> offsets | [kMaxRanks] bases at the end
+  size_t route_cap = 0, route_blocks_cap = 0;
   // stencil post-processing (fdm_post.hpp)
   RegionEntry* d_region = nullptr;   // kMaxRegion entries
   FeatEntry* d_feat_tab = nullptr;   // kMaxRegion entries: the region as k_features_tiled reads it
@@ -1195,6 +1200,8 @@ void fdm_engine_destroy(fdm_engine* e) {
   }
   if (e->mstate) (void)hipFree(e->mstate);
   if (e->mupd_part) (void)hipFree(e->mupd_part);
+  if (e->d_route_owner) (void)hipFree(e->d_route_owner);
+  if (e->d_route_cnt) (void)hipFree(e->d_route_cnt);
   if (e->tile_stamp32) (void)hipFree(e->tile_stamp32);
   if (e->upd_part32) (void)hipFree(e->upd_part32);
   if (e->tile_rare) (void)hipFree(e->tile_rare);
@@ -1349,6 +1356,90 @@ int fdm_engine_integrate_async(fdm_engine* e, uint64_t n, const float* x, const 
   ScanParams P;
   fill_integrate_params(e, P, Tbs, Twb);
   return enqueue_scan(e, P, n, dx, dy, dz, da, dc, dv, gather.x ? &gather : nullptr);
+}
+
+// ---- scan routing for spatially tiled global maps (include/fdm_engine.h) ----
+int fdm_engine_route_scan(fdm_engine* e, const fdm_route_plan* plan, uint64_t n, const float* dx, const float* dy,
+                          const float* dz, const float* dint, const double Tbs[16], const double Twb[16],
+                          float* d_send, uint32_t* d_counts) {
+  if (!e || !plan || !Tbs || !Twb || !d_counts) return fail(FDM_ERR_INVALID, "null argument");
+  if (plan->world < 1 || plan->world > kMaxRanks || plan->grid_rows * plan->grid_cols != plan->world)
+    return fail(FDM_ERR_INVALID, "route plan: 1 .. 16 ranks in a grid_rows x grid_cols grid");
+  if (n && (!dx || !dy || !dz || !d_send)) return fail(FDM_ERR_INVALID, "null xyz / send buffer");
+  if (n >= 0x7FFFFFFFull) return fail(FDM_ERR_INVALID, "point count exceeds 2^31-1");
+  if (e->cfg.mode != 1) return fail(FDM_ERR_INVALID, "scan routing is defined for GLOBAL maps");
+  HIPCK(hipSetDevice(e->device));
+  if (int rc = join_streams(e)) return rc;  // (the committed geometry slot is the current one)
+  RoutePlan R{};
+  R.world = plan->world; R.pr = plan->grid_rows; R.pc = plan->grid_cols;
+  for (int k = 0; k <= kMaxRanks; ++k) { R.row_edge[k] = plan->row_edge[k]; R.col_edge[k] = plan->col_edge[k]; }
+  const unsigned cols = unsigned(R.world + 2);
+  const unsigned blocks = unsigned((n + 255) / 256);
+  if (n > e->route_cap || blocks > e->route_blocks_cap) {
+    if (int rc_sync = sync_all(e)) return rc_sync;
+    if (e->d_route_owner) HIPCK(hipFree(e->d_route_owner));
+    if (e->d_route_cnt) HIPCK(hipFree(e->d_route_cnt));
+    e->d_route_owner = nullptr; e->d_route_cnt = nullptr;
+    e->route_cap = size_t(n) + size_t(n) / 4 + 1024;
+    e->route_blocks_cap = (e->route_cap + 255) / 256;
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_route_owner), e->route_cap));
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_route_cnt),
+                    (e->route_blocks_cap * size_t(kMaxRanks + 2) + kMaxRanks) * sizeof(uint32_t)));
+  }
+  uint32_t* const base = e->d_route_cnt + e->route_blocks_cap * size_t(kMaxRanks + 2);
+  ScanParams P;
+  fill_integrate_params(e, P, Tbs, Twb);
+  sensor_params(e->cfg, P.sensor_type, P.sp);
+  P.n = uint32_t(n);
+  P.slot = int(e->scan_no & 3);
+  if (blocks) {
+    hipLaunchKernelGGL(k_route_count, dim3(blocks), dim3(256), 0, e->stream, P, e->G, R, e->d_state, dx, dy, dz,
+                       e->d_route_owner, e->d_route_cnt);
+    HIPCK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(64u * cols), 0, e->stream, e->d_route_cnt, blocks, R.world, d_counts, base);
+  HIPCK(hipGetLastError());
+  if (blocks) {
+    hipLaunchKernelGGL(k_route_scatter, dim3(blocks), dim3(256), 0, e->stream, unsigned(n), R.world, e->d_route_owner,
+                       e->d_route_cnt, base, dx, dy, dz, dint, reinterpret_cast<float4*>(d_send));
+    HIPCK(hipGetLastError());
+  }
+  return FDM_OK;
+}
+
+int fdm_engine_integrate_points4_device(fdm_engine* e, uint64_t n, const float* d_points4, int has_intensity,
+                                        int any_in_map, const double Tbs[16], const double Twb[16]) {
+  if (!e || !Tbs || !Twb) return fail(FDM_ERR_INVALID, "null argument");
+  if (n && !d_points4) return fail(FDM_ERR_INVALID, "null points");
+  if (n >= 0x7FFFFFFFull) return fail(FDM_ERR_INVALID, "point count exceeds 2^31-1");
+  HIPCK(hipSetDevice(e->device));
+  ScanParams P;
+  fill_integrate_params(e, P, Tbs, Twb);
+  P.force_inside = any_in_map ? 1 : 0;
+  if (n == 0) {
+    if (!any_in_map) {  // nothing of the scan reached any map tile: fastdem.cpp:145-161 leaves the map untouched
+      e->have_scan = true;
+      e->last_n = 0;
+      e->last_n_input = 0;
+      e->ingest_blocks = 0;
+      e->last_was_integrate = 1;
+      return FDM_OK;
+    }
+    // this tile saw none of the scan's points, but the scan did observe cells elsewhere: update() still runs
+    // (the whole-layer obstacle clear, elevation_mapping.cpp:144-146)
+    return enqueue_scan(e, P, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  }
+  int rc;
+  if ((rc = ensure_stage(e, n))) return rc;
+  e->stage_rr = (e->stage_rr + 1) % kStageSlots;  // (a held-back update never reads this block: see ensure_stage)
+  const size_t cap = e->stage_cap;
+  float* base = e->d_stage + size_t(e->stage_rr) * 6 * cap;
+  float* di = has_intensity ? base + cap * 3 : nullptr;
+  const int blocks = int(std::min<uint64_t>((n + 255) / 256, 8192));
+  hipLaunchKernelGGL(k_points4_to_soa, dim3(blocks), dim3(256), 0, e->stream, reinterpret_cast<const float4*>(d_points4),
+                     size_t(n), base, base + cap, base + cap * 2, di);
+  HIPCK(hipGetLastError());
+  return enqueue_scan(e, P, n, base, base + cap, base + cap * 2, di, nullptr, nullptr);
 }
 
 int fdm_engine_update_device(fdm_engine* e, uint64_t n, const float* dx, const float* dy,

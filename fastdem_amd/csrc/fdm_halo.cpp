@@ -115,7 +115,7 @@ int fdm_halo_broadcast_scan(fdm_engine* e, void* nccl_comm, float* d_packed, uin
 int64_t fdm_halo_exchange(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p, const char* const* names,
                           int32_t n_names, float* d_ws, uint64_t ws_bytes) {
   if (!e || !p || !names) return fail(FDM_ERR_INVALID, "null argument");
-  if (p->world == 1 || n_names <= 0) return 0;
+  if ((p->n_sends == 0 && p->n_recvs == 0) || n_names <= 0) return 0;  // (a plan may name the rank itself as a neighbour)
   if (!nccl_comm || !d_ws) return fail(FDM_ERR_INVALID, "null communicator / workspace");
   if (ws_bytes < fdm_halo_workspace_bytes(p, n_names)) return fail(FDM_ERR_INVALID, "workspace too small");
   hipStream_t stream = static_cast<hipStream_t>(fdm_engine_stream(e));
@@ -159,6 +159,81 @@ int64_t fdm_halo_exchange(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p
       return fail(rc, std::string("region_unpack: ") + fdm_last_error());
   }
   return sent;
+}
+
+void fdm_tile_plan_route(const fdm_tile_plan* p, fdm_route_plan* out) {
+  if (!p || !out) return;
+  *out = fdm_route_plan{};
+  out->world = p->world;
+  out->grid_rows = p->grid_rows;
+  out->grid_cols = p->grid_cols;
+  for (int i = 0; i <= p->grid_rows && i <= 16; ++i) {
+    int start, len;
+    split(p->rows, p->grid_rows, std::min(i, p->grid_rows - 1), start, len);
+    out->row_edge[i] = i < p->grid_rows ? start : p->rows;
+  }
+  for (int j = 0; j <= p->grid_cols && j <= 16; ++j) {
+    int start, len;
+    split(p->cols, p->grid_cols, std::min(j, p->grid_cols - 1), start, len);
+    out->col_edge[j] = j < p->grid_cols ? start : p->cols;
+  }
+}
+
+int fdm_halo_gather_counts(fdm_engine* e, void* nccl_comm, const uint32_t* d_counts, uint32_t* d_matrix,
+                           uint32_t* h_matrix, int32_t world) {
+  if (!e || !nccl_comm || !d_counts || !d_matrix || !h_matrix || world < 1) return fail(FDM_ERR_INVALID, "null argument");
+  hipStream_t stream = static_cast<hipStream_t>(fdm_engine_stream(e));
+  const size_t per = size_t(world) + 2;
+  const ncclResult_t r = ncclAllGather(d_counts, d_matrix, per, ncclUint32, static_cast<ncclComm_t>(nccl_comm), stream);
+  if (r != ncclSuccess) return fail(FDM_ERR_HIP, std::string("ncclAllGather: ") + ncclGetErrorString(r));
+  if (hipMemcpyAsync(h_matrix, d_matrix, per * size_t(world) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+      hipStreamSynchronize(stream) != hipSuccess)
+    return fail(FDM_ERR_HIP, "reading the routing counts back");
+  return FDM_OK;
+}
+
+int fdm_halo_route_exchange(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p, const float* d_send,
+                            const uint32_t* h_matrix, float* d_recv, uint64_t recv_capacity, uint64_t* n_recv,
+                            int32_t* any_in_map) {
+  if (!e || !p || !h_matrix || !n_recv || !any_in_map) return fail(FDM_ERR_INVALID, "null argument");
+  const int W = p->world, me = p->rank;
+  const size_t per = size_t(W) + 2;
+  uint64_t total = 0, inside = 0;
+  for (int src = 0; src < W; ++src) {
+    total += h_matrix[size_t(src) * per + size_t(me)];
+    inside += h_matrix[size_t(src) * per + size_t(W) + 1];
+  }
+  *n_recv = total;
+  *any_in_map = inside ? 1 : 0;
+  if (total > recv_capacity) return fail(FDM_ERR_INVALID, "receive buffer too small for the routed points");
+  if (W > 1 && !nccl_comm) return fail(FDM_ERR_INVALID, "null communicator");
+  if ((total && !d_recv) || !d_send) return fail(FDM_ERR_INVALID, "null point buffer");
+  hipStream_t stream = static_cast<hipStream_t>(fdm_engine_stream(e));
+  ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);
+  // where each peer's share starts: in my send buffer (owner-major) / in my receive buffer (source-major)
+  uint64_t send_off = 0, recv_off = 0;
+  ncclResult_t r = ncclSuccess;
+  bool grouped = false;
+  for (int peer = 0; peer < W; ++peer) {
+    const uint64_t ns = h_matrix[size_t(me) * per + size_t(peer)], nr = h_matrix[size_t(peer) * per + size_t(me)];
+    if (peer == me) {
+      if (ns && hipMemcpyAsync(d_recv + 4 * recv_off, d_send + 4 * send_off, ns * 16, hipMemcpyDeviceToDevice, stream) !=
+                    hipSuccess)
+        return fail(FDM_ERR_HIP, "copying the rank's own share");
+    } else if (ns || nr) {
+      if (!grouped) { r = ncclGroupStart(); grouped = true; }
+      if (r == ncclSuccess && nr) r = ncclRecv(d_recv + 4 * recv_off, size_t(nr) * 4, ncclFloat, peer, comm, stream);
+      if (r == ncclSuccess && ns) r = ncclSend(d_send + 4 * send_off, size_t(ns) * 4, ncclFloat, peer, comm, stream);
+    }
+    send_off += ns;
+    recv_off += nr;
+  }
+  if (grouped) {
+    const ncclResult_t r2 = ncclGroupEnd();
+    if (r != ncclSuccess || r2 != ncclSuccess)
+      return fail(FDM_ERR_HIP, std::string("nccl send/recv: ") + ncclGetErrorString(r != ncclSuccess ? r : r2));
+  }
+  return FDM_OK;
 }
 
 }  // extern "C"

@@ -198,7 +198,10 @@ __device__ __forceinline__ DevCand block_candidate(const ScanParams& P, const Ge
       c.px = g.px; c.py = g.py; c.sr = g.sr; c.sc = g.sc; c.shr = 0; c.shc = 0;
     }
     *s_cand = c;
-    if (bid == 0) st->cand[P.slot] = c;
+    if (bid == 0) {
+      st->cand[P.slot] = c;
+      if (P.force_inside) st->flags[P.slot].any_inside = 1u;
+    }
   }
   __syncthreads();
   return *s_cand;

@@ -211,6 +211,26 @@ class Engine:
         """The same between timer_start() and timer_stop(): timer_ms() afterwards is the batch's device time."""
         return self._lib.fdm_engine_integrate_device_batch_timed(self._h, len(scans) if count is None else count, scans)
 
+    # -- scan routing for spatially tiled global maps (fdm_route.hpp) --
+    def route_scan(self, plan, x, y, z, T_base_sensor, T_world_base, send, counts, intensity=None):
+        """Partition this rank's slice (torch device tensors) by owner rank into `send` ([n, 4] float32 device
+        tensor: x, y, z, intensity records) and leave the per-owner counts + n_after_filter + n_in_map in
+        `counts` (device int32 tensor of world + 2).  Enqueue-only."""
+        self.wait_torch()
+        tbs, twb = _colmajor16(T_base_sensor), _colmajor16(T_world_base)
+        _ck(self._lib.fdm_engine_route_scan(
+            self._h, C.byref(plan), x.numel(), _dptr(x), _dptr(y), _dptr(z), _dptr(intensity),
+            tbs.ctypes.data_as(C.POINTER(C.c_double)), twb.ctypes.data_as(C.POINTER(C.c_double)),
+            _dptr(send), _dptr(counts)))
+
+    def integrate_points4_device(self, points4, n, T_base_sensor, T_world_base, has_intensity=True, any_in_map=True):
+        """FastDEM::integrate of `n` received {x, y, z, intensity} records (device tensor).  Enqueue-only."""
+        self.wait_torch()
+        tbs, twb = _colmajor16(T_base_sensor), _colmajor16(T_world_base)
+        _ck(self._lib.fdm_engine_integrate_points4_device(
+            self._h, int(n), _dptr(points4) if n else None, int(bool(has_intensity)), int(bool(any_in_map)),
+            tbs.ctypes.data_as(C.POINTER(C.c_double)), twb.ctypes.data_as(C.POINTER(C.c_double))))
+
     def update(self, x, y, z, robot_xy=(0.0, 0.0), z_var=None, intensity=None, rgb=None):
         x, y, z = _f32(x), _f32(y), _f32(z)
         v, a, c = _f32(z_var), _f32(intensity), _u32(rgb)

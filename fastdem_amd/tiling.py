@@ -223,6 +223,108 @@ def exchange_halos(tile, plan: TilePlan, names: Sequence[str], dist, group=None)
     return nbytes
 
 
+# --------------------------------------------------------------------------- scan routing ----
+def route_plan(plan: TilePlan):
+    """capi.FdmRoutePlan of the tiling: the row / column edges of the owned rects (fdm_route.hpp)."""
+    from . import capi
+    pr, pc = grid_for(plan.world)
+    rp = capi.FdmRoutePlan()
+    rp.world, rp.grid_rows, rp.grid_cols = plan.world, pr, pc
+    rs, cs = _split(plan.rows, pr), _split(plan.cols, pc)
+    for i in range(pr):
+        rp.row_edge[i] = rs[i][0]
+    rp.row_edge[pr] = plan.rows
+    for j in range(pc):
+        rp.col_edge[j] = cs[j][0]
+    rp.col_edge[pc] = plan.cols
+    return rp
+
+
+def slice_bounds(n: int, world: int, align: int = 1) -> List[Tuple[int, int]]:
+    """Contiguous slices of an n-point scan, one per rank, in rank order (starts aligned to `align` points)."""
+    edges = [min(n, ((round(i * n / world) + align - 1) // align) * align) for i in range(world)] + [n]
+    return [(edges[i], edges[i + 1]) for i in range(world)]
+
+
+class RoutedScan:
+    """One logical scan whose points are spread over the ranks (rank r holds slice r; the scan is the
+    concatenation in rank order): every rank routes its slice to the owners of the cells, the owners integrate
+    what they receive — in rank order, i.e. scan order, so every owned cell equals the single map's bit for bit.
+
+    Per scan and rank: fdm_engine_route_scan (3 small kernels) -> all-gather of the world + 2 counters (one host
+    read-back: the sizes of the exchange are host-side arguments) -> point-to-point exchange of 16-byte point
+    records (the rank's own share is a device copy) -> fdm_engine_integrate_points4_device.  `staged`: move the
+    records through host memory (gloo, several ranks on one GPU) instead of the device-to-device path (nccl)."""
+
+    def __init__(self, engine, plan: TilePlan, device, max_points: int, staged: bool = False):
+        import torch
+        self.eng, self.plan, self.torch, self.staged = engine, plan, torch, staged
+        self.rp = route_plan(plan)
+        self.device = device
+        self.send = torch.empty((max(max_points, 1), 4), dtype=torch.float32, device=device)
+        self.counts = torch.zeros(plan.world + 2, dtype=torch.int32, device=device)
+        self.recv = None
+        self.matrix = None
+
+    def _recv_buffer(self, n):
+        if self.recv is None or self.recv.shape[0] < n:
+            self.recv = self.torch.empty((max(n + n // 4, 1024), 4), dtype=self.torch.float32, device=self.device)
+        return self.recv
+
+    def integrate(self, x, y, z, T_base_sensor, T_world_base, dist, intensity=None, group=None):
+        """x, y, z[, intensity]: this rank's slice (device tensors).  Returns the counter matrix (numpy, world x
+        (world + 2)): [src, dst] points sent, [src, world] n_after_filter, [src, world + 1] n_in_map."""
+        torch, W, me = self.torch, self.plan.world, self.plan.rank
+        n = int(x.numel())
+        assert n <= self.send.shape[0]
+        self.eng.route_scan(self.rp, x, y, z, T_base_sensor, T_world_base, self.send, self.counts, intensity=intensity)
+        self.eng.torch_wait()  # torch's stream (the collective's) behind the routing kernels
+        if W > 1:
+            if self.staged:
+                gathered = [torch.empty(W + 2, dtype=torch.int32) for _ in range(W)]
+                dist.all_gather(gathered, self.counts.cpu(), group=group)
+                matrix = torch.stack(gathered).numpy().astype(np.int64)
+            else:
+                dev = torch.empty((W, W + 2), dtype=torch.int32, device=self.device)
+                dist.all_gather_into_tensor(dev, self.counts, group=group)
+                matrix = dev.cpu().numpy().astype(np.int64)
+        else:
+            matrix = self.counts.cpu().numpy().astype(np.int64).reshape(1, W + 2)
+        self.matrix = matrix
+        n_recv = int(matrix[:, me].sum())
+        any_in_map = bool(matrix[:, W + 1].sum() > 0)
+        recv = self._recv_buffer(n_recv)
+        send_off = np.concatenate([[0], np.cumsum(matrix[me, :W])])
+        recv_off = np.concatenate([[0], np.cumsum(matrix[:, me])])
+        ops, keep = [], []
+        for peer in range(W):
+            ns, nr = int(matrix[me, peer]), int(matrix[peer, me])
+            if peer == me:
+                if ns:
+                    recv[recv_off[peer]:recv_off[peer] + ns].copy_(self.send[send_off[peer]:send_off[peer] + ns])
+                continue
+            if nr:
+                rb = torch.empty((nr, 4), dtype=torch.float32) if self.staged else recv[recv_off[peer]:recv_off[peer] + nr]
+                keep.append((peer, rb, nr))
+                ops.append(dist.P2POp(dist.irecv, rb, peer, group))
+            if ns:
+                sb = self.send[send_off[peer]:send_off[peer] + ns]
+                sb = sb.cpu() if self.staged else sb
+                keep.append((None, sb, ns))
+                ops.append(dist.P2POp(dist.isend, sb, peer, group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if self.staged:
+            for peer, rb, nr in keep:
+                if peer is not None:
+                    recv[recv_off[peer]:recv_off[peer] + nr].copy_(rb)
+            torch.cuda.current_stream().synchronize()
+        self.eng.integrate_points4_device(recv, n_recv, T_base_sensor, T_world_base,
+                                          has_intensity=intensity is not None, any_in_map=any_in_map)
+        return matrix
+
+
 # --------------------------------------------------------------------------- bench (C5) ----
 def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]:
     """configs[4]: one 400x400 m @ 0.05 m GLOBAL map tiled over `world` GPUs; a step = scan

@@ -251,6 +251,30 @@ int fdm_engine_region_pack(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, in
 int fdm_engine_region_unpack(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, int32_t nc,
                              const char* const* names, int n_layers, const float* d_buf);
 
+/* ---- Scan routing for a spatially tiled global map (fastdem_amd/tiling.py, include/fdm_halo.h) ----
+ * One logical scan = the concatenation, in rank order, of per-rank slices.  fdm_engine_route_scan runs a slice through
+ * T_base_sensor, cropRange, cropZ, T_world_base and getIndex against the GLOBAL geometry — the operations the owner's
+ * bin kernel repeats — and partitions the slice's RAW points by the rank that owns the cell they fall into, order
+ * preserved: d_send receives {x, y, z, intensity} records (16 B), the points for rank 0 first, then rank 1, ...;
+ * d_counts (device, world + 2 words) receives the points per owner, then the slice's n_after_filter and n_in_map.
+ * Enqueue-only on the engine's stream; the host reads d_counts to size the exchange (fdm_halo_route_exchange).
+ * The plan: owned rect of rank i * grid_cols + j = rows [row_edge[i], row_edge[i+1]) x cols [col_edge[j], col_edge[j+1])
+ * (fdm_tile_plan_route).  GLOBAL mode only.
+ *
+ * fdm_engine_integrate_points4_device: FastDEM::integrate of the points an owner received ({x, y, z, intensity}
+ * records in HBM, rank order = scan order).  any_in_map: some point of the LOGICAL scan landed in the map (the OR over
+ * all slices' n_in_map) — it gates the obstacle-layer clear on every tile, also one that received no point. */
+typedef struct fdm_route_plan {
+  int32_t world, grid_rows, grid_cols, pad;
+  int32_t row_edge[17], col_edge[17];
+} fdm_route_plan;
+int fdm_engine_route_scan(fdm_engine* e, const fdm_route_plan* plan, uint64_t n, const float* d_x, const float* d_y,
+                          const float* d_z, const float* d_intensity, const double T_base_sensor[16],
+                          const double T_world_base[16], float* d_send, uint32_t* d_counts);
+int fdm_engine_integrate_points4_device(fdm_engine* e, uint64_t n, const float* d_points4, int has_intensity,
+                                        int any_in_map, const double T_base_sensor[16],
+                                        const double T_world_base[16]);
+
 /* Scan callbacks of the reference (fastdem.hpp:129-136, fastdem.cpp:139-150): when enabled the
  * kernels also keep (a) every point in the map frame + whether it survived the crops and (b) the
  * min-z observation of every observed cell.

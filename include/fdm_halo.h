@@ -61,6 +61,28 @@ int fdm_halo_broadcast_scan(fdm_engine* e, void* nccl_comm, float* d_packed, uin
 int64_t fdm_halo_exchange(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* plan, const char* const* names,
                           int32_t n_names, float* d_workspace, uint64_t workspace_bytes);
 
+/* ---- Scan routing: every rank holds a SLICE of the logical scan, points travel to the rank that owns their cell ----
+ *     fdm_route_plan route;  fdm_tile_plan_route(&plan, &route);
+ *     per scan, every rank:
+ *       fdm_engine_route_scan(engine, &route, n_slice, d_x, d_y, d_z, d_i, Tbs, Twb, d_send, d_counts);
+ *       fdm_halo_gather_counts(engine, comm, d_counts, d_matrix, h_matrix);      // ncclAllGather + one host read-back
+ *       fdm_halo_route_exchange(engine, comm, &plan, d_send, h_matrix, d_recv, recv_capacity, &n_recv, &any_in_map);
+ *       fdm_engine_integrate_points4_device(engine, n_recv, d_recv, has_intensity, any_in_map, Tbs, Twb);
+ *       fdm_halo_exchange(...);
+ * h_matrix[src * (world + 2) + dst] = points rank src sends to rank dst; columns world / world + 1 = the slice's
+ * n_after_filter / n_in_map.  Received points arrive in rank order = scan order (fdm_engine.h, fdm_engine_route_scan). */
+void fdm_tile_plan_route(const fdm_tile_plan* plan, fdm_route_plan* out);
+/* ncclAllGather of every rank's world + 2 counters into d_matrix (device, world * (world + 2) words), copied to
+ * h_matrix; waits for the stream (the sizes of the exchange are host-side arguments of ncclSend / ncclRecv). */
+int fdm_halo_gather_counts(fdm_engine* e, void* nccl_comm, const uint32_t* d_counts, uint32_t* d_matrix,
+                           uint32_t* h_matrix, int32_t world);
+/* One ncclGroup of ncclSend / ncclRecv of 16-byte point records with every other rank (the rank's own share is a
+ * device copy), on the engine's stream.  d_recv must hold recv_capacity records; *n_recv = records received (rank order),
+ * *any_in_map = some slice had a point inside the map. */
+int fdm_halo_route_exchange(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* plan, const float* d_send,
+                            const uint32_t* h_matrix, float* d_recv, uint64_t recv_capacity, uint64_t* n_recv,
+                            int32_t* any_in_map);
+
 const char* fdm_halo_last_error(void);
 
 #ifdef __cplusplus

@@ -79,3 +79,24 @@ def test_bad_arguments_fail_loudly():
     assert h.fdm_tile_plan_make(5, 16, 100, 100, 80, C.byref(p)) < 0    # halo wider than a tile: > 8 neighbours
     h.fdm_halo_exchange.restype = C.c_int64
     assert h.fdm_halo_exchange(None, None, C.byref(p), None, 0, None, C.c_uint64(0)) < 0
+
+
+def test_route_plan_edges_match_the_python_plan():
+    """fdm_tile_plan_route (C++ hosts) and tiling.route_plan (torch.distributed) cut the owners the same way."""
+    from fastdem_amd import capi, tiling
+    L = lib()
+    for world, rows, cols in ((1, 400, 400), (2, 8000, 8000), (4, 2000, 2000), (8, 8000, 8000), (6, 1001, 777), (16, 4096, 333)):
+        for rank in (0, world - 1):
+            p = Plan()
+            assert L.fdm_tile_plan_make(rank, world, rows, cols, 6, C.byref(p)) == 0
+            rp = capi.FdmRoutePlan()
+            L.fdm_tile_plan_route(C.byref(p), C.byref(rp))
+            py = tiling.route_plan(tiling.make_plan(rank, world, rows, cols, 6))
+            assert (rp.world, rp.grid_rows, rp.grid_cols) == (py.world, py.grid_rows, py.grid_cols)
+            assert list(rp.row_edge)[:rp.grid_rows + 1] == list(py.row_edge)[:py.grid_rows + 1]
+            assert list(rp.col_edge)[:rp.grid_cols + 1] == list(py.col_edge)[:py.grid_cols + 1]
+            # the edges are the owned rects of the plan
+            pr, pc = tiling.grid_for(world)
+            o = tiling.owned_rect(rank, world, rows, cols)
+            i, j = divmod(rank, pc)
+            assert (rp.row_edge[i], rp.row_edge[i + 1], rp.col_edge[j], rp.col_edge[j + 1]) == (o.r0, o.r1, o.c0, o.c1)

@@ -96,3 +96,93 @@ def test_tile_engines_with_halo_exchange_equal_the_untiled_map(world):
     for rank, bad, n_names in sorted(results):
         assert not bad, f"rank {rank}: {bad}"
         assert n_names >= 8
+
+
+# ---------------------------------------------------------------------------------------------
+# Scan routing (fastdem_amd/csrc/fdm_route.hpp, tiling.RoutedScan): every rank holds a SLICE of the scan; the points
+# travel to the owner of their cell; the owners integrate what they receive.
+def _routed_worker(rank, world, port, q, backend):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        sys.path.insert(0, ROOT)
+        import torch
+        import torch.distributed as dist
+        from fastdem_amd import Engine, capi, synth, tiling
+        torch.cuda.set_device(0)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        wl = synth.global_map(n_scans=3, size_m=100.0, n_az=2048, radius=30.0)
+        rows = cols = 2000
+        plan = tiling.make_plan(rank, world, rows, cols, tiling.DEFAULT_HALO)
+        eng = Engine(wl.width, wl.height, wl.resolution, wl.apply_to(capi.default_config()),
+                     tile=plan.fdm_tile() if world > 1 else None, device=0)
+        inner = tiling.EngineTile(eng, plan, "cuda:0")
+        tile = tiling.HostStagedTile(inner) if backend == "gloo" else inner
+        whole = Engine(wl.width, wl.height, wl.resolution, wl.apply_to(capi.default_config()), device=0)
+        n = wl.n_points
+        bounds = tiling.slice_bounds(n, world, align=4)
+        lo, hi = bounds[rank]
+        router = tiling.RoutedScan(eng, plan, "cuda:0", max_points=hi - lo + 8, staged=backend == "gloo")
+        names = None
+        totals = []
+        for k in range(3):
+            s = wl.scan(k)
+            sl = {c: torch.from_numpy(np.ascontiguousarray(s[c][lo:hi])).cuda() for c in ("x", "y", "z", "intensity")}
+            m = router.integrate(sl["x"], sl["y"], sl["z"], wl.T_base_sensor, wl.pose(k), dist, intensity=sl["intensity"])
+            totals.append((int(m[:, :world].sum()), int(m[:, world].sum()), int(m[:, world + 1].sum())))
+            names = [nm for nm in tiling.visible_layers(eng.layers())]
+            have = [None] * world
+            dist.all_gather_object(have, names)
+            names = [nm for nm in names if all(nm in h for h in have)]
+            tiling.exchange_halos(tile, plan, names, dist)
+            rc, st = whole.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k), intensity=s["intensity"])
+            # the routing counters add up to the single map's statistics
+            assert totals[-1] == (st["n_in_map"], st["n_after_filter"], st["n_in_map"]), (totals[-1], st)
+        st_rect = plan.stored if world > 1 else tiling.Rect(0, 0, rows, cols)
+        bad = []
+        for nm in names:
+            got = eng.layer(nm)
+            want = whole.layer(nm)[st_rect.r0:st_rect.r1, st_rect.c0:st_rect.c1]
+            if not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
+                bad.append((nm, int((got.view(np.uint32) != want.view(np.uint32)).sum())))
+        q.put((rank, bad, len(names)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, [("exception", traceback.format_exc(), str(e))], 0))
+
+
+def _run(target, world, *extra):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + extra) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    return sorted(results)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_routed_slices_equal_the_untiled_map(world):
+    """2 / 4 processes on GPU 0, each holding a quarter / half of every scan: route -> exchange (host-staged over gloo)
+    -> integrate on the owners -> halo exchange; every stored window equals the untiled engine integrating the WHOLE
+    scan, bit for bit, and the routing counters add up to its statistics."""
+    for rank, bad, n_names in _run(_routed_worker, world, "gloo"):
+        assert not bad, f"rank {rank}: {bad}"
+        assert n_names >= 8
+
+
+def test_routed_scan_over_rccl_with_one_rank():
+    """The same driver over backend "nccl" (RCCL) with a 1-rank communicator: all-gather of the counters, the self
+    share of the exchange, integrate of the received records — the device-to-device path an N-GPU node runs."""
+    for rank, bad, n_names in _run(_routed_worker, 1, "nccl"):
+        assert not bad, f"rank {rank}: {bad}"
+        assert n_names >= 8
