@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--wave-merge", type=int, default=1)
     ap.add_argument("--set", action="append", default=[], help="engine option key=value (A/B switch)")
     ap.add_argument("--overlap", type=int, default=1, help="bin(t+1) || update(t) on two streams (A/B switch)")
+    ap.add_argument("--collective-timeout", type=int, default=120,
+                    help="seconds a collective may take before RCCL aborts it (a rank that failed leaves with a non-zero "
+                         "exit code at once; its peers follow when this expires)")
     return ap.parse_args()
 
 
@@ -325,13 +328,19 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.workload == "c5":
+        # (c5 runs its collectives over RCCL also with ONE rank: the N-rank code path, a 1-rank communicator)
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")  # a dead peer aborts the collective instead of hanging it
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"),
+                                timeout=datetime.timedelta(seconds=args.collective_timeout))
     from fastdem_amd import synth
 
-    if args.workload == "c5" and world > 1:
+    if args.workload == "c5":
         from fastdem_amd import tiling
+        args.stall_timeout = args.collective_timeout + 60
         result = tiling.bench_global(args, rank, local_rank, world)
     else:
         kw = {"order": args.order} if args.workload in ("c2", "c4") else {}
@@ -518,7 +527,7 @@ def main():
                 del big
             if world == 1 and not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(wl)
-    if world > 1:
+    if world > 1 or args.workload == "c5":
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -1369,7 +1369,6 @@ int fdm_engine_route_scan(fdm_engine* e, const fdm_route_plan* plan, uint64_t n,
   if (n >= 0x7FFFFFFFull) return fail(FDM_ERR_INVALID, "point count exceeds 2^31-1");
   if (e->cfg.mode != 1) return fail(FDM_ERR_INVALID, "scan routing is defined for GLOBAL maps");
   HIPCK(hipSetDevice(e->device));
-  if (int rc = join_streams(e)) return rc;  // (the committed geometry slot is the current one)
   RoutePlan R{};
   R.world = plan->world; R.pr = plan->grid_rows; R.pc = plan->grid_cols;
   for (int k = 0; k <= kMaxRanks; ++k) { R.row_edge[k] = plan->row_edge[k]; R.col_edge[k] = plan->col_edge[k]; }
@@ -1391,13 +1390,16 @@ int fdm_engine_route_scan(fdm_engine* e, const fdm_route_plan* plan, uint64_t n,
   fill_integrate_params(e, P, Tbs, Twb);
   sensor_params(e->cfg, P.sensor_type, P.sp);
   P.n = uint32_t(n);
-  P.slot = int(e->scan_no & 3);
+  // the geometry of a GLOBAL map never moves: while the last scan's update is still held back (it will commit slot
+  // scan_no & 3) the slot that scan read holds the same values
+  P.slot = int((e->chain ? e->scan_no + 3 : e->scan_no) & 3);
   if (blocks) {
     hipLaunchKernelGGL(k_route_count, dim3(blocks), dim3(256), 0, e->stream, P, e->G, R, e->d_state, dx, dy, dz,
                        e->d_route_owner, e->d_route_cnt);
     HIPCK(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(64u * cols), 0, e->stream, e->d_route_cnt, blocks, R.world, d_counts, base);
+  hipLaunchKernelGGL(k_route_scan, dim3(cols), dim3(1024), 0, e->stream, e->d_route_cnt, blocks, R.world, d_counts);
+  hipLaunchKernelGGL(k_route_base, dim3(1), dim3(64), 0, e->stream, d_counts, R.world, base);
   HIPCK(hipGetLastError());
   if (blocks) {
     hipLaunchKernelGGL(k_route_scatter, dim3(blocks), dim3(256), 0, e->stream, unsigned(n), R.world, e->d_route_owner,

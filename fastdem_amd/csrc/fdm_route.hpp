@@ -72,33 +72,53 @@ __global__ __launch_bounds__(256) void k_route_count(const ScanParams P, const G
         s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
 }
 
-// one block, one wavefront per column of cnt (world + 2 <= 18 wavefronts): exclusive scan over the blocks
+// one 1024-thread block per column of cnt (world + 2 columns): exclusive scan over the scan's blocks, eight
+// consecutive entries per thread and pass so that their loads are in flight together (one wavefront walking the
+// column entry by entry spent 100 us of dependent load latency on a 2 M-point slice)
 __global__ __launch_bounds__(1024) void k_route_scan(uint32_t* __restrict__ cnt, unsigned blocks, int world,
-                                                      uint32_t* __restrict__ totals /* [world + 2] */,
-                                                      uint32_t* __restrict__ base /* [world] */) {
-  __shared__ unsigned s_tot[kMaxRanks + 2];
-  const unsigned col = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  const unsigned cols = unsigned(world + 2);
-  if (col < cols) {
-    unsigned run = 0;
-    for (unsigned b0 = 0; b0 < blocks; b0 += 64u) {
-      const unsigned b = b0 + lane;
-      const unsigned v = b < blocks ? cnt[size_t(b) * cols + col] : 0u;
-      unsigned inc = v;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const unsigned o = __shfl_up(inc, d);
-        if (int(lane) >= d) inc += o;
-      }
-      if (b < blocks) cnt[size_t(b) * cols + col] = run + inc - v;  // exclusive, in place
-      run += __shfl(inc, 63);
-    }
-    if (lane == 0u) { s_tot[col] = run; totals[col] = run; }
-  }
+                                                      uint32_t* __restrict__ totals /* [world + 2] */) {
+  __shared__ unsigned s_w[16];
+  __shared__ unsigned s_run;
+  const unsigned col = blockIdx.x, cols = unsigned(world + 2);
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_run = 0u;
   __syncthreads();
-  if (threadIdx.x == 0) {
+  for (unsigned b0 = 0; b0 < blocks; b0 += 8192u) {
+    unsigned v[8], mine = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned b = b0 + threadIdx.x * 8u + unsigned(j);
+      v[j] = b < blocks ? cnt[size_t(b) * cols + col] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mine += v[j];
+    unsigned inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned o = __shfl_up(inc, d);
+      if (int(lane) >= d) inc += o;
+    }
+    if (lane == 63u) s_w[wave] = inc;
+    __syncthreads();
+    unsigned before = s_run + inc - mine;
+    for (unsigned w = 0; w < wave; ++w) before += s_w[w];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned b = b0 + threadIdx.x * 8u + unsigned(j);
+      if (b < blocks) cnt[size_t(b) * cols + col] = before;  // exclusive, in place
+      before += v[j];
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023u) s_run = before;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[col] = s_run;
+}
+// the owners' shares in the send buffer start where the shares of the lower ranks end
+__global__ void k_route_base(const uint32_t* __restrict__ totals, int world, uint32_t* __restrict__ base) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
     unsigned acc = 0;
-    for (int d = 0; d < world; ++d) { base[d] = acc; acc += s_tot[d]; }
+    for (int d = 0; d < world; ++d) { base[d] = acc; acc += totals[d]; }
   }
 }
 

@@ -262,34 +262,56 @@ class RoutedScan:
         self.rp = route_plan(plan)
         self.device = device
         self.send = torch.empty((max(max_points, 1), 4), dtype=torch.float32, device=device)
-        self.counts = torch.zeros(plan.world + 2, dtype=torch.int32, device=device)
+        # this rank's row of the per-step table: world + 2 counters (written by the routing kernels) | the rank's two
+        # transforms as raw float64 bits (64 words, copied from pinned memory without a host sync)
+        W = plan.world
+        self.row = torch.zeros(W + 2 + 64, dtype=torch.int32, device=device)
+        self.counts = self.row[:W + 2]
+        self.pose_pinned = torch.zeros(32, dtype=torch.float64).pin_memory()
+        self.table_dev = torch.zeros((W, W + 2 + 64), dtype=torch.int32, device=device)
+        self.table_pinned = torch.zeros((W, W + 2 + 64), dtype=torch.int32).pin_memory()
         self.recv = None
         self.matrix = None
+        self._obstacle_dirty = True  # (sensors mode) the tile's obstacle layer may hold non-NaN cells
 
     def _recv_buffer(self, n):
         if self.recv is None or self.recv.shape[0] < n:
             self.recv = self.torch.empty((max(n + n // 4, 1024), 4), dtype=self.torch.float32, device=self.device)
         return self.recv
 
-    def integrate(self, x, y, z, T_base_sensor, T_world_base, dist, intensity=None, group=None):
-        """x, y, z[, intensity]: this rank's slice (device tensors).  Returns the counter matrix (numpy, world x
-        (world + 2)): [src, dst] points sent, [src, world] n_after_filter, [src, world + 1] n_in_map."""
+    def integrate(self, x, y, z, T_base_sensor, T_world_base, dist, intensity=None, group=None, sensors=False):
+        """x, y, z[, intensity]: this rank's part of the step (device tensors).
+        sensors=False — ONE logical scan cut into slices: every rank passes the same transforms, the owners integrate
+          everything they received as one scan (= FastDEM::integrate of the concatenated cloud).
+        sensors=True  — N scans, one per rank (N sensors / robots feeding one global map), each with its OWN
+          transforms: the step is N FastDEM::integrate calls in rank order; an owner integrates the records of each
+          source with that source's transforms, in that order.
+        Returns the counter matrix (numpy, world x (world + 2)): [src, dst] points sent, [src, world]
+        n_after_filter, [src, world + 1] n_in_map."""
         torch, W, me = self.torch, self.plan.world, self.plan.rank
         n = int(x.numel())
         assert n <= self.send.shape[0]
         self.eng.route_scan(self.rp, x, y, z, T_base_sensor, T_world_base, self.send, self.counts, intensity=intensity)
         self.eng.torch_wait()  # torch's stream (the collective's) behind the routing kernels
-        if W > 1:
-            if self.staged:
-                gathered = [torch.empty(W + 2, dtype=torch.int32) for _ in range(W)]
-                dist.all_gather(gathered, self.counts.cpu(), group=group)
-                matrix = torch.stack(gathered).numpy().astype(np.int64)
-            else:
-                dev = torch.empty((W, W + 2), dtype=torch.int32, device=self.device)
-                dist.all_gather_into_tensor(dev, self.counts, group=group)
-                matrix = dev.cpu().numpy().astype(np.int64)
+        # one small all-gather: the world + 2 counters and the two transforms of every rank; ONE host read-back
+        self.pose_pinned[:16] = torch.from_numpy(np.asarray(T_base_sensor, dtype=np.float64).reshape(16))
+        self.pose_pinned[16:] = torch.from_numpy(np.asarray(T_world_base, dtype=np.float64).reshape(16))
+        self.row[W + 2:].copy_(self.pose_pinned.view(torch.int32), non_blocking=True)
+        if W > 1 and self.staged:
+            gathered = [torch.empty(W + 66, dtype=torch.int32) for _ in range(W)]
+            dist.all_gather(gathered, self.row.cpu(), group=group)
+            raw = torch.stack(gathered).numpy()
         else:
-            matrix = self.counts.cpu().numpy().astype(np.int64).reshape(1, W + 2)
+            if W > 1:
+                dist.all_gather_into_tensor(self.table_dev, self.row, group=group)
+                self.table_pinned.copy_(self.table_dev, non_blocking=True)
+            else:
+                self.table_pinned[0].copy_(self.row, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            raw = self.table_pinned.numpy()
+        table = np.concatenate([raw[:, :W + 2].astype(np.float64),
+                                np.ascontiguousarray(raw[:, W + 2:]).view(np.float64)], axis=1)
+        matrix = table[:, :W + 2].astype(np.int64)
         self.matrix = matrix
         n_recv = int(matrix[:, me].sum())
         any_in_map = bool(matrix[:, W + 1].sum() > 0)
@@ -320,16 +342,62 @@ class RoutedScan:
                 if peer is not None:
                     recv[recv_off[peer]:recv_off[peer] + nr].copy_(rb)
             torch.cuda.current_stream().synchronize()
-        self.eng.integrate_points4_device(recv, n_recv, T_base_sensor, T_world_base,
-                                          has_intensity=intensity is not None, any_in_map=any_in_map)
+        if not sensors:
+            self.eng.integrate_points4_device(recv, n_recv, T_base_sensor, T_world_base,
+                                              has_intensity=intensity is not None, any_in_map=any_in_map)
+            return matrix
+        for src in range(W):  # N scans, in rank order
+            ns = int(matrix[src, me])
+            seen = bool(matrix[src, W + 1] > 0)  # that scan observed a cell somewhere: update() ran (obstacle clear)
+            if ns == 0 and not (seen and self._obstacle_dirty):
+                continue  # nothing for this tile, and its obstacle layer is clear already: the clear would be a no-op
+            Tbs = table[src, W + 2:W + 18].reshape(4, 4)
+            Twb = table[src, W + 18:W + 34].reshape(4, 4)
+            self.eng.integrate_points4_device(recv[recv_off[src]:recv_off[src] + ns] if ns else recv, ns, Tbs, Twb,
+                                              has_intensity=intensity is not None, any_in_map=seen)
+            self._obstacle_dirty = ns > 0
         return matrix
 
 
 # --------------------------------------------------------------------------- bench (C5) ----
+class Watchdog:
+    """A rank that stalls (a peer died inside a collective, a hung kernel) must not hang the node's benchmark: if
+    `kick()` is not called for `seconds`, the process prints what it was doing and leaves with exit code 3 — plain
+    os._exit from a helper thread; nothing is exec'ed, the GPU context dies with the process."""
+
+    def __init__(self, seconds, what="bench"):
+        import threading
+        import time
+        self._t, self._time, self.what, self.seconds, self.stage = time.monotonic(), time, what, seconds, "start"
+        self._stop = False
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    def kick(self, stage=None):
+        self._t = self._time.monotonic()
+        if stage is not None:
+            self.stage = stage
+
+    def stop(self):
+        self._stop = True
+
+    def _run(self):
+        import os
+        import sys
+        while not self._stop:
+            self._time.sleep(1.0)
+            if self._time.monotonic() - self._t > self.seconds:
+                sys.stderr.write(f"[{self.what}] no progress for {self.seconds} s in stage '{self.stage}': giving up\n")
+                sys.stderr.flush()
+                os._exit(3)
+
+
 def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]:
-    """configs[4]: one 400x400 m @ 0.05 m GLOBAL map tiled over `world` GPUs; a step = scan
-    broadcast from rank 0 + integrate on every rank + halo exchange."""
-    import ctypes as C
+    """configs[4]: one 400x400 m @ 0.05 m GLOBAL map tiled over `world` GPUs.  N-sensor mode (weak scaling): every
+    rank is a robot with its own 2 M-point scan stream, on the same 150 m circle a world-th of a turn apart; a step =
+    `world` FastDEM::integrate calls (rank order) into the one global map = route the own scan by owner -> gather the
+    counters -> exchange the point records -> integrate what arrived, source by source -> halo exchange.  Runs over
+    RCCL (backend nccl) also with ONE rank: the collectives are then 1-rank collectives, the code path is the N-rank one."""
     import time
 
     import torch
@@ -337,76 +405,81 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
 
     from . import Engine, capi, synth
 
-    wl = synth.global_map(n_scans=2)
-    dev = f"cuda:{local_rank}"
-    rows = cols = int(round(float(np.float32(wl.width)) / float(np.float32(wl.resolution))))
-    plan = make_plan(rank, world, rows, cols, DEFAULT_HALO)
-    eng = Engine(wl.width, wl.height, wl.resolution, wl.apply_to(capi.default_config()),
-                 tile=plan.fdm_tile() if world > 1 else None, device=local_rank)
-    tile = EngineTile(eng, plan, dev)
-    names = ["elevation", "variance", "elevation_min", "elevation_max", "upper_bound",
-             "lower_bound", "n_points", "obstacle", "intensity"]
-    chans = ("x", "y", "z", "intensity")
-    n_pts = wl.n_points
-    # rank 0 holds the scans; every rank has ONE packed [4, N] receive buffer (one broadcast per scan, not
-    # one per channel), double-buffered so that scan k+1 can be distributed while scan k is integrated
-    src = [torch.stack([torch.from_numpy(s[c]) for c in chans]).to(dev) for s in wl.scans] if rank == 0 else None
-    staged = [torch.empty((4, n_pts), dtype=torch.float32, device=dev) for _ in range(2)]
-    tbs = (C.c_double * 16)(*np.ascontiguousarray(wl.T_base_sensor.T).reshape(16).tolist())
-    steps, warm = min(args.steps, 200), min(args.warmup, 20)
-    poses = [(C.c_double * 16)(*np.ascontiguousarray(wl.pose(k).T).reshape(16).tolist())
-             for k in range(steps + warm)]
-    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    dog = Watchdog(float(getattr(args, "stall_timeout", 180.0)), what=f"bench c5 rank {rank}")
+    try:
+        wl = synth.global_map(n_scans=2)
+        dev = f"cuda:{local_rank}"
+        rows = cols = int(round(float(np.float32(wl.width)) / float(np.float32(wl.resolution))))
+        plan = make_plan(rank, world, rows, cols, DEFAULT_HALO)
+        dog.kick("engine")
+        eng = Engine(wl.width, wl.height, wl.resolution, wl.apply_to(capi.default_config()),
+                     tile=plan.fdm_tile() if world > 1 else None, device=local_rank)
+        tile = EngineTile(eng, plan, dev)
+        names = ["elevation", "variance", "elevation_min", "elevation_max", "upper_bound",
+                 "lower_bound", "n_points", "obstacle", "intensity"]
+        n_pts = wl.n_points
+        router = RoutedScan(eng, plan, dev, max_points=n_pts)
+        mine = [{c: torch.from_numpy(s[c]).to(dev) for c in ("x", "y", "z", "intensity")} for s in wl.scans]
+        steps, warm = min(args.steps, 200), min(args.warmup, 20)
+        # robot `rank` of `world`: the workload's 150 m circle (0.4 m per pose: 2356 poses per turn), a world-th of a
+        # turn ahead per rank
+        turn = int(round(2.0 * np.pi * 150.0 / 0.4))
+        pose = lambda k: wl.pose(k + (turn * rank) // world)  # noqa: E731
 
-    def step(k):
-        if world > 1:
-            cur = staged[k & 1]
-            if rank == 0:
-                cur.copy_(src[k % len(src)])
-            dist.broadcast(cur, 0)   # on torch's stream ...
-            eng.wait_torch()         # ... which the engine's stream waits for (an event, no host sync)
-        else:
-            cur = src[k % len(src)]
-        rc = eng.integrate_device_raw(n_pts, p(cur[0]), p(cur[1]), p(cur[2]), tbs, poses[k], p(cur[3]))
-        assert rc == 0, rc
-        exchange_halos(tile, plan, names, dist)
-        return n_pts
+        def step(k):
+            d = mine[k % len(mine)]
+            router.integrate(d["x"], d["y"], d["z"], wl.T_base_sensor, pose(k), dist, intensity=d["intensity"],
+                             sensors=True)
+            exchange_halos(tile, plan, names, dist)
+            dog.kick(f"step {k}")
+            return n_pts
 
-    def barrier():
-        eng.sync()
-        torch.cuda.synchronize()
-        if world > 1:
+        def barrier():
+            eng.sync()
+            torch.cuda.synchronize()
             dist.barrier()
 
-    k = 0
-    for _ in range(warm):
-        step(k)
-        k += 1
-    barrier()
-    t0 = time.perf_counter()
-    pts = 0
-    for _ in range(steps):
-        pts += step(k)
-        k += 1
-    eng.sync()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
+        k = 0
+        for _ in range(warm):
+            step(k)
+            k += 1
+        barrier()
+        t0 = time.perf_counter()
+        pts = 0
+        for _ in range(steps):
+            pts += step(k)
+            k += 1
+        eng.sync()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
         dist.barrier()
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    rc, st = eng.last_stats()
+        rc, st = eng.last_stats()
+        routed = router.matrix
+    except BaseException as exc:  # a failing rank leaves at once with a non-zero code: its peers' watchdogs / the
+        import os                 # collective timeout then end them, the launcher sees the failure
+        import sys
+        import traceback
+        traceback.print_exc()
+        sys.stderr.write(f"[bench c5 rank {rank}] failed: {exc!r}\n")
+        sys.stderr.flush()
+        os._exit(2)
+    dog.stop()
     if rank != 0:
         return None
+    pr, pc = grid_for(world)
     return {
         "metric": "M points/s integrated into ElevationMap",
-        "value": pts / dt / 1e6, "unit": "Mpts/s", "n_gpus": world, "steps": steps, "warmup": warm,
-        "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "value": pts * world / dt / 1e6, "unit": "Mpts/s", "n_gpus": world, "steps": steps, "warmup": warm,
+        "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": wl.name, "points_per_scan": wl.n_points, "map_cells": rows * cols,
-                   "parallelism": f"spatial tiles {grid_for(world)[0]}x{grid_for(world)[1]}, halo {DEFAULT_HALO} cells, "
-                                  "one packed scan broadcast + p2p halo exchange per scan, stream-ordered by events",
-                   "inputs": "SoA float32 (x, y, z, intensity) resident in HBM on rank 0"},
+        "config": {"workload": wl.name, "points_per_scan": wl.n_points, "scans_per_step": world, "map_cells": rows * cols,
+                   "parallelism": f"spatial tiles {pr}x{pc}, halo {DEFAULT_HALO} cells; N-sensor mode: every rank routes its own "
+                                  "2 M-point scan to the owners of the cells (16 B point records, point-to-point over RCCL), the "
+                                  "owners integrate source by source, p2p halo exchange per step",
+                   "inputs": "SoA float32 (x, y, z, intensity) resident in HBM on every rank"},
         "rank0_last_scan": st,
+        "rank0_routing_matrix_last_step": routed.tolist() if routed is not None else None,
     }

@@ -48,3 +48,17 @@ def test_cpp_api_spec_tests_on_gpu():
     assert np.isfinite(elev).sum() == 16 and np.allclose(elev[np.isfinite(elev)], 1.25)
     assert {"variance", "n_points", "_kalman_p", "obstacle"} <= set(z.files)
     os.remove(path)
+
+
+@pytest.mark.gpu
+def test_cpp_multi_gpu_loops_with_a_one_rank_rccl_communicator():
+    """INTEGRATION.md §D compiled and run: a C++ host (HIP + RCCL) driving libfdm_halo.so — the replicated-scan loop
+    (ncclBroadcast + integrate + halo exchange) and the routed-scan loop (route + ncclAllGather + point exchange +
+    integrate), each against a plain engine, bit for bit."""
+    exe = os.path.join(ROOT, "fastdem_amd", "cpp", "build", "fdm_halo_loop")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "fastdem_amd", "cpp"), "halo_loop"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "halo loop: ok" in r.stdout

@@ -156,6 +156,58 @@ def _routed_worker(rank, world, port, q, backend):
         q.put((rank, [("exception", traceback.format_exc(), str(e))], 0))
 
 
+def _sensors_worker(rank, world, port, q, backend):
+    """N sensors mode: every rank contributes ITS OWN scan (own pose) to every step; the step is N integrate() calls
+    in rank order on the global map."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        sys.path.insert(0, ROOT)
+        import torch
+        import torch.distributed as dist
+        from fastdem_amd import Engine, capi, synth, tiling
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend, rank=rank, world_size=world,
+                                **({"device_id": torch.device("cuda:0")} if backend == "nccl" else {}))
+        wl = synth.global_map(n_scans=4, size_m=100.0, n_az=1024, radius=30.0)
+        rows = cols = 2000
+        plan = tiling.make_plan(rank, world, rows, cols, tiling.DEFAULT_HALO)
+        eng = Engine(wl.width, wl.height, wl.resolution, wl.apply_to(capi.default_config()),
+                     tile=plan.fdm_tile() if world > 1 else None, device=0)
+        inner = tiling.EngineTile(eng, plan, "cuda:0")
+        tile = tiling.HostStagedTile(inner) if backend == "gloo" else inner
+        whole = Engine(wl.width, wl.height, wl.resolution, wl.apply_to(capi.default_config()), device=0)
+        router = tiling.RoutedScan(eng, plan, "cuda:0", max_points=wl.n_points, staged=backend == "gloo")
+        pose_of = lambda k, r: wl.pose(11 * k + 37 * r)  # noqa: E731  (robots far apart on the circle; some overlap over time)
+        names = None
+        for k in range(4):
+            s = wl.scan((k + rank) % 4)
+            d = {c: torch.from_numpy(s[c]).cuda() for c in ("x", "y", "z", "intensity")}
+            router.integrate(d["x"], d["y"], d["z"], wl.T_base_sensor, pose_of(k, rank), dist, intensity=d["intensity"],
+                             sensors=True)
+            names = [nm for nm in tiling.visible_layers(eng.layers())]
+            have = [None] * world
+            dist.all_gather_object(have, names)
+            names = [nm for nm in names if all(nm in h for h in have)]
+            tiling.exchange_halos(tile, plan, names, dist)
+            for r in range(world):  # the reference order: one integrate() per sensor, rank order
+                sr = wl.scan((k + r) % 4)
+                whole.integrate(sr["x"], sr["y"], sr["z"], wl.T_base_sensor, pose_of(k, r), intensity=sr["intensity"])
+        st_rect = plan.stored if world > 1 else tiling.Rect(0, 0, rows, cols)
+        bad = []
+        for nm in names:
+            got = eng.layer(nm)
+            want = whole.layer(nm)[st_rect.r0:st_rect.r1, st_rect.c0:st_rect.c1]
+            if not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
+                bad.append((nm, int((got.view(np.uint32) != want.view(np.uint32)).sum())))
+        q.put((rank, bad, len(names)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, [("exception", traceback.format_exc(), str(e))], 0))
+
+
 def _run(target, world, *extra):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -184,5 +236,15 @@ def test_routed_scan_over_rccl_with_one_rank():
     """The same driver over backend "nccl" (RCCL) with a 1-rank communicator: all-gather of the counters, the self
     share of the exchange, integrate of the received records — the device-to-device path an N-GPU node runs."""
     for rank, bad, n_names in _run(_routed_worker, 1, "nccl"):
+        assert not bad, f"rank {rank}: {bad}"
+        assert n_names >= 8
+
+
+@pytest.mark.parametrize("world,backend", [(2, "gloo"), (4, "gloo"), (1, "nccl")])
+def test_n_sensors_feeding_one_global_map(world, backend):
+    """Every rank is a sensor with its own scan stream and pose; a step = N integrate() calls in rank order.  Owners
+    integrate each source's records with that source's transforms.  Bit-identical to the untiled engine fed the N
+    scans one after the other."""
+    for rank, bad, n_names in _run(_sensors_worker, world, backend):
         assert not bad, f"rank {rank}: {bad}"
         assert n_names >= 8
