@@ -217,7 +217,10 @@ struct fdm_engine {
   uint32_t* d_route_cnt = nullptr;   // [route_blocks_cap][world + 2] block counts -> offsets | [kMaxRanks] bases at the end
   size_t route_cap = 0, route_blocks_cap = 0;
   // stencil post-processing (fdm_post.hpp)
-  RegionEntry* d_region = nullptr;   // kMaxRegion entries
+  RegionEntry* d_region = nullptr;   // region_cap entries
+  size_t region_cap = 0;
+  float* d_post_pool = nullptr;      // per-thread lists of the big-neighbourhood stencil kernels
+  size_t post_pool_bytes = 0;
   FeatEntry* d_feat_tab = nullptr;   // kMaxRegion entries: the region as k_features_tiled reads it
   int dbg_post = 0;                  // measurement only: 1 = untiled feature kernel
   int dbg_span = 0;                  // measurement only: tiles per update group (0 = automatic)
@@ -1223,6 +1226,7 @@ void fdm_engine_destroy(fdm_engine* e) {
   for (auto& ev : e->ev_timer)
     if (ev) (void)hipEventDestroy(ev);
   if (e->d_region) (void)hipFree(e->d_region);
+  if (e->d_post_pool) (void)hipFree(e->d_post_pool);
   if (e->d_feat_tab) (void)hipFree(e->d_feat_tab);
   if (e->d_timeline) (void)hipFree(e->d_timeline);
   if (e->d_tmp2) (void)hipFree(e->d_tmp2);

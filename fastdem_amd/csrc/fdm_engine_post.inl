@@ -18,8 +18,13 @@ int check_halo(const fdm_engine* e, int need) {
 }
 // neighbourhood offsets, dr-major / dc-minor; box = region(Size(k,k)), disc = region(radius)
 int upload_region(fdm_engine* e, const std::vector<RegionEntry>& reg) {
-  if (reg.size() > size_t(kMaxRegion)) return fail(FDM_ERR_INVALID, "neighbourhood larger than 256 cells");
-  if (!e->d_region) HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_region), kMaxRegion * sizeof(RegionEntry)));
+  if (reg.size() > e->region_cap) {  // (any disc the reference accepts: 0.3 m on a 0.02 m map is 707 cells)
+    if (int rc_sync = sync_all(e)) return rc_sync;
+    if (e->d_region) HIPCK(hipFree(e->d_region));
+    e->d_region = nullptr;
+    e->region_cap = std::max<size_t>(size_t(kMaxRegion), reg.size() + reg.size() / 4);
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_region), e->region_cap * sizeof(RegionEntry)));
+  }
   HIPCK(hipMemcpyAsync(e->d_region, reg.data(), reg.size() * sizeof(RegionEntry), hipMemcpyHostToDevice, e->stream));
   if (int rc_sync = sync_all(e)) return rc_sync;  // `reg` is a host temporary
   return FDM_OK;
@@ -36,6 +41,21 @@ void region_disc(const fdm_engine* e, float radius, std::vector<RegionEntry>& re
     }
 }
 unsigned cell_blocks(const fdm_engine* e) { return unsigned((e->ncell + 255) / 256); }
+// The global list pool of the big-neighbourhood kernels (fdm_post.hpp, k_median_big): `per_thread` floats for each of
+// the threads in flight.  Returns the number of blocks of `threads` threads to launch.
+int ensure_pool(fdm_engine* e, size_t per_thread, unsigned threads, unsigned* blocks_out) {
+  const size_t want_threads = std::min<size_t>(((e->ncell + threads - 1) / threads) * threads, 16384);
+  const size_t bytes = want_threads * per_thread * sizeof(float);
+  if (bytes > e->post_pool_bytes) {
+    if (int rc_sync = sync_all(e)) return rc_sync;
+    if (e->d_post_pool) HIPCK(hipFree(e->d_post_pool));
+    e->d_post_pool = nullptr;
+    e->post_pool_bytes = bytes;
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_post_pool), bytes));
+  }
+  *blocks_out = unsigned(want_threads / threads);
+  return FDM_OK;
+}
 unsigned tile3_blocks(const fdm_engine* e) {  // 32 x 8-cell tiles of the 3x3 stencils (fdm_post.hpp)
   return unsigned((e->G.s_rows + kS3R - 1) / kS3R) * unsigned((e->G.s_cols + kS3C - 1) / kS3C);
 }
@@ -90,8 +110,9 @@ int fdm_engine_apply_inpainting(fdm_engine* e, int max_iterations, int min_valid
 int fdm_engine_apply_spatial_smoothing(fdm_engine* e, const char* layer, int kernel_size, int min_valid) {
   if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !layer) return fail(FDM_ERR_INVALID, "null argument");
-  if (kernel_size < 1 || kernel_size > 15 || (kernel_size & 1) == 0)
-    return fail(FDM_ERR_INVALID, "kernel_size must be odd and in [1, 15]");
+  // (any kernel size the reference accepts: region(Size(k, k)) spans dr, dc in [-k/2, k/2] — for an even k that is the
+  // (k + 1)-wide box; a window beyond kMaxRegion cells takes the pooled kernel)
+  if (kernel_size < 1 || kernel_size > 4096) return fail(FDM_ERR_INVALID, "kernel_size must be in [1, 4096]");
   HIPCK(hipSetDevice(e->device));
   int rc;
   if ((rc = check_halo(e, kernel_size / 2))) return rc;
@@ -106,10 +127,17 @@ int fdm_engine_apply_spatial_smoothing(fdm_engine* e, const char* layer, int ker
   else if (kernel_size == 3)
     hipLaunchKernelGGL(k_median3, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state,
                        int(e->scan_no & 3), e->d_tmp, lptr(e, *l), lstride(e, *l), min_valid, unsigned(e->ncell));
-  else
+  else if ((2 * (kernel_size / 2) + 1) * (2 * (kernel_size / 2) + 1) <= kMaxRegion)
     hipLaunchKernelGGL(k_median, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state,
                        int(e->scan_no & 3), e->d_tmp, lptr(e, *l), lstride(e, *l), kernel_size, min_valid,
                        unsigned(e->ncell));
+  else {
+    const size_t side = size_t(2 * (kernel_size / 2) + 1);
+    unsigned blocks = 0;
+    if ((rc = ensure_pool(e, side * side, 256u, &blocks))) return rc;
+    hipLaunchKernelGGL(k_median_big, dim3(blocks), dim3(256), 0, e->stream, e->G, e->d_state, int(e->scan_no & 3),
+                       e->d_tmp, lptr(e, *l), lstride(e, *l), kernel_size, min_valid, unsigned(e->ncell), e->d_post_pool);
+  }
   HIPCK(hipGetLastError());
   if (std::strcmp(layer, "obstacle") == 0) e->obst_dense_pending = true;
   return FDM_OK;
@@ -168,10 +196,16 @@ int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* 
     hipLaunchKernelGGL(k_fusion<true>, dim3(fblocks), dim3(kFusionThreads), lds, e->stream, e->G, e->d_state,
                        int(e->scan_no & 3), e->d_region, F, e->d_tmp, e->d_tmp2, lptr(e, *up), lstride(e, *up),
                        lptr(e, *lo), lstride(e, *lo), unsigned(e->ncell));
-  } else {
+  } else if (reg.size() <= size_t(kMaxRegion)) {
     hipLaunchKernelGGL(k_fusion<false>, dim3(fblocks), dim3(kFusionThreads), 0, e->stream, e->G, e->d_state,
                        int(e->scan_no & 3), e->d_region, F, e->d_tmp, e->d_tmp2, lptr(e, *up), lstride(e, *up),
                        lptr(e, *lo), lstride(e, *lo), unsigned(e->ncell));
+  } else {  // any radius the reference accepts (config/postprocess.hpp:35)
+    unsigned blocks = 0;
+    if ((rc = ensure_pool(e, 4 * reg.size(), unsigned(kFusionThreads), &blocks))) return rc;
+    hipLaunchKernelGGL(k_fusion_big, dim3(blocks), dim3(kFusionThreads), 0, e->stream, e->G, e->d_state,
+                       int(e->scan_no & 3), e->d_region, F, e->d_tmp, e->d_tmp2, lptr(e, *up), lstride(e, *up),
+                       lptr(e, *lo), lstride(e, *lo), unsigned(e->ncell), e->d_post_pool);
   }
   HIPCK(hipGetLastError());
   return FDM_OK;
@@ -255,7 +289,13 @@ int fdm_engine_apply_feature_extraction(fdm_engine* e, float radius, int min_val
     else launch_tiled(k_features_tiled<16>);
   } else if (pct_ok && need_lo <= 8 && need_hi <= 8) launch_feat(k_features<8>);
   else if (pct_ok && need_lo <= 16 && need_hi <= 16) launch_feat(k_features<16>);
-  else launch_feat(k_features<0>);
+  else if (reg.size() <= size_t(kMaxRegion)) launch_feat(k_features<0>);
+  else {  // any radius the reference accepts (config/postprocess.hpp:45): the sorted heights in the global pool
+    unsigned blocks = 0;
+    if ((rc = ensure_pool(e, reg.size(), 256u, &blocks))) return rc;
+    hipLaunchKernelGGL(k_features_big, dim3(blocks), dim3(256), 0, e->stream, e->G, e->d_state, int(e->scan_no & 3),
+                       e->d_region, F, elev_p, elev_s, O, unsigned(e->ncell), e->d_post_pool);
+  }
   HIPCK(hipGetLastError());
   return FDM_OK;
 }

@@ -105,6 +105,43 @@ __global__ __launch_bounds__(256) void k_median(const GeomConst G, const DevStat
   out[ci * out_stride] = win[n / 2];  // nth_element(size/2)
 }
 
+// Neighbourhoods beyond kMaxRegion cells (a 17 x 17 median, a 0.3 m disc on a 0.02 m map = 707 cells): the
+// per-thread lists live in a global pool, slot-major / thread-minor (`list[k * pitch]`, pitch = threads in flight,
+// so that the lanes of a wavefront touch consecutive words), and a thread walks the map with a grid stride.  The same
+// insertion-sorted lists as the small-neighbourhood kernels — O(n^2) per cell: a slow path that exists so that no
+// call the reference accepts is refused (spatial_smoothing.hpp:38-67, config/postprocess.hpp:35,45).
+struct PoolList {
+  float* base;
+  unsigned pitch;
+  __device__ __forceinline__ float& operator[](int k) const { return base[size_t(k) * pitch]; }
+};
+__global__ __launch_bounds__(256) void k_median_big(const GeomConst G, const DevState* __restrict__ st, int slot,
+                                                    const float* __restrict__ in, float* __restrict__ out,
+                                                    int out_stride, int kernel, int min_valid, unsigned ncell,
+                                                    float* __restrict__ pool) {
+  const unsigned tid = blockIdx.x * 256u + threadIdx.x, pitch = gridDim.x * 256u;
+  const PoolList win{pool + tid, pitch};
+  const PostGeom p = post_geom(st, slot, G);
+  const int h = kernel / 2;
+  for (unsigned t = tid; t < ncell; t += pitch) {
+    const int lc = int(t / unsigned(p.rows)), lr = int(t - unsigned(lc) * unsigned(p.rows));
+    const size_t ci = post_index(p, lr, lc);
+    if (!isfinite(in[ci])) continue;
+    int n = 0;
+    for (int dr = -h; dr <= h; ++dr)
+      for (int dc = -h; dc <= h; ++dc) {
+        if (!post_inside(p, lr + dr, lc + dc)) continue;
+        const float v = in[post_index(p, lr + dr, lc + dc)];
+        if (!isfinite(v)) continue;
+        int k = n++;
+        while (k > 0 && win[k - 1] > v) { win[k] = win[k - 1]; --k; }
+        win[k] = v;
+      }
+    if (n < min_valid) continue;
+    out[ci * out_stride] = win[n / 2];
+  }
+}
+
 // 3x3 window (the default kernel): the nine values are named registers, missing / non-finite
 // neighbours are +inf, a 25-step sorting network (verified on all 512 0-1 inputs) orders them and
 // element n/2 of the n finite ones is the median — no window in scratch memory, no dependent loop.
@@ -237,6 +274,21 @@ struct SampleList {
   float* base;  // LDS: list[slot * kFusionThreads]; scratch: list[slot]
   __device__ __forceinline__ float& operator[](int k) const { return USE_LDS ? base[k * kFusionThreads] : base[k]; }
 };
+template <class LIST>
+__device__ __forceinline__ float ecdf_quantile_l(const LIST& val, const LIST& wgt, int n, float p) {
+  if (n == 0) return __uint_as_float(0x7FC00000u);
+  if (n == 1) return val[0];
+  float total = 0.0f;
+  for (int k = 0; k < n; ++k) total += wgt[k];
+  if (total <= 0.0f) return __uint_as_float(0x7FC00000u);
+  const float target = p * total;
+  float cumulative = 0.0f;
+  for (int k = 0; k < n; ++k) {
+    cumulative += wgt[k];
+    if (cumulative >= target) return val[k];
+  }
+  return val[n - 1];
+}
 template <bool USE_LDS>
 __device__ __forceinline__ float ecdf_quantile_t(const SampleList<USE_LDS>& val, const SampleList<USE_LDS>& wgt, int n,
                                                  float p) {
@@ -301,6 +353,51 @@ __global__ __launch_bounds__(kFusionThreads) void k_fusion(const GeomConst G, co
   if (isfinite(lower) && isfinite(upper)) {
     up_out[ci * up_stride] = upper;
     lo_out[ci * lo_stride] = lower;
+  }
+}
+
+// discs of more than kMaxRegion cells: the four lists in the global pool (see k_median_big)
+__global__ __launch_bounds__(kFusionThreads) void k_fusion_big(const GeomConst G, const DevState* __restrict__ st,
+                                                               int slot, const RegionEntry* __restrict__ reg,
+                                                               const FusionParams F, const float* __restrict__ up_in,
+                                                               const float* __restrict__ lo_in,
+                                                               float* __restrict__ up_out, int up_stride,
+                                                               float* __restrict__ lo_out, int lo_stride,
+                                                               unsigned ncell, float* __restrict__ pool) {
+  const unsigned tid = blockIdx.x * unsigned(kFusionThreads) + threadIdx.x, pitch = gridDim.x * unsigned(kFusionThreads);
+  const size_t list = size_t(F.n_entries) * pitch;
+  const PoolList lv{pool + tid, pitch}, lw{pool + list + tid, pitch}, uv{pool + 2 * list + tid, pitch},
+      uw{pool + 3 * list + tid, pitch};
+  const PostGeom p = post_geom(st, slot, G);
+  for (unsigned t = tid; t < ncell; t += pitch) {
+    const int lc = int(t / unsigned(p.rows)), lr = int(t - unsigned(lc) * unsigned(p.rows));
+    const size_t ci = post_index(p, lr, lc);
+    if (!isfinite(up_in[ci]) || !isfinite(lo_in[ci])) continue;
+    int nl = 0, nu = 0, valid = 0;
+    for (int e = 0; e < F.n_entries; ++e) {
+      const RegionEntry re = reg[e];
+      if (!post_inside(p, lr + re.dr, lc + re.dc)) continue;
+      const size_t ni = post_index(p, lr + re.dr, lc + re.dc);
+      const float nu_v = up_in[ni], nl_v = lo_in[ni];
+      if (!isfinite(nu_v) || !isfinite(nl_v)) continue;
+      const float weight = re.w * (1.0f / ((nu_v - nl_v) + 1e-4f));
+      if (weight > 1e-6f) {
+        int k = nl++;
+        while (k > 0 && lv[k - 1] > nl_v) { lv[k] = lv[k - 1]; lw[k] = lw[k - 1]; --k; }
+        lv[k] = nl_v; lw[k] = weight;
+        k = nu++;
+        while (k > 0 && uv[k - 1] > nu_v) { uv[k] = uv[k - 1]; uw[k] = uw[k - 1]; --k; }
+        uv[k] = nu_v; uw[k] = weight;
+      }
+      ++valid;
+    }
+    if (valid < F.min_valid) continue;
+    const float lower = ecdf_quantile_l(lv, lw, nl, F.q_lower);
+    const float upper = ecdf_quantile_l(uv, uw, nu, F.q_upper);
+    if (isfinite(lower) && isfinite(upper)) {
+      up_out[ci * up_stride] = upper;
+      lo_out[ci * lo_stride] = lower;
+    }
   }
 }
 
@@ -659,6 +756,50 @@ __global__ __launch_bounds__(256) void k_features(const GeomConst G, const DevSt
     z_hi = zs[hi];
   }
   features_store(O, ci, val, normal, trace, z_lo, z_hi);
+}
+
+// discs of more than kMaxRegion cells, any percentile pair: the sorted heights in the global pool (see k_median_big)
+__global__ __launch_bounds__(256) void k_features_big(const GeomConst G, const DevState* __restrict__ st, int slot,
+                                                      const RegionEntry* __restrict__ reg, const FeatureParams F,
+                                                      const float* __restrict__ elev, int elev_stride,
+                                                      const FeatureOut O, unsigned ncell, float* __restrict__ pool) {
+  const unsigned tid = blockIdx.x * 256u + threadIdx.x, pitch = gridDim.x * 256u;
+  const PoolList zs{pool + tid, pitch};
+  const PostGeom p = post_geom(st, slot, G);
+  for (unsigned t = tid; t < ncell; t += pitch) {
+    const int lc = int(t / unsigned(p.rows)), lr = int(t - unsigned(lc) * unsigned(p.rows));
+    const size_t ci = post_index(p, lr, lc);
+    const float center_z = elev[ci * elev_stride];
+    if (!isfinite(center_z)) continue;
+    float sum[3] = {0.f, 0.f, 0.f};
+    float sq[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int count = 0;
+    for (int e = 0; e < F.n_entries; ++e) {
+      const RegionEntry re = reg[e];
+      if (!post_inside(p, lr + re.dr, lc + re.dc)) continue;
+      const float nz = elev[post_index(p, lr + re.dr, lc + re.dc) * elev_stride];
+      if (!isfinite(nz)) continue;
+      const float d[3] = {float(-re.dr) * F.resf, float(-re.dc) * F.resf, nz - center_z};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sum[k] += d[k];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) sq[c * 3 + r] += d[r] * d[c];
+      int k = count++;  // z_vals kept sorted (std::sort at feature_extraction.cpp:100)
+      while (k > 0 && zs[k - 1] > nz) { zs[k] = zs[k - 1]; --k; }
+      zs[k] = nz;
+    }
+    if (count < F.min_valid) continue;
+    float cov[9], trace;
+    if (!features_cov(sum, sq, count, cov, &trace)) continue;
+    float val[3], normal[3];
+    eig3_direct(cov, val, normal);
+    if (val[1] < 1e-8f) continue;  // kMinEigenvalue
+    const int lo = static_cast<int>(F.lo_pct * float(count - 1));
+    const int hi = static_cast<int>(F.hi_pct * float(count - 1));
+    features_store(O, ci, val, normal, trace, zs[lo], zs[hi]);
+  }
 }
 
 // The same stage for dense layers (stride 1) and a region that reaches at most kFeatHaloMax cells: one block per

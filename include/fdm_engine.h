@@ -393,7 +393,9 @@ int fdm_engine_integrate_cloud2(fdm_engine* e, const void* data, int data_on_dev
  *   applySpatialSmoothing(map, layer, kernel_size, min_valid_neighbors)       postprocess/spatial_smoothing.hpp:38-67
  *   applyUncertaintyFusion(map, config::UncertaintyFusion)                    src/uncertainty_fusion.cpp:103-186
  *   applyFeatureExtraction(map, radius, min_valid, lower_pct, upper_pct)      src/feature_extraction.cpp:28-118
- * kernel_size must be odd and <= 15; a disc radius may cover at most 256 cells. */
+ * Any kernel size / radius the reference accepts is accepted: region(Size(k, k)) spans dr, dc in [-k/2, k/2] (for
+ * an even k the (k + 1)-wide box); neighbourhoods beyond 256 cells (a 17 x 17 median, a 0.3 m disc
+ * on a 0.02 m map) run through slower kernels whose per-cell lists live in a global pool. */
 typedef struct fdm_fusion_config {          /* config::UncertaintyFusion (config/postprocess.hpp:32-39) */
   int32_t enabled;
   float search_radius, spatial_sigma, quantile_lower, quantile_upper;

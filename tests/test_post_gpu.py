@@ -110,11 +110,13 @@ def test_median_smoothing_parity(gpu, R):
     eng, ref, shape = rolled_pair(gpu, R, rng)
     el = terrain(rng, shape, holes=0.2)
     el[rng.uniform(size=shape) < 0.02] = 50.0  # spikes
-    for k, mv in ((3, 5), (5, 9), (7, 1)):
+    # odd kernels, EVEN kernels (region(Size(k, k)) spans [-k/2, k/2]: the (k + 1)-wide box) and windows beyond 256
+    # cells (17 x 17 = 289, 22 -> 23 x 23 = 529: the pooled kernel) — every size the reference accepts
+    for k, mv in ((3, 5), (5, 9), (7, 1), (4, 5), (15, 30), (17, 40), (22, 3)):
         both((eng, ref), lambda o: (o.set_layer("elevation", el), o.apply_spatial_smoothing("elevation", k, mv)))
         exact(eng, ref, ["elevation"])
     with pytest.raises(gpu.EngineError):
-        eng.apply_spatial_smoothing("elevation", 4, 5)
+        eng.apply_spatial_smoothing("elevation", 0, 5)
 
 
 def test_uncertainty_fusion_parity(gpu, R):
@@ -127,6 +129,27 @@ def test_uncertainty_fusion_parity(gpu, R):
                                     o.apply_uncertainty_fusion(*cfgv)))
         exact(eng, ref, ["upper_bound", "lower_bound"])
     assert not np.array_equal(eng.layer("upper_bound"), el + half, equal_nan=True)
+
+
+def test_discs_of_more_than_256_cells(gpu, R):
+    """config/postprocess.hpp:35,45 put no bound on the radii: 0.3 m on a 0.02 m map is a disc of 709 cells, 0.15 m
+    one of 177.  The big-neighbourhood kernels (per-cell lists in a global pool) against the oracle: fusion bit-exact;
+    feature extraction bit-exact with correctly rounded trig (as the tiled kernel's test), `step` included."""
+    rng = np.random.default_rng(29)
+    eng, ref, shape = rolled_pair(gpu, R, rng, size=3.0, res=0.02)  # 150 x 150 cells
+    el = terrain(rng, shape, holes=0.2, noise=0.005)
+    half = np.abs(rng.normal(0.03, 0.02, shape)).astype(F32) + F32(0.004)
+    both((eng, ref), lambda o: (o.set_layer("upper_bound", el + half), o.set_layer("lower_bound", el - half),
+                                o.apply_uncertainty_fusion(True, 0.3, 0.1, 0.05, 0.95, 5)))
+    exact(eng, ref, ["upper_bound", "lower_bound"])
+    assert not np.array_equal(eng.layer("upper_bound"), el + half, equal_nan=True)
+    R.set_trig_mode(1)
+    try:
+        both((eng, ref), lambda o: (o.set_layer("elevation", el), o.apply_feature_extraction(0.3, 4, 0.05, 0.95)))
+        assert np.isfinite(eng.layer("slope")).sum() > 0.5 * el.size
+        exact(eng, ref, ["step", "slope", "roughness", "curvature", "_normal_x", "_normal_y", "_normal_z"])
+    finally:
+        R.set_trig_mode(0)
 
 
 EIGEN_LAYERS = ("roughness", "curvature", "_normal_x", "_normal_y", "_normal_z", "slope")
