@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+MEASURED_READ_GBS = 6400.0  # what a plain 16 B/lane read kernel reaches on this machine (profiles/r01/hbm_bw.jsonl)
 # distinct 2 M-point scans of the configs[3] legs: 9 x 33.5 MB = 302 MB of input cycle through the
 # timed region, more than the 256 MiB Infinity Cache can hold, so the read stream comes from HBM
 LARGE_SCANS = 9
@@ -54,6 +55,9 @@ def parse():
     ap.add_argument("--wave-merge", type=int, default=1)
     ap.add_argument("--set", action="append", default=[], help="engine option key=value (A/B switch)")
     ap.add_argument("--overlap", type=int, default=1, help="bin(t+1) || update(t) on two streams (A/B switch)")
+    ap.add_argument("--routed", type=int, default=1,
+                    help="c5: 1 = the tiled / routed multi-GPU path (also with one rank: a 1-rank RCCL communicator); 0 with "
+                         "--gpus 1 = the whole 8000 x 8000 map on one plain engine (the single-GPU roofline of configs[4])")
     ap.add_argument("--collective-timeout", type=int, default=120,
                     help="seconds a collective may take before RCCL aborts it (a rank that failed leaves with a non-zero "
                          "exit code at once; its peers follow when this expires)")
@@ -317,6 +321,64 @@ def cpu_baseline(wl, target_s=12.0):
             "host_cpu": cpu_model, "host_nproc": os.cpu_count()}
 
 
+def host_legs(res, wl, k, iters=50, stream_iters=200):
+    """the reference's own call shape — host arrays in — on the same workload.
+    PCIe-inclusive, reported beside `value`, never as it: synchronous fdm_engine_integrate from pageable / pinned /
+    pooled-pinned arrays (median of `iters` calls) and the steady stream fdm_engine_integrate_async from pinned memory."""
+    import numpy as np
+    import torch
+    from fastdem_amd import host_array
+    s = wl.scan(0)
+    out = {}
+
+    def median_ms(fn):  # (a median: one stalled call must not move a 0.1 ms figure)
+        ts = []
+        for i in range(iters):
+            t0 = time.perf_counter()
+            fn(i)
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2] * 1e3
+
+    out["host_buffers_ms_per_scan"] = median_ms(
+        lambda i: res.eng.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k + 1000 + i),
+                                    intensity=s["intensity"], rgb=s["rgb"]))
+    pin = {c: torch.from_numpy(s[c]).pin_memory() for c in ("x", "y", "z", "intensity", "rgb") if s.get(c) is not None}
+    pn = {c: t.numpy() for c, t in pin.items()}
+    # the same synchronous call on PINNED arrays: read in place by the bin kernel, no copy commands
+    for i in range(3):  # first GPU touch of freshly pinned pages is not what is measured
+        res.eng.integrate(pn["x"], pn["y"], pn["z"], wl.T_base_sensor, wl.pose(k + 1000 + i),
+                          intensity=pn.get("intensity"), rgb=pn.get("rgb"))
+    # ... and on arrays from the engine's own pinned pool (fdm_host_alloc: what every channel of the C++ mirror's
+    # nanopcl::PointCloud is made of): their device aliases come from the pool's table
+    pool = {c: host_array(s[c], np.uint32 if c == "rgb" else np.float32)
+            for c in ("x", "y", "z", "intensity", "rgb") if s.get(c) is not None}
+    pa = {c: h.array for c, h in pool.items()}
+    for i in range(3):
+        res.eng.integrate(pa["x"], pa["y"], pa["z"], wl.T_base_sensor, wl.pose(k + 1000 + i),
+                          intensity=pa.get("intensity"), rgb=pa.get("rgb"))
+    out["host_buffers_pool_ms_per_scan"] = median_ms(
+        lambda i: res.eng.integrate(pa["x"], pa["y"], pa["z"], wl.T_base_sensor, wl.pose(k + 1000 + i),
+                                    intensity=pa.get("intensity"), rgb=pa.get("rgb")))
+    out["host_buffers_pinned_ms_per_scan"] = median_ms(
+        lambda i: res.eng.integrate(pn["x"], pn["y"], pn["z"], wl.T_base_sensor, wl.pose(k + 1000 + i),
+                                    intensity=pn.get("intensity"), rgb=pn.get("rgb")))
+    # steady-state stream from PINNED host memory, no per-scan wait (SURVEY.md §8d iii): PCIe-inclusive
+    hp = {c: C.c_void_p(t.data_ptr()) for c, t in pin.items()}
+    for i in range(64):  # pose matrices are host work that does not belong to the stream's rate
+        res.pose(k + 2000 + i)
+    for i in range(min(20, stream_iters)):
+        res.eng.integrate_async_raw(s["x"].size, hp["x"], hp["y"], hp["z"], res.tbs, res.pose(k + 2000 + i),
+                                    hp.get("intensity"), hp.get("rgb"))
+    res.eng.sync()
+    t0 = time.perf_counter()
+    for i in range(stream_iters):
+        res.eng.integrate_async_raw(s["x"].size, hp["x"], hp["y"], hp["z"], res.tbs, res.pose(k + 2000 + i % 60),
+                                    hp.get("intensity"), hp.get("rgb"))
+    res.eng.sync()
+    out["host_stream_pinned_ms_per_scan"] = (time.perf_counter() - t0) / stream_iters * 1e3
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -328,7 +390,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1 or args.workload == "c5":
+    routed = args.workload == "c5" and (world > 1 or args.routed)
+    if world > 1 or routed:
         # (c5 runs its collectives over RCCL also with ONE rank: the N-rank code path, a 1-rank communicator)
         import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -338,7 +401,7 @@ def main():
                                 timeout=datetime.timedelta(seconds=args.collective_timeout))
     from fastdem_amd import synth
 
-    if args.workload == "c5":
+    if routed:
         from fastdem_amd import tiling
         args.stall_timeout = args.collective_timeout + 60
         result = tiling.bench_global(args, rank, local_rank, world)
@@ -440,59 +503,13 @@ def main():
                         "traffic": pmc_traffic(args.workload, "k_mbatch"), "avg_kernel_us": launch_us,
                         "alg_bytes_per_launch": alg, "scans_per_launch": batch_scans,
                         "measured": "HIP events on the engine stream around the timed region / launches"}
+            roof["frac_of_measured_read_bw"] = roof["achieved"] / MEASURED_READ_GBS
             result["roofline"] = roof
             result["kernels"] = kern
             result["timed_region_us_per_scan_hip_events"] = timed_launch_us
             if not args.no_host_legs:
                 # end-to-end with host staging (PCIe-inclusive) for DESIGN.md — never `value`
-                s = wl.scan(0)
-
-                def median_ms(fn, iters=50):  # (a median: one stalled call of 50 must not move a 0.1 ms figure)
-                    ts = []
-                    for i in range(iters):
-                        t0 = time.perf_counter()
-                        fn(i)
-                        ts.append(time.perf_counter() - t0)
-                    return sorted(ts)[len(ts) // 2] * 1e3
-
-                result["host_buffers_ms_per_scan"] = median_ms(
-                    lambda i: res.eng.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k + 1000 + i),
-                                                intensity=s["intensity"], rgb=s["rgb"]))
-                pin = {c: torch.from_numpy(s[c]).pin_memory() for c in ("x", "y", "z", "intensity", "rgb") if s.get(c) is not None}
-                pn = {c: t.numpy() for c, t in pin.items()}
-                # the same synchronous call on PINNED arrays: read in place by the bin kernel, no copy commands
-                for i in range(3):  # first GPU touch of freshly pinned pages is not what is measured
-                    res.eng.integrate(pn["x"], pn["y"], pn["z"], wl.T_base_sensor, wl.pose(k + 1000 + i),
-                                      intensity=pn.get("intensity"), rgb=pn.get("rgb"))
-                # ... and on arrays from the engine's own pinned pool (fdm_host_alloc: what every channel of the C++
-                # mirror's nanopcl::PointCloud is made of): their device aliases come from the pool's table
-                from fastdem_amd import host_array
-                pool = {c: host_array(s[c], np.uint32 if c == "rgb" else np.float32)
-                        for c in ("x", "y", "z", "intensity", "rgb") if s.get(c) is not None}
-                pa = {c: h.array for c, h in pool.items()}
-                for i in range(3):
-                    res.eng.integrate(pa["x"], pa["y"], pa["z"], wl.T_base_sensor, wl.pose(k + 1000 + i),
-                                      intensity=pa.get("intensity"), rgb=pa.get("rgb"))
-                result["host_buffers_pool_ms_per_scan"] = median_ms(
-                    lambda i: res.eng.integrate(pa["x"], pa["y"], pa["z"], wl.T_base_sensor, wl.pose(k + 1000 + i),
-                                                intensity=pa.get("intensity"), rgb=pa.get("rgb")))
-                result["host_buffers_pinned_ms_per_scan"] = median_ms(
-                    lambda i: res.eng.integrate(pn["x"], pn["y"], pn["z"], wl.T_base_sensor, wl.pose(k + 1000 + i),
-                                                intensity=pn.get("intensity"), rgb=pn.get("rgb")))
-                # steady-state stream from PINNED host memory, no per-scan wait (SURVEY.md §8d iii): PCIe-inclusive
-                hp = {c: C.c_void_p(t.data_ptr()) for c, t in pin.items()}
-                for i in range(64):  # pose matrices are host work that does not belong to the stream's rate
-                    res.pose(k + 2000 + i)
-                for i in range(20):
-                    res.eng.integrate_async_raw(s["x"].size, hp["x"], hp["y"], hp["z"], res.tbs, res.pose(k + 2000 + i),
-                                                hp.get("intensity"), hp.get("rgb"))
-                res.eng.sync()
-                t0 = time.perf_counter()
-                for i in range(200):
-                    res.eng.integrate_async_raw(s["x"].size, hp["x"], hp["y"], hp["z"], res.tbs, res.pose(k + 2000 + i % 60),
-                                                hp.get("intensity"), hp.get("rgb"))
-                res.eng.sync()
-                result["host_stream_pinned_ms_per_scan"] = (time.perf_counter() - t0) / 200 * 1e3
+                result.update(host_legs(res, wl, k))
             if world == 1 and not args.no_large and args.workload != "c4":
                 big = Resident(synth.lidar128(n_scans=LARGE_SCANS), local_rank, args.wave_merge, args.overlap)
                 for kv in args.set:
@@ -520,14 +537,22 @@ def main():
                     kb["k_update_bin"]["GBps"] = gb
                     rb.update({"achieved": gb, "frac": gb / HBM_PEAK_GBS, "avg_kernel_us": big_us,
                                "measured": "HIP events on the engine stream around the timed region / steps"})
+                # the fraction against what a plain read kernel reaches on this machine (scripts/ubench/hbm_bw.hip,
+                # profiles/r01/hbm_bw.jsonl: 6.4 TB/s) beside the 8 TB/s of the data sheet
+                rb["frac_of_measured_read_bw"] = rb["achieved"] / MEASURED_READ_GBS
+                rb["measured_read_bw"] = MEASURED_READ_GBS
+                big_legs = {} if args.no_host_legs else host_legs(big, big.wl, n_warm + n_big + 40, iters=12, stream_iters=40)
                 result["large"] = {"workload": big.wl.name, "value": bpts / dtb / 1e6, "steps": n_big,
                                    "device_value": bpts / (big_us * n_big * 1e-6) / 1e6,
                                    "unit": "Mpts/s", "ms_per_step": dtb / n_big * 1e3,
-                                   "roofline": rb, "kernels": kb}
+                                   "roofline": rb, "kernels": kb,
+                                   # the three times of SURVEY.md §8d: device (above), end to end from host arrays
+                                   # (synchronous call), steady stream from pinned memory — PCIe-inclusive, never `value`
+                                   **big_legs}
                 del big
             if world == 1 and not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(wl)
-    if world > 1 or args.workload == "c5":
+    if world > 1 or routed:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
