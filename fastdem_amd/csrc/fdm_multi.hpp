@@ -22,20 +22,22 @@
 //                block that completes a scan raises its bits in the state word, later scans' blocks poll that ONE
 //                word (a block only ever waits for blocks with a lower index, which never wait before publishing:
 //                no deadlock; the spin is bounded and raises MState::err instead of hanging).
-//   bin half     k_bin's body (one point per thread, wave-merge + per-block LDS cell table, memory-side atomics on
-//                the block's unique cells) for scan k of the batch; thread 0 walks the chain of k moves
+//   bin half     512 points per block (two per thread), scan k of the batch; thread 0 walks the chain of k moves
 //                (move_candidate_fast: no fp64 divide on the common path) while the point loads are in flight.
+//                Points fold straight into a per-block LDS cell table (axis_fast indexing), the table's occupied
+//                entries are compacted and flushed with memory-side atomics on the block's unique cells.
 //                No second look at the scan: the thread that merges a block-local minimum into the scratch also
 //                evaluates that point's sigma_z^2 (the block keeps its points' sensor-frame coordinates in LDS) and
 //                stores {map-frame z, sigma_z^2} at the POINT's index in an observation array; likewise the colour
 //                of a block-local last point.  The update finds the winner's entry through the index in the
 //                reduced key, and the caller's arrays are dead as soon as the launch has run.
-//   update half  one thread per cell, one block per 256-cell tile (memory order).  Round trip 1: the cell's keys of
-//                all scans, its estimator record, the per-scan geometry.  The block's (cell, scan) events are then
-//                compacted into an LDS list and spread evenly over the threads: round trip 2 fetches {aux, zs,
-//                obs} of ALL events at once (a thread holds 2-3 of them whatever their distribution over the
-//                cells), the observations go back through LDS to the cell threads, which walk their events in scan
-//                order: strips vacated since the previous event, estimator step in registers, one record store.
+//   update half  64 cells per block (memory order), four threads per cell.  Round trip 1: the cell's keys of
+//                all scans (four scans per thread), its estimator record, the per-scan geometry.  The block's
+//                (cell, scan) events are then compacted into an LDS list (kEvCap entries) and spread evenly over
+//                the threads: round trip 2 fetches {aux, zs, obs} of ALL events at once (a thread holds 2-3 of them
+//                whatever their distribution over the cells), the observations go back through LDS to the cell's
+//                lead thread, which walks its events in scan order: strips vacated since the previous event,
+//                estimator step in registers, one record store.
 //
 // All per-batch parameters travel as kernel arguments (< 4 KB): no copy command, no upload kernel.
 // Algorithmic bytes are per scan what they were: 12 B/point (+4 intensity, +4 colour), 72 / 124 B per
