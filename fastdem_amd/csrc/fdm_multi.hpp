@@ -48,11 +48,23 @@
 
 namespace fdm {
 
+#if defined(FDM_MB_PHASES) && FDM_MB_PHASES
+__shared__ unsigned g_phase[4];
+#endif
+
 constexpr int kMaxBatch = 16;            // scans per launch (one bit per scan in 16-bit halves of a state word)
 constexpr unsigned kSpinMax = 1u << 22;  // polls before a waiting block gives up (seconds; never reached in practice)
 constexpr int kLineWords = 32;           // a 128-byte line of 32-bit words
 #ifndef FDM_MB_WAVES
 #define FDM_MB_WAVES 6  // waves per SIMD k_mbatch is compiled for (<= 80 VGPRs; the LDS allows 6 blocks per CU): every block of a 16-scan VLP-16 batch resident at once
+#endif
+#ifndef FDM_MB_PHASES
+#define FDM_MB_PHASES 0  // measurement build only (make phases): three intermediate stamps per block in the timeline
+#endif
+#if FDM_MB_PHASES
+#define FDM_PHASE(i) do { if (threadIdx.x == 0) g_phase[i] = unsigned(wall_clock64()); } while (0)
+#else
+#define FDM_PHASE(i) do { } while (0)
 #endif
 constexpr int kMStates = 4;              // ring of batch states: update b-1 | bin b | crop b+1 | being re-armed
 
@@ -302,6 +314,7 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
   if (threadIdx.x == 0 && !must_wait)  // the pass bits are known (or irrelevant): in the shadow of the point loads
     chain((gated && k > 0u) ? (ms->flags[0] >> 16) : 0xFFFFu);
 
+  FDM_PHASE(0);  // table initialised, chain walked (the point loads are still in flight; vmcnt returns in order)
   bool pass[kMPts];
   unsigned npw = 0u;
 #pragma unroll
@@ -316,6 +329,7 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
     npw += unsigned(__popcll(__ballot(pass[h])));
   }
   if (lane == 0u) S.s_pass[wave] = npw;
+  FDM_PHASE(1);  // points arrived, crops + both transforms done
   __syncthreads();  // table, s_pt, s_pass (and s_cand unless the block has to wait)
   const unsigned np = S.s_pass[0] + S.s_pass[1] + S.s_pass[2] + S.s_pass[3];
   if (!B.pre && gated) {  // no crop pass ran ahead of this batch: the blocks publish what they found
@@ -427,6 +441,7 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
   }
   // ---- flush: the occupied slots are compacted first, so that the sigma_z^2 evaluation and the memory-side
   // atomics of a block's ~100 cells keep two wavefronts busy instead of four, twice ----
+  FDM_PHASE(2);  // index + LDS fold done
   __syncthreads();
   uint32_t tc[kMPts];
   unsigned before[kMPts];
@@ -533,6 +548,7 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
   unsigned nib = 0u;
 #pragma unroll
   for (int j = 0; j < 4; ++j) nib |= (kk[j] != kEmptyKey) ? (1u << j) : 0u;
+  FDM_PHASE(0);  // round trip 1 (keys, geometry) back
   unsigned tmask = nib << (4u * cq);  // the cell's scans, all four threads of the cell
   tmask |= unsigned(__shfl_xor(int(tmask), 1));
   tmask |= unsigned(__shfl_xor(int(tmask), 2));
@@ -632,6 +648,7 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
       ob.iobs = 0.0f;
       if (has_int) ob.iobs = (fst & 1u) ? nanv : ((imx == 0x80000000u && (zs_[q].y & 1u)) ? -0.0f : unord(imx));
       S.ob[j] = ob;
+      FDM_PHASE(1);  // round trip 2 (observations, record) back
       const size_t oc = size_t(ev_[q].k) * ncell + (bid * kUpdCells + ev_[q].cell);
       U.key[oc] = kEmptyKey;  // the scratch is clean again for the batch after next
       U.aux[oc] = make_uint4(0u, 0u, kNoIdx, 0u);
@@ -662,6 +679,7 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
     }
     __syncthreads();  // (the next round reuses the lists)
   }
+  FDM_PHASE(2);  // events applied
   // the scans after the cell's last event
   if (owner) {
     const unsigned all = (1u << count) - 1u, from = (1u << lastp1) - 1u;
@@ -708,6 +726,9 @@ __global__ __launch_bounds__(256, MBatchWaves<POLICY>::value) void k_mbatch(cons
                                                 unsigned ncell, unsigned upd_blocks, unsigned upd_rows) {
   __shared__ __align__(16) unsigned char lds[kMLdsBytes<(CH & 2) != 0>];
   const unsigned long long t0 = K.timeline ? wall_clock64() : 0ull;
+#if FDM_MB_PHASES
+  if (threadIdx.x == 0) { g_phase[0] = g_phase[1] = g_phase[2] = unsigned(t0); }
+#endif
   const unsigned row = blockIdx.y, x = blockIdx.x;
   if (row < upd_rows) {
     const unsigned ub = row * gridDim.x + x;
@@ -724,7 +745,13 @@ __global__ __launch_bounds__(256, MBatchWaves<POLICY>::value) void k_mbatch(cons
   if (K.timeline && threadIdx.x == 0) {  // (thread 0's view of the block; scripts/timeline_batch.py)
     const unsigned b = blockIdx.y * gridDim.x + x;
     K.timeline[2u * b] = t0;
+#if FDM_MB_PHASES  // end | phase stamps, 16 bits each, 10 ns ticks after t0
+    const unsigned base = unsigned(t0);
+    auto d16 = [&](unsigned v) { return (unsigned long long)(min(v - base, 0xFFFFu)); };
+    K.timeline[2u * b + 1u] = d16(unsigned(wall_clock64())) | (d16(g_phase[0]) << 16) | (d16(g_phase[1]) << 32) | (d16(g_phase[2]) << 48);
+#else
     K.timeline[2u * b + 1u] = wall_clock64();
+#endif
   }
 }
 

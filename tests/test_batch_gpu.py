@@ -131,6 +131,23 @@ def test_moves_that_wrap_clear_everything_and_come_back(gpu, R, batch_max):
     check_batch(gpu, R, eng, ref, scans, T(z=0.5), poses)
 
 
+def test_moves_on_rounding_ties(gpu, R):
+    """Poses that sit exactly on half a cell, or within 1e-7 of it (move(): half away from zero, decided by the
+    reference's divide), inside one batch.  A dyadic resolution makes the ties exact."""
+    def fill(c):
+        c.z_min, c.z_max, c.range_min, c.range_max = -2.0, 3.0, 0.0, 30.0
+
+    eng, ref = pair(gpu, R, 16.0, 12.0, 0.5, fill)
+    rng = np.random.default_rng(11)
+    xs = [0.0, 0.25, 0.5, 0.75, 0.75 + 1e-7, 1.25 - 1e-7, -0.25, -0.75, -1.25, 2.25, 2.25, 3.0, 3.25 + 4e-5, 3.75 - 4e-5,
+          -6.25, -6.25 + 1e-9, 40.25, 40.75, 0.25, -0.25, 0.24999999, 0.7500001]
+    scans, poses = [], []
+    for k, px in enumerate(xs):
+        scans.append(cloud(rng, 1500 + 13 * k, 7.0, intensity=True))
+        poses.append(T(px, -0.5 * px + 0.25 * (k % 3), 0.0, yaw=0.05 * k))
+    check_batch(gpu, R, eng, ref, scans, T(z=0.5), poses)
+
+
 def test_a_scan_with_every_point_filtered_does_not_move_the_map(gpu, R):
     """fastdem.cpp:138: a scan whose points all fail the crops returns before the move.  Inside a batch the scans
     BEHIND it must be binned against the geometry without that move — the chain of moves depends on device-side
