@@ -22,8 +22,9 @@
 //                block that completes a scan raises its bits in the state word, later scans' blocks poll that ONE
 //                word (a block only ever waits for blocks with a lower index, which never wait before publishing:
 //                no deadlock; the spin is bounded and raises MState::err instead of hanging).
-//   bin half     512 points per block (two per thread), scan k of the batch; thread 0 walks the chain of k moves
-//                (move_candidate_fast: no fp64 divide on the common path) while the point loads are in flight.
+//   bin half     512 points per block (two per thread), scan k of the batch; the first wavefront walks the chain of k
+//                moves (every lane rounds its own scan's pose once; only the position is accumulated in scan order;
+//                the reference's divide only for poses on a rounding tie) while the point loads are in flight.
 //                Points fold straight into a per-block LDS cell table (axis_fast indexing), the table's occupied
 //                entries are compacted and flushed with memory-side atomics on the block's unique cells.
 //                No second look at the scan: the thread that merges a block-local minimum into the scratch also
@@ -85,7 +86,7 @@ struct MCommon {  // what all scans of a batch share
   float sp[4];
   float Tbs[16];  // T_base_sensor (one sensor per batch: a scan with another extrinsic closes the batch)
   int sensor_type, integrate_mode, do_move, gate_on_filter, has_var, bin_table;
-  int dbg, pad;                  // measurement only (results are wrong): 1 = no scratch atomics, 2 = no chain walk
+  int dbg, pad;                  // measurement only: 1 = no scratch atomics, 2 = no chain walk (both: wrong results); 3 = every move by the reference's divide
   unsigned long long* timeline;  // measurement only (nullable): {start, end} of every block in 100 MHz ticks
 };
 struct MScanT {   // per scan: T_world_base without its constant last row (0 0 0 1), column-major 3 x 4 | rotation of the product
@@ -251,6 +252,9 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
   const float* __restrict__ const py = B.py[k];
   const float* __restrict__ const pz = B.pz[k];
 
+  // (the poses leave before the point loads: loads return in order, and the walk below waits for these)
+  double pose_x = 0.0, pose_y = 0.0;
+  if (threadIdx.x < 64u && lane <= k) { pose_x = B.robot_x[lane]; pose_y = B.robot_y[lane]; }
   const unsigned n = B.n[k];
   const unsigned i0 = lb * kMBlock + threadIdx.x;  // the thread's points: i0, i0 + 256 (two coalesced sweeps)
   float xs[kMPts], ys[kMPts], zs[kMPts], vs[kMPts];
@@ -265,6 +269,9 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
       if (has_int) vs[h] = B.pint[k][i];
     }
   }
+#if FDM_MB_PHASES == 2  // (variant: kernel arguments read + loads issued | loads back | chain walked)
+  FDM_PHASE(0);
+#endif
 #pragma unroll
   for (int h = 0; h < kMPts; ++h) {
     const unsigned t = threadIdx.x + unsigned(h) * 256u;
@@ -272,16 +279,25 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
     S.t_cell[t] = kEmptyCell;
     S.t_zmx[t] = 0u; S.t_imx[t] = 0u; S.t_fst[t] = kNoIdx; S.t_lst[t] = 0u;
   }
-  // the chain of moves up to this scan, given which of the earlier scans moved the map.  Lane j of the first
-  // wavefront holds scan j's pose, so that the walk (thread 0) never waits for memory between two moves.
-  double pose_x = 0.0, pose_y = 0.0;
-  if (threadIdx.x < 64u && lane <= k) { pose_x = B.robot_x[lane]; pose_y = B.robot_y[lane]; }
+#if FDM_MB_PHASES == 2
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  FDM_PHASE(1);
+#endif
+  // The chain of moves up to this scan, given which of the earlier scans moved the map — walked by the whole first
+  // wavefront (lane j holds scan j's pose), because a serial instruction costs ~10 ns on a full chip and a block of
+  // the batch's last scan used to spend 6.6 us here.  move() snaps the position to the grid p0 + integer * res, so in
+  // exact arithmetic the TOTAL shift after scan j's move is round((pose_j - p0) / res) whatever happened before it:
+  // lane j rounds its pose ONCE, with move_candidate_fast's own margins (1e-4 cell off a rounding tie; the accumulated
+  // position differs from p0 + V res by ~1e-10 cell at most), and the walk only accumulates the position in scan
+  // order, p <- p + double(v) * res and the per-step index wrap — the operations the reference performs.  A pose that
+  // sits within the margin of a tie (a robot advancing half a cell per scan) takes the reference's subtract + divide
+  // against the position accumulated so far, at its place in the walk.
   auto lane_f64 = [](double v, unsigned j) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), int(j));
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), int(j));
     return __hiloint2double(hi, lo);
   };
-  auto chain = [&](unsigned passmask) {
+  auto chain = [&](unsigned passmask) {  // (every lane of the first wavefront, uniformly)
     DevGeom g;
     if (B.prev) {  // what the update of the previous batch (the other half of this launch) is about to commit
       const unsigned pk = B.prev_count - 1u;
@@ -293,28 +309,73 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
     } else {
       g = st->geom[B.scan_no0 & 3u];
     }
-    if (K.do_move && K.dbg != 2) {
-      for (unsigned j = 0; j < k; ++j) {
-        if (K.gate_on_filter && !((passmask >> j) & 1u)) continue;  // scan j returned before its move
-        const DevCand cj = move_candidate_fast(g, G, lane_f64(pose_x, j), lane_f64(pose_y, j));
-        g.px = cj.px; g.py = cj.py; g.sr = cj.sr; g.sc = cj.sc;
-      }
-    }
     DevCand c;
+    c.px = g.px; c.py = g.py; c.sr = g.sr; c.sc = g.sc; c.shr = 0; c.shc = 0;
     if (K.do_move) {
-      c = move_candidate_fast(g, G, lane_f64(pose_x, k), lane_f64(pose_y, k));
-    } else {
-      c.px = g.px; c.py = g.py; c.sr = g.sr; c.sc = g.sc; c.shr = 0; c.shc = 0;
+      auto nearest = [&](double a, double p0, int& t) -> bool {
+        t = 0;
+        if (!(fabs(p0) < 1.0e7)) return false;
+        if (fabs(a) <= 1e-4) return true;
+        const double ue = a + 0.5 * (a > 0 ? 1 : -1);
+        t = static_cast<int>(ue);
+        const double f = fabs(ue - double(t));
+        return f > 1e-4 && f < 1.0 - 1e-4 && fabs(ue) < 1.0e6;
+      };
+      int tx = 0, ty = 0;
+      const bool sx = nearest((pose_x - g.px) * G.inv_res, g.px, tx), sy = nearest((pose_y - g.py) * G.inv_res, g.py, ty);
+      const unsigned sure_x = K.dbg == 3 ? 0u : uni(unsigned(__ballot(sx))), sure_y = K.dbg == 3 ? 0u : uni(unsigned(__ballot(sy)));
+      int vx = 0, vy = 0;  // total shift so far, in cells
+      auto shift_of = [&](unsigned j, int& dx, int& dy) {  // scan j's move against the geometry walked so far
+        if ((sure_x >> j) & 1u) {
+          dx = __builtin_amdgcn_readlane(tx, int(j)) - vx;
+        } else {  // GridMap::move's own arithmetic
+          const double t = (lane_f64(pose_x, j) - g.px) / G.res;
+          dx = static_cast<int>(t + 0.5 * (t > 0 ? 1 : -1));
+        }
+        if ((sure_y >> j) & 1u) {
+          dy = __builtin_amdgcn_readlane(ty, int(j)) - vy;
+        } else {
+          const double t = (lane_f64(pose_y, j) - g.py) / G.res;
+          dy = static_cast<int>(t + 0.5 * (t > 0 ? 1 : -1));
+        }
+      };
+      unsigned m = K.dbg == 2 ? 0u : ((K.gate_on_filter ? passmask : 0xFFFFu) & ((1u << k) - 1u));  // the moves ahead of scan k
+      while (m) {  // (a scan that returned before its move is not in the mask)
+        const unsigned j = unsigned(__ffs(int(m))) - 1u;
+        m &= m - 1u;
+        int dx, dy;
+        shift_of(j, dx, dy);
+        g.sr -= dx; g.sc -= dy;
+        wrap_index(g.sr, G.rows);
+        wrap_index(g.sc, G.cols);
+        g.px = g.px + double(dx) * G.res;
+        g.py = g.py + double(dy) * G.res;
+        vx += dx; vy += dy;
+      }
+      int dx, dy;
+      shift_of(k, dx, dy);
+      c.sr = g.sr - dx; c.sc = g.sc - dy;
+      wrap_index(c.sr, G.rows);
+      wrap_index(c.sc, G.cols);
+      c.px = g.px + double(dx) * G.res;
+      c.py = g.py + double(dy) * G.res;
+      c.shr = -dx; c.shc = -dy;
     }
-    S.s_cand = c;
-    if (lb == 0u) { ms->E[k] = g; ms->C[k] = c; }
+    if (threadIdx.x == 0) {
+      S.s_cand = c;
+      if (lb == 0u) { ms->E[k] = g; ms->C[k] = c; }
+    }
   };
   const bool gated = K.do_move && K.gate_on_filter;
   const bool must_wait = gated && k > 0u && !B.pre;  // block-uniform
-  if (threadIdx.x == 0 && !must_wait)  // the pass bits are known (or irrelevant): in the shadow of the point loads
-    chain((gated && k > 0u) ? (ms->flags[0] >> 16) : 0xFFFFu);
+  if (threadIdx.x < 64u && !must_wait)  // the pass bits are known (or irrelevant): in the shadow of the point loads
+    chain((gated && k > 0u) ? uni(ms->flags[0] >> 16) : 0xFFFFu);
 
+#if FDM_MB_PHASES == 2
+  FDM_PHASE(2);
+#else
   FDM_PHASE(0);  // table initialised, chain walked (the point loads are still in flight; vmcnt returns in order)
+#endif
   bool pass[kMPts];
   unsigned npw = 0u;
 #pragma unroll
@@ -329,30 +390,35 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
     npw += unsigned(__popcll(__ballot(pass[h])));
   }
   if (lane == 0u) S.s_pass[wave] = npw;
+#if FDM_MB_PHASES != 2
   FDM_PHASE(1);  // points arrived, crops + both transforms done
+#endif
   __syncthreads();  // table, s_pt, s_pass (and s_cand unless the block has to wait)
   const unsigned np = S.s_pass[0] + S.s_pass[1] + S.s_pass[2] + S.s_pass[3];
   if (!B.pre && gated) {  // no crop pass ran ahead of this batch: the blocks publish what they found
-    if (threadIdx.x == 0) {
-      // one add on the scan's own line; the block that completes the scan raises its two bits in `flags`
-      const unsigned mine = 1u | (np ? 0x10000u : 0u);
-      const unsigned tot = atomicAdd(&ms->done[k * kLineWords], mine) + mine;
-      if ((tot & 0xFFFFu) == B.first_block[k + 1u] - B.first_block[k])
-        atomicOr(&ms->flags[0], (1u << k) | ((tot >> 16) ? (0x10000u << k) : 0u));
-      if (must_wait) {  // ... and wait for the scans ahead: ONE word, ONE poller per block
-        const unsigned need = (1u << k) - 1u;
-        unsigned f = 0u, spins = 0u;
-        while (true) {
-          f = __hip_atomic_load(&ms->flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((f & need) == need) break;
-          if (++spins >= kSpinMax) {
-            ms->err = 1u;
-            break;
+    if (threadIdx.x < 64u) {
+      unsigned f = 0u;
+      if (threadIdx.x == 0) {
+        // one add on the scan's own line; the block that completes the scan raises its two bits in `flags`
+        const unsigned mine = 1u | (np ? 0x10000u : 0u);
+        const unsigned tot = atomicAdd(&ms->done[k * kLineWords], mine) + mine;
+        if ((tot & 0xFFFFu) == B.first_block[k + 1u] - B.first_block[k])
+          atomicOr(&ms->flags[0], (1u << k) | ((tot >> 16) ? (0x10000u << k) : 0u));
+        if (must_wait) {  // ... and wait for the scans ahead: ONE word, ONE poller per block
+          const unsigned need = (1u << k) - 1u;
+          unsigned spins = 0u;
+          while (true) {
+            f = __hip_atomic_load(&ms->flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((f & need) == need) break;
+            if (++spins >= kSpinMax) {
+              ms->err = 1u;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(8);  // (~0.25 us: the pollers stay off the line the completing blocks write)
           }
-          __builtin_amdgcn_s_sleep(8);  // (~0.25 us: the pollers stay off the line the completing blocks write)
         }
-        chain(f >> 16);
       }
+      if (must_wait) chain(uni(f) >> 16);  // (lane 0 polled; the wavefront walks)
     }
     if (must_wait) __syncthreads();
   }
@@ -441,7 +507,9 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
   }
   // ---- flush: the occupied slots are compacted first, so that the sigma_z^2 evaluation and the memory-side
   // atomics of a block's ~100 cells keep two wavefronts busy instead of four, twice ----
+#if FDM_MB_PHASES != 2
   FDM_PHASE(2);  // index + LDS fold done
+#endif
   __syncthreads();
   uint32_t tc[kMPts];
   unsigned before[kMPts];

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 from fastdem_amd import capi  # noqa: E402
-capi.LIB_PATH = os.path.join(ROOT, "fastdem_amd", "lib", "libfdm_engine_phases.so")
+capi.LIB_PATH = os.path.join(ROOT, "fastdem_amd", "lib", "libfdm_engine_phases2.so" if "variant=2" in sys.argv else "libfdm_engine_phases.so")
 import bench  # noqa: E402
 from fastdem_amd import synth  # noqa: E402
 
@@ -16,7 +16,7 @@ res = bench.Resident(wl, 0)
 res.eng.set_option("dbg_timeline", 1)
 res.eng.set_option("batch_max", bm)
 for kv in sys.argv[1:]:
-    if "=" in kv:
+    if "=" in kv and not kv.startswith("variant"):
         res.eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 for kk in range(400):
     res.pose(kk)
@@ -47,7 +47,13 @@ def block(idx, names):
             "span_end": round(float((s[idx] + end[idx]).max()), 2)}
 upd = np.arange(0, nu)
 binr = np.concatenate([np.arange((ur + k) * gx, (ur + k) * gx + nb) for k in range(bm)])
+names = ["init_chain", "loads_transforms", "index_fold", "compact_merge_flush"]
+if os.path.basename(capi.LIB_PATH).endswith("phases2.so"):
+    names = ["kernargs_issue", "loads_back", "chain", "rest"]
 out = {"batch_max": bm, "grid": [int(gx), int(len(t) // gx)],
        "update": block(upd, ["rt1_keys", "rt2_obs", "apply", "stores"]),
-       "bin": block(binr, ["init_chain", "loads_transforms", "index_fold", "compact_merge_flush"])}
+       "bin": block(binr, names)}
+for k in (0, 5, 10, 15):
+    if k < bm:
+        out[f"bin_row_{k}"] = block(np.arange((ur + k) * gx, (ur + k) * gx + nb), names)
 print(json.dumps(out))

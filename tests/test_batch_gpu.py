@@ -131,13 +131,18 @@ def test_moves_that_wrap_clear_everything_and_come_back(gpu, R, batch_max):
     check_batch(gpu, R, eng, ref, scans, T(z=0.5), poses)
 
 
-def test_moves_on_rounding_ties(gpu, R):
-    """Poses that sit exactly on half a cell, or within 1e-7 of it (move(): half away from zero, decided by the
-    reference's divide), inside one batch.  A dyadic resolution makes the ties exact."""
+@pytest.mark.parametrize("every_move_by_divide", [0, 1])
+def test_moves_on_rounding_ties(gpu, R, every_move_by_divide):
+    """The bin half rounds every scan's pose once and in parallel (total shift = round((pose - p0) / res)), which is
+    only valid away from rounding ties: poses that sit exactly on half a cell, or within 1e-7 of it, must take the
+    reference's subtract + divide at their place in the walk (move(): half away from zero).  A dyadic resolution
+    makes the ties exact.  `every_move_by_divide` (dbg_batch 3) sends every move down that path: same map."""
     def fill(c):
         c.z_min, c.z_max, c.range_min, c.range_max = -2.0, 3.0, 0.0, 30.0
 
     eng, ref = pair(gpu, R, 16.0, 12.0, 0.5, fill)
+    if every_move_by_divide:
+        eng.set_option("dbg_batch", 3)
     rng = np.random.default_rng(11)
     xs = [0.0, 0.25, 0.5, 0.75, 0.75 + 1e-7, 1.25 - 1e-7, -0.25, -0.75, -1.25, 2.25, 2.25, 3.0, 3.25 + 4e-5, 3.75 - 4e-5,
           -6.25, -6.25 + 1e-9, 40.25, 40.75, 0.25, -0.25, 0.24999999, 0.7500001]
