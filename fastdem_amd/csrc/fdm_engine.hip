@@ -142,6 +142,12 @@ struct fdm_engine {
   size_t vcap = 0;
   void* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
+  int voxel_small = 1;               // option "voxel_small": scans of <= 64 K points take the sort-free voxel filter
+  uint32_t* vs_cnt = nullptr;        // fine | coarse bucket counters | valid points of k_vs_*
+  uint4* vs_rec = nullptr;           // {key, point, bucket start, bucket size} by position
+  size_t vs_rec_cap = 0;
+  int voxel_small_max = 1 << 16;     // option "voxel_small_max": largest scan that takes it
+  VoxelSmall vs{};                   // the last small-scan filter's parameters (k_vs_mark runs from enqueue_ray_stage)
   hipEvent_t ev_ray[2] = {nullptr, nullptr};
   hipEvent_t ev_timer[2] = {nullptr, nullptr};  // fdm_engine_timer_start / _stop
   bool ray_timed = false;
@@ -1243,6 +1249,8 @@ void fdm_engine_destroy(fdm_engine* e) {
   }
   if (e->vsel) (void)hipFree(e->vsel);
   if (e->sort_tmp) (void)hipFree(e->sort_tmp);
+  if (e->vs_cnt) (void)hipFree(e->vs_cnt);
+  if (e->vs_rec) (void)hipFree(e->vs_rec);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -1993,6 +2001,15 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
   }
   if (std::strcmp(key, "batch") == 0) {  // fdm_engine_integrate_device_batch: group small scans into batch launches
     e->batch = value != 0;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "voxel_small") == 0) {  // 0: every scan through the library sort
+    e->voxel_small = value != 0;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "voxel_small_max") == 0) {
+    if (value < 1 || value > (1 << 20)) return fail(FDM_ERR_INVALID, "voxel_small_max: 1 .. 2^20 points");
+    e->voxel_small_max = value;
     return FDM_OK;
   }
   if (std::strcmp(key, "dbg_batch") == 0) {

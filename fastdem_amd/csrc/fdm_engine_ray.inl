@@ -74,7 +74,7 @@ int ensure_voxel_buffers(fdm_engine* e, size_t n) {
 // `box` (nullable): centre (3) + half extent [m] of a box that holds every finite point of the cloud, then the
 // map-frame z interval [lo, hi] they lie in (NaN, NaN if unknown);
 // with it the compact 32-bit key is used when 3 * bits <= 31.  *key_mode tells what the buffers hold:
-// 0 = sorted uint64 keys, 1 = sorted uint32 compact keys.
+// 0 = sorted uint64 keys, 1 = sorted uint32 compact keys, 2 = points grouped by key bucket, unsorted (k_vs_*).
 int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slot, const float* dx,
                        const float* dy, const float* dz, const double* box, int* key_mode) {
   if (int rc = ensure_voxel_buffers(e, n)) return rc;
@@ -108,6 +108,41 @@ int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slo
   const bool compact = C.bits > 0 && key_bits <= 31;  // true: the sorted buffer holds uint32 keys
   *key_mode = compact ? 1 : 0;
   size_t bytes = e->sort_tmp_bytes;
+  if (compact && e->voxel_small && n <= unsigned(e->voxel_small_max)) {
+    // small scans: no sort at all (k_vs_*: fdm_raycast.hpp).  vkeys[0] = keys by point | places by point, vs_rec =
+    // {key, point, bucket start, bucket size} by position; k_vs_mark runs from enqueue_ray_stage (key_mode 2)
+    if (!e->vs_cnt) {
+      const size_t words = (size_t(1) << kVsFineBits) + kVsCoarse + 1u;
+      HIPCK(hipMalloc(reinterpret_cast<void**>(&e->vs_cnt), words * sizeof(uint32_t)));
+      HIPCK(hipMemsetAsync(e->vs_cnt, 0, words * sizeof(uint32_t), e->stream));
+    }
+    VoxelSmall& V = e->vs;
+    // fine buckets = one (z, y) row of voxels when that fits 2^18 counters, else the key's top 18 bits
+    V.shift = unsigned(std::max(C.bits, key_bits - int(kVsFineBits)));
+    V.fine = e->vs_cnt;
+    V.coarse = e->vs_cnt + (size_t(1) << kVsFineBits);
+    V.total = V.coarse + kVsCoarse;
+    uint32_t* k0 = reinterpret_cast<uint32_t*>(e->vkeys[0]);
+    V.place = k0 + e->vcap;                                  // (vkeys[0] holds 2 x vcap uint32)
+    if (e->vs_rec_cap < n) {
+      if (int rc_sync = sync_all(e)) return rc_sync;
+      if (e->vs_rec) HIPCK(hipFree(e->vs_rec));
+      e->vs_rec = nullptr;
+      e->vs_rec_cap = std::max<size_t>(size_t(1) << 16, size_t(n) + n / 4);
+      HIPCK(hipMalloc(reinterpret_cast<void**>(&e->vs_rec), e->vs_rec_cap * sizeof(uint4)));
+    }
+    V.rec = e->vs_rec;
+    V.cap = unsigned(e->vs_rec_cap);
+    V.ibits = 1u;
+    while ((1u << V.ibits) < n) ++V.ibits;
+    const unsigned blocks = (n + 255u) / 256u;
+    hipLaunchKernelGGL(k_vs_count, dim3(blocks), dim3(256), 0, e->stream, n, inv, flag_slot, C, V, e->d_state, dx, dy,
+                       dz, k0, e->vsel);
+    hipLaunchKernelGGL(k_vs_scatter, dim3(blocks), dim3(256), 0, e->stream, n, V, k0);
+    HIPCK(hipGetLastError());
+    *key_mode = 2;
+    return FDM_OK;
+  }
   if (compact) {
     uint32_t* k0 = reinterpret_cast<uint32_t*>(e->vkeys[0]);
     uint32_t* k1 = reinterpret_cast<uint32_t*>(e->vkeys[1]);
@@ -180,7 +215,9 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float
   const unsigned blocks = (Q.n + 255u) / 256u;
   if ((rc = ensure_voxel_buffers(e, Q.n))) return rc;  // vidx[0] doubles as the ray queue
   uint32_t* ray_list = e->vidx[0];
-  if (voxel) {
+  if (voxel && key_mode == 2) {
+    hipLaunchKernelGGL(k_vs_mark, dim3(blocks), dim3(256), 0, e->stream, e->vs, e->vsel);
+  } else if (voxel) {
     if (key_mode == 1)
       hipLaunchKernelGGL(k_voxel_mark<uint32_t>, dim3(blocks), dim3(256), 0, e->stream, Q.n,
                          reinterpret_cast<const uint32_t*>(e->vkeys[1]), e->vidx[1], e->vsel);

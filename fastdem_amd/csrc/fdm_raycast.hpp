@@ -16,7 +16,8 @@
 //     uint encoding of the float (a plain L2 load filters out the rays that cannot lower it);
 //   * ghost resolution: one independent decision per traversed cell, after both of the above.
 // Pipeline (one stream, no host round trip):
-//   k_voxel_keys -> stable radix sort of (key, point index) -> k_voxel_mark -> k_ray_compact
+//   k_voxel_keys -> stable radix sort of (key, point index) -> k_voxel_mark   (small scans: k_vs_count -> k_vs_scatter
+//   -> k_vs_mark, no sort) -> k_ray_compact
 //   (-> k_ray_bin_sum -> k_ray_bin_scan -> k_ray_scatter for large scans) -> k_ray -> k_ray_resolve
 // VoxelMode::ANY picks idx[start + (count*7 + start*13) % count] of each voxel's run in the sorted
 // array.  The reference sorts with std::sort on the key only (unstable: the order inside a voxel is
@@ -192,6 +193,216 @@ __global__ __launch_bounds__(256) void k_voxel_mark(unsigned n, const KEY* __res
   bool head;
   const uint32_t pick = voxel_pick_block(keys, idx, n, head);
   if (head) sel[pick] = 1u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// VoxelMode::ANY without a sort, for small scans (a VLP-16 sweep: the library sort was 8 launches, 45 of the stage's
+// 70 us).  What the filter needs of a point is (a) its voxel's run in the sorted array — `start` = how many valid
+// points have a smaller key, `count` — and (b) its own position in that run under the stable order (= how many points
+// of the same voxel have a smaller index).  Bucketing by a PREFIX of the key gives all three without ordering anything
+// (bucket order = key order).  The key is [z][y][x] and a scan's points sit in a few z levels, so the buckets have to
+// be fine — one (z, y) row of voxels, up to 2^18 of them — and their first positions come from two levels: 32 fine
+// buckets to a coarse one, <= 8192 coarse counters scanned by every block, <= 31 fine counters (one cache line) summed
+// per point.
+//   k_vs_count    key per point (k_voxel_keys' arithmetic); the returning atomicAdd on the fine counter is the
+//                 point's (arbitrary, unique) place inside its bucket; one more add on the coarse counter
+//   k_vs_scatter  {key, index, bucket start, bucket size} of every valid point at start + place
+//   k_vs_mark     thread per placed point: one walk over ITS bucket's members counts the smaller keys, the equal
+//                 keys and the equal keys with a smaller index; the point is its voxel's representative iff the last
+//                 count equals (count * 7 + start * 13) % count.  sel[] as k_voxel_mark leaves it.  Then it puts its
+//                 bucket's two counters back to zero (nobody reads them any more): no memset launches.
+constexpr unsigned kVsFineBits = 18u, kVsCoarse = 1u << (kVsFineBits - 5u);
+struct VoxelSmall {
+  unsigned shift;          // fine bucket = key >> shift; coarse bucket = fine >> 5
+  uint32_t* fine;          // [2^kVsFineBits] zero between scans
+  uint32_t* coarse;        // [kVsCoarse]     zero between scans
+  uint32_t* total;         // [1] valid points of this scan
+  uint32_t* place;         // [n] by point
+  uint4* rec;              // [cap] by position: key | point | bucket start | bucket size
+  unsigned cap;            // entries of rec (reads beyond the scan's positions stay inside the allocation)
+  unsigned ibits;          // bits of a point index
+};
+
+__global__ __launch_bounds__(256) void k_vs_count(unsigned n, float inv_voxel, int flag_slot, const VoxelCompact C,
+                                                  const VoxelSmall V, DevState* __restrict__ st,
+                                                  const float* __restrict__ x, const float* __restrict__ y,
+                                                  const float* __restrict__ z, uint32_t* __restrict__ keys,
+                                                  uint32_t* __restrict__ sel) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  const unsigned lane = threadIdx.x & 63u;
+  bool valid = false;
+  uint32_t k = kInvalidVoxel32;
+  if (i < n) {
+    const float a = x[i], b = y[i], c = z[i];
+    valid = isfinite(a) && isfinite(b) && isfinite(c);
+    if (valid) k = voxel_pack_compact<uint32_t>(a, b, c, inv_voxel, C);
+    keys[i] = k;
+    sel[i] = 0u;
+  }
+  // Same-address atomics serialise at the memory side (a ring that runs along a row of voxels puts a hundred
+  // consecutive points into one counter; the coarse counters of the ground's z levels collect thousands: 45 us for a
+  // VLP-16 sweep with one atomic per point).  One add per distinct counter and wavefront, fine and coarse.
+  const unsigned f = valid ? k >> V.shift : 0xFFFFFFFFu;
+  {  // one returning add per distinct fine bucket of the wavefront, all of them in flight together; the bucket's lanes
+     // take consecutive places behind their leader's base
+    unsigned long long todo = __ballot(valid);
+    int my_lead = int(lane);
+    unsigned my_rank = 0u, my_size = 0u;
+    while (todo) {
+      const int lead = __ffsll((long long)todo) - 1;
+      const unsigned f0 = unsigned(__builtin_amdgcn_readlane(int(f), lead));
+      const unsigned long long same = __ballot(valid && f == f0);
+      if (f == f0) {
+        my_lead = lead;
+        my_rank = unsigned(__popcll(same & ((1ull << lane) - 1ull)));
+        my_size = unsigned(__popcll(same));
+      }
+      todo &= ~same;
+    }
+    unsigned base = 0u;
+    if (valid && my_lead == int(lane)) base = atomicAdd(&V.fine[f], my_size);
+    base = unsigned(__shfl(int(base), my_lead));
+    if (valid) V.place[i] = base + my_rank;
+  }
+  {
+    const unsigned g = f >> 5;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+      const int lead = __ffsll((long long)todo) - 1;
+      const unsigned g0 = unsigned(__builtin_amdgcn_readlane(int(g), lead));
+      const unsigned long long same = __ballot(valid && g == g0);
+      if (int(lane) == lead) atomicAdd(&V.coarse[g0], unsigned(__popcll(same)));
+      todo &= ~same;
+    }
+  }
+  if (flag_slot >= 0 && __ballot(valid) && (threadIdx.x & 63) == 0) st->flags[flag_slot].ray_any = 1u;
+}
+
+__global__ __launch_bounds__(256) void k_vs_scatter(unsigned n, const VoxelSmall V, const uint32_t* __restrict__ keys) {
+  __shared__ uint32_t s_start[kVsCoarse];
+  __shared__ uint32_t s_wave[4];
+  const unsigned t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  constexpr unsigned per = kVsCoarse / 256u;  // coarse counters per thread, consecutive
+  uint32_t c_[per];
+  uint32_t mine = 0u;
+#pragma unroll
+  for (unsigned j = 0; j < per; ++j) { c_[j] = V.coarse[t * per + j]; mine += c_[j]; }
+  uint32_t inc = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(inc, d);
+    if (int(lane) >= d) inc += o;
+  }
+  if (lane == 63u) s_wave[wave] = inc;
+  __syncthreads();
+  uint32_t run = inc - mine;
+  for (unsigned w = 0; w < wave; ++w) run += s_wave[w];
+#pragma unroll
+  for (unsigned j = 0; j < per; ++j) { s_start[t * per + j] = run; run += c_[j]; }
+  if (blockIdx.x == 0 && t == 255u) *V.total = run;
+  __syncthreads();
+  const unsigned i = blockIdx.x * 256u + t;
+  if (i >= n) return;
+  const uint32_t k = keys[i];
+  if (k == kInvalidVoxel32) return;  // (dropped / non-finite points sort behind every voxel: never a representative)
+  const unsigned f = k >> V.shift, f0 = f & ~31u, fl = f & 31u;
+  uint32_t s = s_start[f >> 5], m = 0u;
+  const uint4* const grp = reinterpret_cast<const uint4*>(V.fine + f0);  // the group's 32 counters: one 128-byte line
+  uint4 c4[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) c4[q] = grp[q];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const uint32_t w[4] = {c4[q].x, c4[q].y, c4[q].z, c4[q].w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const unsigned j = unsigned(q * 4 + r);
+      s += j < fl ? w[r] : 0u;
+      m = j == fl ? w[r] : m;
+    }
+  }
+  V.rec[s + V.place[i]] = make_uint4(k, i, s, m);
+}
+
+__global__ __launch_bounds__(256) void k_vs_mark(const VoxelSmall V, uint32_t* __restrict__ sel) {
+  const unsigned p = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u, w0 = p - lane;
+  const unsigned total = *V.total;
+  // a bucket's members are neighbours: the wavefront's own 64 positions and the 128 on either side are compared in
+  // registers (five independent loads, one round trip); a per-lane walk over memory is one dependent round trip per
+  // step (a single 148-point row of a VLP-16 sweep: 20 us) and is left to what reaches beyond that window
+  const uint4 dead = make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
+  auto at = [&](unsigned q) { return V.rec[min(q, V.cap - 1u)]; };  // (q - 128 wraps to a huge value: clamped)
+  uint4 me = at(p);
+  uint4 nb[4] = {at(p - 128u), at(p - 64u), at(p + 64u), at(p + 128u)};
+  const bool live = p < total;
+  if (!live) me = dead;
+  if (p < 128u) nb[0] = dead;
+  if (p < 64u) nb[1] = dead;
+  if (p + 64u >= total) nb[2] = dead;
+  if (p + 128u >= total) nb[3] = dead;
+  const uint32_t k = me.x, i = me.y;
+  unsigned lower = 0u, equal = 0u, before = 0u;
+  // One window of 64 positions against this lane's point, bit-serially: the bucket's members are the lanes
+  // [from, to) of the window (positions are contiguous); walking the key's low bits from the top, `pre` keeps the
+  // members equal to the lane's key so far and `less` collects those that turn smaller; the same walk over the
+  // point index among the equal keys.  ~25 ballots instead of 64 x three lane reads.
+  const unsigned kbits = V.shift;  // keys of one bucket differ in their low `shift` bits only
+  auto window = [&](const uint4& w, unsigned wpos) {
+    const unsigned a = me.z > wpos ? me.z - wpos : 0u;
+    const unsigned b = live ? (me.z + me.w > wpos ? min(me.z + me.w - wpos, 64u) : 0u) : 0u;
+    unsigned long long pre = (a < b) ? (((b >= 64u) ? ~0ull : ((1ull << b) - 1ull)) & ~((1ull << a) - 1ull)) : 0ull;
+    unsigned long long less = 0ull;
+    for (int bit = int(kbits) - 1; bit >= 0; --bit) {  // (uniform trip count)
+      const unsigned long long ones = __ballot((w.x >> bit) & 1u);
+      const bool mine = ((k >> bit) & 1u) != 0u;
+      less |= mine ? (pre & ~ones) : 0ull;
+      pre &= mine ? ones : ~ones;
+    }
+    lower += unsigned(__popcll(less));
+    equal += unsigned(__popcll(pre));
+    unsigned long long lessi = 0ull;
+    for (int bit = int(V.ibits) - 1; bit >= 0; --bit) {
+      const unsigned long long ones = __ballot((w.y >> bit) & 1u);
+      const bool mine = ((i >> bit) & 1u) != 0u;
+      lessi |= mine ? (pre & ~ones) : 0ull;
+      pre &= mine ? ones : ~ones;
+    }
+    before += unsigned(__popcll(lessi));
+  };
+  const unsigned end = live ? me.z + me.w : 0u;
+  window(me, w0);
+  if (__ballot(live && me.z + 64u < w0)) window(nb[0], w0 - 128u);  // (wave-uniform conditions)
+  if (__ballot(live && me.z < w0)) window(nb[1], w0 - 64u);
+  if (__ballot(live && end > w0 + 64u)) window(nb[2], w0 + 64u);
+  if (__ballot(live && end > w0 + 128u)) window(nb[3], w0 + 128u);
+  if (!live) return;
+  // buckets of more than ~130 points: what lies beyond the window, eight independent loads per step
+  const unsigned wlo = w0 >= 128u ? w0 - 128u : 0u, whi = w0 + 192u;
+  auto beyond = [&](unsigned q0, unsigned q1) {
+    for (unsigned q = q0; q < q1; q += 8u) {
+      uint2 o[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) o[r] = *reinterpret_cast<const uint2*>(V.rec + min(q + unsigned(r), q1 - 1u));
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const bool on = q + unsigned(r) < q1;
+        lower += (on && o[r].x < k) ? 1u : 0u;
+        equal += (on && o[r].x == k) ? 1u : 0u;
+        before += (on && o[r].x == k && o[r].y < i) ? 1u : 0u;
+      }
+    }
+  };
+  if (me.z < wlo) beyond(me.z, min(end, wlo));
+  if (end > whi) beyond(max(me.z, whi), end);
+  // (count * 7 + start * 13) % count, size_t arithmetic in the reference (voxel_grid_impl.hpp:171-173); with at most
+  // 2^20 points neither product leaves 32 bits
+  const unsigned s0 = me.z + lower;
+  if (before == (equal * 7u + s0 * 13u) % equal) sel[i] = 1u;
+  if (p == me.z) {  // the bucket's first position puts its counters back to zero
+    const unsigned f = k >> V.shift;
+    V.fine[f] = 0u;
+    V.coarse[f >> 5] = 0u;
+  }
 }
 
 // processScan (raycasting.cpp:142-173), first half: one ray-scan point per thread.

@@ -438,6 +438,8 @@ int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2);
  *   "bin_table"   0/1   : k_bin folds poorly merged waves into a per-block LDS cell table before the atomics
  *   "zero_copy"   n     : host entry points read PINNED input arrays of up to n points in place (0 = always copy)
  *   "overlap"     0/1   : hold the update of a small scan back and fuse it with the next scan's bin launch
+ *   "voxel_small" 0/1, "voxel_small_max" n : raycasting's voxel filter without a sort for scans of up to n points
+ *                         (default on, 65536; fdm_raycast.hpp k_vs_*); 0 = every scan through the stable radix sort
  *   "batch" 0/1, "batch_max" n, "batch_crop" 0/1, "batch_fuse" 0/1 : fdm_engine_integrate_device_batch groups small
  *                         scans into batch launches (default on, 16 per launch); evaluate the next batch's crops
  *                         one launch ahead; hold a batch's update back for the next batch's launch

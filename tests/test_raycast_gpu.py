@@ -282,6 +282,55 @@ class TestIntegrateWithRaycasting:
         assert cleared > 0 and np.nansum(eng.layer("ghost_removal")) > 0
         assert {"ghost_removal", "raycasting", "_visibility_logodds"} <= set(eng.layers())
 
+    @pytest.mark.parametrize("voxel_small", [1, 0])
+    def test_small_scans_without_and_with_the_library_sort(self, gpu, R, voxel_small):
+        """Scans of <= 64 K points take the sort-free voxel filter (k_vs_count / k_vs_scatter / k_vs_mark: buckets of
+        the compact key's top bits, every point ranks itself inside its bucket); option voxel_small 0 sends them
+        through the stable radix sort instead.  Both must select the oracle's representatives: dense clusters
+        (hundreds of points per voxel and thousands per bucket), duplicates, dropped points, ragged sizes."""
+        def fill(cfg):
+            cfg.z_min, cfg.z_max, cfg.range_min, cfg.range_max = -2.0, 4.0, 0.2, 12.0
+            return ray_cfg(rc_log_odds_ghost=0.8, rc_clear_threshold=-1.0)(cfg)
+        eng, ref = pair(gpu, R, 16.0, 16.0, 0.1, fill)
+        eng.set_option("voxel_small", voxel_small)
+        rng = np.random.default_rng(17)
+        Tbs = np.eye(4)
+        Tbs[2, 3] = 1.2
+        for k, n in enumerate((1, 63, 257, 5000, 20000, 40000, 65536)):
+            x = rng.uniform(-7.0, 7.0, n).astype(F32)
+            y = rng.uniform(-7.0, 7.0, n).astype(F32)
+            z = (rng.uniform(-1.0, 0.4, n) - 1.2).astype(F32)
+            m = n // 3  # a third of the points in a 0.6 m cube: ~200 voxels share them; exact duplicates among them
+            x[:m] = (2.0 + rng.uniform(0, 0.6, m)).astype(F32)
+            y[:m] = (-1.0 + rng.uniform(0, 0.6, m)).astype(F32)
+            z[:m] = (-1.5 + rng.uniform(0, 0.6, m)).astype(F32)
+            if m > 10:
+                x[5:m:7], y[5:m:7], z[5:m:7] = x[4], y[4], z[4]
+            z[n // 2::11] += 30.0  # dropped by cropZ: x = NaN in the stage's input
+            T = np.eye(4)
+            T[0, 3], T[1, 3] = 0.13 * k, -0.07 * k
+            run_both(eng, ref, {"x": x, "y": y, "z": z, "intensity": None, "rgb": None}, Tbs, T)
+            assert_layers_equal(eng, ref)
+        assert ref.last_ray_stats()["n_rays"] > 1000
+
+    def test_sort_free_filter_beyond_64k_points(self, gpu, R):
+        """Option voxel_small_max lifts the size limit of the sort-free filter (17-bit point indices, buckets far larger
+        than the register window: the batched walk over memory)."""
+        def fill(cfg):
+            cfg.z_min, cfg.z_max, cfg.range_min, cfg.range_max = -2.0, 4.0, 0.2, 12.0
+            return ray_cfg(rc_log_odds_ghost=0.8, rc_clear_threshold=-1.0)(cfg)
+        eng, ref = pair(gpu, R, 16.0, 16.0, 0.1, fill)
+        eng.set_option("voxel_small_max", 1 << 20)
+        rng = np.random.default_rng(23)
+        n = 100_000
+        x = rng.uniform(-7.0, 7.0, n).astype(F32)
+        y = (np.round(rng.uniform(-7.0, 7.0, n) * 2) / 2).astype(F32)   # 29 rows of voxels hold everything
+        z = (np.round(rng.uniform(-1.0, 0.4, n) * 4) / 4 - 1.2).astype(F32)
+        Tbs = np.eye(4)
+        Tbs[2, 3] = 1.2
+        run_both(eng, ref, {"x": x, "y": y, "z": z, "intensity": None, "rgb": None}, Tbs, np.eye(4))
+        assert_layers_equal(eng, ref)
+
     def test_c3_rgbd_p2_records_cleared(self, gpu, R):
         """P2 cell records (128 B) wiped by clearAt.  The depth image observes every cell it can ray
         through except the strip between the camera and the nearest ground hit: ghosts go there."""
