@@ -23,13 +23,13 @@
 #include <unordered_map>
 #include <vector>
 
-#include <rocprim/device/device_radix_sort.hpp>  // stable (key, index) sort of the voxel filter
 
 #include "fdm_kernels.hpp"
 #include "fdm_tiled.hpp"
 #include "fdm_multi.hpp"
 #include "fdm_route.hpp"
 #include "fdm_raycast.hpp"
+#include "fdm_rsort.hpp"
 #include "fdm_egress.hpp"
 #include "fdm_ingest.hpp"
 #include "fdm_post.hpp"

@@ -30,12 +30,6 @@ int ensure_ray_cells(fdm_engine* e) {
   return FDM_OK;
 }
 
-// rocPRIM switches radix_sort_pairs to a merge sort below 1 M items: 18 launches (114 us) for a 272 K-point
-// RGB-D scan, 8 (41 us) for a VLP-16 sweep.  This config keeps the onesweep radix sort; used from 64 K
-// items up (C3 stage 246 -> 231 us; at 28.8 K items the radix passes lose: 148 vs 70 us).
-using RadixAlways = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                               rocprim::default_config, 4096>;
-
 int ensure_voxel_buffers(fdm_engine* e, size_t n) {
   if (n <= e->vcap) return FDM_OK;
   if (int rc_sync = sync_all(e)) return rc_sync;
@@ -51,22 +45,33 @@ int ensure_voxel_buffers(fdm_engine* e, size_t n) {
     HIPCK(hipMalloc(reinterpret_cast<void**>(&e->vidx[k]), e->vcap * sizeof(uint32_t)));
   }
   HIPCK(hipMalloc(reinterpret_cast<void**>(&e->vsel), e->vcap * sizeof(uint32_t)));
-  e->sort_tmp_bytes = 0;
-  HIPCK(rocprim::radix_sort_pairs(nullptr, e->sort_tmp_bytes, e->vkeys[0], e->vkeys[1], e->vidx[0],
-                                  e->vidx[1], e->vcap, 0, 64, e->stream));
-  {  // the compact-key sort reuses the same allocations (uint32 view of the key buffers)
-    size_t b32 = 0;
-    HIPCK(rocprim::radix_sort_pairs(nullptr, b32, reinterpret_cast<uint32_t*>(e->vkeys[0]),
-                                    reinterpret_cast<uint32_t*>(e->vkeys[1]), e->vidx[0], e->vidx[1], e->vcap, 0,
-                                    32, e->stream));
-    e->sort_tmp_bytes = std::max(e->sort_tmp_bytes, b32);
-    b32 = 0;
-    HIPCK(rocprim::radix_sort_pairs<RadixAlways>(nullptr, b32, reinterpret_cast<uint32_t*>(e->vkeys[0]),
-                                                 reinterpret_cast<uint32_t*>(e->vkeys[1]), e->vidx[0], e->vidx[1],
-                                                 e->vcap, 0, 32, e->stream));
-    e->sort_tmp_bytes = std::max(e->sort_tmp_bytes, b32);
+  // the radix sort's histogram: 256 bins x tiles, + the 256 totals (fdm_rsort.hpp)
+  const size_t tiles = (e->vcap + kRsTile - 1) / kRsTile;
+  e->sort_tmp_bytes = (256u * tiles + 256u) * sizeof(uint32_t);
+  HIPCK(hipMalloc(&e->sort_tmp, e->sort_tmp_bytes));
+  return FDM_OK;
+}
+
+// Stable sort of the n pairs in (vkeys[src], vidx[src]) by the low `bits` bits of the key; the result lands in
+// (vkeys[1], vidx[1]).  `src` must be voxel_sort_source(bits): the buffers alternate once per pass.
+int voxel_sort_passes(unsigned bits) { return int((bits + 7u) / 8u); }
+int voxel_sort_source(unsigned bits) { return (voxel_sort_passes(bits) & 1) ? 0 : 1; }
+template <typename KEY>
+int enqueue_radix_sort(fdm_engine* e, unsigned n, unsigned bits) {
+  const unsigned tiles = (n + kRsTile - 1u) / kRsTile;
+  uint32_t* const hist = static_cast<uint32_t*>(e->sort_tmp);
+  uint32_t* const total = hist + size_t(256) * tiles;
+  int src = voxel_sort_source(bits);
+  for (int pass = 0; pass < voxel_sort_passes(bits); ++pass, src ^= 1) {
+    const KEY* kin = reinterpret_cast<const KEY*>(e->vkeys[src]);
+    KEY* kout = reinterpret_cast<KEY*>(e->vkeys[src ^ 1]);
+    const unsigned shift = unsigned(pass) * 8u;
+    hipLaunchKernelGGL(k_rs_hist<KEY>, dim3(tiles), dim3(256), 0, e->stream, n, kin, shift, tiles, hist);
+    hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(256), 0, e->stream, tiles, hist, total);
+    hipLaunchKernelGGL(k_rs_scatter<KEY>, dim3(tiles), dim3(256), 0, e->stream, n, kin, e->vidx[src], kout,
+                       e->vidx[src ^ 1], shift, tiles, hist, total);
   }
-  HIPCK(hipMalloc(&e->sort_tmp, e->sort_tmp_bytes ? e->sort_tmp_bytes : 16));
+  HIPCK(hipGetLastError());
   return FDM_OK;
 }
 
@@ -107,7 +112,6 @@ int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slo
   const int key_bits = 2 * C.bits + C.zbits;
   const bool compact = C.bits > 0 && key_bits <= 31;  // true: the sorted buffer holds uint32 keys
   *key_mode = compact ? 1 : 0;
-  size_t bytes = e->sort_tmp_bytes;
   if (compact && e->voxel_small && n <= unsigned(e->voxel_small_max)) {
     // small scans: no sort at all (k_vs_*: fdm_raycast.hpp).  vkeys[0] = keys by point | places by point, vs_rec =
     // {key, point, bucket start, bucket size} by position; k_vs_mark runs from enqueue_ray_stage (key_mode 2)
@@ -144,27 +148,21 @@ int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slo
     return FDM_OK;
   }
   if (compact) {
-    uint32_t* k0 = reinterpret_cast<uint32_t*>(e->vkeys[0]);
-    uint32_t* k1 = reinterpret_cast<uint32_t*>(e->vkeys[1]);
-    hipLaunchKernelGGL(k_voxel_keys<uint32_t>, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, inv, flag_slot, C,
-                       e->d_state, dx, dy, dz, k0, e->vidx[0], e->vsel);
-    HIPCK(hipGetLastError());
     // bits 3*bits .. 31 are zero in every valid key and one in the invalid key (all ones): sorting
     // one bit past the fields is enough to keep the dropped points behind every voxel
-    if (n < (1u << 16))
-      HIPCK(rocprim::radix_sort_pairs(e->sort_tmp, bytes, k0, k1, e->vidx[0], e->vidx[1], size_t(n), 0,
-                                      unsigned(key_bits + 1), e->stream));
-    else
-      HIPCK(rocprim::radix_sort_pairs<RadixAlways>(e->sort_tmp, bytes, k0, k1, e->vidx[0], e->vidx[1], size_t(n), 0,
-                                                   unsigned(key_bits + 1), e->stream));
-  } else {
-    hipLaunchKernelGGL(k_voxel_keys<unsigned long long>, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, inv,
-                       flag_slot, C, e->d_state, dx, dy, dz, e->vkeys[0], e->vidx[0], e->vsel);
+    const unsigned sort_bits = unsigned(key_bits + 1);
+    const int src = voxel_sort_source(sort_bits);
+    hipLaunchKernelGGL(k_voxel_keys<uint32_t>, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, inv, flag_slot, C,
+                       e->d_state, dx, dy, dz, reinterpret_cast<uint32_t*>(e->vkeys[src]), e->vidx[src], e->vsel);
     HIPCK(hipGetLastError());
-    HIPCK(rocprim::radix_sort_pairs(e->sort_tmp, bytes, e->vkeys[0], e->vkeys[1], e->vidx[0], e->vidx[1],
-                                    size_t(n), 0, C.bits > 0 ? unsigned(key_bits + 1) : 64u, e->stream));
+    return enqueue_radix_sort<uint32_t>(e, n, sort_bits);
   }
-  return FDM_OK;
+  const unsigned sort_bits = C.bits > 0 ? unsigned(key_bits + 1) : 64u;
+  const int src = voxel_sort_source(sort_bits);
+  hipLaunchKernelGGL(k_voxel_keys<unsigned long long>, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, inv,
+                     flag_slot, C, e->d_state, dx, dy, dz, e->vkeys[src], e->vidx[src], e->vsel);
+  HIPCK(hipGetLastError());
+  return enqueue_radix_sort<unsigned long long>(e, n, sort_bits);
 }
 
 fdm_raycast_config ray_config_of(const fdm_config& c) {
