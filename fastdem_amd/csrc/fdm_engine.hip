@@ -1637,6 +1637,31 @@ int fdm_engine_debug_timeline(fdm_engine* e, uint64_t* ticks, uint64_t cap_block
   return FDM_OK;
 }
 
+// measurement / debugging only: how many entries of the batch pipeline's per-scan scratch sets are NOT in their
+// clean state once everything enqueued has run (the update half leaves every entry it consumed clean; anything else
+// would leak into a later batch).  out[0..2] = keys, aux words, zero-sign words.
+int fdm_engine_debug_batch_dirty(fdm_engine* e, uint64_t out[3]) {
+  if (!e || !out) return fail(FDM_ERR_INVALID, "null argument");
+  out[0] = out[1] = out[2] = 0;
+  if (int rc = sync_all(e)) return rc;
+  if (!e->mkey[0]) return FDM_OK;
+  const size_t slots = size_t(kMaxBatch) * e->ncell;
+  std::vector<unsigned long long> hk(slots);
+  std::vector<uint4> ha(slots);
+  std::vector<uint2> hz(slots);
+  for (int k = 0; k < 2; ++k) {
+    HIPCK(hipMemcpy(hk.data(), e->mkey[k], slots * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(ha.data(), e->maux[k], slots * sizeof(uint4), hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(hz.data(), e->mzs[k], slots * sizeof(uint2), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < slots; ++i) {
+      out[0] += hk[i] != kEmptyKey;
+      out[1] += (ha[i].x != 0u) + (ha[i].y != 0u) + (ha[i].z != kNoIdx) + (ha[i].w != 0u);
+      out[2] += (hz[i].x != 0xFFFFFFFFu) + (hz[i].y != 0xFFFFFFFFu);
+    }
+  }
+  return FDM_OK;
+}
+
 int fdm_engine_record_event(fdm_engine* e, void* hip_event) {
   if (!e || !hip_event) return fail(FDM_ERR_INVALID, "null argument");
   if (int rc = join_streams(e)) return rc;  // the map is current behind this event

@@ -501,9 +501,12 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
     }
     niw += unsigned(__popcll(__ballot(inside)));
   }
+  // (the ballot BEFORE the lane test: inside `if (lane == 0)` it would see lane 0 alone — a small scan whose first
+  // point lies outside the map then never reported "observed", and the obstacle layer kept the previous scan's values)
+  const bool wave_glob = __ballot(any_glob) != 0ull;
   if (lane == 0u) {
     S.s_in[wave] = niw;
-    if (__ballot(any_glob)) ms->inside[k] = 1u;
+    if (wave_glob) ms->inside[k] = 1u;
   }
   // ---- flush: the occupied slots are compacted first, so that the sigma_z^2 evaluation and the memory-side
   // atomics of a block's ~100 cells keep two wavefronts busy instead of four, twice ----

@@ -262,6 +262,12 @@ class Engine:
         _ck(self._lib.fdm_engine_timer_ms(self._h, C.byref(ms)))
         return float(ms.value)
 
+    def debug_batch_dirty(self):
+        """(keys, aux words, zero-sign words) of the batch scratch that are not clean after a flush: (0, 0, 0)."""
+        out = (C.c_uint64 * 3)()
+        _ck(self._lib.fdm_engine_debug_batch_dirty(self._h, out))
+        return tuple(int(v) for v in out)
+
     def debug_timeline(self, cap_blocks=1 << 16):
         """(option dbg_timeline=1) -> (ticks[n_blocks, 2] uint64 of the 100 MHz clock, n_update_blocks) of the
         last fused large-scan launch."""

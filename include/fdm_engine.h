@@ -208,6 +208,10 @@ int fdm_engine_last_batch(fdm_engine* e);
 int fdm_engine_timer_start(fdm_engine* e);
 int fdm_engine_timer_stop(fdm_engine* e);
 int fdm_engine_timer_ms(fdm_engine* e, float* ms);
+/* Measurement / debugging only: after everything enqueued has run, how many entries of the batch pipeline's scratch
+ * sets are not in their clean state (keys, aux words, zero-sign words) — 0 0 0 in a healthy engine. */
+int fdm_engine_debug_batch_dirty(fdm_engine* e, uint64_t out[3]);
+
 /* Measurement tool (engine option "dbg_timeline" = 1): start / end time of every block of the last fused
  * large-scan launch, in ticks of the 100 MHz constant clock — ticks[2*b], ticks[2*b + 1] for block b; blocks
  * [0, *n_update_blocks) are tile-update groups of scan t, the rest bin blocks of scan t+1.  Waits for the stream. */

@@ -153,6 +153,30 @@ def test_moves_on_rounding_ties(gpu, R, every_move_by_divide):
     check_batch(gpu, R, eng, ref, scans, T(z=0.5), poses)
 
 
+def test_small_scans_whose_first_points_miss_the_map_still_clear_the_obstacle_layer(gpu, R):
+    """Regression (found by scripts/soak_r03.py): 'some point of scan k landed in the map' was taken from lane 0 of
+    each wavefront only, so a scan whose points 0, 64, 128, ... lie outside the map never counted as observing —
+    the obstacle layer then kept the previous scan's values (elevation_mapping.cpp:144-146 clears it per observing
+    scan).  Tiny scans behind big ones, their leading points outside the map."""
+    def fill(c):
+        c.z_min, c.z_max, c.range_min, c.range_max = -2.0, 3.0, 0.0, 40.0
+
+    eng, ref = pair(gpu, R, 10.0, 10.0, 0.1, fill)
+    rng = np.random.default_rng(41)
+    scans, poses = [], []
+    for k in range(14):
+        n = 20000 if k % 3 == 0 else int(rng.integers(20, 300))
+        s = cloud(rng, n, 4.5, intensity=True)
+        if n < 20000:  # every 64th point (lane 0 of its wavefront) far outside the map, a few points in one cell
+            s["x"][::64] = 30.0
+            s["x"][1:9], s["y"][1:9] = 0.31, -0.72
+            s["z"][1:9] = np.linspace(-0.3, 0.4, 8).astype(F32)
+        scans.append(s)
+        poses.append(T(0.11 * k, -0.06 * k, 0.0))
+    check_batch(gpu, R, eng, ref, scans, T(z=0.5), poses)
+    assert np.isfinite(eng.layer("obstacle")).sum() < 50  # only the last (small) scan's cells
+
+
 def test_a_scan_with_every_point_filtered_does_not_move_the_map(gpu, R):
     """fastdem.cpp:138: a scan whose points all fail the crops returns before the move.  Inside a batch the scans
     BEHIND it must be binned against the geometry without that move — the chain of moves depends on device-side
