@@ -17,6 +17,12 @@ F32 = np.float32
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 every = int(sys.argv[2]) if len(sys.argv) > 2 else 5   # compare every so many calls
 with_oracle = len(sys.argv) > 3 and sys.argv[3] == "oracle"  # the CPU oracle in lock-step (slow): who is right
+profile = sys.argv[4] if len(sys.argv) > 4 else "small"
+# small: 16 m map, Kalman, LOCAL       A = defaults, B = batch 0 + voxel_small 0
+# tiled: 60 m map (351 tiles), scans up to 300 K points     A = defaults (record-pool pipeline), B = tiled 0
+# p2   : 12 m GLOBAL map, P2 quantile estimator, colour + intensity     A = defaults, B = batch 0 + voxel_small 0
+SIZE = {"small": 16.0, "tiled": 60.0, "p2": 12.0}[profile]
+BIG = {"small": 70000, "tiled": 300000, "p2": 40000}[profile]
 rng = np.random.default_rng(2026)
 
 
@@ -36,12 +42,17 @@ def make(raycast):
     cfg = capi.default_config()
     cfg.z_min, cfg.z_max, cfg.range_min, cfg.range_max = -2.0, 4.0, 0.2, 12.0
     cfg.raycast_enabled = raycast
+    if profile == "p2":
+        cfg.mode = 1
+        cfg.estimation_type = 1
+        cfg.sensor_type = 2
     return cfg
 
 
 def cloud(n):
-    x = rng.uniform(-9.0, 9.0, n).astype(F32)
-    y = rng.uniform(-9.0, 9.0, n).astype(F32)
+    half = SIZE / 2 + 1.0
+    x = rng.uniform(-half, half, n).astype(F32)
+    y = rng.uniform(-half, half, n).astype(F32)
     z = (rng.uniform(-1.0, 0.4, n) - 1.2).astype(F32)
     kind = rng.integers(0, 12)
     if kind == 0:
@@ -52,22 +63,30 @@ def cloud(n):
         y[:m] = (-2.0 + rng.uniform(0, 0.5, m)).astype(F32)
         x[3:m:5], y[3:m:5], z[3:m:5] = x[2], y[2], z[2]
     a = rng.uniform(0, 1, n).astype(F32)
+    if kind == 2:
+        a[::7] = np.nan
+        z[::5] = 0.0 - 1.2
     return x, y, z, a
 
 
 Tbs = np.eye(4)
 Tbs[2, 3] = 1.2
-A = Engine(16.0, 16.0, 0.1, make(0))
-B = Engine(16.0, 16.0, 0.1, make(0))
-B.set_option("batch", 0)
-B.set_option("voxel_small", 0)
+A = Engine(SIZE, SIZE, 0.1, make(0))
+B = Engine(SIZE, SIZE, 0.1, make(0))
+if profile == "tiled":
+    B.set_option("tiled", 0)
+else:
+    B.set_option("batch", 0)
+    B.set_option("voxel_small", 0)
 Rf = None
 if with_oracle:
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import fdm_ref_py as R  # (the checker)
     rcfg = R.default_config()
     rcfg.z_min, rcfg.z_max, rcfg.range_min, rcfg.range_max = -2.0, 4.0, 0.2, 12.0
-    Rf = R.RefEngine(16.0, 16.0, 0.1, rcfg)
+    if profile == "p2":
+        rcfg.mode, rcfg.estimation_type, rcfg.sensor_type = 1, 1, 2
+    Rf = R.RefEngine(SIZE, SIZE, 0.1, rcfg)
 t0 = time.perf_counter()
 scans = calls = compares = 0
 px = py = 0.0
@@ -79,24 +98,25 @@ while time.perf_counter() - t0 < budget:
         cfg.raycast_enabled = ray
         e.set_config(cfg)
     count = int(rng.integers(1, 40))
-    sizes = [int(rng.integers(1, 70000)) if rng.integers(0, 4) == 0 else int(rng.integers(1, 6000)) for _ in range(count)]
+    sizes = [int(rng.integers(1, BIG)) if rng.integers(0, 4) == 0 else int(rng.integers(1, 6000)) for _ in range(count)]
     keep, arr = [], (capi.FdmDeviceScan * count)()
     alive.append(keep)
     for k, n in enumerate(sizes):
         x, y, z, a = cloud(n)
-        d = [torch.from_numpy(v).cuda() for v in (x, y, z, a)]
+        rgb = rng.integers(0, 1 << 24, n, dtype=np.uint32) if profile == "p2" else None
+        d = [torch.from_numpy(v).cuda() for v in (x, y, z, a)] + ([torch.from_numpy(rgb.view(np.int32)).cuda()] if rgb is not None else [])
         keep.append(d)
         host = (x, y, z, a)
         px += float(rng.uniform(-0.3, 0.4))
         py += float(rng.uniform(-0.2, 0.2))
         arr[k].n = n
-        arr[k].x, arr[k].y, arr[k].z, arr[k].intensity = (t.data_ptr() for t in d)
-        arr[k].rgb = None
+        arr[k].x, arr[k].y, arr[k].z, arr[k].intensity = (t.data_ptr() for t in d[:4])
+        arr[k].rgb = d[4].data_ptr() if rgb is not None else None
         arr[k].sigma_z2 = None
         arr[k].T_base_sensor = col16(Tbs)
         arr[k].T_world_base = col16(T(px, py, 0.01 * scans))
         if Rf:
-            Rf.integrate(host[0], host[1], host[2], Tbs, T(px, py, 0.01 * scans), intensity=host[3])
+            Rf.integrate(host[0], host[1], host[2], Tbs, T(px, py, 0.01 * scans), intensity=host[3], rgb=rgb)
         scans += 1
     torch.cuda.synchronize()
     assert A.integrate_device_batch(arr) == 0
@@ -127,5 +147,5 @@ while time.perf_counter() - t0 < budget:
                 raise SystemExit(f"layer {name} differs in {(~same).sum()} cells after {scans} scans")
         compares += 1
         alive.clear()
-print(json.dumps({"seconds": round(time.perf_counter() - t0, 1), "scans": scans, "batch_calls": calls, "exact_compares": compares,
+print(json.dumps({"profile": profile, "seconds": round(time.perf_counter() - t0, 1), "scans": scans, "batch_calls": calls, "exact_compares": compares,
                   "layers": len(A.layers()), "finite_cells": int(np.isfinite(A.layer("elevation")).sum())}))
