@@ -119,8 +119,25 @@ while time.perf_counter() - t0 < budget:
             Rf.integrate(host[0], host[1], host[2], Tbs, T(px, py, 0.01 * scans), intensity=host[3], rgb=rgb)
         scans += 1
     torch.cuda.synchronize()
-    assert A.integrate_device_batch(arr) == 0
-    assert B.integrate_device_batch(arr) == 0
+    how = int(rng.integers(0, 8))
+    if how == 0 and profile != "p2":  # the same scans one by one (enqueue-only calls) ...
+        for d, sc in zip(keep, arr):
+            Tb, Tw = np.array(sc.T_base_sensor).reshape(4, 4).T, np.array(sc.T_world_base).reshape(4, 4).T
+            for e in (A, B):
+                e.integrate_device(d[0], d[1], d[2], Tb, Tw, intensity=d[3])
+    elif how == 1 and profile != "p2":  # ... or the first as a synchronous host call, the rest as a batch
+        d, sc = keep[0], arr[0]
+        Tb, Tw = np.array(sc.T_base_sensor).reshape(4, 4).T, np.array(sc.T_world_base).reshape(4, 4).T
+        hx, hy, hz, ha = (t.cpu().numpy() for t in d[:4])
+        ra, rb = A.integrate(hx, hy, hz, Tb, Tw, intensity=ha), B.integrate(hx, hy, hz, Tb, Tw, intensity=ha)
+        assert ra == rb, (ra, rb)
+        if count > 1:
+            rest = (capi.FdmDeviceScan * (count - 1))(*list(arr)[1:])
+            assert A.integrate_device_batch(rest) == 0
+            assert B.integrate_device_batch(rest) == 0
+    else:
+        assert A.integrate_device_batch(arr) == 0
+        assert B.integrate_device_batch(arr) == 0
     calls += 1
     if calls % every == 0:
         A.sync()
