@@ -423,15 +423,15 @@ __global__ __launch_bounds__(256) void k_vs_mark(const VoxelSmall V, uint32_t* _
 // returning atomic that counts the bucket is the ray's rank in it; k_ray_bin_sum / k_ray_bin_scan turn
 // the counts into offsets and k_ray_scatter places the rays.
 constexpr unsigned kRayWedges = 2048u, kRayLenClasses = 128u, kRayBins = kRayWedges * kRayLenClasses;
-// Length classes (round 3): finer for the short rays (a third of a 2 M-point sweep ends within 5 m), and for scans of
-// >= 2^20 points the queue is ordered (length group, wedge, class inside the group) instead of (wedge, class): a
-// wavefront then holds rays of two or three neighbouring wedges whose lengths differ by a few cells — they end together —
-// instead of half a wedge's rays of every length (configs[3] stage 0.83 -> 0.79 ms; the 272 K-point RGB-D scan prefers
-// the wedge-major order, 0.150 vs 0.168 ms).  Also measured: ONE k_ray LAUNCH PER LENGTH GROUP, shortest first, so that
-// the long rays find the near cells already lowered and their visits are settled by the read (each (wavefront, cell)
-// pair is otherwise one lowering event: 4.1 M events for 1.0 M cells) — 0.92 ms: four launches each pay the whole
-// latency chain of a walk with a quarter of the wavefronts.  Removed.
-constexpr unsigned kRayGroups = 4u, kRayGroupClasses = kRayLenClasses / kRayGroups;  // 32 classes per group
+// Length classes (round 3): finer for the short rays (a third of a 2 M-point sweep ends within 5 m), and the queue is
+// ordered (length group, wedge, class inside the group) with TWO groups — rays below / beyond 224 cells — instead of
+// (wedge, class): the wavefronts of the short half hold rays of neighbouring wedges whose lengths differ by a few cells,
+// they end together.  configs[3] stage by number of groups: 1 (wedge-major) 0.832 ms, 2: 0.774, 4: 0.790, 8: 0.910,
+// 16: 1.20; the 272 K-point RGB-D scan: 0.150 / 0.150 / 0.167 / 0.170 / 0.174.  Also measured: ONE k_ray LAUNCH PER
+// LENGTH GROUP (four), shortest first, so that the long rays find the near cells already lowered and their visits are
+// settled by the read (each (wavefront, cell) pair is otherwise one lowering event: 4.1 M events for 1.0 M cells) —
+// 0.92 ms: every launch pays the whole latency chain of a walk with a fraction of the wavefronts.  Removed.
+constexpr unsigned kRayGroups = 2u, kRayGroupClasses = kRayLenClasses / kRayGroups;  // 64 classes per group: rays below / beyond 224 cells
 __device__ __forceinline__ unsigned ray_len_key(unsigned cells) {  // group * 32 + class inside the group
   // Manhattan length in cells: [0, 96) in classes of 3, [96, 224) of 4, [224, 480) of 8, beyond in classes of 16
   if (cells < 96u) return cells / 3u;
@@ -485,8 +485,10 @@ __global__ __launch_bounds__(256) void k_ray_compact(const RayParams Q, const Ge
           // (2048 wedges; 1024: +1 %, 512: +20 %; length classes of 2..16 cells measured the same)
           const unsigned wedge = min(kRayWedges - 1u, unsigned(a * float(kRayWedges / 4u)));
           const unsigned lk = ray_len_key(unsigned(min(sum / Q.resolution, 1.0e6f)));
-          key[k] = Q.n < (1u << 20) ? wedge * kRayLenClasses + lk
-                                    : (lk / kRayGroupClasses) * (kRayWedges * kRayGroupClasses) + wedge * kRayGroupClasses + (lk % kRayGroupClasses);
+          // (measurement override: dbg bits 16..19 = log2(groups) + 1)
+          unsigned cpg = kRayGroupClasses;
+          if ((Q.dbg >> 16) & 15) cpg = kRayLenClasses >> (((Q.dbg >> 16) & 15) - 1);
+          key[k] = (lk / cpg) * (kRayWedges * cpg) + wedge * cpg + (lk % cpg);
           rank[k] = atomicAdd(&bin_cnt[key[k]], 1u);
         }
       }
