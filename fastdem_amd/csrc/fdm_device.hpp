@@ -16,7 +16,28 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Measurement builds only (make -C fastdem_amd/csrc phases): three intermediate time stamps per block of the fused
+// launches, packed into the timeline's end word (scripts/phases_batch.py, scripts/phases_tiled.py).
+#ifndef FDM_MB_PHASES
+#define FDM_MB_PHASES 0
+#endif
+#if FDM_MB_PHASES
+#define FDM_PHASE(i) do { if (threadIdx.x == 0) fdm::g_phase[i] = unsigned(wall_clock64()); } while (0)
+#else
+#define FDM_PHASE(i) do { } while (0)
+#endif
+
 namespace fdm {
+
+#if FDM_MB_PHASES
+__shared__ unsigned g_phase[4];
+// end | phase stamps, 16 bits each, 10 ns ticks after t0
+__device__ __forceinline__ unsigned long long phase_word(unsigned long long t0) {
+  const unsigned base = unsigned(t0);
+  auto d16 = [&](unsigned v) { return (unsigned long long)(min(v - base, 0xFFFFu)); };
+  return d16(unsigned(wall_clock64())) | (d16(g_phase[0]) << 16) | (d16(g_phase[1]) << 32) | (d16(g_phase[2]) << 48);
+}
+#endif
 
 constexpr float kFltMax = 3.402823466e+38f;
 constexpr uint64_t kEmptyKey = ~0ull;

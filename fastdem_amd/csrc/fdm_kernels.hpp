@@ -193,7 +193,9 @@ __device__ __forceinline__ DevCand block_candidate(const ScanParams& P, const Ge
     }
     DevCand c;
     if (P.do_move) {
-      c = move_candidate(g, G, P.robot_x, P.robot_y);
+      // (every block of a launch walks this on ONE thread while the others wait at the barrier: the variant without
+      // the two fp64 divides on the common path, bit-identical by construction — fdm_device.hpp)
+      c = move_candidate_fast(g, G, P.robot_x, P.robot_y);
     } else {
       c.px = g.px; c.py = g.py; c.sr = g.sr; c.sc = g.sc; c.shr = 0; c.shc = 0;
     }

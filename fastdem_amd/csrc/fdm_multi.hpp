@@ -49,23 +49,11 @@
 
 namespace fdm {
 
-#if defined(FDM_MB_PHASES) && FDM_MB_PHASES
-__shared__ unsigned g_phase[4];
-#endif
-
 constexpr int kMaxBatch = 16;            // scans per launch (one bit per scan in 16-bit halves of a state word)
 constexpr unsigned kSpinMax = 1u << 22;  // polls before a waiting block gives up (seconds; never reached in practice)
 constexpr int kLineWords = 32;           // a 128-byte line of 32-bit words
 #ifndef FDM_MB_WAVES
 #define FDM_MB_WAVES 6  // waves per SIMD k_mbatch is compiled for (<= 80 VGPRs; the LDS allows 6 blocks per CU): every block of a 16-scan VLP-16 batch resident at once
-#endif
-#ifndef FDM_MB_PHASES
-#define FDM_MB_PHASES 0  // measurement build only (make phases): three intermediate stamps per block in the timeline
-#endif
-#if FDM_MB_PHASES
-#define FDM_PHASE(i) do { if (threadIdx.x == 0) g_phase[i] = unsigned(wall_clock64()); } while (0)
-#else
-#define FDM_PHASE(i) do { } while (0)
 #endif
 constexpr int kMStates = 4;              // ring of batch states: update b-1 | bin b | crop b+1 | being re-armed
 
@@ -816,10 +804,8 @@ __global__ __launch_bounds__(256, MBatchWaves<POLICY>::value) void k_mbatch(cons
   if (K.timeline && threadIdx.x == 0) {  // (thread 0's view of the block; scripts/timeline_batch.py)
     const unsigned b = blockIdx.y * gridDim.x + x;
     K.timeline[2u * b] = t0;
-#if FDM_MB_PHASES  // end | phase stamps, 16 bits each, 10 ns ticks after t0
-    const unsigned base = unsigned(t0);
-    auto d16 = [&](unsigned v) { return (unsigned long long)(min(v - base, 0xFFFFu)); };
-    K.timeline[2u * b + 1u] = d16(unsigned(wall_clock64())) | (d16(g_phase[0]) << 16) | (d16(g_phase[1]) << 32) | (d16(g_phase[2]) << 48);
+#if FDM_MB_PHASES
+    K.timeline[2u * b + 1u] = phase_word(t0);
 #else
     K.timeline[2u * b + 1u] = wall_clock64();
 #endif

@@ -285,6 +285,7 @@ __device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& 
   }
   if (threadIdx.x == 0) s_rare = 0u;
   const DevCand cand = block_candidate(P, G, st, &s_cand, bid);  // contains the __syncthreads
+  FDM_PHASE(0);  // table initialised, candidate known (the point loads may still be in flight)
 
   // phase 1: all four points through the arithmetic
   int cells[4];
@@ -293,6 +294,7 @@ __device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& 
   bool any_glob = false;
   tbin_points<HAS_INT, THREADS, LEAN, true>(P, G, TG, I, S, cell_ids, cand, bid, xs, ys, zin, cells, zs, n_pass, n_in,
                                             any_glob);
+  FDM_PHASE(1);  // points arrived, transforms + index done
   if (dbg == 2) {
     S.bin_part[bid] = (cells[0] + cells[1] + cells[2] + cells[3] == 0x7FFFFFF1) ? 1ull : 0x100000001ull;
     return;
@@ -409,6 +411,7 @@ __device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& 
       if (cc[q] != kEmptyCell) s_list[p++] = uint16_t(l0 + q);
   }
   __syncthreads();
+  FDM_PHASE(2);  // LDS fold + compaction done
   // (b) record j = threadIdx.x + q * THREADS leaves the table for registers; its sigma_z^2 is evaluated
   // from the winning point (re-read from L2: the block loaded it a few microseconds ago)
   constexpr int kRounds = 4;
@@ -764,6 +767,7 @@ __device__ __forceinline__ void tupdate_tile(
     }
   }
 
+  FDM_PHASE(1);  // records folded into the tile image
   if (P.dbg_upd == 2) {
     if (lt == 0 && tile_ok && n_chunks) Q.desc[size_t(tile) * Q.stride] = 0ull;
     return;  // measurement only (block-uniform)
@@ -873,6 +877,7 @@ __device__ __forceinline__ void tupdate_tile(
         if (has_col) reinterpret_cast<uint32_t*>(L.color)[o] = rgb_[b] & 0x00FFFFFFu;
       }
     }
+    FDM_PHASE(2);  // touched cells updated
     // untouched cells: stores only
     if (obst_tile || strips) {
 #pragma unroll
@@ -956,6 +961,7 @@ __device__ __forceinline__ void tupdate_body(
     if (lt == 0) { s_live = m; s_ob = mo; s_rare = 0u; }
   }
   __syncthreads();
+  FDM_PHASE(0);  // round trip 1 (descriptor row, stamps, context) back
   unsigned live_lo = uni(unsigned(s_live)), live_hi = uni(unsigned(s_live >> 32));
   const unsigned ob_lo = uni(unsigned(s_ob)), ob_hi = uni(unsigned(s_ob >> 32));
   while (live_lo | live_hi) {  // block-uniform walk over the live slots
@@ -1001,13 +1007,20 @@ __global__ __launch_bounds__(THREADS, FDM_UPD_WAVES) void k_tupdate_tbin(
   const unsigned u0 = blockIdx.x < upd_blocks ? blockIdx.x : upd_blocks;
   const unsigned u1 = blockIdx.x < upd_blocks ? blockIdx.x + 1u : upd_blocks;
   const unsigned long long t0 = A.timeline ? wall_clock64() : 0ull;
+#if FDM_MB_PHASES
+  if (threadIdx.x == 0) { g_phase[0] = g_phase[1] = g_phase[2] = unsigned(t0); }
+#endif
   if (u1 > u0)
     tupdate_body<POLICY, THREADS, HAS_INT, HAS_COL>(Pu, G, TG, st, L, all_layers, n_layers, Qu, A, span, dyn_lds, u0);
   else
     tbin_body<HAS_INT, HAS_COL, THREADS, LEAN>(Pb, G, TG, st, Ib, Sb, Qb, cell_ids, dyn_lds, blockIdx.x - u0);
   if (A.timeline && threadIdx.x == 0) {  // (thread 0's view of the block; bench A/B tool, see scripts/timeline.py)
     A.timeline[2u * blockIdx.x] = t0;
+#if FDM_MB_PHASES
+    A.timeline[2u * blockIdx.x + 1u] = phase_word(t0);
+#else
     A.timeline[2u * blockIdx.x + 1u] = wall_clock64();
+#endif
   }
 }
 
