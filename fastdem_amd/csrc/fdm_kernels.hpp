@@ -175,26 +175,39 @@ __device__ __forceinline__ void note_zeros(const Scratch& S, uint32_t cell, unsi
     atomicMin(reinterpret_cast<uint32_t*>(S.zs) + size_t(cell) * 2 + 1, (i << 1) | (__float_as_uint(v) >> 31));
 }
 
-__device__ __forceinline__ DevCand block_candidate(const ScanParams& P, const GeomConst& G,
-                                                   DevState* __restrict__ st, DevCand* s_cand,
-                                                   unsigned bid) {
+// In two steps, so that a kernel can put work between the state read and the walk (k_tbin: the transforms and crops of
+// its points, which need no geometry — 255 threads used to idle at the barrier while thread 0 waited for the state):
+//   candidate_begin   thread 0 issues the loads of the geometry ring entry it chains from
+//   candidate_finish  thread 0 walks the move, publishes; barrier; every thread returns the candidate
+struct CandState {
+  DevGeom g;
+  DevCand pc;
+  unsigned any_pass;
+};
+__device__ __forceinline__ void candidate_begin(const ScanParams& P, const DevState* __restrict__ st, CandState& cs) {
   if (threadIdx.x == 0) {
-    DevGeom g;
     if (P.chain_prev) {  // what k_update of the previous scan commits to geom[P.slot] (make_ctx)
       const int ps = (P.slot + 3) & 3;
-      g = st->geom[ps];
-      const bool applied = P.prev_do_move && (!P.prev_gate || st->flags[ps].any_pass != 0u);
-      if (applied) {
-        const DevCand pc = st->cand[ps];
-        g.px = pc.px; g.py = pc.py; g.sr = pc.sr; g.sc = pc.sc;
-      }
+      cs.g = st->geom[ps];
+      cs.any_pass = st->flags[ps].any_pass;
+      cs.pc = st->cand[ps];
     } else {
-      g = st->geom[P.slot];
+      cs.g = st->geom[P.slot];
+    }
+  }
+}
+__device__ __forceinline__ DevCand candidate_finish(const ScanParams& P, const GeomConst& G, DevState* __restrict__ st,
+                                                    const CandState& cs, DevCand* s_cand, unsigned bid) {
+  if (threadIdx.x == 0) {
+    DevGeom g = cs.g;
+    if (P.chain_prev) {
+      const bool applied = P.prev_do_move && (!P.prev_gate || cs.any_pass != 0u);
+      if (applied) { g.px = cs.pc.px; g.py = cs.pc.py; g.sr = cs.pc.sr; g.sc = cs.pc.sc; }
     }
     DevCand c;
     if (P.do_move) {
-      // (every block of a launch walks this on ONE thread while the others wait at the barrier: the variant without
-      // the two fp64 divides on the common path, bit-identical by construction — fdm_device.hpp)
+      // (every block of a launch walks this on ONE thread: the variant without the two fp64 divides on the common
+      // path, bit-identical by construction — fdm_device.hpp)
       c = move_candidate_fast(g, G, P.robot_x, P.robot_y);
     } else {
       c.px = g.px; c.py = g.py; c.sr = g.sr; c.sc = g.sc; c.shr = 0; c.shc = 0;
@@ -207,6 +220,13 @@ __device__ __forceinline__ DevCand block_candidate(const ScanParams& P, const Ge
   }
   __syncthreads();
   return *s_cand;
+}
+__device__ __forceinline__ DevCand block_candidate(const ScanParams& P, const GeomConst& G,
+                                                   DevState* __restrict__ st, DevCand* s_cand,
+                                                   unsigned bid) {
+  CandState cs;
+  candidate_begin(P, st, cs);
+  return candidate_finish(P, G, st, cs, s_cand, bid);
 }
 
 // ---------------------------------------------------------------------------------------------

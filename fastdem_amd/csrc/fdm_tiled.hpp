@@ -139,19 +139,17 @@ __host__ __device__ constexpr unsigned tbin_lds_bytes(bool has_int, bool has_col
 // T_world_base and getIndex.  cells[j] = tile << 10 | cell in tile of an owned cell, -1 outside the map
 // (or dropped by the crops), -2 inside the map but owned by another engine tile.  zs[] = map-frame z,
 // vs[] = intensity.  SIDE: also the captures, cell ids and statistics (the block's first walk only).
+// tbin_prep: the part that needs no map geometry (T_base_sensor, the crops, T_world_base, captures) — it runs while
+// thread 0 waits for the state it chains the geometry from.  tbin_points: getIndex + tile of the surviving points.
 template <bool HAS_INT, int THREADS, bool LEAN, bool SIDE>
-__device__ __forceinline__ void tbin_points(const ScanParams& P, const GeomConst& G, const TileGrid& TG,
-                                            const ScanInputs& I, const Scratch& S, int32_t* __restrict__ cell_ids,
-                                            const DevCand& cand, const unsigned bid, const float (&xin)[4],
-                                            const float (&yin)[4], const float (&zin)[4], int (&cells)[4],
-                                            float (&zs)[4], unsigned& n_pass, unsigned& n_in, bool& any_glob) {
+__device__ __forceinline__ void tbin_prep(const ScanParams& P, const Scratch& S, const unsigned bid,
+                                          const float (&xin)[4], const float (&yin)[4], const float (&zin)[4],
+                                          float (&xs)[4], float (&ys)[4], float (&zs)[4], bool (&pass)[4],
+                                          unsigned& n_pass) {
   float* const cap_x = (LEAN || !SIDE) ? nullptr : S.cap_x;
   float* const cap_var = (LEAN || !SIDE) ? nullptr : S.cap_var;
-  int32_t* const ids = (LEAN || !SIDE) ? nullptr : cell_ids;
   const bool drop_nf = LEAN ? false : P.drop_nonfinite != 0;
   const unsigned i0 = bid * unsigned(THREADS * 4) + threadIdx.x * 4u;
-  float xs[4], ys[4];
-  bool pass[4];
   // Branch-lean on purpose (the first version spent as many issue slots on exec-mask bookkeeping as on
   // arithmetic): the transforms and the fixed-point index estimate run for all four points without a branch;
   // the reference's exact index arithmetic is one shared, rarely taken branch for the lanes whose estimate
@@ -177,6 +175,14 @@ __device__ __forceinline__ void tbin_points(const ScanParams& P, const GeomConst
     }
     n_pass += pass[j] ? 1u : 0u;
   }
+}
+template <bool HAS_INT, int THREADS, bool LEAN, bool SIDE>
+__device__ __forceinline__ void tbin_points(const ScanParams& P, const GeomConst& G, const TileGrid& TG,
+                                            int32_t* __restrict__ cell_ids, const DevCand& cand, const unsigned bid,
+                                            const float (&xs)[4], const float (&ys)[4], const bool (&pass)[4],
+                                            int (&cells)[4], unsigned& n_in, bool& any_glob) {
+  int32_t* const ids = (LEAN || !SIDE) ? nullptr : cell_ids;
+  const unsigned i0 = bid * unsigned(THREADS * 4) + threadIdx.x * 4u;
   const bool any_start = cand.sr != 0 || cand.sc != 0;
   int kr[4], kc[4];
   bool sure_r[4], sure_c[4], inside[4];
@@ -213,7 +219,6 @@ __device__ __forceinline__ void tbin_points(const ScanParams& P, const GeomConst
     if (ids && i0 + j < P.n)
       ids[i0 + j] = owned ? sc * G.s_rows + sr : (!pass[j] ? -1 : (in_map ? -3 : -2));
   }
-  (void)I;
 }
 
 template <bool HAS_INT, bool HAS_COL, int THREADS, bool LEAN>
@@ -284,17 +289,21 @@ __device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& 
     if (HAS_COL) reinterpret_cast<uint4*>(h_last)[threadIdx.x] = zero;
   }
   if (threadIdx.x == 0) s_rare = 0u;
-  const DevCand cand = block_candidate(P, G, st, &s_cand, bid);  // contains the __syncthreads
-  FDM_PHASE(0);  // table initialised, candidate known (the point loads may still be in flight)
+  CandState cstate;
+  candidate_begin(P, st, cstate);  // (thread 0's state loads leave; the walk follows the transforms below)
 
-  // phase 1: all four points through the arithmetic
+  // phase 1: all four points through the arithmetic — first what needs no geometry (both transforms, the crops), in
+  // the shadow of thread 0's state read, then the geometry candidate (barrier), then getIndex
   int cells[4];
-  float zs[4];
+  float xm[4], ym[4], zs[4];
+  bool pass[4];
   unsigned n_pass = 0, n_in = 0;
   bool any_glob = false;
-  tbin_points<HAS_INT, THREADS, LEAN, true>(P, G, TG, I, S, cell_ids, cand, bid, xs, ys, zin, cells, zs, n_pass, n_in,
-                                            any_glob);
-  FDM_PHASE(1);  // points arrived, transforms + index done
+  tbin_prep<HAS_INT, THREADS, LEAN, true>(P, S, bid, xs, ys, zin, xm, ym, zs, pass, n_pass);
+  const DevCand cand = candidate_finish(P, G, st, cstate, &s_cand, bid);  // contains the __syncthreads
+  FDM_PHASE(0);  // table initialised, points transformed and cropped, candidate known
+  tbin_points<HAS_INT, THREADS, LEAN, true>(P, G, TG, cell_ids, cand, bid, xm, ym, pass, cells, n_in, any_glob);
+  FDM_PHASE(1);  // index done
   if (dbg == 2) {
     S.bin_part[bid] = (cells[0] + cells[1] + cells[2] + cells[3] == 0x7FFFFFF1) ? 1ull : 0x100000001ull;
     return;

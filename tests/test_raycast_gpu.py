@@ -115,6 +115,16 @@ class TestVoxelGridAny:
         sel = check_voxel(gpu, R, x, y, z, 0.25)
         assert 1000 < sel.size < n
 
+    def test_five_million_points(self, gpu, R):
+        """More than 1024 tiles of 4096 pairs: the radix sort's per-bin scan over the tiles carries across its steps
+        (fdm_rsort.hpp k_rs_scan); 64-bit keys, eight passes."""
+        rng = np.random.default_rng(5)
+        n = 5_000_000
+        x, y = (rng.uniform(-40, 40, n).astype(F32) for _ in range(2))
+        z = rng.uniform(-1, 3, n).astype(F32)
+        sel = check_voxel(gpu, R, x, y, z, 0.2)
+        assert 100_000 < sel.size < n
+
     def test_dense_voxels_and_long_runs(self, gpu, R):
         rng = np.random.default_rng(4)
         n = 100_000  # ~100 voxels: runs of ~1000 points exercise the bisection of voxel_pick
