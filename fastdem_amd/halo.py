@@ -1,0 +1,140 @@
+"""ctypes plumbing for libfdm_halo.so (include/fdm_halo.h): the tile plan and the routed step of a tiled GLOBAL map as
+ONE C call per scan (fdm_halo_routed_step) — the host loop of tiling.RoutedScan.integrate without an interpreter between
+its launches.  The RCCL communicator is the library's own (ncclCommInitRank through ctypes on the librccl that torch
+loaded); the unique id travels over whatever torch.distributed group the ranks already share."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfdm_halo.so")
+
+
+class FdmRect(C.Structure):
+    _fields_ = [("r0", C.c_int32), ("c0", C.c_int32), ("nr", C.c_int32), ("nc", C.c_int32)]
+
+
+class FdmTilePlan(C.Structure):  # fdm_tile_plan
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("halo", C.c_int32), ("grid_rows", C.c_int32), ("grid_cols", C.c_int32),
+                ("owned", FdmRect), ("stored", FdmRect), ("n_sends", C.c_int32), ("n_recvs", C.c_int32),
+                ("send_rank", C.c_int32 * 8), ("send_rect", FdmRect * 8),
+                ("recv_rank", C.c_int32 * 8), ("recv_rect", FdmRect * 8)]
+
+
+class NcclUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+_lib = None
+_nccl = None
+
+
+def load():
+    """dlopen libfdm_halo.so (after libfdm_engine.so, as a host application links both)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    capi.load()
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `make -C fastdem_amd/csrc`")
+    lib = C.CDLL(LIB_PATH)
+    P = C.c_void_p
+    lib.fdm_halo_last_error.restype = C.c_char_p
+    lib.fdm_tile_plan_make.argtypes = [C.c_int32] * 5 + [C.POINTER(FdmTilePlan)]
+    lib.fdm_tile_plan_route.argtypes = [C.POINTER(FdmTilePlan), C.POINTER(capi.FdmRoutePlan)]
+    lib.fdm_tile_plan_route.restype = None
+    lib.fdm_halo_routed_ws_create.argtypes = [C.POINTER(FdmTilePlan), C.c_uint64, C.POINTER(P)]
+    lib.fdm_halo_routed_ws_destroy.argtypes = [P]
+    lib.fdm_halo_routed_ws_destroy.restype = None
+    lib.fdm_halo_routed_step.argtypes = [P, P, C.POINTER(FdmTilePlan), C.POINTER(capi.FdmRoutePlan), P, C.c_uint64,
+                                         P, P, P, P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, P]
+    _lib = lib
+    return lib
+
+
+def _rccl():
+    global _nccl
+    if _nccl is None:
+        import torch
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        _nccl = C.CDLL(cand if os.path.exists(cand) else "librccl.so")
+        _nccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, NcclUniqueId, C.c_int]
+        _nccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    return _nccl
+
+
+def make_comm(rank, world, dist=None, group=None):
+    """An ncclComm of `world` ranks (None for world == 1 when no collective is wanted).  Rank 0 draws the unique id;
+    it reaches the others through torch.distributed's object broadcast (any backend)."""
+    nccl = _rccl()
+    uid = NcclUniqueId()
+    if rank == 0:
+        assert nccl.ncclGetUniqueId(C.byref(uid)) == 0
+    if world > 1:
+        box = [bytes(uid.internal)] if rank == 0 else [None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        C.memmove(C.byref(uid), box[0].ljust(128, b"\0"), 128)
+    comm = C.c_void_p()
+    rc = nccl.ncclCommInitRank(C.byref(comm), world, uid, rank)
+    if rc != 0:
+        raise RuntimeError(f"ncclCommInitRank failed: {rc}")
+    return comm
+
+
+def destroy_comm(comm):
+    if comm:
+        _rccl().ncclCommDestroy(comm)
+
+
+def _col16(T):
+    a = np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(4, 4).T).reshape(16)
+    return (C.c_double * 16)(*a.tolist())
+
+
+class NativeRoutedScan:
+    """tiling.RoutedScan.integrate as one C call per step (fdm_halo_routed_step).  `comm`: an ncclComm of the plan's
+    world (make_comm); may be None when world == 1."""
+
+    def __init__(self, engine, rank, world, rows, cols, halo, max_points, comm=None):
+        self.lib = load()
+        self.eng, self.comm = engine, comm
+        self.plan = FdmTilePlan()
+        rc = self.lib.fdm_tile_plan_make(rank, world, rows, cols, halo, C.byref(self.plan))
+        if rc != 0:
+            raise RuntimeError(self.lib.fdm_halo_last_error().decode())
+        self.route = capi.FdmRoutePlan()
+        self.lib.fdm_tile_plan_route(C.byref(self.plan), C.byref(self.route))
+        self.ws = C.c_void_p()
+        rc = self.lib.fdm_halo_routed_ws_create(C.byref(self.plan), int(max_points), C.byref(self.ws))
+        if rc != 0:
+            raise RuntimeError(self.lib.fdm_halo_last_error().decode())
+        self.matrix = np.zeros((world, world + 2), dtype=np.uint32)
+
+    def close(self):
+        if self.ws:
+            self.lib.fdm_halo_routed_ws_destroy(self.ws)
+            self.ws = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def integrate(self, x, y, z, T_base_sensor, T_world_base, intensity=None, sensors=False):
+        """x, y, z[, intensity]: this rank's part of the step (torch device tensors).  Returns the counter matrix."""
+        self.eng.wait_torch()
+        n = int(x.numel())
+        rc = self.lib.fdm_halo_routed_step(
+            self.eng._h, self.comm, C.byref(self.plan), C.byref(self.route), self.ws, n,
+            C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(z.data_ptr()),
+            C.c_void_p(intensity.data_ptr()) if intensity is not None else None,
+            _col16(T_base_sensor), _col16(T_world_base), 1 if sensors else 0,
+            self.matrix.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise RuntimeError(f"fdm_halo_routed_step: {rc} {self.lib.fdm_halo_last_error().decode()}")
+        return self.matrix.astype(np.int64)

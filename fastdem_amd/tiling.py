@@ -419,6 +419,11 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
                  "lower_bound", "n_points", "obstacle", "intensity"]
         n_pts = wl.n_points
         router = RoutedScan(eng, plan, dev, max_points=n_pts)
+        native = None
+        if int(getattr(args, "native_routed", 1)):  # the routed step as ONE C call (libfdm_halo: fdm_halo_routed_step)
+            from . import halo as halo_c
+            comm = halo_c.make_comm(rank, world, dist)
+            native = halo_c.NativeRoutedScan(eng, rank, world, rows, cols, DEFAULT_HALO, n_pts, comm=comm)
         mine = [{c: torch.from_numpy(s[c]).to(dev) for c in ("x", "y", "z", "intensity")} for s in wl.scans]
         steps, warm = min(args.steps, 200), min(args.warmup, 20)
         # robot `rank` of `world`: the workload's 150 m circle (0.4 m per pose: 2356 poses per turn), a world-th of a
@@ -428,8 +433,12 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
 
         def step(k):
             d = mine[k % len(mine)]
-            router.integrate(d["x"], d["y"], d["z"], wl.T_base_sensor, pose(k), dist, intensity=d["intensity"],
-                             sensors=True)
+            if native is not None:
+                router.matrix = native.integrate(d["x"], d["y"], d["z"], wl.T_base_sensor, pose(k), intensity=d["intensity"],
+                                                 sensors=True)
+            else:
+                router.integrate(d["x"], d["y"], d["z"], wl.T_base_sensor, pose(k), dist, intensity=d["intensity"],
+                                 sensors=True)
             exchange_halos(tile, plan, names, dist)
             dog.kick(f"step {k}")
             return n_pts
@@ -479,7 +488,8 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
                    "parallelism": f"spatial tiles {pr}x{pc}, halo {DEFAULT_HALO} cells; N-sensor mode: every rank routes its own "
                                   "2 M-point scan to the owners of the cells (16 B point records, point-to-point over RCCL), the "
                                   "owners integrate source by source, p2p halo exchange per step",
-                   "inputs": "SoA float32 (x, y, z, intensity) resident in HBM on every rank"},
+                   "inputs": "SoA float32 (x, y, z, intensity) resident in HBM on every rank",
+                   "routed_step": "one C call per step (fdm_halo_routed_step)" if native is not None else "Python loop (tiling.RoutedScan)"},
         "rank0_last_scan": st,
         "rank0_routing_matrix_last_step": routed.tolist() if routed is not None else None,
     }

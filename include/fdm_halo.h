@@ -83,6 +83,22 @@ int fdm_halo_route_exchange(fdm_engine* e, void* nccl_comm, const fdm_tile_plan*
                             const uint32_t* h_matrix, float* d_recv, uint64_t recv_capacity, uint64_t* n_recv,
                             int32_t* any_in_map);
 
+/* The whole routed step as ONE call (what fastdem_amd/tiling.py::RoutedScan.integrate does, without an interpreter
+ * between the launches): route this rank's slice -> all-gather of the counters and the rank's transforms, one host
+ * read-back -> point exchange -> the owner integrates.  sensors = 0: the slices are ONE logical scan (every rank passes
+ * the same transforms); sensors = 1: one scan per rank with its own transforms, integrated by the owners in rank
+ * order (an owner skips a source that sent it nothing unless that source's scan must clear its obstacle layer).
+ * The workspace holds the send / receive / table buffers (max_points = largest slice); h_matrix_out (nullable,
+ * world * (world + 2) words) receives the counter matrix of the step.  nccl_comm may be null when world == 1.
+ * Followed, as before, by fdm_halo_exchange for the halo rings. */
+typedef struct fdm_routed_ws fdm_routed_ws;
+int fdm_halo_routed_ws_create(const fdm_tile_plan* plan, uint64_t max_points, fdm_routed_ws** out);
+void fdm_halo_routed_ws_destroy(fdm_routed_ws* ws);
+int fdm_halo_routed_step(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* plan, const fdm_route_plan* route,
+                         fdm_routed_ws* ws, uint64_t n, const float* d_x, const float* d_y, const float* d_z,
+                         const float* d_intensity, const double T_base_sensor[16], const double T_world_base[16],
+                         int32_t sensors, uint32_t* h_matrix_out);
+
 const char* fdm_halo_last_error(void);
 
 #ifdef __cplusplus

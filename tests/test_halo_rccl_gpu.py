@@ -137,3 +137,37 @@ def test_routed_scan_sequence_through_rccl(rccl):
         assert n_recv.value == st["n_in_map"] and any_in.value == 1
     for name in ref.layers():
         assert np.array_equal(eng.layer(name).view(np.uint32), ref.layer(name).view(np.uint32)), name
+
+
+@pytest.mark.parametrize("sensors", [False, True])
+def test_routed_step_as_one_c_call(rccl, sensors):
+    """fdm_halo_routed_step (fastdem_amd/halo.py::NativeRoutedScan): route -> table all-gather + one read-back -> point
+    exchange -> integrate, inside ONE call — with a 1-rank communicator and without one (world == 1 needs none).  The
+    map equals the plain engine's bit for bit; the counter matrix is the plain engine's statistics."""
+    import torch
+    import fastdem_amd as fa
+    from fastdem_amd import halo as H
+    _, comm = rccl
+    ref = fa.Engine(40.0, 40.0, 0.1, global_cfg(fa))
+    engs = [fa.Engine(40.0, 40.0, 0.1, global_cfg(fa)) for _ in range(2)]
+    routed = [H.NativeRoutedScan(engs[0], 0, 1, 400, 400, 6, 200000, comm=comm),
+              H.NativeRoutedScan(engs[1], 0, 1, 400, 400, 6, 200000, comm=None)]
+    rng = np.random.default_rng(7)
+    for k in range(4):
+        n = 150000 if k != 2 else 777
+        s = cloud(rng, n, 25.0)
+        if k == 3:
+            s["z"] = (s["z"] + 50.0).astype(F32)  # every point filtered: no move, no obstacle clear
+        T = np.eye(4)
+        T[:3, 3] = (0.5 + 0.3 * k, -0.25, 0.4)
+        d = {c: torch.from_numpy(s[c]).cuda() for c in s}
+        rc, st = ref.integrate(s["x"], s["y"], s["z"], np.eye(4), T, intensity=s["intensity"])
+        for r in routed:
+            m = r.integrate(d["x"], d["y"], d["z"], np.eye(4), T, intensity=d["intensity"], sensors=sensors)
+            assert m.shape == (1, 3) and (m[0, 0], m[0, 1], m[0, 2]) == (st["n_in_map"], st["n_after_filter"], st["n_in_map"])
+    for e in engs:
+        e.sync()
+        for name in ref.layers():
+            assert np.array_equal(e.layer(name).view(np.uint32), ref.layer(name).view(np.uint32)), name
+    for r in routed:
+        r.close()
