@@ -115,6 +115,21 @@ class TestVoxelGridAny:
         sel = check_voxel(gpu, R, x, y, z, 0.25)
         assert 1000 < sel.size < n
 
+    @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, 8191, 8193,
+                                   65535, 65536, 65537, 262143, 262145, 1048577])
+    def test_sizes_around_the_sort_s_tile_and_wavefront_edges(self, gpu, R, n):
+        """The radix sort walks tiles of 4096 pairs, wavefronts of 1024, rounds of 64: sizes on either side of every
+        edge, many duplicates of a few keys among unique ones (runs that straddle tiles)."""
+        rng = np.random.default_rng(n)
+        x, y, z = (rng.uniform(-30, 30, n).astype(F32) for _ in range(3))
+        m = n // 3
+        if m:
+            x[:m] = rng.integers(0, 4, m).astype(F32) * 0.5
+            y[:m] = 1.0
+            z[:m] = -2.0
+            rng.shuffle(x)
+        check_voxel(gpu, R, x, y, z, 0.3)
+
     def test_five_million_points(self, gpu, R):
         """More than 1024 tiles of 4096 pairs: the radix sort's per-bin scan over the tiles carries across its steps
         (fdm_rsort.hpp k_rs_scan); 64-bit keys, eight passes."""
