@@ -11,12 +11,13 @@ import bench  # noqa: E402
 from fastdem_amd import synth  # noqa: E402
 
 bm = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 16
-wl = synth.make("c2", n_scans=8)
+WL = next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("workload=")), "c2")
+wl = synth.make(WL, n_scans=8)
 res = bench.Resident(wl, 0)
 res.eng.set_option("dbg_timeline", 1)
 res.eng.set_option("batch_max", bm)
 for kv in sys.argv[1:]:
-    if "=" in kv and not kv.startswith("variant"):
+    if "=" in kv and not kv.startswith("variant") and not kv.startswith("workload"):
         res.eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 for kk in range(400):
     res.pose(kk)
@@ -35,9 +36,9 @@ end = (w & np.uint64(0xFFFF)).astype(np.float64) / 100.0
 p0 = ((w >> np.uint64(16)) & np.uint64(0xFFFF)).astype(np.float64) / 100.0
 p1 = ((w >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.float64) / 100.0
 p2 = ((w >> np.uint64(48)) & np.uint64(0xFFFF)).astype(np.float64) / 100.0
-nb = (28800 + 511) // 512
+nb = (wl.n_points + 511) // 512
 cells = 64
-nu = (22500 + cells - 1) // cells
+nu = (int(res.eng.rows) * int(res.eng.cols) + cells - 1) // cells
 ur = (nu + gx - 1) // gx
 def q(x): return [round(float(v), 2) for v in np.percentile(x, [10, 50, 90])] if len(x) else []
 def block(idx, names):
