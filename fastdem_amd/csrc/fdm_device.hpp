@@ -427,6 +427,42 @@ __device__ __forceinline__ void kalman_step(KalmanState& s, float z, float meas_
   s.lower = s.x - 2.0f * sigma;
 }
 
+// The same update for a cell that takes SEVERAL observations before its state is stored (fdm_multi.hpp): the sample
+// variance and the bounds are functions of (x, count, m2) alone — no later step reads them — so kalman_core leaves them
+// out and kalman_finish computes them once, after the last observation, with the operations kalman_step uses (its
+// first-sample branch sets var = 0 with m2 = 0: the same value the formula gives).
+__device__ __forceinline__ void kalman_core(KalmanState& s, float z, float meas_var, float min_var, float max_var, float q) {
+  const float R = (meas_var > 0.0f) ? meas_var : max_var;
+  if (isnan(s.x)) {
+    s.x = z;
+    s.P = R;
+    s.count = 1.0f;
+  } else {
+    s.P += q;
+    const float K = s.P / (s.P + R);
+    s.x = s.x + K * (z - s.x);
+    s.P = (1.0f - K) * s.P;
+    s.P = clampf(s.P, min_var, max_var);
+    s.count += 1.0f;
+  }
+  if (isnan(s.mean)) {
+    s.mean = z;
+    s.m2 = 0.0f;
+  } else {
+    const float delta = z - s.mean;
+    const float new_mean = s.mean + (delta / s.count);
+    const float delta2 = z - new_mean;
+    s.m2 += delta * delta2;
+    s.mean = new_mean;
+  }
+}
+__device__ __forceinline__ void kalman_finish(KalmanState& s) {
+  s.var = (s.count > 1.0f) ? s.m2 / (s.count - 1.0f) : 0.0f;
+  const float sigma = sqrtf((0.0f < s.var) ? s.var : 0.0f);
+  s.upper = s.x + 2.0f * sigma;
+  s.lower = s.x - 2.0f * sigma;
+}
+
 struct P2Params {
   float dn[5];
   int marker;

@@ -741,11 +741,13 @@ struct KalmanRecPolicy {  // cell records
   }
   // the same update split in two for a cell that takes SEVERAL observations in one kernel (fdm_multi.hpp): step()
   // keeps everything in registers, store() writes the record once at the end
+  // (the sample variance and the bounds once, in finish(), after the cell's last observation)
   static __device__ __forceinline__ void step(const Layers& L, State& t, float min_z, float var, float max_z) {
-    kalman_step(t.s, min_z, var, L.min_var, L.max_var, L.q);
+    kalman_core(t.s, min_z, var, L.min_var, L.max_var, L.q);
     t.smin = (isnan(t.smin) || min_z < t.smin) ? min_z : t.smin;
     t.smax = (isnan(t.smax) || max_z > t.smax) ? max_z : t.smax;
   }
+  static __device__ __forceinline__ void finish(State& t) { kalman_finish(t.s); }
   static __device__ __forceinline__ void store(const Layers& L, unsigned o, const State& t) {
     float4* r = reinterpret_cast<float4*>(L.rec + size_t(o) * kKalmanRec);
     r[0] = make_float4(t.s.x, t.smin, t.smax, t.s.var);
@@ -832,6 +834,7 @@ struct P2RecPolicy {  // cell records
     t.smin = (isnan(t.smin) || min_z < t.smin) ? min_z : t.smin;
     t.smax = (isnan(t.smax) || max_z > t.smax) ? max_z : t.smax;
   }
+  static __device__ __forceinline__ void finish(State&) {}
   static __device__ __forceinline__ void store(const Layers& L, unsigned o, const State& t) {
     float4* r = reinterpret_cast<float4*>(L.rec + size_t(o) * kP2Rec);
     r[0] = make_float4(t.s.elevation, t.smin, t.smax, t.s.variance);

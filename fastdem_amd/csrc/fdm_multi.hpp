@@ -240,9 +240,26 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
   const float* __restrict__ const py = B.py[k];
   const float* __restrict__ const pz = B.pz[k];
 
-  // (the poses leave before the point loads: loads return in order, and the walk below waits for these)
+  // (the poses and the geometry the chain starts from leave before the point loads: loads return in order, and the
+  // walk below waits for these; the previous batch's candidate is fetched whether or not it will apply — one round
+  // trip instead of flag -> candidate)
   double pose_x = 0.0, pose_y = 0.0;
-  if (threadIdx.x < 64u && lane <= k) { pose_x = B.robot_x[lane]; pose_y = B.robot_y[lane]; }
+  DevGeom g_start;
+  DevCand c_prev;
+  unsigned f_prev = 0u;
+  g_start.px = g_start.py = 0.0; g_start.sr = g_start.sc = 0; g_start.pad0 = g_start.pad1 = 0;
+  c_prev.px = c_prev.py = 0.0; c_prev.sr = c_prev.sc = c_prev.shr = c_prev.shc = 0;
+  if (threadIdx.x < 64u) {
+    if (lane <= k) { pose_x = B.robot_x[lane]; pose_y = B.robot_y[lane]; }
+    if (B.prev) {
+      const unsigned pk = B.prev_count - 1u;
+      g_start = B.prev->E[pk];
+      c_prev = B.prev->C[pk];
+      f_prev = B.prev->flags[0];
+    } else {
+      g_start = st->geom[B.scan_no0 & 3u];
+    }
+  }
   const unsigned n = B.n[k];
   const unsigned i0 = lb * kMBlock + threadIdx.x;  // the thread's points: i0, i0 + 256 (two coalesced sweeps)
   float xs[kMPts], ys[kMPts], zs[kMPts], vs[kMPts];
@@ -286,16 +303,12 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
     return __hiloint2double(hi, lo);
   };
   auto chain = [&](unsigned passmask) {  // (every lane of the first wavefront, uniformly)
-    DevGeom g;
+    DevGeom g = g_start;
     if (B.prev) {  // what the update of the previous batch (the other half of this launch) is about to commit
       const unsigned pk = B.prev_count - 1u;
-      g = B.prev->E[pk];
-      if (K.do_move && (!K.gate_on_filter || ((B.prev->flags[0] >> (16u + pk)) & 1u) != 0u)) {
-        const DevCand pc = B.prev->C[pk];
-        g.px = pc.px; g.py = pc.py; g.sr = pc.sr; g.sc = pc.sc;
+      if (K.do_move && (!K.gate_on_filter || ((f_prev >> (16u + pk)) & 1u) != 0u)) {
+        g.px = c_prev.px; g.py = c_prev.py; g.sr = c_prev.sr; g.sc = c_prev.sc;
       }
-    } else {
-      g = st->geom[B.scan_no0 & 3u];
     }
     DevCand c;
     c.px = g.px; c.py = g.py; c.sr = g.sr; c.sc = g.sc; c.shr = 0; c.shc = 0;
@@ -756,7 +769,10 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
       }
       POLICY::clear_cell(L, o);
     }
-    if (evt && !cleared) POLICY::store(L, o, stt);
+    if (evt && !cleared) {
+      POLICY::finish(stt);
+      POLICY::store(L, o, stt);
+    }
     if (obst_dirty) L.obstacle[o] = obst;
     if (has_int && (evt || strip_any)) L.intensity[o] = sint;
     if (has_col && (evt || strip_any)) reinterpret_cast<uint32_t*>(L.color)[o] = colv;
