@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10000)
     ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
-    ap.add_argument("--native-routed", type=int, default=1, help="c5 routed: the step as one C call (libfdm_halo) instead of the Python loop")
+    ap.add_argument("--native-routed", type=int, default=1, help="c5 routed: 1 = the step as one C call (libfdm_halo), 2 = that call pipelined over consecutive scans (one rank), 0 = the Python loop")
     ap.add_argument("--order", default="azimuth", choices=["azimuth", "ring"])
     ap.add_argument("--scans", type=int, default=0,
                     help="distinct synthetic scans resident in HBM (0 = per workload: enough that the 2 M-point "

@@ -238,18 +238,118 @@ int fdm_halo_route_exchange(fdm_engine* e, void* nccl_comm, const fdm_tile_plan*
 }
 
 // ---- the routed step as ONE call (the host loop of tiling.RoutedScan in C: no interpreter between the launches) ----
-struct fdm_routed_ws {
-  int world = 0;
-  uint64_t max_points = 0, recv_cap = 0;
+// Two halves: the FRONT (route the slice, gather the table, copy it to the host — enqueue only, an event behind it) and
+// the BACK (wait for the table, exchange the points, integrate).  fdm_halo_routed_step runs both for one scan;
+// fdm_halo_routed_submit runs the front of scan k+1 and THEN the back of scan k, so that the device works on scan k's
+// points while the host waits for scan k+1's table (two sets of send / table buffers).
+struct RoutedSlot {
   float* d_send = nullptr;      // [max_points] x 16 B, owner-major
-  float* d_recv = nullptr;      // [recv_cap] x 16 B, source-major
   uint32_t* d_row = nullptr;    // world + 2 counters | the rank's two transforms as raw fp64 bits (64 words)
   uint32_t* d_table = nullptr;  // [world] rows
   uint32_t* h_table = nullptr;  // pinned copy
   double* h_pose = nullptr;     // pinned: T_base_sensor | T_world_base
-  uint32_t* h_matrix = nullptr; // [world][world + 2] (plain host memory)
+  hipEvent_t ready = nullptr;   // the table is on the host
+  double T[32];                 // the caller's transforms of the scan in this slot
+  int has_i = 0, sensors = 0;
+  bool pending = false;
+};
+struct fdm_routed_ws {
+  int world = 0;
+  uint64_t max_points = 0, recv_cap = 0;
+  RoutedSlot slot[2];
+  unsigned seq = 0;
+  float* d_recv = nullptr;      // [recv_cap] x 16 B, source-major
+  uint32_t* h_matrix = nullptr; // [world][world + 2] of the last finished scan (plain host memory)
   bool obstacle_dirty = true;   // (sensors mode) the tile's obstacle layer may hold non-NaN cells
 };
+
+namespace {
+int routed_front(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p, const fdm_route_plan* route, fdm_routed_ws* w,
+                 RoutedSlot& s, uint64_t n, const float* d_x, const float* d_y, const float* d_z, const float* d_i,
+                 const double* Tbs, const double* Twb, int sensors) {
+  const int W = p->world;
+  const size_t per = size_t(W) + 2, row = per + 64;
+  hipStream_t stream = static_cast<hipStream_t>(fdm_engine_stream(e));
+  // 1. this rank's slice, partitioned by owner (three small kernels); its counters land in the row
+  if (int rc = fdm_engine_route_scan(e, route, n, d_x, d_y, d_z, d_i, Tbs, Twb, s.d_send, s.d_row))
+    return fail(rc, std::string("fdm_engine_route_scan: ") + fdm_last_error());
+  // 2. the row travels with the rank's transforms (N-sensor mode: the owners need every source's)
+  for (int k = 0; k < 16; ++k) { s.h_pose[k] = s.T[k] = Tbs[k]; s.h_pose[16 + k] = s.T[16 + k] = Twb[k]; }
+  s.has_i = d_i ? 1 : 0;
+  s.sensors = sensors;
+  if (hipMemcpyAsync(s.d_row + per, s.h_pose, 32 * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess)
+    return fail(FDM_ERR_HIP, "uploading the transforms");
+  // 3. one small all-gather, ONE host read-back (the sizes of the exchange are host-side arguments)
+  if (W > 1) {
+    const ncclResult_t r = ncclAllGather(s.d_row, s.d_table, row, ncclUint32, static_cast<ncclComm_t>(nccl_comm), stream);
+    if (r != ncclSuccess) return fail(FDM_ERR_HIP, std::string("ncclAllGather: ") + ncclGetErrorString(r));
+  }
+  if (hipMemcpyAsync(s.h_table, W > 1 ? s.d_table : s.d_row, row * 4 * size_t(W), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+      hipEventRecord(s.ready, stream) != hipSuccess)
+    return fail(FDM_ERR_HIP, "reading the routing table back");
+  s.pending = true;
+  (void)w;
+  return FDM_OK;
+}
+
+int routed_back(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p, fdm_routed_ws* w, RoutedSlot& s,
+                uint32_t* h_matrix_out) {
+  const int W = p->world, me = p->rank;
+  const size_t per = size_t(W) + 2, row = per + 64;
+  if (hipEventSynchronize(s.ready) != hipSuccess) return fail(FDM_ERR_HIP, "waiting for the routing table");
+  s.pending = false;
+  for (int src = 0; src < W; ++src)
+    for (size_t j = 0; j < per; ++j) w->h_matrix[size_t(src) * per + j] = s.h_table[size_t(src) * row + j];
+  if (h_matrix_out) std::copy(w->h_matrix, w->h_matrix + size_t(W) * per, h_matrix_out);
+  // 4. the points travel to their owners
+  uint64_t total = 0;
+  for (int src = 0; src < W; ++src) total += w->h_matrix[size_t(src) * per + size_t(me)];
+  if (total > w->recv_cap) {
+    if (w->d_recv) {
+      if (hipStreamSynchronize(static_cast<hipStream_t>(fdm_engine_stream(e))) != hipSuccess)  // (an earlier integrate may read it)
+        return fail(FDM_ERR_HIP, "stream");
+      (void)hipFree(w->d_recv);
+    }
+    w->d_recv = nullptr;
+    w->recv_cap = total + total / 4 + 1024;
+    if (hipMalloc(reinterpret_cast<void**>(&w->d_recv), w->recv_cap * 16) != hipSuccess)
+      return fail(FDM_ERR_HIP, "allocating the receive buffer");
+  }
+  uint64_t n_recv = 0;
+  int32_t any_in_map = 0;
+  if (int rc = fdm_halo_route_exchange(e, nccl_comm, p, s.d_send, w->h_matrix, w->d_recv, w->recv_cap, &n_recv, &any_in_map))
+    return rc;
+  // 5. the owners integrate: the logical scan as one, or — N sensors — every source with its own transforms, in rank order
+  if (!s.sensors) {
+    if (int rc = fdm_engine_integrate_points4_device(e, n_recv, w->d_recv, s.has_i, any_in_map, s.T, s.T + 16))
+      return fail(rc, std::string("fdm_engine_integrate_points4_device: ") + fdm_last_error());
+    return FDM_OK;
+  }
+  uint64_t off = 0;
+  for (int src = 0; src < W; ++src) {
+    const uint64_t ns = w->h_matrix[size_t(src) * per + size_t(me)];
+    const bool seen = w->h_matrix[size_t(src) * per + size_t(W) + 1] > 0;  // that scan observed a cell somewhere
+    if (ns || (seen && w->obstacle_dirty)) {  // (else: nothing for this tile and its obstacle layer is clear already)
+      double T[32];
+      std::memcpy(T, s.h_table + size_t(src) * row + per, sizeof(T));
+      if (int rc = fdm_engine_integrate_points4_device(e, ns, ns ? w->d_recv + 4 * off : w->d_recv, s.has_i, seen ? 1 : 0, T, T + 16))
+        return fail(rc, std::string("fdm_engine_integrate_points4_device: ") + fdm_last_error());
+      w->obstacle_dirty = ns > 0;
+    }
+    off += ns;
+  }
+  return FDM_OK;
+}
+
+int routed_check(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p, const fdm_route_plan* route, fdm_routed_ws* w,
+                 uint64_t n, const double* Tbs, const double* Twb) {
+  if (!e || !p || !route || !w || !Tbs || !Twb) return fail(FDM_ERR_INVALID, "null argument");
+  if (w->world != p->world) return fail(FDM_ERR_INVALID, "workspace of another plan");
+  if (n > w->max_points) return fail(FDM_ERR_INVALID, "more points than the workspace holds");
+  if (p->world > 1 && !nccl_comm) return fail(FDM_ERR_INVALID, "null communicator");
+  return FDM_OK;
+}
+}  // namespace
 
 int fdm_halo_routed_ws_create(const fdm_tile_plan* p, uint64_t max_points, fdm_routed_ws** out) {
   if (!p || !out || p->world < 1) return fail(FDM_ERR_INVALID, "null argument");
@@ -257,12 +357,16 @@ int fdm_halo_routed_ws_create(const fdm_tile_plan* p, uint64_t max_points, fdm_r
   w->world = p->world;
   w->max_points = max_points ? max_points : 1;
   const size_t row = size_t(p->world) + 2 + 64;
-  bool ok = hipMalloc(reinterpret_cast<void**>(&w->d_send), w->max_points * 16) == hipSuccess &&
-            hipMalloc(reinterpret_cast<void**>(&w->d_row), row * 4) == hipSuccess &&
-            hipMalloc(reinterpret_cast<void**>(&w->d_table), row * 4 * size_t(p->world)) == hipSuccess &&
-            hipHostMalloc(reinterpret_cast<void**>(&w->h_table), row * 4 * size_t(p->world), hipHostMallocDefault) == hipSuccess &&
-            hipHostMalloc(reinterpret_cast<void**>(&w->h_pose), 32 * sizeof(double), hipHostMallocDefault) == hipSuccess &&
-            hipMemset(w->d_row, 0, row * 4) == hipSuccess;
+  bool ok = true;
+  for (RoutedSlot& s : w->slot) {
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&s.d_send), w->max_points * 16) == hipSuccess &&
+         hipMalloc(reinterpret_cast<void**>(&s.d_row), row * 4) == hipSuccess &&
+         hipMalloc(reinterpret_cast<void**>(&s.d_table), row * 4 * size_t(p->world)) == hipSuccess &&
+         hipHostMalloc(reinterpret_cast<void**>(&s.h_table), row * 4 * size_t(p->world), hipHostMallocDefault) == hipSuccess &&
+         hipHostMalloc(reinterpret_cast<void**>(&s.h_pose), 32 * sizeof(double), hipHostMallocDefault) == hipSuccess &&
+         hipMemset(s.d_row, 0, row * 4) == hipSuccess &&
+         hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) == hipSuccess;
+  }
   w->h_matrix = new uint32_t[size_t(p->world) * (size_t(p->world) + 2)];
   if (!ok) {
     fdm_halo_routed_ws_destroy(w);
@@ -274,12 +378,15 @@ int fdm_halo_routed_ws_create(const fdm_tile_plan* p, uint64_t max_points, fdm_r
 
 void fdm_halo_routed_ws_destroy(fdm_routed_ws* w) {
   if (!w) return;
-  if (w->d_send) (void)hipFree(w->d_send);
+  for (RoutedSlot& s : w->slot) {
+    if (s.d_send) (void)hipFree(s.d_send);
+    if (s.d_row) (void)hipFree(s.d_row);
+    if (s.d_table) (void)hipFree(s.d_table);
+    if (s.h_table) (void)hipHostFree(s.h_table);
+    if (s.h_pose) (void)hipHostFree(s.h_pose);
+    if (s.ready) (void)hipEventDestroy(s.ready);
+  }
   if (w->d_recv) (void)hipFree(w->d_recv);
-  if (w->d_row) (void)hipFree(w->d_row);
-  if (w->d_table) (void)hipFree(w->d_table);
-  if (w->h_table) (void)hipHostFree(w->h_table);
-  if (w->h_pose) (void)hipHostFree(w->h_pose);
   delete[] w->h_matrix;
   delete w;
 }
@@ -288,64 +395,38 @@ int fdm_halo_routed_step(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p,
                          fdm_routed_ws* w, uint64_t n, const float* d_x, const float* d_y, const float* d_z,
                          const float* d_intensity, const double T_base_sensor[16], const double T_world_base[16],
                          int32_t sensors, uint32_t* h_matrix_out) {
-  if (!e || !p || !route || !w || !T_base_sensor || !T_world_base) return fail(FDM_ERR_INVALID, "null argument");
-  if (w->world != p->world) return fail(FDM_ERR_INVALID, "workspace of another plan");
-  if (n > w->max_points) return fail(FDM_ERR_INVALID, "more points than the workspace holds");
-  const int W = p->world, me = p->rank;
-  if (W > 1 && !nccl_comm) return fail(FDM_ERR_INVALID, "null communicator");
-  const size_t per = size_t(W) + 2, row = per + 64;
-  hipStream_t stream = static_cast<hipStream_t>(fdm_engine_stream(e));
-  // 1. this rank's slice, partitioned by owner (three small kernels); its counters land in the row
-  if (int rc = fdm_engine_route_scan(e, route, n, d_x, d_y, d_z, d_intensity, T_base_sensor, T_world_base, w->d_send, w->d_row))
-    return fail(rc, std::string("fdm_engine_route_scan: ") + fdm_last_error());
-  // 2. the row travels with the rank's transforms (N-sensor mode: the owners need every source's)
-  for (int k = 0; k < 16; ++k) { w->h_pose[k] = T_base_sensor[k]; w->h_pose[16 + k] = T_world_base[k]; }
-  if (hipMemcpyAsync(w->d_row + per, w->h_pose, 32 * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess)
-    return fail(FDM_ERR_HIP, "uploading the transforms");
-  // 3. one small all-gather, ONE host read-back (the sizes of the exchange are host-side arguments)
-  if (W > 1) {
-    const ncclResult_t r = ncclAllGather(w->d_row, w->d_table, row, ncclUint32, static_cast<ncclComm_t>(nccl_comm), stream);
-    if (r != ncclSuccess) return fail(FDM_ERR_HIP, std::string("ncclAllGather: ") + ncclGetErrorString(r));
-  }
-  if (hipMemcpyAsync(w->h_table, W > 1 ? w->d_table : w->d_row, row * 4 * size_t(W), hipMemcpyDeviceToHost, stream) != hipSuccess ||
-      hipStreamSynchronize(stream) != hipSuccess)
-    return fail(FDM_ERR_HIP, "reading the routing table back");
-  for (int src = 0; src < W; ++src)
-    for (size_t j = 0; j < per; ++j) w->h_matrix[size_t(src) * per + j] = w->h_table[size_t(src) * row + j];
-  if (h_matrix_out) std::copy(w->h_matrix, w->h_matrix + size_t(W) * per, h_matrix_out);
-  // 4. the points travel to their owners
-  uint64_t total = 0;
-  for (int src = 0; src < W; ++src) total += w->h_matrix[size_t(src) * per + size_t(me)];
-  if (total > w->recv_cap) {
-    if (w->d_recv) (void)hipFree(w->d_recv);
-    w->d_recv = nullptr;
-    w->recv_cap = total + total / 4 + 1024;
-    if (hipMalloc(reinterpret_cast<void**>(&w->d_recv), w->recv_cap * 16) != hipSuccess)
-      return fail(FDM_ERR_HIP, "allocating the receive buffer");
-  }
-  uint64_t n_recv = 0;
-  int32_t any_in_map = 0;
-  if (int rc = fdm_halo_route_exchange(e, nccl_comm, p, w->d_send, w->h_matrix, w->d_recv, w->recv_cap, &n_recv, &any_in_map))
+  if (int rc = routed_check(e, nccl_comm, p, route, w, n, T_base_sensor, T_world_base)) return rc;
+  if (int rc = fdm_halo_routed_flush(e, nccl_comm, p, w, nullptr)) return rc;  // (a submitted scan comes first)
+  RoutedSlot& s = w->slot[w->seq++ & 1u];
+  if (int rc = routed_front(e, nccl_comm, p, route, w, s, n, d_x, d_y, d_z, d_intensity, T_base_sensor, T_world_base, sensors))
     return rc;
-  // 5. the owners integrate: the logical scan as one, or — N sensors — every source with its own transforms, in rank order
-  const int has_i = d_intensity ? 1 : 0;
-  if (!sensors) {
-    if (int rc = fdm_engine_integrate_points4_device(e, n_recv, w->d_recv, has_i, any_in_map, T_base_sensor, T_world_base))
-      return fail(rc, std::string("fdm_engine_integrate_points4_device: ") + fdm_last_error());
-    return FDM_OK;
-  }
-  uint64_t off = 0;
-  for (int src = 0; src < W; ++src) {
-    const uint64_t ns = w->h_matrix[size_t(src) * per + size_t(me)];
-    const bool seen = w->h_matrix[size_t(src) * per + size_t(W) + 1] > 0;  // that scan observed a cell somewhere
-    if (ns || (seen && w->obstacle_dirty)) {  // (else: nothing for this tile and its obstacle layer is clear already)
-      double T[32];
-      std::memcpy(T, w->h_table + size_t(src) * row + per, sizeof(T));
-      if (int rc = fdm_engine_integrate_points4_device(e, ns, ns ? w->d_recv + 4 * off : w->d_recv, has_i, seen ? 1 : 0, T, T + 16))
-        return fail(rc, std::string("fdm_engine_integrate_points4_device: ") + fdm_last_error());
-      w->obstacle_dirty = ns > 0;
-    }
-    off += ns;
+  return routed_back(e, nccl_comm, p, w, s, h_matrix_out);
+}
+
+int fdm_halo_routed_submit(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p, const fdm_route_plan* route,
+                           fdm_routed_ws* w, uint64_t n, const float* d_x, const float* d_y, const float* d_z,
+                           const float* d_intensity, const double T_base_sensor[16], const double T_world_base[16],
+                           int32_t sensors, uint32_t* h_matrix_prev) {
+  if (int rc = routed_check(e, nccl_comm, p, route, w, n, T_base_sensor, T_world_base)) return rc;
+  RoutedSlot& s = w->slot[w->seq & 1u];
+  RoutedSlot& prev = w->slot[(w->seq & 1u) ^ 1u];
+  ++w->seq;
+  if (s.pending) return fail(FDM_ERR_INVALID, "internal: routed slot still pending");
+  // the front of this scan first: its kernels and its table copy run while the host is busy with the previous scan ...
+  if (int rc = routed_front(e, nccl_comm, p, route, w, s, n, d_x, d_y, d_z, d_intensity, T_base_sensor, T_world_base, sensors))
+    return rc;
+  // ... whose table arrived during the previous call: exchange + integrate are enqueued behind this scan's front
+  if (prev.pending) return routed_back(e, nccl_comm, p, w, prev, h_matrix_prev);
+  return FDM_OK;
+}
+
+int fdm_halo_routed_flush(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p, fdm_routed_ws* w, uint32_t* h_matrix_out) {
+  if (!e || !p || !w) return fail(FDM_ERR_INVALID, "null argument");
+  // (oldest first: with submit() at most one slot is pending)
+  for (unsigned k = 0; k < 2u; ++k) {
+    RoutedSlot& s = w->slot[(w->seq + k) & 1u];
+    if (s.pending)
+      if (int rc = routed_back(e, nccl_comm, p, w, s, h_matrix_out)) return rc;
   }
   return FDM_OK;
 }

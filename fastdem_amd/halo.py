@@ -52,6 +52,8 @@ def load():
     lib.fdm_halo_routed_ws_destroy.restype = None
     lib.fdm_halo_routed_step.argtypes = [P, P, C.POINTER(FdmTilePlan), C.POINTER(capi.FdmRoutePlan), P, C.c_uint64,
                                          P, P, P, P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, P]
+    lib.fdm_halo_routed_submit.argtypes = lib.fdm_halo_routed_step.argtypes
+    lib.fdm_halo_routed_flush.argtypes = [P, P, C.POINTER(FdmTilePlan), P, P]
     _lib = lib
     return lib
 
@@ -125,11 +127,15 @@ class NativeRoutedScan:
         except Exception:
             pass
 
-    def integrate(self, x, y, z, T_base_sensor, T_world_base, intensity=None, sensors=False):
-        """x, y, z[, intensity]: this rank's part of the step (torch device tensors).  Returns the counter matrix."""
+    def integrate(self, x, y, z, T_base_sensor, T_world_base, intensity=None, sensors=False, pipelined=False):
+        """x, y, z[, intensity]: this rank's part of the step (torch device tensors).  Returns the counter matrix of the
+        scan the call integrated — with `pipelined` that is the PREVIOUS scan (fdm_halo_routed_submit: this scan is
+        routed now and integrated by the next call or by flush()); the tensors may be reused once the routing kernels
+        have run (the engine's stream)."""
         self.eng.wait_torch()
         n = int(x.numel())
-        rc = self.lib.fdm_halo_routed_step(
+        fn = self.lib.fdm_halo_routed_submit if pipelined else self.lib.fdm_halo_routed_step
+        rc = fn(
             self.eng._h, self.comm, C.byref(self.plan), C.byref(self.route), self.ws, n,
             C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(z.data_ptr()),
             C.c_void_p(intensity.data_ptr()) if intensity is not None else None,
@@ -137,4 +143,12 @@ class NativeRoutedScan:
             self.matrix.ctypes.data_as(C.c_void_p))
         if rc != 0:
             raise RuntimeError(f"fdm_halo_routed_step: {rc} {self.lib.fdm_halo_last_error().decode()}")
+        return self.matrix.astype(np.int64)
+
+    def flush(self):
+        """Integrate the scan a pipelined call left pending (no-op otherwise)."""
+        rc = self.lib.fdm_halo_routed_flush(self.eng._h, self.comm, C.byref(self.plan), self.ws,
+                                            self.matrix.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise RuntimeError(f"fdm_halo_routed_flush: {rc} {self.lib.fdm_halo_last_error().decode()}")
         return self.matrix.astype(np.int64)

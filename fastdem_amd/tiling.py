@@ -420,6 +420,7 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
         n_pts = wl.n_points
         router = RoutedScan(eng, plan, dev, max_points=n_pts)
         native = None
+        pipelined = int(getattr(args, "native_routed", 1)) == 2 and world == 1  # (with halo rings to refresh per step: not pipelined)
         if int(getattr(args, "native_routed", 1)):  # the routed step as ONE C call (libfdm_halo: fdm_halo_routed_step)
             from . import halo as halo_c
             comm = halo_c.make_comm(rank, world, dist)
@@ -435,7 +436,7 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
             d = mine[k % len(mine)]
             if native is not None:
                 router.matrix = native.integrate(d["x"], d["y"], d["z"], wl.T_base_sensor, pose(k), intensity=d["intensity"],
-                                                 sensors=True)
+                                                 sensors=True, pipelined=pipelined)
             else:
                 router.integrate(d["x"], d["y"], d["z"], wl.T_base_sensor, pose(k), dist, intensity=d["intensity"],
                                  sensors=True)
@@ -458,6 +459,8 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
         for _ in range(steps):
             pts += step(k)
             k += 1
+        if native is not None:
+            native.flush()
         eng.sync()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -489,7 +492,8 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
                                   "2 M-point scan to the owners of the cells (16 B point records, point-to-point over RCCL), the "
                                   "owners integrate source by source, p2p halo exchange per step",
                    "inputs": "SoA float32 (x, y, z, intensity) resident in HBM on every rank",
-                   "routed_step": "one C call per step (fdm_halo_routed_step)" if native is not None else "Python loop (tiling.RoutedScan)"},
+                   "routed_step": ("one C call per step, pipelined over consecutive scans (fdm_halo_routed_submit)" if pipelined else
+                                   "one C call per step (fdm_halo_routed_step)") if native is not None else "Python loop (tiling.RoutedScan)"},
         "rank0_last_scan": st,
         "rank0_routing_matrix_last_step": routed.tolist() if routed is not None else None,
     }

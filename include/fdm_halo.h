@@ -98,6 +98,17 @@ int fdm_halo_routed_step(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* pl
                          fdm_routed_ws* ws, uint64_t n, const float* d_x, const float* d_y, const float* d_z,
                          const float* d_intensity, const double T_base_sensor[16], const double T_world_base[16],
                          int32_t sensors, uint32_t* h_matrix_out);
+/* The same step, software-pipelined over consecutive scans: submit() routes scan k+1 and enqueues the copy of its
+ * table, THEN exchanges and integrates scan k (whose table arrived meanwhile) — the device works on scan k's points while
+ * the host waits for scan k+1's table.  Scans are integrated in submission order, one call late; flush() integrates
+ * the last one (fdm_halo_routed_step flushes first).  h_matrix_prev / h_matrix_out: the counter matrix of the scan
+ * that was integrated by the call (nullable).  The caller's arrays of scan k+1 are read by submit(k+1)'s kernels only. */
+int fdm_halo_routed_submit(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* plan, const fdm_route_plan* route,
+                           fdm_routed_ws* ws, uint64_t n, const float* d_x, const float* d_y, const float* d_z,
+                           const float* d_intensity, const double T_base_sensor[16], const double T_world_base[16],
+                           int32_t sensors, uint32_t* h_matrix_prev);
+int fdm_halo_routed_flush(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* plan, fdm_routed_ws* ws,
+                          uint32_t* h_matrix_out);
 
 const char* fdm_halo_last_error(void);
 

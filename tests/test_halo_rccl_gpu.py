@@ -171,3 +171,35 @@ def test_routed_step_as_one_c_call(rccl, sensors):
             assert np.array_equal(e.layer(name).view(np.uint32), ref.layer(name).view(np.uint32)), name
     for r in routed:
         r.close()
+
+
+def test_routed_step_pipelined_over_consecutive_scans(rccl):
+    """fdm_halo_routed_submit: scan k+1 is routed before scan k is exchanged and integrated; after flush() the map equals
+    the plain engine's, and the matrix a call returns is the previous scan's."""
+    import torch
+    import fastdem_amd as fa
+    from fastdem_amd import halo as H
+    _, comm = rccl
+    ref = fa.Engine(40.0, 40.0, 0.1, global_cfg(fa))
+    eng = fa.Engine(40.0, 40.0, 0.1, global_cfg(fa))
+    r = H.NativeRoutedScan(eng, 0, 1, 400, 400, 6, 200000, comm=comm)
+    rng = np.random.default_rng(8)
+    stats, keep = [], []
+    for k in range(6):
+        n = 120000 if k % 2 == 0 else 3000
+        s = cloud(rng, n, 25.0)
+        T = np.eye(4)
+        T[:3, 3] = (0.2 * k, -0.1 * k, 0.4)
+        d = {c: torch.from_numpy(s[c]).cuda() for c in s}
+        keep.append(d)
+        rc, st = ref.integrate(s["x"], s["y"], s["z"], np.eye(4), T, intensity=s["intensity"])
+        stats.append(st)
+        m = r.integrate(d["x"], d["y"], d["z"], np.eye(4), T, intensity=d["intensity"], sensors=(k >= 3), pipelined=True)
+        if k:
+            assert (m[0, 0], m[0, 1]) == (stats[k - 1]["n_in_map"], stats[k - 1]["n_after_filter"])
+    m = r.flush()
+    assert (m[0, 0], m[0, 1]) == (stats[-1]["n_in_map"], stats[-1]["n_after_filter"])
+    eng.sync()
+    for name in ref.layers():
+        assert np.array_equal(eng.layer(name).view(np.uint32), ref.layer(name).view(np.uint32)), name
+    r.close()
