@@ -3,10 +3,13 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5]
 
-A "step" is ONE FastDEM::integrate() of one synthetic scan whose SoA channels are already
-resident in HBM (fdm_engine_integrate_device through the C ABI; enqueue-only, no host sync
-inside the timed region).  Default workload = BASELINE.json configs[1]: VLP-16 ~30 K-pt scan into
-a 15x15 m @ 0.1 m LOCAL map, Kalman estimator.  N>1 (launched by torch.distributed.run): LOCAL
+A "step" is ONE pass of the hot path over one batch of synthetic input whose SoA channels are already
+resident in HBM (through the C ABI; enqueue-only, no host sync inside the timed region).  For the small-scan
+workloads (c2, c3) the hot path is the batch launch — fdm_engine_integrate_device_batch bins sixteen scans per
+launch (fastdem_amd/csrc/fdm_multi.hpp) — so a step hands it SIXTEEN FastDEM::integrate() calls (config.scans_per_step);
+the large-scan workloads (c4, c5) launch once per scan and a step is one scan.  `value` is points per second either
+way, ms_per_step is per step; the single-scan latency path is reported beside it (latency_path).
+Default workload = BASELINE.json configs[1]: VLP-16 ~30 K-pt scan into a 15x15 m @ 0.1 m LOCAL map, Kalman estimator.  N>1 (launched by torch.distributed.run): LOCAL
 maps do not shard so every rank runs an independent replica (weak scaling, no
 data-path collective); `--workload c5` instead tiles ONE global map across the ranks with an
 RCCL halo exchange per scan (fastdem_amd/tiling.py).
@@ -38,8 +41,12 @@ LARGE_SCANS = 9
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10000)
-    ap.add_argument("--warmup", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: 625 steps of 16 scans for the small-scan workloads, 10000 scans otherwise)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--scans-per-step", type=int, default=0,
+                    help="scans one step hands to the hot path: 0 = 16 for the workloads the batch pipeline takes (c2, c3: a "
+                         "step is ONE launch over one batch of 16 scans), 1 for the large-scan workloads (one launch per scan)")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--native-routed", type=int, default=1, help="c5 routed: 1 = the step as one C call (libfdm_halo), 2 = that call pipelined over consecutive scans (one rank), 0 = the Python loop")
     ap.add_argument("--order", default="azimuth", choices=["azimuth", "ring"])
@@ -62,7 +69,13 @@ def parse():
     ap.add_argument("--collective-timeout", type=int, default=120,
                     help="seconds a collective may take before RCCL aborts it (a rank that failed leaves with a non-zero "
                          "exit code at once; its peers follow when this expires)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    small = a.workload in ("c2", "c3") and (a.scans_per_step or 16) > 1
+    if a.steps is None:
+        a.steps = 625 if small else 10000
+    if a.warmup is None:
+        a.warmup = 64 if small else 1000
+    return a
 
 
 def colmajor16(T):
@@ -423,18 +436,23 @@ def main():
 
         # host-side pose matrices for every step are built BEFORE the timed region (numpy 4x4
         # products cost more than the two kernel launches of a 30 K-point scan)
-        for kk in range(args.warmup + args.steps + args.profile_steps + 8):
+        # A STEP = one pass of the hot path over one batch of synthetic input.  For the small-scan workloads the hot
+        # path is the batch launch (fdm_multi.hpp: k_mbatch over 16 scans), so a step hands it 16 scans; the large-scan
+        # workloads launch once per scan.  `value` is points per second either way; ms_per_step is per STEP.
+        sps = args.scans_per_step or (16 if args.workload in ("c2", "c3") else 1)
+        n_timed, n_warm = args.steps * sps, args.warmup * sps
+        for kk in range(n_warm + n_timed + args.profile_steps + 8):
             res.pose(kk)
         k = 0
-        if args.warmup > 0:  # the warm-up steps take the timed region's own entry point (its first call is not free)
-            wbatch, _ = res.batch(k, args.warmup)
+        if n_warm > 0:  # the warm-up steps take the timed region's own entry point (its first call is not free)
+            wbatch, _ = res.batch(k, n_warm)
             if res.eng.integrate_device_batch_timed(wbatch) != 0:
                 raise RuntimeError("integrate_device_batch (warm-up) failed")
-            k += args.warmup
+            k += n_warm
         # the K timed steps leave as ONE call across the language boundary (fdm_engine_integrate_device_batch:
         # K x fdm_engine_integrate_device in C++): with a Python / ctypes call per 6 us scan the timed region
         # would measure the interpreter, not the engine
-        batch, pts = res.batch(k, args.steps)
+        batch, pts = res.batch(k, n_timed)
         barrier()
         t0 = time.perf_counter()
         # K scans + the last scan's held-back update between two HIP events on the engine's stream, ONE call
@@ -443,10 +461,10 @@ def main():
         dt = time.perf_counter() - t0
         if rc != 0:
             raise RuntimeError(f"integrate_device_batch failed: {rc}")
-        k += args.steps
+        k += n_timed
         # scans per launch of the timed region: 16 when the batch pipeline took it (fdm_multi.hpp), 1 otherwise
         batch_scans = max(1, res.eng.last_batch())
-        timed_launch_us = res.eng.timer_ms() / args.steps * 1e3  # HIP events on the engine's stream
+        timed_launch_us = res.eng.timer_ms() / n_timed * 1e3  # per SCAN: HIP events on the engine's stream
         if world > 1:
             dist.barrier()
             t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -461,14 +479,16 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             # the same K steps by the GPU's own clock (HIP events on the engine's stream around the region);
             # `value` is the host wall clock incl. the final sync — for very short regions it is launch-bound
-            "device_value": pts / (timed_launch_us * args.steps * 1e-6) / 1e6,
+            "device_value": pts / (timed_launch_us * n_timed * 1e-6) / 1e6,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl.name, "points_per_scan": wl.n_points,
                        "map_cells": res.eng.rows * res.eng.cols, "point_order": args.order,
                        "parallelism": "replicas only (LOCAL map does not shard)" if world > 1 else "1 gpu",
                        "inputs": "SoA float32 resident in HBM", "wave_merge": args.wave_merge,
-                       "distinct_scans": len(wl.scans), "scans_per_launch": batch_scans},
+                       "distinct_scans": len(wl.scans), "scans_per_launch": batch_scans, "scans_per_step": sps,
+                       "step": (f"one launch of the batch pipeline over {sps} scans (fdm_engine_integrate_device_batch)"
+                                if sps > 1 else "one scan")},
         }
         if rank == 0:
             kern, roof = measure_kernels(res, k, args.profile_steps, args.workload, args.overlap)
@@ -487,9 +507,9 @@ def main():
                 # The timed region was the BATCH pipeline: back-to-back k_mbatch launches, each the bin of 16 scans, the
                 # map update of the previous 16 and the crop pass of the next 16.  Algorithmic bytes per launch = 16 x the
                 # per-scan figure; duration = HIP events around the region / launches (gaps between launches included).
-                launches = -(-args.steps // batch_scans)
-                launch_us = timed_launch_us * args.steps / launches
-                alg = kern["k_update_bin"]["alg_bytes"] * args.steps / launches
+                launches = -(-n_timed // batch_scans)
+                launch_us = timed_launch_us * n_timed / launches
+                alg = kern["k_update_bin"]["alg_bytes"] * n_timed / launches
                 gbps = alg / (launch_us * 1e-6) / 1e9
                 kern["k_mbatch"] = {"ms": launch_us * 1e-3, "alg_bytes": alg, "GBps": gbps, "scans_per_launch": batch_scans,
                                     "launches": launches}
