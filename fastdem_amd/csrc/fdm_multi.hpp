@@ -405,12 +405,14 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
         const unsigned tot = atomicAdd(&ms->done[k * kLineWords], mine) + mine;
         if ((tot & 0xFFFFu) == B.first_block[k + 1u] - B.first_block[k])
           atomicOr(&ms->flags[0], (1u << k) | ((tot >> 16) ? (0x10000u << k) : 0u));
+        else if (np && (tot >> 16) == 1u)  // the scan's FIRST block with a surviving point says so at once: "scan k
+          atomicOr(&ms->flags[0], 0x10000u << k);  // moves the map" is then known long before its last block is done
         if (must_wait) {  // ... and wait for the scans ahead: ONE word, ONE poller per block
           const unsigned need = (1u << k) - 1u;
           unsigned spins = 0u;
-          while (true) {
+          while (true) {  // every earlier scan either has a surviving point (pass bit) or is through its crops (done bit)
             f = __hip_atomic_load(&ms->flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((f & need) == need) break;
+            if (((f | (f >> 16)) & need) == need) break;
             if (++spins >= kSpinMax) {
               ms->err = 1u;
               break;
