@@ -138,6 +138,7 @@ int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slo
     V.rec = e->vs_rec;
     V.cap = unsigned(e->vs_rec_cap);
     V.ibits = 1u;
+    V.dbg = (e->dbg_ray >> 8) & 3;
     while ((1u << V.ibits) < n) ++V.ibits;
     const unsigned blocks = (n + 255u) / 256u;
     hipLaunchKernelGGL(k_vs_count, dim3(blocks), dim3(256), 0, e->stream, n, inv, flag_slot, C, V, e->d_state, dx, dy,

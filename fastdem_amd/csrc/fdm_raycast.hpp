@@ -221,6 +221,7 @@ struct VoxelSmall {
   uint4* rec;              // [cap] by position: key | point | bucket start | bucket size
   unsigned cap;            // entries of rec (reads beyond the scan's positions stay inside the allocation)
   unsigned ibits;          // bits of a point index
+  int dbg;                 // measurement only (wrong results): 1 = no fine atomics, 2 = no coarse atomics, 3 = neither
 };
 
 __global__ __launch_bounds__(256) void k_vs_count(unsigned n, float inv_voxel, int flag_slot, const VoxelCompact C,
@@ -260,20 +261,34 @@ __global__ __launch_bounds__(256) void k_vs_count(unsigned n, float inv_voxel, i
       todo &= ~same;
     }
     unsigned base = 0u;
-    if (valid && my_lead == int(lane)) base = atomicAdd(&V.fine[f], my_size);
+    if (valid && my_lead == int(lane) && !(V.dbg & 1)) base = atomicAdd(&V.fine[f], my_size);
     base = unsigned(__shfl(int(base), my_lead));
     if (valid) V.place[i] = base + my_rank;
   }
-  {
+  {  // coarse counters: per wavefront one add per distinct counter into a small LDS table of the block (direct-mapped;
+     // a collision goes to memory at once), per block one add per occupied entry — the ground's z levels put more than
+     // a thousand points of a sweep into ONE counter, and same-address atomics serialise at the memory side (5 of this
+     // kernel's 11 us with one add per wavefront and counter)
+    __shared__ uint32_t s_id[256], s_n[256];
+    s_id[threadIdx.x] = 0xFFFFFFFFu;
+    s_n[threadIdx.x] = 0u;
+    __syncthreads();
     const unsigned g = f >> 5;
     unsigned long long todo = __ballot(valid);
     while (todo) {
       const int lead = __ffsll((long long)todo) - 1;
       const unsigned g0 = unsigned(__builtin_amdgcn_readlane(int(g), lead));
       const unsigned long long same = __ballot(valid && g == g0);
-      if (int(lane) == lead) atomicAdd(&V.coarse[g0], unsigned(__popcll(same)));
+      if (int(lane) == lead && !(V.dbg & 2)) {
+        const unsigned slot = g0 & 255u, cnt = unsigned(__popcll(same));
+        const uint32_t prev = atomicCAS(&s_id[slot], 0xFFFFFFFFu, g0);
+        if (prev == 0xFFFFFFFFu || prev == g0) atomicAdd(&s_n[slot], cnt);
+        else atomicAdd(&V.coarse[g0], cnt);
+      }
       todo &= ~same;
     }
+    __syncthreads();
+    if (s_n[threadIdx.x]) atomicAdd(&V.coarse[s_id[threadIdx.x]], s_n[threadIdx.x]);
   }
   if (flag_slot >= 0 && __ballot(valid) && (threadIdx.x & 63) == 0) st->flags[flag_slot].ray_any = 1u;
 }
