@@ -329,14 +329,14 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
       auto shift_of = [&](unsigned j, int& dx, int& dy) {  // scan j's move against the geometry walked so far
         if ((sure_x >> j) & 1u) {
           dx = __builtin_amdgcn_readlane(tx, int(j)) - vx;
-        } else {  // GridMap::move's own arithmetic
-          const double t = (lane_f64(pose_x, j) - g.px) / G.res;
+        } else {  // GridMap::move's own arithmetic (the quotient correctly rounded: div_by_res)
+          const double t = div_by_res(lane_f64(pose_x, j) - g.px, G.res, G.inv_res);
           dx = static_cast<int>(t + 0.5 * (t > 0 ? 1 : -1));
         }
         if ((sure_y >> j) & 1u) {
           dy = __builtin_amdgcn_readlane(ty, int(j)) - vy;
         } else {
-          const double t = (lane_f64(pose_y, j) - g.py) / G.res;
+          const double t = div_by_res(lane_f64(pose_y, j) - g.py, G.res, G.inv_res);
           dy = static_cast<int>(t + 0.5 * (t > 0 ? 1 : -1));
         }
       };
