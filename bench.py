@@ -40,7 +40,14 @@ LARGE_SCANS = 9
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of this node (default: WORLD_SIZE when a launcher set it, else 1).  With N > 1 and no "
+                         "launcher, bench.py starts the N ranks itself (torch.distributed.run) before it touches the GPU")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the N > 1 / c5 runs: nccl = RCCL over xGMI; gloo = host-staged (tests: "
+                         "several ranks on ONE device, which RCCL refuses)")
+    ap.add_argument("--devices", default="",
+                    help="comma-separated device of every local rank (default: local rank r -> device r); '0,0' = two ranks on device 0")
     ap.add_argument("--steps", type=int, default=None,
                     help="timed steps (default: 625 steps of 16 scans for the small-scan workloads, 10000 scans otherwise)")
     ap.add_argument("--warmup", type=int, default=None)
@@ -60,6 +67,9 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large", action="store_true")
+    ap.add_argument("--no-global-map", action="store_true",
+                    help="N > 1 on a LOCAL-map workload: skip the second object of the line (`global_map`: BASELINE configs[4], "
+                         "ONE global map tiled over the N GPUs with routed scans and a halo exchange per step)")
     ap.add_argument("--wave-merge", type=int, default=1)
     ap.add_argument("--set", action="append", default=[], help="engine option key=value (A/B switch)")
     ap.add_argument("--overlap", type=int, default=1, help="bin(t+1) || update(t) on two streams (A/B switch)")
@@ -70,6 +80,10 @@ def parse():
                     help="seconds a collective may take before RCCL aborts it (a rank that failed leaves with a non-zero "
                          "exit code at once; its peers follow when this expires)")
     a = ap.parse_args()
+    if a.gpus is None:
+        a.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
     small = a.workload in ("c2", "c3") and (a.scans_per_step or 16) > 1
     if a.steps is None:
         a.steps = 625 if small else 10000
@@ -393,17 +407,48 @@ def host_legs(res, wl, k, iters=50, stream_iters=200):
     return out
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks here — one process per GPU through
+    torch.distributed.run, rendezvous on 127.0.0.1 — BEFORE this process has touched the GPU (it never does: it only
+    waits).  Rank 0's JSON line is the children's stdout; any rank that fails makes the launcher, and this process,
+    exit non-zero."""
+    import socket
+    import subprocess
+    if under_profiler():
+        raise SystemExit("bench.py --gpus N under a profiler: launch the ranks with torch.distributed.run yourself "
+                         "(no child processes behind a profiler preload)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    device = local_rank
+    if args.devices:
+        devs = [int(d) for d in args.devices.split(",")]
+        if len(devs) < world:
+            raise SystemExit(f"bench.py: --devices names {len(devs)} devices for {world} ranks")
+        device = devs[local_rank]
     import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(device)
+    local_rank = device  # (from here on: the device this rank computes on)
     routed = args.workload == "c5" and (world > 1 or args.routed)
     if world > 1 or routed:
         # (c5 runs its collectives over RCCL also with ONE rank: the N-rank code path, a 1-rank communicator)
@@ -411,8 +456,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")  # a dead peer aborts the collective instead of hanging it
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"),
-                                timeout=datetime.timedelta(seconds=args.collective_timeout))
+        kw_pg = {"device_id": torch.device(f"cuda:{device}")} if args.backend == "nccl" else {}
+        dist.init_process_group(args.backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=args.collective_timeout), **kw_pg)
+        if args.backend == "gloo":
+            args.native_routed = 0  # (libfdm_halo's routed step talks RCCL: the host-staged Python loop instead)
     from fastdem_amd import synth
 
     if routed:
@@ -467,7 +515,7 @@ def main():
         timed_launch_us = res.eng.timer_ms() / n_timed * 1e3  # per SCAN: HIP events on the engine's stream
         if world > 1:
             dist.barrier()
-            t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+            t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         rc, st = res.eng.last_stats()
@@ -573,6 +621,15 @@ def main():
                 del big
             if world == 1 and not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(wl)
+    if world > 1 and not routed and not args.no_global_map:
+        # LOCAL maps do not shard: `value` above is N independent replicas.  The configuration in which the GPUs of a
+        # node share ONE map is BASELINE configs[4]; its line for the same N rides along, so that a 1 / 2 / 4 / 8 sweep
+        # of the default command has rows for both.
+        from fastdem_amd import tiling
+        args.stall_timeout = args.collective_timeout + 60
+        g = tiling.bench_global(args, rank, local_rank, world)
+        if rank == 0:
+            result["global_map"] = g
     if world > 1 or routed:
         dist.barrier()
         dist.destroy_process_group()

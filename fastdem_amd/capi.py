@@ -155,6 +155,7 @@ PROTOTYPES = {
     "fdm_engine_timer_stop": (C.c_int, [_P]),
     "fdm_engine_timer_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "fdm_engine_debug_batch_dirty": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "fdm_engine_debug_batch_launches": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "fdm_engine_debug_timeline": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "fdm_engine_record_event": (C.c_int, [_P, _P]),
     "fdm_engine_wait_event": (C.c_int, [_P, _P]),

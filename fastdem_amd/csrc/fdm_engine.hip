@@ -6,6 +6,7 @@
 // there is NO CPU fallback: without a HIP device fdm_engine_create fails with
 // FDM_ERR_NO_DEVICE.
 #include "../../include/fdm_engine.h"
+#include "../../include/fdm_engine_debug.h"
 
 #include <hip/hip_runtime.h>
 
@@ -27,6 +28,7 @@
 #include "fdm_kernels.hpp"
 #include "fdm_tiled.hpp"
 #include "fdm_multi.hpp"
+#include "fdm_tbatch.hpp"
 #include "fdm_route.hpp"
 #include "fdm_raycast.hpp"
 #include "fdm_rsort.hpp"
@@ -170,6 +172,9 @@ struct fdm_engine {
     bool multi = false;     // a whole batch (fdm_multi.hpp): MU / ch are what matters
     MUpd MU;
     int ch = 0;
+    bool tb = false;        // a tile batch (fdm_tbatch.hpp): TU / tb_hi / tb_hc are what matters
+    TBUpd TU;
+    bool tb_hi = false, tb_hc = false;
     bool tiled = false;     // large-scan pipeline (fdm_tiled.hpp) or the per-cell scratch one
     ScanParams P;
     Scratch S;              // scratch pipeline: the key / aux set of the scan's parity, captures
@@ -211,6 +216,8 @@ struct fdm_engine {
   MState* mstate = nullptr;          // [kMStates] ring, slot = batch number % kMStates
   unsigned mseq = 0;                 // batches enqueued so far
   int last_batch_n = 0;              // scans of the batch launch the last scan left in (0: it took the single-scan path)
+  uint64_t n_mbatch = 0, n_tbatch = 0;  // batch launches since creation (fdm_engine_debug_batch_launches)
+  bool fault_watch = false;          // a launch with an in-kernel bounded wait was enqueued since DevState::fault was last read
   int dbg_batch = 0;                 // measurement only (option "dbg_batch")
   int batch_crop = 1;                // option "batch_crop": evaluate the next batch's crops one launch ahead
   bool pre_valid = false;            // the last launch carried the crop pass of the batch (pre_scans, pre_count) = number pre_seq
@@ -218,6 +225,18 @@ struct fdm_engine {
   uint32_t pre_count = 0;
   unsigned pre_seq = 0;
   const unsigned long long* last_bin_part = nullptr;  // per-block statistics of the last scan (either pipeline)
+  // ---- tile batches (fdm_tbatch.hpp): up to tbatch_max LARGE scans per launch on the record pools ----
+  int tbatch = 1;                    // option "tbatch": fdm_engine_integrate_device_batch groups eligible large scans
+  int tbatch_max = 4;                // option "tbatch_max": scans per launch (2 .. kTBMax)
+  unsigned tbatch_min = 65536;       // option "tbatch_min": scans from this many points up
+  int tb_groups = 512;               // option "tb_groups": update groups of a launch (each pulls tiles off a queue)
+  TileRec* tb_rec[2] = {nullptr, nullptr};              // [tb_slots][tb_rec_stride] per batch parity
+  unsigned long long* tb_desc[2] = {nullptr, nullptr};  // [tb_slots][n_tiles][tb_stride]
+  unsigned long long* tb_bin_part[2] = {nullptr, nullptr};
+  size_t tb_rec_stride = 0;          // records per scan slot
+  unsigned tb_stride = 0;            // words per descriptor row
+  int tb_slots = 0;                  // scan slots the pools hold
+  size_t tb_bin_cap = 0;             // bin blocks per batch the statistics arrays hold
   // scan routing (fdm_route.hpp)
   uint8_t* d_route_owner = nullptr;  // [route_cap] owner rank of every point of the slice
   uint32_t* d_route_cnt = nullptr;   // [route_blocks_cap][world + 2] block counts -> offsets | [kMaxRanks] bases at the end
@@ -265,6 +284,18 @@ int sync_all(fdm_engine* e) {
   if (int rc = join_streams(e)) return rc;
   HIPCK(hipStreamSynchronize(e->stream));
   return FDM_OK;
+}
+// DevState::fault after the stream has drained: a batch launch whose in-kernel wait for the scans ahead ran out of
+// polls (fdm_multi.hpp / fdm_tbatch.hpp).  Sticky on the device until it has been reported ONCE — the maps of that
+// batch are undefined, reset() and go on.  Only looked at when such a launch was enqueued since the last look.
+int report_fault(fdm_engine* e) {
+  if (!e->fault_watch) return FDM_OK;
+  e->fault_watch = false;
+  unsigned f = 0u;
+  HIPCK(hipMemcpy(&f, &e->d_state->fault, sizeof(f), hipMemcpyDeviceToHost));
+  if (!f) return FDM_OK;
+  HIPCK(hipMemset(&e->d_state->fault, 0, sizeof(f)));
+  return fail(FDM_ERR_HIP, "device-side fault: a batch's geometry-chain wait ran out of polls (the batch's map update is undefined)");
 }
 
 Layer* find_layer(fdm_engine* e, const char* name) {
@@ -680,7 +711,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   const bool fusable = tiled || ((!use_bin4 || (e->rec_kind >= 0 && e->S.dense)) && e->wave_merge);
   // (the fused tiled launch compiles the channels in once, for both halves)
   const bool same_channels = !tiled || (e->pend.P.has_intensity == P.has_intensity && e->pend.P.has_color == P.has_color);
-  const bool fuse_now = e->chain && plain && fusable && !e->pend.multi && e->pend.tiled == tiled && same_channels;
+  const bool fuse_now = e->chain && plain && fusable && !e->pend.multi && !e->pend.tb && e->pend.tiled == tiled && same_channels;
   if (e->chain && !fuse_now && (rc = join_streams(e))) return rc;
   P.chain_prev = 0;
   if (e->profile) HIPCK(hipEventRecord(e->ev[0], e->stream));
@@ -727,6 +758,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   // this scan's update: held back (the next scan's launch or a flush carries it) or launched now
   fdm_engine::PendingUpdate& u = e->pend;
   u.multi = false;
+  u.tb = false;
   u.tiled = tiled;
   u.P = P;
   u.S = e->S;
@@ -832,6 +864,7 @@ void fill_update_params(fdm_engine* e, ScanParams& P, double rx, double ry, bool
 }
 
 #include "fdm_engine_multi.inl"  // the batch pipeline's host side: eligibility, buffers, enqueue_multi
+#include "fdm_engine_tbatch.inl" // the tile-batch pipeline's host side (large scans): eligibility, pools, enqueue_tbatch
 
 // Staging for host-array entry points: kStageSlots rotating blocks of 6 channels.  A block is reused
 // three scans later, when the update that gathers from it (held back by at most one scan) has long
@@ -958,7 +991,11 @@ int read_stats(fdm_engine* e, fdm_scan_stats* out, int* status) {
       HIPCK(hipGetLastError());
     }
   }
-  if (e->h_stats->fault) return fail(FDM_ERR_HIP, "device-side fault: a batch's geometry-chain wait ran out of polls");
+  if (e->h_stats->fault) {
+    e->fault_watch = false;
+    HIPCK(hipMemset(&e->d_state->fault, 0, sizeof(unsigned)));  // (reported once)
+    return fail(FDM_ERR_HIP, "device-side fault: a batch's geometry-chain wait ran out of polls (the batch's map update is undefined)");
+  }
   const uint64_t np = e->h_stats->n_pass, ni = e->h_stats->n_in, nt = e->h_stats->n_touched;
   if (e->ingest_blocks) {  // PointCloud2 scan: cloud.size() is the number of finite points (from_impl)
     e->last_n_input = uint32_t(e->h_stats->n_finite);
@@ -1209,6 +1246,11 @@ void fdm_engine_destroy(fdm_engine* e) {
   }
   if (e->mstate) (void)hipFree(e->mstate);
   if (e->mupd_part) (void)hipFree(e->mupd_part);
+  for (int k = 0; k < 2; ++k) {
+    if (e->tb_rec[k]) (void)hipFree(e->tb_rec[k]);
+    if (e->tb_desc[k]) (void)hipFree(e->tb_desc[k]);
+    if (e->tb_bin_part[k]) (void)hipFree(e->tb_bin_part[k]);
+  }
   if (e->d_route_owner) (void)hipFree(e->d_route_owner);
   if (e->d_route_cnt) (void)hipFree(e->d_route_cnt);
   if (e->tile_stamp32) (void)hipFree(e->tile_stamp32);
@@ -1303,6 +1345,13 @@ int fdm_engine_integrate_device(fdm_engine* e, uint64_t n, const float* dx, cons
 int fdm_engine_integrate_device_batch(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) {
   if (!e || (count && !scans)) return fail(FDM_ERR_INVALID, "null argument");
   for (uint32_t k = 0; k < count; ++k) {
+    // runs of LARGE plain scans leave as tile batches (fdm_tbatch.hpp): one launch per tbatch_max scans
+    if (const uint32_t run = tbatch_run(e, count - k, scans + k)) {
+      HIPCK(hipSetDevice(e->device));
+      if (int rc = enqueue_tbatch(e, run, scans + k)) return rc;
+      k += run - 1u;
+      continue;
+    }
     // runs of small plain scans leave as batches: one bin launch + one update launch per kMaxBatch scans
     if (const uint32_t run = multi_run(e, count - k, scans + k)) {
       HIPCK(hipSetDevice(e->device));
@@ -1386,12 +1435,14 @@ int fdm_engine_route_scan(fdm_engine* e, const fdm_route_plan* plan, uint64_t n,
   for (int k = 0; k <= kMaxRanks; ++k) { R.row_edge[k] = plan->row_edge[k]; R.col_edge[k] = plan->col_edge[k]; }
   const unsigned cols = unsigned(R.world + 2);
   const unsigned blocks = unsigned((n + 255) / 256);
-  if (n > e->route_cap || blocks > e->route_blocks_cap) {
+  // (also on the FIRST call when its slice is empty: k_route_scan / k_route_base write the totals and the base offsets
+  // whatever n is — a null table there was a GPU memory fault that took the rank down and left its peers waiting)
+  if (!e->d_route_cnt || !e->d_route_owner || n > e->route_cap || blocks > e->route_blocks_cap) {
     if (int rc_sync = sync_all(e)) return rc_sync;
     if (e->d_route_owner) HIPCK(hipFree(e->d_route_owner));
     if (e->d_route_cnt) HIPCK(hipFree(e->d_route_cnt));
     e->d_route_owner = nullptr; e->d_route_cnt = nullptr;
-    e->route_cap = size_t(n) + size_t(n) / 4 + 1024;
+    e->route_cap = std::max<size_t>(e->route_cap, size_t(n) + size_t(n) / 4 + 1024);
     e->route_blocks_cap = (e->route_cap + 255) / 256;
     HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_route_owner), e->route_cap));
     HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_route_cnt),
@@ -1621,7 +1672,7 @@ int fdm_engine_timer_ms(fdm_engine* e, float* ms) {
   if (!e || !ms) return fail(FDM_ERR_INVALID, "null argument");
   if (int rc = sync_all(e)) return rc;
   HIPCK(hipEventElapsedTime(ms, e->ev_timer[0], e->ev_timer[1]));
-  return FDM_OK;
+  return report_fault(e);  // (the timed work has run: a batch whose chain wait gave up must not pass as a measurement)
 }
 
 int fdm_engine_debug_timeline(fdm_engine* e, uint64_t* ticks, uint64_t cap_blocks, uint32_t* n_blocks,
@@ -1662,6 +1713,13 @@ int fdm_engine_debug_batch_dirty(fdm_engine* e, uint64_t out[3]) {
   return FDM_OK;
 }
 
+int fdm_engine_debug_batch_launches(fdm_engine* e, uint64_t out[2]) {
+  if (!e || !out) return fail(FDM_ERR_INVALID, "null argument");
+  out[0] = e->n_mbatch;
+  out[1] = e->n_tbatch;
+  return FDM_OK;
+}
+
 int fdm_engine_record_event(fdm_engine* e, void* hip_event) {
   if (!e || !hip_event) return fail(FDM_ERR_INVALID, "null argument");
   if (int rc = join_streams(e)) return rc;  // the map is current behind this event
@@ -1679,7 +1737,7 @@ int fdm_engine_sync(fdm_engine* e) {
   if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e) return fail(FDM_ERR_INVALID, "null engine");
   if (int rc_sync = sync_all(e)) return rc_sync;
-  return FDM_OK;
+  return report_fault(e);
 }
 
 int fdm_engine_last_stats(fdm_engine* e, fdm_scan_stats* out) {
@@ -2052,6 +2110,25 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
   if (std::strcmp(key, "batch_max") == 0) {
     if (value < 2 || value > kMaxBatch) return fail(FDM_ERR_INVALID, "batch_max: 2 .. 16 scans per launch");
     e->batch_max = value;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "tbatch") == 0) {  // fdm_engine_integrate_device_batch: group LARGE scans into tile-batch launches
+    e->tbatch = value != 0;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "tbatch_max") == 0) {
+    if (value < 2 || value > kTBMax) return fail(FDM_ERR_INVALID, "tbatch_max: 2 .. 8 scans per launch");
+    e->tbatch_max = value;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "tbatch_min") == 0) {
+    if (value < 1) return fail(FDM_ERR_INVALID, "tbatch_min: a point count");
+    e->tbatch_min = unsigned(value);
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "tb_groups") == 0) {
+    if (value < 1 || value > 65535) return fail(FDM_ERR_INVALID, "tb_groups: 1 .. 65535 update groups");
+    e->tb_groups = value;
     return FDM_OK;
   }
   if (std::strcmp(key, "zero_copy") == 0) {

@@ -84,7 +84,9 @@ unsigned tile_span(const fdm_engine* e) {
 }
 
 // The record pools of the tiled pipeline: `records` per pool, `blocks` chunk slots per tile.
-int ensure_tile_pool(fdm_engine* e, size_t records, unsigned blocks, bool has_int, bool has_col) {
+// What the tile groups keep between scans (stamps, statistics, rare-path scratch): shared by the one-scan launches and
+// the tile batches.
+int ensure_tile_aux(fdm_engine* e) {
   if (!e->tile_stamp32) {
     e->TG.tiles_r = (e->G.s_rows + kTS - 1) / kTS;
     e->TG.tiles_c = (e->G.s_cols + kTC - 1) / kTC;
@@ -102,6 +104,11 @@ int ensure_tile_pool(fdm_engine* e, size_t records, unsigned blocks, bool has_in
     HIPCK(hipMalloc(reinterpret_cast<void**>(&e->tile_rare), groups * 3u * kTileCells * sizeof(uint32_t)));
     for (auto& q : e->pool) q.rare = e->tile_rare;
   }
+  return FDM_OK;
+}
+
+int ensure_tile_pool(fdm_engine* e, size_t records, unsigned blocks, bool has_int, bool has_col) {
+  if (int rc_aux = ensure_tile_aux(e)) return rc_aux;
   const bool grow_rec = records > e->pool_cap;
   (void)has_int; (void)has_col;
   const bool grow_desc = blocks + 1u > e->desc_stride;
@@ -153,7 +160,9 @@ int launch_tbin(fdm_engine* e, const ScanParams& P, const ScanInputs& in, const 
 
 // The held-back (or just enqueued) update on its own.
 int launch_multi_update(fdm_engine* e, const fdm_engine::PendingUpdate& u);  // a whole batch (fdm_engine_multi.inl)
+int launch_tbatch_update(fdm_engine* e, const fdm_engine::PendingUpdate& u); // a tile batch (fdm_engine_tbatch.inl)
 int launch_update_alone(fdm_engine* e, const fdm_engine::PendingUpdate& u) {
+  if (u.tb) return launch_tbatch_update(e, u);
   if (u.multi) return launch_multi_update(e, u);
   return with_policy(e, [&](auto tag, const auto& layers) -> int {
     using POLICY = decltype(tag);

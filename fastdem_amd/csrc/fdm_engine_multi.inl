@@ -38,22 +38,48 @@ uint32_t multi_run(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) 
   return run >= 2u ? run : 0u;
 }
 
+// The ring of batch states, shared by the small-scan batches (k_mbatch) and the tile batches (k_tbatch): both number
+// their batches with e->mseq and re-arm the state of the batch after next the same way.
+int ensure_mstate(fdm_engine* e) {
+  if (e->mstate) return FDM_OK;
+  HIPCK(hipMalloc(reinterpret_cast<void**>(&e->mstate), kMStates * sizeof(MState)));
+  HIPCK(hipMemsetAsync(e->mstate, 0, kMStates * sizeof(MState), e->stream));
+  return FDM_OK;
+}
+
 int ensure_multi(fdm_engine* e, size_t max_n, size_t blocks) {
   const size_t slots = size_t(kMaxBatch) * e->ncell;
-  if (!e->mkey[0]) {
+  if (int rc = ensure_mstate(e)) return rc;
+  if (!e->mkey[0] || !e->mupd_part) {  // (all or nothing: a partial set after a failed hipMalloc is given back)
+    auto release = [&]() {
+      for (int k = 0; k < 2; ++k) {
+        if (e->mkey[k]) (void)hipFree(e->mkey[k]);
+        if (e->maux[k]) (void)hipFree(e->maux[k]);
+        if (e->mzs[k]) (void)hipFree(e->mzs[k]);
+        e->mkey[k] = nullptr; e->maux[k] = nullptr; e->mzs[k] = nullptr;
+      }
+      if (e->mupd_part) (void)hipFree(e->mupd_part);
+      e->mupd_part = nullptr;
+    };
+    release();
+    auto alloc = [&](auto*& ptr, size_t bytes) { return hipMalloc(reinterpret_cast<void**>(&ptr), bytes) == hipSuccess; };
+    bool ok = true;
+    for (int k = 0; k < 2 && ok; ++k)
+      ok = alloc(e->mkey[k], slots * sizeof(unsigned long long)) && alloc(e->maux[k], slots * sizeof(uint4)) &&
+           alloc(e->mzs[k], slots * sizeof(uint2));
+    ok = ok && alloc(e->mupd_part, ((e->ncell + kUpdCells - 1u) / kUpdCells) * sizeof(uint32_t));
+    if (!ok) {
+      (void)hipGetLastError();
+      release();
+      return fail(FDM_ERR_HIP, "batch pipeline: out of device memory for the per-scan scratch sets");
+    }
     for (int k = 0; k < 2; ++k) {
-      HIPCK(hipMalloc(reinterpret_cast<void**>(&e->mkey[k]), slots * sizeof(unsigned long long)));
-      HIPCK(hipMalloc(reinterpret_cast<void**>(&e->maux[k]), slots * sizeof(uint4)));
-      HIPCK(hipMalloc(reinterpret_cast<void**>(&e->mzs[k]), slots * sizeof(uint2)));
       const int blocks_f = int(std::min<size_t>((slots + 255) / 256, 4096));
       hipLaunchKernelGGL(k_fill_u64, dim3(blocks_f), dim3(256), 0, e->stream, e->mkey[k], kEmptyKey, slots);
       hipLaunchKernelGGL(k_fill_aux, dim3(blocks_f), dim3(256), 0, e->stream, e->maux[k], slots);
       HIPCK(hipGetLastError());
       HIPCK(hipMemsetAsync(e->mzs[k], 0xFF, slots * sizeof(uint2), e->stream));
     }
-    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->mupd_part), ((e->ncell + kUpdCells - 1u) / kUpdCells) * sizeof(uint32_t)));
-    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->mstate), kMStates * sizeof(MState)));
-    HIPCK(hipMemsetAsync(e->mstate, 0, kMStates * sizeof(MState), e->stream));
   }
   if (max_n > e->mobs_stride) {
     if (int rc_sync = sync_all(e)) return rc_sync;  // (a held-back batch update reads the old arrays)
@@ -240,6 +266,7 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
   N.key = B.key; N.aux = B.aux; N.zs = B.zs; N.obs = B.obs; N.cobs = B.cobs;
   N.upd_part = e->mupd_part;
   e->pend.multi = true;
+  e->pend.tb = false;
   e->pend.ch = ch;
   e->pend.tiled = false;
   e->chain = true;
@@ -256,6 +283,8 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
   e->ray_timed = false;
   e->scan_no += count;
   e->last_batch_n = int(count);
+  e->fault_watch = true;
+  ++e->n_mbatch;
   e->have_scan = true;
   e->last_n = uint32_t(l.n);
   e->last_n_input = uint32_t(l.n);

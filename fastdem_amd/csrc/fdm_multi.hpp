@@ -66,7 +66,9 @@ struct MState {
   unsigned flags[kLineWords];  // [0]: bit k = every block of scan k is past the crops, bit 16 + k = scan k has a surviving point
   unsigned inside[kMaxBatch];  // some point of scan k landed in the map (elevation_mapping.cpp:118)
   unsigned err;                // a waiting block ran out of polls
-  unsigned pad[15];
+  unsigned tq;                 // tile batches (fdm_tbatch.hpp): the update groups' tile queue ...
+  unsigned gdone;              // ... and how many of them have left (the last one commits the geometry ring)
+  unsigned pad[13];
 };
 
 struct MCommon {  // what all scans of a batch share
@@ -74,7 +76,7 @@ struct MCommon {  // what all scans of a batch share
   float sp[4];
   float Tbs[16];  // T_base_sensor (one sensor per batch: a scan with another extrinsic closes the batch)
   int sensor_type, integrate_mode, do_move, gate_on_filter, has_var, bin_table;
-  int dbg, pad;                  // measurement only: 1 = no scratch atomics, 2 = no chain walk (both: wrong results); 3 = every move by the reference's divide
+  int dbg, pad;                  // measurement only: 1 = no scratch atomics, 2 = no chain walk (both: wrong results); 3 = every move by the reference's divide; 4 = a chain wait gives up after two polls (tests: MState::err)
   unsigned long long* timeline;  // measurement only (nullable): {start, end} of every block in 100 MHz ticks
 };
 struct MScanT {   // per scan: T_world_base without its constant last row (0 0 0 1), column-major 3 x 4 | rotation of the product
@@ -413,7 +415,7 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
           while (true) {  // every earlier scan either has a surviving point (pass bit) or is through its crops (done bit)
             f = __hip_atomic_load(&ms->flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (((f | (f >> 16)) & need) == need) break;
-            if (++spins >= kSpinMax) {
+            if (++spins >= kSpinMax || (K.dbg == 4 && spins >= 2u)) {  // (dbg 4: tests provoke the fault)
               ms->err = 1u;
               break;
             }
@@ -616,7 +618,7 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
   if (bid == 0 && lt >= 64u && lt < 64u + unsigned(kMaxBatch)) {  // re-arm the state of the batch after next
     U.rearm->done[(lt - 64u) * kLineWords] = 0u;
     U.rearm->inside[lt - 64u] = 0u;
-    if (lt == 64u) U.rearm->flags[0] = 0u;
+    if (lt == 64u) { U.rearm->flags[0] = 0u; U.rearm->err = 0u; U.rearm->tq = 0u; U.rearm->gdone = 0u; }
   }
 
   unsigned nib = 0u;

@@ -141,8 +141,8 @@ __host__ __device__ constexpr unsigned tbin_lds_bytes(bool has_int, bool has_col
 // vs[] = intensity.  SIDE: also the captures, cell ids and statistics (the block's first walk only).
 // tbin_prep: the part that needs no map geometry (T_base_sensor, the crops, T_world_base, captures) — it runs while
 // thread 0 waits for the state it chains the geometry from.  tbin_points: getIndex + tile of the surviving points.
-template <bool HAS_INT, int THREADS, bool LEAN, bool SIDE>
-__device__ __forceinline__ void tbin_prep(const ScanParams& P, const Scratch& S, const unsigned bid,
+template <bool HAS_INT, int THREADS, bool LEAN, bool SIDE, class PT>
+__device__ __forceinline__ void tbin_prep(const PT& P, const Scratch& S, const unsigned bid,
                                           const float (&xin)[4], const float (&yin)[4], const float (&zin)[4],
                                           float (&xs)[4], float (&ys)[4], float (&zs)[4], bool (&pass)[4],
                                           unsigned& n_pass) {
@@ -176,8 +176,8 @@ __device__ __forceinline__ void tbin_prep(const ScanParams& P, const Scratch& S,
     n_pass += pass[j] ? 1u : 0u;
   }
 }
-template <bool HAS_INT, int THREADS, bool LEAN, bool SIDE>
-__device__ __forceinline__ void tbin_points(const ScanParams& P, const GeomConst& G, const TileGrid& TG,
+template <bool HAS_INT, int THREADS, bool LEAN, bool SIDE, class PT>
+__device__ __forceinline__ void tbin_points(const PT& P, const GeomConst& G, const TileGrid& TG,
                                             int32_t* __restrict__ cell_ids, const DevCand& cand, const unsigned bid,
                                             const float (&xs)[4], const float (&ys)[4], const bool (&pass)[4],
                                             int (&cells)[4], unsigned& n_in, bool& any_glob) {
@@ -221,10 +221,26 @@ __device__ __forceinline__ void tbin_points(const ScanParams& P, const GeomConst
   }
 }
 
-template <bool HAS_INT, bool HAS_COL, int THREADS, bool LEAN>
-__device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& G, const TileGrid& TG,
-                                          DevState* __restrict__ st, const ScanInputs& I,
-                                          const Scratch& S, const TilePool& Q,
+// Where a bin block gets the post-move geometry from and where its scan-wide flags go.  One scan per launch: the
+// DevState ring (candidate_begin / candidate_finish).  A batch of scans per launch: fdm_tbatch.hpp's chain.
+struct TbinRing {
+  const ScanParams& P;
+  DevState* st;
+  CandState cs;
+  __device__ __forceinline__ TbinRing(const ScanParams& p, DevState* s) : P(p), st(s) {}
+  __device__ __forceinline__ void begin() { candidate_begin(P, st, cs); }
+  // (n_pass: this thread's points that survived the crops — the batch hook publishes "some point passed" here)
+  __device__ __forceinline__ DevCand finish(const GeomConst& G, DevCand* s_cand, unsigned bid, unsigned /*n_pass*/) {
+    return candidate_finish(P, G, st, cs, s_cand, bid);
+  }
+  __device__ __forceinline__ void note_inside() { st->flags[P.slot].any_inside = 1u; }
+  __device__ __forceinline__ void note_pass() { st->flags[P.slot].any_pass = 1u; }
+};
+
+template <bool HAS_INT, bool HAS_COL, int THREADS, bool LEAN, class PT, class HOOK>
+__device__ __forceinline__ void tbin_body(const PT& P, const GeomConst& G, const TileGrid& TG,
+                                          HOOK& H, const ScanInputs& I,
+                                          const Scratch& S, unsigned long long* __restrict__ bin_part, const TilePool& Q,
                                           int32_t* __restrict__ cell_ids, unsigned char* lds,
                                           const unsigned bid) {
   const int dbg = LEAN ? 0 : P.dbg_no_atomics;  // measurement only: leave the kernel after a phase (results are wrong)
@@ -289,8 +305,7 @@ __device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& 
     if (HAS_COL) reinterpret_cast<uint4*>(h_last)[threadIdx.x] = zero;
   }
   if (threadIdx.x == 0) s_rare = 0u;
-  CandState cstate;
-  candidate_begin(P, st, cstate);  // (thread 0's state loads leave; the walk follows the transforms below)
+  H.begin();  // (thread 0's state loads leave; the walk follows the transforms below)
 
   // phase 1: all four points through the arithmetic — first what needs no geometry (both transforms, the crops), in
   // the shadow of thread 0's state read, then the geometry candidate (barrier), then getIndex
@@ -300,12 +315,12 @@ __device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& 
   unsigned n_pass = 0, n_in = 0;
   bool any_glob = false;
   tbin_prep<HAS_INT, THREADS, LEAN, true>(P, S, bid, xs, ys, zin, xm, ym, zs, pass, n_pass);
-  const DevCand cand = candidate_finish(P, G, st, cstate, &s_cand, bid);  // contains the __syncthreads
+  const DevCand cand = H.finish(G, &s_cand, bid, n_pass);  // contains the __syncthreads
   FDM_PHASE(0);  // table initialised, points transformed and cropped, candidate known
   tbin_points<HAS_INT, THREADS, LEAN, true>(P, G, TG, cell_ids, cand, bid, xm, ym, pass, cells, n_in, any_glob);
   FDM_PHASE(1);  // index done
   if (dbg == 2) {
-    S.bin_part[bid] = (cells[0] + cells[1] + cells[2] + cells[3] == 0x7FFFFFF1) ? 1ull : 0x100000001ull;
+    bin_part[bid] = (cells[0] + cells[1] + cells[2] + cells[3] == 0x7FFFFFF1) ? 1ull : 0x100000001ull;
     return;
   }
 
@@ -313,7 +328,7 @@ __device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& 
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
   if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = v;
-  if (__ballot(any_glob) && (threadIdx.x & 63) == 0) st->flags[P.slot].any_inside = 1u;
+  if (__ballot(any_glob) && (threadIdx.x & 63) == 0) H.note_inside();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
   // probe of the block's cell table: claim-or-find in ONE LDS operation per step.  (Multiplicative hash: the low
@@ -384,8 +399,8 @@ __device__ __forceinline__ void tbin_body(const ScanParams& P, const GeomConst& 
   if (threadIdx.x == 0) {
     unsigned np = 0, ni = 0;
     for (int w = 0; w < kWaves; ++w) { np += s_cnt[w] & 0xFFFFu; ni += s_cnt[w] >> 16; }
-    if (np) st->flags[P.slot].any_pass = 1u;
-    S.bin_part[bid] = (unsigned long long)np | ((unsigned long long)ni << 32);
+    if (np) H.note_pass();
+    bin_part[bid] = (unsigned long long)np | ((unsigned long long)ni << 32);
   }
   const bool rare_block = s_rare != 0u;  // block-uniform
 
@@ -581,7 +596,8 @@ __global__ __launch_bounds__(THREADS) void k_tbin(const ScanParams P, const Geom
                                                   const Scratch S, const TilePool Q,
                                                   int32_t* __restrict__ cell_ids) {
   extern __shared__ __align__(16) unsigned char dyn_lds[];
-  tbin_body<HAS_INT, HAS_COL, THREADS, LEAN>(P, G, TG, st, I, S, Q, cell_ids, dyn_lds, blockIdx.x);
+  TbinRing H(P, st);
+  tbin_body<HAS_INT, HAS_COL, THREADS, LEAN>(P, G, TG, H, I, S, S.bin_part, Q, cell_ids, dyn_lds, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -644,12 +660,21 @@ __device__ __forceinline__ bool tile_hits_strips(const TileCtx& u, const GeomCon
          span_hits_strip(tc * kTC + G.s_c0, kTC, u.E.sc, u.C.shc, G.cols);
 }
 
+// What differs between the scans a tile group works through (one per launch, or the scans of a batch in order).
+struct TileJob {
+  unsigned scan_no;
+  int dbg_upd;       // measurement only (ScanParams::dbg_upd)
+  bool write_obst;   // touched cells write the obstacle layer (a batch: only its LAST updating scan — every updating scan
+                     // clears the whole layer first, elevation_mapping.cpp:144-146, so earlier values never survive)
+  bool set_stamp;    // ... and that scan stamps the tiles it touched
+};
+
 // One tile by one 256-thread group (`lt` = thread inside the group).  Block-uniform control flow
 // around the barriers: `n_chunks_max` is the largest chunk count among the block's groups.
 // `d0` = word `lt` of the tile's descriptor row, already loaded by the caller (word 0 is the count).
 template <typename POLICY, int BLOCK, bool HAS_INT, bool HAS_COL>
 __device__ __forceinline__ void tupdate_tile(
-    const ScanParams& P, const GeomConst& G, const TileGrid& TG, const TileCtx& u,
+    const TileJob& J, const GeomConst& G, const TileGrid& TG, const TileCtx& u,
     const typename POLICY::Layers& L, float* const* __restrict__ all_layers, int n_layers,
     const TilePool& Q, const TileAux& A, unsigned char* lds, const unsigned tile, const bool tile_ok,
     const unsigned n_chunks, const unsigned n_chunks_max, const unsigned long long d0, const bool obst_tile,
@@ -669,7 +694,7 @@ __device__ __forceinline__ void tupdate_tile(
   uint32_t* const g_first = g_zs + 2u * kTileCells;                       // (pos << 1 | first intensity is NaN) of the first record
   const unsigned long long* const row = Q.desc + size_t(tile_ok ? tile : 0u) * Q.stride;
 
-  if (P.dbg_upd == 1) {
+  if (J.dbg_upd == 1) {
     if (d0 == 0x7FFFFFF1ull) A.upd_part[0] = 1u;
     if (lt == 0 && tile_ok && n_chunks) Q.desc[size_t(tile) * Q.stride] = 0ull;
     return;
@@ -777,7 +802,7 @@ __device__ __forceinline__ void tupdate_tile(
   }
 
   FDM_PHASE(1);  // records folded into the tile image
-  if (P.dbg_upd == 2) {
+  if (J.dbg_upd == 2) {
     if (lt == 0 && tile_ok && n_chunks) Q.desc[size_t(tile) * Q.stride] = 0ull;
     return;  // measurement only (block-uniform)
   }
@@ -877,7 +902,7 @@ __device__ __forceinline__ void tupdate_tile(
         const float max_z = zm_[b] ? signed_value(zm_[b], zsw_[b] & 1u) : -kFltMax;
         if (A.ras_z) A.ras_z[o] = min_z;
         POLICY::update(L, o, stt_[b], min_z, var_[b], max_z);
-        L.obstacle[o] = (max_z > min_z) ? max_z : nanv;
+        if (J.write_obst) L.obstacle[o] = (max_z > min_z) ? max_z : nanv;
         if (has_int) {
           const float obs = (fst_[b] & 1u) ? nanv  // first point NaN -> stays NaN (elevation_mapping.cpp:73-79)
                                            : signed_value(im_[b], izw_[b] & 1u);
@@ -921,7 +946,7 @@ __device__ __forceinline__ void tupdate_tile(
     A.upd_part[tile] = n_touched;
     if (n_chunks) {
       Q.desc[size_t(tile) * Q.stride] = 0ull;
-      if (u.do_update) A.stamp[tile] = P.scan_no;
+      if (u.do_update && J.set_stamp) A.stamp[tile] = J.scan_no;
     }
   }
 }
@@ -984,7 +1009,8 @@ __device__ __forceinline__ void tupdate_body(
       if (lt <= nch && lt < Q.stride) dq = Q.desc[size_t(tile) * Q.stride + lt];
     }
     const bool obst_tile = ((q < 32u ? ob_lo >> q : ob_hi >> (q - 32u)) & 1u) != 0u;
-    tupdate_tile<POLICY, BLOCK, HAS_INT, HAS_COL>(P, G, TG, u, L, all_layers, n_layers, Q, A, dyn_lds, tile, true, nch,
+    const TileJob J{P.scan_no, P.dbg_upd, true, true};
+    tupdate_tile<POLICY, BLOCK, HAS_INT, HAS_COL>(J, G, TG, u, L, all_layers, n_layers, Q, A, dyn_lds, tile, true, nch,
                                                   nch, dq, obst_tile, lt, first, &s_rare);
     __syncthreads();
     if (lt == 0) s_rare = 0u;  // (read only behind barriers inside tupdate_tile)
@@ -1021,8 +1047,10 @@ __global__ __launch_bounds__(THREADS, FDM_UPD_WAVES) void k_tupdate_tbin(
 #endif
   if (u1 > u0)
     tupdate_body<POLICY, THREADS, HAS_INT, HAS_COL>(Pu, G, TG, st, L, all_layers, n_layers, Qu, A, span, dyn_lds, u0);
-  else
-    tbin_body<HAS_INT, HAS_COL, THREADS, LEAN>(Pb, G, TG, st, Ib, Sb, Qb, cell_ids, dyn_lds, blockIdx.x - u0);
+  else {
+    TbinRing H(Pb, st);
+    tbin_body<HAS_INT, HAS_COL, THREADS, LEAN>(Pb, G, TG, H, Ib, Sb, Sb.bin_part, Qb, cell_ids, dyn_lds, blockIdx.x - u0);
+  }
   if (A.timeline && threadIdx.x == 0) {  // (thread 0's view of the block; bench A/B tool, see scripts/timeline.py)
     A.timeline[2u * blockIdx.x] = t0;
 #if FDM_MB_PHASES

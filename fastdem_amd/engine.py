@@ -268,6 +268,12 @@ class Engine:
         _ck(self._lib.fdm_engine_debug_batch_dirty(self._h, out))
         return tuple(int(v) for v in out)
 
+    def batch_launches(self):
+        """(small-scan batch launches, tile-batch launches) enqueued since the engine was created."""
+        out = (C.c_uint64 * 2)()
+        _ck(self._lib.fdm_engine_debug_batch_launches(self._h, out))
+        return int(out[0]), int(out[1])
+
     def debug_timeline(self, cap_blocks=1 << 16):
         """(option dbg_timeline=1) -> (ticks[n_blocks, 2] uint64 of the 100 MHz clock, n_update_blocks) of the
         last fused large-scan launch."""

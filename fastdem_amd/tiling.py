@@ -409,19 +409,22 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
     try:
         wl = synth.global_map(n_scans=2)
         dev = f"cuda:{local_rank}"
+        staged = dist.get_backend() == "gloo"  # host-staged exchange (several ranks on one device: RCCL refuses that)
         rows = cols = int(round(float(np.float32(wl.width)) / float(np.float32(wl.resolution))))
         plan = make_plan(rank, world, rows, cols, DEFAULT_HALO)
         dog.kick("engine")
         eng = Engine(wl.width, wl.height, wl.resolution, wl.apply_to(capi.default_config()),
                      tile=plan.fdm_tile() if world > 1 else None, device=local_rank)
         tile = EngineTile(eng, plan, dev)
+        if staged:
+            tile = HostStagedTile(tile)
         names = ["elevation", "variance", "elevation_min", "elevation_max", "upper_bound",
                  "lower_bound", "n_points", "obstacle", "intensity"]
         n_pts = wl.n_points
-        router = RoutedScan(eng, plan, dev, max_points=n_pts)
+        router = RoutedScan(eng, plan, dev, max_points=n_pts, staged=staged)
         native = None
         pipelined = int(getattr(args, "native_routed", 1)) == 2 and world == 1  # (with halo rings to refresh per step: not pipelined)
-        if int(getattr(args, "native_routed", 1)):  # the routed step as ONE C call (libfdm_halo: fdm_halo_routed_step)
+        if int(getattr(args, "native_routed", 1)) and not staged:  # the routed step as ONE C call (libfdm_halo: fdm_halo_routed_step)
             from . import halo as halo_c
             comm = halo_c.make_comm(rank, world, dist)
             native = halo_c.NativeRoutedScan(eng, rank, world, rows, cols, DEFAULT_HALO, n_pts, comm=comm)
@@ -465,11 +468,18 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         dist.barrier()
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if staged else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         rc, st = eng.last_stats()
         routed = router.matrix
+        # SURVEY.md §8d algorithmic bytes of a step, summed over the ranks: every source's points are read once where
+        # they are routed (16 B: x, y, z, intensity) and once where they are integrated; every touched cell is one
+        # record read-modify-write (72 B Kalman + 8 B intensity).  GLOBAL map: no map-sized term.  Touched cells: this
+        # rank's last integrate, taken for every (source, owner) pair that exchanged points in the last step.
+        touched = torch.tensor([float(st["n_cells_touched"])], dtype=torch.float64, device="cpu" if staged else dev)
+        dist.all_reduce(touched, op=dist.ReduceOp.SUM)
+        touched = float(touched.item())
     except BaseException as exc:  # a failing rank leaves at once with a non-zero code: its peers' watchdogs / the
         import os                 # collective timeout then end them, the launcher sees the failure
         import sys
@@ -494,6 +504,21 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
                    "inputs": "SoA float32 (x, y, z, intensity) resident in HBM on every rank",
                    "routed_step": ("one C call per step, pipelined over consecutive scans (fdm_halo_routed_submit)" if pipelined else
                                    "one C call per step (fdm_halo_routed_step)") if native is not None else "Python loop (tiling.RoutedScan)"},
+        "roofline": _global_roofline(world, n_pts, routed, touched, dt / steps),
         "rank0_last_scan": st,
         "rank0_routing_matrix_last_step": routed.tolist() if routed is not None else None,
     }
+
+
+def _global_roofline(world, n_pts, matrix, touched_last, step_s):
+    """The routed step against the HBM roofline of the `world` GPUs it ran on (8 TB/s each): bytes the algorithm has
+    to move per step / step time.  A step is launch- and synchronisation-bound (one host read-back per step), so
+    the fraction is small by construction — it is there so that every bench line carries the same object."""
+    routed_pts = float(np.asarray(matrix)[:, :world].sum()) if matrix is not None else float(n_pts) * world
+    alg = world * n_pts * 16.0 + routed_pts * 16.0 + touched_last * 80.0
+    gbps = alg / step_s / 1e9
+    peak = 8000.0 * world
+    return {"bound": "hbm", "kernel": "routed step (k_route_* + exchange + k_tupdate_tbin per source)", "achieved": gbps,
+            "peak": peak, "unit": "GB/s", "frac": gbps / peak, "traffic": None, "alg_bytes_per_step": alg,
+            "avg_step_us": step_s * 1e6,
+            "note": "algorithmic bytes of all ranks per step / step time; peak = n_gpus x 8 TB/s"}

@@ -160,10 +160,7 @@ typedef struct fdm_device_scan {
   double T_world_base[16];
 } fdm_device_scan;
 int fdm_engine_integrate_device_batch(fdm_engine* e, uint32_t count, const fdm_device_scan* scans);
-/* Returns FDM_OK or the first error (< 0); an empty cloud in the batch is skipped and the batch goes on.
- * _timed: the same between fdm_engine_timer_start and fdm_engine_timer_stop (below), i.e. the held-back update of the
- * last scan is launched and fdm_engine_timer_ms returns the device-side duration of the whole batch. */
-int fdm_engine_integrate_device_batch_timed(fdm_engine* e, uint32_t count, const fdm_device_scan* scans);
+/* Returns FDM_OK or the first error (< 0); an empty cloud in the batch is skipped and the batch goes on. */
 
 /* Same, HOST arrays, enqueue-only; nothing waits.  For a stream of scans from host memory (bag replay,
  * a ROS callback).
@@ -208,15 +205,6 @@ int fdm_engine_last_batch(fdm_engine* e);
 int fdm_engine_timer_start(fdm_engine* e);
 int fdm_engine_timer_stop(fdm_engine* e);
 int fdm_engine_timer_ms(fdm_engine* e, float* ms);
-/* Measurement / debugging only: after everything enqueued has run, how many entries of the batch pipeline's scratch
- * sets are not in their clean state (keys, aux words, zero-sign words) — 0 0 0 in a healthy engine. */
-int fdm_engine_debug_batch_dirty(fdm_engine* e, uint64_t out[3]);
-
-/* Measurement tool (engine option "dbg_timeline" = 1): start / end time of every block of the last fused
- * large-scan launch, in ticks of the 100 MHz constant clock — ticks[2*b], ticks[2*b + 1] for block b; blocks
- * [0, *n_update_blocks) are tile-update groups of scan t, the rest bin blocks of scan t+1.  Waits for the stream. */
-int fdm_engine_debug_timeline(fdm_engine* e, uint64_t* ticks, uint64_t cap_blocks, uint32_t* n_blocks,
-                              uint32_t* n_update_blocks);
 /* Order a consumer behind the engine: launches a held-back update, then records `hip_event`
  * (hipEvent_t) on the engine's stream — everything enqueued so far, the map update of the last scan
  * included, is complete when the event fires (the reference's callers hold a shared_mutex around

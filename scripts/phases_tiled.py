@@ -32,6 +32,8 @@ def q(x): return [round(float(v), 2) for v in np.percentile(x, [10, 50, 90, 99])
 def block(idx, names, mask=None):
     if mask is not None:
         idx = idx[mask[idx]]
+    if len(idx) == 0:
+        return {"n": 0}
     return {"n": int(len(idx)), "start": q(s[idx]), names[0]: q(p0[idx]), names[1]: q(p1[idx] - p0[idx]),
             names[2]: q(p2[idx] - p1[idx]), names[3]: q(end[idx] - p2[idx]), "dur": q(end[idx]),
             "last_end": round(float((s[idx] + end[idx]).max()), 2)}
@@ -39,9 +41,14 @@ U, B = np.arange(0, nu), np.arange(nu, len(t))
 un = ["rt1_rows", "records_fold", "cells", "untouched_stores"]
 out = {"workload": w, "blocks": int(len(t)), "update_groups": int(nu), "span_us": round(float((s + end).max()), 2),
        "update_all": block(U, un),
-       "update_heavy": block(U, un, end > np.percentile(end[U], 90)),
-       "update_light": block(U, un, end < np.percentile(end[U], 30)),
+       "update_heavy": block(U, un, end > np.percentile(end[U], 90)) if nu else {},
+       "update_light": block(U, un, end < np.percentile(end[U], 30)) if nu else {},
        "bin": block(B, ["init_candidate", "loads_transforms_index", "fold_compact", "flush"]),
        "bin_first_round": block(B, ["init_candidate", "loads_transforms_index", "fold_compact", "flush"], s < 2.0),
        "bin_late": block(B, ["init_candidate", "loads_transforms_index", "fold_compact", "flush"], s > 12.0)}
+bn = ["init_candidate", "loads_transforms_index", "fold_compact", "flush"]
+span = float((s + end).max())
+if span > 60.0:  # a tile batch (fdm_tbatch.hpp): the bin blocks by when they start
+    out["bin_by_start"] = {f"{int(a)}-{int(b)}us": block(B, bn, (s >= a) & (s < b))
+                           for a, b in ((0, 2), (2, 30), (30, 60), (60, 90), (90, 120), (120, 150), (150, 1e9))}
 print(json.dumps(out))

@@ -37,6 +37,12 @@ out = {"workload": a.workload, "blocks": int(len(t)), "update_groups": int(nu), 
 def q(x): return [round(float(v), 2) for v in np.percentile(x, [0, 10, 50, 90, 99, 100])]
 out["update_start_us_pct"] = q(s[U]); out["update_end_us_pct"] = q(e[U]); out["update_dur_us_pct"] = q(d[U])
 out["bin_start_us_pct"] = q(s[B]); out["bin_end_us_pct"] = q(e[B]); out["bin_dur_us_pct"] = q(d[B])
+# bin blocks in grid order = scan order (a tile batch: K scans back to back): duration / start by eighth of the bin grid
+nb = len(t) - nu
+if nb >= 8:
+    out["bin_by_eighth"] = [{"dur_med": round(float(np.median(d[nu + i * nb // 8: nu + (i + 1) * nb // 8])), 2),
+                             "start_med": round(float(np.median(s[nu + i * nb // 8: nu + (i + 1) * nb // 8])), 2),
+                             "end_max": round(float(e[nu + i * nb // 8: nu + (i + 1) * nb // 8].max()), 2)} for i in range(8)]
 grid = np.arange(0.0, float(e.max()) + 1.0, 1.0)
 out["resident_by_us"] = [{"t": float(g), "update": int(((s[U] <= g) & (e[U] > g)).sum()), "bin": int(((s[B] <= g) & (e[B] > g)).sum())} for g in grid]
 heavy = np.argsort(-d[U])[:8]

@@ -33,6 +33,8 @@ def gpu(request):
     import fastdem_amd
     fastdem_amd.capi.load()
     saved = dict(fastdem_amd.Engine.default_options)
-    fastdem_amd.Engine.default_options = {"tiled_min": 1} if request.param == "tiled_all" else {}
+    # (tbatch_min 1: in that variant fdm_engine_integrate_device_batch also groups its scans into TILE batches,
+    # fdm_tbatch.hpp — every batch test then checks that pipeline against the oracle as well)
+    fastdem_amd.Engine.default_options = {"tiled_min": 1, "tbatch_min": 1} if request.param == "tiled_all" else {}
     yield fastdem_amd
     fastdem_amd.Engine.default_options = saved

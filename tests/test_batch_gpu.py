@@ -62,9 +62,17 @@ def oracle_scan_by_scan(ref, scans, Tbs, poses):
     return rc, st
 
 
-def check_batch(gpu, R, eng, ref, scans, Tbs, poses, exact=True):
+def check_batch(gpu, R, eng, ref, scans, Tbs, poses, exact=True, expect_batches=True):
+    """One fdm_engine_integrate_device_batch call against the oracle run scan by scan.  `pair()` switches the per-point
+    cell ids on, and an engine that owes its caller cell ids takes NO batch launch (fdm_engine_multi.inl / _tbatch.inl:
+    the batch bin halves do not write them) — so they are switched off here, and the call must have left in batch
+    launches (round 3's version of this helper never did: its scans all took the one-scan path)."""
+    eng.enable_cell_ids(False)
+    before = sum(eng.batch_launches())
     b = DeviceBatch(gpu, scans, Tbs, poses)
     assert eng.integrate_device_batch(b.arr) == 0
+    if expect_batches and len(scans) >= 3:  # (the first scan of a fresh engine goes alone: it creates the layers)
+        assert sum(eng.batch_launches()) > before, "the call took no batch launch"
     rc_r, st_r = oracle_scan_by_scan(ref, scans, Tbs, poses)
     rc_e, st_e = eng.last_stats()
     assert (rc_e, st_e) == (rc_r, st_r), (rc_e, st_e, rc_r, st_r)

@@ -1,0 +1,39 @@
+"""bench.py end to end on the GPU box with N > 1: `--gpus 2` with NO launcher around it must start
+its two ranks itself and print ONE JSON line that says n_gpus 2.  There is one GPU here and RCCL refuses two ranks on
+one device, so both ranks compute on device 0 and the collectives are host-staged (gloo) — the rank plumbing, the tile
+plan, the routing / pack / unpack kernels and the exchange loop are the ones the RCCL run uses."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*argv, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], cwd=ROOT, env=env, timeout=timeout,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_gpus_2_global_map_unwrapped():
+    """`python3 bench.py --gpus 2 --workload c5`: configs[4], one 8000 x 8000 global map cut into 1 x 2 tiles."""
+    r = run_bench("--gpus", "2", "--workload", "c5", "--backend", "gloo", "--devices", "0,0", "--steps", "3", "--warmup", "1")
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["value"] > 0
+    assert r["config"]["workload"].startswith("global_400x400m") and r["config"]["scans_per_step"] == 2
+    assert r["roofline"] and r["roofline"]["achieved"] > 0 and 0 < r["roofline"]["frac"] < 1
+
+
+def test_gpus_2_default_workload_prints_replicas_and_the_global_map():
+    r = run_bench("--gpus", "2", "--backend", "gloo", "--devices", "0,0", "--steps", "4", "--warmup", "2",
+                  "--no-cpu-baseline", "--no-host-legs")
+    assert r["n_gpus"] == 2 and "replicas" in r["config"]["parallelism"]
+    g = r["global_map"]
+    assert g["n_gpus"] == 2 and g["roofline"]["achieved"] > 0 and g["value"] > 0

@@ -10,10 +10,21 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "fdm_engine.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(fdm_[a-z0-9_]+)\s*\(", src)))
+def declared_symbols(headers=("fdm_engine.h", "fdm_engine_debug.h")):
+    """Every function the engine library's headers declare: the drop-in boundary (fdm_engine.h) and the measurement /
+    debugging entry points kept apart from it (fdm_engine_debug.h)."""
+    out = set()
+    for h in headers:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        out |= set(re.findall(r"\b(fdm_[a-z0-9_]+)\s*\(", src))
+    return sorted(out)
+
+
+def test_measurement_entry_points_stay_out_of_the_boundary_header():
+    public = declared_symbols(("fdm_engine.h",))
+    assert not [s for s in public if "debug" in s or s.endswith("_timed")], public
+    assert "fdm_engine_debug_timeline" in declared_symbols(("fdm_engine_debug.h",))
 
 
 def test_header_declares_the_boundary():
