@@ -226,8 +226,10 @@ struct fdm_engine {
   unsigned pre_seq = 0;
   const unsigned long long* last_bin_part = nullptr;  // per-block statistics of the last scan (either pipeline)
   // ---- tile batches (fdm_tbatch.hpp): up to tbatch_max LARGE scans per launch on the record pools ----
-  int tbatch = 1;                    // option "tbatch": fdm_engine_integrate_device_batch groups eligible large scans
-  int tbatch_max = 4;                // option "tbatch_max": scans per launch (2 .. kTBMax)
+  int tbatch = 0;                    // option "tbatch": fdm_engine_integrate_device_batch groups eligible large scans into tile
+                                     // batches.  OFF by default: measured at configs[3] it does not beat one fused launch per
+                                     // scan (35.6-42 us per scan at 8 / 4 scans per launch against 33.7-34.4: DESIGN.md §3c)
+  int tbatch_max = 8;                // option "tbatch_max": scans per launch (2 .. kTBMax)
   unsigned tbatch_min = 65536;       // option "tbatch_min": scans from this many points up
   int tb_groups = 512;               // option "tb_groups": update groups of a launch (each pulls tiles off a queue)
   TileRec* tb_rec[2] = {nullptr, nullptr};              // [tb_slots][tb_rec_stride] per batch parity
@@ -237,6 +239,10 @@ struct fdm_engine {
   unsigned tb_stride = 0;            // words per descriptor row
   int tb_slots = 0;                  // scan slots the pools hold
   size_t tb_bin_cap = 0;             // bin blocks per batch the statistics arrays hold
+  bool tpre_valid = false;           // the last tile-batch launch carried the scouts of the batch (tpre_scans, tpre_count) = number tpre_seq
+  const fdm_device_scan* tpre_scans = nullptr;
+  uint32_t tpre_count = 0;
+  unsigned tpre_seq = 0;
   // scan routing (fdm_route.hpp)
   uint8_t* d_route_owner = nullptr;  // [route_cap] owner rank of every point of the slice
   uint32_t* d_route_cnt = nullptr;   // [route_blocks_cap][world + 2] block counts -> offsets | [kMaxRanks] bases at the end
@@ -1348,7 +1354,9 @@ int fdm_engine_integrate_device_batch(fdm_engine* e, uint32_t count, const fdm_d
     // runs of LARGE plain scans leave as tile batches (fdm_tbatch.hpp): one launch per tbatch_max scans
     if (const uint32_t run = tbatch_run(e, count - k, scans + k)) {
       HIPCK(hipSetDevice(e->device));
-      if (int rc = enqueue_tbatch(e, run, scans + k)) return rc;
+      // (look-ahead: the batch after this one, whose scouts ride in this launch)
+      const uint32_t next = k + run < count ? tbatch_run(e, count - k - run, scans + k + run) : 0u;
+      if (int rc = enqueue_tbatch(e, run, scans + k, next)) return rc;
       k += run - 1u;
       continue;
     }

@@ -40,6 +40,7 @@ uint32_t multi_run(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) 
 
 // The ring of batch states, shared by the small-scan batches (k_mbatch) and the tile batches (k_tbatch): both number
 // their batches with e->mseq and re-arm the state of the batch after next the same way.
+int drop_scouted(fdm_engine* e);  // (fdm_engine_tbatch.inl)
 int ensure_mstate(fdm_engine* e) {
   if (e->mstate) return FDM_OK;
   HIPCK(hipMalloc(reinterpret_cast<void**>(&e->mstate), kMStates * sizeof(MState)));
@@ -208,6 +209,7 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
   K.bin_table = e->bin_table;
   K.dbg = e->dbg_batch;
 
+  if ((rc = drop_scouted(e))) return rc;  // (a tile batch scouted scans that now leave as a small-scan batch)
   const unsigned seq = e->mseq++;
   const int slot = int(seq % unsigned(kMStates)), par = int(seq & 1u);
   // the crop pass that ran one launch ahead left this batch's pass bits in its state word — if it was for THIS batch

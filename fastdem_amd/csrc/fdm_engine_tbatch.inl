@@ -19,7 +19,7 @@ uint32_t tbatch_run(fdm_engine* e, uint32_t count, const fdm_device_scan* scans)
   for (; run < cap; ++run) {
     const fdm_device_scan& s = scans[run];
     if (s.n == 0 || !s.x || !s.y || !s.z) break;
-    if (s.n < e->tbatch_min || s.n < e->tiled_min || s.n >= 0x3000000ull) break;  // (<= 49 152 bin blocks: 16-bit counters)
+    if (s.n < e->tbatch_min || s.n < e->tiled_min || s.n >= 0xF00000ull) break;  // (4 wavefronts x 15 360 bin blocks: 16-bit counters)
     const bool enough_tiles = e->tiled_forced || kt >= 240 || (kt >= 160 && s.n >= 100000);
     if (!enough_tiles) break;
     if (!al16(s.x) || !al16(s.y) || !al16(s.z) || !al16(s.intensity)) break;
@@ -83,13 +83,14 @@ int ensure_tbatch(fdm_engine* e, size_t max_n, unsigned max_blocks, unsigned tot
   return FDM_OK;
 }
 
-// One k_tbatch launch: [ update U | bin B ], either of which may be empty (count == 0).
-int launch_tbatch(fdm_engine* e, bool hi, bool hc, const TBUpd& U, const TBBin& B, const TBCommon& K) {
-  static_assert(sizeof(TBUpd) + sizeof(TBBin) + sizeof(TBCommon) + sizeof(GeomConst) + sizeof(TileGrid) + sizeof(TileAux) + 200 <= 4096,
+// One k_tbatch launch: [ update U | bin B | scouts C ], any of which may be empty (count == 0).
+int launch_tbatch(fdm_engine* e, bool hi, bool hc, const TBUpd& U, const TBBin& B, const TBScout& C, const TBCommon& K) {
+  static_assert(sizeof(TBUpd) + sizeof(TBBin) + sizeof(TBScout) + sizeof(TBCommon) + sizeof(GeomConst) + sizeof(TileGrid) + sizeof(TileAux) + 200 <= 4096,
                 "k_tbatch: kernel arguments beyond 4 KB");
   const unsigned ug = U.count ? U.n_groups : 0u;
   const unsigned bb = B.count ? B.first_block[B.count] : 0u;
-  if (ug + bb == 0u) return FDM_OK;
+  const unsigned sb = C.count * kScoutBlocks;
+  if (ug + bb + sb == 0u) return FDM_OK;
   const unsigned lds = std::max(tile_lds_bytes(hi, hc), tbin_lds_bytes(hi, hc, 256u));
   TBCommon Kt = K;
   Kt.timeline = (e->d_timeline && ug + bb <= e->timeline_cap && B.count) ? e->d_timeline : nullptr;
@@ -101,7 +102,7 @@ int launch_tbatch(fdm_engine* e, bool hi, bool hc, const TBUpd& U, const TBBin& 
       int rc = FDM_OK;
       auto go = [&](auto kern) {
         if ((rc = allow_lds(kern, lds))) return;
-        hipLaunchKernelGGL(kern, dim3(ug + bb), dim3(256), lds, e->stream, U, B, Kt, e->G, e->TG, e->d_state, layers,
+        hipLaunchKernelGGL(kern, dim3(ug + bb + sb), dim3(256), lds, e->stream, U, B, C, Kt, e->G, e->TG, e->d_state, layers,
                            e->d_layer_ptrs, e->n_layer_ptrs, A, ug);
       };
       if (hi && hc) go(k_tbatch<POLICY, true, true>);
@@ -120,15 +121,38 @@ int launch_tbatch(fdm_engine* e, bool hi, bool hc, const TBUpd& U, const TBBin& 
 // The held-back update of a tile batch on its own (launch_update_alone forwards here).
 int launch_tbatch_update(fdm_engine* e, const fdm_engine::PendingUpdate& u) {
   TBBin B;
+  TBScout C;
   TBCommon K;
   std::memset(&B, 0, sizeof(B));
+  std::memset(&C, 0, sizeof(C));
   std::memset(&K, 0, sizeof(K));
-  return launch_tbatch(e, u.tb_hi, u.tb_hc, u.TU, B, K);
+  return launch_tbatch(e, u.tb_hi, u.tb_hc, u.TU, B, C, K);
+}
+
+// Scout flags written for a batch that did not come (the caller's next scans took another path): the state they were
+// written into is cleaned before anybody reads it.
+int drop_scouted(fdm_engine* e) {
+  if (!e->tpre_valid) return FDM_OK;
+  e->tpre_valid = false;
+  MState* const ms = e->mstate + int(e->tpre_seq % unsigned(kMStates));
+  HIPCK(hipMemsetAsync(ms->done, 0, sizeof(ms->done), e->stream));
+  return FDM_OK;
+}
+
+void fill_scout(TBScout& C, MState* ms, uint32_t count, const fdm_device_scan* scans) {
+  std::memset(&C, 0, sizeof(C));
+  C.count = count;
+  C.ms = ms;
+  for (uint32_t k = 0; k < count; ++k) {
+    C.n[k] = uint32_t(scans[k].n);
+    C.px[k] = scans[k].x; C.py[k] = scans[k].y; C.pz[k] = scans[k].z;
+  }
 }
 
 // `count` (2 .. tbatch_max) scans that tbatch_run() accepted leave as ONE launch: the held-back update of the previous
-// tile batch (when there is one) and this batch's bin.  This batch's update is held back.
-int enqueue_tbatch(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) {
+// tile batch (when there is one), this batch's bin and — `next_count` >= 2 — the scouts of the batch the caller will
+// enqueue next (scans[count .. count + next_count)).  This batch's update is held back.
+int enqueue_tbatch(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, uint32_t next_count) {
   int rc;
   const fdm_device_scan& f = scans[0];
   const bool hi = f.intensity != nullptr, hc = f.rgb != nullptr, hv = f.sigma_z2 != nullptr;
@@ -177,6 +201,31 @@ int enqueue_tbatch(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) 
   if (e->pre_valid)  // (crop bits a small-scan batch launch left for a batch that never came)
     HIPCK(hipMemsetAsync(e->mstate[slot].flags, 0, sizeof(unsigned) * kLineWords, e->stream));
   e->pre_valid = false;
+  // "scan k has a point that survives the crops" (it moves a LOCAL map, fastdem.cpp:138-145) must be known when the bin
+  // blocks start: the scouts of the previous launch left it in this batch's state — if they scouted THIS batch;
+  // otherwise a small launch of scouts runs ahead of the batch (the first batch of a chain: once per call)
+  const bool gated = K.do_move && K.gate_on_filter;
+  const bool scouted = e->tpre_valid && e->tpre_scans == scans && e->tpre_count == count && e->tpre_seq == seq;
+  if (e->tpre_valid && !scouted && (rc = drop_scouted(e))) return rc;
+  e->tpre_valid = false;
+  TBScout Cs;
+  std::memset(&Cs, 0, sizeof(Cs));
+  if (gated && !scouted) {
+    TBUpd U0;
+    TBBin B0;
+    std::memset(&U0, 0, sizeof(U0));
+    std::memset(&B0, 0, sizeof(B0));
+    fill_scout(Cs, e->mstate + slot, count, scans);
+    if ((rc = launch_tbatch(e, hi, hc, U0, B0, Cs, K))) return rc;
+    std::memset(&Cs, 0, sizeof(Cs));
+  }
+  if (gated && next_count >= 2u && std::memcmp(scans[count].T_base_sensor, f.T_base_sensor, 16 * sizeof(double)) == 0) {
+    fill_scout(Cs, e->mstate + int((seq + 1u) % unsigned(kMStates)), next_count, scans + count);
+    e->tpre_valid = true;
+    e->tpre_scans = scans + count;
+    e->tpre_count = next_count;
+    e->tpre_seq = seq + 1u;
+  }
   const bool fuse = e->chain && e->pend.tb;  // (same channels: checked above)
   B.count = count;
   B.scan_no0 = uint32_t(e->scan_no);
@@ -192,7 +241,7 @@ int enqueue_tbatch(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) 
   B.bin_part = e->tb_bin_part[par];
   if (fuse) U = e->pend.TU;
   e->chain = false;
-  if ((rc = launch_tbatch(e, hi, hc, U, B, K))) return rc;
+  if ((rc = launch_tbatch(e, hi, hc, U, B, Cs, K))) return rc;
 
   // this batch's update is held back (option "batch_fuse" 0: launched at once, for per-kernel measurements)
   TBUpd& N = e->pend.TU;

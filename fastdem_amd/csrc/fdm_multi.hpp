@@ -76,7 +76,7 @@ struct MCommon {  // what all scans of a batch share
   float sp[4];
   float Tbs[16];  // T_base_sensor (one sensor per batch: a scan with another extrinsic closes the batch)
   int sensor_type, integrate_mode, do_move, gate_on_filter, has_var, bin_table;
-  int dbg, pad;                  // measurement only: 1 = no scratch atomics, 2 = no chain walk (both: wrong results); 3 = every move by the reference's divide; 4 = a chain wait gives up after two polls (tests: MState::err)
+  int dbg, pad;                  // measurement only: 1 = no scratch atomics, 2 = no chain walk (both: wrong results); 3 = every move by the reference's divide; 4 = a chain wait reports MState::err as if it had run out of polls (tests)
   unsigned long long* timeline;  // measurement only (nullable): {start, end} of every block in 100 MHz ticks
 };
 struct MScanT {   // per scan: T_world_base without its constant last row (0 0 0 1), column-major 3 x 4 | rotation of the product
@@ -412,10 +412,11 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
         if (must_wait) {  // ... and wait for the scans ahead: ONE word, ONE poller per block
           const unsigned need = (1u << k) - 1u;
           unsigned spins = 0u;
+          if (K.dbg == 4) ms->err = 1u;  // (tests provoke the fault: as if this wait had run out of polls)
           while (true) {  // every earlier scan either has a surviving point (pass bit) or is through its crops (done bit)
             f = __hip_atomic_load(&ms->flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (((f | (f >> 16)) & need) == need) break;
-            if (++spins >= kSpinMax || (K.dbg == 4 && spins >= 2u)) {  // (dbg 4: tests provoke the fault)
+            if (++spins >= kSpinMax) {
               ms->err = 1u;
               break;
             }
@@ -617,6 +618,7 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
   }
   if (bid == 0 && lt >= 64u && lt < 64u + unsigned(kMaxBatch)) {  // re-arm the state of the batch after next
     U.rearm->done[(lt - 64u) * kLineWords] = 0u;
+    U.rearm->done[(lt - 64u) * kLineWords + 1u] = 0u;  // (the tile batches' flag word on the same line, fdm_tbatch.hpp)
     U.rearm->inside[lt - 64u] = 0u;
     if (lt == 64u) { U.rearm->flags[0] = 0u; U.rearm->err = 0u; U.rearm->tq = 0u; U.rearm->gdone = 0u; }
   }

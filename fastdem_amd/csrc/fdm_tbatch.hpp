@@ -5,18 +5,15 @@
 // its 2 048 bin blocks run on a draining chip (two quantised rounds on 1 792 slots): 33.7 us per scan for 19 us of
 // vector issue.  fdm_engine_integrate_device_batch sees its scans up front, so K consecutive large scans leave as
 //
-//   k_tbatch = [ update of batch b-1 : a FEW tile groups that pull tiles from a queue | bin of batch b : K x blocks ]
+//   k_tbatch = [ update of batch b-1 : a FEW tile groups that pull tiles from a queue | bin of batch b : K x blocks |
+//                scouts of batch b+1 : "does scan k have a point that survives the crops?" ]
 //
 //   bin half     tbin_body as it is (fdm_tiled.hpp) — scan k of the batch writes its records into pool k of the
 //                batch's parity.  The geometry scan k is binned against depends on whether the scans before it moved
 //                the map, i.e. on whether any of their points survived the crops (fastdem.cpp:138) — device-side
-//                data.  In-launch protocol (as fdm_multi.hpp's): after its crops a block adds itself to its scan's
-//                counter; the FIRST block of a scan that holds a surviving point raises the scan's pass bit at once,
-//                the block that completes a scan raises its done bit; a block of scan k > 0 polls ONE word until
-//                every earlier scan is decided, then walks the k moves ahead of its own (GridMap::move arithmetic,
-//                move_candidate_fast: the operations the single-scan path performs, in the same order).  A block only
-//                waits for blocks with a lower index, which publish before they wait and are dispatched first: no
-//                deadlock; the spin is bounded and raises MState::err.
+//                data, decided ONE LAUNCH AHEAD by a few scout blocks per scan (tscout_body: first survivor, early
+//                exit): when a bin block starts, the flags of the scans ahead of it are final, and thread 0 walks the
+//                k moves (GridMap::move arithmetic, move_candidate_fast, in scan order).  No in-launch waiting.
 //   update half  `n_groups` (<= 512) groups instead of one per tile, so that the bin blocks own most of the chip
 //                from t = 0.  A group pulls tiles off a queue (one atomic per tile, heavy and idle tiles mix), reads
 //                the tile's K chunk counts in one round trip and then works through the scans IN ORDER — per cell
@@ -97,83 +94,52 @@ struct TBScanView {
 
 // tbin_body's hook for a scan inside a batch (see TbinRing for the one-scan-per-launch version).
 //
-// The in-launch protocol lives in ONE word per scan, MState::done[k * kLineWords] (its own 128-byte line): every block
-// of scan k adds 1 | (it holds a surviving point) << 16 once, after its crops — a fire-and-forget atomic, nothing
-// waits for it.  Scan j is DECIDED for a later scan's block as soon as the word's upper half is non-zero (some block
-// saw a surviving point: the scan moves the map) or its lower half has reached the scan's block count (no block did).
-// A block of scan k reads the k words ahead of it at its very start (lane j of the first wavefront: word j), in the
-// shadow of its point loads; in the steady state of a launch they are long decided and the block never waits.
-// (First version: a returning atomicAdd + a flags word polled after the crops — two dependent memory round trips on
-// every block's critical path: bin blocks lived 17 us instead of 11.4, profiles/r04/timeline_c4_tbatch_v1.json.)
-__device__ __forceinline__ bool tb_decided(unsigned d, unsigned nblocks) { return (d >> 16) != 0u || (d & 0xFFFFu) == nblocks; }
-
+// Which of the scans ahead of scan k moved the map is known BEFORE the launch starts: MState::done[j * kLineWords + 1]
+// != 0 <=> scan j has a point that survives the crops (fastdem.cpp:138-145), written by the SCOUT blocks of the previous
+// launch (or of a small launch of their own ahead of the first batch of a chain) — tscout_body below.  A bin block
+// reads the flags ahead of it at its very start, in the shadow of its point loads, and thread 0 walks the k moves
+// (GridMap::move arithmetic, move_candidate_fast: the operations the single-scan path performs, in the same order).
+// Nothing is published, nothing is polled: no in-launch protocol at all.
+// (What was measured on the way, profiles/r04/phases_*.json: an in-launch protocol — every block or wavefront adds /
+// stores its "some point survived" to its scan's word, later scans' blocks poll it — makes the 1 536 blocks of a
+// launch's FIRST round hit one address at once; a returning atomicAdd per block: bin blocks 17 us instead of 11; one
+// fire-and-forget add per wavefront: those blocks waited 30-70 us for 6 000 same-address atomics to drain at the
+// memory side; one agent-scope store per wavefront: 90-210 us.)
 struct TbinChain {
   const TBBin& B;
   const TBCommon& K;
   DevState* st;
-  const unsigned k, nblocks;
-  unsigned* s_w;  // [4] LDS: per wavefront "some point survived the crops"
+  const unsigned k;
   DevGeom g0;
   DevCand cprev;
-  unsigned dprev;  // the previous batch's last scan: its `done` word (final)
-  unsigned dj;     // lane j < k of the first wavefront: scan j's `done` word
-  unsigned nbj;    // ... and its block count
-  __device__ __forceinline__ TbinChain(const TBBin& b, const TBCommon& kk, DevState* s, unsigned scan, unsigned nb, unsigned* w)
-      : B(b), K(kk), st(s), k(scan), nblocks(nb), s_w(w) {}
+  unsigned dprev;  // the previous batch's last scan: its flag
+  unsigned fj;     // lane j < k of the first wavefront: scan j's flag
+  __device__ __forceinline__ TbinChain(const TBBin& b, const TBCommon& kk, DevState* s, unsigned scan) : B(b), K(kk), st(s), k(scan) {}
   __device__ __forceinline__ bool gated() const { return K.do_move != 0 && K.gate_on_filter != 0; }
   __device__ __forceinline__ void begin() {
-    dj = 0u; nbj = 0u; dprev = 0u;
+    fj = 0u; dprev = 0u;
     if (threadIdx.x < 64u) {
-      if (gated() && threadIdx.x < k) {
-        dj = __hip_atomic_load(&B.ms->done[threadIdx.x * kLineWords], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        nbj = B.first_block[threadIdx.x + 1u] - B.first_block[threadIdx.x];
-      }
+      if (gated() && threadIdx.x < k) fj = B.ms->done[threadIdx.x * kLineWords + 1u];
       if (threadIdx.x == 0) {  // the geometry the chain starts from (in flight while the points are transformed)
         cprev.px = cprev.py = 0.0; cprev.sr = cprev.sc = cprev.shr = cprev.shc = 0;
         if (B.prev) {
           const unsigned pk = B.prev_count - 1u;
           g0 = B.prev->E[pk];
           cprev = B.prev->C[pk];
-          dprev = B.prev->done[pk * kLineWords];
+          dprev = B.prev->done[pk * kLineWords + 1u];
         } else {
           g0 = st->geom[B.scan_no0 & 3u];
         }
       }
     }
   }
-  __device__ __forceinline__ DevCand finish(const GeomConst& G, DevCand* s_cand, unsigned lb, unsigned n_pass) {
-    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (gated()) {
-      const bool wp = __ballot(n_pass != 0u) != 0ull;
-      if (lane == 0u) s_w[wave] = wp ? 1u : 0u;
-      __syncthreads();
-    }
-    if (threadIdx.x < 64u) {  // the first wavefront: lane j looks after scan j's word, thread 0 publishes and walks
-      MState* const ms = B.ms;
-      unsigned passmask = 0xFFFFu;
-      if (gated()) {
-        if (threadIdx.x == 0) {
-          const unsigned np = s_w[0] | s_w[1] | s_w[2] | s_w[3];
-          (void)atomicAdd(&ms->done[k * kLineWords], 1u | (np ? 0x10000u : 0u));  // (result unused: no round trip)
-        }
-        unsigned spins = 0u;
-        if (K.dbg == 4 && k > 0u && lane == 0u) ms->err = 1u;  // (dbg 4: tests provoke the fault)
-        while (true) {  // (wave-uniform) every earlier scan either has a surviving point or is through its crops
-          const bool open = lane < k && !tb_decided(dj, nbj);
-          if (!__ballot(open)) break;
-          if (++spins >= kSpinMax) {
-            if (lane == 0u) ms->err = 1u;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(8);
-          if (open) dj = __hip_atomic_load(&ms->done[lane * kLineWords], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        passmask = uni(unsigned(__ballot(lane < k && (dj >> 16) != 0u)));
-      }
+  __device__ __forceinline__ DevCand finish(const GeomConst& G, DevCand* s_cand, unsigned lb, unsigned /*n_pass*/) {
+    if (threadIdx.x < 64u) {
+      const unsigned passmask = gated() ? uni(unsigned(__ballot((threadIdx.x & 63u) < k && fj != 0u))) : 0xFFFFu;
       if (threadIdx.x == 0) {
         DevGeom g = g0;
         if (B.prev) {  // what the update of the previous batch (the other half of this launch) is about to commit
-          if (K.do_move && (!K.gate_on_filter || (dprev >> 16) != 0u)) {
+          if (K.do_move && (!K.gate_on_filter || dprev != 0u)) {
             g.px = cprev.px; g.py = cprev.py; g.sr = cprev.sr; g.sc = cprev.sc;
           }
         }
@@ -188,7 +154,7 @@ struct TbinChain {
           c = move_candidate_fast(g, G, B.robot_x[k], B.robot_y[k]);
         }
         *s_cand = c;
-        if (lb == 0u) { ms->E[k] = g; ms->C[k] = c; }
+        if (lb == 0u) { B.ms->E[k] = g; B.ms->C[k] = c; }
       }
     }
     __syncthreads();
@@ -197,6 +163,48 @@ struct TbinChain {
   __device__ __forceinline__ void note_inside() { B.ms->inside[k] = 1u; }
   __device__ __forceinline__ void note_pass() {}
 };
+
+// ---------------------------------------------------------------------------------------------
+// scout blocks: does scan k of the NEXT batch hold a point that survives the crops?  kScoutBlocks blocks per scan walk
+// the scan with a grid stride, four points per thread and step, and leave at the first step in which any thread of the
+// block sees a survivor — for a real scan that is the first step (one round trip); only a scan without survivors (a
+// covered sensor) is read to its end.  The crops are preprocess_point's own float operations (T_base_sensor,
+// cropRange, cropZ: crop_impl.hpp:79-96,167-178), so the flag is exactly what the bin blocks would find.
+constexpr unsigned kScoutBlocks = 32u;
+struct TBScout {   // scans of the batch after this one (count == 0: none)
+  unsigned count, pad;
+  unsigned n[kTBMax];
+  MState* ms;
+  const float* px[kTBMax];
+  const float* py[kTBMax];
+  const float* pz[kTBMax];
+};
+__device__ __forceinline__ void tscout_body(const TBScout& C, const TBCommon& K, const unsigned k, const unsigned sb) {
+  MView V;
+  V.Tbs = K.Tbs; V.Twb12 = nullptr; V.R = nullptr; V.sp = K.sp;
+  V.min_sq = K.min_sq; V.max_sq = K.max_sq; V.z_min = K.z_min; V.z_max = K.z_max;
+  V.sensor_type = K.sensor_type; V.integrate_mode = 1;
+  const float* __restrict__ const px = C.px[k];
+  const float* __restrict__ const py = C.py[k];
+  const float* __restrict__ const pz = C.pz[k];
+  const unsigned n = C.n[k];
+#pragma unroll 1
+  for (unsigned i0 = sb * 1024u; i0 < n; i0 += kScoutBlocks * 1024u) {  // (block-uniform loop)
+    bool pass = false;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const unsigned i = i0 + unsigned(h) * 256u + threadIdx.x;
+      if (i < n) {
+        float x = px[i], y = py[i], z = pz[i], w;
+        pass = mcrops(V, x, y, z, w) || pass;
+      }
+    }
+    if (__syncthreads_or(pass ? 1 : 0)) {
+      if (threadIdx.x == 0) C.ms->done[k * kLineWords + 1u] = 1u;  // (<= kScoutBlocks plain stores of the same value)
+      return;
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // update half: group `gid` of U.n_groups.
@@ -226,7 +234,7 @@ __device__ __forceinline__ void tbupdate_body(const TBUpd& U, const GeomConst& G
   const unsigned ob_prev = uni(st->obst[U.scan_no0 & 3u].scan);  // (the ring is committed by the LAST group to leave)
   if (lt < 64u) {
     // (a scan has a surviving point iff some block said so in its `done` word: final, the bin ran one launch ago)
-    const bool v_pass = lane < count && (ms->done[lane * kLineWords] >> 16) != 0u;
+    const bool v_pass = lane < count && ms->done[lane * kLineWords + 1u] != 0u;
     const bool v_applied = lane < count && U.do_move && (!U.gate_on_filter || v_pass);
     const unsigned long long mu = __ballot(lane < count && v_in != 0u), msx = __ballot(v_applied && v_shift), mp = __ballot(v_pass);
     if (lt == 0) { s_masks[0] = unsigned(mu); s_masks[1] = unsigned(msx); s_masks[2] = unsigned(mp); s_rare = 0u; }
@@ -241,7 +249,10 @@ __device__ __forceinline__ void tbupdate_body(const TBUpd& U, const GeomConst& G
 #pragma unroll 1
   while (pop < U.n_pops) {  // block-uniform
     // round trip 1: chunk counts of the pop's tiles in every scan of the batch + the tiles' stamps.  Slot q of pop i is
-    // tile i + q * n_pops (the tiles a scan touches are neighbours: strided, a pop holds few live ones)
+    // tile i + q * n_pops (the tiles a scan touches are neighbours: strided, a pop holds few live ones).  One tile per
+    // pop: the descriptor row of the batch's FIRST scan rides in the same round trip (word 0 is its count).
+    unsigned long long d_spec = 0ull;
+    if (U.span == 1u && lt < U.stride) d_spec = U.desc0[size_t(pop) * U.stride + lt];
     if (lt < 64u) {
       const unsigned q = lt >> kTBShift, k = lt & unsigned(kTBMax - 1);
       const unsigned tile = pop + q * U.n_pops;
@@ -279,7 +290,8 @@ __device__ __forceinline__ void tbupdate_body(const TBUpd& U, const GeomConst& G
       {  // the first scan's descriptor row (the next one's is fetched while this one is worked on)
         const unsigned k0 = unsigned(__ffs(int(kbits))) - 1u;
         const unsigned n0 = uni(s_nch[sh + k0]);
-        if (lt <= n0 && lt < U.stride) d = U.desc0[size_t(k0) * U.desc_stride + row0 + lt];
+        if (U.span == 1u && k0 == 0u) d = lt <= n0 ? d_spec : 0ull;
+        else if (lt <= n0 && lt < U.stride) d = U.desc0[size_t(k0) * U.desc_stride + row0 + lt];
       }
 #pragma unroll 1
       while (kbits) {
@@ -345,7 +357,9 @@ __device__ __forceinline__ void tbupdate_body(const TBUpd& U, const GeomConst& G
         if (HAS_COL && st->vis_col == 0u) st->vis_col = 3u * first_upd + 2u;
       }
       if (ms->err) st->fault = 1u;
-      for (int q = 0; q < kMaxBatch; ++q) { U.rearm->done[q * kLineWords] = 0u; U.rearm->inside[q] = 0u; }
+      for (int q = 0; q < kMaxBatch; ++q) {
+        U.rearm->done[q * kLineWords] = 0u; U.rearm->done[q * kLineWords + 1] = 0u; U.rearm->inside[q] = 0u;
+      }
       U.rearm->flags[0] = 0u;
       U.rearm->err = 0u;
       U.rearm->tq = 0u;
@@ -357,14 +371,13 @@ __device__ __forceinline__ void tbupdate_body(const TBUpd& U, const GeomConst& G
 // [ update of batch b-1 | bin of batch b ] — either may be empty.  Update groups come first in the grid (short chains
 // that start at once), then the bin blocks scan by scan.
 template <typename POLICY, bool HAS_INT, bool HAS_COL>
-__global__ __launch_bounds__(256, FDM_UPD_WAVES) void k_tbatch(const TBUpd U, const TBBin B, const TBCommon K,
+__global__ __launch_bounds__(256, FDM_UPD_WAVES) void k_tbatch(const TBUpd U, const TBBin B, const TBScout C, const TBCommon K,
                                                               const GeomConst G, const TileGrid TG,
                                                               DevState* __restrict__ st,
                                                               const typename POLICY::Layers L,
                                                               float* const* __restrict__ all_layers, int n_layers,
                                                               const TileAux A, unsigned upd_groups) {
   extern __shared__ __align__(16) unsigned char dyn_lds[];
-  __shared__ unsigned s_w[4];
   const unsigned long long t0 = K.timeline ? wall_clock64() : 0ull;
 #if FDM_MB_PHASES
   if (threadIdx.x == 0) { g_phase[0] = g_phase[1] = g_phase[2] = unsigned(t0); }
@@ -374,6 +387,9 @@ __global__ __launch_bounds__(256, FDM_UPD_WAVES) void k_tbatch(const TBUpd U, co
 #endif
   if (FDM_TB_ONLY != 1 && blockIdx.x < upd_groups) {
     tbupdate_body<POLICY, HAS_INT, HAS_COL>(U, G, TG, st, L, all_layers, n_layers, A, dyn_lds, blockIdx.x);
+  } else if (blockIdx.x >= upd_groups + (B.count ? B.first_block[B.count] : 0u)) {
+    const unsigned sb = blockIdx.x - upd_groups - (B.count ? B.first_block[B.count] : 0u);
+    tscout_body(C, K, sb / kScoutBlocks, sb % kScoutBlocks);
   } else if (FDM_TB_ONLY != 2) {
     const unsigned b = blockIdx.x - upd_groups;
     unsigned k = 0u;  // the block's scan: a short prefix table, uniform compares
@@ -393,7 +409,7 @@ __global__ __launch_bounds__(256, FDM_UPD_WAVES) void k_tbatch(const TBUpd U, co
     Q.stride = B.stride;
     Q.rare = B.rare;
     const Scratch S{};  // (LEAN bin body: no captures, no write-through)
-    TbinChain H(B, K, st, k, B.first_block[k + 1u] - B.first_block[k], s_w);
+    TbinChain H(B, K, st, k);
     tbin_body<HAS_INT, HAS_COL, 256, true>(P, G, TG, H, I, S, B.bin_part + B.first_block[k], Q, nullptr, dyn_lds, lb);
   }
   if (K.timeline && threadIdx.x == 0) {  // (thread 0's view of the block; scripts/timeline.py)

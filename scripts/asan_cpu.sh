@@ -15,3 +15,8 @@ echo "== C++ mirror host-only code under ASan/UBSan =="
 make -s -C $R/fastdem_amd/cpp asan
 FDM_CONFIG_DIR=$R/fastdem_amd/config ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=halt_on_error=1 \
   $R/fastdem_amd/cpp/build/fdm_cpp_tests_asan ConfigLoad.
+echo "== libfdm_halo host code (tile plan, route plan) under ASan/UBSan =="
+make -s -C $R/fastdem_amd/csrc asan
+LD_PRELOAD="$ASAN_LIB $(gcc -print-file-name=libstdc++.so.6)" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
+  FDM_HALO_LIB=$R/fastdem_amd/lib/libfdm_halo_asan.so \
+  python -m pytest $R/tests/test_halo_capi.py -q -m "not gpu" -p no:cacheprovider

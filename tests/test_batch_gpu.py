@@ -336,3 +336,38 @@ def test_batch_option_off_is_the_same_map(gpu, R):
     for n in b.layers():
         assert_arrays_close(a.layer(n), b.layer(n), n, 0.0, 0.0)
     assert same_geometry(a.geometry(), b.geometry())
+
+
+def test_a_chain_wait_that_runs_out_of_polls_fails_loudly_and_the_engine_recovers(gpu, R):
+    """MState::err (fdm_multi.hpp): a bin block of a small-scan batch that waits for the scans ahead of it gives up after
+    a bounded number of polls instead of hanging the GPU.  `dbg_batch` 4 makes every such wait give up after two polls:
+    the call's next synchronisation point reports FDM_ERR_HIP — once — and after reset() the same engine integrates
+    correctly again.  (The tile batches have no in-kernel wait: their flags are decided one launch ahead.)"""
+    def fill(c):
+        c.z_min, c.z_max, c.range_min, c.range_max = -2.0, 3.0, 0.0, 30.0
+
+    eng, ref = pair(gpu, R, 8.0, 6.0, 0.1, fill)
+    rng = np.random.default_rng(29)
+    scans = [cloud(rng, 30000, 3.5, intensity=True) for _ in range(17)]
+    poses = [T(0.3 * k, 0.1 * k, 0.0) for k in range(17)]
+    eng.enable_cell_ids(False)  # (an engine that owes its caller cell ids takes no batch launch)
+    b0 = DeviceBatch(gpu, scans[:1], T(z=0.5), poses[:1])
+    assert eng.integrate_device_batch(b0.arr) == 0  # the first scan creates the layers, alone
+    eng.sync()
+    if eng.last_pipeline() == 1:
+        pytest.skip("this fixture variant sends every scan through the record pools: no small-scan batch, no wait")
+    eng.set_option("dbg_batch", 4)
+    eng.set_option("batch_crop", 0)  # (no crops one launch ahead: every batch waits in its own launch)
+    b = DeviceBatch(gpu, scans[1:], T(z=0.5), poses[1:])
+    assert eng.integrate_device_batch(b.arr) == 0  # (enqueue-only: nothing has run yet)
+    with pytest.raises(RuntimeError, match="fault"):
+        eng.sync()
+    eng.sync()  # reported once
+    eng.set_option("dbg_batch", 0)
+    eng.set_option("batch_crop", 1)
+    for m in (eng, ref):  # FastDEM::reset() = clearAll on both sides, the window back where it started
+        m.clear()
+        m.set_position(0.0, 0.0)
+        m.set_start_index(0, 0)
+    check_batch(gpu, R, eng, ref, scans, T(z=0.5), poses)
+    assert eng.batch_launches()[0] >= 2

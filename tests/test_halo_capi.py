@@ -8,7 +8,7 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "fastdem_amd", "lib", "libfdm_halo.so")
+LIB = os.environ.get("FDM_HALO_LIB") or os.path.join(ROOT, "fastdem_amd", "lib", "libfdm_halo.so")  # (scripts/asan_cpu.sh: the sanitizer build)
 
 
 class Rect(C.Structure):

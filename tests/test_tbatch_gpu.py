@@ -22,6 +22,16 @@ def took_tile_batches(eng):
     return eng.last_pipeline() == 1 and eng.last_batch() >= 2
 
 
+@pytest.fixture(autouse=True)
+def tile_batches_on(gpu):
+    """The pipeline is an engine option, off by default (it does not beat one fused launch per scan):
+    every engine these tests build has it on, four scans to a launch unless a test says otherwise."""
+    saved = dict(gpu.Engine.default_options)
+    gpu.Engine.default_options = {**saved, "tbatch": 1, "tbatch_max": 4}
+    yield
+    gpu.Engine.default_options = saved
+
+
 # ---------------------------------------------------------------------------------------------
 def test_c4_stream_at_full_size_through_the_batch_entry(gpu, R):
     """configs[3] at its stated size: 2 097 152-point scans into the 1200 x 1200 rolling map, an 8-cell shift per
@@ -172,28 +182,23 @@ def test_tile_batches_off_is_the_same_map(gpu, R):
     assert took_tile_batches(a) and not took_tile_batches(b)
 
 
-def test_a_chain_wait_that_runs_out_of_polls_fails_loudly_and_the_engine_recovers(gpu, R):
-    """MState::err: a bin block that waits for the scans ahead of it gives up after a bounded number of polls instead of
-    hanging the GPU.  `dbg_batch` 4 makes every such wait give up at once: the call's next synchronisation point
-    reports FDM_ERR_HIP (sticky until reported), and after reset() the engine integrates correctly again."""
+def test_scouted_flags_of_a_batch_that_never_comes_are_dropped(gpu, R):
+    """The scouts of a launch decide 'scan k has a surviving point' for the NEXT batch of the same call.  Scans whose
+    points are all filtered sit in every position (first / last of a batch, a whole batch), and between two calls the
+    look-ahead is empty (a small launch of scouts runs ahead of each call's first batch)."""
     def fill(c):
-        c.z_min, c.z_max, c.range_min, c.range_max = -2.0, 3.0, 0.0, 60.0
+        c.z_min, c.z_max, c.range_min, c.range_max = -1.0, 2.0, 0.5, 60.0
 
     eng, ref = pair(gpu, R, 32.0, 20.0, 0.05, fill)
     eng.set_option("tbatch_min", 1000)
-    rng = np.random.default_rng(29)
-    scans = [cloud(rng, 60000, 14.0, intensity=True) for _ in range(8)]
-    poses = [T(0.3 * k, 0.1 * k, 0.0) for k in range(8)]
-    eng.set_option("dbg_batch", 4)
-    b = DeviceBatch(gpu, scans, T(z=0.5), poses)
-    assert eng.integrate_device_batch(b.arr) == 0  # (enqueue-only: nothing has run yet)
-    with pytest.raises(RuntimeError, match="fault"):
-        eng.sync()
-    eng.sync()  # reported once
-    eng.set_option("dbg_batch", 0)
-    for m in (eng, ref):  # FastDEM::reset() = clearAll on both sides, the window back where it started
-        m.clear()
-        m.set_position(0.0, 0.0)
-        m.set_start_index(0, 0)
-    check_batch(gpu, R, eng, ref, scans, T(z=0.5), poses)
-    assert took_tile_batches(eng)
+    eng.set_option("tbatch_max", 3)
+    rng = np.random.default_rng(31)
+    for call, dead in enumerate(((2, 3, 4), (0,), (5,), (0, 1, 2, 3, 4, 5), ())):
+        scans, poses = [], []
+        for k in range(6 + call):
+            s = cloud(rng, 40000, 14.0, intensity=True)
+            if k in dead:
+                s["z"] = (s["z"] + 50.0).astype(F32)
+            scans.append(s)
+            poses.append(T(0.45 * (k + 7 * call), -0.15 * k, 0.0))
+        check_batch(gpu, R, eng, ref, scans, T(z=0.4), poses)
