@@ -139,6 +139,8 @@ PROTOTYPES = {
                                              C.POINTER(C.c_double)]),
     "fdm_engine_route_scan": (C.c_int, [_P, C.POINTER(FdmRoutePlan), C.c_uint64, _P, _P, _P, _P, _D, _D, _P, _P]),
     "fdm_engine_integrate_points4_device": (C.c_int, [_P, C.c_uint64, _P, C.c_int, C.c_int, _D, _D]),
+    "fdm_engine_route_scan_soa": (C.c_int, [_P, C.POINTER(FdmRoutePlan), C.c_uint64, _P, _P, _P, _P, _D, _D, _P, _P]),
+    "fdm_engine_integrate_soa4_device": (C.c_int, [_P, C.c_uint64, _P, C.c_int, C.c_int, _D, _D]),
     "fdm_engine_update": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, C.c_double,
                                     C.c_double, C.POINTER(FdmScanStats)]),
     "fdm_engine_update_device": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, C.c_double,
@@ -176,6 +178,8 @@ PROTOTYPES = {
     "fdm_engine_region_pack": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.POINTER(C.c_char_p), C.c_int, _P]),
     "fdm_engine_region_unpack": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+    "fdm_engine_regions_pack": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int, _P]),
+    "fdm_engine_regions_unpack": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int, _P]),
                                            C.POINTER(C.c_char_p), C.c_int, _P]),
     "fdm_engine_capture": (C.c_int, [_P, C.c_int, C.c_int]),
     "fdm_engine_last_preprocessed": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, C.POINTER(C.c_uint64)]),

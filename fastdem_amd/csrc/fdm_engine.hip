@@ -1428,9 +1428,9 @@ int fdm_engine_integrate_async(fdm_engine* e, uint64_t n, const float* x, const 
 }
 
 // ---- scan routing for spatially tiled global maps (include/fdm_engine.h) ----
-int fdm_engine_route_scan(fdm_engine* e, const fdm_route_plan* plan, uint64_t n, const float* dx, const float* dy,
-                          const float* dz, const float* dint, const double Tbs[16], const double Twb[16],
-                          float* d_send, uint32_t* d_counts) {
+static int route_scan_impl(fdm_engine* e, const fdm_route_plan* plan, uint64_t n, const float* dx, const float* dy,
+                           const float* dz, const float* dint, const double Tbs[16], const double Twb[16],
+                           float* d_send, uint32_t* d_counts, bool soa) {
   if (!e || !plan || !Tbs || !Twb || !d_counts) return fail(FDM_ERR_INVALID, "null argument");
   if (plan->world < 1 || plan->world > kMaxRanks || plan->grid_rows * plan->grid_cols != plan->world)
     return fail(FDM_ERR_INVALID, "route plan: 1 .. 16 ranks in a grid_rows x grid_cols grid");
@@ -1470,14 +1470,45 @@ int fdm_engine_route_scan(fdm_engine* e, const fdm_route_plan* plan, uint64_t n,
     HIPCK(hipGetLastError());
   }
   hipLaunchKernelGGL(k_route_scan, dim3(cols), dim3(1024), 0, e->stream, e->d_route_cnt, blocks, R.world, d_counts);
-  hipLaunchKernelGGL(k_route_base, dim3(1), dim3(64), 0, e->stream, d_counts, R.world, base);
+  hipLaunchKernelGGL(k_route_base, dim3(1), dim3(64), 0, e->stream, d_counts, R.world, base, soa ? 1 : 0);
   HIPCK(hipGetLastError());
   if (blocks) {
-    hipLaunchKernelGGL(k_route_scatter, dim3(blocks), dim3(256), 0, e->stream, unsigned(n), R.world, e->d_route_owner,
-                       e->d_route_cnt, base, dx, dy, dz, dint, reinterpret_cast<float4*>(d_send));
+    if (soa)
+      hipLaunchKernelGGL(k_route_scatter<true>, dim3(blocks), dim3(256), 0, e->stream, unsigned(n), R.world, e->d_route_owner,
+                         e->d_route_cnt, base, d_counts, dx, dy, dz, dint, reinterpret_cast<float4*>(d_send));
+    else
+      hipLaunchKernelGGL(k_route_scatter<false>, dim3(blocks), dim3(256), 0, e->stream, unsigned(n), R.world, e->d_route_owner,
+                         e->d_route_cnt, base, d_counts, dx, dy, dz, dint, reinterpret_cast<float4*>(d_send));
     HIPCK(hipGetLastError());
   }
   return FDM_OK;
+}
+
+int fdm_engine_route_scan(fdm_engine* e, const fdm_route_plan* plan, uint64_t n, const float* dx, const float* dy,
+                          const float* dz, const float* dint, const double Tbs[16], const double Twb[16],
+                          float* d_send, uint32_t* d_counts) {
+  return route_scan_impl(e, plan, n, dx, dy, dz, dint, Tbs, Twb, d_send, d_counts, false);
+}
+int fdm_engine_route_scan_soa(fdm_engine* e, const fdm_route_plan* plan, uint64_t n, const float* dx, const float* dy,
+                              const float* dz, const float* dint, const double Tbs[16], const double Twb[16],
+                              float* d_send, uint32_t* d_counts) {
+  return route_scan_impl(e, plan, n, dx, dy, dz, dint, Tbs, Twb, d_send, d_counts, true);
+}
+
+int fdm_engine_integrate_soa4_device(fdm_engine* e, uint64_t n, const float* d_block, int has_intensity, int any_in_map,
+                                     const double Tbs[16], const double Twb[16]) {
+  if (!e || !Tbs || !Twb) return fail(FDM_ERR_INVALID, "null argument");
+  if (n && !d_block) return fail(FDM_ERR_INVALID, "null points");
+  if (n >= 0x7FFFFFFFull) return fail(FDM_ERR_INVALID, "point count exceeds 2^31-1");
+  if (n && (reinterpret_cast<uintptr_t>(d_block) & 15u)) return fail(FDM_ERR_INVALID, "share not 16-byte aligned");
+  HIPCK(hipSetDevice(e->device));
+  if (n == 0) return fdm_engine_integrate_points4_device(e, 0, nullptr, has_intensity, any_in_map, Tbs, Twb);
+  ScanParams P;
+  fill_integrate_params(e, P, Tbs, Twb);
+  P.force_inside = any_in_map ? 1 : 0;
+  const size_t stride = (size_t(n) + 3u) & ~size_t(3);  // the share's channel blocks: x | y | z | intensity
+  return enqueue_scan(e, P, n, d_block, d_block + stride, d_block + 2 * stride,
+                      has_intensity ? d_block + 3 * stride : nullptr, nullptr, nullptr);
 }
 
 int fdm_engine_integrate_points4_device(fdm_engine* e, uint64_t n, const float* d_points4, int has_intensity,
@@ -1912,31 +1943,65 @@ int fdm_engine_clear(fdm_engine* e, const char* name) {
   return FDM_OK;
 }
 
-static int region_copy(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, int32_t nc,
-                       const char* const* names, int n_layers, float* d_buf, int to_buf) {
-  if (!e || !names || !d_buf) return fail(FDM_ERR_INVALID, "null argument");
-  if (nr <= 0 || nc <= 0 || r0 < 0 || c0 < 0 || r0 + nr > e->G.s_rows || c0 + nc > e->G.s_cols)
-    return fail(FDM_ERR_INVALID, "region outside the stored window");
+// One launch for `n_rects` rectangles x `n_layers` layers (k_regions_copy); more than kRegionRects / kRegionLayers of
+// either: several launches.
+static int regions_copy(fdm_engine* e, int n_rects, const fdm_region* rects, const char* const* names, int n_layers,
+                        float* d_buf, int to_buf) {
+  if (!e || !names || !d_buf || (n_rects && !rects)) return fail(FDM_ERR_INVALID, "null argument");
+  if (n_rects < 0 || n_layers < 0) return fail(FDM_ERR_INVALID, "negative count");
   HIPCK(hipSetDevice(e->device));
+  std::vector<Layer*> L(size_t(std::max(n_layers, 0)));
   for (int k = 0; k < n_layers; ++k) {
-    Layer* l = find_layer(e, names[k]);
-    if (!l) return fail(FDM_ERR_NO_LAYER, std::string("no layer ") + names[k]);
-    hipLaunchKernelGGL(k_region_copy, dim3((nr + 255) / 256, nc), dim3(256), 0, e->stream, lptr(e, *l),
-                       lstride(e, *l), d_buf + size_t(k) * nr * nc, e->G.s_rows, r0, c0, nr, nc, to_buf);
-    HIPCK(hipGetLastError());
+    L[k] = find_layer(e, names[k]);
+    if (!L[k]) return fail(FDM_ERR_NO_LAYER, std::string("no layer ") + names[k]);
+  }
+  for (int q = 0; q < n_rects; ++q) {
+    const fdm_region& r = rects[q];
+    if (r.nr <= 0 || r.nc <= 0 || r.r0 < 0 || r.c0 < 0 || r.r0 + r.nr > e->G.s_rows || r.c0 + r.nc > e->G.s_cols)
+      return fail(FDM_ERR_INVALID, "region outside the stored window");
+  }
+  for (int q0 = 0; q0 < n_rects; q0 += kRegionRects) {
+    const int nq = std::min(kRegionRects, n_rects - q0);
+    for (int l0 = 0; l0 < n_layers; l0 += kRegionLayers) {
+      const int nl = std::min(kRegionLayers, n_layers - l0);
+      RegionArgs A{};
+      size_t max_cells = 0;
+      for (int q = 0; q < nq; ++q) {
+        const fdm_region& r = rects[q0 + q];
+        const size_t cells = size_t(r.nr) * size_t(r.nc);
+        A.r0[q] = r.r0; A.c0[q] = r.c0; A.nr[q] = r.nr; A.nc[q] = r.nc;
+        A.off[q] = r.offset + size_t(l0) * cells;  // (the rectangle's block is layer-major over ALL n_layers)
+        max_cells = std::max(max_cells, cells);
+      }
+      for (int l = 0; l < nl; ++l) { A.layer[l] = lptr(e, *L[l0 + l]); A.es[l] = lstride(e, *L[l0 + l]); }
+      A.n_rects = nq; A.n_layers = nl; A.s_rows = e->G.s_rows; A.to_buf = to_buf;
+      const unsigned gx = unsigned(std::min<size_t>((max_cells + 255) / 256, 1024));
+      hipLaunchKernelGGL(k_regions_copy, dim3(gx, unsigned(nq * nl)), dim3(256), 0, e->stream, A, d_buf);
+      HIPCK(hipGetLastError());
+    }
   }
   return FDM_OK;
 }
 
+int fdm_engine_regions_pack(fdm_engine* e, int32_t n_rects, const fdm_region* rects, const char* const* names,
+                            int n_layers, float* d_buf) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
+  return regions_copy(e, n_rects, rects, names, n_layers, d_buf, 1);
+}
+int fdm_engine_regions_unpack(fdm_engine* e, int32_t n_rects, const fdm_region* rects, const char* const* names,
+                              int n_layers, const float* d_buf) {
+  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
+  return regions_copy(e, n_rects, rects, names, n_layers, const_cast<float*>(d_buf), 0);
+}
 int fdm_engine_region_pack(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, int32_t nc,
                            const char* const* names, int n_layers, float* d_buf) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  return region_copy(e, r0, c0, nr, nc, names, n_layers, d_buf, 1);
+  const fdm_region r{r0, c0, nr, nc, 0};
+  return fdm_engine_regions_pack(e, 1, &r, names, n_layers, d_buf);
 }
 int fdm_engine_region_unpack(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, int32_t nc,
                              const char* const* names, int n_layers, const float* d_buf) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  return region_copy(e, r0, c0, nr, nc, names, n_layers, const_cast<float*>(d_buf), 0);
+  const fdm_region r{r0, c0, nr, nc, 0};
+  return fdm_engine_regions_unpack(e, 1, &r, names, n_layers, d_buf);
 }
 
 int fdm_engine_capture(fdm_engine* e, int preprocessed, int rasterized) {

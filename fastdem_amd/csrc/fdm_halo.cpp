@@ -54,11 +54,46 @@ fdm_rect intersect(const fdm_rect& a, const fdm_rect& b) {
   const int r1 = std::min(a.r0 + a.nr, b.r0 + b.nr), c1 = std::min(a.c0 + a.nc, b.c0 + b.nc);
   return fdm_rect{r0, c0, std::max(0, r1 - r0), std::max(0, c1 - c0)};
 }
+// ---- transport: RCCL unless the host installed its own (include/fdm_halo.h) ----
+fdm_halo_transport g_transport{};
+bool g_custom = false;
+int comm_all_gather(void* comm, const void* d_send, void* d_recv, size_t bytes, hipStream_t stream) {
+  if (g_custom) return g_transport.all_gather(comm, d_send, d_recv, bytes, stream) ? fail(FDM_ERR_HIP, "transport: all_gather") : FDM_OK;
+  const ncclResult_t r = ncclAllGather(d_send, d_recv, bytes, ncclUint8, static_cast<ncclComm_t>(comm), stream);
+  return r == ncclSuccess ? FDM_OK : fail(FDM_ERR_HIP, std::string("ncclAllGather: ") + ncclGetErrorString(r));
+}
+int comm_group_start(void* comm) {
+  if (g_custom) return g_transport.group_start(comm) ? fail(FDM_ERR_HIP, "transport: group_start") : FDM_OK;
+  const ncclResult_t r = ncclGroupStart();
+  return r == ncclSuccess ? FDM_OK : fail(FDM_ERR_HIP, std::string("ncclGroupStart: ") + ncclGetErrorString(r));
+}
+int comm_send(void* comm, const void* d_buf, size_t bytes, int peer, hipStream_t stream) {
+  if (g_custom) return g_transport.send(comm, d_buf, bytes, peer, stream) ? fail(FDM_ERR_HIP, "transport: send") : FDM_OK;
+  const ncclResult_t r = ncclSend(d_buf, bytes, ncclUint8, peer, static_cast<ncclComm_t>(comm), stream);
+  return r == ncclSuccess ? FDM_OK : fail(FDM_ERR_HIP, std::string("ncclSend: ") + ncclGetErrorString(r));
+}
+int comm_recv(void* comm, void* d_buf, size_t bytes, int peer, hipStream_t stream) {
+  if (g_custom) return g_transport.recv(comm, d_buf, bytes, peer, stream) ? fail(FDM_ERR_HIP, "transport: recv") : FDM_OK;
+  const ncclResult_t r = ncclRecv(d_buf, bytes, ncclUint8, peer, static_cast<ncclComm_t>(comm), stream);
+  return r == ncclSuccess ? FDM_OK : fail(FDM_ERR_HIP, std::string("ncclRecv: ") + ncclGetErrorString(r));
+}
+int comm_group_end(void* comm, hipStream_t stream) {
+  if (g_custom) return g_transport.group_end(comm, stream) ? fail(FDM_ERR_HIP, "transport: group_end") : FDM_OK;
+  const ncclResult_t r = ncclGroupEnd();
+  return r == ncclSuccess ? FDM_OK : fail(FDM_ERR_HIP, std::string("ncclGroupEnd: ") + ncclGetErrorString(r));
+}
+bool have_comm(void* comm) { return g_custom || comm != nullptr; }
+uint64_t pad4(uint64_t v) { return (v + 3u) & ~uint64_t(3); }
 }  // namespace
 
 extern "C" {
 
 const char* fdm_halo_last_error(void) { return g_err.c_str(); }
+
+void fdm_halo_set_transport(const fdm_halo_transport* t) {
+  g_custom = t != nullptr;
+  g_transport = t ? *t : fdm_halo_transport{};
+}
 
 int fdm_tile_plan_make(int32_t rank, int32_t world, int32_t rows, int32_t cols, int32_t halo, fdm_tile_plan* out) {
   if (!out) return fail(FDM_ERR_INVALID, "null plan");
@@ -117,48 +152,47 @@ int64_t fdm_halo_exchange(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p
                           int32_t n_names, float* d_ws, uint64_t ws_bytes) {
   if (!e || !p || !names) return fail(FDM_ERR_INVALID, "null argument");
   if ((p->n_sends == 0 && p->n_recvs == 0) || n_names <= 0) return 0;  // (a plan may name the rank itself as a neighbour)
-  if (!nccl_comm || !d_ws) return fail(FDM_ERR_INVALID, "null communicator / workspace");
+  if (!have_comm(nccl_comm) || !d_ws) return fail(FDM_ERR_INVALID, "null communicator / workspace");
   if (ws_bytes < fdm_halo_workspace_bytes(p, n_names)) return fail(FDM_ERR_INVALID, "workspace too small");
   hipStream_t stream = static_cast<hipStream_t>(fdm_engine_stream(e));
-  ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);
-  // pack (the first region call launches a held-back update: the map is current)
+  // pack: ONE launch for every strip and layer (the call launches a held-back update first: the map is current)
   float* cur = d_ws;
   float* send_buf[FDM_MAX_NEIGHBOURS];
   float* recv_buf[FDM_MAX_NEIGHBOURS];
+  fdm_region sreg[FDM_MAX_NEIGHBOURS], rreg[FDM_MAX_NEIGHBOURS];
   int64_t sent = 0;
   for (int k = 0; k < p->n_sends; ++k) {
     const fdm_rect& r = p->send_rect[k];
     send_buf[k] = cur;
+    sreg[k] = fdm_region{r.r0 - p->stored.r0, r.c0 - p->stored.c0, r.nr, r.nc, uint64_t(cur - d_ws)};
     cur += size_t(r.nr) * size_t(r.nc) * size_t(n_names);
-    if (int rc = fdm_engine_region_pack(e, r.r0 - p->stored.r0, r.c0 - p->stored.c0, r.nr, r.nc, names, n_names,
-                                        send_buf[k]))
-      return fail(rc, std::string("region_pack: ") + fdm_last_error());
     sent += int64_t(r.nr) * r.nc * n_names * int64_t(sizeof(float));
   }
+  if (p->n_sends)
+    if (int rc = fdm_engine_regions_pack(e, p->n_sends, sreg, names, n_names, d_ws))
+      return fail(rc, std::string("regions_pack: ") + fdm_last_error());
   for (int k = 0; k < p->n_recvs; ++k) {
     const fdm_rect& r = p->recv_rect[k];
     recv_buf[k] = cur;
+    rreg[k] = fdm_region{r.r0 - p->stored.r0, r.c0 - p->stored.c0, r.nr, r.nc, uint64_t(cur - d_ws)};
     cur += size_t(r.nr) * size_t(r.nc) * size_t(n_names);
   }
   // one group: xGMI is point-to-point, a strip is ~10^2 KB — latency-bound, so everything leaves together
-  ncclResult_t r = ncclGroupStart();
-  for (int k = 0; r == ncclSuccess && k < p->n_recvs; ++k) {
+  if (int rc = comm_group_start(nccl_comm)) return rc;
+  int rc_x = FDM_OK;
+  for (int k = 0; rc_x == FDM_OK && k < p->n_recvs; ++k) {
     const fdm_rect& q = p->recv_rect[k];
-    r = ncclRecv(recv_buf[k], size_t(q.nr) * size_t(q.nc) * size_t(n_names), ncclFloat, p->recv_rank[k], comm, stream);
+    rc_x = comm_recv(nccl_comm, recv_buf[k], size_t(q.nr) * size_t(q.nc) * size_t(n_names) * 4u, p->recv_rank[k], stream);
   }
-  for (int k = 0; r == ncclSuccess && k < p->n_sends; ++k) {
+  for (int k = 0; rc_x == FDM_OK && k < p->n_sends; ++k) {
     const fdm_rect& q = p->send_rect[k];
-    r = ncclSend(send_buf[k], size_t(q.nr) * size_t(q.nc) * size_t(n_names), ncclFloat, p->send_rank[k], comm, stream);
+    rc_x = comm_send(nccl_comm, send_buf[k], size_t(q.nr) * size_t(q.nc) * size_t(n_names) * 4u, p->send_rank[k], stream);
   }
-  const ncclResult_t r2 = ncclGroupEnd();
-  if (r != ncclSuccess || r2 != ncclSuccess)
-    return fail(FDM_ERR_HIP, std::string("nccl send/recv: ") + ncclGetErrorString(r != ncclSuccess ? r : r2));
-  for (int k = 0; k < p->n_recvs; ++k) {
-    const fdm_rect& q = p->recv_rect[k];
-    if (int rc = fdm_engine_region_unpack(e, q.r0 - p->stored.r0, q.c0 - p->stored.c0, q.nr, q.nc, names, n_names,
-                                          recv_buf[k]))
-      return fail(rc, std::string("region_unpack: ") + fdm_last_error());
-  }
+  const int rc_e = comm_group_end(nccl_comm, stream);
+  if (rc_x || rc_e) return rc_x ? rc_x : rc_e;
+  if (p->n_recvs)
+    if (int rc = fdm_engine_regions_unpack(e, p->n_recvs, rreg, names, n_names, d_ws))
+      return fail(rc, std::string("regions_unpack: ") + fdm_last_error());
   return sent;
 }
 
@@ -182,59 +216,71 @@ void fdm_tile_plan_route(const fdm_tile_plan* p, fdm_route_plan* out) {
 
 int fdm_halo_gather_counts(fdm_engine* e, void* nccl_comm, const uint32_t* d_counts, uint32_t* d_matrix,
                            uint32_t* h_matrix, int32_t world) {
-  if (!e || !nccl_comm || !d_counts || !d_matrix || !h_matrix || world < 1) return fail(FDM_ERR_INVALID, "null argument");
+  if (!e || !have_comm(nccl_comm) || !d_counts || !d_matrix || !h_matrix || world < 1) return fail(FDM_ERR_INVALID, "null argument");
   hipStream_t stream = static_cast<hipStream_t>(fdm_engine_stream(e));
   const size_t per = size_t(world) + 2;
-  const ncclResult_t r = ncclAllGather(d_counts, d_matrix, per, ncclUint32, static_cast<ncclComm_t>(nccl_comm), stream);
-  if (r != ncclSuccess) return fail(FDM_ERR_HIP, std::string("ncclAllGather: ") + ncclGetErrorString(r));
+  if (int rc = comm_all_gather(nccl_comm, d_counts, d_matrix, per * 4u, stream)) return rc;
   if (hipMemcpyAsync(h_matrix, d_matrix, per * size_t(world) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess ||
       hipStreamSynchronize(stream) != hipSuccess)
     return fail(FDM_ERR_HIP, "reading the routing counts back");
   return FDM_OK;
 }
 
-int fdm_halo_route_exchange(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p, const float* d_send,
-                            const uint32_t* h_matrix, float* d_recv, uint64_t recv_capacity, uint64_t* n_recv,
-                            int32_t* any_in_map) {
+namespace {
+// soa: shares are four channel blocks of pad4(count) floats (fdm_engine_route_scan_soa) and the rank's own share
+// stays in the send buffer; else 16-byte records, the own share copied into its place among the sources.
+int route_exchange_impl(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p, const float* d_send,
+                        const uint32_t* h_matrix, float* d_recv, uint64_t recv_capacity, uint64_t* n_recv,
+                        int32_t* any_in_map, bool soa) {
   if (!e || !p || !h_matrix || !n_recv || !any_in_map) return fail(FDM_ERR_INVALID, "null argument");
   const int W = p->world, me = p->rank;
   const size_t per = size_t(W) + 2;
+  auto rows = [&](uint64_t v) { return soa ? pad4(v) : v; };  // 16-byte rows a share of v points takes
   uint64_t total = 0, inside = 0;
   for (int src = 0; src < W; ++src) {
-    total += h_matrix[size_t(src) * per + size_t(me)];
+    if (!(soa && src == me)) total += rows(h_matrix[size_t(src) * per + size_t(me)]);
     inside += h_matrix[size_t(src) * per + size_t(W) + 1];
   }
   *n_recv = total;
   *any_in_map = inside ? 1 : 0;
   if (total > recv_capacity) return fail(FDM_ERR_INVALID, "receive buffer too small for the routed points");
-  if (W > 1 && !nccl_comm) return fail(FDM_ERR_INVALID, "null communicator");
+  if (W > 1 && !have_comm(nccl_comm)) return fail(FDM_ERR_INVALID, "null communicator");
   if ((total && !d_recv) || !d_send) return fail(FDM_ERR_INVALID, "null point buffer");
   hipStream_t stream = static_cast<hipStream_t>(fdm_engine_stream(e));
-  ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);
   // where each peer's share starts: in my send buffer (owner-major) / in my receive buffer (source-major)
   uint64_t send_off = 0, recv_off = 0;
-  ncclResult_t r = ncclSuccess;
+  int rc = FDM_OK;
   bool grouped = false;
-  for (int peer = 0; peer < W; ++peer) {
-    const uint64_t ns = h_matrix[size_t(me) * per + size_t(peer)], nr = h_matrix[size_t(peer) * per + size_t(me)];
+  for (int peer = 0; peer < W && rc == FDM_OK; ++peer) {
+    const uint64_t ns = rows(h_matrix[size_t(me) * per + size_t(peer)]), nr = rows(h_matrix[size_t(peer) * per + size_t(me)]);
     if (peer == me) {
-      if (ns && hipMemcpyAsync(d_recv + 4 * recv_off, d_send + 4 * send_off, ns * 16, hipMemcpyDeviceToDevice, stream) !=
-                    hipSuccess)
+      if (!soa && ns && hipMemcpyAsync(d_recv + 4 * recv_off, d_send + 4 * send_off, ns * 16, hipMemcpyDeviceToDevice, stream) !=
+                            hipSuccess)
         return fail(FDM_ERR_HIP, "copying the rank's own share");
-    } else if (ns || nr) {
-      if (!grouped) { r = ncclGroupStart(); grouped = true; }
-      if (r == ncclSuccess && nr) r = ncclRecv(d_recv + 4 * recv_off, size_t(nr) * 4, ncclFloat, peer, comm, stream);
-      if (r == ncclSuccess && ns) r = ncclSend(d_send + 4 * send_off, size_t(ns) * 4, ncclFloat, peer, comm, stream);
+      send_off += ns;
+      if (!soa) recv_off += nr;
+      continue;
+    }
+    if (ns || nr) {
+      if (!grouped) { rc = comm_group_start(nccl_comm); grouped = true; }
+      if (rc == FDM_OK && nr) rc = comm_recv(nccl_comm, d_recv + 4 * recv_off, size_t(nr) * 16u, peer, stream);
+      if (rc == FDM_OK && ns) rc = comm_send(nccl_comm, d_send + 4 * send_off, size_t(ns) * 16u, peer, stream);
     }
     send_off += ns;
     recv_off += nr;
   }
   if (grouped) {
-    const ncclResult_t r2 = ncclGroupEnd();
-    if (r != ncclSuccess || r2 != ncclSuccess)
-      return fail(FDM_ERR_HIP, std::string("nccl send/recv: ") + ncclGetErrorString(r != ncclSuccess ? r : r2));
+    const int rc2 = comm_group_end(nccl_comm, stream);
+    if (rc || rc2) return rc ? rc : rc2;
   }
-  return FDM_OK;
+  return rc;
+}
+}  // namespace
+
+int fdm_halo_route_exchange(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p, const float* d_send,
+                            const uint32_t* h_matrix, float* d_recv, uint64_t recv_capacity, uint64_t* n_recv,
+                            int32_t* any_in_map) {
+  return route_exchange_impl(e, nccl_comm, p, d_send, h_matrix, d_recv, recv_capacity, n_recv, any_in_map, false);
 }
 
 // ---- the routed step as ONE call (the host loop of tiling.RoutedScan in C: no interpreter between the launches) ----
@@ -261,6 +307,7 @@ struct fdm_routed_ws {
   float* d_recv = nullptr;      // [recv_cap] x 16 B, source-major
   uint32_t* h_matrix = nullptr; // [world][world + 2] of the last finished scan (plain host memory)
   bool obstacle_dirty = true;   // (sensors mode) the tile's obstacle layer may hold non-NaN cells
+  bool single_pending = false;  // world == 1: a submitted scan whose matrix has not been handed out yet
 };
 
 namespace {
@@ -271,7 +318,9 @@ int routed_front(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p, const f
   const size_t per = size_t(W) + 2, row = per + 64;
   hipStream_t stream = static_cast<hipStream_t>(fdm_engine_stream(e));
   // 1. this rank's slice, partitioned by owner (three small kernels); its counters land in the row
-  if (int rc = fdm_engine_route_scan(e, route, n, d_x, d_y, d_z, d_i, Tbs, Twb, s.d_send, s.d_row))
+  // (N scans, one per rank: shares as channel blocks the owners read in place; one scan cut into slices: records)
+  if (int rc = sensors ? fdm_engine_route_scan_soa(e, route, n, d_x, d_y, d_z, d_i, Tbs, Twb, s.d_send, s.d_row)
+                       : fdm_engine_route_scan(e, route, n, d_x, d_y, d_z, d_i, Tbs, Twb, s.d_send, s.d_row))
     return fail(rc, std::string("fdm_engine_route_scan: ") + fdm_last_error());
   // 2. the row travels with the rank's transforms (N-sensor mode: the owners need every source's)
   for (int k = 0; k < 16; ++k) { s.h_pose[k] = s.T[k] = Tbs[k]; s.h_pose[16 + k] = s.T[16 + k] = Twb[k]; }
@@ -280,10 +329,8 @@ int routed_front(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p, const f
   if (hipMemcpyAsync(s.d_row + per, s.h_pose, 32 * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess)
     return fail(FDM_ERR_HIP, "uploading the transforms");
   // 3. one small all-gather, ONE host read-back (the sizes of the exchange are host-side arguments)
-  if (W > 1) {
-    const ncclResult_t r = ncclAllGather(s.d_row, s.d_table, row, ncclUint32, static_cast<ncclComm_t>(nccl_comm), stream);
-    if (r != ncclSuccess) return fail(FDM_ERR_HIP, std::string("ncclAllGather: ") + ncclGetErrorString(r));
-  }
+  if (W > 1)
+    if (int rc = comm_all_gather(nccl_comm, s.d_row, s.d_table, row * 4u, stream)) return rc;
   if (hipMemcpyAsync(s.h_table, W > 1 ? s.d_table : s.d_row, row * 4 * size_t(W), hipMemcpyDeviceToHost, stream) != hipSuccess ||
       hipEventRecord(s.ready, stream) != hipSuccess)
     return fail(FDM_ERR_HIP, "reading the routing table back");
@@ -302,8 +349,10 @@ int routed_back(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p, fdm_rout
     for (size_t j = 0; j < per; ++j) w->h_matrix[size_t(src) * per + j] = s.h_table[size_t(src) * row + j];
   if (h_matrix_out) std::copy(w->h_matrix, w->h_matrix + size_t(W) * per, h_matrix_out);
   // 4. the points travel to their owners
+  const bool soa = s.sensors != 0;
   uint64_t total = 0;
-  for (int src = 0; src < W; ++src) total += w->h_matrix[size_t(src) * per + size_t(me)];
+  for (int src = 0; src < W; ++src)
+    if (!(soa && src == me)) total += soa ? pad4(w->h_matrix[size_t(src) * per + size_t(me)]) : w->h_matrix[size_t(src) * per + size_t(me)];
   if (total > w->recv_cap) {
     if (w->d_recv) {
       if (hipStreamSynchronize(static_cast<hipStream_t>(fdm_engine_stream(e))) != hipSuccess)  // (an earlier integrate may read it)
@@ -317,7 +366,7 @@ int routed_back(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p, fdm_rout
   }
   uint64_t n_recv = 0;
   int32_t any_in_map = 0;
-  if (int rc = fdm_halo_route_exchange(e, nccl_comm, p, s.d_send, w->h_matrix, w->d_recv, w->recv_cap, &n_recv, &any_in_map))
+  if (int rc = route_exchange_impl(e, nccl_comm, p, s.d_send, w->h_matrix, w->d_recv, w->recv_cap, &n_recv, &any_in_map, soa))
     return rc;
   // 5. the owners integrate: the logical scan as one, or — N sensors — every source with its own transforms, in rank order
   if (!s.sensors) {
@@ -325,18 +374,21 @@ int routed_back(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p, fdm_rout
       return fail(rc, std::string("fdm_engine_integrate_points4_device: ") + fdm_last_error());
     return FDM_OK;
   }
-  uint64_t off = 0;
+  // (shares: the sources' in the receive buffer in rank order, this rank's own where the routing kernels left it)
+  uint64_t off = 0, own_off = 0;
+  for (int d = 0; d < me; ++d) own_off += pad4(w->h_matrix[size_t(me) * per + size_t(d)]);
   for (int src = 0; src < W; ++src) {
     const uint64_t ns = w->h_matrix[size_t(src) * per + size_t(me)];
     const bool seen = w->h_matrix[size_t(src) * per + size_t(W) + 1] > 0;  // that scan observed a cell somewhere
     if (ns || (seen && w->obstacle_dirty)) {  // (else: nothing for this tile and its obstacle layer is clear already)
       double T[32];
       std::memcpy(T, s.h_table + size_t(src) * row + per, sizeof(T));
-      if (int rc = fdm_engine_integrate_points4_device(e, ns, ns ? w->d_recv + 4 * off : w->d_recv, s.has_i, seen ? 1 : 0, T, T + 16))
-        return fail(rc, std::string("fdm_engine_integrate_points4_device: ") + fdm_last_error());
+      const float* share = src == me ? s.d_send + 4 * own_off : w->d_recv + 4 * off;
+      if (int rc = fdm_engine_integrate_soa4_device(e, ns, ns ? share : nullptr, s.has_i, seen ? 1 : 0, T, T + 16))
+        return fail(rc, std::string("fdm_engine_integrate_soa4_device: ") + fdm_last_error());
       w->obstacle_dirty = ns > 0;
     }
-    off += ns;
+    if (src != me) off += pad4(ns);
   }
   return FDM_OK;
 }
@@ -346,7 +398,23 @@ int routed_check(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p, const f
   if (!e || !p || !route || !w || !Tbs || !Twb) return fail(FDM_ERR_INVALID, "null argument");
   if (w->world != p->world) return fail(FDM_ERR_INVALID, "workspace of another plan");
   if (n > w->max_points) return fail(FDM_ERR_INVALID, "more points than the workspace holds");
-  if (p->world > 1 && !nccl_comm) return fail(FDM_ERR_INVALID, "null communicator");
+  if (p->world > 1 && !have_comm(nccl_comm)) return fail(FDM_ERR_INVALID, "null communicator");
+  return FDM_OK;
+}
+
+// world == 1: every cell is this rank's, nothing has to be routed — the step IS fdm_engine_integrate_device (the bin
+// kernel drops what the crops and the map reject, as it does for any scan).  The counter matrix is the engine's
+// statistics, read (a wait for the scan) only when the caller asked for it.
+int routed_single(fdm_engine* e, uint64_t n, const float* d_x, const float* d_y, const float* d_z, const float* d_i,
+                  const double* Tbs, const double* Twb, uint32_t* h_matrix_out) {
+  if (int rc = fdm_engine_integrate_device(e, n, d_x, d_y, d_z, d_i, nullptr, nullptr, Tbs, Twb); rc < 0)
+    return fail(rc, std::string("fdm_engine_integrate_device: ") + fdm_last_error());
+  if (h_matrix_out) {
+    fdm_scan_stats st{};
+    const int rc = fdm_engine_last_stats(e, &st);
+    if (rc < 0) return fail(rc, std::string("fdm_engine_last_stats: ") + fdm_last_error());
+    h_matrix_out[0] = st.n_in_map; h_matrix_out[1] = st.n_after_filter; h_matrix_out[2] = st.n_in_map;
+  }
   return FDM_OK;
 }
 }  // namespace
@@ -359,7 +427,7 @@ int fdm_halo_routed_ws_create(const fdm_tile_plan* p, uint64_t max_points, fdm_r
   const size_t row = size_t(p->world) + 2 + 64;
   bool ok = true;
   for (RoutedSlot& s : w->slot) {
-    ok = ok && hipMalloc(reinterpret_cast<void**>(&s.d_send), w->max_points * 16) == hipSuccess &&
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&s.d_send), (w->max_points + 3u * size_t(p->world) + 4u) * 16) == hipSuccess &&
          hipMalloc(reinterpret_cast<void**>(&s.d_row), row * 4) == hipSuccess &&
          hipMalloc(reinterpret_cast<void**>(&s.d_table), row * 4 * size_t(p->world)) == hipSuccess &&
          hipHostMalloc(reinterpret_cast<void**>(&s.h_table), row * 4 * size_t(p->world), hipHostMallocDefault) == hipSuccess &&
@@ -397,6 +465,7 @@ int fdm_halo_routed_step(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p,
                          int32_t sensors, uint32_t* h_matrix_out) {
   if (int rc = routed_check(e, nccl_comm, p, route, w, n, T_base_sensor, T_world_base)) return rc;
   if (int rc = fdm_halo_routed_flush(e, nccl_comm, p, w, nullptr)) return rc;  // (a submitted scan comes first)
+  if (p->world == 1) return routed_single(e, n, d_x, d_y, d_z, d_intensity, T_base_sensor, T_world_base, h_matrix_out);
   RoutedSlot& s = w->slot[w->seq++ & 1u];
   if (int rc = routed_front(e, nccl_comm, p, route, w, s, n, d_x, d_y, d_z, d_intensity, T_base_sensor, T_world_base, sensors))
     return rc;
@@ -408,6 +477,15 @@ int fdm_halo_routed_submit(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* 
                            const float* d_intensity, const double T_base_sensor[16], const double T_world_base[16],
                            int32_t sensors, uint32_t* h_matrix_prev) {
   if (int rc = routed_check(e, nccl_comm, p, route, w, n, T_base_sensor, T_world_base)) return rc;
+  if (p->world == 1) {  // (nothing to overlap: the scan is enqueued at once; its matrix is the engine's statistics)
+    if (h_matrix_prev && w->single_pending) {
+      fdm_scan_stats st{};
+      if (int rc = fdm_engine_last_stats(e, &st); rc < 0) return fail(rc, std::string("fdm_engine_last_stats: ") + fdm_last_error());
+      h_matrix_prev[0] = st.n_in_map; h_matrix_prev[1] = st.n_after_filter; h_matrix_prev[2] = st.n_in_map;
+    }
+    w->single_pending = true;
+    return routed_single(e, n, d_x, d_y, d_z, d_intensity, T_base_sensor, T_world_base, nullptr);
+  }
   RoutedSlot& s = w->slot[w->seq & 1u];
   RoutedSlot& prev = w->slot[(w->seq & 1u) ^ 1u];
   ++w->seq;
@@ -422,6 +500,15 @@ int fdm_halo_routed_submit(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* 
 
 int fdm_halo_routed_flush(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* p, fdm_routed_ws* w, uint32_t* h_matrix_out) {
   if (!e || !p || !w) return fail(FDM_ERR_INVALID, "null argument");
+  if (p->world == 1 && w->single_pending) {
+    w->single_pending = false;
+    if (h_matrix_out) {
+      fdm_scan_stats st{};
+      if (int rc = fdm_engine_last_stats(e, &st); rc < 0) return fail(rc, std::string("fdm_engine_last_stats: ") + fdm_last_error());
+      h_matrix_out[0] = st.n_in_map; h_matrix_out[1] = st.n_after_filter; h_matrix_out[2] = st.n_in_map;
+    }
+    return FDM_OK;
+  }
   // (oldest first: with submit() at most one slot is pending)
   for (unsigned k = 0; k < 2u; ++k) {
     RoutedSlot& s = w->slot[(w->seq + k) & 1u];

@@ -1196,4 +1196,29 @@ __global__ void k_region_copy(float* __restrict__ layer, int es, float* __restri
   if (to_buf) *b = *a; else *a = *b;
 }
 
+// The same for SEVERAL rectangles and layers in one launch (a halo exchange packs <= 8 strips x every visible layer:
+// one launch instead of one per strip and layer).  blockIdx.y = rectangle * n_layers + layer; the buffer holds the
+// rectangles one after the other, each layer-major, each rectangle column-major — the layout of k_region_copy.
+constexpr int kRegionRects = 8, kRegionLayers = 24;
+struct RegionArgs {
+  int r0[kRegionRects], c0[kRegionRects], nr[kRegionRects], nc[kRegionRects];
+  unsigned long long off[kRegionRects];  // first float of the rectangle's block in the buffer
+  float* layer[kRegionLayers];
+  int es[kRegionLayers];
+  int n_rects, n_layers, s_rows, to_buf;
+};
+__global__ void k_regions_copy(const RegionArgs A, float* __restrict__ buf) {
+  const int q = blockIdx.y / A.n_layers, l = blockIdx.y % A.n_layers;
+  const int nr = A.nr[q], nc = A.nc[q];
+  const size_t cells = size_t(nr) * size_t(nc);
+  float* const lay = A.layer[l];
+  const size_t es = size_t(A.es[l]);
+  float* const b0 = buf + A.off[q] + size_t(l) * cells;
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < cells; i += size_t(gridDim.x) * blockDim.x) {
+    const int c = int(i / size_t(nr)), r = int(i % size_t(nr));
+    float* a = lay + (size_t(A.c0[q] + c) * A.s_rows + size_t(A.r0[q] + r)) * es;
+    if (A.to_buf) b0[i] = *a; else *a = b0[i];
+  }
+}
+
 }  // namespace fdm

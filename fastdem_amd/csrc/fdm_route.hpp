@@ -115,16 +115,24 @@ __global__ __launch_bounds__(1024) void k_route_scan(uint32_t* __restrict__ cnt,
   if (threadIdx.x == 0) totals[col] = s_run;
 }
 // the owners' shares in the send buffer start where the shares of the lower ranks end
-__global__ void k_route_base(const uint32_t* __restrict__ totals, int world, uint32_t* __restrict__ base) {
+// (soa: every share is padded to a multiple of four points, so that each of its four channels starts 16-byte aligned)
+__global__ void k_route_base(const uint32_t* __restrict__ totals, int world, uint32_t* __restrict__ base, int soa) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     unsigned acc = 0;
-    for (int d = 0; d < world; ++d) { base[d] = acc; acc += totals[d]; }
+    for (int d = 0; d < world; ++d) { base[d] = acc; acc += soa ? ((totals[d] + 3u) & ~3u) : totals[d]; }
   }
 }
 
+// SOA: the share of owner d is four channel blocks x | y | z | intensity of P_d = pad4(count_d) floats each, starting
+// at float 4 * base[d] — what the bin kernels read in place (fdm_engine_integrate_soa4_device): no de-interleave pass
+// on the receiving side, and the rank's own share is never copied.  AoS ({x, y, z, intensity} records): the layout a
+// scan cut into SLICES needs (its owners integrate all sources as ONE scan: the records of consecutive sources must
+// be contiguous).
+template <bool SOA>
 __global__ __launch_bounds__(256) void k_route_scatter(unsigned n, int world, const uint8_t* __restrict__ owner_in,
                                                        const uint32_t* __restrict__ off /* scanned cnt */,
-                                                       const uint32_t* __restrict__ base, const float* __restrict__ px,
+                                                       const uint32_t* __restrict__ base,
+                                                       const uint32_t* __restrict__ totals, const float* __restrict__ px,
                                                        const float* __restrict__ py, const float* __restrict__ pz,
                                                        const float* __restrict__ pint, float4* __restrict__ send) {
   __shared__ unsigned s_cnt[4][kMaxRanks];
@@ -140,8 +148,17 @@ __global__ __launch_bounds__(256) void k_route_scatter(unsigned n, int world, co
   if (owner == kNoOwner) return;
   unsigned before = 0;
   for (unsigned w = 0; w < wave; ++w) before += s_cnt[w][owner];
-  const unsigned dst = base[owner] + off[size_t(blockIdx.x) * unsigned(world + 2) + owner] + before + rank_in_wave;
-  send[dst] = make_float4(px[i], py[i], pz[i], pint ? pint[i] : 0.0f);
+  const unsigned j = off[size_t(blockIdx.x) * unsigned(world + 2) + owner] + before + rank_in_wave;  // place inside the share
+  if (SOA) {
+    const unsigned P = (totals[owner] + 3u) & ~3u;
+    float* const blk = reinterpret_cast<float*>(send) + 4u * size_t(base[owner]);
+    blk[j] = px[i];
+    blk[size_t(P) + j] = py[i];
+    blk[2u * size_t(P) + j] = pz[i];
+    blk[3u * size_t(P) + j] = pint ? pint[i] : 0.0f;
+  } else {
+    send[base[owner] + j] = make_float4(px[i], py[i], pz[i], pint ? pint[i] : 0.0f);
+  }
 }
 
 // received points {x, y, z, intensity} -> the SoA channels the bin kernels read

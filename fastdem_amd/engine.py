@@ -212,13 +212,15 @@ class Engine:
         return self._lib.fdm_engine_integrate_device_batch_timed(self._h, len(scans) if count is None else count, scans)
 
     # -- scan routing for spatially tiled global maps (fdm_route.hpp) --
-    def route_scan(self, plan, x, y, z, T_base_sensor, T_world_base, send, counts, intensity=None):
+    def route_scan(self, plan, x, y, z, T_base_sensor, T_world_base, send, counts, intensity=None, soa=False):
         """Partition this rank's slice (torch device tensors) by owner rank into `send` ([n, 4] float32 device
-        tensor: x, y, z, intensity records) and leave the per-owner counts + n_after_filter + n_in_map in
+        tensor: x, y, z, intensity records; `soa`: per owner four channel blocks of pad4(count) floats, the buffer
+        then needs n + 3 * world rows) and leave the per-owner counts + n_after_filter + n_in_map in
         `counts` (device int32 tensor of world + 2).  Enqueue-only."""
         self.wait_torch()
         tbs, twb = _colmajor16(T_base_sensor), _colmajor16(T_world_base)
-        _ck(self._lib.fdm_engine_route_scan(
+        fn = self._lib.fdm_engine_route_scan_soa if soa else self._lib.fdm_engine_route_scan
+        _ck(fn(
             self._h, C.byref(plan), x.numel(), _dptr(x), _dptr(y), _dptr(z), _dptr(intensity),
             tbs.ctypes.data_as(C.POINTER(C.c_double)), twb.ctypes.data_as(C.POINTER(C.c_double)),
             _dptr(send), _dptr(counts)))
@@ -229,6 +231,15 @@ class Engine:
         tbs, twb = _colmajor16(T_base_sensor), _colmajor16(T_world_base)
         _ck(self._lib.fdm_engine_integrate_points4_device(
             self._h, int(n), _dptr(points4) if n else None, int(bool(has_intensity)), int(bool(any_in_map)),
+            tbs.ctypes.data_as(C.POINTER(C.c_double)), twb.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def integrate_soa4_device(self, share, n, T_base_sensor, T_world_base, has_intensity=True, any_in_map=True):
+        """FastDEM::integrate of one routed share (route_scan(soa=True)): `share` = flat float32 device tensor holding
+        x | y | z | intensity, pad4(n) floats each, read in place.  Enqueue-only."""
+        self.wait_torch()
+        tbs, twb = _colmajor16(T_base_sensor), _colmajor16(T_world_base)
+        _ck(self._lib.fdm_engine_integrate_soa4_device(
+            self._h, int(n), _dptr(share) if n else None, int(bool(has_intensity)), int(bool(any_in_map)),
             tbs.ctypes.data_as(C.POINTER(C.c_double)), twb.ctypes.data_as(C.POINTER(C.c_double))))
 
     def update(self, x, y, z, robot_xy=(0.0, 0.0), z_var=None, intensity=None, rgb=None):

@@ -54,8 +54,111 @@ def load():
                                          P, P, P, P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, P]
     lib.fdm_halo_routed_submit.argtypes = lib.fdm_halo_routed_step.argtypes
     lib.fdm_halo_routed_flush.argtypes = [P, P, C.POINTER(FdmTilePlan), P, P]
+    lib.fdm_halo_workspace_bytes.argtypes = [C.POINTER(FdmTilePlan), C.c_int32]
+    lib.fdm_halo_workspace_bytes.restype = C.c_uint64
+    lib.fdm_halo_exchange.argtypes = [P, P, C.POINTER(FdmTilePlan), C.POINTER(C.c_char_p), C.c_int32, P, C.c_uint64]
+    lib.fdm_halo_exchange.restype = C.c_int64
+    lib.fdm_halo_set_transport.argtypes = [C.POINTER(FdmHaloTransport)]
+    lib.fdm_halo_set_transport.restype = None
     _lib = lib
     return lib
+
+
+# ---- transport (include/fdm_halo.h): RCCL by default; tests install a host-staged one ----
+_AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+_GS = C.CFUNCTYPE(C.c_int, C.c_void_p)
+_SR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p)
+_GE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+
+
+class FdmHaloTransport(C.Structure):  # fdm_halo_transport
+    _fields_ = [("all_gather", _AG), ("group_start", _GS), ("send", _SR), ("recv", _SR), ("group_end", _GE)]
+
+
+class HostStagedTransport:
+    """libfdm_halo's collectives over a torch.distributed group that only moves HOST memory (gloo): device buffers are
+    staged through the host around every operation.  For the tests: it lets the library's multi-rank code (per-peer
+    offsets, one group per exchange, source order) run with real peers on a box with ONE GPU, where RCCL refuses two ranks
+    on one device.  Every operation synchronises the engine's stream — correct, slow, not for production."""
+
+    def __init__(self, dist, group=None):
+        import torch
+        self.dist, self.group, self.torch = dist, group, torch
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self.ops = None
+        self.calls = {"all_gather": 0, "send": 0, "recv": 0, "groups": 0}
+        self._cb = FdmHaloTransport(_AG(self._all_gather), _GS(self._group_start), _SR(self._send), _SR(self._recv),
+                                    _GE(self._group_end))
+
+    def install(self):
+        load().fdm_halo_set_transport(C.byref(self._cb))
+
+    @staticmethod
+    def uninstall():
+        load().fdm_halo_set_transport(None)
+
+    def _to_host(self, d_ptr, nbytes, stream):
+        self.hip.hipStreamSynchronize(stream)
+        t = self.torch.empty(nbytes, dtype=self.torch.uint8)
+        assert self.hip.hipMemcpy(t.data_ptr(), d_ptr, nbytes, 2) == 0  # hipMemcpyDeviceToHost
+        return t
+
+    def _to_device(self, d_ptr, t):
+        assert self.hip.hipMemcpy(d_ptr, t.data_ptr(), t.numel(), 1) == 0  # hipMemcpyHostToDevice
+
+    def _all_gather(self, comm, d_send, d_recv, nbytes, stream):
+        try:
+            self.calls["all_gather"] += 1
+            mine = self._to_host(d_send, nbytes, stream)
+            W = self.dist.get_world_size(self.group)
+            parts = [self.torch.empty(nbytes, dtype=self.torch.uint8) for _ in range(W)]
+            self.dist.all_gather(parts, mine, group=self.group)
+            self._to_device(d_recv, self.torch.cat(parts))
+            return 0
+        except Exception:  # (no exception may cross the C boundary)
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def _group_start(self, comm):
+        self.ops = []
+        self.calls["groups"] += 1
+        return 0
+
+    def _send(self, comm, d_buf, nbytes, peer, stream):
+        try:
+            self.calls["send"] += 1
+            self.ops.append(("send", self._to_host(d_buf, nbytes, stream), peer, None))
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def _recv(self, comm, d_buf, nbytes, peer, stream):
+        self.calls["recv"] += 1
+        self.ops.append(("recv", self.torch.empty(nbytes, dtype=self.torch.uint8), peer, d_buf))
+        return 0
+
+    def _group_end(self, comm, stream):
+        try:
+            p2p = [self.dist.P2POp(self.dist.isend if kind == "send" else self.dist.irecv, t, peer, self.group)
+                   for kind, t, peer, _ in self.ops]
+            if p2p:
+                for req in self.dist.batch_isend_irecv(p2p):
+                    req.wait()
+            self.hip.hipStreamSynchronize(stream)
+            for kind, t, _, d_buf in self.ops:
+                if kind == "recv":
+                    self._to_device(d_buf, t)
+            self.ops = None
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
 
 
 def _rccl():
@@ -127,11 +230,13 @@ class NativeRoutedScan:
         except Exception:
             pass
 
-    def integrate(self, x, y, z, T_base_sensor, T_world_base, intensity=None, sensors=False, pipelined=False):
+    def integrate(self, x, y, z, T_base_sensor, T_world_base, intensity=None, sensors=False, pipelined=False,
+                  want_matrix=True):
         """x, y, z[, intensity]: this rank's part of the step (torch device tensors).  Returns the counter matrix of the
         scan the call integrated — with `pipelined` that is the PREVIOUS scan (fdm_halo_routed_submit: this scan is
         routed now and integrated by the next call or by flush()); the tensors may be reused once the routing kernels
-        have run (the engine's stream)."""
+        have run (the engine's stream).  `want_matrix` False: no matrix is asked for (with ONE rank nothing is routed and
+        the matrix would be a statistics read-back that waits for the scan)."""
         self.eng.wait_torch()
         n = int(x.numel())
         fn = self.lib.fdm_halo_routed_submit if pipelined else self.lib.fdm_halo_routed_step
@@ -140,10 +245,10 @@ class NativeRoutedScan:
             C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(z.data_ptr()),
             C.c_void_p(intensity.data_ptr()) if intensity is not None else None,
             _col16(T_base_sensor), _col16(T_world_base), 1 if sensors else 0,
-            self.matrix.ctypes.data_as(C.c_void_p))
+            self.matrix.ctypes.data_as(C.c_void_p) if want_matrix else None)
         if rc != 0:
             raise RuntimeError(f"fdm_halo_routed_step: {rc} {self.lib.fdm_halo_last_error().decode()}")
-        return self.matrix.astype(np.int64)
+        return self.matrix.astype(np.int64) if want_matrix else None
 
     def flush(self):
         """Integrate the scan a pipelined call left pending (no-op otherwise)."""

@@ -261,7 +261,8 @@ class RoutedScan:
         self.eng, self.plan, self.torch, self.staged = engine, plan, torch, staged
         self.rp = route_plan(plan)
         self.device = device
-        self.send = torch.empty((max(max_points, 1), 4), dtype=torch.float32, device=device)
+        # (+ 3 rows per owner: N-sensor mode pads every owner's share to a multiple of four points)
+        self.send = torch.empty((max(max_points, 1) + 3 * plan.world + 4, 4), dtype=torch.float32, device=device)
         # this rank's row of the per-step table: world + 2 counters (written by the routing kernels) | the rank's two
         # transforms as raw float64 bits (64 words, copied from pinned memory without a host sync)
         W = plan.world
@@ -290,8 +291,13 @@ class RoutedScan:
         n_after_filter, [src, world + 1] n_in_map."""
         torch, W, me = self.torch, self.plan.world, self.plan.rank
         n = int(x.numel())
-        assert n <= self.send.shape[0]
-        self.eng.route_scan(self.rp, x, y, z, T_base_sensor, T_world_base, self.send, self.counts, intensity=intensity)
+        assert n + 3 * W <= self.send.shape[0]
+        # N scans, one per rank: a share is integrated as a scan of its own, so it travels as four channel blocks the bin
+        # kernels read in place (no de-interleave pass, the rank's own share is never copied).  ONE scan cut into slices:
+        # 16-byte records, contiguous across sources (the owner integrates them as one scan).
+        soa = bool(sensors)
+        self.eng.route_scan(self.rp, x, y, z, T_base_sensor, T_world_base, self.send, self.counts, intensity=intensity,
+                            soa=soa)
         self.eng.torch_wait()  # torch's stream (the collective's) behind the routing kernels
         # one small all-gather: the world + 2 counters and the two transforms of every rank; ONE host read-back
         self.pose_pinned[:16] = torch.from_numpy(np.asarray(T_base_sensor, dtype=np.float64).reshape(16))
@@ -313,16 +319,20 @@ class RoutedScan:
                                 np.ascontiguousarray(raw[:, W + 2:]).view(np.float64)], axis=1)
         matrix = table[:, :W + 2].astype(np.int64)
         self.matrix = matrix
-        n_recv = int(matrix[:, me].sum())
+        pad = (lambda v: (v + 3) // 4 * 4) if soa else (lambda v: v)  # rows a share of v points takes
+        n_recv = int(pad(matrix[:, me]).sum()) - (int(pad(matrix[me, me])) if soa else 0)
         any_in_map = bool(matrix[:, W + 1].sum() > 0)
         recv = self._recv_buffer(n_recv)
-        send_off = np.concatenate([[0], np.cumsum(matrix[me, :W])])
-        recv_off = np.concatenate([[0], np.cumsum(matrix[:, me])])
+        send_off = np.concatenate([[0], np.cumsum(pad(matrix[me, :W]))])
+        rsizes = pad(matrix[:, me]).copy()
+        if soa:
+            rsizes[me] = 0  # (the own share stays where the routing kernels put it)
+        recv_off = np.concatenate([[0], np.cumsum(rsizes)])
         ops, keep = [], []
         for peer in range(W):
-            ns, nr = int(matrix[me, peer]), int(matrix[peer, me])
+            ns, nr = int(pad(matrix[me, peer])), int(pad(matrix[peer, me]))
             if peer == me:
-                if ns:
+                if ns and not soa:
                     recv[recv_off[peer]:recv_off[peer] + ns].copy_(self.send[send_off[peer]:send_off[peer] + ns])
                 continue
             if nr:
@@ -353,8 +363,8 @@ class RoutedScan:
                 continue  # nothing for this tile, and its obstacle layer is clear already: the clear would be a no-op
             Tbs = table[src, W + 2:W + 18].reshape(4, 4)
             Twb = table[src, W + 18:W + 34].reshape(4, 4)
-            self.eng.integrate_points4_device(recv[recv_off[src]:recv_off[src] + ns] if ns else recv, ns, Tbs, Twb,
-                                              has_intensity=intensity is not None, any_in_map=seen)
+            share = (self.send[send_off[me]:] if src == me else recv[recv_off[src]:]).reshape(-1)
+            self.eng.integrate_soa4_device(share, ns, Tbs, Twb, has_intensity=intensity is not None, any_in_map=seen)
             self._obstacle_dirty = ns > 0
         return matrix
 
@@ -438,8 +448,8 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
         def step(k):
             d = mine[k % len(mine)]
             if native is not None:
-                router.matrix = native.integrate(d["x"], d["y"], d["z"], wl.T_base_sensor, pose(k), intensity=d["intensity"],
-                                                 sensors=True, pipelined=pipelined)
+                native.integrate(d["x"], d["y"], d["z"], wl.T_base_sensor, pose(k), intensity=d["intensity"],
+                                 sensors=True, pipelined=pipelined, want_matrix=False)
             else:
                 router.integrate(d["x"], d["y"], d["z"], wl.T_base_sensor, pose(k), dist, intensity=d["intensity"],
                                  sensors=True)
@@ -467,6 +477,12 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
         eng.sync()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if native is not None:  # (the routing matrix of one more step, outside the timed region)
+            d = mine[k % len(mine)]
+            router.matrix = native.integrate(d["x"], d["y"], d["z"], wl.T_base_sensor, pose(k), intensity=d["intensity"],
+                                             sensors=True)
+            exchange_halos(tile, plan, names, dist)
+            eng.sync()
         dist.barrier()
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if staged else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -499,8 +515,10 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl.name, "points_per_scan": wl.n_points, "scans_per_step": world, "map_cells": rows * cols,
                    "parallelism": f"spatial tiles {pr}x{pc}, halo {DEFAULT_HALO} cells; N-sensor mode: every rank routes its own "
-                                  "2 M-point scan to the owners of the cells (16 B point records, point-to-point over RCCL), the "
-                                  "owners integrate source by source, p2p halo exchange per step",
+                                  "2 M-point scan to the owners of the cells (shares as four channel blocks the owner's bin "
+                                  "kernel reads in place, point-to-point), the owners integrate source by source, p2p halo "
+                                  "exchange per step (one pack + one unpack launch); ONE rank: nothing is routed, the step is "
+                                  "one integrate()",
                    "inputs": "SoA float32 (x, y, z, intensity) resident in HBM on every rank",
                    "routed_step": ("one C call per step, pipelined over consecutive scans (fdm_halo_routed_submit)" if pipelined else
                                    "one C call per step (fdm_halo_routed_step)") if native is not None else "Python loop (tiling.RoutedScan)"},
@@ -514,11 +532,15 @@ def _global_roofline(world, n_pts, matrix, touched_last, step_s):
     """The routed step against the HBM roofline of the `world` GPUs it ran on (8 TB/s each): bytes the algorithm has
     to move per step / step time.  A step is launch- and synchronisation-bound (one host read-back per step), so
     the fraction is small by construction — it is there so that every bench line carries the same object."""
-    routed_pts = float(np.asarray(matrix)[:, :world].sum()) if matrix is not None else float(n_pts) * world
-    alg = world * n_pts * 16.0 + routed_pts * 16.0 + touched_last * 80.0
+    if world == 1:  # nothing is routed: the step is one integrate() of the scan
+        alg = n_pts * 16.0 + touched_last * 80.0
+    else:           # slice read where it is routed + share written + share read where it is integrated + the cells
+        routed_pts = float(np.asarray(matrix)[:, :world].sum()) if matrix is not None else float(n_pts) * world
+        alg = world * n_pts * 16.0 + 2.0 * routed_pts * 16.0 + touched_last * 80.0
     gbps = alg / step_s / 1e9
     peak = 8000.0 * world
-    return {"bound": "hbm", "kernel": "routed step (k_route_* + exchange + k_tupdate_tbin per source)", "achieved": gbps,
+    return {"bound": "hbm", "kernel": "k_tupdate_tbin (one rank: the step is one integrate())" if world == 1 else
+            "routed step (k_route_* + exchange + k_tupdate_tbin per source)", "achieved": gbps,
             "peak": peak, "unit": "GB/s", "frac": gbps / peak, "traffic": None, "alg_bytes_per_step": alg,
             "avg_step_us": step_s * 1e6,
             "note": "algorithmic bytes of all ranks per step / step time; peak = n_gpus x 8 TB/s"}

@@ -242,6 +242,17 @@ int fdm_engine_region_pack(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, in
                            const char* const* names, int n_layers, float* d_buf);
 int fdm_engine_region_unpack(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, int32_t nc,
                              const char* const* names, int n_layers, const float* d_buf);
+/* The same for several rectangles at once — ONE launch for all the strips and layers of a halo exchange (up to 8
+ * rectangles x 24 layers per launch): rectangle q's block starts at float `offset` of d_buf and is laid out as
+ * above (layer-major over the n_layers, column-major inside). */
+typedef struct fdm_region {
+  int32_t r0, c0, nr, nc;
+  uint64_t offset;
+} fdm_region;
+int fdm_engine_regions_pack(fdm_engine* e, int32_t n_rects, const fdm_region* rects, const char* const* names,
+                            int n_layers, float* d_buf);
+int fdm_engine_regions_unpack(fdm_engine* e, int32_t n_rects, const fdm_region* rects, const char* const* names,
+                              int n_layers, const float* d_buf);
 
 /* ---- Scan routing for a spatially tiled global map (fastdem_amd/tiling.py, include/fdm_halo.h) ----
  * One logical scan = the concatenation, in rank order, of per-rank slices.  fdm_engine_route_scan runs a slice through
@@ -266,6 +277,16 @@ int fdm_engine_route_scan(fdm_engine* e, const fdm_route_plan* plan, uint64_t n,
 int fdm_engine_integrate_points4_device(fdm_engine* e, uint64_t n, const float* d_points4, int has_intensity,
                                         int any_in_map, const double T_base_sensor[16],
                                         const double T_world_base[16]);
+/* The same two halves with the shares laid out as CHANNEL BLOCKS (N scans, one per rank: every source's share is
+ * integrated as a scan of its own, so nothing has to be contiguous across sources): the share of owner d starts at
+ * float 4 * base_d of d_send, base_d = sum of pad4(count) over the lower owners, and holds x | y | z | intensity, each
+ * pad4(count_d) floats.  A share is what the bin kernels read in place — no de-interleave pass on the receiving side,
+ * the rank's own share is never copied.  d_send must hold 4 * (n + 3 * world) floats. */
+int fdm_engine_route_scan_soa(fdm_engine* e, const fdm_route_plan* plan, uint64_t n, const float* d_x, const float* d_y,
+                              const float* d_z, const float* d_intensity, const double T_base_sensor[16],
+                              const double T_world_base[16], float* d_send, uint32_t* d_counts);
+int fdm_engine_integrate_soa4_device(fdm_engine* e, uint64_t n, const float* d_share, int has_intensity,
+                                     int any_in_map, const double T_base_sensor[16], const double T_world_base[16]);
 
 /* Scan callbacks of the reference (fastdem.hpp:129-136, fastdem.cpp:139-150): when enabled the
  * kernels also keep (a) every point in the map frame + whether it survived the crops and (b) the

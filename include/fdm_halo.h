@@ -88,6 +88,10 @@ int fdm_halo_route_exchange(fdm_engine* e, void* nccl_comm, const fdm_tile_plan*
  * read-back -> point exchange -> the owner integrates.  sensors = 0: the slices are ONE logical scan (every rank passes
  * the same transforms); sensors = 1: one scan per rank with its own transforms, integrated by the owners in rank
  * order (an owner skips a source that sent it nothing unless that source's scan must clear its obstacle layer).
+ * sensors = 1 moves every share as four channel blocks (fdm_engine_route_scan_soa): the owner's bin kernel reads a
+ * share in place — no de-interleave pass, the rank's own share is not copied.  world == 1: nothing is routed at all,
+ * the step IS fdm_engine_integrate_device (the bin kernel drops what the crops / the map reject itself); the counter
+ * matrix is then read from the engine's statistics only when h_matrix_out asks for it (that read waits for the scan).
  * The workspace holds the send / receive / table buffers (max_points = largest slice); h_matrix_out (nullable,
  * world * (world + 2) words) receives the counter matrix of the step.  nccl_comm may be null when world == 1.
  * Followed, as before, by fdm_halo_exchange for the halo rings. */
@@ -109,6 +113,22 @@ int fdm_halo_routed_submit(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* 
                            int32_t sensors, uint32_t* h_matrix_prev);
 int fdm_halo_routed_flush(fdm_engine* e, void* nccl_comm, const fdm_tile_plan* plan, fdm_routed_ws* ws,
                           uint32_t* h_matrix_out);
+
+/* ---- Transport ----
+ * Every collective above goes through a small table of operations; the default one is RCCL on the engine's stream
+ * (`nccl_comm` = an ncclComm_t).  A host may install another transport — the tests install one that stages through
+ * host memory over torch.distributed/gloo, so that the multi-rank code of this library (per-peer offsets, grouping,
+ * source order) runs with REAL peers on a box with one GPU, where RCCL refuses two ranks on one device.  `nccl_comm`
+ * is then handed to the callbacks untouched as `comm`.  Byte counts; device pointers; every operation is issued on
+ * the engine's stream (`hip_stream`) and may complete asynchronously on it.  Process-wide; NULL restores RCCL. */
+typedef struct fdm_halo_transport {
+  int (*all_gather)(void* comm, const void* d_send, void* d_recv, uint64_t bytes_per_rank, void* hip_stream);
+  int (*group_start)(void* comm);
+  int (*send)(void* comm, const void* d_buf, uint64_t bytes, int32_t peer, void* hip_stream);
+  int (*recv)(void* comm, void* d_buf, uint64_t bytes, int32_t peer, void* hip_stream);
+  int (*group_end)(void* comm, void* hip_stream);
+} fdm_halo_transport;
+void fdm_halo_set_transport(const fdm_halo_transport* t);
 
 const char* fdm_halo_last_error(void);
 

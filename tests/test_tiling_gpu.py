@@ -208,6 +208,110 @@ def _sensors_worker(rank, world, port, q, backend):
         q.put((rank, [("exception", traceback.format_exc(), str(e))], 0))
 
 
+def _native_worker(rank, world, port, q, mode):
+    """libfdm_halo's routed step (fdm_halo_routed_step / _submit + fdm_halo_exchange: the C code bench.py's c5 runs over
+    RCCL) with REAL peers: the library's transport table is pointed at a host-staged one over gloo
+    (fastdem_amd.halo.HostStagedTransport), everything else — routing kernels, per-peer offsets, one group per
+    exchange, source order, pack / unpack — is the production path.  mode: "slices" (one scan cut into slices),
+    "sensors" (one scan per rank), "pipelined" (sensors, software-pipelined over consecutive scans)."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        sys.path.insert(0, ROOT)
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from fastdem_amd import Engine, capi, synth, tiling
+        from fastdem_amd import halo as H
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        wl = synth.global_map(n_scans=4, size_m=100.0, n_az=1024, radius=30.0)
+        rows = cols = 2000
+        plan = tiling.make_plan(rank, world, rows, cols, tiling.DEFAULT_HALO)
+        eng = Engine(wl.width, wl.height, wl.resolution, wl.apply_to(capi.default_config()),
+                     tile=plan.fdm_tile() if world > 1 else None, device=0)
+        whole = Engine(wl.width, wl.height, wl.resolution, wl.apply_to(capi.default_config()), device=0)
+        transport = H.HostStagedTransport(dist)
+        transport.install()
+        native = H.NativeRoutedScan(eng, rank, world, rows, cols, tiling.DEFAULT_HALO, wl.n_points, comm=None)
+        lib = H.load()
+        sensors = mode != "slices"
+        pose_of = lambda k, r: wl.pose(11 * k + 37 * r)  # noqa: E731
+        bounds = tiling.slice_bounds(wl.n_points, world, align=4)
+        ws = None
+        names = None
+        for k in range(4):
+            if sensors:
+                s = wl.scan((k + rank) % 4)
+                lo, hi = (0, 0) if (k == 0 and rank == 1) else (0, wl.n_points)  # rank 1's FIRST scan is empty
+                Twb = pose_of(k, rank)
+            else:
+                s = wl.scan(k)
+                lo, hi = bounds[rank]
+                if k == 0 and rank == 1:
+                    hi = lo  # (an empty slice on the first step)
+                Twb = wl.pose(k)
+            d = {c: torch.from_numpy(np.ascontiguousarray(s[c][lo:hi])).cuda() for c in ("x", "y", "z", "intensity")}
+            if hi == lo:  # (data_ptr() of an empty tensor is null; the C call takes n = 0)
+                d = {c: torch.zeros(4, device="cuda") for c in d}
+                class _Empty:  # noqa: E306
+                    def __init__(self, t): self.t = t
+                    def numel(self): return 0
+                    def data_ptr(self): return self.t.data_ptr()
+                d = {c: _Empty(t) for c, t in d.items()}
+            native.integrate(d["x"], d["y"], d["z"], wl.T_base_sensor, Twb, intensity=d["intensity"], sensors=sensors,
+                             pipelined=mode == "pipelined")
+            if mode == "pipelined" and k == 3:
+                native.flush()
+            if mode != "pipelined":  # (halo rings through the library's own exchange, on the same transport)
+                names = [nm for nm in tiling.visible_layers(eng.layers())]
+                have = [None] * world
+                dist.all_gather_object(have, names)
+                names = [nm for nm in names if all(nm in h for h in have)]
+                arr = (C.c_char_p * len(names))(*[nm.encode() for nm in names])
+                need = lib.fdm_halo_workspace_bytes(C.byref(native.plan), len(names))
+                if ws is None or ws.numel() * 4 < need:
+                    ws = torch.empty(max(int(need) // 4, 4), dtype=torch.float32, device="cuda")
+                sent = lib.fdm_halo_exchange(eng._h, None, C.byref(native.plan), arr, len(names), C.c_void_p(ws.data_ptr()),
+                                             ws.numel() * 4)
+                assert sent >= 0, lib.fdm_halo_last_error()
+            # the reference order on the untiled engine
+            if sensors:
+                for r in range(world):
+                    sr = wl.scan((k + r) % 4)
+                    if k == 0 and r == 1:
+                        continue  # (its scan was empty: integrate() of an empty cloud touches nothing)
+                    whole.integrate(sr["x"], sr["y"], sr["z"], wl.T_base_sensor, pose_of(k, r), intensity=sr["intensity"])
+            else:
+                keep = np.ones(wl.n_points, dtype=bool)
+                if k == 0 and world > 1:
+                    keep[bounds[1][0]:bounds[1][1]] = False
+                whole.integrate(s["x"][keep], s["y"][keep], s["z"][keep], wl.T_base_sensor, wl.pose(k),
+                                intensity=s["intensity"][keep])
+        eng.sync()
+        names = [nm for nm in tiling.visible_layers(eng.layers())]
+        have = [None] * world
+        dist.all_gather_object(have, names)
+        names = [nm for nm in names if all(nm in h for h in have)]
+        rect = (plan.stored if mode != "pipelined" else plan.owned) if world > 1 else tiling.Rect(0, 0, rows, cols)
+        st = plan.stored if world > 1 else tiling.Rect(0, 0, rows, cols)
+        bad = []
+        for nm in names:
+            got = eng.layer(nm)[rect.r0 - st.r0:rect.r1 - st.r0, rect.c0 - st.c0:rect.c1 - st.c0]
+            want = whole.layer(nm)[rect.r0:rect.r1, rect.c0:rect.c1]
+            if not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
+                bad.append((nm, int((got.view(np.uint32) != want.view(np.uint32)).sum())))
+        if world > 1 and not (transport.calls["all_gather"] >= 4 and transport.calls["send"] > 0 and transport.calls["recv"] > 0):
+            bad.append(("transport", dict(transport.calls)))
+        H.HostStagedTransport.uninstall()
+        q.put((rank, bad, len(names)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, [("exception", traceback.format_exc(), str(e))], 0))
+
+
 def _run(target, world, *extra):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -246,5 +350,16 @@ def test_n_sensors_feeding_one_global_map(world, backend):
     integrate each source's records with that source's transforms.  Bit-identical to the untiled engine fed the N
     scans one after the other."""
     for rank, bad, n_names in _run(_sensors_worker, world, backend):
+        assert not bad, f"rank {rank}: {bad}"
+        assert n_names >= 8
+
+
+@pytest.mark.parametrize("world,mode", [(2, "sensors"), (4, "sensors"), (2, "slices"), (4, "slices"), (2, "pipelined")])
+def test_native_routed_step_with_real_peers(world, mode):
+    """fdm_halo_routed_step had only ever run with a 1-rank communicator, where its send / receive loop is the
+    self copy.  Two and four processes on GPU 0, libfdm_halo's transport table pointed at a host-staged one over gloo:
+    per-peer offsets, grouping, source order and the halo exchange with real peers — every stored window bit-identical to
+    the untiled engine; rank 1's first scan / slice is EMPTY (fdm_engine_route_scan used to write through a null table)."""
+    for rank, bad, n_names in _run(_native_worker, world, mode):
         assert not bad, f"rank {rank}: {bad}"
         assert n_names >= 8
