@@ -178,9 +178,9 @@ PROTOTYPES = {
     "fdm_engine_region_pack": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.POINTER(C.c_char_p), C.c_int, _P]),
     "fdm_engine_region_unpack": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-    "fdm_engine_regions_pack": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int, _P]),
-    "fdm_engine_regions_unpack": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int, _P]),
                                            C.POINTER(C.c_char_p), C.c_int, _P]),
+    "fdm_engine_regions_pack": (C.c_int, [_P, C.c_int32, _P, C.POINTER(C.c_char_p), C.c_int, _P]),
+    "fdm_engine_regions_unpack": (C.c_int, [_P, C.c_int32, _P, C.POINTER(C.c_char_p), C.c_int, _P]),
     "fdm_engine_capture": (C.c_int, [_P, C.c_int, C.c_int]),
     "fdm_engine_last_preprocessed": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, C.POINTER(C.c_uint64)]),
     "fdm_engine_last_preprocessed_cov": (C.c_int, [_P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
