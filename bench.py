@@ -36,6 +36,7 @@ MEASURED_READ_GBS = 6400.0  # what a plain 16 B/lane read kernel reaches on this
 # distinct 2 M-point scans of the configs[3] legs: 9 x 33.5 MB = 302 MB of input cycle through the
 # timed region, more than the 256 MiB Infinity Cache can hold, so the read stream comes from HBM
 LARGE_SCANS = 9
+STREAM_BYTES = 300 * 1024 * 1024  # input the small-scan workloads' timed region cycles through (> the 256 MiB Infinity Cache)
 
 
 def parse():
@@ -390,6 +391,27 @@ def host_legs(res, wl, k, iters=50, stream_iters=200):
     out["host_buffers_pinned_ms_per_scan"] = median_ms(
         lambda i: res.eng.integrate(pn["x"], pn["y"], pn["z"], wl.T_base_sensor, wl.pose(k + 1000 + i),
                                     intensity=pn.get("intensity"), rgb=pn.get("rgb")))
+    # N integrate() calls on host clouds as ONE call (fdm_engine_integrate_host_batch: what the C++ mirror's
+    # FastDEM::integrateBatch does): 64 scans from the pinned pool, read in place by the batch launches, one wait at the end
+    from fastdem_amd import capi
+    nb = 64
+    harr = (capi.FdmDeviceScan * nb)()
+    for i in range(nb):
+        d = harr[i]
+        d.n = int(s["x"].size)
+        d.x, d.y, d.z = pa["x"].ctypes.data, pa["y"].ctypes.data, pa["z"].ctypes.data
+        d.intensity = pa["intensity"].ctypes.data if "intensity" in pa else None
+        d.rgb = pa["rgb"].ctypes.data if "rgb" in pa else None
+        d.sigma_z2 = None
+        d.T_base_sensor = res.tbs
+        d.T_world_base = res.pose(k + 3000 + i)
+    res.eng.integrate_host_batch(harr)  # (first call: buffers)
+    ts = []
+    for _ in range(max(3, iters // 8)):
+        t0 = time.perf_counter()
+        res.eng.integrate_host_batch(harr)
+        ts.append((time.perf_counter() - t0) / nb)
+    out["host_batch_pool_ms_per_scan"] = sorted(ts)[len(ts) // 2] * 1e3
     # steady-state stream from PINNED host memory, no per-scan wait (SURVEY.md §8d iii): PCIe-inclusive
     hp = {c: C.c_void_p(t.data_ptr()) for c, t in pin.items()}
     for i in range(64):  # pose matrices are host work that does not belong to the stream's rate
@@ -471,6 +493,14 @@ def main():
         kw = {"order": args.order} if args.workload in ("c2", "c4") else {}
         if args.scans or args.workload in ("c4", "c5"):
             kw["n_scans"] = args.scans or LARGE_SCANS
+        else:
+            # the small-scan workloads: enough DISTINCT scans that the timed region's input (> 256 MiB) cannot sit in the
+            # Infinity Cache — `value` is measured on inputs that stream from HBM (with four scans cycling
+            # through a batch the input lived in L2 / MALL); the cache-resident figure is reported beside it
+            probe = synth.make(args.workload, n_scans=1, **kw)
+            per_scan = probe.n_points * (12 + (4 if probe.scans[0]["intensity"] is not None else 0) +
+                                         (4 if probe.scans[0]["rgb"] is not None else 0))
+            kw["n_scans"] = int(min(640, max(4, -(-STREAM_BYTES // per_scan))))
         wl = synth.make(args.workload, **kw)
         res = Resident(wl, local_rank, args.wave_merge, args.overlap)
         for kv in args.set:
@@ -489,30 +519,36 @@ def main():
         # workloads launch once per scan.  `value` is points per second either way; ms_per_step is per STEP.
         sps = args.scans_per_step or (16 if args.workload in ("c2", "c3") else 1)
         n_timed, n_warm = args.steps * sps, args.warmup * sps
-        for kk in range(n_warm + n_timed + args.profile_steps + 8):
-            res.pose(kk)
-        k = 0
-        if n_warm > 0:  # the warm-up steps take the timed region's own entry point (its first call is not free)
-            wbatch, _ = res.batch(k, n_warm)
-            if res.eng.integrate_device_batch_timed(wbatch) != 0:
-                raise RuntimeError("integrate_device_batch (warm-up) failed")
-            k += n_warm
-        # the K timed steps leave as ONE call across the language boundary (fdm_engine_integrate_device_batch:
-        # K x fdm_engine_integrate_device in C++): with a Python / ctypes call per 6 us scan the timed region
-        # would measure the interpreter, not the engine
-        batch, pts = res.batch(k, n_timed)
-        barrier()
-        t0 = time.perf_counter()
-        # K scans + the last scan's held-back update between two HIP events on the engine's stream, ONE call
-        rc = res.eng.integrate_device_batch_timed(batch)
-        torch.cuda.synchronize()  # (device-wide: covers the engine's stream)
-        dt = time.perf_counter() - t0
-        if rc != 0:
-            raise RuntimeError(f"integrate_device_batch failed: {rc}")
-        k += n_timed
-        # scans per launch of the timed region: 16 when the batch pipeline took it (fdm_multi.hpp), 1 otherwise
-        batch_scans = max(1, res.eng.last_batch())
-        timed_launch_us = res.eng.timer_ms() / n_timed * 1e3  # per SCAN: HIP events on the engine's stream
+
+        def timed_region(r, k0):
+            """warm-up, then the K timed steps as ONE call across the language boundary (fdm_engine_integrate_device_batch:
+            K x fdm_engine_integrate_device in C++; with a Python / ctypes call per 6 us scan the region would measure the
+            interpreter), K scans + the last scan's held-back update between two HIP events on the engine's stream.
+            Returns (wall seconds incl. the final sync, points, HIP-event us per scan, scans per launch, next k)."""
+            for kk in range(k0, k0 + n_warm + n_timed + 8):
+                r.pose(kk)
+            k = k0
+            if n_warm > 0:  # the warm-up steps take the timed region's own entry point (its first call is not free)
+                wbatch, _ = r.batch(k, n_warm)
+                if r.eng.integrate_device_batch_timed(wbatch) != 0:
+                    raise RuntimeError("integrate_device_batch (warm-up) failed")
+                k += n_warm
+            batch, pts_ = r.batch(k, n_timed)
+            r.eng.sync()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t0_ = time.perf_counter()
+            rc_ = r.eng.integrate_device_batch_timed(batch)
+            torch.cuda.synchronize()  # (device-wide: covers the engine's stream)
+            dt_ = time.perf_counter() - t0_
+            if rc_ != 0:
+                raise RuntimeError(f"integrate_device_batch failed: {rc_}")
+            return dt_, pts_, r.eng.timer_ms() / n_timed * 1e3, max(1, r.eng.last_batch()), k + n_timed
+
+        for kk in range(args.profile_steps + 8):
+            res.pose(n_warm + n_timed + kk)
+        dt, pts, timed_launch_us, batch_scans, k = timed_region(res, 0)
         if world > 1:
             dist.barrier()
             t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
@@ -533,7 +569,12 @@ def main():
             "config": {"workload": wl.name, "points_per_scan": wl.n_points,
                        "map_cells": res.eng.rows * res.eng.cols, "point_order": args.order,
                        "parallelism": "replicas only (LOCAL map does not shard)" if world > 1 else "1 gpu",
-                       "inputs": "SoA float32 resident in HBM", "wave_merge": args.wave_merge,
+                       "inputs": (f"SoA float32 resident in HBM; `value` cycles through {len(wl.scans)} distinct scans = "
+                                  f"{len(wl.scans) * res.bytes_per_point() * wl.n_points / 2**20:.0f} MiB of input"
+                                  + (" (more than the 256 MiB Infinity Cache: the reads come from HBM); `cache_resident` = the "
+                                     "same region over 4 scans that stay in L2 / Infinity Cache"
+                                     if len(wl.scans) * res.bytes_per_point() * wl.n_points > 2**28 else "")),
+                       "wave_merge": args.wave_merge,
                        "distinct_scans": len(wl.scans), "scans_per_launch": batch_scans, "scans_per_step": sps,
                        "step": (f"one launch of the batch pipeline over {sps} scans (fdm_engine_integrate_device_batch)"
                                 if sps > 1 else "one scan")},
@@ -575,6 +616,18 @@ def main():
             roof["frac_of_measured_read_bw"] = roof["achieved"] / MEASURED_READ_GBS
             result["roofline"] = roof
             result["kernels"] = kern
+            if world == 1 and len(wl.scans) > 4 and args.workload in ("c2", "c3") and not args.scans:
+                # round 3's protocol beside it: four distinct scans cycling through the batches (input in L2 / MALL)
+                wl4 = synth.make(args.workload, n_scans=4, **{k_: v for k_, v in kw.items() if k_ != "n_scans"})
+                res4 = Resident(wl4, local_rank, args.wave_merge, args.overlap)
+                for kv in args.set:
+                    res4.eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+                dt4, pts4, us4, bs4, _ = timed_region(res4, 0)
+                result["cache_resident"] = {"value": pts4 / dt4 / 1e6, "unit": "Mpts/s", "device_value": wl4.n_points / (us4 * 1e-6) / 1e6,
+                                            "us_per_scan_hip_events": us4, "distinct_scans": 4, "scans_per_launch": bs4,
+                                            "roofline_frac": roof["alg_bytes_per_launch"] / max(1, roof.get("scans_per_launch", 1)) /
+                                                             (us4 * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                del res4
             result["timed_region_us_per_scan_hip_events"] = timed_launch_us
             if not args.no_host_legs:
                 # end-to-end with host staging (PCIe-inclusive) for DESIGN.md — never `value`

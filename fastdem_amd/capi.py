@@ -135,6 +135,7 @@ PROTOTYPES = {
     "fdm_engine_integrate_device": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, _D, _D]),
     "fdm_engine_integrate_device_batch": (C.c_int, [_P, C.c_uint32, _P]),
     "fdm_engine_integrate_device_batch_timed": (C.c_int, [_P, C.c_uint32, _P]),
+    "fdm_engine_integrate_host_batch": (C.c_int, [_P, C.c_uint32, _P, _P]),
     "fdm_engine_integrate_async": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_double),
                                              C.POINTER(C.c_double)]),
     "fdm_engine_route_scan": (C.c_int, [_P, C.POINTER(FdmRoutePlan), C.c_uint64, _P, _P, _P, _P, _D, _D, _P, _P]),

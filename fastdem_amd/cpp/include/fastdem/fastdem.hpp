@@ -31,41 +31,50 @@ class FastDEM {
     sensor_model_ = createSensorModel(cfg_.sensor_model);
     mapping_ = std::make_unique<ElevationMapping>(map_, cfg_);
   }
-  ~FastDEM() = default;
+  ~FastDEM() {
+    try { drain(); } catch (...) {}  // (queued clouds are borrowed: the GPU must be done with them)
+  }
   FastDEM(const FastDEM&) = delete;
   FastDEM& operator=(const FastDEM&) = delete;
 
   FastDEM& setMappingMode(MappingMode mode) {
     cfg_.mapping.mode = mode;
+    cfg_dirty_ = true;
     mapping_->setConfig(cfg_);
     return *this;
   }
   FastDEM& setEstimatorType(EstimationType type) {
     cfg_.mapping.estimation_type = type;
+    cfg_dirty_ = true;
     mapping_->setConfig(cfg_);
     return *this;
   }
   FastDEM& setSensorModel(SensorType type) {
     cfg_.sensor_model.type = type;
+    cfg_dirty_ = true;
     sensor_model_ = createSensorModel(cfg_.sensor_model);
     return *this;
   }
   FastDEM& setSensorModel(std::unique_ptr<SensorModel> model) noexcept {
     sensor_model_ = std::move(model);
+    cfg_dirty_ = true;
     return *this;
   }
   FastDEM& setHeightFilter(float z_min, float z_max) noexcept {
     cfg_.point_filter.z_min = z_min;
+    cfg_dirty_ = true;
     cfg_.point_filter.z_max = z_max;
     return *this;
   }
   FastDEM& setRangeFilter(float range_min, float range_max) noexcept {
     cfg_.point_filter.range_min = range_min;
+    cfg_dirty_ = true;
     cfg_.point_filter.range_max = range_max;
     return *this;
   }
   FastDEM& enableRaycasting(bool enabled = true) noexcept {
     cfg_.raycasting.enabled = enabled;  // step 3 of integrateImpl (fastdem.cpp:152-159), on the device
+    cfg_dirty_ = true;
     return *this;
   }
   FastDEM& setCalibrationProvider(std::shared_ptr<Calibration> c) noexcept {
@@ -83,7 +92,7 @@ class FastDEM {
     return *this;
   }
 
-  void reset() { map_.clearAll(); }
+  void reset() { drain(); map_.clearAll(); }
   const Config& config() const noexcept { return cfg_; }
   bool hasTransformProvider() const noexcept { return calibration_ != nullptr && odometry_ != nullptr; }
 
@@ -125,6 +134,82 @@ class FastDEM {
       return false;
     }
     return integrateImpl(cloud, T_base_sensor, T_world_base);
+  }
+
+  // ---- not in the reference: the two ways a host gets more than one synchronous call per scan out of the engine ----
+
+  /// One scan of integrateBatch(): what integrate(cloud, T_base_sensor, T_world_base) takes.  The cloud is borrowed.
+  struct Scan {
+    const PointCloud* cloud;
+    Eigen::Isometry3d T_base_sensor, T_world_base;
+  };
+  /// N consecutive integrate(cloud, T_base_sensor, T_world_base) calls as ONE call: the map afterwards is bit for bit
+  /// what the N calls leave (per cell the reference fixes only the order of the scans, elevation_mapping.cpp:94-125),
+  /// but the engine sees the scans up front and bins up to sixteen of them per launch (fdm_engine_integrate_host_batch;
+  /// PointCloud channels live in pinned memory and are read in place).  Returns what the LAST call would have returned
+  /// (false: its cloud was empty or entirely filtered); lastStats() are that scan's.  Empty clouds inside the batch are
+  /// skipped with the reference's warning.  Scan callbacks and user SensorModel subclasses need host work per scan:
+  /// with either, the scans are integrated one by one.
+  bool integrateBatch(const std::vector<Scan>& scans) {
+    if (scans.empty()) return false;
+    SensorType builtin;
+    const bool custom = sensor_model_ && !sensor_model_->builtin(builtin);
+    if (on_preprocessed_ || on_rasterized_ || custom) {
+      bool last = false;
+      for (const Scan& s : scans) last = s.cloud && integrate(*s.cloud, s.T_base_sensor, s.T_world_base);
+      return last;
+    }
+    drain();
+    map_.flushToDevice();
+    const fdm_config f = detail::toEngineConfig(effectiveConfig());
+    detail::ck(fdm_engine_set_config(map_.engine(), &f), "fdm_engine_set_config");
+    batch_.clear();
+    batch_.reserve(scans.size());
+    bool last_empty = false;
+    for (const Scan& s : scans) {
+      last_empty = !s.cloud || s.cloud->empty();
+      if (last_empty) {
+        std::fprintf(stderr, "[warn] [FastDEM] Received empty cloud. Skipping...\n");
+        continue;
+      }
+      fdm_device_scan d{};
+      d.n = s.cloud->size();
+      d.x = s.cloud->xData(); d.y = s.cloud->yData(); d.z = s.cloud->zData();
+      d.intensity = s.cloud->intensityData();
+      d.rgb = s.cloud->rgbData();
+      std::memcpy(d.T_base_sensor, s.T_base_sensor.matrix().data(), sizeof(d.T_base_sensor));
+      std::memcpy(d.T_world_base, s.T_world_base.matrix().data(), sizeof(d.T_world_base));
+      batch_.push_back(d);
+    }
+    if (batch_.empty()) return false;
+    const int rc = fdm_engine_integrate_host_batch(map_.engine(), uint32_t(batch_.size()), batch_.data(), &last_);
+    detail::ck(rc, "fdm_engine_integrate_host_batch");
+    map_.invalidateHost();
+    return rc == FDM_OK && !last_empty;
+  }
+
+  /// Queued mode.  integrate() then ENQUEUES the scan (the cloud's pinned channels are read in place by the launch) and
+  /// returns without waiting for the GPU: `true` means "accepted", `false` keeps its host-decidable meanings (empty
+  /// cloud, missing providers).  The one case the reference decides from the data — every point filtered: false, and
+  /// the map does not move (fastdem.cpp:138) — is still honoured ON THE DEVICE (nothing moves, nothing is written);
+  /// only its `false` arrives late: drain() waits for everything queued and returns what the LAST queued integrate()
+  /// would have returned synchronously.  Contract for the caller: a queued cloud must stay alive and untouched until
+  /// drain(), reset(), the next map access through ElevationMap, or the destructor — whichever comes first (all of
+  /// them drain).  Scan callbacks and user SensorModel subclasses keep integrate() synchronous.
+  FastDEM& setQueued(bool on) {
+    if (!on) drain();
+    queued_ = on;
+    return *this;
+  }
+  bool queued() const noexcept { return queued_; }
+  /// Wait for every queued scan; the status the last one would have returned (true when nothing was queued).
+  bool drain() {
+    if (!pending_) return true;
+    pending_ = false;
+    const int rc = fdm_engine_last_stats(map_.engine(), &last_);
+    detail::ck(rc, "fdm_engine_last_stats");
+    map_.invalidateHost();
+    return rc == FDM_OK;
   }
 
   /// sensor_msgs/PointCloud2-shaped message straight to the device (what the ROS scan callback does
@@ -200,6 +285,23 @@ class FastDEM {
   // integrateImpl (fastdem.cpp:133-162): preprocessScan + ElevationMapping::update, on the device
   bool integrateImpl(const PointCloud& cloud, const Eigen::Isometry3d& T_base_sensor,
                      const Eigen::Isometry3d& T_world_base) {
+    SensorType bi;
+    if (queued_ && !on_preprocessed_ && !on_rasterized_ && (!sensor_model_ || sensor_model_->builtin(bi))) {
+      map_.flushToDevice();  // (host writes to the map since the last call; nothing to do when there were none)
+      if (cfg_dirty_) {      // (the engine takes its parameters when a scan is ENQUEUED: scans already queued keep theirs)
+        const fdm_config fq = detail::toEngineConfig(effectiveConfig());
+        detail::ck(fdm_engine_set_config(map_.engine(), &fq), "fdm_engine_set_config");
+        cfg_dirty_ = false;
+      }
+      detail::ck(fdm_engine_integrate_async(map_.engine(), cloud.size(), cloud.xData(), cloud.yData(), cloud.zData(),
+                                            cloud.intensityData(), cloud.rgbData(), nullptr,
+                                            T_base_sensor.matrix().data(), T_world_base.matrix().data()),
+                 "fdm_engine_integrate_async");
+      pending_ = true;
+      map_.invalidateHost();
+      return true;
+    }
+    drain();
     map_.flushToDevice();
     Config eff = effectiveConfig();
     const float* sigma = nullptr;
@@ -220,6 +322,7 @@ class FastDEM {
     }
     const fdm_config f = detail::toEngineConfig(eff);
     detail::ck(fdm_engine_set_config(map_.engine(), &f), "fdm_engine_set_config");
+    cfg_dirty_ = false;
     const int rc = fdm_engine_integrate(map_.engine(), cloud.size(), cloud.xData(), cloud.yData(), cloud.zData(),
                                         cloud.intensityData(), cloud.rgbData(), sigma,
                                         T_base_sensor.matrix().data(), T_world_base.matrix().data(), &last_);
@@ -287,6 +390,8 @@ class FastDEM {
   std::vector<float> sigma_;
   Eigen::Matrix3f R_last_;
   fdm_scan_stats last_{};
+  std::vector<fdm_device_scan> batch_;
+  bool queued_ = false, pending_ = false, cfg_dirty_ = true;
 };
 
 }  // namespace fastdem

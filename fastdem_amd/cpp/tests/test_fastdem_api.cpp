@@ -978,4 +978,104 @@ TEST(SensorModels, HostClassesAndFactory) {  // test_sensor_models.cpp:17-262
   EXPECT_NEAR(rgbd.computeCovariance(Eigen::Vector3f(1, 2, -0.5f))(0, 0), 0.01f, 1e-6f);
 }
 
+
+// ---------------------------------------------------------------- queued mode / integrateBatch (not in the reference) ----
+namespace {
+// a scan stream with every case the reference distinguishes: plain scans, an empty cloud, a scan whose points are all
+// filtered (false, and the LOCAL map must not move: fastdem.cpp:138), a pose sequence that shifts the window
+struct Stream {
+  std::vector<PointCloud> clouds;
+  std::vector<Eigen::Isometry3d> poses;
+  Stream() {
+    for (int k = 0; k < 23; ++k) {
+      PointCloud c;
+      if (k != 7) {  // (scan 7: an empty cloud)
+        const float h = (k == 11 || k == 22) ? 50.0f : 0.2f + 0.05f * float(k % 5);  // (11, 22: above the height filter)
+        for (int i = -12; i <= 12; ++i)
+          for (int j = -12; j <= 12; ++j) c.add(0.21f * float(i) + 0.01f * float(k), 0.19f * float(j), h + 0.01f * float((i * 7 + j * 3) % 5));
+      }
+      clouds.push_back(std::move(c));
+      Eigen::Isometry3d T = Eigen::Isometry3d::Identity();
+      T.translation() = Eigen::Vector3d(0.3 * k, -0.2 * k, 0.0);
+      poses.push_back(T);
+    }
+  }
+};
+bool sameMaps(ElevationMap& a, ElevationMap& b) {
+  if (a.getLayers() != b.getLayers()) return false;
+  if (a.getStartIndex()(0) != b.getStartIndex()(0) || a.getStartIndex()(1) != b.getStartIndex()(1)) return false;
+  if (a.getPosition()(0) != b.getPosition()(0) || a.getPosition()(1) != b.getPosition()(1)) return false;
+  for (const auto& name : a.getLayers()) {
+    const auto& A = a.get(name);
+    const auto& B = b.get(name);
+    for (int i = 0; i < A.rows(); ++i)
+      for (int j = 0; j < A.cols(); ++j) {
+        const float va = A(i, j), vb = B(i, j);
+        uint32_t x, y;
+        std::memcpy(&x, &va, 4);
+        std::memcpy(&y, &vb, 4);
+        if (x != y && !(std::isnan(va) && std::isnan(vb))) return false;
+      }
+  }
+  return true;
+}
+}  // namespace
+TEST(QueuedMode, SameMapAsTheSynchronousCallsAndTheLateStatus) {
+  Stream st;
+  ElevationMap m_sync(12.0f, 9.0f, 0.1f, "map"), m_q(12.0f, 9.0f, 0.1f, "map");
+  FastDEM a(m_sync), b(m_q);
+  a.setHeightFilter(-1.0f, 2.0f).setRangeFilter(0.0f, 30.0f).setSensorModel(SensorType::Constant);
+  b.setHeightFilter(-1.0f, 2.0f).setRangeFilter(0.0f, 30.0f).setSensorModel(SensorType::Constant).setQueued(true);
+  EXPECT_TRUE(b.queued());
+  Eigen::Isometry3d Tbs = Eigen::Isometry3d::Identity();
+  std::vector<bool> ra;
+  for (size_t k = 0; k < st.clouds.size(); ++k) ra.push_back(a.integrate(st.clouds[k], Tbs, st.poses[k]));
+  EXPECT_FALSE(ra[7]);
+  EXPECT_FALSE(ra[11]);
+  EXPECT_TRUE(ra[12]);
+  for (size_t k = 0; k < st.clouds.size(); ++k) {
+    const bool accepted = b.integrate(st.clouds[k], Tbs, st.poses[k]);
+    EXPECT_EQ(accepted, !st.clouds[k].empty());  // queued: `true` = accepted; an empty cloud is decided on the host
+    if (k == 11) {                               // the data-dependent `false` arrives with drain()
+      EXPECT_FALSE(b.drain());
+      EXPECT_EQ(b.lastStats().n_after_filter, 0u);
+    }
+    if (k == 12) EXPECT_TRUE(b.drain());
+  }
+  EXPECT_FALSE(b.drain());  // scan 22: every point filtered
+  EXPECT_TRUE(b.drain());   // (nothing queued any more)
+  EXPECT_TRUE(sameMaps(m_sync, m_q));
+  // a configuration change between two queued scans applies to the scans queued after it
+  a.setHeightFilter(-1.0f, 100.0f).setRangeFilter(0.0f, 200.0f);
+  b.setHeightFilter(-1.0f, 100.0f).setRangeFilter(0.0f, 200.0f);
+  EXPECT_TRUE(a.integrate(st.clouds[22], Tbs, st.poses[22]));
+  EXPECT_TRUE(b.integrate(st.clouds[22], Tbs, st.poses[22]));
+  EXPECT_TRUE(b.drain());
+  EXPECT_TRUE(sameMaps(m_sync, m_q));
+}
+TEST(IntegrateBatch, SameMapAsScanByScanAndTheLastScansResult) {
+  Stream st;
+  ElevationMap m_one(12.0f, 9.0f, 0.1f, "map"), m_b(12.0f, 9.0f, 0.1f, "map");
+  FastDEM a(m_one), b(m_b);
+  a.setHeightFilter(-1.0f, 2.0f).setRangeFilter(0.0f, 30.0f).setSensorModel(SensorType::Constant);
+  b.setHeightFilter(-1.0f, 2.0f).setRangeFilter(0.0f, 30.0f).setSensorModel(SensorType::Constant);
+  Eigen::Isometry3d Tbs = Eigen::Isometry3d::Identity();
+  bool last = false;
+  for (size_t k = 0; k < st.clouds.size(); ++k) last = a.integrate(st.clouds[k], Tbs, st.poses[k]);
+  std::vector<FastDEM::Scan> scans;
+  for (size_t k = 0; k < st.clouds.size(); ++k) scans.push_back(FastDEM::Scan{&st.clouds[k], Tbs, st.poses[k]});
+  EXPECT_EQ(b.integrateBatch(scans), last);  // scan 22 is filtered: false
+  EXPECT_FALSE(last);
+  EXPECT_EQ(b.lastStats().n_after_filter, a.lastStats().n_after_filter);
+  EXPECT_TRUE(sameMaps(m_one, m_b));
+  // a shorter batch that ends on a good scan, on the same maps
+  scans.resize(9);
+  for (size_t k = 0; k < 9; ++k) last = a.integrate(st.clouds[k], Tbs, st.poses[k]);
+  EXPECT_EQ(b.integrateBatch(scans), last);
+  EXPECT_TRUE(last);
+  EXPECT_EQ(b.lastStats().n_cells_touched, a.lastStats().n_cells_touched);
+  EXPECT_TRUE(sameMaps(m_one, m_b));
+  EXPECT_FALSE(b.integrateBatch({}));
+}
+
 int main(int argc, char** argv) { return mini::run(argc > 1 ? argv[1] : nullptr); }

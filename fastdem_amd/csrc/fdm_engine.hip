@@ -239,6 +239,9 @@ struct fdm_engine {
   unsigned tb_stride = 0;            // words per descriptor row
   int tb_slots = 0;                  // scan slots the pools hold
   size_t tb_bin_cap = 0;             // bin blocks per batch the statistics arrays hold
+  float* d_bstage = nullptr;         // fdm_engine_integrate_host_batch: pageable clouds of a call, staged back to back
+  size_t bstage_cap = 0;             // floats
+  bool bstage_busy = false;          // launches of the previous call may still be reading it
   bool tpre_valid = false;           // the last tile-batch launch carried the scouts of the batch (tpre_scans, tpre_count) = number tpre_seq
   const fdm_device_scan* tpre_scans = nullptr;
   uint32_t tpre_count = 0;
@@ -1257,6 +1260,7 @@ void fdm_engine_destroy(fdm_engine* e) {
     if (e->tb_desc[k]) (void)hipFree(e->tb_desc[k]);
     if (e->tb_bin_part[k]) (void)hipFree(e->tb_bin_part[k]);
   }
+  if (e->d_bstage) (void)hipFree(e->d_bstage);
   if (e->d_route_owner) (void)hipFree(e->d_route_owner);
   if (e->d_route_cnt) (void)hipFree(e->d_route_cnt);
   if (e->tile_stamp32) (void)hipFree(e->tile_stamp32);
@@ -1375,6 +1379,79 @@ int fdm_engine_integrate_device_batch(fdm_engine* e, uint32_t count, const fdm_d
     if (rc < 0) return rc;  // (an empty cloud is skipped like the reference does, the batch goes on)
   }
   return FDM_OK;
+}
+
+// N consecutive FastDEM::integrate calls on HOST clouds.  Pinned channels are handed to the batch launches through
+// their device-visible alias (read in place, once, over PCIe: no batch kernel looks at a scan twice); pageable ones are
+// copied into an engine-owned block first (hipMemcpyAsync, which the runtime stages).
+int fdm_engine_integrate_host_batch(fdm_engine* e, uint32_t count, const fdm_device_scan* host_scans, fdm_scan_stats* out_last) {
+  if (!e || (count && !host_scans)) return fail(FDM_ERR_INVALID, "null argument");
+  HIPCK(hipSetDevice(e->device));
+  std::vector<fdm_device_scan> d(host_scans, host_scans + count);
+  // what has to be staged: floats per scan (x y z [i] [rgb] [var]) of the scans whose channels are not all pinned
+  std::vector<char> stage(count, 0);
+  size_t need = 0;
+  for (uint32_t k = 0; k < count; ++k) {
+    fdm_device_scan& s = d[k];
+    if (s.n == 0) continue;
+    if (!s.x || !s.y || !s.z) return fail(FDM_ERR_INVALID, "null xyz");
+    if (s.n >= 0x7FFFFFFFull) return fail(FDM_ERR_INVALID, "point count exceeds 2^31-1");
+    const float* mx = e->zero_copy ? static_cast<const float*>(pinned_alias(s.x)) : nullptr;
+    const float* my = mx ? static_cast<const float*>(pinned_alias(s.y)) : nullptr;
+    const float* mz = my ? static_cast<const float*>(pinned_alias(s.z)) : nullptr;
+    const float* ma = (mz && s.intensity) ? static_cast<const float*>(pinned_alias(s.intensity)) : nullptr;
+    const uint32_t* mc = (mz && s.rgb) ? static_cast<const uint32_t*>(pinned_alias(s.rgb)) : nullptr;
+    const float* mv = (mz && s.sigma_z2) ? static_cast<const float*>(pinned_alias(s.sigma_z2)) : nullptr;
+    if (mz && (!s.intensity || ma) && (!s.rgb || mc) && (!s.sigma_z2 || mv)) {
+      s.x = mx; s.y = my; s.z = mz; s.intensity = ma; s.rgb = mc; s.sigma_z2 = mv;
+    } else {
+      stage[k] = 1;
+      const size_t pad = (size_t(s.n) + 3u) & ~size_t(3);  // (every channel 16-byte aligned)
+      need += pad * (3u + (s.intensity ? 1u : 0u) + (s.rgb ? 1u : 0u) + (s.sigma_z2 ? 1u : 0u));
+    }
+  }
+  if (need > e->bstage_cap) {
+    if (int rc_sync = sync_all(e)) return rc_sync;  // (a launch still in flight may read the old block)
+    if (e->d_bstage) HIPCK(hipFree(e->d_bstage));
+    e->d_bstage = nullptr;
+    e->bstage_cap = need + need / 4 + 4096;
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_bstage), e->bstage_cap * sizeof(float)));
+  } else if (need && e->bstage_busy) {
+    // the previous call's launches may still be reading the block this call is about to overwrite
+    if (int rc_sync = sync_all(e)) return rc_sync;
+  }
+  float* cur = e->d_bstage;
+  for (uint32_t k = 0; k < count; ++k) {
+    if (!stage[k]) continue;
+    fdm_device_scan& s = d[k];
+    const size_t pad = (size_t(s.n) + 3u) & ~size_t(3);
+    auto up = [&](const void* src) -> const float* {
+      float* dst = cur;
+      cur += pad;
+      return hipMemcpyAsync(dst, src, size_t(s.n) * 4u, hipMemcpyHostToDevice, e->stream) == hipSuccess ? dst : nullptr;
+    };
+    const float *ux = up(s.x), *uy = up(s.y), *uz = up(s.z);
+    const float* ua = s.intensity ? up(s.intensity) : nullptr;
+    const float* uc = s.rgb ? up(s.rgb) : nullptr;
+    const float* uv = s.sigma_z2 ? up(s.sigma_z2) : nullptr;
+    if (!ux || !uy || !uz || (s.intensity && !ua) || (s.rgb && !uc) || (s.sigma_z2 && !uv))
+      return fail(FDM_ERR_HIP, "staging a host cloud");
+    s.x = ux; s.y = uy; s.z = uz; s.intensity = ua; s.rgb = reinterpret_cast<const uint32_t*>(uc); s.sigma_z2 = uv;
+  }
+  e->bstage_busy = need != 0;
+  // (clouds read in place cross PCIe once: no crop pass one launch ahead — it would read x / y / z a second time)
+  bool in_place = false;
+  for (uint32_t k = 0; k < count; ++k) in_place = in_place || (d[k].n && !stage[k]);
+  const int saved_crop = e->batch_crop;
+  if (in_place) e->batch_crop = 0;
+  const int rc_batch = fdm_engine_integrate_device_batch(e, count, d.data());
+  e->batch_crop = saved_crop;
+  if (rc_batch) return rc_batch;
+  if (!out_last) return FDM_OK;
+  int status = FDM_OK;
+  if (int rc = read_stats(e, out_last, &status)) return rc;
+  e->bstage_busy = false;  // (the stream has drained)
+  return status;
 }
 
 int fdm_engine_integrate_device_batch_timed(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) {

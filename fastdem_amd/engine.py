@@ -207,6 +207,14 @@ class Engine:
         across the language boundary."""
         return self._lib.fdm_engine_integrate_device_batch(self._h, len(scans) if count is None else count, scans)
 
+    def integrate_host_batch(self, scans, count=None, wait=True):
+        """`scans`: a ctypes array of capi.FdmDeviceScan whose pointers are HOST pointers (pinned: read in place; pageable:
+        staged) — N consecutive integrate() calls in batch launches.  wait: (status, statistics) of the last scan."""
+        st = FdmScanStats()
+        rc = _ck(self._lib.fdm_engine_integrate_host_batch(self._h, len(scans) if count is None else count, scans,
+                                                           C.byref(st) if wait else None))
+        return (rc, st.as_dict()) if wait else rc
+
     def integrate_device_batch_timed(self, scans, count=None):
         """The same between timer_start() and timer_stop(): timer_ms() afterwards is the batch's device time."""
         return self._lib.fdm_engine_integrate_device_batch_timed(self._h, len(scans) if count is None else count, scans)

@@ -161,6 +161,13 @@ typedef struct fdm_device_scan {
 } fdm_device_scan;
 int fdm_engine_integrate_device_batch(fdm_engine* e, uint32_t count, const fdm_device_scan* scans);
 /* Returns FDM_OK or the first error (< 0); an empty cloud in the batch is skipped and the batch goes on. */
+/* The same for HOST clouds (the pointers of `host_scans` are host pointers): N consecutive FastDEM::integrate calls —
+ * a bag replay, a driver that hands over the scans of the last 100 ms — in batch launches.  Pinned channels
+ * (fdm_host_alloc: every nanopcl::PointCloud of the C++ mirror) are read in place over PCIe, once; pageable ones are
+ * staged.  out_last != NULL: waits and returns the LAST scan's status and statistics like fdm_engine_integrate;
+ * NULL: enqueue-only — pinned clouds must then stay untouched until fdm_engine_sync(). */
+int fdm_engine_integrate_host_batch(fdm_engine* e, uint32_t count, const fdm_device_scan* host_scans,
+                                    fdm_scan_stats* out_last);
 
 /* Same, HOST arrays, enqueue-only; nothing waits.  For a stream of scans from host memory (bag replay,
  * a ROS callback).

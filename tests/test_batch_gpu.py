@@ -371,3 +371,48 @@ def test_a_chain_wait_that_runs_out_of_polls_fails_loudly_and_the_engine_recover
         m.set_start_index(0, 0)
     check_batch(gpu, R, eng, ref, scans, T(z=0.5), poses)
     assert eng.batch_launches()[0] >= 2
+
+
+def test_host_batch_entry_pinned_in_place_and_pageable(gpu, R):
+    """fdm_engine_integrate_host_batch: N integrate() calls on HOST clouds as one call.  Clouds from the engine's pinned
+    pool are read in place by the batch launches, pageable ones are staged — both against the oracle scan by scan;
+    status and statistics are the last scan's."""
+    import ctypes as C
+    wl = gpu.synth.vlp16(n_scans=5)
+    eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
+    eng.enable_cell_ids(False)
+    keep = []
+
+    def host_scans(ks, pinned):
+        arr = (gpu.capi.FdmDeviceScan * len(ks))()
+        for i, k in enumerate(ks):
+            s = wl.scan(k % 5)
+            d = arr[i]
+            d.n = int(s["x"].size)
+            for c in ("x", "y", "z", "intensity"):
+                if pinned:
+                    h = gpu.host_array(s[c], np.float32)
+                    keep.append(h)
+                    a = h.array
+                else:
+                    a = np.ascontiguousarray(s[c])
+                    keep.append(a)
+                setattr(d, c, a.ctypes.data)
+            d.rgb, d.sigma_z2 = None, None
+            d.T_base_sensor = (C.c_double * 16)(*np.ascontiguousarray(np.asarray(wl.T_base_sensor, dtype=np.float64).T).reshape(16))
+            d.T_world_base = (C.c_double * 16)(*np.ascontiguousarray(np.asarray(wl.pose(k), dtype=np.float64).T).reshape(16))
+        return arr
+
+    k0 = 0
+    for pinned, n in ((True, 21), (False, 19), (True, 3)):
+        ks = list(range(k0, k0 + n))
+        before = sum(eng.batch_launches())
+        rc_e, st_e = eng.integrate_host_batch(host_scans(ks, pinned))
+        for k in ks:
+            s = wl.scan(k % 5)
+            rc_r, st_r = ref.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k), intensity=s["intensity"])
+        assert (rc_e, st_e) == (rc_r, st_r)
+        assert sum(eng.batch_launches()) > before
+        assert_layers_bit_identical(eng, ref)
+        assert same_geometry(eng.geometry(), ref.geometry())
+        k0 += n
