@@ -228,7 +228,7 @@ struct fdm_engine {
   // ---- tile batches (fdm_tbatch.hpp): up to tbatch_max LARGE scans per launch on the record pools ----
   int tbatch = 0;                    // option "tbatch": fdm_engine_integrate_device_batch groups eligible large scans into tile
                                      // batches.  OFF by default: measured at configs[3] it does not beat one fused launch per
-                                     // scan (35.6-42 us per scan at 8 / 4 scans per launch against 33.7-34.4: DESIGN.md §3c)
+                                     // scan (35.6-42 us per scan at 8 / 4 scans per launch against 33.7-34.4: DESIGN.md §0 #1 / §3a)
   int tbatch_max = 8;                // option "tbatch_max": scans per launch (2 .. kTBMax)
   unsigned tbatch_min = 65536;       // option "tbatch_min": scans from this many points up
   int tb_groups = 512;               // option "tb_groups": update groups of a launch (each pulls tiles off a queue)

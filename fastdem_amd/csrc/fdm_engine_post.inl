@@ -263,7 +263,7 @@ int fdm_engine_apply_feature_extraction(fdm_engine* e, float radius, int min_val
   const int need_hi = nmax > 0 ? (nmax - 1) - static_cast<int>(hi_pct * float(nmax - 1)) + 1 : 1;
   const bool pct_ok = lo_pct >= 0.0f && hi_pct <= 1.0f && lo_pct <= 1.0f && hi_pct >= 0.0f;
   // the stencil reads ~113 neighbours per cell: from a cell-record field (64 B stride) every one of them
-  // is its own cache line — a dense copy of the layer first (C4: 0.82 -> see DESIGN.md §7)
+  // is its own cache line — a dense copy of the layer first (C4: 0.82 -> see LABNOTES.md, rounds 1-3 §7)
   const float* elev_p = lptr(e, *elev);
   int elev_s = lstride(e, *elev);
   if (elev_s != 1) {

@@ -24,7 +24,7 @@ def took_tile_batches(eng):
 
 @pytest.fixture(autouse=True)
 def tile_batches_on(gpu):
-    """The pipeline is an engine option, off by default (it does not beat one fused launch per scan, DESIGN.md §3c):
+    """The pipeline is an engine option, off by default (it does not beat one fused launch per scan, DESIGN.md §0 #1):
     every engine these tests build has it on, four scans to a launch unless a test says otherwise."""
     saved = dict(gpu.Engine.default_options)
     gpu.Engine.default_options = {**saved, "tbatch": 1, "tbatch_max": 4}
