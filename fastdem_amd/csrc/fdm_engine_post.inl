@@ -43,7 +43,14 @@ void region_disc(const fdm_engine* e, float radius, std::vector<RegionEntry>& re
 unsigned cell_blocks(const fdm_engine* e) { return unsigned((e->ncell + 255) / 256); }
 // The global list pool of the big-neighbourhood kernels (fdm_post.hpp, k_median_big): `per_thread` floats for each of
 // the threads in flight.  Returns the number of blocks of `threads` threads to launch.
-int ensure_pool(fdm_engine* e, size_t per_thread, unsigned threads, unsigned* blocks_out) {
+// The pooled kernels insertion-sort every cell's neighbourhood in global memory: ~ entries^2 / 4 moves per cell.  A call
+// is refused when that is more than ~1e13 moves over the map (minutes on the device — effectively a hang):
+// 1.44 M cells take neighbourhoods of up to ~5 000 entries (a 71 x 71 median), a 64 M-cell map ~790 (28 x 28).
+constexpr double kBigStencilMoves = 1.0e13;
+int ensure_pool(fdm_engine* e, size_t per_thread, unsigned threads, unsigned* blocks_out, size_t entries) {
+  if (double(entries) * double(entries) * 0.25 * double(e->ncell) > kBigStencilMoves)
+    return fail(FDM_ERR_INVALID, "neighbourhood too large for this map: " + std::to_string(entries) + " entries per cell x " +
+                                     std::to_string(e->ncell) + " cells would keep the device busy for minutes");
   const size_t want_threads = std::min<size_t>(((e->ncell + threads - 1) / threads) * threads, 16384);
   const size_t bytes = want_threads * per_thread * sizeof(float);
   if (bytes > e->post_pool_bytes) {
@@ -134,7 +141,7 @@ int fdm_engine_apply_spatial_smoothing(fdm_engine* e, const char* layer, int ker
   else {
     const size_t side = size_t(2 * (kernel_size / 2) + 1);
     unsigned blocks = 0;
-    if ((rc = ensure_pool(e, side * side, 256u, &blocks))) return rc;
+    if ((rc = ensure_pool(e, side * side, 256u, &blocks, side * side))) return rc;
     hipLaunchKernelGGL(k_median_big, dim3(blocks), dim3(256), 0, e->stream, e->G, e->d_state, int(e->scan_no & 3),
                        e->d_tmp, lptr(e, *l), lstride(e, *l), kernel_size, min_valid, unsigned(e->ncell), e->d_post_pool);
   }
@@ -202,7 +209,7 @@ int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* 
                        lptr(e, *lo), lstride(e, *lo), unsigned(e->ncell));
   } else {  // any radius the reference accepts (config/postprocess.hpp:35)
     unsigned blocks = 0;
-    if ((rc = ensure_pool(e, 4 * reg.size(), unsigned(kFusionThreads), &blocks))) return rc;
+    if ((rc = ensure_pool(e, 4 * reg.size(), unsigned(kFusionThreads), &blocks, reg.size()))) return rc;
     hipLaunchKernelGGL(k_fusion_big, dim3(blocks), dim3(kFusionThreads), 0, e->stream, e->G, e->d_state,
                        int(e->scan_no & 3), e->d_region, F, e->d_tmp, e->d_tmp2, lptr(e, *up), lstride(e, *up),
                        lptr(e, *lo), lstride(e, *lo), unsigned(e->ncell), e->d_post_pool);
@@ -292,7 +299,7 @@ int fdm_engine_apply_feature_extraction(fdm_engine* e, float radius, int min_val
   else if (reg.size() <= size_t(kMaxRegion)) launch_feat(k_features<0>);
   else {  // any radius the reference accepts (config/postprocess.hpp:45): the sorted heights in the global pool
     unsigned blocks = 0;
-    if ((rc = ensure_pool(e, reg.size(), 256u, &blocks))) return rc;
+    if ((rc = ensure_pool(e, reg.size(), 256u, &blocks, reg.size()))) return rc;
     hipLaunchKernelGGL(k_features_big, dim3(blocks), dim3(256), 0, e->stream, e->G, e->d_state, int(e->scan_no & 3),
                        e->d_region, F, elev_p, elev_s, O, unsigned(e->ncell), e->d_post_pool);
   }

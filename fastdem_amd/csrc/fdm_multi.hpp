@@ -490,20 +490,66 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
     if (inside) {
       if (z == 0.0f) atomicMin(S_zs + size_t(cell) * 2, (i << 1) | (__float_as_uint(z) >> 31));
       if (has_int && vint == 0.0f) atomicMin(S_zs + size_t(cell) * 2 + 1, (i << 1) | (__float_as_uint(vint) >> 31));
+    }
+    // what this point contributes to its cell
+    unsigned long long key = kEmptyKey;
+    uint32_t zmx = 0u, imx = 0u, fst = kNoIdx, lst = 0u;
+    if (inside) {
+      key = make_key(z, i);
+      zmx = make_zmax(z);
+      if (has_int) {
+        const bool vnan = isnan(vint);
+        imx = vnan ? 0u : ord(vint);
+        fst = (i << 1) | (vnan ? 1u : 0u);
+      }
+      lst = i;
+    }
+    // Neighbouring lanes are neighbouring points: on an image-ordered cloud (RGB-D rows) they fall into the same cell
+    // in runs of ten or twenty, and every LDS atomic of such a wavefront serialises on a handful of table slots
+    // (SQ_LDS_ADDR_CONFLICT, profiles/r04/pmc_lds_mbatch_halves.txt).  A wavefront whose runs are long merges them in
+    // registers first (segmented scan over runs of equal cell, as k_bin does) and only the run TAILS touch the table;
+    // a firing-order LiDAR scan (neighbouring lanes = different beams: every lane its own run) skips the merge —
+    // decided per wavefront from two ballots.  min / max are idempotent: either way the table ends up the same.
+    bool commit = inside;
+    {
+      const int prev_cell = __shfl_up(inside ? cell : -1, 1);
+      const bool head = inside && (lane == 0u || prev_cell != cell);
+      const unsigned n_in = unsigned(__popcll(__ballot(inside))), n_runs = unsigned(__popcll(__ballot(head)));
+      if (n_runs * 4u <= n_in) {  // (wave-uniform) average run >= 4 points
+        const int mcell = inside ? cell : -1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int ocell = __shfl_up(mcell, d);
+          const unsigned long long okey = __shfl_up(key, d);
+          const uint32_t ozmx = __shfl_up(zmx, d);
+          const uint32_t oimx = has_int ? __shfl_up(imx, d) : 0u;
+          const uint32_t ofst = has_int ? __shfl_up(fst, d) : kNoIdx;
+          if (int(lane) >= d && ocell == mcell && inside) {
+            key = okey < key ? okey : key;
+            zmx = ozmx > zmx ? ozmx : zmx;
+            imx = oimx > imx ? oimx : imx;
+            fst = ofst < fst ? ofst : fst;
+          }
+        }
+        // (lst: the tail of a run is its highest point index already)
+        const int next_cell = __shfl_down(mcell, 1);
+        commit = inside && (lane == 63u || next_cell != cell);
+      }
+    }
+    if (commit) {
       uint32_t hh = uint32_t(cell) & (kMBlock - 1u);
       while (true) {
         const uint32_t prev = atomicCAS(&S.t_cell[hh], kEmptyCell, uint32_t(cell));
         if (prev == kEmptyCell || prev == uint32_t(cell)) break;
         hh = (hh + 1) & (kMBlock - 1u);
       }
-      atomicMin(&S.t_key[hh], make_key(z, i));
-      atomicMax(&S.t_zmx[hh], make_zmax(z));  // (max with 0: no-op)
+      atomicMin(&S.t_key[hh], key);
+      atomicMax(&S.t_zmx[hh], zmx);  // (max with 0: no-op)
       if (has_int) {
-        const bool vnan = isnan(vint);
-        atomicMax(&S.t_imx[hh], vnan ? 0u : ord(vint));
-        atomicMin(&S.t_fst[hh], (i << 1) | (vnan ? 1u : 0u));
+        atomicMax(&S.t_imx[hh], imx);
+        atomicMin(&S.t_fst[hh], fst);
       }
-      if (has_col) atomicMax(&S.t_lst[hh], i);
+      if (has_col) atomicMax(&S.t_lst[hh], lst);
     }
     niw += unsigned(__popcll(__ballot(inside)));
   }
