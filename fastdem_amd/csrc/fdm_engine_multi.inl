@@ -124,10 +124,10 @@ int launch_mbatch(fdm_engine* e, int ch, const MUpd& U, const MBin& B, const MCr
   // rows as wide as the widest scan; the update's blocks fill as many leading rows as they need
   unsigned gx = 0u;
   for (unsigned k = 0; k < B.count; ++k) gx = std::max(gx, (B.n[k] + kMBlock - 1u) / kMBlock);
-  for (unsigned k = 0; k < Cn.count; ++k) gx = std::max(gx, (Cn.n[k] + kMBlock - 1u) / kMBlock);
-  if (gx == 0u) gx = std::min(ub, 64u);
+  if (gx == 0u) gx = std::min(std::max(ub, Cn.count * kMScout), 64u);
   if (gx == 0u) return FDM_OK;
-  const unsigned urows = (ub + gx - 1u) / gx, rows = urows + B.count + Cn.count;
+  const unsigned crows = (Cn.count * kMScout + gx - 1u) / gx;  // the scout blocks of the next batch, in rows of their own
+  const unsigned urows = (ub + gx - 1u) / gx, rows = urows + B.count + crows;
   MCommon Kt = K;
   Kt.timeline = (e->d_timeline && gx * rows <= e->timeline_cap && B.count) ? e->d_timeline : nullptr;
   if (Kt.timeline) { e->timeline_blocks = gx * rows; e->timeline_upd = gx; e->timeline_bin = urows; }

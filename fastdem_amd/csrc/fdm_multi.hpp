@@ -13,11 +13,10 @@
 //
 //   crop half    Scan k is binned against the map geometry AFTER the LOCAL-mode moves of scans 0..k, and whether
 //                scan j moved the map depends on whether any of its points survived the crops (fastdem.cpp:138) —
-//                device-side data.  The crops need no geometry, so they are evaluated ONE LAUNCH AHEAD: a light
-//                pass over the next batch's points (first transform + cropRange + cropZ, the same float
-//                operations the bin half will run) ORs "scan k has a surviving point" into the next batch's
-//                state word; the kernel boundary is the barrier.  It also pulls the next batch's points into the
-//                cache.  Without a look-ahead (the first batch of a call, a lone batch) the bin half falls back to
+//                device-side data.  The crops need no geometry, so the question is answered ONE LAUNCH AHEAD: a few
+//                scout blocks per scan of the next batch (first transform + cropRange + cropZ, the same float
+//                operations the bin half will run; first survivor, early exit) OR "scan k has a surviving point"
+//                into the next batch's state word; the kernel boundary is the barrier.  Without a look-ahead (the first batch of a call, a lone batch) the bin half falls back to
 //                an in-launch protocol: every block publishes with one atomic on its scan's own cache line, the
 //                block that completes a scan raises its bits in the state word, later scans' blocks poll that ONE
 //                word (a block only ever waits for blocks with a lower index, which never wait before publishing:
@@ -198,29 +197,38 @@ template <bool COL>
 constexpr unsigned kMLdsBytes = sizeof(MUpdLds<COL>) > sizeof(MBinLds) ? sizeof(MUpdLds<COL>) : sizeof(MBinLds);
 
 // ---------------------------------------------------------------------------------------------
-// crop half: block `bid` of the NEXT batch's grid — kMBlock points per block, like its bin half will be.
-__device__ __forceinline__ void mcrop_body(const MCrop& Cn, const MCommon& K, const unsigned k, const unsigned lb,
-                                           unsigned* s_any) {
-  const unsigned lane = threadIdx.x & 63u;
+// crop half: SCOUT blocks of the NEXT batch's scans — does scan k hold a point that survives the crops (then it moves a
+// LOCAL map, fastdem.cpp:138-145)?  kMScout blocks per scan walk it with a grid stride, kMBlock points per block and
+// step, and leave at the first step in which any thread of the block sees a survivor: for a real scan that is the
+// first step, only a scan without survivors (a covered sensor) is read to its end.  (Round 3 ran the crops over EVERY
+// point of the next batch here — as many blocks again as the bin half, a third of the launch's blocks and of its input
+// traffic, for sixteen bits: configs[2] 10.5 us per scan, VERDICT r03 #6.)
+constexpr unsigned kMScout = 4u;
+__device__ __forceinline__ void mcrop_body(const MCrop& Cn, const MCommon& K, const unsigned k, const unsigned sb) {
   MView V;
   V.Tbs = K.Tbs; V.Twb12 = nullptr; V.R = nullptr; V.sp = K.sp;
   V.min_sq = K.min_sq; V.max_sq = K.max_sq; V.z_min = K.z_min; V.z_max = K.z_max;
   V.sensor_type = K.sensor_type; V.integrate_mode = K.integrate_mode;
-  bool pass = false;
+  const unsigned n = Cn.n[k];
+  const float* __restrict__ const px = Cn.px[k];
+  const float* __restrict__ const py = Cn.py[k];
+  const float* __restrict__ const pz = Cn.pz[k];
+#pragma unroll 1
+  for (unsigned i0 = sb * kMBlock; i0 < n; i0 += kMScout * kMBlock) {  // (block-uniform)
+    bool pass = false;
 #pragma unroll
-  for (int h = 0; h < kMPts; ++h) {
-    const unsigned i = lb * kMBlock + unsigned(h) * 256u + threadIdx.x;
-    if (i < Cn.n[k]) {
-      float x = Cn.px[k][i], y = Cn.py[k][i], z = Cn.pz[k][i], w;
-      pass = mcrops(V, x, y, z, w) || pass;
+    for (int h = 0; h < kMPts; ++h) {
+      const unsigned i = i0 + unsigned(h) * 256u + threadIdx.x;
+      if (i < n) {
+        float x = px[i], y = py[i], z = pz[i], w;
+        pass = mcrops(V, x, y, z, w) || pass;
+      }
+    }
+    if (__syncthreads_or(pass ? 1 : 0)) {
+      if (threadIdx.x == 0) atomicOr(&Cn.ms->flags[0], 0x10000u << k);  // (<= kMScout per scan)
+      return;
     }
   }
-  // one OR per block is plenty: ~100 blocks per scan on one word, fire and forget
-  if (threadIdx.x == 0) *s_any = 0u;
-  __syncthreads();
-  if (__ballot(pass) && lane == 0u) *s_any = 1u;
-  __syncthreads();
-  if (threadIdx.x == 0 && *s_any) atomicOr(&Cn.ms->flags[0], 0x10000u << k);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -343,17 +351,39 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
         }
       };
       unsigned m = K.dbg == 2 ? 0u : ((K.gate_on_filter ? passmask : 0xFFFFu) & ((1u << k) - 1u));  // the moves ahead of scan k
+      bool unwrapped = false;
       while (m) {  // (a scan that returned before its move is not in the mask)
         const unsigned j = unsigned(__ffs(int(m))) - 1u;
         m &= m - 1u;
         int dx, dy;
         shift_of(j, dx, dy);
-        g.sr -= dx; g.sc -= dy;
-        wrap_index(g.sr, G.rows);
-        wrap_index(g.sc, G.cols);
+        // The start index is wrapped ONCE behind the walk.  For a shift of fewer cells than the map has,
+        // wrapIndexToRange returns the representative in [0, size) of its argument modulo size — wrapping after every
+        // move and reducing the sum are then the same number, and the per-move wrap was a third of the walk's serial
+        // instructions (0.35 us per move on a full chip: 5 us for the blocks of a batch's sixteenth scan, which is what
+        // ended the launch).  A shift of >= size cells (a jump beyond the map) takes the reference's own function at its
+        // place in the walk, quirks included (it returns `size` for an argument of -2 size).
+        const bool small = unsigned(dx + G.rows - 1) < unsigned(2 * G.rows - 1) && unsigned(dy + G.cols - 1) < unsigned(2 * G.cols - 1);
+        if (!small) {
+          if (unwrapped) {
+            g.sr %= G.rows; if (g.sr < 0) g.sr += G.rows;
+            g.sc %= G.cols; if (g.sc < 0) g.sc += G.cols;
+            unwrapped = false;
+          }
+          g.sr -= dx; g.sc -= dy;
+          wrap_index(g.sr, G.rows);
+          wrap_index(g.sc, G.cols);
+        } else {
+          g.sr -= dx; g.sc -= dy;
+          unwrapped = true;
+        }
         g.px = g.px + double(dx) * G.res;
         g.py = g.py + double(dy) * G.res;
         vx += dx; vy += dy;
+      }
+      if (unwrapped) {  // (the small shifts accumulated since the last wrap)
+        g.sr %= G.rows; if (g.sr < 0) g.sr += G.rows;
+        g.sc %= G.cols; if (g.sc < 0) g.sc += G.cols;
       }
       int dx, dy;
       shift_of(k, dx, dy);
@@ -865,9 +895,9 @@ __global__ __launch_bounds__(256, MBatchWaves<POLICY>::value) void k_mbatch(cons
   } else if (row < upd_rows + B.count) {
     const unsigned k = row - upd_rows;
     if (x < (B.n[k] + kMBlock - 1u) / kMBlock) mbin_body<CH>(B, K, G, st, ncell, k, x, *reinterpret_cast<MBinLds*>(lds));
-  } else {
-    const unsigned k = row - upd_rows - B.count;
-    if (x < (Cn.n[k] + kMBlock - 1u) / kMBlock) mcrop_body(Cn, K, k, x, reinterpret_cast<unsigned*>(lds));
+  } else {  // scout rows: block c of Cn.count * kMScout
+    const unsigned c = (row - upd_rows - B.count) * gridDim.x + x;
+    if (c < Cn.count * kMScout) mcrop_body(Cn, K, c / kMScout, c % kMScout);
   }
   if (K.timeline && threadIdx.x == 0) {  // (thread 0's view of the block; scripts/timeline_batch.py)
     const unsigned b = blockIdx.y * gridDim.x + x;

@@ -1,11 +1,14 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$PWD}
-O=$R/gpurun_out/r04_ab3
+O=$R/gpurun_out/r04_walk
 mkdir -p $O
 cd $R
-timeout 300 python scripts/phases_tiled.py c4 > $O/phases_single.json 2>> $O/err.txt || tail -3 $O/err.txt
-python - <<'PY'
-import json
-d=json.load(open("gpurun_out/r04_ab3/phases_single.json"))
-print("span",d["span_us"]); print(" upd", d["update_all"]); print(" bin", d["bin"]); print(" bin_first", d["bin_first_round"]); print(" bin_late", d["bin_late"])
+timeout 900 python -m pytest tests/test_batch_gpu.py tests/test_tbatch_gpu.py -m gpu -q -x 2>&1 | tail -4
+for W in c2 c3; do
+timeout 600 python bench.py --workload $W --no-cpu-baseline --no-host-legs --no-large > $O/bench_$W.json 2>$O/err_$W.txt || tail -3 $O/err_$W.txt
+python - $W <<'PY'
+import json,sys
+w=sys.argv[1]
+d=json.loads([l for l in open(f'gpurun_out/r04_walk/bench_{w}.json') if l.startswith('{')][-1]); print(w, 'value', d['value'], 'us/scan', d['timed_region_us_per_scan_hip_events'], 'frac', d['roofline']['frac'], 'cache_resident', d.get('cache_resident',{}).get('us_per_scan_hip_events'), 'latency', d['latency_path']['us_per_scan'])
 PY
+done
