@@ -77,8 +77,8 @@ struct DevState {
   unsigned vis_int;
   unsigned ray_count;  // rays queued by k_ray_compact for k_ray; k_ray_resolve puts it back to 0
   unsigned vis_col, vis_ray;
-  unsigned fault;      // sticky: a device-side invariant failed (a batch's chain wait ran out of polls); reported by
-  unsigned pad_f[3];   // the next statistics read-back as FDM_ERR_HIP
+  unsigned fault;      // a device-side invariant failed: reported once by the next sync / statistics read-back as FDM_ERR_HIP.
+  unsigned pad_f[3];   // (Nothing sets it since round 4: no kernel of the engine waits for another block any more.)
 };
 
 struct GeomConst {

@@ -217,7 +217,7 @@ struct fdm_engine {
   unsigned mseq = 0;                 // batches enqueued so far
   int last_batch_n = 0;              // scans of the batch launch the last scan left in (0: it took the single-scan path)
   uint64_t n_mbatch = 0, n_tbatch = 0;  // batch launches since creation (fdm_engine_debug_batch_launches)
-  bool fault_watch = false;          // a launch with an in-kernel bounded wait was enqueued since DevState::fault was last read
+  bool fault_watch = false;          // a launch that can raise DevState::fault was enqueued since it was last read (none can since round 4)
   int dbg_batch = 0;                 // measurement only (option "dbg_batch")
   int batch_crop = 1;                // option "batch_crop": evaluate the next batch's crops one launch ahead
   bool pre_valid = false;            // the last launch carried the crop pass of the batch (pre_scans, pre_count) = number pre_seq
@@ -1439,14 +1439,7 @@ int fdm_engine_integrate_host_batch(fdm_engine* e, uint32_t count, const fdm_dev
     s.x = ux; s.y = uy; s.z = uz; s.intensity = ua; s.rgb = reinterpret_cast<const uint32_t*>(uc); s.sigma_z2 = uv;
   }
   e->bstage_busy = need != 0;
-  // (clouds read in place cross PCIe once: no crop pass one launch ahead — it would read x / y / z a second time)
-  bool in_place = false;
-  for (uint32_t k = 0; k < count; ++k) in_place = in_place || (d[k].n && !stage[k]);
-  const int saved_crop = e->batch_crop;
-  if (in_place) e->batch_crop = 0;
-  const int rc_batch = fdm_engine_integrate_device_batch(e, count, d.data());
-  e->batch_crop = saved_crop;
-  if (rc_batch) return rc_batch;
+  if (int rc_batch = fdm_engine_integrate_device_batch(e, count, d.data())) return rc_batch;
   if (!out_last) return FDM_OK;
   int status = FDM_OK;
   if (int rc = read_stats(e, out_last, &status)) return rc;

@@ -224,7 +224,6 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
   B.prev = fuse ? e->pend.MU.ms : nullptr;
   B.prev_count = fuse ? e->pend.MU.count : 0u;
   B.obs_stride = unsigned(e->mobs_stride);
-  B.pre = pre ? 1u : 0u;
   B.key = e->mkey[par];
   B.aux = e->maux[par];
   B.zs = e->mzs[par];
@@ -233,20 +232,33 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
   B.bin_part = e->mbin_part[par];
   if (fuse) U = e->pend.MU;
 
-  // crop pass for the batch after this one (only a gated LOCAL-mode chain depends on it)
-  if (next_count >= 2u && K.do_move && K.gate_on_filter && e->batch_crop &&
-      std::memcmp(scans[count].T_base_sensor, f.T_base_sensor, 16 * sizeof(double)) == 0) {
-    unsigned cb = 0;
-    for (uint32_t k = 0; k < next_count; ++k) {
-      const fdm_device_scan& s = scans[count + k];
-      Cn.first_block[k] = cb;
-      Cn.n[k] = uint32_t(s.n);
-      Cn.px[k] = s.x; Cn.py[k] = s.y; Cn.pz[k] = s.z;
-      cb += unsigned((s.n + kMBlock - 1u) / kMBlock);
+  // "scan k has a point that survives the crops" (it moves a LOCAL map, fastdem.cpp:138-145) must be in the batch's
+  // state word when its bin blocks start: the scouts of the previous launch left it there if they scouted THIS batch;
+  // otherwise (the first batch of a call) a small launch of scouts runs ahead of it
+  auto fill_scouts = [&](MCrop& C, uint32_t n, const fdm_device_scan* ss, MState* ms) {
+    std::memset(&C, 0, sizeof(C));
+    for (uint32_t k = 0; k < n; ++k) {
+      C.n[k] = uint32_t(ss[k].n);
+      C.px[k] = ss[k].x; C.py[k] = ss[k].y; C.pz[k] = ss[k].z;
     }
-    for (uint32_t k = next_count; k <= uint32_t(kMaxBatch); ++k) Cn.first_block[k] = cb;
-    Cn.count = next_count;
-    Cn.ms = e->mstate + int((seq + 1u) % unsigned(kMStates));
+    C.count = n;
+    C.ms = ms;
+  };
+  const bool gated = K.do_move && K.gate_on_filter;
+  if (gated && !pre) {
+    MUpd U0;
+    MBin B0;
+    MCrop C0;
+    std::memset(&U0, 0, sizeof(U0));
+    std::memset(&B0, 0, sizeof(B0));
+    fill_scouts(C0, count, scans, e->mstate + slot);
+    if ((rc = launch_mbatch(e, ch, U0, B0, C0, K))) return rc;
+  }
+  B.pre = 1u;
+  // ... and the scouts of the batch after this one ride in this launch (option "batch_crop" 0: they never do)
+  if (next_count >= 2u && gated && e->batch_crop &&
+      std::memcmp(scans[count].T_base_sensor, f.T_base_sensor, 16 * sizeof(double)) == 0) {
+    fill_scouts(Cn, next_count, scans + count, e->mstate + int((seq + 1u) % unsigned(kMStates)));
     e->pre_valid = true;
     e->pre_scans = scans + count;
     e->pre_count = next_count;
@@ -285,7 +297,6 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
   e->ray_timed = false;
   e->scan_no += count;
   e->last_batch_n = int(count);
-  e->fault_watch = true;
   ++e->n_mbatch;
   e->have_scan = true;
   e->last_n = uint32_t(l.n);

@@ -277,7 +277,6 @@ int enqueue_tbatch(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, 
   e->ray_timed = false;
   e->scan_no += count;
   e->last_batch_n = int(count);
-  e->fault_watch = true;
   ++e->n_tbatch;
   e->have_scan = true;
   e->last_n = uint32_t(l.n);

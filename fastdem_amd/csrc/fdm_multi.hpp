@@ -16,11 +16,10 @@
 //                device-side data.  The crops need no geometry, so the question is answered ONE LAUNCH AHEAD: a few
 //                scout blocks per scan of the next batch (first transform + cropRange + cropZ, the same float
 //                operations the bin half will run; first survivor, early exit) OR "scan k has a surviving point"
-//                into the next batch's state word; the kernel boundary is the barrier.  Without a look-ahead (the first batch of a call, a lone batch) the bin half falls back to
-//                an in-launch protocol: every block publishes with one atomic on its scan's own cache line, the
-//                block that completes a scan raises its bits in the state word, later scans' blocks poll that ONE
-//                word (a block only ever waits for blocks with a lower index, which never wait before publishing:
-//                no deadlock; the spin is bounded and raises MState::err instead of hanging).
+//                into the next batch's state word; the kernel boundary is the barrier.  The first batch of a call has
+//                no launch ahead of it: its scouts run as a small launch of their own.  (Rounds 3: an in-launch protocol
+//                for that case — every block adds itself to its scan's counter, later scans' blocks poll a state word,
+//                bounded spin, a sticky fault when it ran out.  Gone: no block of this kernel ever waits for another.)
 //   bin half     512 points per block (two per thread), scan k of the batch; the first wavefront walks the chain of k
 //                moves (every lane rounds its own scan's pose once; only the position is accumulated in scan order;
 //                the reference's divide only for poses on a rounding tie) while the point loads are in flight.
@@ -49,7 +48,6 @@
 namespace fdm {
 
 constexpr int kMaxBatch = 16;            // scans per launch (one bit per scan in 16-bit halves of a state word)
-constexpr unsigned kSpinMax = 1u << 22;  // polls before a waiting block gives up (seconds; never reached in practice)
 constexpr int kLineWords = 32;           // a 128-byte line of 32-bit words
 #ifndef FDM_MB_WAVES
 #define FDM_MB_WAVES 6  // waves per SIMD k_mbatch is compiled for (<= 80 VGPRs; the LDS allows 6 blocks per CU): every block of a 16-scan VLP-16 batch resident at once
@@ -61,10 +59,10 @@ constexpr int kMStates = 4;              // ring of batch states: update b-1 | b
 struct MState {
   DevGeom E[kMaxBatch];        // geometry before scan k (written by the scan's first bin block)
   DevCand C[kMaxBatch];        // geometry after its move + the index shift
-  unsigned done[kMaxBatch * kLineWords];  // [k * 32]: blocks of scan k past the crops | blocks with a surviving point << 16
+  unsigned done[kMaxBatch * kLineWords];  // tile batches (fdm_tbatch.hpp): [k * 32 + 1] = scan k has a surviving point (each on its own line)
   unsigned flags[kLineWords];  // [0]: bit k = every block of scan k is past the crops, bit 16 + k = scan k has a surviving point
   unsigned inside[kMaxBatch];  // some point of scan k landed in the map (elevation_mapping.cpp:118)
-  unsigned err;                // a waiting block ran out of polls
+  unsigned err;                // (unused since round 4: nothing waits inside a launch)
   unsigned tq;                 // tile batches (fdm_tbatch.hpp): the update groups' tile queue ...
   unsigned gdone;              // ... and how many of them have left (the last one commits the geometry ring)
   unsigned pad[13];
@@ -89,7 +87,7 @@ struct MBin {     // bin half: batch b
   const MState* prev;                    // the previous batch's state while its update shares this launch (else null)
   unsigned prev_count;
   unsigned obs_stride;                   // points per scan slot of obs / cobs
-  unsigned pre;                          // 1: the crop pass of the previous launch left the batch's pass bits in ms->flags
+  unsigned pre;                          // (always 1: scouts decided the batch's pass bits before this launch)
   unsigned pad;
   // per-scan scratch, slot k at + k * ncell (key, aux, zs as in Scratch)
   unsigned long long* key;
@@ -399,10 +397,11 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
       if (lb == 0u) { ms->E[k] = g; ms->C[k] = c; }
     }
   };
+  // (which of the scans ahead moved the map is known before the launch starts: the scout blocks of the previous launch —
+  // or a small launch of their own ahead of a call's first batch — left it in the state word.  The walk runs in the
+  // shadow of the point loads; nothing is published, nothing is polled)
   const bool gated = K.do_move && K.gate_on_filter;
-  const bool must_wait = gated && k > 0u && !B.pre;  // block-uniform
-  if (threadIdx.x < 64u && !must_wait)  // the pass bits are known (or irrelevant): in the shadow of the point loads
-    chain((gated && k > 0u) ? uni(ms->flags[0] >> 16) : 0xFFFFu);
+  if (threadIdx.x < 64u) chain((gated && k > 0u) ? uni(ms->flags[0] >> 16) : 0xFFFFu);
 
 #if FDM_MB_PHASES == 2
   FDM_PHASE(2);
@@ -426,38 +425,8 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
 #if FDM_MB_PHASES != 2
   FDM_PHASE(1);  // points arrived, crops + both transforms done
 #endif
-  __syncthreads();  // table, s_pt, s_pass (and s_cand unless the block has to wait)
+  __syncthreads();  // table, s_pt, s_pass, s_cand
   const unsigned np = S.s_pass[0] + S.s_pass[1] + S.s_pass[2] + S.s_pass[3];
-  if (!B.pre && gated) {  // no crop pass ran ahead of this batch: the blocks publish what they found
-    if (threadIdx.x < 64u) {
-      unsigned f = 0u;
-      if (threadIdx.x == 0) {
-        // one add on the scan's own line; the block that completes the scan raises its two bits in `flags`
-        const unsigned mine = 1u | (np ? 0x10000u : 0u);
-        const unsigned tot = atomicAdd(&ms->done[k * kLineWords], mine) + mine;
-        if ((tot & 0xFFFFu) == B.first_block[k + 1u] - B.first_block[k])
-          atomicOr(&ms->flags[0], (1u << k) | ((tot >> 16) ? (0x10000u << k) : 0u));
-        else if (np && (tot >> 16) == 1u)  // the scan's FIRST block with a surviving point says so at once: "scan k
-          atomicOr(&ms->flags[0], 0x10000u << k);  // moves the map" is then known long before its last block is done
-        if (must_wait) {  // ... and wait for the scans ahead: ONE word, ONE poller per block
-          const unsigned need = (1u << k) - 1u;
-          unsigned spins = 0u;
-          if (K.dbg == 4) ms->err = 1u;  // (tests provoke the fault: as if this wait had run out of polls)
-          while (true) {  // every earlier scan either has a surviving point (pass bit) or is through its crops (done bit)
-            f = __hip_atomic_load(&ms->flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (((f | (f >> 16)) & need) == need) break;
-            if (++spins >= kSpinMax) {
-              ms->err = 1u;
-              break;
-            }
-            __builtin_amdgcn_s_sleep(8);  // (~0.25 us: the pollers stay off the line the completing blocks write)
-          }
-        }
-      }
-      if (must_wait) chain(uni(f) >> 16);  // (lane 0 polled; the wavefront walks)
-    }
-    if (must_wait) __syncthreads();
-  }
   const DevCand cand = S.s_cand;
 
   unsigned long long* const S_key = B.key + size_t(k) * ncell;
@@ -690,7 +659,6 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
       if (has_int && st->vis_int == 0u) st->vis_int = 3u * first_upd + 2u;
       if (has_col && st->vis_col == 0u) st->vis_col = 3u * first_upd + 2u;
     }
-    if (ms->err) st->fault = 1u;
   }
   if (bid == 0 && lt >= 64u && lt < 64u + unsigned(kMaxBatch)) {  // re-arm the state of the batch after next
     U.rearm->done[(lt - 64u) * kLineWords] = 0u;

@@ -356,7 +356,6 @@ __device__ __forceinline__ void tbupdate_body(const TBUpd& U, const GeomConst& G
         if (HAS_INT && st->vis_int == 0u) st->vis_int = 3u * first_upd + 2u;
         if (HAS_COL && st->vis_col == 0u) st->vis_col = 3u * first_upd + 2u;
       }
-      if (ms->err) st->fault = 1u;
       for (int q = 0; q < kMaxBatch; ++q) {
         U.rearm->done[q * kLineWords] = 0u; U.rearm->done[q * kLineWords + 1] = 0u; U.rearm->inside[q] = 0u;
       }

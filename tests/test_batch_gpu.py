@@ -338,39 +338,30 @@ def test_batch_option_off_is_the_same_map(gpu, R):
     assert same_geometry(a.geometry(), b.geometry())
 
 
-def test_a_chain_wait_that_runs_out_of_polls_fails_loudly_and_the_engine_recovers(gpu, R):
-    """MState::err (fdm_multi.hpp): a bin block of a small-scan batch that waits for the scans ahead of it gives up after
-    a bounded number of polls instead of hanging the GPU.  `dbg_batch` 4 makes every such wait give up after two polls:
-    the call's next synchronisation point reports FDM_ERR_HIP — once — and after reset() the same engine integrates
-    correctly again.  (The tile batches have no in-kernel wait: their flags are decided one launch ahead.)"""
+def test_first_batch_of_every_call_and_short_calls(gpu, R):
+    """No block of a batch launch waits for another one: which scans of a batch move the map is decided before the launch
+    starts, by scout blocks that ride in the previous launch — or, for the FIRST batch of a call, in a small launch of
+    their own.  Many short calls (2 ... 5 scans: every batch is a first batch), filtered scans first / last / everywhere,
+    against the oracle scan by scan."""
     def fill(c):
-        c.z_min, c.z_max, c.range_min, c.range_max = -2.0, 3.0, 0.0, 30.0
+        c.z_min, c.z_max, c.range_min, c.range_max = -1.0, 2.0, 0.5, 20.0
 
-    eng, ref = pair(gpu, R, 8.0, 6.0, 0.1, fill)
-    rng = np.random.default_rng(29)
-    scans = [cloud(rng, 30000, 3.5, intensity=True) for _ in range(17)]
-    poses = [T(0.3 * k, 0.1 * k, 0.0) for k in range(17)]
-    eng.enable_cell_ids(False)  # (an engine that owes its caller cell ids takes no batch launch)
-    b0 = DeviceBatch(gpu, scans[:1], T(z=0.5), poses[:1])
-    assert eng.integrate_device_batch(b0.arr) == 0  # the first scan creates the layers, alone
-    eng.sync()
-    if eng.last_pipeline() == 1:
-        pytest.skip("this fixture variant sends every scan through the record pools: no small-scan batch, no wait")
-    eng.set_option("dbg_batch", 4)
-    eng.set_option("batch_crop", 0)  # (no crops one launch ahead: every batch waits in its own launch)
-    b = DeviceBatch(gpu, scans[1:], T(z=0.5), poses[1:])
-    assert eng.integrate_device_batch(b.arr) == 0  # (enqueue-only: nothing has run yet)
-    with pytest.raises(RuntimeError, match="fault"):
-        eng.sync()
-    eng.sync()  # reported once
-    eng.set_option("dbg_batch", 0)
-    eng.set_option("batch_crop", 1)
-    for m in (eng, ref):  # FastDEM::reset() = clearAll on both sides, the window back where it started
-        m.clear()
-        m.set_position(0.0, 0.0)
-        m.set_start_index(0, 0)
-    check_batch(gpu, R, eng, ref, scans, T(z=0.5), poses)
-    assert eng.batch_launches()[0] >= 2
+    eng, ref = pair(gpu, R, 10.0, 10.0, 0.1, fill)
+    rng = np.random.default_rng(123)
+    k = 0
+    for call in range(14):
+        n = 2 + call % 4
+        dead = {(call * 3) % n} if call % 3 else ({0, n - 1} if call % 2 else set(range(n)))
+        scans, poses = [], []
+        for j in range(n):
+            s = cloud(rng, 1800 + 50 * j, 4.0, intensity=True)
+            if j in dead:
+                s["z"] = (s["z"] + 50.0).astype(F32)
+            scans.append(s)
+            poses.append(T(0.23 * k, -0.17 * k, 0.0, yaw=0.02 * k))
+            k += 1
+        check_batch(gpu, R, eng, ref, scans, T(z=0.4), poses, expect_batches=False)
+    assert sum(eng.batch_launches()) >= 14
 
 
 def test_host_batch_entry_pinned_in_place_and_pageable(gpu, R):
