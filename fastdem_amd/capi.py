@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfdm_engine.so")
+LIB_PATH = os.environ.get("FDM_ENGINE_LIB") or os.path.join(_HERE, "lib", "libfdm_engine.so")  # (FDM_ENGINE_LIB: another build of the same ABI, for A/B measurements)
 
 
 class FdmConfig(C.Structure):

@@ -31,6 +31,7 @@
 #include "fdm_tbatch.hpp"
 #include "fdm_route.hpp"
 #include "fdm_raycast.hpp"
+#include "fdm_rbatch.hpp"
 #include "fdm_rsort.hpp"
 #include "fdm_egress.hpp"
 #include "fdm_ingest.hpp"
@@ -225,6 +226,17 @@ struct fdm_engine {
   uint32_t pre_count = 0;
   unsigned pre_seq = 0;
   const unsigned long long* last_bin_part = nullptr;  // per-block statistics of the last scan (either pipeline)
+  // ---- raycasting inside the small-scan batches (fdm_rbatch.hpp) ----
+  int batch_ray = 1;                 // option "batch_ray": 0 = an engine with raycasting on takes the single-scan path
+  int batch_ray_seg = 4;             // option "batch_ray_seg": lanes per ray of k_rb_ray (1, 4, 8, 16)
+  RState* rb_state = nullptr;
+  float* rb_cap = nullptr;           // [3][kMaxBatch][rb_stride] preprocessed clouds of the batch being binned
+  uint32_t* rb_u32 = nullptr;        // keys | place | sel | ray_list, [kMaxBatch][rb_stride] each
+  uint4* rb_rec = nullptr;           // [kMaxBatch][rb_stride]
+  uint32_t* rb_counters = nullptr;   // fine [kMaxBatch][2^18] | coarse [kMaxBatch][kVsCoarse]
+  uint32_t* rb_img = nullptr;        // rc_cnt [kMaxBatch][ncell] | rc_min [kMaxBatch][ncell]
+  size_t rb_stride = 0;
+  unsigned rb_seq = 0;               // stamp of the last batch's ray launches (RState::any)
   // ---- tile batches (fdm_tbatch.hpp): up to tbatch_max LARGE scans per launch on the record pools ----
   int tbatch = 0;                    // option "tbatch": fdm_engine_integrate_device_batch groups eligible large scans into tile
                                      // batches.  OFF by default: measured at configs[3] it does not beat one fused launch per
@@ -525,6 +537,8 @@ int activate_records(fdm_engine* e, int kind) {
 // ---- raycasting stage: defined in fdm_engine_ray.inl (same translation unit) ----
 bool voxel_size_ok(float v);
 int ensure_ray_layers(fdm_engine* e);
+VoxelCompact voxel_compact_of(float voxel_size, const double* box);
+void ray_box_of(const fdm_engine* e, const ScanParams& P, double box[6]);
 int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slot, const float* dx,
                        const float* dy, const float* dz, const double* box, int* key_mode);
 fdm_raycast_config ray_config_of(const fdm_config& c);
@@ -799,20 +813,8 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   if (ray_on) {  // step 3 of integrateImpl (fastdem.cpp:152-159) on the map this scan just updated
     if (e->profile) HIPCK(hipEventRecord(e->ev_ray[0], e->stream));
     const float origin[3] = {P.ray_ox, P.ray_oy, P.ray_oz};
-    // cropRange keeps d^2 <= range_max^2 around the BASE origin, i.e. around T_world_base's translation
-    // ... and cropZ keeps z_base in [z_min, z_max]: z_map = R20 x + R21 y + R22 z + t_z with |R20 x + R21 y|
-    // <= hypot(R20, R21) * range_max (column-major Twb: R2j = Twb[4 j + 2])
-    double zlo = NAN, zhi = NAN;
-    if (std::isfinite(double(e->cfg.z_min)) && std::isfinite(double(e->cfg.z_max)) &&
-        std::fabs(double(e->cfg.z_min)) < 1e6 && std::fabs(double(e->cfg.z_max)) < 1e6 &&
-        std::isfinite(double(e->cfg.range_max)) && double(e->cfg.range_max) < 1e6) {
-      const double r20 = double(P.Twb[2]), r21 = double(P.Twb[6]), r22 = double(P.Twb[10]);
-      const double tilt = std::hypot(r20, r21) * double(e->cfg.range_max);
-      const double a = r22 * double(e->cfg.z_min), b = r22 * double(e->cfg.z_max);
-      zlo = P.base_z + std::min(a, b) - tilt;
-      zhi = P.base_z + std::max(a, b) + tilt;
-    }
-    const double box[6] = {P.base_x, P.base_y, P.base_z, double(e->cfg.range_max), zlo, zhi};
+    double box[6];
+    ray_box_of(e, P, box);
     int key_mode = 0;
     if ((rc = enqueue_voxel_sort(e, P.n, static_cast<float>(e->G.res), P.slot, e->S.cap_x, e->S.cap_y,
                                  e->S.cap_z, box, &key_mode)))
@@ -1255,6 +1257,12 @@ void fdm_engine_destroy(fdm_engine* e) {
   }
   if (e->mstate) (void)hipFree(e->mstate);
   if (e->mupd_part) (void)hipFree(e->mupd_part);
+  if (e->rb_state) (void)hipFree(e->rb_state);
+  if (e->rb_cap) (void)hipFree(e->rb_cap);
+  if (e->rb_u32) (void)hipFree(e->rb_u32);
+  if (e->rb_rec) (void)hipFree(e->rb_rec);
+  if (e->rb_counters) (void)hipFree(e->rb_counters);
+  if (e->rb_img) (void)hipFree(e->rb_img);
   for (int k = 0; k < 2; ++k) {
     if (e->tb_rec[k]) (void)hipFree(e->tb_rec[k]);
     if (e->tb_desc[k]) (void)hipFree(e->tb_desc[k]);
@@ -2244,6 +2252,15 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
   }
   if (std::strcmp(key, "batch_crop") == 0) {
     e->batch_crop = value != 0;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "batch_ray") == 0) {  // 0: scans of an engine with raycasting on leave one by one
+    e->batch_ray = value != 0;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "batch_ray_seg") == 0) {
+    if (value != 1 && value != 4 && value != 8 && value != 16) return fail(FDM_ERR_INVALID, "batch_ray_seg: 1, 4, 8 or 16 lanes per ray");
+    e->batch_ray_seg = value;
     return FDM_OK;
   }
   if (std::strcmp(key, "batch_fuse") == 0) {

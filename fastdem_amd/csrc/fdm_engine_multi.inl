@@ -15,7 +15,14 @@ bool affine_last_row(const double* T) { return T[3] == 0.0 && T[7] == 0.0 && T[1
 uint32_t multi_run(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) {
   if (!e->batch || count < 2u || !e->overlap || !e->wave_merge || e->bin_variant == 4) return 0u;
   if (!e->estimator_ready || e->rec_kind < 0 || !e->S.dense || e->ncell > kBatchMaxCells) return 0u;
-  if (e->cfg.raycast_enabled || e->cap_pre || e->cap_ras || e->want_ids || e->profile) return 0u;
+  if (e->cap_pre || e->cap_ras || e->want_ids || e->profile) return 0u;
+  // raycasting on (fastdem.cpp:152-159): the stage rides in the batch (fdm_rbatch.hpp) if every scan can take the
+  // sort-free voxel filter on compact keys and the engine holds the whole map
+  const bool ray = e->cfg.raycast_enabled != 0;
+  if (ray) {
+    if (!e->batch_ray || !e->voxel_small || !voxel_size_ok(static_cast<float>(e->G.res))) return 0u;
+    if (e->G.o_rows != e->G.rows || e->G.o_cols != e->G.cols || e->G.s_rows != e->G.rows || e->G.s_cols != e->G.cols) return 0u;
+  }
   if (e->obst_dense_pending || e->last_kind == 1 || e->next_drop_nonfinite) return 0u;
   if (e->dbg_no_atomics || e->dbg_upd) return 0u;
   const fdm_device_scan& f = scans[0];
@@ -34,6 +41,15 @@ uint32_t multi_run(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) 
       break;
     if (!affine_last_row(s.T_base_sensor) || !affine_last_row(s.T_world_base)) break;
     if (std::memcmp(s.T_base_sensor, f.T_base_sensor, 16 * sizeof(double)) != 0) break;
+    if (ray) {
+      if (s.n > uint64_t(e->voxel_small_max)) break;
+      ScanParams P;
+      double box[6];
+      fill_integrate_params(e, P, s.T_base_sensor, s.T_world_base);
+      ray_box_of(e, P, box);
+      const VoxelCompact C = voxel_compact_of(static_cast<float>(e->G.res), box);
+      if (C.bits <= 0 || 2 * C.bits + C.zbits > 31) break;
+    }
   }
   return run >= 2u ? run : 0u;
 }
@@ -106,6 +122,68 @@ int ensure_multi(fdm_engine* e, size_t max_n, size_t blocks) {
   return FDM_OK;
 }
 
+// Buffers of the batch's raycasting launches (fdm_rbatch.hpp), slots as wide as the observation arrays' (mobs_stride).
+int ensure_rbatch(fdm_engine* e) {
+  auto alloc = [&](auto*& ptr, size_t bytes) { return hipMalloc(reinterpret_cast<void**>(&ptr), bytes) == hipSuccess; };
+  if (!e->rb_state) {
+    const size_t counters = size_t(kMaxBatch) * ((size_t(1) << kVsFineBits) + kVsCoarse);
+    const size_t img = size_t(kMaxBatch) * e->ncell;
+    bool ok = alloc(e->rb_state, sizeof(RState)) && alloc(e->rb_counters, counters * sizeof(uint32_t)) &&
+              alloc(e->rb_img, 2u * img * sizeof(uint32_t));
+    if (!ok) {
+      (void)hipGetLastError();
+      if (e->rb_state) (void)hipFree(e->rb_state);
+      if (e->rb_counters) (void)hipFree(e->rb_counters);
+      if (e->rb_img) (void)hipFree(e->rb_img);
+      e->rb_state = nullptr; e->rb_counters = nullptr; e->rb_img = nullptr;
+      return fail(FDM_ERR_HIP, "batch pipeline: out of device memory for the raycasting images");
+    }
+    HIPCK(hipMemsetAsync(e->rb_state, 0, sizeof(RState), e->stream));
+    HIPCK(hipMemsetAsync(e->rb_counters, 0, counters * sizeof(uint32_t), e->stream));
+    HIPCK(hipMemsetAsync(e->rb_img, 0, img * sizeof(uint32_t), e->stream));                      // evidence counts
+    HIPCK(hipMemsetAsync(e->rb_img + img, 0xFF, img * sizeof(uint32_t), e->stream));            // kRayEmpty
+  }
+  if (e->rb_stride != e->mobs_stride) {
+    if (int rc_sync = sync_all(e)) return rc_sync;
+    if (e->rb_cap) HIPCK(hipFree(e->rb_cap));
+    if (e->rb_u32) HIPCK(hipFree(e->rb_u32));
+    if (e->rb_rec) HIPCK(hipFree(e->rb_rec));
+    e->rb_cap = nullptr; e->rb_u32 = nullptr; e->rb_rec = nullptr;
+    e->rb_stride = 0;
+    const size_t slots = size_t(kMaxBatch) * e->mobs_stride;
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->rb_cap), 3u * slots * sizeof(float)));
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->rb_u32), 4u * slots * sizeof(uint32_t)));
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->rb_rec), slots * sizeof(uint4)));
+    e->rb_stride = e->mobs_stride;
+  }
+  return FDM_OK;
+}
+
+// The five raycasting launches of the batch the launch before binned (its preprocessed clouds are in rb_cap).
+int launch_rbatch(fdm_engine* e, const RBatch& R) {
+  unsigned max_n = 0u;
+  for (unsigned k = 0; k < R.count; ++k) max_n = std::max(max_n, R.n[k]);
+  const dim3 grid((max_n + 255u) / 256u, R.count);
+  hipLaunchKernelGGL(k_rb_count, grid, dim3(256), 0, e->stream, R, e->G);
+  hipLaunchKernelGGL(k_rb_scatter, grid, dim3(256), 0, e->stream, R);
+  hipLaunchKernelGGL(k_rb_mark, grid, dim3(256), 0, e->stream, R);
+  hipLaunchKernelGGL(k_rb_compact, grid, dim3(256), 0, e->stream, R, e->G);
+  // upper bound of a scan's queue: every point a ray, padded to whole wavefronts per segment
+  auto rays = [&](auto seg) {
+    constexpr int SEG = decltype(seg)::value;
+    const unsigned threads = ((max_n + 63u) & ~63u) * unsigned(SEG);
+    hipLaunchKernelGGL((k_rb_ray<SEG>), dim3((threads + 255u) / 256u, R.count), dim3(256), 0, e->stream, R, e->G);
+  };
+  switch (e->batch_ray_seg) {
+    case 1: rays(std::integral_constant<int, 1>{}); break;
+    case 8: rays(std::integral_constant<int, 8>{}); break;
+    case 16: rays(std::integral_constant<int, 16>{}); break;
+    default: rays(std::integral_constant<int, 4>{}); break;
+  }
+  HIPCK(hipGetLastError());
+  return FDM_OK;
+}
+
 template <typename F>
 int with_channels(int ch, F&& f) {
   switch (ch & 3) {
@@ -136,8 +214,12 @@ int launch_mbatch(fdm_engine* e, int ch, const MUpd& U, const MBin& B, const MCr
     if constexpr (is_rec_policy<POLICY>) {
       return with_channels(ch, [&](auto chc) -> int {
         constexpr int CH = decltype(chc)::value;
-        hipLaunchKernelGGL((k_mbatch<POLICY, CH>), dim3(gx, rows), dim3(256), 0, e->stream, U, B, Cn, Kt, e->G,
-                           e->d_state, layers, e->d_layer_ptrs, e->n_layer_ptrs, unsigned(e->ncell), ub, urows);
+        if (U.ray.stamp != 0u || B.cap != nullptr)  // (a half with raycasting: the variant whose update resolves ray events)
+          hipLaunchKernelGGL((k_mbatch<POLICY, CH, true>), dim3(gx, rows), dim3(256), 0, e->stream, U, B, Cn, Kt, e->G,
+                             e->d_state, layers, e->d_layer_ptrs, e->n_layer_ptrs, unsigned(e->ncell), ub, urows);
+        else
+          hipLaunchKernelGGL((k_mbatch<POLICY, CH, false>), dim3(gx, rows), dim3(256), 0, e->stream, U, B, Cn, Kt, e->G,
+                             e->d_state, layers, e->d_layer_ptrs, e->n_layer_ptrs, unsigned(e->ncell), ub, urows);
         HIPCK(hipGetLastError());
         return FDM_OK;
       });
@@ -166,7 +248,9 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
   const fdm_device_scan& f = scans[0];
   const bool hi = f.intensity != nullptr, hc = f.rgb != nullptr, hv = f.sigma_z2 != nullptr;
   const int ch = (hi ? 1 : 0) | (hc ? 2 : 0);
+  const bool ray = e->cfg.raycast_enabled != 0;  // (multi_run checked that the batch can carry the stage)
   if ((rc = ensure_scratch_channels(e, hi, hc))) return rc;
+  if (ray && (rc = ensure_ray_layers(e))) return rc;
   if ((rc = refresh_layer_ptrs(e))) return rc;
   // a held-back update of another kind (single scan, other channels) leaves first
   if (e->chain && !(e->pend.multi && e->pend.ch == ch) && (rc = join_streams(e))) return rc;
@@ -175,10 +259,12 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
   MCrop Cn;
   MCommon K;
   MUpd U;
+  RBatch R;
   std::memset(&B, 0, sizeof(B));
   std::memset(&Cn, 0, sizeof(Cn));
   std::memset(&K, 0, sizeof(K));
   std::memset(&U, 0, sizeof(U));
+  std::memset(&R, 0, sizeof(R));
   size_t max_n = 0;
   unsigned blocks = 0;
   ScanParams P;
@@ -195,9 +281,21 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
     B.robot_y[k] = P.robot_y;
     blocks += unsigned((s.n + kMBlock - 1u) / kMBlock);
     max_n = std::max<size_t>(max_n, s.n);
+    if (ray) {  // the stage's per-scan parameters, as enqueue_scan derives them for one scan
+      double box[6];
+      ray_box_of(e, P, box);
+      R.C[k] = voxel_compact_of(static_cast<float>(e->G.res), box);
+      const int key_bits = 2 * R.C[k].bits + R.C[k].zbits;
+      R.shift[k] = unsigned(std::max(R.C[k].bits, key_bits - int(kVsFineBits)));
+      R.ibits[k] = 1u;
+      while ((1u << R.ibits[k]) < unsigned(s.n)) ++R.ibits[k];
+      R.n[k] = uint32_t(s.n);
+      R.ox[k] = P.ray_ox; R.oy[k] = P.ray_oy; R.oz[k] = P.ray_oz;
+    }
   }
   for (uint32_t k = count; k <= uint32_t(kMaxBatch); ++k) B.first_block[k] = blocks;
   if ((rc = ensure_multi(e, max_n, blocks))) return rc;
+  if (ray && (rc = ensure_rbatch(e))) return rc;
 
   K.min_sq = P.min_sq; K.max_sq = P.max_sq; K.z_min = P.z_min; K.z_max = P.z_max;
   sensor_params(e->cfg, K.sensor_type, K.sp);
@@ -230,6 +328,7 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
   B.obs = e->mobs[par];
   B.cobs = e->mcobs[par];
   B.bin_part = e->mbin_part[par];
+  B.cap = ray ? e->rb_cap : nullptr;
   if (fuse) U = e->pend.MU;
 
   // "scan k has a point that survives the crops" (it moves a LOCAL map, fastdem.cpp:138-145) must be in the batch's
@@ -266,6 +365,29 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
   }
   e->chain = false;
   if ((rc = launch_mbatch(e, ch, U, B, Cn, K))) return rc;
+  if (ray) {  // this batch's raycasting images, between the launch that binned it and the one that will update it
+    if (++e->rb_seq == 0u) ++e->rb_seq;
+    const size_t slots = size_t(kMaxBatch) * e->rb_stride, img = size_t(kMaxBatch) * e->ncell;
+    R.count = count;
+    R.stride = unsigned(e->rb_stride);
+    R.ncell = unsigned(e->ncell);
+    R.stamp = e->rb_seq;
+    R.do_move = K.do_move;
+    R.gate_on_filter = K.gate_on_filter;
+    R.dbg = e->dbg_ray;
+    R.ms = B.ms;
+    R.rs = e->rb_state;
+    R.resolution = static_cast<float>(e->G.res);
+    R.inv_voxel = 1.0f / R.resolution;  // (voxel size = map resolution; RayParams::inv_voxel, VoxelCompact's 1 / voxel_size)
+    R.cap = e->rb_cap;
+    R.keys = e->rb_u32; R.place = e->rb_u32 + slots; R.sel = e->rb_u32 + 2u * slots; R.ray_list = e->rb_u32 + 3u * slots;
+    R.rec = e->rb_rec;
+    R.fine = e->rb_counters;
+    R.coarse = e->rb_counters + (size_t(kMaxBatch) << kVsFineBits);
+    R.rc_cnt = e->rb_img;
+    R.rc_min = e->rb_img + img;
+    if ((rc = launch_rbatch(e, R))) return rc;
+  }
 
   // this batch's update is held back (option "batch_fuse" 0: launched at once, for per-kernel measurements)
   MUpd& N = e->pend.MU;
@@ -279,6 +401,18 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
   N.rearm = e->mstate + int((seq + 3u) % unsigned(kMStates));
   N.key = B.key; N.aux = B.aux; N.zs = B.zs; N.obs = B.obs; N.cobs = B.cobs;
   N.upd_part = e->mupd_part;
+  if (ray) {
+    const fdm_raycast_config c = ray_config_of(e->cfg);
+    N.ray.rs = e->rb_state;
+    N.ray.stamp = e->rb_seq;
+    N.ray.rc_cnt = R.rc_cnt;
+    N.ray.rc_min = R.rc_min;
+    N.ray.logodds = find_layer(e, "_visibility_logodds")->d;
+    N.ray.ray_min = find_layer(e, "raycasting")->d;
+    N.ray.ghost = find_layer(e, "ghost_removal")->d;
+    N.ray.l_obs = c.log_odds_observed; N.ray.l_ghost = c.log_odds_ghost; N.ray.l_max = c.log_odds_max;
+    N.ray.clear_thr = c.clear_threshold; N.ray.conflict_thr = c.height_conflict_threshold;
+  }
   e->pend.multi = true;
   e->pend.tb = false;
   e->pend.ch = ch;

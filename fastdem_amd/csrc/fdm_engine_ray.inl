@@ -80,9 +80,9 @@ int enqueue_radix_sort(fdm_engine* e, unsigned n, unsigned bits) {
 // map-frame z interval [lo, hi] they lie in (NaN, NaN if unknown);
 // with it the compact 32-bit key is used when 3 * bits <= 31.  *key_mode tells what the buffers hold:
 // 0 = sorted uint64 keys, 1 = sorted uint32 compact keys, 2 = points grouped by key bucket, unsorted (k_vs_*).
-int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slot, const float* dx,
-                       const float* dy, const float* dz, const double* box, int* key_mode) {
-  if (int rc = ensure_voxel_buffers(e, n)) return rc;
+// The compact voxel key of a scan whose points lie in `box` (see enqueue_voxel_sort): bits == 0 if the box is unknown
+// or too large for it.
+VoxelCompact voxel_compact_of(float voxel_size, const double* box) {
   const float inv = 1.0f / voxel_size;  // voxel_grid_impl.hpp:46
   VoxelCompact C{0, 0, 0, 0, 0};
   if (box && std::isfinite(box[3]) && box[3] > 0.0 && box[3] * double(inv) < 4.0e6) {
@@ -109,6 +109,31 @@ int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slo
       }
     }
   }
+  return C;
+}
+
+// The box an integrate() scan's preprocessed points lie in: cropRange keeps d^2 <= range_max^2 around the BASE origin,
+// i.e. around T_world_base's translation, and cropZ keeps z_base in [z_min, z_max]: z_map = R20 x + R21 y + R22 z + t_z
+// with |R20 x + R21 y| <= hypot(R20, R21) * range_max (column-major Twb: R2j = Twb[4 j + 2])
+void ray_box_of(const fdm_engine* e, const ScanParams& P, double box[6]) {
+  double zlo = NAN, zhi = NAN;
+  if (std::isfinite(double(e->cfg.z_min)) && std::isfinite(double(e->cfg.z_max)) &&
+      std::fabs(double(e->cfg.z_min)) < 1e6 && std::fabs(double(e->cfg.z_max)) < 1e6 &&
+      std::isfinite(double(e->cfg.range_max)) && double(e->cfg.range_max) < 1e6) {
+    const double r20 = double(P.Twb[2]), r21 = double(P.Twb[6]), r22 = double(P.Twb[10]);
+    const double tilt = std::hypot(r20, r21) * double(e->cfg.range_max);
+    const double a = r22 * double(e->cfg.z_min), b = r22 * double(e->cfg.z_max);
+    zlo = P.base_z + std::min(a, b) - tilt;
+    zhi = P.base_z + std::max(a, b) + tilt;
+  }
+  box[0] = P.base_x; box[1] = P.base_y; box[2] = P.base_z; box[3] = double(e->cfg.range_max); box[4] = zlo; box[5] = zhi;
+}
+
+int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slot, const float* dx,
+                       const float* dy, const float* dz, const double* box, int* key_mode) {
+  if (int rc = ensure_voxel_buffers(e, n)) return rc;
+  const float inv = 1.0f / voxel_size;  // voxel_grid_impl.hpp:46
+  const VoxelCompact C = voxel_compact_of(voxel_size, box);
   const int key_bits = 2 * C.bits + C.zbits;
   const bool compact = C.bits > 0 && key_bits <= 31;  // true: the sorted buffer holds uint32 keys
   *key_mode = compact ? 1 : 0;

@@ -748,6 +748,7 @@ struct KalmanRecPolicy {  // cell records
     t.smax = (isnan(t.smax) || max_z > t.smax) ? max_z : t.smax;
   }
   static __device__ __forceinline__ void finish(State& t) { kalman_finish(t.s); }
+  static __device__ __forceinline__ float elevation(const State& t) { return t.s.x; }  // what store() leaves in the elevation field
   static __device__ __forceinline__ void store(const Layers& L, unsigned o, const State& t) {
     float4* r = reinterpret_cast<float4*>(L.rec + size_t(o) * kKalmanRec);
     r[0] = make_float4(t.s.x, t.smin, t.smax, t.s.var);
@@ -800,6 +801,7 @@ struct P2RecPolicy {  // cell records
   static __device__ __forceinline__ void load(const Layers& L, unsigned o, State& t) {
     const float4* r = reinterpret_cast<const float4*>(L.rec + size_t(o) * kP2Rec);
     const float4 a = r[0], b = r[1], c = r[2], d = r[3];
+    t.s.elevation = a.x;  // (p2_step rewrites it; the batch update's ray events read it for cells without an observation)
     t.smin = a.y; t.smax = a.z;
     t.s.count = b.x;
     t.s.q[0] = b.y; t.s.q[1] = b.z; t.s.q[2] = b.w; t.s.q[3] = c.x; t.s.q[4] = c.y;
@@ -835,6 +837,7 @@ struct P2RecPolicy {  // cell records
     t.smax = (isnan(t.smax) || max_z > t.smax) ? max_z : t.smax;
   }
   static __device__ __forceinline__ void finish(State&) {}
+  static __device__ __forceinline__ float elevation(const State& t) { return t.s.elevation; }
   static __device__ __forceinline__ void store(const Layers& L, unsigned o, const State& t) {
     float4* r = reinterpret_cast<float4*>(L.rec + size_t(o) * kP2Rec);
     r[0] = make_float4(t.s.elevation, t.smin, t.smax, t.s.variance);

@@ -96,6 +96,7 @@ struct MBin {     // bin half: batch b
   float2* obs;                           // [count][obs_stride] {map-frame z, sigma_z^2} of block-local minima, by point index
   uint32_t* cobs;                        // [count][obs_stride] colour of block-local last points, by point index
   unsigned long long* bin_part;          // [bin blocks]
+  float* cap;                            // raycasting: [3][count][obs_stride] map-frame x (NaN: dropped by the crops), y, z by point index (else null)
   double robot_x[kMaxBatch], robot_y[kMaxBatch];  // T_world_base translation of every scan (the chain of moves)
   const float* px[kMaxBatch];
   const float* py[kMaxBatch];
@@ -105,10 +106,33 @@ struct MBin {     // bin half: batch b
   const float* pvar[kMaxBatch];
   MScanT t[kMaxBatch];
 };
+// Raycasting stage of the batch's scans (fastdem.cpp:152-159, once per scan BEHIND that scan's map update).  The ray
+// launches of fdm_rbatch.hpp leave, per scan, the two order-free images of processScan — observed-evidence counts and the
+// minimum ray height per cell — and the update half resolves them cell by cell, each scan's behind that scan's
+// observation (resolveGhostCells, raycasting.cpp:175-202).
+struct RState {   // device bookkeeping of a batch's ray launches (one per engine: they run between the launch that bins the batch and the one that updates it)
+  unsigned any[16];        // == the batch's stamp: the voxel-filtered scan k is not empty (raycasting.cpp:207-209)
+  unsigned origin_in[16];  // the sensor origin lies in the map after scan k's move (raycasting.cpp:217-220)
+  unsigned ray_count[16];  // queued downward rays of scan k
+  unsigned total[16];      // valid points of scan k (VoxelSmall::total)
+};
+struct MRay {
+  const RState* rs;
+  unsigned stamp;          // 0: no raycasting in this batch
+  unsigned pad;
+  uint32_t* rc_cnt;        // [count][ncell] observed-evidence counts; zero between batches
+  uint32_t* rc_min;        // [count][ncell] ord(min ray height); kRayEmpty between batches
+  float* logodds;          // _visibility_logodds
+  float* ray_min;          // raycasting
+  float* ghost;            // ghost_removal
+  float l_obs, l_ghost, l_max, clear_thr, conflict_thr;
+  float pad2;
+};
 struct MUpd {     // update half: batch b-1
   unsigned count, scan_no0, obs_stride;
   int do_move, gate_on_filter;
   unsigned pad;
+  MRay ray;
   MState* ms;
   MState* rearm;                         // the state of the batch after next: zeroed by the committing block
   unsigned long long* key;
@@ -184,15 +208,18 @@ struct MBinLds {
 };
 struct MEvent { uint32_t idx; uint16_t cell, k; };  // winner's point index | cell in tile | scan
 struct MObs { float min_z, var, max_z, iobs; };
-template <bool COL>
+constexpr unsigned kUpdCells = 64u;
+constexpr uint32_t kMRayEmpty = 0xFFFFFFFFu;  // (= kRayEmpty, fdm_raycast.hpp)
+template <bool COL, bool RAY>
 struct MUpdLds {
   MEvent ev[kEvCap];
   MObs ob[kEvCap];
   uint32_t rgb[COL ? kEvCap : 1];
+  uint32_t rcnt[RAY ? kMaxBatch * kUpdCells : 1], rmin[RAY ? kMaxBatch * kUpdCells : 1];  // [scan][cell of the block]
   unsigned s_w[4], s_t[4];
 };
-template <bool COL>
-constexpr unsigned kMLdsBytes = sizeof(MUpdLds<COL>) > sizeof(MBinLds) ? sizeof(MUpdLds<COL>) : sizeof(MBinLds);
+template <bool COL, bool RAY>
+constexpr unsigned kMLdsBytes = sizeof(MUpdLds<COL, RAY>) > sizeof(MBinLds) ? sizeof(MUpdLds<COL, RAY>) : sizeof(MBinLds);
 
 // ---------------------------------------------------------------------------------------------
 // crop half: SCOUT blocks of the NEXT batch's scans — does scan k hold a point that survives the crops (then it moves a
@@ -231,7 +258,7 @@ __device__ __forceinline__ void mcrop_body(const MCrop& Cn, const MCommon& K, co
 
 // ---------------------------------------------------------------------------------------------
 // bin half: block `bid` of the batch's bin grid.  CH: bit 0 intensity, bit 1 colour (compile-time, as k_bin's).
-template <int CH>
+template <int CH, bool RAY>
 __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const GeomConst& G,
                                           DevState* __restrict__ st, const unsigned ncell, const unsigned k,
                                           const unsigned lb, MBinLds& S) {
@@ -418,6 +445,12 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
     pass[h] = false;
     if (i < n) pass[h] = mcrops(V, xs[h], ys[h], zs[h], w);
     transform4_affine(V.Twb12, xs[h], ys[h], zs[h], w);
+    if (RAY && B.cap && i < n) {  // the raycasting stage's input: the preprocessed cloud by point index (as k_bin's capture)
+      const size_t at = size_t(k) * B.obs_stride + i, plane = size_t(kMaxBatch) * B.obs_stride;
+      B.cap[at] = pass[h] ? xs[h] : __uint_as_float(0x7FC00000u);
+      B.cap[plane + at] = ys[h];
+      B.cap[2u * plane + at] = zs[h];
+    }
     S.s_pt[threadIdx.x + unsigned(h) * 256u] = make_float4(sx, sy, sz, zs[h]);
     npw += unsigned(__popcll(__ballot(pass[h])));
   }
@@ -603,13 +636,12 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
 // 4 c + q looks after cell c in scans 4 q .. 4 q + 3 — so that a block holds at most 1024 events (two rounds of
 // the exchange) and the densest corner of the map (every cell touched by every scan) is a chain as short as any
 // other; the cell's own thread (q == 0) applies the events.
-constexpr unsigned kUpdCells = 64u;
-template <typename POLICY, int CH>
+template <typename POLICY, int CH, bool RAY>
 __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, DevState* __restrict__ st,
                                              const typename POLICY::Layers& L,
                                              float* const* __restrict__ all_layers, int n_layers,
                                              const unsigned ncell, const unsigned bid,
-                                             MUpdLds<(CH & 2) != 0>& S) {
+                                             MUpdLds<(CH & 2) != 0, RAY>& S) {
   constexpr bool has_int = (CH & 1) != 0, has_col = (CH & 2) != 0;
   const float nanv = __uint_as_float(0x7FC00000u);
   const unsigned lt = threadIdx.x, lane = lt & 63u, wave = lt >> 6;
@@ -630,11 +662,28 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
   }
   int v_sr = 0, v_sc = 0, v_shr = 0, v_shc = 0;
   unsigned v_in = 0u;
+  bool v_run = false;
   if (lane < count) {
     v_sr = ms->E[lane].sr; v_sc = ms->E[lane].sc;
     v_shr = ms->C[lane].shr; v_shc = ms->C[lane].shc;
     v_in = ms->inside[lane];
+    if (RAY && U.ray.stamp) v_run = U.ray.rs->any[lane] == U.ray.stamp && U.ray.rs->origin_in[lane] != 0u;
   }
+  // raycasting: the thread's four (evidence count, min ray height) pairs join round trip 1 (the images of a scan whose
+  // stage did not run are clean: no events)
+  uint32_t rc_[4], rh_[4];
+  if (RAY) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned k = cq * 4u + unsigned(j);
+      rc_[j] = 0u; rh_[j] = kMRayEmpty;
+      if (U.ray.stamp && k < count && valid) {
+        rc_[j] = U.ray.rc_cnt[size_t(k) * ncell + o];
+        rh_[j] = U.ray.rc_min[size_t(k) * ncell + o];
+      }
+    }
+  }
+  const unsigned runmask = RAY ? uni(unsigned(__ballot(v_run))) : 0u;  // scans whose raycasting stage runs (raycasting.cpp:207-220)
   const unsigned passbits = uni(ms->flags[0]) >> 16;
   const bool v_applied = lane < count && U.do_move && (!U.gate_on_filter || ((passbits >> lane) & 1u) != 0u);
   const unsigned umask = uni(unsigned(__ballot(lane < count && v_in != 0u)));                     // scans that observed a cell
@@ -659,6 +708,8 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
       if (has_int && st->vis_int == 0u) st->vis_int = 3u * first_upd + 2u;
       if (has_col && st->vis_col == 0u) st->vis_col = 3u * first_upd + 2u;
     }
+    if (RAY && runmask && st->vis_ray == 0u)  // the three layers become visible with the first frame that runs (raycasting.cpp:223-226)
+      st->vis_ray = 3u * (U.scan_no0 + unsigned(__ffs(int(runmask))) - 1u) + 3u;
   }
   if (bid == 0 && lt >= 64u && lt < 64u + unsigned(kMaxBatch)) {  // re-arm the state of the batch after next
     U.rearm->done[(lt - 64u) * kLineWords] = 0u;
@@ -674,6 +725,24 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
   unsigned tmask = nib << (4u * cq);  // the cell's scans, all four threads of the cell
   tmask |= unsigned(__shfl_xor(int(tmask), 1));
   tmask |= unsigned(__shfl_xor(int(tmask), 2));
+  unsigned rmask = 0u;  // the cell's ray events: scans whose stage left evidence or a ray height in it
+  if (RAY) {
+    unsigned rb = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned k = cq * 4u + unsigned(j);
+      if (rc_[j] != 0u || rh_[j] != kMRayEmpty) {
+        rb |= 1u << j;
+        if (rc_[j] != 0u) U.ray.rc_cnt[size_t(k) * ncell + o] = 0u;  // the images are clean again for the next batch
+        if (rh_[j] != kMRayEmpty) U.ray.rc_min[size_t(k) * ncell + o] = kMRayEmpty;
+      }
+      S.rcnt[k * kUpdCells + cl] = rc_[j];
+      S.rmin[k * kUpdCells + cl] = rh_[j];
+    }
+    rmask = rb << (4u * cq);
+    rmask |= unsigned(__shfl_xor(int(rmask), 1));
+    rmask |= unsigned(__shfl_xor(int(rmask), 2));
+  }
   // which scans' moves vacated THIS cell
   unsigned smask = 0u;
   if (stripmask) {
@@ -707,9 +776,60 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
   POLICY::set_nan(stt);
   float sint = nanv;
   unsigned lastp1 = 0u, m = owner ? tmask : 0u, e_next = base;  // (owner: the events still to be applied, the next one's number)
-  bool evt = false, cleared = false, strip_any = false, obst_dirty = false;
+  unsigned rm = (RAY && owner) ? rmask : 0u;                        // ... and its ray events
+  unsigned lastu1 = 0u;                                             // (RAY: behind the cell's last OBSERVATION; lastp1 counts ray events too)
+  bool evt = false, st_dirty = false, strip_any = false, obst_dirty = false;
   float obst = nanv;
   uint32_t colv = 0x7FC00000u;
+  // raycasting state of the cell: visibility log-odds, the elevation the last event left, what the raycasting layer ends
+  // up with (the LAST running frame's minimum: map.clear(raycasting) + that frame's rays)
+  float lo = nanv, elev = nanv, ray_val = nanv;
+  bool lo_dirty = false, ghost_one = false;
+  const int k_last_run = runmask ? 31 - __clz(int(runmask)) : -1;
+  // NaN in every layer of the cell: a strip GridMap::move vacated, or ElevationMap::clearAt (elevation_map.hpp:131-135)
+  auto wipe = [&]() {
+    POLICY::set_nan(stt);
+    sint = nanv;
+    colv = 0x7FC00000u;
+    strip_any = true;
+    st_dirty = false;
+    if (RAY) { obst = nanv; obst_dirty = true; lo = nanv; lo_dirty = false; ghost_one = false; elev = nanv; ray_val = nanv; }
+  };
+  // resolveGhostCells (raycasting.cpp:175-202) for this cell and scan k: the scan's evidence, then its ghost decision
+  auto resolve = [&](const unsigned k) {
+    const uint32_t cnt = S.rcnt[k * kUpdCells + cl], hmin = S.rmin[k * kUpdCells + cl];
+    if (cnt) {  // observed evidence, once per ray-scan point in the cell (raycasting.cpp:156-163)
+      if (isnan(lo)) lo = 0.0f;
+      for (uint32_t q = 0; q < cnt; ++q) {
+        const float a = lo + U.ray.l_obs;
+        const float nx = (U.ray.l_max < a) ? U.ray.l_max : a;  // std::min(a, l_max)
+        if (nx == lo) break;  // fixed point reached: the remaining folds change nothing
+        lo = nx;
+      }
+      lo_dirty = true;
+    }
+    float ray = nanv;
+    if (hmin != kMRayEmpty) {
+      ray = unord(hmin);
+      if (!isnan(elev) && elev > ray + U.ray.conflict_thr) {
+        if (isnan(lo)) lo = 0.0f;
+        lo -= U.ray.l_ghost;
+        lo_dirty = true;
+        if (lo < U.ray.clear_thr) {  // clearAt: NaN in every layer, then the marker (no min ray height for the frame)
+          wipe();
+          ghost_one = true;
+          ray = nanv;
+        }
+      }
+    }
+    if (int(k) == k_last_run) ray_val = ray;
+  };
+  if (RAY && owner && (tmask | rmask)) {  // (a block of the batch may hold ray events only: the record is fetched up front)
+    POLICY::load(L, o, stt);
+    if (has_int) sint = L.intensity[o];
+    elev = POLICY::elevation(stt);
+    if (rmask) lo = U.ray.logodds[o];
+  }
 #pragma unroll 1
   for (unsigned r0 = 0; r0 < total; r0 += unsigned(kEvCap)) {  // one round for all but the densest corners
     const unsigned r1 = min(r0 + unsigned(kEvCap), total);
@@ -752,7 +872,7 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
         zs_[q] = U.zs[oc];
       }
     }
-    if (r0 == 0u && owner && tmask) {  // (the record joins the same round trip)
+    if (!RAY && r0 == 0u && owner && tmask) {  // (the record joins the same round trip)
       POLICY::load(L, o, stt);
       if (has_int) sint = L.intensity[o];
     }
@@ -778,36 +898,80 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
     }
     __syncthreads();
     // the cells' own threads apply their events of this round, in scan order
-    while (m && e_next < r1) {
-      const unsigned k = unsigned(__ffs(int(m))) - 1u;
-      m &= m - 1u;
-      const MObs ob = S.ob[e_next - r0];
-      const uint32_t rgb = has_col ? S.rgb[e_next - r0] : 0u;
-      ++e_next;
-      const unsigned upto = (2u << k) - 1u, from = (1u << lastp1) - 1u;  // scans lastp1 .. k
-      if (smask & upto & ~from) {  // vacated since the last event: NaN in every layer (GridMap::move)
-        POLICY::set_nan(stt);
-        sint = nanv;
-        colv = 0x7FC00000u;
-        strip_any = true;
+    if constexpr (!RAY) {
+      while (m && e_next < r1) {
+        const unsigned k = unsigned(__ffs(int(m))) - 1u;
+        m &= m - 1u;
+        const MObs ob = S.ob[e_next - r0];
+        const uint32_t rgb = has_col ? S.rgb[e_next - r0] : 0u;
+        ++e_next;
+        const unsigned upto = (2u << k) - 1u, from = (1u << lastp1) - 1u;  // scans lastp1 .. k
+        if (smask & upto & ~from) {  // vacated since the last event: NaN in every layer (GridMap::move)
+          POLICY::set_nan(stt);
+          sint = nanv;
+          colv = 0x7FC00000u;
+          strip_any = true;
+        }
+        POLICY::step(L, stt, ob.min_z, ob.var, ob.max_z);
+        obst = (ob.max_z > ob.min_z) ? ob.max_z : nanv;
+        obst_dirty = true;
+        if (has_int && (isnan(sint) || ob.iobs > sint)) sint = ob.iobs;
+        if (has_col) colv = rgb & 0x00FFFFFFu;
+        evt = true;
+        st_dirty = true;
+        lastp1 = k + 1u;
       }
-      POLICY::step(L, stt, ob.min_z, ob.var, ob.max_z);
-      obst = (ob.max_z > ob.min_z) ? ob.max_z : nanv;
-      obst_dirty = true;
-      if (has_int && (isnan(sint) || ob.iobs > sint)) sint = ob.iobs;
-      if (has_col) colv = rgb & 0x00FFFFFFu;
-      evt = true;
-      lastp1 = k + 1u;
+    } else {
+      while (m | rm) {
+        const unsigned k = unsigned(__ffs(int(m | rm))) - 1u, bit = 1u << k;
+        if ((m & bit) && e_next >= r1) break;  // (its observation arrives with the next round)
+        const unsigned upto = (2u << k) - 1u, from = (1u << lastp1) - 1u;  // scans lastp1 .. k
+        if (smask & upto & ~from) wipe();  // vacated since the last event: NaN in every layer (GridMap::move)
+        if (m & bit) {
+          m &= ~bit;
+          const MObs ob = S.ob[e_next - r0];
+          const uint32_t rgb = has_col ? S.rgb[e_next - r0] : 0u;
+          ++e_next;
+          POLICY::step(L, stt, ob.min_z, ob.var, ob.max_z);
+          obst = (ob.max_z > ob.min_z) ? ob.max_z : nanv;
+          obst_dirty = true;
+          if (has_int && (isnan(sint) || ob.iobs > sint)) sint = ob.iobs;
+          if (has_col) colv = rgb & 0x00FFFFFFu;
+          evt = true;
+          st_dirty = true;
+          if (RAY) { elev = POLICY::elevation(stt); lastu1 = k + 1u; }
+        }
+        if (RAY && (rm & bit)) {  // scan k's raycasting stage, behind its observation
+          rm &= ~bit;
+          resolve(k);
+        }
+        lastp1 = k + 1u;
+      }
     }
     __syncthreads();  // (the next round reuses the lists)
+  }
+  if (RAY) {  // ray events behind the block's last observation (or of a block without any)
+    while (rm) {
+      const unsigned k = unsigned(__ffs(int(rm))) - 1u;
+      rm &= rm - 1u;
+      const unsigned upto = (2u << k) - 1u, from = (1u << lastp1) - 1u;
+      if (smask & upto & ~from) wipe();
+      resolve(k);
+      lastp1 = k + 1u;
+    }
   }
   FDM_PHASE(2);  // events applied
   // the scans after the cell's last event
   if (owner) {
     const unsigned all = (1u << count) - 1u, from = (1u << lastp1) - 1u;
     const unsigned tail = all & ~from;
-    if (smask & tail) { strip_any = true; cleared = true; sint = nanv; colv = 0x7FC00000u; obst = nanv; obst_dirty = true; }
-    if (umask & tail) { obst = nanv; obst_dirty = true; }  // map_.clear(obstacle), elevation_mapping.cpp:144-146
+    if (smask & tail) {
+      strip_any = true; st_dirty = false; sint = nanv; colv = 0x7FC00000u; obst = nanv; obst_dirty = true;
+      if (RAY) { lo = nanv; lo_dirty = false; ghost_one = false; ray_val = nanv; }
+    }
+    // map_.clear(obstacle) by every scan that observed a cell (elevation_mapping.cpp:144-146), behind the cell's last observation
+    const unsigned tail_u = RAY ? (all & ~((1u << lastu1) - 1u)) : tail;
+    if (umask & tail_u) { obst = nanv; obst_dirty = true; }
     if (strip_any) {
       for (int l0 = 0; l0 < n_layers; l0 += 8) {
         float* p[8];
@@ -819,13 +983,18 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
       }
       POLICY::clear_cell(L, o);
     }
-    if (evt && !cleared) {
+    if (st_dirty) {
       POLICY::finish(stt);
       POLICY::store(L, o, stt);
     }
     if (obst_dirty) L.obstacle[o] = obst;
     if (has_int && (evt || strip_any)) L.intensity[o] = sint;
     if (has_col && (evt || strip_any)) reinterpret_cast<uint32_t*>(L.color)[o] = colv;
+    if (RAY && U.ray.stamp) {
+      if (lo_dirty) U.ray.logodds[o] = lo;
+      if (ghost_one) U.ray.ghost[o] = 1.0f;
+      if (runmask) U.ray.ray_min[o] = ray_val;  // every cell, every running frame: the layer is cleared first (raycasting.cpp:228)
+    }
   }
   // touched-cell count of the batch's last scan (what the synchronous statistics report), per update block
   const unsigned long long mt = __ballot(owner && ((tmask >> (count - 1u)) & 1u) != 0u);
@@ -843,13 +1012,13 @@ template <typename POLICY> struct MBatchWaves { static constexpr int value = FDM
 template <> struct MBatchWaves<P2RecPolicy> { static constexpr int value = FDM_MB_WAVES - 1; };
 template <> struct MBatchWaves<P2Policy> { static constexpr int value = FDM_MB_WAVES - 1; };
 
-template <typename POLICY, int CH>
+template <typename POLICY, int CH, bool RAY>
 __global__ __launch_bounds__(256, MBatchWaves<POLICY>::value) void k_mbatch(const MUpd U, const MBin B, const MCrop Cn, const MCommon K,
                                                 const GeomConst G, DevState* __restrict__ st,
                                                 const typename POLICY::Layers L,
                                                 float* const* __restrict__ all_layers, int n_layers,
                                                 unsigned ncell, unsigned upd_blocks, unsigned upd_rows) {
-  __shared__ __align__(16) unsigned char lds[kMLdsBytes<(CH & 2) != 0>];
+  __shared__ __align__(16) unsigned char lds[kMLdsBytes<(CH & 2) != 0, RAY>];
   const unsigned long long t0 = K.timeline ? wall_clock64() : 0ull;
 #if FDM_MB_PHASES
   if (threadIdx.x == 0) { g_phase[0] = g_phase[1] = g_phase[2] = unsigned(t0); }
@@ -858,11 +1027,11 @@ __global__ __launch_bounds__(256, MBatchWaves<POLICY>::value) void k_mbatch(cons
   if (row < upd_rows) {
     const unsigned ub = row * gridDim.x + x;
     if (ub < upd_blocks)
-      mupdate_body<POLICY, CH>(U, G, st, L, all_layers, n_layers, ncell, ub,
-                               *reinterpret_cast<MUpdLds<(CH & 2) != 0>*>(lds));
+      mupdate_body<POLICY, CH, RAY>(U, G, st, L, all_layers, n_layers, ncell, ub,
+                                    *reinterpret_cast<MUpdLds<(CH & 2) != 0, RAY>*>(lds));
   } else if (row < upd_rows + B.count) {
     const unsigned k = row - upd_rows;
-    if (x < (B.n[k] + kMBlock - 1u) / kMBlock) mbin_body<CH>(B, K, G, st, ncell, k, x, *reinterpret_cast<MBinLds*>(lds));
+    if (x < (B.n[k] + kMBlock - 1u) / kMBlock) mbin_body<CH, RAY>(B, K, G, st, ncell, k, x, *reinterpret_cast<MBinLds*>(lds));
   } else {  // scout rows: block c of Cn.count * kMScout
     const unsigned c = (row - upd_rows - B.count) * gridDim.x + x;
     if (c < Cn.count * kMScout) mcrop_body(Cn, K, c / kMScout, c % kMScout);

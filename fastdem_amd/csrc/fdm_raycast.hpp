@@ -224,12 +224,14 @@ struct VoxelSmall {
   int dbg;                 // measurement only (wrong results): 1 = no fine atomics, 2 = no coarse atomics, 3 = neither
 };
 
-__global__ __launch_bounds__(256) void k_vs_count(unsigned n, float inv_voxel, int flag_slot, const VoxelCompact C,
-                                                  const VoxelSmall V, DevState* __restrict__ st,
-                                                  const float* __restrict__ x, const float* __restrict__ y,
-                                                  const float* __restrict__ z, uint32_t* __restrict__ keys,
-                                                  uint32_t* __restrict__ sel) {
-  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+// (bodies take the block number and the word that reports "the scan has a valid point" as arguments: the batch kernels
+// of fdm_rbatch.hpp run the same code for scan blockIdx.y of a batch)
+__device__ __forceinline__ void vs_count_body(unsigned n, float inv_voxel, const VoxelCompact& C, const VoxelSmall& V,
+                                              const float* __restrict__ x, const float* __restrict__ y,
+                                              const float* __restrict__ z, uint32_t* __restrict__ keys,
+                                              uint32_t* __restrict__ sel, unsigned* __restrict__ any_word,
+                                              unsigned any_val, unsigned blk) {
+  const unsigned i = blk * 256u + threadIdx.x;
   const unsigned lane = threadIdx.x & 63u;
   bool valid = false;
   uint32_t k = kInvalidVoxel32;
@@ -290,10 +292,19 @@ __global__ __launch_bounds__(256) void k_vs_count(unsigned n, float inv_voxel, i
     __syncthreads();
     if (s_n[threadIdx.x]) atomicAdd(&V.coarse[s_id[threadIdx.x]], s_n[threadIdx.x]);
   }
-  if (flag_slot >= 0 && __ballot(valid) && (threadIdx.x & 63) == 0) st->flags[flag_slot].ray_any = 1u;
+  if (any_word && __ballot(valid) && (threadIdx.x & 63) == 0) *any_word = any_val;
+}
+__global__ __launch_bounds__(256) void k_vs_count(unsigned n, float inv_voxel, int flag_slot, const VoxelCompact C,
+                                                  const VoxelSmall V, DevState* __restrict__ st,
+                                                  const float* __restrict__ x, const float* __restrict__ y,
+                                                  const float* __restrict__ z, uint32_t* __restrict__ keys,
+                                                  uint32_t* __restrict__ sel) {
+  vs_count_body(n, inv_voxel, C, V, x, y, z, keys, sel, flag_slot >= 0 ? &st->flags[flag_slot].ray_any : nullptr, 1u,
+                blockIdx.x);
 }
 
-__global__ __launch_bounds__(256) void k_vs_scatter(unsigned n, const VoxelSmall V, const uint32_t* __restrict__ keys) {
+__device__ __forceinline__ void vs_scatter_body(unsigned n, const VoxelSmall& V, const uint32_t* __restrict__ keys,
+                                                unsigned blk) {
   __shared__ uint32_t s_start[kVsCoarse];
   __shared__ uint32_t s_wave[4];
   const unsigned t = threadIdx.x, lane = t & 63u, wave = t >> 6;
@@ -314,9 +325,9 @@ __global__ __launch_bounds__(256) void k_vs_scatter(unsigned n, const VoxelSmall
   for (unsigned w = 0; w < wave; ++w) run += s_wave[w];
 #pragma unroll
   for (unsigned j = 0; j < per; ++j) { s_start[t * per + j] = run; run += c_[j]; }
-  if (blockIdx.x == 0 && t == 255u) *V.total = run;
+  if (blk == 0 && t == 255u) *V.total = run;
   __syncthreads();
-  const unsigned i = blockIdx.x * 256u + t;
+  const unsigned i = blk * 256u + t;
   if (i >= n) return;
   const uint32_t k = keys[i];
   if (k == kInvalidVoxel32) return;  // (dropped / non-finite points sort behind every voxel: never a representative)
@@ -338,9 +349,12 @@ __global__ __launch_bounds__(256) void k_vs_scatter(unsigned n, const VoxelSmall
   }
   V.rec[s + V.place[i]] = make_uint4(k, i, s, m);
 }
+__global__ __launch_bounds__(256) void k_vs_scatter(unsigned n, const VoxelSmall V, const uint32_t* __restrict__ keys) {
+  vs_scatter_body(n, V, keys, blockIdx.x);
+}
 
-__global__ __launch_bounds__(256) void k_vs_mark(const VoxelSmall V, uint32_t* __restrict__ sel) {
-  const unsigned p = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u, w0 = p - lane;
+__device__ __forceinline__ void vs_mark_body(const VoxelSmall& V, uint32_t* __restrict__ sel, unsigned blk) {
+  const unsigned p = blk * 256u + threadIdx.x, lane = threadIdx.x & 63u, w0 = p - lane;
   const unsigned total = *V.total;
   // a bucket's members are neighbours: the wavefront's own 64 positions and the 128 on either side are compared in
   // registers (five independent loads, one round trip); a per-lane walk over memory is one dependent round trip per
@@ -419,6 +433,9 @@ __global__ __launch_bounds__(256) void k_vs_mark(const VoxelSmall V, uint32_t* _
     V.coarse[f >> 5] = 0u;
   }
 }
+__global__ __launch_bounds__(256) void k_vs_mark(const VoxelSmall V, uint32_t* __restrict__ sel) {
+  vs_mark_body(V, sel, blockIdx.x);
+}
 
 // processScan (raycasting.cpp:142-173), first half: one ray-scan point per thread.
 //   VOXEL = true : point i counts if the voxel filter kept it (sel[i] != 0)
@@ -457,29 +474,25 @@ __device__ __forceinline__ unsigned ray_len_key(unsigned cells) {  // group * 32
 constexpr unsigned kRayBinBlock = 1024u;  // bins per block of the two scan kernels
 
 template <bool VOXEL, int PTS>
-__global__ __launch_bounds__(256) void k_ray_compact(const RayParams Q, const GeomConst G,
-                                                     DevState* __restrict__ st,
-                                                     const float* __restrict__ x,
-                                                     const float* __restrict__ y,
-                                                     const float* __restrict__ z,
-                                                     const uint32_t* __restrict__ sel,
-                                                     uint32_t* __restrict__ rc_cnt,
-                                                     uint32_t* __restrict__ ray_list,
-                                                     uint32_t* __restrict__ ray_key,
-                                                     uint32_t* __restrict__ ray_rank,
-                                                     uint32_t* __restrict__ bin_cnt) {
+__device__ __forceinline__ void ray_compact_body(const RayParams& Q, const GeomConst& G, const DevGeom& g,
+                                                 const float* __restrict__ x,
+                                                 const float* __restrict__ y,
+                                                 const float* __restrict__ z,
+                                                 const uint32_t* __restrict__ sel,
+                                                 uint32_t* __restrict__ rc_cnt,
+                                                 uint32_t* __restrict__ ray_list,
+                                                 uint32_t* __restrict__ ray_key,
+                                                 uint32_t* __restrict__ ray_rank,
+                                                 uint32_t* __restrict__ bin_cnt,
+                                                 unsigned* __restrict__ ray_count, const unsigned blk) {
   __shared__ unsigned s_wave[PTS][4];
   __shared__ unsigned s_base;
-  const DevGeom g = st->geom[Q.slot];
-  if (!ray_stage_runs(Q, st, g, G)) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && st->vis_ray == 0u)
-    st->vis_ray = Q.vis_stamp;  // the three layers become visible (raycasting.cpp:223-226)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   unsigned idx[PTS], key[PTS], rank[PTS];
   unsigned long long mask[PTS];
 #pragma unroll
   for (int k = 0; k < PTS; ++k) {
-    const unsigned i = (blockIdx.x * unsigned(PTS) + unsigned(k)) * 256u + threadIdx.x;
+    const unsigned i = (blk * unsigned(PTS) + unsigned(k)) * 256u + threadIdx.x;
     idx[k] = i;
     key[k] = 0u;
     rank[k] = 0u;
@@ -516,7 +529,7 @@ __global__ __launch_bounds__(256) void k_ray_compact(const RayParams Q, const Ge
     unsigned tot = 0u;
 #pragma unroll
     for (int k = 0; k < PTS; ++k) tot += s_wave[k][0] + s_wave[k][1] + s_wave[k][2] + s_wave[k][3];
-    s_base = tot ? atomicAdd(&st->ray_count, tot) : 0u;
+    s_base = tot ? atomicAdd(ray_count, tot) : 0u;
   }
   __syncthreads();
   unsigned off = s_base;
@@ -533,6 +546,25 @@ __global__ __launch_bounds__(256) void k_ray_compact(const RayParams Q, const Ge
     }
     off += s_wave[k][0] + s_wave[k][1] + s_wave[k][2] + s_wave[k][3];
   }
+}
+template <bool VOXEL, int PTS>
+__global__ __launch_bounds__(256) void k_ray_compact(const RayParams Q, const GeomConst G,
+                                                     DevState* __restrict__ st,
+                                                     const float* __restrict__ x,
+                                                     const float* __restrict__ y,
+                                                     const float* __restrict__ z,
+                                                     const uint32_t* __restrict__ sel,
+                                                     uint32_t* __restrict__ rc_cnt,
+                                                     uint32_t* __restrict__ ray_list,
+                                                     uint32_t* __restrict__ ray_key,
+                                                     uint32_t* __restrict__ ray_rank,
+                                                     uint32_t* __restrict__ bin_cnt) {
+  const DevGeom g = st->geom[Q.slot];
+  if (!ray_stage_runs(Q, st, g, G)) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && st->vis_ray == 0u)
+    st->vis_ray = Q.vis_stamp;  // the three layers become visible (raycasting.cpp:223-226)
+  ray_compact_body<VOXEL, PTS>(Q, G, g, x, y, z, sel, rc_cnt, ray_list, ray_key, ray_rank, bin_cnt, &st->ray_count,
+                               blockIdx.x);
 }
 
 // bucket counts -> offsets, in two launches of kRayBins / kRayBinBlock blocks: per-block sums, then every block
@@ -628,17 +660,15 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 // sit in different wavefronts (thread = seg * padded_rays + ray), so the lanes of a wavefront are
 // still neighbouring rays at the same step and the segmented min-scan keeps working.
 template <bool TILED, int SEG>
-__global__ __launch_bounds__(256) void k_ray(const RayParams Q, const GeomConst G,
-                                             DevState* __restrict__ st,
-                                             const float* __restrict__ x, const float* __restrict__ y,
-                                             const float* __restrict__ z,
-                                             const uint32_t* __restrict__ ray_list,
-                                             uint32_t* __restrict__ rc_min) {
+__device__ __forceinline__ void ray_walk_body(const RayParams& Q, const GeomConst& G, const DevGeom& g,
+                                              const unsigned n_rays,
+                                              const float* __restrict__ x, const float* __restrict__ y,
+                                              const float* __restrict__ z,
+                                              const uint32_t* __restrict__ ray_list,
+                                              uint32_t* __restrict__ rc_min, const unsigned gid) {
   // large scans (one lane per ray, queue sorted by wedge and length) walk 32 cells between two rounds of
   // loads (C4 stage: 8 cells 1.16 ms, 16: 1.10, 32: 1.05, 64: 1.16); the segmented small-scan variants stay at 8
   constexpr int kB = SEG == 1 ? kRayBatchLarge : kRayBatch;
-  const unsigned n_rays = st->ray_count;
-  const unsigned gid = blockIdx.x * 256u + threadIdx.x;
   const unsigned n_pad = (n_rays + 63u) & ~63u;  // whole wavefronts per segment
   unsigned i = gid, seg = 0;
   if (SEG > 1) {
@@ -649,7 +679,6 @@ __global__ __launch_bounds__(256) void k_ray(const RayParams Q, const GeomConst 
   } else if ((gid & ~63u) >= n_rays) {
     return;  // whole wavefront beyond the queue
   }
-  const DevGeom g = st->geom[Q.slot];
   const bool have = i < n_rays;
   const unsigned pi = have ? ray_list[i] : 0u;
   const float ex = have ? x[pi] : 0.f, ey = have ? y[pi] : 0.f, ez = have ? z[pi] : 0.f;
@@ -790,6 +819,17 @@ __global__ __launch_bounds__(256) void k_ray(const RayParams Q, const GeomConst 
       }
     }
   }
+}
+template <bool TILED, int SEG>
+__global__ __launch_bounds__(256) void k_ray(const RayParams Q, const GeomConst G,
+                                             DevState* __restrict__ st,
+                                             const float* __restrict__ x, const float* __restrict__ y,
+                                             const float* __restrict__ z,
+                                             const uint32_t* __restrict__ ray_list,
+                                             uint32_t* __restrict__ rc_min) {
+  const unsigned n_rays = st->ray_count;
+  const DevGeom g = st->geom[Q.slot];
+  ray_walk_body<TILED, SEG>(Q, G, g, n_rays, x, y, z, ray_list, rc_min, blockIdx.x * 256u + threadIdx.x);
 }
 
 // voxelGrid(ANY) on its own (fdm_engine_voxel_any): sel[i] = picked point index if sorted position

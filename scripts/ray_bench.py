@@ -49,11 +49,20 @@ def run(raycast):
             ray += res.eng.last_ray_ms()
         res.eng.enable_profile(False)
         ray /= a.steps
-    return wall, ray
+    # the batch entry point (fdm_engine_integrate_device_batch): small scans leave in batches of 16, raycasting included
+    w, _ = res.batch(0, 64)
+    assert res.eng.integrate_device_batch_timed(w) == 0
+    n_b = 640 if wl.n_points < 65536 else 32
+    b, _ = res.batch(64, n_b)
+    launches = sum(res.eng.batch_launches())
+    assert res.eng.integrate_device_batch_timed(b) == 0
+    batch_us = res.eng.timer_ms() / n_b * 1e3
+    batched = sum(res.eng.batch_launches()) > launches
+    return wall, ray, batch_us, batched
 
 
-wall_off, _ = run(0)
-wall_on, ray_ms = run(1)
+wall_off, _, batch_off, _ = run(0)
+wall_on, ray_ms, batch_on, batched = run(1)
 
 import fdm_ref_py as R  # noqa: E402  (checker / CPU baseline only)
 
@@ -73,6 +82,8 @@ cpu_off, cpu_on = cpu(0), cpu(1)
 print(json.dumps({"workload": a.workload, "points": wl.n_points,
                   "gpu_ray_stage_ms": round(ray_ms, 4),
                   "gpu_integrate_ms": {"raycast_off": round(wall_off, 4), "raycast_on": round(wall_on, 4)},
+                  "gpu_batch_call_us_per_scan": {"raycast_off": round(batch_off, 3), "raycast_on": round(batch_on, 3),
+                                                 "raycast_on_took_batch_launches": batched},
                   "cpu_oracle_ms": {"raycast_off": round(cpu_off, 3), "raycast_on": round(cpu_on, 3),
                                     "stage": round(cpu_on - cpu_off, 3)},
                   "speedup_stage": round((cpu_on - cpu_off) / max(ray_ms, 1e-9), 1)}))
