@@ -229,6 +229,10 @@ struct fdm_engine {
   // ---- raycasting inside the small-scan batches (fdm_rbatch.hpp) ----
   int batch_ray = 1;                 // option "batch_ray": 0 = an engine with raycasting on takes the single-scan path
   int batch_ray_seg = 4;             // option "batch_ray_seg": lanes per ray of k_rb_ray (1, 4, 8, 16)
+  int batch_ray_lds = 1;             // option "batch_ray_lds": 0 = always the global-atomic walk (k_rb_ray)
+  int batch_ray_parts = 0;           // option "batch_ray_parts": workgroups per quadrant and scan of k_rb_ray_lds (0 = fill the chip)
+  int batch_ray_words = 0;           // option "batch_ray_words": LDS image words of k_rb_ray_lds (0 = twice a centred sensor's quadrant)
+  unsigned rb_lds_words = 0;         // dynamic LDS k_rb_ray_lds may use, in 32-bit words (0: not asked yet)
   RState* rb_state = nullptr;
   float* rb_cap = nullptr;           // [3][kMaxBatch][rb_stride] preprocessed clouds of the batch being binned
   uint32_t* rb_u32 = nullptr;        // keys | place | sel | ray_list, [kMaxBatch][rb_stride] each
@@ -2256,6 +2260,20 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
   }
   if (std::strcmp(key, "batch_ray") == 0) {  // 0: scans of an engine with raycasting on leave one by one
     e->batch_ray = value != 0;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "batch_ray_lds") == 0) {
+    e->batch_ray_lds = value != 0;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "batch_ray_words") == 0) {
+    if (value < 0) return fail(FDM_ERR_INVALID, "batch_ray_words: >= 0");
+    e->batch_ray_words = value;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "batch_ray_parts") == 0) {
+    if (value < 0 || value > 64) return fail(FDM_ERR_INVALID, "batch_ray_parts: 0 (automatic) .. 64");
+    e->batch_ray_parts = value;
     return FDM_OK;
   }
   if (std::strcmp(key, "batch_ray_seg") == 0) {

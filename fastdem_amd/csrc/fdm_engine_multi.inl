@@ -152,7 +152,7 @@ int ensure_rbatch(fdm_engine* e) {
     e->rb_stride = 0;
     const size_t slots = size_t(kMaxBatch) * e->mobs_stride;
     HIPCK(hipMalloc(reinterpret_cast<void**>(&e->rb_cap), 3u * slots * sizeof(float)));
-    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->rb_u32), 4u * slots * sizeof(uint32_t)));
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&e->rb_u32), 7u * slots * sizeof(uint32_t)));  // keys | place | sel | 4 ray queues
     HIPCK(hipMalloc(reinterpret_cast<void**>(&e->rb_rec), slots * sizeof(uint4)));
     e->rb_stride = e->mobs_stride;
   }
@@ -168,17 +168,39 @@ int launch_rbatch(fdm_engine* e, const RBatch& R) {
   hipLaunchKernelGGL(k_rb_scatter, grid, dim3(256), 0, e->stream, R);
   hipLaunchKernelGGL(k_rb_mark, grid, dim3(256), 0, e->stream, R);
   hipLaunchKernelGGL(k_rb_compact, grid, dim3(256), 0, e->stream, R, e->G);
-  // upper bound of a scan's queue: every point a ray, padded to whole wavefronts per segment
-  auto rays = [&](auto seg) {
-    constexpr int SEG = decltype(seg)::value;
-    const unsigned threads = ((max_n + 63u) & ~63u) * unsigned(SEG);
-    hipLaunchKernelGGL((k_rb_ray<SEG>), dim3((threads + 255u) / 256u, R.count), dim3(256), 0, e->stream, R, e->G);
-  };
-  switch (e->batch_ray_seg) {
-    case 1: rays(std::integral_constant<int, 1>{}); break;
-    case 8: rays(std::integral_constant<int, 8>{}); break;
-    case 16: rays(std::integral_constant<int, 16>{}); break;
-    default: rays(std::integral_constant<int, 4>{}); break;
+  // The walks.  LDS images (k_rb_ray_lds) when a quadrant of a centred sensor fits the workgroup's LDS with room to
+  // spare for a sensor off the centre; else one lane (or SEG lanes) per ray on global atomics.
+  if (e->rb_lds_words == 0u) {  // (once per engine: the largest dynamic LDS a workgroup of this kernel may ask for)
+    e->rb_lds_words = 16384u;   // 64 KB without asking
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_rb_ray_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            128 * 1024) == hipSuccess)
+      e->rb_lds_words = 32768u;
+    else
+      (void)hipGetLastError();
+  }
+  const size_t quadrant = (size_t(e->G.rows) / 2 + 2) * (size_t(e->G.cols) / 2 + 2);
+  if (e->batch_ray_lds && quadrant * 2 <= e->rb_lds_words) {
+    unsigned parts = e->batch_ray_parts > 0 ? unsigned(e->batch_ray_parts) : std::max(1u, 256u / (4u * R.count));
+    parts = std::min(parts, std::max(1u, (max_n + kRbRayThreads - 1u) / kRbRayThreads));
+    // (LDS for twice a centred sensor's quadrant — a LOCAL map follows the robot, a GLOBAL map's sensor may wander: a
+    // larger quadrant takes the kernel's global-atomic loop — or for the whole map when that is less)
+    const unsigned words = unsigned(std::min<size_t>({size_t(e->rb_lds_words), size_t(e->G.rows) * size_t(e->G.cols),
+                                                      e->batch_ray_words > 0 ? size_t(e->batch_ray_words) : quadrant * 2}));
+    hipLaunchKernelGGL(k_rb_ray_lds, dim3(4u * parts, R.count), dim3(kRbRayThreads), words * sizeof(uint32_t), e->stream,
+                       R, e->G, parts, words);
+  } else {
+    // upper bound of a scan's queue: every point a ray, padded to whole wavefronts per segment
+    auto rays = [&](auto seg) {
+      constexpr int SEG = decltype(seg)::value;
+      const unsigned threads = ((max_n + 63u) & ~63u) * unsigned(SEG);
+      hipLaunchKernelGGL((k_rb_ray<SEG>), dim3((threads + 255u) / 256u, R.count, 4), dim3(256), 0, e->stream, R, e->G);
+    };
+    switch (e->batch_ray_seg) {
+      case 1: rays(std::integral_constant<int, 1>{}); break;
+      case 8: rays(std::integral_constant<int, 8>{}); break;
+      case 16: rays(std::integral_constant<int, 16>{}); break;
+      default: rays(std::integral_constant<int, 4>{}); break;
+    }
   }
   HIPCK(hipGetLastError());
   return FDM_OK;
@@ -380,7 +402,7 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
     R.resolution = static_cast<float>(e->G.res);
     R.inv_voxel = 1.0f / R.resolution;  // (voxel size = map resolution; RayParams::inv_voxel, VoxelCompact's 1 / voxel_size)
     R.cap = e->rb_cap;
-    R.keys = e->rb_u32; R.place = e->rb_u32 + slots; R.sel = e->rb_u32 + 2u * slots; R.ray_list = e->rb_u32 + 3u * slots;
+    R.keys = e->rb_u32; R.place = e->rb_u32 + slots; R.sel = e->rb_u32 + 2u * slots; R.ray_list = e->rb_u32 + 3u * slots;  // (4 x slots)
     R.rec = e->rb_rec;
     R.fine = e->rb_counters;
     R.coarse = e->rb_counters + (size_t(kMaxBatch) << kVsFineBits);

@@ -113,7 +113,7 @@ struct MBin {     // bin half: batch b
 struct RState {   // device bookkeeping of a batch's ray launches (one per engine: they run between the launch that bins the batch and the one that updates it)
   unsigned any[16];        // == the batch's stamp: the voxel-filtered scan k is not empty (raycasting.cpp:207-209)
   unsigned origin_in[16];  // the sensor origin lies in the map after scan k's move (raycasting.cpp:217-220)
-  unsigned ray_count[16];  // queued downward rays of scan k
+  unsigned qcount[16][4];  // queued downward rays of scan k, by the quadrant they leave the sensor's cell into
   unsigned total[16];      // valid points of scan k (VoxelSmall::total)
 };
 struct MRay {
@@ -683,6 +683,16 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
       }
     }
   }
+  // ... and so does the cell's stored state: with raycasting nearly every cell has an event, and asking for the record
+  // only once the images are back would be one more dependent round trip
+  typename POLICY::State rec_early;
+  POLICY::set_nan(rec_early);
+  float sint_early = nanv, lo_early = nanv;
+  if (RAY && owner) {
+    POLICY::load(L, o, rec_early);
+    if (has_int) sint_early = L.intensity[o];
+    if (U.ray.stamp) lo_early = U.ray.logodds[o];
+  }
   const unsigned runmask = RAY ? uni(unsigned(__ballot(v_run))) : 0u;  // scans whose raycasting stage runs (raycasting.cpp:207-220)
   const unsigned passbits = uni(ms->flags[0]) >> 16;
   const bool v_applied = lane < count && U.do_move && (!U.gate_on_filter || ((passbits >> lane) & 1u) != 0u);
@@ -824,11 +834,13 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
     }
     if (int(k) == k_last_run) ray_val = ray;
   };
-  if (RAY && owner && (tmask | rmask)) {  // (a block of the batch may hold ray events only: the record is fetched up front)
-    POLICY::load(L, o, stt);
-    if (has_int) sint = L.intensity[o];
-    elev = POLICY::elevation(stt);
-    if (rmask) lo = U.ray.logodds[o];
+  if (RAY && owner) {  // (rays cross most cells of the map: the cell's state was fetched with round trip 1, see rec_early)
+    if (tmask | rmask) {
+      stt = rec_early;
+      if (has_int) sint = sint_early;
+      elev = POLICY::elevation(stt);
+      if (rmask) lo = lo_early;
+    }
   }
 #pragma unroll 1
   for (unsigned r0 = 0; r0 < total; r0 += unsigned(kEvCap)) {  // one round for all but the densest corners

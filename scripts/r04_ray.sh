@@ -17,6 +17,6 @@ PY
 done
 done
 unset FDM_ENGINE_LIB
-for seg in 4 8 16 1; do
-timeout 300 python scripts/ray_bench.py c2 --set batch_ray_seg=$seg --cpu-iters 2 2>/dev/null | tee -a $O/ray_bench_seg.jsonl
+for seg in 4; do
+timeout 300 python scripts/ray_bench.py c2 --set batch_ray_seg=$seg --set batch_ray_lds=${LDS:-1} --cpu-iters 2 2>/dev/null | tee -a $O/ray_bench_seg.jsonl
 done

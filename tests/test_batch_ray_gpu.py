@@ -63,13 +63,19 @@ def batch_vs_oracle(gpu, eng, ref, scans, Tbs, poses, expect_batches=True):
     return cleared
 
 
-@pytest.mark.parametrize("seg", [4, 1, 8, 16])
-def test_vlp16_stream_with_raycasting_in_batches(gpu, R, seg):
+@pytest.mark.parametrize("walk", ["lds", "lds_parts=1", "lds_parts=7", "seg=4", "seg=1", "seg=16"])
+def test_vlp16_stream_with_raycasting_in_batches(gpu, R, walk):
     """configs[1] under the shipped YAML's raycasting switch: 2 scans one by one (they create the layers), phantom
-    obstacles planted, then 35 scans in one batch call (16 + 16 + 3) with a LOCAL shift every other scan."""
+    obstacles planted, then 35 scans in one batch call (16 + 16 + 3) with a LOCAL shift every other scan.  Every variant
+    of the ray walk: the per-quadrant LDS images (the default; 1 and 7 workgroups per quadrant) and the global-atomic
+    walk with 4, 1 and 16 lanes per ray."""
     wl = gpu.synth.vlp16(n_scans=6)
     eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, ray_on(wl.apply_to, rc_log_odds_ghost=1.2))
-    eng.set_option("batch_ray_seg", seg)
+    if walk.startswith("lds_parts"):
+        eng.set_option("batch_ray_parts", int(walk.split("=")[1]))
+    elif walk.startswith("seg"):
+        eng.set_option("batch_ray_lds", 0)
+        eng.set_option("batch_ray_seg", int(walk.split("=")[1]))
     for k in range(2):
         run_both(eng, ref, wl.scan(k), wl.T_base_sensor, wl.pose(k))
     for o in (eng, ref):
@@ -181,3 +187,26 @@ def test_option_off_takes_the_one_scan_path_and_agrees(gpu, R):
     assert sum(eng.batch_launches()) == before
     oracle_cleared(ref, scans, wl.T_base_sensor, poses)
     assert_layers_bit_identical(eng, ref)
+
+
+def test_large_map_and_a_sensor_off_the_centre(gpu, R):
+    """40 x 40 m at 0.1 m (160 K cells): a quadrant of the map does not fit the LDS image of the default walk, the
+    batch takes the global-atomic walk; then a 24 x 24 m GLOBAL map whose sensor wanders from the centre to a corner:
+    the LDS walk's quadrant rectangles grow from a quarter of the map to all of it."""
+    def fill(c):
+        c.z_min, c.z_max, c.range_min, c.range_max = -2.0, 3.0, 0.0, 40.0
+        c.mode = 1
+
+    rng = np.random.default_rng(33)
+    for size, spread in ((40.0, 22.0), (24.0, 13.0)):
+        eng, ref = pair(gpu, R, size, size, 0.1, ray_on(fill, rc_log_odds_ghost=0.9, rc_clear_threshold=-0.5))
+        scans, poses = [], []
+        for k in range(18):
+            n = int(rng.integers(2000, 9000))
+            s = cloud(rng, n, spread, intensity=True)
+            s["z"] = (s["z"] + F32(0.5) * (rng.uniform(size=n) < 0.3)).astype(F32)
+            scans.append(s)
+            d = (size / 2 - 0.3) * k / 17.0
+            poses.append(T(d, -d, 0.0, yaw=0.05 * k))
+            s["x"] = (s["x"] - F32(d) * F32(0.5)).astype(F32)
+        batch_vs_oracle(gpu, eng, ref, scans, T(z=1.3), poses)
