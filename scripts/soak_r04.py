@@ -23,8 +23,10 @@ profile = sys.argv[4] if len(sys.argv) > 4 else "small"
 # tiled: 60 m map (351 tiles), scans up to 300 K points     A = defaults (record-pool pipeline), B = tiled 0
 # p2   : 12 m GLOBAL map, P2 quantile estimator, colour + intensity     A = defaults, B = batch 0 + voxel_small 0
 # tbatch: 60 m map, scans up to 300 K points    A = tile batches on (tbatch 1, tbatch_min 1000), B = defaults (one launch per scan)
-SIZE = {"small": 16.0, "tiled": 60.0, "p2": 12.0, "tbatch": 60.0}[profile]
-BIG = {"small": 70000, "tiled": 300000, "p2": 40000, "tbatch": 300000}[profile]
+# ray   : 16 m map, raycasting on in every call      A = the stage inside the batches (fdm_rbatch.hpp), B = batch_ray 0 (one scan per launch)
+# rayp2 : the same with the P2 estimator + colour
+SIZE = {"small": 16.0, "tiled": 60.0, "p2": 12.0, "tbatch": 60.0, "ray": 16.0, "rayp2": 12.0}[profile]
+BIG = {"small": 70000, "tiled": 300000, "p2": 40000, "tbatch": 300000, "ray": 70000, "rayp2": 40000}[profile]
 rng = np.random.default_rng(2026)
 
 
@@ -44,10 +46,12 @@ def make(raycast):
     cfg = capi.default_config()
     cfg.z_min, cfg.z_max, cfg.range_min, cfg.range_max = -2.0, 4.0, 0.2, 12.0
     cfg.raycast_enabled = raycast
-    if profile == "p2":
-        cfg.mode = 1
+    if profile in ("p2", "rayp2"):
+        cfg.mode = 1 if profile == "p2" else 0
         cfg.estimation_type = 1
         cfg.sensor_type = 2
+    if profile in ("ray", "rayp2"):  # ghosts get cleared now and then
+        cfg.rc_log_odds_ghost, cfg.rc_clear_threshold, cfg.rc_height_conflict_threshold = 0.9, -0.5, 0.02
     return cfg
 
 
@@ -80,6 +84,8 @@ if profile == "tiled":
 elif profile == "tbatch":
     A.set_option("tbatch", 1)
     A.set_option("tbatch_min", 1000)
+elif profile in ("ray", "rayp2"):
+    B.set_option("batch_ray", 0)
 else:
     B.set_option("batch", 0)
     B.set_option("voxel_small", 0)
@@ -89,15 +95,17 @@ if with_oracle:
     import fdm_ref_py as R  # (the checker)
     rcfg = R.default_config()
     rcfg.z_min, rcfg.z_max, rcfg.range_min, rcfg.range_max = -2.0, 4.0, 0.2, 12.0
-    if profile == "p2":
-        rcfg.mode, rcfg.estimation_type, rcfg.sensor_type = 1, 1, 2
+    if profile in ("p2", "rayp2"):
+        rcfg.mode, rcfg.estimation_type, rcfg.sensor_type = (1 if profile == "p2" else 0), 1, 2
+    if profile in ("ray", "rayp2"):
+        rcfg.rc_log_odds_ghost, rcfg.rc_clear_threshold, rcfg.rc_height_conflict_threshold = 0.9, -0.5, 0.02
     Rf = R.RefEngine(SIZE, SIZE, 0.1, rcfg)
 t0 = time.perf_counter()
 scans = calls = compares = 0
 px = py = 0.0
 alive = []  # device arrays stay alive until both engines have synchronised (the calls only enqueue)
 while time.perf_counter() - t0 < budget:
-    ray = int(rng.integers(0, 3) == 0)
+    ray = 1 if profile in ("ray", "rayp2") else int(rng.integers(0, 3) == 0)
     for e in (A, B) + ((Rf,) if Rf else ()):
         cfg = e.cfg
         cfg.raycast_enabled = ray
@@ -108,7 +116,7 @@ while time.perf_counter() - t0 < budget:
     alive.append(keep)
     for k, n in enumerate(sizes):
         x, y, z, a = cloud(n)
-        rgb = rng.integers(0, 1 << 24, n, dtype=np.uint32) if profile == "p2" else None
+        rgb = rng.integers(0, 1 << 24, n, dtype=np.uint32) if profile in ("p2", "rayp2") else None
         d = [torch.from_numpy(v).cuda() for v in (x, y, z, a)] + ([torch.from_numpy(rgb.view(np.int32)).cuda()] if rgb is not None else [])
         keep.append(d)
         host = (x, y, z, a)
@@ -125,12 +133,12 @@ while time.perf_counter() - t0 < budget:
         scans += 1
     torch.cuda.synchronize()
     how = int(rng.integers(0, 8))
-    if how == 0 and profile != "p2":  # the same scans one by one (enqueue-only calls) ...
+    if how == 0 and profile not in ("p2", "rayp2"):  # the same scans one by one (enqueue-only calls) ...
         for d, sc in zip(keep, arr):
             Tb, Tw = np.array(sc.T_base_sensor).reshape(4, 4).T, np.array(sc.T_world_base).reshape(4, 4).T
             for e in (A, B):
                 e.integrate_device(d[0], d[1], d[2], Tb, Tw, intensity=d[3])
-    elif how == 1 and profile != "p2":  # ... or the first as a synchronous host call, the rest as a batch
+    elif how == 1 and profile not in ("p2", "rayp2"):  # ... or the first as a synchronous host call, the rest as a batch
         d, sc = keep[0], arr[0]
         Tb, Tw = np.array(sc.T_base_sensor).reshape(4, 4).T, np.array(sc.T_world_base).reshape(4, 4).T
         hx, hy, hz, ha = (t.cpu().numpy() for t in d[:4])
