@@ -483,6 +483,11 @@ def main():
                                 timeout=datetime.timedelta(seconds=args.collective_timeout), **kw_pg)
         if args.backend == "gloo":
             args.native_routed = 0  # (libfdm_halo's routed step talks RCCL: the host-staged Python loop instead)
+        # The first collective builds the communicator (RCCL: ~50 ms of device-side set-up that the call only enqueues):
+        # it happens HERE, not behind the barrier in front of a timed region (measured: the first engine call after an
+        # un-warmed barrier blocked for 50 ms — 100 one-rank c5 steps read 0.54 ms instead of 0.037 ms per step)
+        dist.barrier()
+        torch.cuda.synchronize()
     from fastdem_amd import synth
 
     if routed:
@@ -511,6 +516,7 @@ def main():
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
+                torch.cuda.synchronize()  # (the barrier's own device work is done before a timed region starts)
 
         # host-side pose matrices for every step are built BEFORE the timed region (numpy 4x4
         # products cost more than the two kernel launches of a 30 K-point scan)
@@ -538,6 +544,7 @@ def main():
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
+                torch.cuda.synchronize()
             t0_ = time.perf_counter()
             rc_ = r.eng.integrate_device_batch_timed(batch)
             torch.cuda.synchronize()  # (device-wide: covers the engine's stream)

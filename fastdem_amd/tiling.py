@@ -402,6 +402,9 @@ class Watchdog:
                 os._exit(3)
 
 
+import os as _os_mod  # noqa: E402
+
+
 def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]:
     """configs[4]: one 400x400 m @ 0.05 m GLOBAL map tiled over `world` GPUs.  N-sensor mode (weak scaling): every
     rank is a robot with its own 2 M-point scan stream, on the same 150 m circle a world-th of a turn apart; a step =
@@ -439,17 +442,22 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
             comm = halo_c.make_comm(rank, world, dist)
             native = halo_c.NativeRoutedScan(eng, rank, world, rows, cols, DEFAULT_HALO, n_pts, comm=comm)
         mine = [{c: torch.from_numpy(s[c]).to(dev) for c in ("x", "y", "z", "intensity")} for s in wl.scans]
-        steps, warm = min(args.steps, 200), min(args.warmup, 20)
+        steps, warm = min(args.steps, 200), min(args.warmup, 400)
         # robot `rank` of `world`: the workload's 150 m circle (0.4 m per pose: 2356 poses per turn), a world-th of a
         # turn ahead per rank
         turn = int(round(2.0 * np.pi * 150.0 / 0.4))
         pose = lambda k: wl.pose(k + (turn * rank) // world)  # noqa: E731
 
+        trace = [] if _os_mod.environ.get("FDM_BENCH_TRACE") else None  # (measurement: host time of every step's parts)
+
         def step(k):
             d = mine[k % len(mine)]
+            t_a = time.perf_counter()
             if native is not None:
                 native.integrate(d["x"], d["y"], d["z"], wl.T_base_sensor, pose(k), intensity=d["intensity"],
                                  sensors=True, pipelined=pipelined, want_matrix=False)
+                if trace is not None:
+                    trace.append(time.perf_counter() - t_a)
             else:
                 router.integrate(d["x"], d["y"], d["z"], wl.T_base_sensor, pose(k), dist, intensity=d["intensity"],
                                  sensors=True)
@@ -461,6 +469,7 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
             eng.sync()
             torch.cuda.synchronize()
             dist.barrier()
+            torch.cuda.synchronize()  # (the barrier's own device work is done before the timed region starts)
 
         k = 0
         for _ in range(warm):
@@ -477,6 +486,11 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
         eng.sync()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if trace:
+            import sys
+            tr = np.asarray(trace[-steps:]) * 1e6
+            sys.stderr.write(f"[trace] native.integrate host us per step: median {np.median(tr):.1f} p90 {np.percentile(tr, 90):.1f} "
+                             f"max {tr.max():.1f} sum_ms {tr.sum() / 1e3:.2f} of {dt * 1e3:.2f}; first 12: {np.round(tr[:12], 1).tolist()}\n")
         if native is not None:  # (the routing matrix of one more step, outside the timed region)
             d = mine[k % len(mine)]
             router.matrix = native.integrate(d["x"], d["y"], d["z"], wl.T_base_sensor, pose(k), intensity=d["intensity"],
