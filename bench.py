@@ -601,7 +601,7 @@ def main():
                              "measured": "HIP events on the engine stream around the timed region / steps"})
             if batch_scans > 1:
                 # The timed region was the BATCH pipeline: back-to-back k_mbatch launches, each the bin of 16 scans, the
-                # map update of the previous 16 and the crop pass of the next 16.  Algorithmic bytes per launch = 16 x the
+                # map update of the previous 16 and the scout blocks of the next 16.  Algorithmic bytes per launch = 16 x the
                 # per-scan figure; duration = HIP events around the region / launches (gaps between launches included).
                 launches = -(-n_timed // batch_scans)
                 launch_us = timed_launch_us * n_timed / launches
@@ -615,7 +615,7 @@ def main():
                                           "Mpts_per_s": wl.n_points / (kern["k_update_bin"]["ms"] * 1e-3) / 1e6,
                                           "note": "fdm_engine_integrate_device scan by scan (event pair per launch)"}
                 roof = {"bound": "hbm",
-                        "kernel": "k_mbatch (one launch per 16 scans: update of batch b-1 | bin of batch b | crop pass of batch b+1)",
+                        "kernel": "k_mbatch (one launch per 16 scans: update of batch b-1 | bin of batch b | scout blocks of batch b+1)",
                         "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
                         "traffic": pmc_traffic(args.workload, "k_mbatch"), "avg_kernel_us": launch_us,
                         "alg_bytes_per_launch": alg, "scans_per_launch": batch_scans,
@@ -639,6 +639,30 @@ def main():
             if not args.no_host_legs:
                 # end-to-end with host staging (PCIe-inclusive) for DESIGN.md — never `value`
                 result.update(host_legs(res, wl, k))
+            if world == 1 and not args.no_host_legs and args.workload in ("c2", "c3"):
+                # the same stream with the shipped YAML's raycasting switch on (fastdem/config/default.yaml:40-41;
+                # SURVEY.md §8 f1): small scans carry the stage inside the batches (fdm_rbatch.hpp)
+                ray = Resident(wl, local_rank, args.wave_merge, args.overlap)
+                for kv in args.set:
+                    ray.eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+                cfg_r = ray.eng.cfg
+                cfg_r.raycast_enabled = 1
+                ray.eng.set_config(cfg_r)
+                n_ray = 320 if wl.n_points <= 65536 else 24
+                wr, _ = ray.batch(0, 48 if wl.n_points <= 65536 else 8)
+                if ray.eng.integrate_device_batch(wr) != 0:
+                    raise RuntimeError("integrate_device_batch (raycasting leg warm-up) failed")
+                ray.eng.sync()
+                br, _ = ray.batch(48, n_ray)
+                launches0 = sum(ray.eng.batch_launches())
+                if ray.eng.integrate_device_batch_timed(br) != 0:
+                    raise RuntimeError("integrate_device_batch (raycasting leg) failed")
+                ray_us = ray.eng.timer_ms() / n_ray * 1e3
+                result["raycasting_on"] = {"us_per_scan_hip_events": ray_us, "Mpts_per_s": wl.n_points / (ray_us * 1e-6) / 1e6,
+                                           "scans": n_ray, "in_batch_launches": sum(ray.eng.batch_launches()) > launches0,
+                                           "note": "fdm_engine_integrate_device_batch with raycast_enabled: voxel filter + "
+                                                   "ray walks + ghost resolution of every scan; never `value`"}
+                del ray
             if world == 1 and not args.no_large and args.workload != "c4":
                 big = Resident(synth.lidar128(n_scans=LARGE_SCANS), local_rank, args.wave_merge, args.overlap)
                 for kv in args.set:

@@ -13,4 +13,12 @@ cp $O/pmc_traffic.json $R/profiles/pmc_traffic.json   # what bench.py's roofline
 cp $O/pmc_sq.txt $P/pmc_sq_c2_c4.txt
 cp $O/timeline_c2_batch.json $O/timeline_c4_fused.json $P/
 for f in bench_default bench_c3 bench_c4 bench_c5_plain bench_c5_routed_1rank; do grep '^{' $O/$f.json | tail -1 > $P/$f.json; done
+cp $O/ray_bench.jsonl $P/ray_bench.jsonl
+cp $(find $O/rocprof_ray_batch -name "rb_kernel_stats.csv" | head -1) $P/rocprof_ray_batch_c2_kernel_stats.csv
+cp $O/ray_batch_c2.json $P/ray_batch_c2.json
+python3 - $O/soak.jsonl > $P/soak.json <<'PY'
+import json, sys
+print(json.dumps({"script": "scripts/soak_r04.py (engine against engine, every layer compared bit for bit every 5 calls)",
+                  "profiles": [json.loads(l) for l in open(sys.argv[1]) if l.startswith("{")]}, indent=1))
+PY
 ls -la $P

@@ -66,3 +66,12 @@ timeout 300 python3 bench.py --workload c5 --routed 0 --steps 500 --warmup 50 --
 timeout 300 python3 bench.py --workload c5 --steps 100 --warmup 10 > $O/bench_c5_routed_1rank.json 2> $O/bench_c5_routed_1rank.err
 ls $O | head -60
 cat $O/pmc_traffic.json | python3 -c "import json,sys; d=json.load(sys.stdin); print({w: {k: round(v.get('hbm_bytes_per_launch', 0)) for k, v in e.items()} for w, e in d.items()})"
+# (6) raycasting: stage bench per workload (single-scan stage, batch call), kernel stats of the batch call with raycasting
+rm -f $O/ray_bench.jsonl
+for W in c2 c3 c4; do timeout 600 python3 scripts/ray_bench.py $W --cpu-iters 2 2>/dev/null >> $O/ray_bench.jsonl; done
+cat $O/ray_bench.jsonl | cut -c1-330
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_ray_batch -o rb -- python3 $R/scripts/ray_batch_run.py 640 > $O/ray_batch_c2.json 2> $O/ray_batch_c2.err)
+# (7) soak of the end-of-round code: engine against engine, bit for bit, every profile
+rm -f $O/soak.jsonl
+for P in small p2 tiled tbatch ray rayp2; do timeout 400 python3 scripts/soak_r04.py ${SOAK_S:-75} 5 no $P 2>/dev/null | tail -1 >> $O/soak.jsonl; done
+cat $O/soak.jsonl
