@@ -148,9 +148,12 @@ int fdm_engine_integrate_device(fdm_engine* e, uint64_t n, const float* d_x, con
  * exactly what `count` consecutive fdm_engine_integrate_device calls leave (every layer bit for bit), without the
  * per-call crossing of the language boundary — and, because the engine sees the scans up front, without one launch
  * per scan: runs of small plain scans of one sensor (same T_base_sensor, same optional channels, no captures / cell
- * ids / raycasting, a map of at most 2^18 cells) are binned sixteen to a launch and applied cell by cell in scan
- * order by the same launch's update half (fastdem_amd/csrc/fdm_multi.hpp; configs[1]: 1.2 us instead of 6 us per
- * scan).  Scans that do not qualify take the single-scan path in place.  Options "batch" 0/1, "batch_max" 2..16. */
+ * ids, a map of at most 2^18 cells) are binned sixteen to a launch and applied cell by cell in scan order by the
+ * same launch's update half (fastdem_amd/csrc/fdm_multi.hpp; configs[1]: 1.05 us instead of 4-6 us per scan).  With
+ * raycast_enabled (fastdem.cpp:152-159) the stage of every scan rides in the batch as well — voxel filter, ray walks,
+ * ghost resolution, each scan's behind that scan's map update (fdm_rbatch.hpp; scans of <= 64 K points on an untiled
+ * engine; 9.3 us instead of 60 us per VLP-16 scan).  Scans that do not qualify take the single-scan path in place.
+ * Options "batch" 0/1, "batch_max" 2..16, "batch_ray" 0/1. */
 typedef struct fdm_device_scan {
   uint64_t n;
   const float *x, *y, *z, *intensity; /* device pointers; intensity nullable */
@@ -468,6 +471,8 @@ int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2);
  *   "sync_spin_us" n     : a synchronous call polls the pinned statistics block for up to n microseconds before it
  *                         falls back to a stream wait (default 150; 0 = wait at once)
  *   "tiled" 0/1, "tiled_min" n : large-scan pipeline (per-tile record pools) on/off, its point-count threshold
+ *   "batch_ray" 0/1     : raycasting inside the small-scan batches (1); "batch_ray_lds" 0/1: its ray walk on LDS images
+ *                         (1) or memory-side atomics with "batch_ray_seg" 1/4/8/16 lanes per ray
  *   "dbg_*"             : measurement-only switches used by scripts/ab_kernels.py */
 int fdm_engine_set_option(fdm_engine* e, const char* key, int value);
 
