@@ -221,6 +221,7 @@ struct fdm_engine {
   bool fault_watch = false;          // a launch that can raise DevState::fault was enqueued since it was last read (none can since round 4)
   int dbg_batch = 0;                 // measurement only (option "dbg_batch")
   int batch_crop = 1;                // option "batch_crop": evaluate the next batch's crops one launch ahead
+  int batch_walk = -1;               // option "batch_walk": the chain of moves walked one launch ahead (fdm_multi.hpp mwalk_body): -1 = for the quantile estimator only, 0 off, 1 on
   bool pre_valid = false;            // the last launch carried the crop pass of the batch (pre_scans, pre_count) = number pre_seq
   const fdm_device_scan* pre_scans = nullptr;
   uint32_t pre_count = 0;
@@ -2252,6 +2253,11 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
   }
   if (std::strcmp(key, "dbg_batch") == 0) {
     e->dbg_batch = value;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "batch_walk") == 0) {
+    if (value < -1 || value > 1) return fail(FDM_ERR_INVALID, "batch_walk: -1 (automatic), 0, 1");
+    e->batch_walk = value;
     return FDM_OK;
   }
   if (std::strcmp(key, "batch_crop") == 0) {

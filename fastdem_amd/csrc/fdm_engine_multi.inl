@@ -224,9 +224,9 @@ int launch_mbatch(fdm_engine* e, int ch, const MUpd& U, const MBin& B, const MCr
   // rows as wide as the widest scan; the update's blocks fill as many leading rows as they need
   unsigned gx = 0u;
   for (unsigned k = 0; k < B.count; ++k) gx = std::max(gx, (B.n[k] + kMBlock - 1u) / kMBlock);
-  if (gx == 0u) gx = std::min(std::max(ub, Cn.count * kMScout), 64u);
+  if (gx == 0u) gx = std::min(std::max(ub, Cn.count * kMScout + 1u), 64u);
   if (gx == 0u) return FDM_OK;
-  const unsigned crows = (Cn.count * kMScout + gx - 1u) / gx;  // the scout blocks of the next batch, in rows of their own
+  const unsigned crows = Cn.count ? (Cn.count * kMScout + 1u + gx - 1u) / gx : 0u;  // the scout blocks of the next batch + its walker block, in rows of their own
   const unsigned urows = (ub + gx - 1u) / gx, rows = urows + B.count + crows;
   MCommon Kt = K;
   Kt.timeline = (e->d_timeline && gx * rows <= e->timeline_cap && B.count) ? e->d_timeline : nullptr;
@@ -328,6 +328,7 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
   K.has_var = hv ? 1 : 0;
   K.bin_table = e->bin_table;
   K.dbg = e->dbg_batch;
+  K.walk = e->batch_walk < 0 ? (e->cfg.estimation_type == 1 ? 1 : 0) : e->batch_walk;
 
   if ((rc = drop_scouted(e))) return rc;  // (a tile batch scouted scans that now leave as a small-scan batch)
   const unsigned seq = e->mseq++;
@@ -361,6 +362,8 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
     for (uint32_t k = 0; k < n; ++k) {
       C.n[k] = uint32_t(ss[k].n);
       C.px[k] = ss[k].x; C.py[k] = ss[k].y; C.pz[k] = ss[k].z;
+      C.robot_x[k] = ss[k].T_world_base[12];  // T_world_base.translation().head<2>() (fastdem.cpp:144), as MBin::robot_x
+      C.robot_y[k] = ss[k].T_world_base[13];
     }
     C.count = n;
     C.ms = ms;
@@ -373,6 +376,10 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
     std::memset(&U0, 0, sizeof(U0));
     std::memset(&B0, 0, sizeof(B0));
     fill_scouts(C0, count, scans, e->mstate + slot);
+    // (no batch is binned by this launch: the walker block starts the chain where this batch's bin blocks will)
+    C0.prev = fuse ? e->pend.MU.ms : nullptr;
+    C0.prev_count = fuse ? e->pend.MU.count : 0u;
+    C0.scan_no0 = uint32_t(e->scan_no);
     if ((rc = launch_mbatch(e, ch, U0, B0, C0, K))) return rc;
   }
   B.pre = 1u;

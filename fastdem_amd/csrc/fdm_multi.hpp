@@ -60,12 +60,14 @@ struct MState {
   DevGeom E[kMaxBatch];        // geometry before scan k (written by the scan's first bin block)
   DevCand C[kMaxBatch];        // geometry after its move + the index shift
   unsigned done[kMaxBatch * kLineWords];  // tile batches (fdm_tbatch.hpp): [k * 32 + 1] = scan k has a surviving point (each on its own line)
-  unsigned flags[kLineWords];  // [0]: bit k = every block of scan k is past the crops, bit 16 + k = scan k has a surviving point
+  unsigned flags[kLineWords];  // [0]: bit 16 + k = scan k has a surviving point (scouts); [1]: bit 31 = PE / PC below are valid, bits 0..15 = the pass bits they assume
   unsigned inside[kMaxBatch];  // some point of scan k landed in the map (elevation_mapping.cpp:118)
   unsigned err;                // (unused since round 4: nothing waits inside a launch)
   unsigned tq;                 // tile batches (fdm_tbatch.hpp): the update groups' tile queue ...
   unsigned gdone;              // ... and how many of them have left (the last one commits the geometry ring)
   unsigned pad[13];
+  DevGeom PE[kMaxBatch];       // the chain of moves walked ONE LAUNCH AHEAD by the walker block (mwalk_body): geometry before
+  DevCand PC[kMaxBatch];       // scan k / after its move, assuming the pass bits in flags[1]
 };
 
 struct MCommon {  // what all scans of a batch share
@@ -73,7 +75,7 @@ struct MCommon {  // what all scans of a batch share
   float sp[4];
   float Tbs[16];  // T_base_sensor (one sensor per batch: a scan with another extrinsic closes the batch)
   int sensor_type, integrate_mode, do_move, gate_on_filter, has_var, bin_table;
-  int dbg, pad;                  // measurement only: 1 = no scratch atomics, 2 = no chain walk (both: wrong results); 3 = every move by the reference's divide; 4 = a chain wait reports MState::err as if it had run out of polls (tests)
+  int dbg, walk;                 // walk: 1 = the chain of moves is walked one launch ahead (mwalk_body).  dbg, measurement only: 1 = no scratch atomics, 2 = no chain walk (both: wrong results); 3 = every move by the reference's divide; 4 = a chain wait reports MState::err as if it had run out of polls (tests)
   unsigned long long* timeline;  // measurement only (nullable): {start, end} of every block in 100 MHz ticks
 };
 struct MScanT {   // per scan: T_world_base without its constant last row (0 0 0 1), column-major 3 x 4 | rotation of the product
@@ -147,6 +149,11 @@ struct MCrop {    // crop half: batch b+1 (count == 0: none)
   unsigned first_block[kMaxBatch + 1];
   unsigned n[kMaxBatch];
   MState* ms;
+  // the walker block: the scouted batch's poses, and — when no batch is binned by this launch (the scout-only launch in
+  // front of a call's first batch) — where its chain starts: the previous batch's state (complete), or the geometry ring
+  double robot_x[kMaxBatch], robot_y[kMaxBatch];
+  const MState* prev;
+  unsigned prev_count, scan_no0;
   const float* px[kMaxBatch];
   const float* py[kMaxBatch];
   const float* pz[kMaxBatch];
@@ -257,6 +264,124 @@ __device__ __forceinline__ void mcrop_body(const MCrop& Cn, const MCommon& K, co
 }
 
 // ---------------------------------------------------------------------------------------------
+// The chain of LOCAL-mode moves of a batch, walked ONCE and one launch ahead.  Scan k is binned against the geometry
+// after the moves of scans 0 .. k - 1, and every bin block used to walk that chain itself behind its point loads — up to
+// fifteen dependent moves (~0.3 us each on a full chip: every second pose of a robot advancing half a cell per scan sits
+// on a rounding tie and takes the reference's subtract + divide), 4.5 us for the blocks of a batch's sixteenth scan, which
+// is what ended the launch.  One extra block of the scout rows (the WALKER) walks the NEXT batch's chain while this
+// launch runs — geometry before / after every scan's move into MState::PE / PC — assuming every scan of it passes the
+// crops (the scouts' answer is not complete before the launch ends; a scan with no surviving point is a covered sensor).
+// A bin block whose scan's predecessors did pass takes PE[k] / PC[k] (two loads that leave with its point loads); if
+// one did not, it walks as before.  Measured (16 scans per launch): configs[2] (P2, colour; 87 us launches) 5.40 -> 4.79 us
+// per scan; configs[1] (Kalman; 16 us launches) unchanged on streamed inputs and SLOWER on cache-resident ones (1.02 ->
+// 1.30 us per scan): that launch is bound by its memory-side atomics, the chains staggered the sixteen rows of bin blocks
+// by 0.3 us each and left the update half the first microseconds — all rows at once make the update half the last to
+// finish (phase stamps: 13.6 -> 17.1 us).  So the walker is ON for the quantile estimator and OFF for Kalman by default
+// (option "batch_walk": -1 automatic, 0 off, 1 on).  The walk itself is the reference's sequence, scan by scan: geometry before scan
+// k + 1 = scan k's candidate if scan k moved the map, else unchanged — the same numbers the per-block walk produces
+// (it defers the index wrap of short moves, which yields the candidate's wrapped index).
+//
+// Geometry before the first scan of a batch, from the state of the batch before it (complete) or the geometry ring.
+__device__ __forceinline__ DevGeom mbatch_start(const MState* __restrict__ prev, unsigned prev_count, unsigned scan_no0,
+                                                const MCommon& K, const DevState* __restrict__ st) {
+  if (!prev) return st->geom[scan_no0 & 3u];
+  const unsigned pk = prev_count - 1u;
+  DevGeom g = prev->E[pk];
+  if (K.do_move && (!K.gate_on_filter || ((prev->flags[0] >> (16u + pk)) & 1u) != 0u)) {
+    const DevCand c = prev->C[pk];
+    g.px = c.px; g.py = c.py; g.sr = c.sr; g.sc = c.sc;
+  }
+  return g;
+}
+// One batch's chain from `g` on (every lane of one wavefront, uniformly; lane j holds scan j's pose): E / C of every scan
+// into `out` (nullable), the last scan's returned.  The arithmetic is mbin_body's chain walk (see there for `nearest`,
+// the margins and the divide).
+__device__ __forceinline__ void mwalk_batch(DevGeom g, const unsigned count, const double* __restrict__ rx,
+                                            const double* __restrict__ ry, const unsigned passmask, const MCommon& K,
+                                            const GeomConst& G, MState* __restrict__ out, DevGeom& e_last, DevCand& c_last) {
+  const unsigned lane = threadIdx.x & 63u;
+  double pose_x = 0.0, pose_y = 0.0;
+  if (lane < count) { pose_x = rx[lane]; pose_y = ry[lane]; }
+  auto lane_f64 = [](double v, unsigned j) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), int(j));
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), int(j));
+    return __hiloint2double(hi, lo);
+  };
+  auto nearest = [&](double a, double p0, int& t) -> bool {
+    t = 0;
+    if (!(fabs(p0) < 1.0e7)) return false;
+    if (fabs(a) <= 1e-4) return true;
+    const double ue = a + 0.5 * (a > 0 ? 1 : -1);
+    t = static_cast<int>(ue);
+    const double f = fabs(ue - double(t));
+    return f > 1e-4 && f < 1.0 - 1e-4 && fabs(ue) < 1.0e6;
+  };
+  int tx = 0, ty = 0;
+  const bool sx = nearest((pose_x - g.px) * G.inv_res, g.px, tx), sy = nearest((pose_y - g.py) * G.inv_res, g.py, ty);
+  const unsigned sure_x = K.dbg == 3 ? 0u : uni(unsigned(__ballot(sx))), sure_y = K.dbg == 3 ? 0u : uni(unsigned(__ballot(sy)));
+  int vx = 0, vy = 0;
+  DevCand c;
+  c.px = g.px; c.py = g.py; c.sr = g.sr; c.sc = g.sc; c.shr = 0; c.shc = 0;
+#pragma unroll 1
+  for (unsigned k = 0; k < count; ++k) {
+    int dx, dy;
+    if ((sure_x >> k) & 1u) {
+      dx = __builtin_amdgcn_readlane(tx, int(k)) - vx;
+    } else {
+      const double t = div_by_res(lane_f64(pose_x, k) - g.px, G.res, G.inv_res);
+      dx = static_cast<int>(t + 0.5 * (t > 0 ? 1 : -1));
+    }
+    if ((sure_y >> k) & 1u) {
+      dy = __builtin_amdgcn_readlane(ty, int(k)) - vy;
+    } else {
+      const double t = div_by_res(lane_f64(pose_y, k) - g.py, G.res, G.inv_res);
+      dy = static_cast<int>(t + 0.5 * (t > 0 ? 1 : -1));
+    }
+    c.sr = g.sr - dx; c.sc = g.sc - dy;
+    wrap_index(c.sr, G.rows);
+    wrap_index(c.sc, G.cols);
+    c.px = g.px + double(dx) * G.res;
+    c.py = g.py + double(dy) * G.res;
+    c.shr = -dx; c.shc = -dy;
+    if (out && lane == 0u) { out->PE[k] = g; out->PC[k] = c; }
+    e_last = g;
+    if ((passmask >> k) & 1u) {  // GridMap::move: the map is where the candidate says
+      g.px = c.px; g.py = c.py; g.sr = c.sr; g.sc = c.sc;
+      vx += dx; vy += dy;
+    }
+  }
+  c_last = c;
+}
+// The walker block (first wavefront): chain of the scouted batch Cn into Cn.ms->PE / PC.
+__device__ __forceinline__ void mwalk_body(const MBin& B, const MCrop& Cn, const MCommon& K, const GeomConst& G,
+                                           const DevState* __restrict__ st) {
+  if (threadIdx.x >= 64u || !K.do_move || !K.walk || K.dbg == 2) return;
+  const unsigned lane = threadIdx.x & 63u;
+  DevGeom g;
+  if (B.count) {  // behind the batch this launch bins: its own chain as pre-walked if its scouts agreed, else walked here
+    const unsigned act = K.gate_on_filter ? (uni(B.ms->flags[0]) >> 16) : 0xFFFFu, pre = uni(B.ms->flags[1]);
+    const unsigned last = B.count - 1u;
+    DevGeom e_l;
+    DevCand c_l;
+    if ((pre >> 31) != 0u && ((pre ^ act) & ((1u << last) - 1u)) == 0u) {
+      e_l = B.ms->PE[last];
+      c_l = B.ms->PC[last];
+    } else {
+      mwalk_batch(mbatch_start(B.prev, B.prev_count, B.scan_no0, K, st), B.count, B.robot_x, B.robot_y, act, K, G, nullptr,
+                  e_l, c_l);
+    }
+    g = e_l;
+    if ((act >> last) & 1u) { g.px = c_l.px; g.py = c_l.py; g.sr = c_l.sr; g.sc = c_l.sc; }
+  } else {
+    g = mbatch_start(Cn.prev, Cn.prev_count, Cn.scan_no0, K, st);
+  }
+  DevGeom e_l;
+  DevCand c_l;
+  mwalk_batch(g, Cn.count, Cn.robot_x, Cn.robot_y, 0xFFFFu, K, G, Cn.ms, e_l, c_l);
+  if (lane == 0u) Cn.ms->flags[1] = 0x80000000u | ((1u << Cn.count) - 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
 // bin half: block `bid` of the batch's bin grid.  CH: bit 0 intensity, bit 1 colour (compile-time, as k_bin's).
 template <int CH, bool RAY>
 __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const GeomConst& G,
@@ -279,12 +404,18 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
   // walk below waits for these; the previous batch's candidate is fetched whether or not it will apply — one round
   // trip instead of flag -> candidate)
   double pose_x = 0.0, pose_y = 0.0;
-  DevGeom g_start;
-  DevCand c_prev;
-  unsigned f_prev = 0u;
+  DevGeom g_start, g_pre;
+  DevCand c_prev, c_pre;
+  unsigned f_prev = 0u, w_pre = 0u;
   g_start.px = g_start.py = 0.0; g_start.sr = g_start.sc = 0; g_start.pad0 = g_start.pad1 = 0;
   c_prev.px = c_prev.py = 0.0; c_prev.sr = c_prev.sc = c_prev.shr = c_prev.shc = 0;
+  g_pre = g_start;
+  c_pre = c_prev;
   if (threadIdx.x < 64u) {
+    // (the chain as the walker block of the previous launch left it: used if the scouts confirmed what it assumed)
+    w_pre = ms->flags[1];
+    g_pre = ms->PE[k];
+    c_pre = ms->PC[k];
     if (lane <= k) { pose_x = B.robot_x[lane]; pose_y = B.robot_y[lane]; }
     if (B.prev) {
       const unsigned pk = B.prev_count - 1u;
@@ -338,6 +469,14 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
     return __hiloint2double(hi, lo);
   };
   auto chain = [&](unsigned passmask) {  // (every lane of the first wavefront, uniformly)
+    if (K.do_move && K.walk && K.dbg != 2 && K.dbg != 3 && (uni(w_pre) >> 31) != 0u &&
+        ((uni(w_pre) ^ passmask) & ((1u << k) - 1u)) == 0u) {  // pre-walked (mwalk_body): nothing to walk
+      if (threadIdx.x == 0) {
+        S.s_cand = c_pre;
+        if (lb == 0u) { ms->E[k] = g_pre; ms->C[k] = c_pre; }
+      }
+      return;
+    }
     DevGeom g = g_start;
     if (B.prev) {  // what the update of the previous batch (the other half of this launch) is about to commit
       const unsigned pk = B.prev_count - 1u;
@@ -725,7 +864,7 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
     U.rearm->done[(lt - 64u) * kLineWords] = 0u;
     U.rearm->done[(lt - 64u) * kLineWords + 1u] = 0u;  // (the tile batches' flag word on the same line, fdm_tbatch.hpp)
     U.rearm->inside[lt - 64u] = 0u;
-    if (lt == 64u) { U.rearm->flags[0] = 0u; U.rearm->err = 0u; U.rearm->tq = 0u; U.rearm->gdone = 0u; }
+    if (lt == 64u) { U.rearm->flags[0] = 0u; U.rearm->flags[1] = 0u; U.rearm->err = 0u; U.rearm->tq = 0u; U.rearm->gdone = 0u; }
   }
 
   unsigned nib = 0u;
@@ -1047,6 +1186,7 @@ __global__ __launch_bounds__(256, MBatchWaves<POLICY>::value) void k_mbatch(cons
   } else {  // scout rows: block c of Cn.count * kMScout
     const unsigned c = (row - upd_rows - B.count) * gridDim.x + x;
     if (c < Cn.count * kMScout) mcrop_body(Cn, K, c / kMScout, c % kMScout);
+    else if (c == Cn.count * kMScout && Cn.count) mwalk_body(B, Cn, K, G, st);
   }
   if (K.timeline && threadIdx.x == 0) {  // (thread 0's view of the block; scripts/timeline_batch.py)
     const unsigned b = blockIdx.y * gridDim.x + x;

@@ -360,6 +360,7 @@ __device__ __forceinline__ void tbupdate_body(const TBUpd& U, const GeomConst& G
         U.rearm->done[q * kLineWords] = 0u; U.rearm->done[q * kLineWords + 1] = 0u; U.rearm->inside[q] = 0u;
       }
       U.rearm->flags[0] = 0u;
+      U.rearm->flags[1] = 0u;  // (k_mbatch's pre-walked chain word)
       U.rearm->err = 0u;
       U.rearm->tq = 0u;
       U.rearm->gdone = 0u;

@@ -16,8 +16,12 @@ wl = synth.make(WL, n_scans=8)
 res = bench.Resident(wl, 0)
 res.eng.set_option("dbg_timeline", 1)
 res.eng.set_option("batch_max", bm)
+if "raycast=1" in sys.argv:  # the variant whose update half resolves ray events
+    cfg = res.eng.cfg
+    cfg.raycast_enabled = 1
+    res.eng.set_config(cfg)
 for kv in sys.argv[1:]:
-    if "=" in kv and not kv.startswith("variant") and not kv.startswith("workload"):
+    if "=" in kv and not kv.startswith("variant") and not kv.startswith("workload") and not kv.startswith("raycast"):
         res.eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 for kk in range(400):
     res.pose(kk)

@@ -12,6 +12,11 @@ wl = synth.make("c2", n_scans=8)
 res = bench.Resident(wl, 0)
 res.eng.set_option("dbg_timeline", 1)
 for kv in sys.argv[1:]:
+    if kv == "raycast=1":  # the k_mbatch variant whose update half resolves ray events (fdm_rbatch.hpp ran in between)
+        cfg = res.eng.cfg
+        cfg.raycast_enabled = 1
+        res.eng.set_config(cfg)
+        continue
     res.eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 for kk in range(400):
     res.pose(kk)

@@ -17,6 +17,19 @@ pytestmark = pytest.mark.gpu
 F32 = np.float32
 
 
+@pytest.fixture(autouse=True, params=["walk_auto", "walk_on"])
+def chain_walk(request, gpu):
+    """Every test of this module twice: the engine's own choice of who walks a batch's chain of LOCAL-mode moves
+    (every bin block for the Kalman estimator, the walker block of the previous launch for the quantile estimator:
+    option `batch_walk` -1), and the walker for every engine (`batch_walk` 1: scans that do not pass the crops in the
+    middle of a batch then falsify what it assumed, and the blocks behind them — and the next walker — walk themselves)."""
+    saved = dict(gpu.Engine.default_options)
+    if request.param == "walk_on":
+        gpu.Engine.default_options = dict(saved, batch_walk=1)
+    yield request.param
+    gpu.Engine.default_options = saved
+
+
 def T(x=0.0, y=0.0, z=0.0, yaw=0.0, pitch=0.0):
     M = np.eye(4)
     c, s = np.cos(yaw), np.sin(yaw)
