@@ -711,6 +711,9 @@ def main():
         # of the default command has rows for both.
         from fastdem_amd import tiling
         args.stall_timeout = args.collective_timeout + 60
+        # (this leg has never run on two devices: whatever happens in it, the replicas' line above is printed)
+        args.global_map_fatal = False
+        args.partial_result = result if rank == 0 else None
         g = tiling.bench_global(args, rank, local_rank, world)
         if rank == 0:
             result["global_map"] = g

@@ -375,11 +375,12 @@ class Watchdog:
     `kick()` is not called for `seconds`, the process prints what it was doing and leaves with exit code 3 — plain
     os._exit from a helper thread; nothing is exec'ed, the GPU context dies with the process."""
 
-    def __init__(self, seconds, what="bench"):
+    def __init__(self, seconds, what="bench", on_stall=None):
         import threading
         import time
         self._t, self._time, self.what, self.seconds, self.stage = time.monotonic(), time, what, seconds, "start"
         self._stop = False
+        self.on_stall = on_stall  # (called with the message instead of leaving with exit code 3)
         self._thread = threading.Thread(target=self._run, daemon=True)
         self._thread.start()
 
@@ -397,8 +398,11 @@ class Watchdog:
         while not self._stop:
             self._time.sleep(1.0)
             if self._time.monotonic() - self._t > self.seconds:
-                sys.stderr.write(f"[{self.what}] no progress for {self.seconds} s in stage '{self.stage}': giving up\n")
+                msg = f"[{self.what}] no progress for {self.seconds} s in stage '{self.stage}': giving up"
+                sys.stderr.write(msg + "\n")
                 sys.stderr.flush()
+                if self.on_stall is not None:
+                    self.on_stall(msg)
                 os._exit(3)
 
 
@@ -418,8 +422,29 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
 
     from . import Engine, capi, synth
 
-    dog = Watchdog(float(getattr(args, "stall_timeout", 180.0)), what=f"bench c5 rank {rank}")
+    # `global_map_fatal` False (the leg rides behind the replicas of the default workload): a failure or a stall of THIS
+    # leg must not take the replicas' line with it — rank 0 prints the line it has, with the error in `global_map`, and
+    # every rank leaves with code 0 (peers blocked in a collective leave through their own watchdogs the same way).
+    fatal = bool(getattr(args, "global_map_fatal", True))
+
+    def give_up(msg, code):
+        import json
+        import os
+        import sys
+        if fatal:
+            os._exit(code)
+        if rank == 0 and getattr(args, "partial_result", None) is not None:
+            line = dict(args.partial_result)
+            line["global_map"] = {"error": msg}
+            sys.stdout.write(json.dumps(line) + "\n")
+            sys.stdout.flush()
+        os._exit(0)
+
+    dog = Watchdog(float(getattr(args, "stall_timeout", 180.0)), what=f"bench c5 rank {rank}",
+                   on_stall=lambda msg: give_up(msg, 3))
     try:
+        if _os_mod.environ.get("FDM_BENCH_FAIL_GLOBAL") == str(rank):  # (tests: this leg failing on one rank)
+            raise RuntimeError("FDM_BENCH_FAIL_GLOBAL")
         wl = synth.global_map(n_scans=2)
         dev = f"cuda:{local_rank}"
         staged = dist.get_backend() == "gloo"  # host-staged exchange (several ranks on one device: RCCL refuses that)
@@ -517,7 +542,7 @@ def bench_global(args, rank: int, local_rank: int, world: int) -> Optional[dict]
         traceback.print_exc()
         sys.stderr.write(f"[bench c5 rank {rank}] failed: {exc!r}\n")
         sys.stderr.flush()
-        os._exit(2)
+        give_up(f"rank {rank}: {exc!r}", 2)
     dog.stop()
     if rank != 0:
         return None

@@ -25,8 +25,9 @@ profile = sys.argv[4] if len(sys.argv) > 4 else "small"
 # tbatch: 60 m map, scans up to 300 K points    A = tile batches on (tbatch 1, tbatch_min 1000), B = defaults (one launch per scan)
 # ray   : 16 m map, raycasting on in every call      A = the stage inside the batches (fdm_rbatch.hpp), B = batch_ray 0 (one scan per launch)
 # rayp2 : the same with the P2 estimator + colour
-SIZE = {"small": 16.0, "tiled": 60.0, "p2": 12.0, "tbatch": 60.0, "ray": 16.0, "rayp2": 12.0}[profile]
-BIG = {"small": 70000, "tiled": 300000, "p2": 40000, "tbatch": 300000, "ray": 70000, "rayp2": 40000}[profile]
+# walk  : 16 m LOCAL map, Kalman     A = the walker block walks every batch's chain of moves one launch ahead (batch_walk 1), B = batch_walk 0
+SIZE = {"small": 16.0, "tiled": 60.0, "p2": 12.0, "tbatch": 60.0, "ray": 16.0, "rayp2": 12.0, "walk": 16.0}[profile]
+BIG = {"small": 70000, "tiled": 300000, "p2": 40000, "tbatch": 300000, "ray": 70000, "rayp2": 40000, "walk": 30000}[profile]
 rng = np.random.default_rng(2026)
 
 
@@ -86,6 +87,9 @@ elif profile == "tbatch":
     A.set_option("tbatch_min", 1000)
 elif profile in ("ray", "rayp2"):
     B.set_option("batch_ray", 0)
+elif profile == "walk":
+    A.set_option("batch_walk", 1)
+    B.set_option("batch_walk", 0)
 else:
     B.set_option("batch", 0)
     B.set_option("voxel_small", 0)

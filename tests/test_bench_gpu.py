@@ -13,8 +13,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*argv, timeout=900):
+def run_bench(*argv, timeout=900, extra_env=None):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env or {})
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], cwd=ROOT, env=env, timeout=timeout,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -37,3 +38,14 @@ def test_gpus_2_default_workload_prints_replicas_and_the_global_map():
     assert r["n_gpus"] == 2 and "replicas" in r["config"]["parallelism"]
     g = r["global_map"]
     assert g["n_gpus"] == 2 and g["roofline"]["achieved"] > 0 and g["value"] > 0
+
+
+def test_a_failing_global_map_leg_does_not_take_the_replicas_line_with_it():
+    """The global-map leg behind the replicas has never run on two devices.  Whatever happens in it — here rank 1 raises
+    at its start (FDM_BENCH_FAIL_GLOBAL) — rank 0 still prints the replicas' line, with the error in `global_map`, and
+    every rank leaves with code 0."""
+    r = run_bench("--gpus", "2", "--backend", "gloo", "--devices", "0,0", "--steps", "4", "--warmup", "2",
+                  "--no-cpu-baseline", "--no-host-legs", "--collective-timeout", "20",
+                  extra_env={"FDM_BENCH_FAIL_GLOBAL": "1"})
+    assert r["n_gpus"] == 2 and r["value"] > 0 and "replicas" in r["config"]["parallelism"]
+    assert "error" in r["global_map"]
