@@ -1875,528 +1875,8 @@ int fdm_engine_last_stats(fdm_engine* e, fdm_scan_stats* out) {
   return rc ? rc : status;
 }
 
-int fdm_engine_move(fdm_engine* e, double x, double y) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e) return fail(FDM_ERR_INVALID, "null engine");
-  if (e->G.s_rows != e->G.rows || e->G.s_cols != e->G.cols)
-    return fail(FDM_ERR_INVALID, "move() is not defined for tiled engines");
-  HIPCK(hipSetDevice(e->device));
-  ScanParams P;
-  fill_update_params(e, P, x, y, true);
-  return enqueue_scan(e, P, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-}
-
-int fdm_engine_get_geometry(fdm_engine* e, fdm_geometry* out) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e || !out) return fail(FDM_ERR_INVALID, "null argument");
-  if (int rc_sync = sync_all(e)) return rc_sync;
-  DevGeom g;
-  HIPCK(hipMemcpy(&g, &e->d_state->geom[e->scan_no & 3], sizeof(DevGeom), hipMemcpyDeviceToHost));
-  out->length_x = e->G.len_x;
-  out->length_y = e->G.len_y;
-  out->resolution = e->G.res;
-  out->position_x = g.px;
-  out->position_y = g.py;
-  out->rows = e->G.rows;
-  out->cols = e->G.cols;
-  out->start_row = g.sr;
-  out->start_col = g.sc;
-  return FDM_OK;
-}
-
-int fdm_engine_set_position(fdm_engine* e, double x, double y) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e) return fail(FDM_ERR_INVALID, "null engine");
-  if (int rc_sync = sync_all(e)) return rc_sync;
-  const double p[2] = {x, y};
-  HIPCK(hipMemcpy(&e->d_state->geom[e->scan_no & 3].px, p, sizeof(p), hipMemcpyHostToDevice));
-  return FDM_OK;
-}
-
-int fdm_engine_set_start_index(fdm_engine* e, int32_t row, int32_t col) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e) return fail(FDM_ERR_INVALID, "null engine");
-  if (row < 0 || col < 0 || row >= e->G.rows || col >= e->G.cols)
-    return fail(FDM_ERR_INVALID, "start index out of range");
-  if ((row || col) && (e->G.s_rows != e->G.rows || e->G.s_cols != e->G.cols))
-    return fail(FDM_ERR_INVALID, "tiled engines need start index 0");
-  if (int rc_sync = sync_all(e)) return rc_sync;
-  const int s[2] = {row, col};
-  HIPCK(hipMemcpy(&e->d_state->geom[e->scan_no & 3].sr, s, sizeof(s), hipMemcpyHostToDevice));
-  return FDM_OK;
-}
-
-int fdm_engine_num_layers(fdm_engine* e) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e) return fail(FDM_ERR_INVALID, "null engine");
-  if (int rc = resolve_pending(e)) return rc;
-  int n = 0;
-  for (auto& l : e->layers) n += l.pending ? 0 : 1;
-  return n;
-}
-
-const char* fdm_engine_layer_name(fdm_engine* e, int i) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return nullptr; } }
-  if (!e) return nullptr;
-  if (resolve_pending(e)) return nullptr;
-  int k = 0;
-  for (auto& l : e->layers) {
-    if (l.pending) continue;
-    if (k++ == i) return l.name.c_str();
-  }
-  return nullptr;
-}
-
-int fdm_engine_layer_exists(fdm_engine* e, const char* name) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e || !name) return fail(FDM_ERR_INVALID, "null argument");
-  if (int rc = resolve_pending(e)) return rc;
-  Layer* l = find_layer(e, name);
-  return (l && !l->pending) ? 1 : 0;
-}
-
-int fdm_engine_layer_add(fdm_engine* e, const char* name, float value) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e || !name) return fail(FDM_ERR_INVALID, "null argument");
-  HIPCK(hipSetDevice(e->device));
-  if (std::strcmp(name, "obstacle") == 0) e->obst_dense_pending = true;
-  if (int rc = resolve_pending(e)) return rc;  // keeps getLayers() in the reference's creation order
-  return add_layer(e, name, value, false);
-}
-
-int fdm_engine_layer_download(fdm_engine* e, const char* name, float* host, int32_t rows, int32_t cols) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e || !name || !host) return fail(FDM_ERR_INVALID, "null argument");
-  if (rows != e->G.s_rows || cols != e->G.s_cols) return fail(FDM_ERR_INVALID, "shape mismatch");
-  if (int rc = resolve_pending(e)) return rc;
-  Layer* l = find_layer(e, name);
-  if (!l || l->pending) return fail(FDM_ERR_NO_LAYER, std::string("no layer ") + name);
-  const float* src = l->d;
-  if (l->field >= 0) {  // record field: gather into a contiguous staging array first
-    if (int rc = ensure_tmp(e)) return rc;
-    if (int rc = copy_strided(e, e->d_tmp, 1, lptr(e, *l), lstride(e, *l))) return rc;
-    src = e->d_tmp;
-  }
-  HIPCK(hipMemcpyAsync(host, src, e->ncell * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-  if (int rc_sync = sync_all(e)) return rc_sync;
-  return FDM_OK;
-}
-
-int fdm_engine_layer_upload(fdm_engine* e, const char* name, const float* host, int32_t rows, int32_t cols) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e || !name || !host) return fail(FDM_ERR_INVALID, "null argument");
-  if (rows != e->G.s_rows || cols != e->G.s_cols) return fail(FDM_ERR_INVALID, "shape mismatch");
-  HIPCK(hipSetDevice(e->device));
-  Layer* l = find_layer(e, name);
-  if (!l) {
-    if (int rc = add_layer(e, name, NAN, false)) return rc;
-    l = find_layer(e, name);
-  }
-  l->pending = false;
-  if (std::strcmp(name, "obstacle") == 0) e->obst_dense_pending = true;
-  if (l->field >= 0) {
-    if (int rc = ensure_tmp(e)) return rc;
-    HIPCK(hipMemcpyAsync(e->d_tmp, host, e->ncell * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    if (int rc = copy_strided(e, lptr(e, *l), lstride(e, *l), e->d_tmp, 1)) return rc;
-  } else {
-    HIPCK(hipMemcpyAsync(l->d, host, e->ncell * sizeof(float), hipMemcpyHostToDevice, e->stream));
-  }
-  if (int rc_sync = sync_all(e)) return rc_sync;
-  return FDM_OK;
-}
-
-float* fdm_engine_layer_device_ptr(fdm_engine* e, const char* name) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return nullptr; } }
-  if (!e || !name) return nullptr;
-  Layer* l = find_layer(e, name);
-  return (l && l->field < 0) ? l->d : nullptr;  // record fields have no contiguous array
-}
-
-int fdm_engine_clear(fdm_engine* e, const char* name) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e) return fail(FDM_ERR_INVALID, "null engine");
-  HIPCK(hipSetDevice(e->device));
-  if (name) {
-    Layer* l = find_layer(e, name);
-    if (!l || l->pending) return fail(FDM_ERR_NO_LAYER, std::string("no layer ") + name);
-    return fill_async(e, lptr(e, *l), NAN, e->ncell, lstride(e, *l));
-  }
-  for (auto& l : e->layers)
-    if (int rc = fill_async(e, lptr(e, l), NAN, e->ncell, lstride(e, l))) return rc;
-  return FDM_OK;
-}
-
-// One launch for `n_rects` rectangles x `n_layers` layers (k_regions_copy); more than kRegionRects / kRegionLayers of
-// either: several launches.
-static int regions_copy(fdm_engine* e, int n_rects, const fdm_region* rects, const char* const* names, int n_layers,
-                        float* d_buf, int to_buf) {
-  if (!e || !names || !d_buf || (n_rects && !rects)) return fail(FDM_ERR_INVALID, "null argument");
-  if (n_rects < 0 || n_layers < 0) return fail(FDM_ERR_INVALID, "negative count");
-  HIPCK(hipSetDevice(e->device));
-  std::vector<Layer*> L(size_t(std::max(n_layers, 0)));
-  for (int k = 0; k < n_layers; ++k) {
-    L[k] = find_layer(e, names[k]);
-    if (!L[k]) return fail(FDM_ERR_NO_LAYER, std::string("no layer ") + names[k]);
-  }
-  for (int q = 0; q < n_rects; ++q) {
-    const fdm_region& r = rects[q];
-    if (r.nr <= 0 || r.nc <= 0 || r.r0 < 0 || r.c0 < 0 || r.r0 + r.nr > e->G.s_rows || r.c0 + r.nc > e->G.s_cols)
-      return fail(FDM_ERR_INVALID, "region outside the stored window");
-  }
-  for (int q0 = 0; q0 < n_rects; q0 += kRegionRects) {
-    const int nq = std::min(kRegionRects, n_rects - q0);
-    for (int l0 = 0; l0 < n_layers; l0 += kRegionLayers) {
-      const int nl = std::min(kRegionLayers, n_layers - l0);
-      RegionArgs A{};
-      size_t max_cells = 0;
-      for (int q = 0; q < nq; ++q) {
-        const fdm_region& r = rects[q0 + q];
-        const size_t cells = size_t(r.nr) * size_t(r.nc);
-        A.r0[q] = r.r0; A.c0[q] = r.c0; A.nr[q] = r.nr; A.nc[q] = r.nc;
-        A.off[q] = r.offset + size_t(l0) * cells;  // (the rectangle's block is layer-major over ALL n_layers)
-        max_cells = std::max(max_cells, cells);
-      }
-      for (int l = 0; l < nl; ++l) { A.layer[l] = lptr(e, *L[l0 + l]); A.es[l] = lstride(e, *L[l0 + l]); }
-      A.n_rects = nq; A.n_layers = nl; A.s_rows = e->G.s_rows; A.to_buf = to_buf;
-      const unsigned gx = unsigned(std::min<size_t>((max_cells + 255) / 256, 1024));
-      hipLaunchKernelGGL(k_regions_copy, dim3(gx, unsigned(nq * nl)), dim3(256), 0, e->stream, A, d_buf);
-      HIPCK(hipGetLastError());
-    }
-  }
-  return FDM_OK;
-}
-
-int fdm_engine_regions_pack(fdm_engine* e, int32_t n_rects, const fdm_region* rects, const char* const* names,
-                            int n_layers, float* d_buf) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  return regions_copy(e, n_rects, rects, names, n_layers, d_buf, 1);
-}
-int fdm_engine_regions_unpack(fdm_engine* e, int32_t n_rects, const fdm_region* rects, const char* const* names,
-                              int n_layers, const float* d_buf) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  return regions_copy(e, n_rects, rects, names, n_layers, const_cast<float*>(d_buf), 0);
-}
-int fdm_engine_region_pack(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, int32_t nc,
-                           const char* const* names, int n_layers, float* d_buf) {
-  const fdm_region r{r0, c0, nr, nc, 0};
-  return fdm_engine_regions_pack(e, 1, &r, names, n_layers, d_buf);
-}
-int fdm_engine_region_unpack(fdm_engine* e, int32_t r0, int32_t c0, int32_t nr, int32_t nc,
-                             const char* const* names, int n_layers, const float* d_buf) {
-  const fdm_region r{r0, c0, nr, nc, 0};
-  return fdm_engine_regions_unpack(e, 1, &r, names, n_layers, d_buf);
-}
-
-int fdm_engine_capture(fdm_engine* e, int preprocessed, int rasterized) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e) return fail(FDM_ERR_INVALID, "null engine");
-  e->cap_pre = preprocessed != 0;
-  e->cap_cov = preprocessed == 2;
-  e->cap_ras = rasterized != 0;
-  if (e->cap_pre) e->want_ids = true;  // the per-point pass flag rides on the cell-id buffer
-  return FDM_OK;
-}
-
-int fdm_engine_last_preprocessed(fdm_engine* e, uint64_t cap, float* x, float* y, float* z,
-                                 float* sigma_z2, uint64_t* n_out) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e || !n_out) return fail(FDM_ERR_INVALID, "null argument");
-  *n_out = 0;
-  if (!e->cap_pre) return fail(FDM_ERR_INVALID, "preprocessed-scan capture is off");
-  const size_t n = e->last_n;
-  if (!e->have_scan || n == 0 || !e->d_cap || !e->d_cell_ids) return FDM_OK;
-  if (int rc_sync = sync_all(e)) return rc_sync;
-  std::vector<float> h(4 * n);
-  std::vector<int32_t> ids(n);
-  for (int c = 0; c < 4; ++c)
-    HIPCK(hipMemcpy(h.data() + c * n, e->d_cap + c * e->cap_cap, n * sizeof(float), hipMemcpyDeviceToHost));
-  HIPCK(hipMemcpy(ids.data(), e->d_cell_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-  uint64_t w = 0;
-  for (size_t i = 0; i < n; ++i) {  // order-preserving compaction = marshalling, like filterInPlace
-    if (ids[i] == -1) continue;     // dropped by cropRange / cropZ
-    if (w < cap) {
-      if (x) x[w] = h[i];
-      if (y) y[w] = h[n + i];
-      if (z) z[w] = h[2 * n + i];
-      if (sigma_z2) sigma_z2[w] = h[3 * n + i];
-    }
-    ++w;
-  }
-  *n_out = w;
-  return FDM_OK;
-}
-
-int fdm_engine_last_preprocessed_cov(fdm_engine* e, uint64_t cap, float* cov9, uint64_t* n_out) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e || !n_out || !cov9) return fail(FDM_ERR_INVALID, "null argument");
-  *n_out = 0;
-  if (!e->cap_pre || !e->cap_cov) return fail(FDM_ERR_INVALID, "covariance capture is off (fdm_engine_capture(e, 2, ..))");
-  const size_t n = e->last_n;
-  if (!e->have_scan || n == 0 || !e->d_cap || !e->d_cell_ids) return FDM_OK;
-  if (int rc_sync = sync_all(e)) return rc_sync;
-  std::vector<float> h(9 * n);
-  std::vector<int32_t> ids(n);
-  for (int c = 0; c < 9; ++c)
-    HIPCK(hipMemcpy(h.data() + c * n, e->d_cap + (4 + c) * e->cap_cap, n * sizeof(float), hipMemcpyDeviceToHost));
-  HIPCK(hipMemcpy(ids.data(), e->d_cell_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-  uint64_t w = 0;
-  for (size_t i = 0; i < n; ++i) {  // the same order-preserving compaction as fdm_engine_last_preprocessed
-    if (ids[i] == -1) continue;
-    if (w < cap)
-      for (int c = 0; c < 9; ++c) cov9[w * 9 + c] = h[c * n + i];
-    ++w;
-  }
-  *n_out = w;
-  return FDM_OK;
-}
-
-int fdm_engine_last_rasterized(fdm_engine* e, uint64_t cap, float* x, float* y, float* z,
-                               uint64_t* n_out) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e || !n_out) return fail(FDM_ERR_INVALID, "null argument");
-  *n_out = 0;
-  if (!e->cap_ras) return fail(FDM_ERR_INVALID, "rasterized-scan capture is off");
-  if (!e->have_scan || !e->d_ras) return FDM_OK;
-  if (int rc_sync = sync_all(e)) return rc_sync;
-  std::vector<float> h(e->ncell);
-  HIPCK(hipMemcpy(h.data(), e->d_ras, e->ncell * sizeof(float), hipMemcpyDeviceToHost));
-  fdm_geometry g;
-  if (int rc = fdm_engine_get_geometry(e, &g)) return rc;
-  uint64_t w = 0;
-  const GeomConst& G = e->G;
-  for (size_t o = 0; o < e->ncell; ++o) {
-    if (std::isnan(h[o])) continue;
-    if (w < cap) {
-      const int r = int(o % size_t(G.s_rows)) + G.s_r0, c = int(o / size_t(G.s_rows)) + G.s_c0;
-      int ur = r - g.start_row, uc = c - g.start_col;  // getPositionFromIndex (grid_map_core)
-      if (ur < 0) ur += G.rows;
-      if (uc < 0) uc += G.cols;
-      const double px = g.position_x + (0.5 * G.len_x - 0.5 * G.res) + G.res * double(-ur);
-      const double py = g.position_y + (0.5 * G.len_y - 0.5 * G.res) + G.res * double(-uc);
-      if (x) x[w] = float(px);
-      if (y) y[w] = float(py);
-      if (z) z[w] = h[o];
-    }
-    ++w;
-  }
-  *n_out = w;
-  return FDM_OK;
-}
-
-int fdm_engine_enable_cell_ids(fdm_engine* e, int on) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e) return fail(FDM_ERR_INVALID, "null engine");
-  e->want_ids = on != 0;
-  return FDM_OK;
-}
-
-int fdm_engine_last_cell_ids(fdm_engine* e, int32_t* host_out, uint64_t n) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e || !host_out) return fail(FDM_ERR_INVALID, "null argument");
-  if (!e->want_ids || !e->d_cell_ids || n != e->last_n)
-    return fail(FDM_ERR_INVALID, "cell ids not recorded for the last scan");
-  HIPCK(hipMemcpyAsync(host_out, e->d_cell_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
-  if (int rc_sync = sync_all(e)) return rc_sync;
-  return FDM_OK;
-}
-
-int fdm_engine_enable_profile(fdm_engine* e, int on) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e) return fail(FDM_ERR_INVALID, "null engine");
-  e->profile = on != 0;
-  return FDM_OK;
-}
-
-int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2) {
-  if (!e || !ms2) return fail(FDM_ERR_INVALID, "null argument");
-  if (!e->profile) return fail(FDM_ERR_INVALID, "profiling is off");
-  HIPCK(hipEventSynchronize(e->ev[3]));  // no flush: a held-back update stays held (the chain is what is timed)
-  // an event pair around ONE short kernel also times the gap to the next command; the empty
-  // pair (ev2 -> ev3) measures that gap and is subtracted, so the figures agree with rocprofv3
-  float raw0 = 0.f, raw1 = 0.f, gap = 0.f;
-  HIPCK(hipEventElapsedTime(&raw0, e->ev[0], e->ev[1]));
-  HIPCK(hipEventElapsedTime(&raw1, e->ev[1], e->ev[2]));
-  HIPCK(hipEventElapsedTime(&gap, e->ev[2], e->ev[3]));
-  ms2[0] = raw0 > gap ? raw0 - gap : raw0;
-  ms2[1] = e->chain ? 0.0f : (raw1 > gap ? raw1 - gap : raw1);  // held back: it rides with the next launch
-  return FDM_OK;
-}
-
-/* tuning knob used by bench.py's A/B runs (not part of the reference surface) */
-int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
-  if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
-  if (!e || !key) return fail(FDM_ERR_INVALID, "null argument");
-  if (std::strcmp(key, "wave_merge") == 0) {
-    e->wave_merge = value != 0;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "bin_table") == 0) {
-    e->bin_table = value != 0;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "overlap") == 0) {
-    e->overlap = value != 0;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "batch") == 0) {  // fdm_engine_integrate_device_batch: group small scans into batch launches
-    e->batch = value != 0;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "voxel_small") == 0) {  // 0: every scan through the library sort
-    e->voxel_small = value != 0;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "voxel_small_max") == 0) {
-    if (value < 1 || value > (1 << 20)) return fail(FDM_ERR_INVALID, "voxel_small_max: 1 .. 2^20 points");
-    e->voxel_small_max = value;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "dbg_batch") == 0) {
-    e->dbg_batch = value;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "batch_walk") == 0) {
-    if (value < -1 || value > 1) return fail(FDM_ERR_INVALID, "batch_walk: -1 (automatic), 0, 1");
-    e->batch_walk = value;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "batch_crop") == 0) {
-    e->batch_crop = value != 0;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "batch_ray") == 0) {  // 0: scans of an engine with raycasting on leave one by one
-    e->batch_ray = value != 0;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "batch_ray_lds") == 0) {
-    e->batch_ray_lds = value != 0;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "batch_ray_words") == 0) {
-    if (value < 0) return fail(FDM_ERR_INVALID, "batch_ray_words: >= 0");
-    e->batch_ray_words = value;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "batch_ray_parts") == 0) {
-    if (value < 0 || value > 64) return fail(FDM_ERR_INVALID, "batch_ray_parts: 0 (automatic) .. 64");
-    e->batch_ray_parts = value;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "batch_ray_seg") == 0) {
-    if (value != 1 && value != 4 && value != 8 && value != 16) return fail(FDM_ERR_INVALID, "batch_ray_seg: 1, 4, 8 or 16 lanes per ray");
-    e->batch_ray_seg = value;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "batch_fuse") == 0) {
-    e->batch_fuse = value != 0;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "batch_max") == 0) {
-    if (value < 2 || value > kMaxBatch) return fail(FDM_ERR_INVALID, "batch_max: 2 .. 16 scans per launch");
-    e->batch_max = value;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "tbatch") == 0) {  // fdm_engine_integrate_device_batch: group LARGE scans into tile-batch launches
-    e->tbatch = value != 0;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "tbatch_max") == 0) {
-    if (value < 2 || value > kTBMax) return fail(FDM_ERR_INVALID, "tbatch_max: 2 .. 8 scans per launch");
-    e->tbatch_max = value;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "tbatch_min") == 0) {
-    if (value < 1) return fail(FDM_ERR_INVALID, "tbatch_min: a point count");
-    e->tbatch_min = unsigned(value);
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "tb_groups") == 0) {
-    if (value < 1 || value > 65535) return fail(FDM_ERR_INVALID, "tb_groups: 1 .. 65535 update groups");
-    e->tb_groups = value;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "zero_copy") == 0) {
-    if (value < 0) return fail(FDM_ERR_INVALID, "zero_copy: a point count (0 = off)");
-    e->zero_copy = value;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "dbg_timeline") == 0) {  // measurement only: block start / end ticks of the fused tiled launches
-    if (int rc_sync = sync_all(e)) return rc_sync;
-    if (e->d_timeline) { (void)hipFree(e->d_timeline); e->d_timeline = nullptr; }
-    e->timeline_cap = 0;
-    if (value > 0) {
-      e->timeline_cap = 1u << 16;
-      HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_timeline), size_t(e->timeline_cap) * 16));
-      HIPCK(hipMemset(e->d_timeline, 0, size_t(e->timeline_cap) * 16));
-    }
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "sync_spin_us") == 0) {
-    e->sync_spin_us = value < 0 ? 0 : value;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "dbg_span") == 0) {  // measurement only: tiles per update group, 0 = automatic
-    if (value < 0 || value > 64) return fail(FDM_ERR_INVALID, "dbg_span: 0 (automatic) or 1..64 tiles per group");
-    if (int rc_sync = sync_all(e)) return rc_sync;
-    e->dbg_span = value;
-    if (e->tile_rare) {  // sized per update group: the group count follows the span
-      HIPCK(hipFree(e->tile_rare));
-      e->tile_rare = nullptr;
-      for (auto& q : e->pool) q.rare = nullptr;
-    }
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "dbg_post") == 0) {
-    e->dbg_post = value;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "ray_large_min") == 0) {
-    e->ray_large_min = value < 1 ? 1 : value;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "dbg_ray") == 0) {
-    e->dbg_ray = value;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "tiled") == 0) {  // large scans through per-tile record pools (1, default) or the per-cell scratch (0)
-    e->tiled = value != 0;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "borrow_inputs") == 0) {  // 1: device arrays of enqueue-only scans stay untouched by the caller
-    e->borrow_inputs = value != 0;              //    until the NEXT-BUT-ONE scan is enqueued (or a flush): no staging copy
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "tiled_min") == 0) {
-    if (value < 0) return fail(FDM_ERR_INVALID, "tiled_min: a point count");
-    e->tiled_min = unsigned(value);
-    e->tiled_forced = true;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "bin_variant") == 0) {
-    if (value != 0 && value != 1 && value != 4) return fail(FDM_ERR_INVALID, "bin_variant must be 0, 1 or 4");
-    e->bin_variant = value;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "records") == 0) {  // cell-record layout (1, default) or one array per layer (0)
-    e->use_records = value != 0;
-    if (e->estimator_ready) return activate_records(e, e->cfg.estimation_type == 1 ? 1 : 0);
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "dense") == 0) {  // force stamp-gated (0) or dense (1) update sweeps
-    e->S.dense = value != 0;
-    e->obst_dense_pending = true;  // stamps were not maintained while dense
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "dbg_upd") == 0) {
-    e->dbg_upd = value;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "dbg_no_atomics") == 0) {  // measurement only: results are wrong when set
-    e->dbg_no_atomics = value;
-    return FDM_OK;
-  }
-  return fail(FDM_ERR_INVALID, std::string("unknown option ") + key);
-}
+#include "fdm_engine_layers.inl"  // geometry, named layers, halo regions
+#include "fdm_engine_opts.inl"    // captures, cell ids, profile, options
 
 }  // extern "C"
 
