@@ -54,7 +54,7 @@ __device__ __forceinline__ VoxelSmall rb_voxel(const RBatch& R, const unsigned k
   V.rec = R.rec + size_t(k) * R.stride;
   V.cap = R.stride;
   V.ibits = R.ibits[k];
-  V.dbg = 0;
+  V.dbg = (R.dbg >> 8) & 3;  // (measurement only, as the single-scan path's dbg_ray bits 8..9)
   return V;
 }
 // map geometry after scan k's move (what the bin half binned the scan against)
