@@ -9,9 +9,9 @@
 // GridMap::move strips and the obstacle-layer clear happen between scans), and that order is kept exactly — the
 // map after the batch is bit-identical to integrating the scans one by one.
 //
-// One launch per batch, k_mbatch = [ update of batch b-1 | bin of batch b | crop pass of batch b+1 ]:
+// One launch per batch, k_mbatch = [ update of batch b-1 | bin of batch b | scouts (+ walker) of batch b+1 ]:
 //
-//   crop half    Scan k is binned against the map geometry AFTER the LOCAL-mode moves of scans 0..k, and whether
+//   scout rows   Scan k is binned against the map geometry AFTER the LOCAL-mode moves of scans 0..k, and whether
 //                scan j moved the map depends on whether any of its points survived the crops (fastdem.cpp:138) —
 //                device-side data.  The crops need no geometry, so the question is answered ONE LAUNCH AHEAD: a few
 //                scout blocks per scan of the next batch (first transform + cropRange + cropZ, the same float
@@ -20,6 +20,8 @@
 //                no launch ahead of it: its scouts run as a small launch of their own.  (Rounds 3: an in-launch protocol
 //                for that case — every block adds itself to its scan's counter, later scans' blocks poll a state word,
 //                bounded spin, a sticky fault when it ran out.  Gone: no block of this kernel ever waits for another.)
+//                One more block of these rows, the WALKER (mwalk_body), walks the next batch's chain of moves ahead of
+//                its launch, assuming every scan passes (on for the quantile estimator: option "batch_walk").
 //   bin half     512 points per block (two per thread), scan k of the batch; the first wavefront walks the chain of k
 //                moves (every lane rounds its own scan's pose once; only the position is accumulated in scan order;
 //                the reference's divide only for poses on a rounding tie) while the point loads are in flight.
@@ -36,7 +38,9 @@
 //                the threads: round trip 2 fetches {aux, zs, obs} of ALL events at once (a thread holds 2-3 of them
 //                whatever their distribution over the cells), the observations go back through LDS to the cell's
 //                lead thread, which walks its events in scan order: strips vacated since the previous event,
-//                estimator step in registers, one record store.
+//                estimator step in registers, one record store.  With raycast_enabled (template RAY) the walk also
+//                resolves every scan's raycasting stage behind that scan's observation — the images come from the
+//                launches of fdm_rbatch.hpp between the launch that binned the batch and this one.
 //
 // All per-batch parameters travel as kernel arguments (< 4 KB): no copy command, no upload kernel.
 // Algorithmic bytes are per scan what they were: 12 B/point (+4 intensity, +4 colour), 72 / 124 B per
