@@ -1078,4 +1078,28 @@ TEST(IntegrateBatch, SameMapAsScanByScanAndTheLastScansResult) {
   EXPECT_FALSE(b.integrateBatch({}));
 }
 
+TEST(IntegrateBatch, WithRaycastingTheStageOfEveryScanRidesInTheBatch) {
+  // the shipped YAML's switch (config/default.yaml:40-41): step 3 of integrateImpl behind every scan's map update —
+  // scan by scan on one mapper, as one batch on the other (voxel filter, ray walks and ghost resolution of the
+  // scans inside the batch launches), and through the queued mode on a third
+  Stream st;
+  ElevationMap m_one(12.0f, 9.0f, 0.1f, "map"), m_b(12.0f, 9.0f, 0.1f, "map"), m_q(12.0f, 9.0f, 0.1f, "map");
+  FastDEM a(m_one), b(m_b), q(m_q);
+  for (FastDEM* f : {&a, &b, &q})
+    f->setHeightFilter(-1.0f, 2.0f).setRangeFilter(0.0f, 30.0f).setSensorModel(SensorType::Constant).enableRaycasting();
+  q.setQueued(true);
+  Eigen::Isometry3d Tbs = Eigen::Isometry3d::Identity();
+  Tbs.translation() = Eigen::Vector3d(0.0, 0.0, 1.5);  // the sensor above the points: downward rays
+  bool last = false;
+  for (size_t k = 0; k < st.clouds.size(); ++k) last = a.integrate(st.clouds[k], Tbs, st.poses[k]);
+  std::vector<FastDEM::Scan> scans;
+  for (size_t k = 0; k < st.clouds.size(); ++k) scans.push_back(FastDEM::Scan{&st.clouds[k], Tbs, st.poses[k]});
+  EXPECT_EQ(b.integrateBatch(scans), last);
+  for (size_t k = 0; k < st.clouds.size(); ++k) q.integrate(st.clouds[k], Tbs, st.poses[k]);
+  q.drain();
+  EXPECT_TRUE(m_one.exists("raycasting"));
+  EXPECT_TRUE(sameMaps(m_one, m_b));
+  EXPECT_TRUE(sameMaps(m_one, m_q));
+}
+
 int main(int argc, char** argv) { return mini::run(argc > 1 ? argv[1] : nullptr); }
