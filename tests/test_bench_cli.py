@@ -1,6 +1,7 @@
 """bench.py's command line (no GPU): what a step is for each workload, and the defaults the driver relies on
 (`python bench.py` alone must pick N = 1 and a K / W that finish within minutes)."""
 import os
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -78,3 +79,15 @@ def test_world_size_must_match_gpus(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
     with pytest.raises(SystemExit, match="WORLD_SIZE=2"):
         bench.main()
+
+
+def test_watchdog_hands_a_stall_to_its_callback():
+    """tiling.Watchdog: a rank that makes no progress leaves — through `on_stall` when one is given (bench.py's riding
+    global-map leg prints the replicas' line there and leaves with code 0), else with code 3."""
+    code = ("import os, sys, time; sys.path.insert(0, %r); from fastdem_amd.tiling import Watchdog;"
+            "w = Watchdog(0.3, what='t', on_stall=(lambda m: (print('STALL', m), sys.stdout.flush(), os._exit(0))) if sys.argv[1] == 'cb' else None);"
+            "time.sleep(5); print('not reached')") % ROOT
+    r = subprocess.run([sys.executable, "-c", code, "cb"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "STALL" in r.stdout and "not reached" not in r.stdout, (r.returncode, r.stdout, r.stderr)
+    r = subprocess.run([sys.executable, "-c", code, "plain"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3 and "no progress" in r.stderr, (r.returncode, r.stdout, r.stderr)
