@@ -28,7 +28,6 @@
 #include "fdm_kernels.hpp"
 #include "fdm_tiled.hpp"
 #include "fdm_multi.hpp"
-#include "fdm_tbatch.hpp"
 #include "fdm_route.hpp"
 #include "fdm_raycast.hpp"
 #include "fdm_rbatch.hpp"
@@ -173,9 +172,6 @@ struct fdm_engine {
     bool multi = false;     // a whole batch (fdm_multi.hpp): MU / ch are what matters
     MUpd MU;
     int ch = 0;
-    bool tb = false;        // a tile batch (fdm_tbatch.hpp): TU / tb_hi / tb_hc are what matters
-    TBUpd TU;
-    bool tb_hi = false, tb_hc = false;
     bool tiled = false;     // large-scan pipeline (fdm_tiled.hpp) or the per-cell scratch one
     ScanParams P;
     Scratch S;              // scratch pipeline: the key / aux set of the scan's parity, captures
@@ -217,7 +213,7 @@ struct fdm_engine {
   MState* mstate = nullptr;          // [kMStates] ring, slot = batch number % kMStates
   unsigned mseq = 0;                 // batches enqueued so far
   int last_batch_n = 0;              // scans of the batch launch the last scan left in (0: it took the single-scan path)
-  uint64_t n_mbatch = 0, n_tbatch = 0;  // batch launches since creation (fdm_engine_debug_batch_launches)
+  uint64_t n_mbatch = 0;             // batch launches since creation (fdm_engine_debug_batch_launches)
   bool fault_watch = false;          // a launch that can raise DevState::fault was enqueued since it was last read (none can since round 4)
   int dbg_batch = 0;                 // measurement only (option "dbg_batch")
   int batch_crop = 1;                // option "batch_crop": evaluate the next batch's crops one launch ahead
@@ -242,27 +238,9 @@ struct fdm_engine {
   uint32_t* rb_img = nullptr;        // rc_cnt [kMaxBatch][ncell] | rc_min [kMaxBatch][ncell]
   size_t rb_stride = 0;
   unsigned rb_seq = 0;               // stamp of the last batch's ray launches (RState::any)
-  // ---- tile batches (fdm_tbatch.hpp): up to tbatch_max LARGE scans per launch on the record pools ----
-  int tbatch = 0;                    // option "tbatch": fdm_engine_integrate_device_batch groups eligible large scans into tile
-                                     // batches.  OFF by default: measured at configs[3] it does not beat one fused launch per
-                                     // scan (35.6-42 us per scan at 8 / 4 scans per launch against 33.7-34.4: DESIGN.md §0 #1 / §3a)
-  int tbatch_max = 8;                // option "tbatch_max": scans per launch (2 .. kTBMax)
-  unsigned tbatch_min = 65536;       // option "tbatch_min": scans from this many points up
-  int tb_groups = 512;               // option "tb_groups": update groups of a launch (each pulls tiles off a queue)
-  TileRec* tb_rec[2] = {nullptr, nullptr};              // [tb_slots][tb_rec_stride] per batch parity
-  unsigned long long* tb_desc[2] = {nullptr, nullptr};  // [tb_slots][n_tiles][tb_stride]
-  unsigned long long* tb_bin_part[2] = {nullptr, nullptr};
-  size_t tb_rec_stride = 0;          // records per scan slot
-  unsigned tb_stride = 0;            // words per descriptor row
-  int tb_slots = 0;                  // scan slots the pools hold
-  size_t tb_bin_cap = 0;             // bin blocks per batch the statistics arrays hold
   float* d_bstage = nullptr;         // fdm_engine_integrate_host_batch: pageable clouds of a call, staged back to back
   size_t bstage_cap = 0;             // floats
   bool bstage_busy = false;          // launches of the previous call may still be reading it
-  bool tpre_valid = false;           // the last tile-batch launch carried the scouts of the batch (tpre_scans, tpre_count) = number tpre_seq
-  const fdm_device_scan* tpre_scans = nullptr;
-  uint32_t tpre_count = 0;
-  unsigned tpre_seq = 0;
   // scan routing (fdm_route.hpp)
   uint8_t* d_route_owner = nullptr;  // [route_cap] owner rank of every point of the slice
   uint32_t* d_route_cnt = nullptr;   // [route_blocks_cap][world + 2] block counts -> offsets | [kMaxRanks] bases at the end
@@ -312,7 +290,7 @@ int sync_all(fdm_engine* e) {
   return FDM_OK;
 }
 // DevState::fault after the stream has drained: a batch launch whose in-kernel wait for the scans ahead ran out of
-// polls (fdm_multi.hpp / fdm_tbatch.hpp).  Sticky on the device until it has been reported ONCE — the maps of that
+// polls (fdm_multi.hpp).  Sticky on the device until it has been reported ONCE — the maps of that
 // batch are undefined, reset() and go on.  Only looked at when such a launch was enqueued since the last look.
 int report_fault(fdm_engine* e) {
   if (!e->fault_watch) return FDM_OK;
@@ -739,7 +717,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   const bool fusable = tiled || ((!use_bin4 || (e->rec_kind >= 0 && e->S.dense)) && e->wave_merge);
   // (the fused tiled launch compiles the channels in once, for both halves)
   const bool same_channels = !tiled || (e->pend.P.has_intensity == P.has_intensity && e->pend.P.has_color == P.has_color);
-  const bool fuse_now = e->chain && plain && fusable && !e->pend.multi && !e->pend.tb && e->pend.tiled == tiled && same_channels;
+  const bool fuse_now = e->chain && plain && fusable && !e->pend.multi && e->pend.tiled == tiled && same_channels;
   if (e->chain && !fuse_now && (rc = join_streams(e))) return rc;
   P.chain_prev = 0;
   if (e->profile) HIPCK(hipEventRecord(e->ev[0], e->stream));
@@ -786,7 +764,6 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   // this scan's update: held back (the next scan's launch or a flush carries it) or launched now
   fdm_engine::PendingUpdate& u = e->pend;
   u.multi = false;
-  u.tb = false;
   u.tiled = tiled;
   u.P = P;
   u.S = e->S;
@@ -880,7 +857,6 @@ void fill_update_params(fdm_engine* e, ScanParams& P, double rx, double ry, bool
 }
 
 #include "fdm_engine_multi.inl"  // the batch pipeline's host side: eligibility, buffers, enqueue_multi
-#include "fdm_engine_tbatch.inl" // the tile-batch pipeline's host side (large scans): eligibility, pools, enqueue_tbatch
 
 // Staging for host-array entry points: kStageSlots rotating blocks of 6 channels.  A block is reused
 // three scans later, when the update that gathers from it (held back by at most one scan) has long
@@ -1268,11 +1244,6 @@ void fdm_engine_destroy(fdm_engine* e) {
   if (e->rb_rec) (void)hipFree(e->rb_rec);
   if (e->rb_counters) (void)hipFree(e->rb_counters);
   if (e->rb_img) (void)hipFree(e->rb_img);
-  for (int k = 0; k < 2; ++k) {
-    if (e->tb_rec[k]) (void)hipFree(e->tb_rec[k]);
-    if (e->tb_desc[k]) (void)hipFree(e->tb_desc[k]);
-    if (e->tb_bin_part[k]) (void)hipFree(e->tb_bin_part[k]);
-  }
   if (e->d_bstage) (void)hipFree(e->d_bstage);
   if (e->d_route_owner) (void)hipFree(e->d_route_owner);
   if (e->d_route_cnt) (void)hipFree(e->d_route_cnt);
@@ -1368,15 +1339,6 @@ int fdm_engine_integrate_device(fdm_engine* e, uint64_t n, const float* dx, cons
 int fdm_engine_integrate_device_batch(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) {
   if (!e || (count && !scans)) return fail(FDM_ERR_INVALID, "null argument");
   for (uint32_t k = 0; k < count; ++k) {
-    // runs of LARGE plain scans leave as tile batches (fdm_tbatch.hpp): one launch per tbatch_max scans
-    if (const uint32_t run = tbatch_run(e, count - k, scans + k)) {
-      HIPCK(hipSetDevice(e->device));
-      // (look-ahead: the batch after this one, whose scouts ride in this launch)
-      const uint32_t next = k + run < count ? tbatch_run(e, count - k - run, scans + k + run) : 0u;
-      if (int rc = enqueue_tbatch(e, run, scans + k, next)) return rc;
-      k += run - 1u;
-      continue;
-    }
     // runs of small plain scans leave as batches: one bin launch + one update launch per kMaxBatch scans
     if (const uint32_t run = multi_run(e, count - k, scans + k)) {
       HIPCK(hipSetDevice(e->device));
@@ -1838,7 +1800,7 @@ int fdm_engine_debug_batch_dirty(fdm_engine* e, uint64_t out[3]) {
 int fdm_engine_debug_batch_launches(fdm_engine* e, uint64_t out[2]) {
   if (!e || !out) return fail(FDM_ERR_INVALID, "null argument");
   out[0] = e->n_mbatch;
-  out[1] = e->n_tbatch;
+  out[1] = 0;  // (tile batches: removed in round 5, the slot stays for the callers of the array)
   return FDM_OK;
 }
 

@@ -84,8 +84,7 @@ unsigned tile_span(const fdm_engine* e) {
 }
 
 // The record pools of the tiled pipeline: `records` per pool, `blocks` chunk slots per tile.
-// What the tile groups keep between scans (stamps, statistics, rare-path scratch): shared by the one-scan launches and
-// the tile batches.
+// What the tile groups keep between scans (stamps, statistics, rare-path scratch).
 int ensure_tile_aux(fdm_engine* e) {
   if (!e->tile_stamp32) {
     e->TG.tiles_r = (e->G.s_rows + kTS - 1) / kTS;
@@ -160,9 +159,7 @@ int launch_tbin(fdm_engine* e, const ScanParams& P, const ScanInputs& in, const 
 
 // The held-back (or just enqueued) update on its own.
 int launch_multi_update(fdm_engine* e, const fdm_engine::PendingUpdate& u);  // a whole batch (fdm_engine_multi.inl)
-int launch_tbatch_update(fdm_engine* e, const fdm_engine::PendingUpdate& u); // a tile batch (fdm_engine_tbatch.inl)
 int launch_update_alone(fdm_engine* e, const fdm_engine::PendingUpdate& u) {
-  if (u.tb) return launch_tbatch_update(e, u);
   if (u.multi) return launch_multi_update(e, u);
   return with_policy(e, [&](auto tag, const auto& layers) -> int {
     using POLICY = decltype(tag);

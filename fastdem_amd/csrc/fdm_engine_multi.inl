@@ -54,9 +54,7 @@ uint32_t multi_run(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) 
   return run >= 2u ? run : 0u;
 }
 
-// The ring of batch states, shared by the small-scan batches (k_mbatch) and the tile batches (k_tbatch): both number
-// their batches with e->mseq and re-arm the state of the batch after next the same way.
-int drop_scouted(fdm_engine* e);  // (fdm_engine_tbatch.inl)
+// The ring of batch states: batches are numbered with e->mseq, a launch re-arms the state of the batch after next.
 int ensure_mstate(fdm_engine* e) {
   if (e->mstate) return FDM_OK;
   HIPCK(hipMalloc(reinterpret_cast<void**>(&e->mstate), kMStates * sizeof(MState)));
@@ -330,7 +328,6 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
   K.dbg = e->dbg_batch;
   K.walk = e->batch_walk < 0 ? (e->cfg.estimation_type == 1 ? 1 : 0) : e->batch_walk;
 
-  if ((rc = drop_scouted(e))) return rc;  // (a tile batch scouted scans that now leave as a small-scan batch)
   const unsigned seq = e->mseq++;
   const int slot = int(seq % unsigned(kMStates)), par = int(seq & 1u);
   // the crop pass that ran one launch ahead left this batch's pass bits in its state word — if it was for THIS batch
@@ -443,7 +440,6 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
     N.ray.clear_thr = c.clear_threshold; N.ray.conflict_thr = c.height_conflict_threshold;
   }
   e->pend.multi = true;
-  e->pend.tb = false;
   e->pend.ch = ch;
   e->pend.tiled = false;
   e->chain = true;

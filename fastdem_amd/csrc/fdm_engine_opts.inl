@@ -210,25 +210,6 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
     e->batch_max = value;
     return FDM_OK;
   }
-  if (std::strcmp(key, "tbatch") == 0) {  // fdm_engine_integrate_device_batch: group LARGE scans into tile-batch launches
-    e->tbatch = value != 0;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "tbatch_max") == 0) {
-    if (value < 2 || value > kTBMax) return fail(FDM_ERR_INVALID, "tbatch_max: 2 .. 8 scans per launch");
-    e->tbatch_max = value;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "tbatch_min") == 0) {
-    if (value < 1) return fail(FDM_ERR_INVALID, "tbatch_min: a point count");
-    e->tbatch_min = unsigned(value);
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "tb_groups") == 0) {
-    if (value < 1 || value > 65535) return fail(FDM_ERR_INVALID, "tb_groups: 1 .. 65535 update groups");
-    e->tb_groups = value;
-    return FDM_OK;
-  }
   if (std::strcmp(key, "zero_copy") == 0) {
     if (value < 0) return fail(FDM_ERR_INVALID, "zero_copy: a point count (0 = off)");
     e->zero_copy = value;

@@ -63,13 +63,9 @@ constexpr int kMStates = 4;              // ring of batch states: update b-1 | b
 struct MState {
   DevGeom E[kMaxBatch];        // geometry before scan k (written by the scan's first bin block)
   DevCand C[kMaxBatch];        // geometry after its move + the index shift
-  unsigned done[kMaxBatch * kLineWords];  // tile batches (fdm_tbatch.hpp): [k * 32 + 1] = scan k has a surviving point (each on its own line)
   unsigned flags[kLineWords];  // [0]: bit 16 + k = scan k has a surviving point (scouts); [1]: bit 31 = PE / PC below are valid, bits 0..15 = the pass bits they assume
   unsigned inside[kMaxBatch];  // some point of scan k landed in the map (elevation_mapping.cpp:118)
-  unsigned err;                // (unused since round 4: nothing waits inside a launch)
-  unsigned tq;                 // tile batches (fdm_tbatch.hpp): the update groups' tile queue ...
-  unsigned gdone;              // ... and how many of them have left (the last one commits the geometry ring)
-  unsigned pad[13];
+  unsigned pad[16];
   DevGeom PE[kMaxBatch];       // the chain of moves walked ONE LAUNCH AHEAD by the walker block (mwalk_body): geometry before
   DevCand PC[kMaxBatch];       // scan k / after its move, assuming the pass bits in flags[1]
 };
@@ -865,10 +861,8 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
       st->vis_ray = 3u * (U.scan_no0 + unsigned(__ffs(int(runmask))) - 1u) + 3u;
   }
   if (bid == 0 && lt >= 64u && lt < 64u + unsigned(kMaxBatch)) {  // re-arm the state of the batch after next
-    U.rearm->done[(lt - 64u) * kLineWords] = 0u;
-    U.rearm->done[(lt - 64u) * kLineWords + 1u] = 0u;  // (the tile batches' flag word on the same line, fdm_tbatch.hpp)
     U.rearm->inside[lt - 64u] = 0u;
-    if (lt == 64u) { U.rearm->flags[0] = 0u; U.rearm->flags[1] = 0u; U.rearm->err = 0u; U.rearm->tq = 0u; U.rearm->gdone = 0u; }
+    if (lt == 64u) { U.rearm->flags[0] = 0u; U.rearm->flags[1] = 0u; }
   }
 
   unsigned nib = 0u;

@@ -222,7 +222,7 @@ __device__ __forceinline__ void tbin_points(const PT& P, const GeomConst& G, con
 }
 
 // Where a bin block gets the post-move geometry from and where its scan-wide flags go.  One scan per launch: the
-// DevState ring (candidate_begin / candidate_finish).  A batch of scans per launch: fdm_tbatch.hpp's chain.
+// DevState ring (candidate_begin / candidate_finish).
 struct TbinRing {
   const ScanParams& P;
   DevState* st;

@@ -20,14 +20,14 @@ int fdm_engine_integrate_device_batch_timed(fdm_engine* e, uint32_t count, const
  * their clean state (keys, aux words, zero-sign words) — 0 0 0 in a healthy engine. */
 int fdm_engine_debug_batch_dirty(fdm_engine* e, uint64_t out[3]);
 
-/* Engine option "dbg_timeline" = 1: start / end time of every block of the last fused large-scan launch (one scan
- * per launch or a tile batch), in ticks of the 100 MHz constant clock — ticks[2*b], ticks[2*b + 1] for block b;
+/* Engine option "dbg_timeline" = 1: start / end time of every block of the last fused large-scan launch (update of
+ * scan t | bin of scan t + 1), in ticks of the 100 MHz constant clock — ticks[2*b], ticks[2*b + 1] for block b;
  * blocks [0, *n_update_blocks) are tile-update groups, the rest bin blocks.  Waits for the stream. */
 int fdm_engine_debug_timeline(fdm_engine* e, uint64_t* ticks, uint64_t cap_blocks, uint32_t* n_blocks,
                               uint32_t* n_update_blocks);
 
 /* How many batch launches the engine has enqueued since it was created: out[0] small-scan batches (k_mbatch,
- * fdm_multi.hpp), out[1] tile batches (k_tbatch, fdm_tbatch.hpp).  Tests assert with it that a call really took the
+ * fdm_multi.hpp), out[1] always 0 (the tile batches of round 4 are gone).  Tests assert with it that a call really took the
  * pipeline they mean to check. */
 int fdm_engine_debug_batch_launches(fdm_engine* e, uint64_t out[2]);
 

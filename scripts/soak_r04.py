@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Round-4 soak (profile `tbatch`: tile batches on vs off; every profile: now and then the call goes in through
+"""Round-4 soak (every profile: now and then the call goes in through
 fdm_engine_integrate_host_batch on pageable host arrays on side A).  Otherwise the round-3 soak: the new paths against the old ones, engine against engine, bit for bit, for a few minutes.
   A: defaults — batch launches (fdm_multi.hpp), the sort-free voxel filter (k_vs_*), the own radix sort
   B: batch 0, voxel_small 0 — one launch per scan, every voxel filter through the radix sort
@@ -22,12 +22,11 @@ profile = sys.argv[4] if len(sys.argv) > 4 else "small"
 # small: 16 m map, Kalman, LOCAL       A = defaults, B = batch 0 + voxel_small 0
 # tiled: 60 m map (351 tiles), scans up to 300 K points     A = defaults (record-pool pipeline), B = tiled 0
 # p2   : 12 m GLOBAL map, P2 quantile estimator, colour + intensity     A = defaults, B = batch 0 + voxel_small 0
-# tbatch: 60 m map, scans up to 300 K points    A = tile batches on (tbatch 1, tbatch_min 1000), B = defaults (one launch per scan)
 # ray   : 16 m map, raycasting on in every call      A = the stage inside the batches (fdm_rbatch.hpp), B = batch_ray 0 (one scan per launch)
 # rayp2 : the same with the P2 estimator + colour
 # walk  : 16 m LOCAL map, Kalman     A = the walker block walks every batch's chain of moves one launch ahead (batch_walk 1), B = batch_walk 0
-SIZE = {"small": 16.0, "tiled": 60.0, "p2": 12.0, "tbatch": 60.0, "ray": 16.0, "rayp2": 12.0, "walk": 16.0}[profile]
-BIG = {"small": 70000, "tiled": 300000, "p2": 40000, "tbatch": 300000, "ray": 70000, "rayp2": 40000, "walk": 30000}[profile]
+SIZE = {"small": 16.0, "tiled": 60.0, "p2": 12.0, "ray": 16.0, "rayp2": 12.0, "walk": 16.0}[profile]
+BIG = {"small": 70000, "tiled": 300000, "p2": 40000, "ray": 70000, "rayp2": 40000, "walk": 30000}[profile]
 rng = np.random.default_rng(2026)
 
 
@@ -82,9 +81,6 @@ A = Engine(SIZE, SIZE, 0.1, make(0))
 B = Engine(SIZE, SIZE, 0.1, make(0))
 if profile == "tiled":
     B.set_option("tiled", 0)
-elif profile == "tbatch":
-    A.set_option("tbatch", 1)
-    A.set_option("tbatch_min", 1000)
 elif profile in ("ray", "rayp2"):
     B.set_option("batch_ray", 0)
 elif profile == "walk":
@@ -167,8 +163,6 @@ while time.perf_counter() - t0 < budget:
         A.integrate_host_batch(harr)
         assert B.integrate_device_batch(arr) == 0
     else:
-        if profile == "tbatch" and calls % 7 == 0:
-            A.set_option("tbatch_max", int(rng.integers(2, 9)))
         assert A.integrate_device_batch(arr) == 0
         assert B.integrate_device_batch(arr) == 0
     calls += 1

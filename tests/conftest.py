@@ -33,8 +33,6 @@ def gpu(request):
     import fastdem_amd
     fastdem_amd.capi.load()
     saved = dict(fastdem_amd.Engine.default_options)
-    # (tbatch_min 1: in that variant fdm_engine_integrate_device_batch also groups its scans into TILE batches,
-    # fdm_tbatch.hpp — every batch test then checks that pipeline against the oracle as well)
-    fastdem_amd.Engine.default_options = {"tiled_min": 1, "tbatch": 1, "tbatch_min": 1, "tbatch_max": 4} if request.param == "tiled_all" else {}
+    fastdem_amd.Engine.default_options = {"tiled_min": 1} if request.param == "tiled_all" else {}
     yield fastdem_amd
     fastdem_amd.Engine.default_options = saved

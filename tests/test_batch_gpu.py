@@ -77,14 +77,17 @@ def oracle_scan_by_scan(ref, scans, Tbs, poses):
 
 def check_batch(gpu, R, eng, ref, scans, Tbs, poses, exact=True, expect_batches=True):
     """One fdm_engine_integrate_device_batch call against the oracle run scan by scan.  `pair()` switches the per-point
-    cell ids on, and an engine that owes its caller cell ids takes NO batch launch (fdm_engine_multi.inl / _tbatch.inl:
+    cell ids on, and an engine that owes its caller cell ids takes NO batch launch (fdm_engine_multi.inl:
     the batch bin halves do not write them) — so they are switched off here, and the call must have left in batch
     launches (round 3's version of this helper never did: its scans all took the one-scan path)."""
     eng.enable_cell_ids(False)
     before = sum(eng.batch_launches())
     b = DeviceBatch(gpu, scans, Tbs, poses)
     assert eng.integrate_device_batch(b.arr) == 0
-    if expect_batches and len(scans) >= 3:  # (the first scan of a fresh engine goes alone: it creates the layers)
+    # (the first scan of a fresh engine goes alone: it creates the layers.  In the `tiled_all` fixture variant every scan is
+    # forced through the record pools, which take one fused launch per scan: the call is then checked against the oracle
+    # as a sequence of those)
+    if expect_batches and len(scans) >= 3 and "tiled_min" not in gpu.Engine.default_options:
         assert sum(eng.batch_launches()) > before, "the call took no batch launch"
     rc_r, st_r = oracle_scan_by_scan(ref, scans, Tbs, poses)
     rc_e, st_e = eng.last_stats()
@@ -374,7 +377,8 @@ def test_first_batch_of_every_call_and_short_calls(gpu, R):
             poses.append(T(0.23 * k, -0.17 * k, 0.0, yaw=0.02 * k))
             k += 1
         check_batch(gpu, R, eng, ref, scans, T(z=0.4), poses, expect_batches=False)
-    assert sum(eng.batch_launches()) >= 14
+    if "tiled_min" not in gpu.Engine.default_options:
+        assert sum(eng.batch_launches()) >= 14
 
 
 def test_host_batch_entry_pinned_in_place_and_pageable(gpu, R):
@@ -416,7 +420,8 @@ def test_host_batch_entry_pinned_in_place_and_pageable(gpu, R):
             s = wl.scan(k % 5)
             rc_r, st_r = ref.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k), intensity=s["intensity"])
         assert (rc_e, st_e) == (rc_r, st_r)
-        assert sum(eng.batch_launches()) > before
+        if "tiled_min" not in gpu.Engine.default_options:
+            assert sum(eng.batch_launches()) > before
         assert_layers_bit_identical(eng, ref)
         assert same_geometry(eng.geometry(), ref.geometry())
         k0 += n
