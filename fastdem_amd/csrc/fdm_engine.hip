@@ -186,6 +186,7 @@ struct fdm_engine {
   unsigned tiled_min = 2048;        // ... from this many points up (on a map of >= 512 tiles the pipeline wins at every
                                     // size measured: 2 K points 13.1 vs 14.6 us, 32 K 16.6 vs 20.5, 262 K 18.9 vs 34.3)
   bool tiled_forced = false;        // tiled_min was set by hand (option "tiled_min"): no map-size condition
+  int tbin_ver = 2;                 // option "tbin_ver": edition of the bin half (fdm_tbin2.hpp; 1 = the first edition, A/B only)
   TileGrid TG{};
   TilePool pool[2] = {};            // by scan parity
   size_t pool_cap = 0;              // records per pool

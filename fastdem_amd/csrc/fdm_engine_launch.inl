@@ -145,12 +145,13 @@ int launch_tbin(fdm_engine* e, const ScanParams& P, const ScanInputs& in, const 
     hipLaunchKernelGGL(kern, dim3(bin_blocks), dim3(bv.threads), lds, e->stream, P, e->G, e->TG, e->d_state, in, e->S,
                        Q, ids);
   };
-#define FDM_TBIN(LN)                                               \
-  if (bv.has_int && bv.has_col) go(k_tbin<true, true, 256, LN>);    \
-  else if (bv.has_int) go(k_tbin<true, false, 256, LN>);            \
-  else if (bv.has_col) go(k_tbin<false, true, 256, LN>);            \
-  else go(k_tbin<false, false, 256, LN>);
-  if (bv.lean == 1) { FDM_TBIN(true) } else { FDM_TBIN(false) }
+#define FDM_TBIN(LN, V)                                               \
+  if (bv.has_int && bv.has_col) go(k_tbin<true, true, 256, LN, V>);    \
+  else if (bv.has_int) go(k_tbin<true, false, 256, LN, V>);            \
+  else if (bv.has_col) go(k_tbin<false, true, 256, LN, V>);            \
+  else go(k_tbin<false, false, 256, LN, V>);
+  if (e->tbin_ver == 2) { if (bv.lean == 1) { FDM_TBIN(true, 2) } else { FDM_TBIN(false, 2) } }
+  else { if (bv.lean == 1) { FDM_TBIN(true, 1) } else { FDM_TBIN(false, 1) } }
 #undef FDM_TBIN
   if (rc) return rc;
   HIPCK(hipGetLastError());
@@ -220,12 +221,13 @@ int launch_update_fused(fdm_engine* e, const fdm_engine::PendingUpdate& u, const
                              e->d_state, layers, e->d_layer_ptrs, e->n_layer_ptrs, u.Q, A, span, ub, Pb, Ib, Sb, Qb,
                              ids_b);
         };
-#define FDM_TF(LN)                                                                  \
-        if (bv.has_int && bv.has_col) go(k_tupdate_tbin<POLICY, true, true, 256, LN>);   \
-        else if (bv.has_int) go(k_tupdate_tbin<POLICY, true, false, 256, LN>);           \
-        else if (bv.has_col) go(k_tupdate_tbin<POLICY, false, true, 256, LN>);           \
-        else go(k_tupdate_tbin<POLICY, false, false, 256, LN>);
-        if (bv.lean == 1) { FDM_TF(true) } else { FDM_TF(false) }
+#define FDM_TF(LN, V)                                                                  \
+        if (bv.has_int && bv.has_col) go(k_tupdate_tbin<POLICY, true, true, 256, LN, V>);   \
+        else if (bv.has_int) go(k_tupdate_tbin<POLICY, true, false, 256, LN, V>);           \
+        else if (bv.has_col) go(k_tupdate_tbin<POLICY, false, true, 256, LN, V>);           \
+        else go(k_tupdate_tbin<POLICY, false, false, 256, LN, V>);
+        if (e->tbin_ver == 2) { if (bv.lean == 1) { FDM_TF(true, 2) } else { FDM_TF(false, 2) } }
+        else { if (bv.lean == 1) { FDM_TF(true, 1) } else { FDM_TF(false, 1) } }
 #undef FDM_TF
         if (rc) return rc;
       } else {

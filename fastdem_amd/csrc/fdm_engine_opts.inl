@@ -210,6 +210,12 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
     e->batch_max = value;
     return FDM_OK;
   }
+  if (std::strcmp(key, "tbin_ver") == 0) {  // measurement only: edition of the large-scan bin half
+    if (value != 1 && value != 2) return fail(FDM_ERR_INVALID, "tbin_ver: 1 or 2");
+    if (int rc_sync = sync_all(e)) return rc_sync;
+    e->tbin_ver = value;
+    return FDM_OK;
+  }
   if (std::strcmp(key, "zero_copy") == 0) {
     if (value < 0) return fail(FDM_ERR_INVALID, "zero_copy: a point count (0 = off)");
     e->zero_copy = value;

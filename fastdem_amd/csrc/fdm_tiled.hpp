@@ -590,14 +590,21 @@ __device__ __forceinline__ void tbin_body(const PT& P, const GeomConst& G, const
   }
 }
 
-template <bool HAS_INT, bool HAS_COL, int THREADS, bool LEAN>
+}  // namespace fdm
+#include "fdm_tbin2.hpp"  // tbin2_body: the second edition of the bin half (VER = 2 below)
+namespace fdm {
+
+template <bool HAS_INT, bool HAS_COL, int THREADS, bool LEAN, int VER = 2>
 __global__ __launch_bounds__(THREADS) void k_tbin(const ScanParams P, const GeomConst G, const TileGrid TG,
                                                   DevState* __restrict__ st, const ScanInputs I,
                                                   const Scratch S, const TilePool Q,
                                                   int32_t* __restrict__ cell_ids) {
   extern __shared__ __align__(16) unsigned char dyn_lds[];
   TbinRing H(P, st);
-  tbin_body<HAS_INT, HAS_COL, THREADS, LEAN>(P, G, TG, H, I, S, S.bin_part, Q, cell_ids, dyn_lds, blockIdx.x);
+  if constexpr (VER == 2)
+    tbin2_body<HAS_INT, HAS_COL, LEAN>(P, G, TG, H, I, S, S.bin_part, Q, cell_ids, dyn_lds, blockIdx.x);
+  else
+    tbin_body<HAS_INT, HAS_COL, THREADS, LEAN>(P, G, TG, H, I, S, S.bin_part, Q, cell_ids, dyn_lds, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1027,7 +1034,7 @@ __global__ __launch_bounds__(256, FDM_UPD_WAVES) void k_tupdate(
 }
 
 // update of scan t + bin of scan t+1 in one launch (the pools are double-buffered by scan parity)
-template <typename POLICY, bool HAS_INT, bool HAS_COL, int THREADS, bool LEAN>
+template <typename POLICY, bool HAS_INT, bool HAS_COL, int THREADS, bool LEAN, int VER = 2>
 __global__ __launch_bounds__(THREADS, FDM_UPD_WAVES) void k_tupdate_tbin(
     const ScanParams Pu, const GeomConst G, const TileGrid TG, DevState* __restrict__ st,
     const typename POLICY::Layers L, float* const* __restrict__ all_layers, int n_layers,
@@ -1049,7 +1056,10 @@ __global__ __launch_bounds__(THREADS, FDM_UPD_WAVES) void k_tupdate_tbin(
     tupdate_body<POLICY, THREADS, HAS_INT, HAS_COL>(Pu, G, TG, st, L, all_layers, n_layers, Qu, A, span, dyn_lds, u0);
   else {
     TbinRing H(Pb, st);
-    tbin_body<HAS_INT, HAS_COL, THREADS, LEAN>(Pb, G, TG, H, Ib, Sb, Sb.bin_part, Qb, cell_ids, dyn_lds, blockIdx.x - u0);
+    if constexpr (VER == 2)
+      tbin2_body<HAS_INT, HAS_COL, LEAN>(Pb, G, TG, H, Ib, Sb, Sb.bin_part, Qb, cell_ids, dyn_lds, blockIdx.x - u0);
+    else
+      tbin_body<HAS_INT, HAS_COL, THREADS, LEAN>(Pb, G, TG, H, Ib, Sb, Sb.bin_part, Qb, cell_ids, dyn_lds, blockIdx.x - u0);
   }
   if (A.timeline && threadIdx.x == 0) {  // (thread 0's view of the block; bench A/B tool, see scripts/timeline.py)
     A.timeline[2u * blockIdx.x] = t0;
