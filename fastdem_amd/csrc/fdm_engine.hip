@@ -186,14 +186,19 @@ struct fdm_engine {
   unsigned tiled_min = 2048;        // ... from this many points up (on a map of >= 512 tiles the pipeline wins at every
                                     // size measured: 2 K points 13.1 vs 14.6 us, 32 K 16.6 vs 20.5, 262 K 18.9 vs 34.3)
   bool tiled_forced = false;        // tiled_min was set by hand (option "tiled_min"): no map-size condition
-  int tbin_ver = 2;                 // option "tbin_ver": edition of the bin half (fdm_tbin2.hpp; 1 = the first edition, A/B only)
+  int upd_blocks = 512;             // option "upd_blocks": update blocks (four tile wavefronts each) of a FUSED launch
+  int upd_blocks_alone = 2048;      // option "upd_blocks_alone": ... of an update launch of its own
+  int upd_prio = 1;                 // option "upd_prio": update wavefronts run at raised issue priority
+  int cnt_shift = 5;                // option "cnt_shift": one tile counter per 2^cnt_shift words (TilePool::cnt_shift); takes effect before the pools exist
+  int bin_stagger = 0;              // option "bin_stagger": start stagger of the fused launch's first-round bin blocks (TileWork::stagger)
+  size_t tile_rare_waves = 0;       // update wavefronts the rare-path scratch is sized for
   TileGrid TG{};
   TilePool pool[2] = {};            // by scan parity
   size_t pool_cap = 0;              // records per pool
   unsigned desc_stride = 0;
   uint32_t* tile_stamp32 = nullptr;
   uint32_t* upd_part32 = nullptr;
-  uint32_t* tile_rare = nullptr;    // k_tupdate's rare-path scratch, 12 KB per update group
+  uint32_t* tile_rare = nullptr;    // the update's rare-path scratch, 3 KB per update wavefront
   unsigned last_upd_tiles = 0;      // length of the per-tile statistics of the last scan
   uint32_t* last_upd_part = nullptr;
   int last_kind = -1;               // pipeline of the last scan (0 scratch, 1 tiled)
@@ -253,7 +258,6 @@ struct fdm_engine {
   size_t post_pool_bytes = 0;
   FeatEntry* d_feat_tab = nullptr;   // kMaxRegion entries: the region as k_features_tiled reads it
   int dbg_post = 0;                  // measurement only: 1 = untiled feature kernel
-  int dbg_span = 0;                  // measurement only: tiles per update group (0 = automatic)
   unsigned long long* d_timeline = nullptr;  // measurement only: {start, end} ticks per block of the last fused launch
   unsigned timeline_cap = 0;         // blocks the buffer holds
   unsigned timeline_blocks = 0, timeline_upd = 0;  // grid of the last fused launch, its update blocks
@@ -1226,7 +1230,9 @@ void fdm_engine_destroy(fdm_engine* e) {
   for (auto* z : e->zs2) if (z) (void)hipFree(z);
 
   for (auto& q : e->pool) {
-    if (q.rec) (void)hipFree(q.rec);
+    if (q.hot) (void)hipFree(q.hot);
+    if (q.cold) (void)hipFree(q.cold);
+    if (q.cnt) (void)hipFree(q.cnt);
     if (q.desc) (void)hipFree(q.desc);
   }
   for (int k = 0; k < 2; ++k) {

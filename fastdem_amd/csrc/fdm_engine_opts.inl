@@ -210,10 +210,25 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
     e->batch_max = value;
     return FDM_OK;
   }
-  if (std::strcmp(key, "tbin_ver") == 0) {  // measurement only: edition of the large-scan bin half
-    if (value != 1 && value != 2) return fail(FDM_ERR_INVALID, "tbin_ver: 1 or 2");
+  if (std::strcmp(key, "bin_stagger") == 0) {
+    if (value < 0 || value > 64) return fail(FDM_ERR_INVALID, "bin_stagger: 0 .. 64");
+    e->bin_stagger = value;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "cnt_shift") == 0) {
+    if (value < 0 || value > 5) return fail(FDM_ERR_INVALID, "cnt_shift: 0 .. 5");
+    if (e->pool[0].cnt) return fail(FDM_ERR_INVALID, "cnt_shift: the record pools exist already");
+    e->cnt_shift = value;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "upd_prio") == 0) {
+    e->upd_prio = value != 0;
+    return FDM_OK;
+  }
+  if (std::strcmp(key, "upd_blocks") == 0 || std::strcmp(key, "upd_blocks_alone") == 0) {  // update blocks of a large-scan launch
+    if (value < 1 || value > 65535) return fail(FDM_ERR_INVALID, "upd_blocks: 1 .. 65535");
     if (int rc_sync = sync_all(e)) return rc_sync;
-    e->tbin_ver = value;
+    if (key[10] == '_') e->upd_blocks_alone = value; else e->upd_blocks = value;
     return FDM_OK;
   }
   if (std::strcmp(key, "zero_copy") == 0) {
@@ -234,17 +249,6 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
   }
   if (std::strcmp(key, "sync_spin_us") == 0) {
     e->sync_spin_us = value < 0 ? 0 : value;
-    return FDM_OK;
-  }
-  if (std::strcmp(key, "dbg_span") == 0) {  // measurement only: tiles per update group, 0 = automatic
-    if (value < 0 || value > 64) return fail(FDM_ERR_INVALID, "dbg_span: 0 (automatic) or 1..64 tiles per group");
-    if (int rc_sync = sync_all(e)) return rc_sync;
-    e->dbg_span = value;
-    if (e->tile_rare) {  // sized per update group: the group count follows the span
-      HIPCK(hipFree(e->tile_rare));
-      e->tile_rare = nullptr;
-      for (auto& q : e->pool) q.rare = nullptr;
-    }
     return FDM_OK;
   }
   if (std::strcmp(key, "dbg_post") == 0) {

@@ -5,10 +5,9 @@ mkdir -p build/prof && cd build/prof
 cat > one.hip <<'EOS'
 #include "../../fastdem_amd/csrc/fdm_tiled.hpp"
 using namespace fdm;
-template __global__ void fdm::k_tbin<true,false,256,true,2>(const ScanParams, const GeomConst, const TileGrid, DevState*, const ScanInputs, const Scratch, const TilePool, int32_t*);
-template __global__ void fdm::k_tbin<true,false,256,true,1>(const ScanParams, const GeomConst, const TileGrid, DevState*, const ScanInputs, const Scratch, const TilePool, int32_t*);
-template __global__ void fdm::k_tupdate<KalmanRecPolicy, true, false>(const ScanParams, const GeomConst, const TileGrid, DevState*, const KalmanRecLayers, float* const*, int, const TilePool, const TileAux, unsigned);
-template __global__ void fdm::k_tupdate_tbin<KalmanRecPolicy, true, false, 256, true, 2>(const ScanParams, const GeomConst, const TileGrid, DevState*, const KalmanRecLayers, float* const*, int, const TilePool, const TileAux, unsigned, unsigned, const ScanParams, const ScanInputs, const Scratch, const TilePool, int32_t*);
+template __global__ void fdm::k_tbin<true,false,256,true>(const ScanParams, const GeomConst, const TileGrid, DevState*, const ScanInputs, const Scratch, const TilePool, int32_t*);
+template __global__ void fdm::k_tupdate<KalmanRecPolicy, true, false>(const ScanParams, const GeomConst, const TileGrid, DevState*, const KalmanRecLayers, float* const*, int, const TilePool, const TileAux, const TileWork);
+template __global__ void fdm::k_tupdate_tbin<KalmanRecPolicy, true, false, 256, true>(const ScanParams, const GeomConst, const TileGrid, DevState*, const KalmanRecLayers, float* const*, int, const TilePool, const TileAux, const TileWork, unsigned, const ScanParams, const ScanInputs, const Scratch, const TilePool, int32_t*);
 EOS
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -gline-tables-only -save-temps "$@" -Rpass-analysis=kernel-resource-usage -c one.hip -o one.o 2>&1 | awk '
 /Function Name:/ {name=$0; sub(/.*Function Name: /,"",name); sub(/ \[-Rpass.*/,"",name)}

@@ -368,7 +368,7 @@ def test_update_device_chain(gpu, R):
 
 def test_fused_launch_timeline_tool(gpu):
     """fdm_engine_debug_timeline (option dbg_timeline): start / end ticks of every block of the last fused
-    large-scan launch — tile groups first, bin blocks behind them, every block ends after it starts."""
+    large-scan launch — update blocks first, bin blocks behind them, every block ends after it starts."""
     import torch
     wl = gpu.synth.lidar128(n_scans=3, n_az=2048)
     eng = gpu.Engine(wl.width, wl.height, wl.resolution, wl.apply_to(gpu.capi.default_config()))
@@ -383,8 +383,9 @@ def test_fused_launch_timeline_tool(gpu):
         eng.integrate_device(d["x"], d["y"], d["z"], wl.T_base_sensor, wl.pose(k), intensity=d["intensity"])
     assert eng.last_pipeline() == 1
     ticks, n_upd = eng.debug_timeline()
-    tiles = ((eng.rows + 31) // 32) * ((eng.cols + 31) // 32)
-    assert n_upd == tiles and len(ticks) == tiles + (wl.n_points + 1023) // 1024
+    # update blocks (four tile wavefronts each, 16 x 16-cell tiles; at most the option's default of 512) + bin blocks
+    tiles = ((eng.rows + 15) // 16) * ((eng.cols + 15) // 16)
+    assert n_upd == min((tiles + 3) // 4, 512) and len(ticks) == n_upd + (wl.n_points + 1023) // 1024
     assert (ticks[:, 1] >= ticks[:, 0]).all() and ticks[:, 0].min() > 0
     span_us = (int(ticks[:, 1].max()) - int(ticks[:, 0].min())) / 100.0
     assert 1.0 < span_us < 5000.0
