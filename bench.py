@@ -65,6 +65,14 @@ def parse():
                     help="skip the PCIe-inclusive host entry points (reported beside `value`, never as it): they launch "
                          "the same kernels on host memory, which pulls a rocprofv3 per-kernel average of this "
                          "command away from the timed region")
+    ap.add_argument("--global-size-m", type=float, default=400.0,
+                    help="side of the GLOBAL map of configs[4] / the global_map leg (tests: a reduced map for N processes on one GPU)")
+    ap.add_argument("--global-n-az", type=int, default=2048, help="azimuth steps of the reduced global map's scans")
+    ap.add_argument("--fail-global-rank", type=int, default=-1,
+                    help="tests: the global-map leg raises at its start on this rank (default: never)")
+    ap.add_argument("--trace-steps", action="store_true", help="c5: host time of every routed step's parts on stderr (measurement)")
+    ap.add_argument("--repeats", type=int, default=25,
+                    help="a timed region shorter than 5 ms is repeated this many times; ms_per_step / value are the median")
     ap.add_argument("--profile-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large", action="store_true")
@@ -210,7 +218,11 @@ def measure_kernels(res, k0, steps, tag=None, overlap=1):
     out["kernel_names"] = {k: real.get(k, k) for k in ("k_bin", "k_update", "k_update_bin") if k in out}
     names = {"k_update_bin": "k_update_bin (one launch: update of scan t + bin of scan t+1)",
              "k_tupdate_tbin": "k_tupdate_tbin (one launch: update of scan t + bin of scan t+1, per-tile record pools)"}
-    roof = {"bound": "hbm", "kernel": names.get(real.get(dom, dom), real.get(dom, dom)), "achieved": out[dom]["GBps"],
+    # `bound`: the roofline the fraction is taken against (the contract's "hbm": no contraction on this path).
+    # `limited_by`: what the counters say the launch actually waits for (profiles/r05: the large-scan launch is
+    # instruction-issue / dependent-round-trip bound at ~20 % of the HBM roofline; the small-scan kernels are latency chains)
+    roof = {"bound": "hbm", "limited_by": "issue" if tiled else "latency",
+            "kernel": names.get(real.get(dom, dom), real.get(dom, dom)), "achieved": out[dom]["GBps"],
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": out[dom]["GBps"] / HBM_PEAK_GBS,
             "traffic": pmc_traffic(tag, real.get(dom, dom)),
             "avg_kernel_us": out[dom]["ms"] * 1e3,
@@ -391,6 +403,16 @@ def host_legs(res, wl, k, iters=50, stream_iters=200):
     out["host_buffers_pinned_ms_per_scan"] = median_ms(
         lambda i: res.eng.integrate(pn["x"], pn["y"], pn["z"], wl.T_base_sensor, wl.pose(k + 1000 + i),
                                     intensity=pn.get("intensity"), rgb=pn.get("rgb")))
+    # the reference's own cloud layout: {x, y, z, 1} records (nanopcl::PointCloud::points()), pinned pool memory,
+    # through fdm_engine_integrate_points4 — no host AoS -> SoA loop; 16 B per point over PCIe instead of 12
+    n_pts = int(s["x"].size)
+    aos = host_array(np.stack([s["x"], s["y"], s["z"], np.ones(n_pts, np.float32)], axis=1).reshape(-1), np.float32)
+    a4 = aos.array.reshape(n_pts, 4)
+    for i in range(3):
+        res.eng.integrate_points4(a4, wl.T_base_sensor, wl.pose(k + 1000 + i), intensity=pa.get("intensity"), rgb=pa.get("rgb"))
+    out["host_points4_pool_ms_per_scan"] = median_ms(
+        lambda i: res.eng.integrate_points4(a4, wl.T_base_sensor, wl.pose(k + 1000 + i), intensity=pa.get("intensity"),
+                                            rgb=pa.get("rgb")))
     # N integrate() calls on host clouds as ONE call (fdm_engine_integrate_host_batch: what the C++ mirror's
     # FastDEM::integrateBatch does): 64 scans from the pinned pool, read in place by the batch launches, one wait at the end
     from fastdem_amd import capi
@@ -530,8 +552,13 @@ def main():
             """warm-up, then the K timed steps as ONE call across the language boundary (fdm_engine_integrate_device_batch:
             K x fdm_engine_integrate_device in C++; with a Python / ctypes call per 6 us scan the region would measure the
             interpreter), K scans + the last scan's held-back update between two HIP events on the engine's stream.
-            Returns (wall seconds incl. the final sync, points, HIP-event us per scan, scans per launch, next k)."""
-            for kk in range(k0, k0 + n_warm + n_timed + 8):
+            A region shorter than 5 ms (the driver's `--steps 20 --warmup 5` is 0.4 ms at configs[1]) is one launch latency
+            and one sync away from noise: the IDENTICAL K-step region — barrier + synchronize on both sides each time —
+            is then repeated `args.repeats` times on fresh scans and the MEDIAN is reported, with min / max beside it.
+            Returns (wall seconds incl. the final sync [median], points, HIP-event us per scan, scans per launch, next k,
+            the list of wall seconds of every repeat)."""
+            reps_max = max(1, args.repeats)
+            for kk in range(k0, k0 + n_warm + n_timed * reps_max + 8):
                 r.pose(kk)
             k = k0
             if n_warm > 0:  # the warm-up steps take the timed region's own entry point (its first call is not free)
@@ -539,28 +566,47 @@ def main():
                 if r.eng.integrate_device_batch_timed(wbatch) != 0:
                     raise RuntimeError("integrate_device_batch (warm-up) failed")
                 k += n_warm
-            batch, pts_ = r.batch(k, n_timed)
-            r.eng.sync()
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
+
+            def one(k_):
+                batch, pts_ = r.batch(k_, n_timed)
+                r.eng.sync()
                 torch.cuda.synchronize()
-            t0_ = time.perf_counter()
-            rc_ = r.eng.integrate_device_batch_timed(batch)
-            torch.cuda.synchronize()  # (device-wide: covers the engine's stream)
-            dt_ = time.perf_counter() - t0_
-            if rc_ != 0:
-                raise RuntimeError(f"integrate_device_batch failed: {rc_}")
-            return dt_, pts_, r.eng.timer_ms() / n_timed * 1e3, max(1, r.eng.last_batch()), k + n_timed
+                if world > 1:
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                rc_ = r.eng.integrate_device_batch_timed(batch)
+                torch.cuda.synchronize()  # (device-wide: covers the engine's stream)
+                dt_ = time.perf_counter() - t0_
+                if rc_ != 0:
+                    raise RuntimeError(f"integrate_device_batch failed: {rc_}")
+                return dt_, pts_, r.eng.timer_ms() / n_timed * 1e3, max(1, r.eng.last_batch())
+
+            dt_, pts_, us_, bs_ = one(k)
+            k += n_timed
+            wall, dev = [dt_], [us_]
+            again = 1 if (dt_ < 5e-3 and reps_max > 1) else 0
+            if world > 1:  # every rank repeats or none does
+                flag = torch.tensor([again], dtype=torch.int32, device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                again = int(flag.item())
+            if again:
+                for _ in range(reps_max - 1):
+                    d_, _, u_, _ = one(k)
+                    k += n_timed
+                    wall.append(d_)
+                    dev.append(u_)
+            return float(np.median(wall)), pts_, float(np.median(dev)), bs_, k, wall
 
         for kk in range(args.profile_steps + 8):
             res.pose(n_warm + n_timed + kk)
-        dt, pts, timed_launch_us, batch_scans, k = timed_region(res, 0)
-        if world > 1:
+        dt, pts, timed_launch_us, batch_scans, k, wall_reps = timed_region(res, 0)
+        if world > 1:  # the MAX over ranks of every repeat, then the median
             dist.barrier()
-            t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
+            t = torch.tensor(wall_reps, dtype=torch.float64, device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            wall_reps = [float(v) for v in t.tolist()]
+            dt = float(np.median(wall_reps))
         rc, st = res.eng.last_stats()
         assert rc == 0 and st["n_in_map"] > 0, (rc, st)
         total_pts = pts * world
@@ -568,6 +614,9 @@ def main():
             "metric": "M points/s integrated into ElevationMap",
             "value": total_pts / dt / 1e6, "unit": "Mpts/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            # (a region under 5 ms is repeated: ms_per_step / value are the MEDIAN over `repeats` identical K-step regions)
+            "repeats": len(wall_reps), "ms_per_step_min": min(wall_reps) / args.steps * 1e3,
+            "ms_per_step_max": max(wall_reps) / args.steps * 1e3,
             # the same K steps by the GPU's own clock (HIP events on the engine's stream around the region);
             # `value` is the host wall clock incl. the final sync — for very short regions it is launch-bound
             "device_value": pts / (timed_launch_us * n_timed * 1e-6) / 1e6,
@@ -614,7 +663,7 @@ def main():
                 result["latency_path"] = {"kernel": roof["kernel"], "us_per_scan": kern["k_update_bin"]["ms"] * 1e3,
                                           "Mpts_per_s": wl.n_points / (kern["k_update_bin"]["ms"] * 1e-3) / 1e6,
                                           "note": "fdm_engine_integrate_device scan by scan (event pair per launch)"}
-                roof = {"bound": "hbm",
+                roof = {"bound": "hbm", "limited_by": "latency",
                         "kernel": "k_mbatch (one launch per 16 scans: update of batch b-1 | bin of batch b | scout blocks of batch b+1)",
                         "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
                         "traffic": pmc_traffic(args.workload, "k_mbatch"), "avg_kernel_us": launch_us,
@@ -629,7 +678,7 @@ def main():
                 res4 = Resident(wl4, local_rank, args.wave_merge, args.overlap)
                 for kv in args.set:
                     res4.eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
-                dt4, pts4, us4, bs4, _ = timed_region(res4, 0)
+                dt4, pts4, us4, bs4, _, _ = timed_region(res4, 0)
                 result["cache_resident"] = {"value": pts4 / dt4 / 1e6, "unit": "Mpts/s", "device_value": wl4.n_points / (us4 * 1e-6) / 1e6,
                                             "us_per_scan_hip_events": us4, "distinct_scans": 4, "scans_per_launch": bs4,
                                             "roofline_frac": roof["alg_bytes_per_launch"] / max(1, roof.get("scans_per_launch", 1)) /
@@ -717,6 +766,7 @@ def main():
         g = tiling.bench_global(args, rank, local_rank, world)
         if rank == 0:
             result["global_map"] = g
+            result["global_map_ok"] = bool(g) and "error" not in g
     if world > 1 or routed:
         dist.barrier()
         dist.destroy_process_group()

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("FDM_ENGINE_LIB") or os.path.join(_HERE, "lib", "libfdm_engine.so")  # (FDM_ENGINE_LIB: another build of the same ABI, for A/B measurements)
+LIB_PATH = os.path.join(_HERE, "lib", "libfdm_engine.so")  # (measurement scripts assign another build of the same ABI here before load())
 
 
 class FdmConfig(C.Structure):
@@ -132,6 +132,7 @@ PROTOTYPES = {
     "fdm_engine_set_stream": (C.c_int, [_P, _P]),
     "fdm_engine_integrate": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, _D, _D,
                                        C.POINTER(FdmScanStats)]),
+    "fdm_engine_integrate_points4": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _D, _D, C.POINTER(FdmScanStats)]),
     "fdm_engine_integrate_device": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, _D, _D]),
     "fdm_engine_integrate_device_batch": (C.c_int, [_P, C.c_uint32, _P]),
     "fdm_engine_integrate_device_batch_timed": (C.c_int, [_P, C.c_uint32, _P]),

@@ -100,6 +100,8 @@ struct fdm_engine {
   int last_was_integrate = 0;
   // staging for the host-pointer entry points
   float* d_stage = nullptr;
+  float4* d_aos = nullptr;  // fdm_engine_integrate_points4 on pageable memory: the cloud's {x, y, z, 1} records
+  size_t aos_cap = 0;
   size_t stage_cap = 0;  // in points
   int stage_rr = 0;      // rotating staging block
   int32_t* d_cell_ids = nullptr;
@@ -186,7 +188,7 @@ struct fdm_engine {
   unsigned tiled_min = 2048;        // ... from this many points up (on a map of >= 512 tiles the pipeline wins at every
                                     // size measured: 2 K points 13.1 vs 14.6 us, 32 K 16.6 vs 20.5, 262 K 18.9 vs 34.3)
   bool tiled_forced = false;        // tiled_min was set by hand (option "tiled_min"): no map-size condition
-  int upd_blocks = 512;             // option "upd_blocks": update blocks (four tile wavefronts each) of a FUSED launch
+  int upd_blocks = 768;             // option "upd_blocks": update blocks (four tile wavefronts each) of a FUSED launch
   int upd_blocks_alone = 2048;      // option "upd_blocks_alone": ... of an update launch of its own
   int upd_prio = 1;                 // option "upd_prio": update wavefronts run at raised issue priority
   int cnt_shift = 5;                // option "cnt_shift": one tile counter per 2^cnt_shift words (TilePool::cnt_shift); takes effect before the pools exist
@@ -224,6 +226,8 @@ struct fdm_engine {
   int dbg_batch = 0;                 // measurement only (option "dbg_batch")
   int batch_crop = 1;                // option "batch_crop": evaluate the next batch's crops one launch ahead
   int batch_walk = -1;               // option "batch_walk": the chain of moves walked one launch ahead (fdm_multi.hpp mwalk_body): -1 = for the quantile estimator only, 0 off, 1 on
+  unsigned long long batch_call = 0; // calls of fdm_engine_integrate_device_batch so far: a look-ahead is only ever honoured inside the call that made it
+  unsigned long long pre_call = 0;
   bool pre_valid = false;            // the last launch carried the crop pass of the batch (pre_scans, pre_count) = number pre_seq
   const fdm_device_scan* pre_scans = nullptr;
   uint32_t pre_count = 0;
@@ -292,6 +296,7 @@ int join_streams(fdm_engine* e) {
 int sync_all(fdm_engine* e) {
   if (int rc = join_streams(e)) return rc;
   HIPCK(hipStreamSynchronize(e->stream));
+  e->bstage_busy = false;  // (the stream has drained: nothing reads the host-batch staging block any more)
   return FDM_OK;
 }
 // DevState::fault after the stream has drained: a batch launch whose in-kernel wait for the scans ahead ran out of
@@ -1265,6 +1270,7 @@ void fdm_engine_destroy(fdm_engine* e) {
   if (e->h_stats) (void)hipHostFree(e->h_stats);
   if (e->d_stats_acc) (void)hipFree(e->d_stats_acc);
   if (e->d_stage) (void)hipFree(e->d_stage);
+  if (e->d_aos) (void)hipFree(e->d_aos);
   if (e->d_cell_ids) (void)hipFree(e->d_cell_ids);
   if (e->d_cap) (void)hipFree(e->d_cap);
   if (e->d_ras) (void)hipFree(e->d_ras);
@@ -1345,6 +1351,7 @@ int fdm_engine_integrate_device(fdm_engine* e, uint64_t n, const float* dx, cons
 
 int fdm_engine_integrate_device_batch(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) {
   if (!e || (count && !scans)) return fail(FDM_ERR_INVALID, "null argument");
+  ++e->batch_call;  // (the look-ahead of an earlier call — keyed on the caller's array ADDRESS — must never match a later call's array)
   for (uint32_t k = 0; k < count; ++k) {
     // runs of small plain scans leave as batches: one bin launch + one update launch per kMaxBatch scans
     if (const uint32_t run = multi_run(e, count - k, scans + k)) {
@@ -1378,7 +1385,8 @@ int fdm_engine_integrate_host_batch(fdm_engine* e, uint32_t count, const fdm_dev
     if (s.n == 0) continue;
     if (!s.x || !s.y || !s.z) return fail(FDM_ERR_INVALID, "null xyz");
     if (s.n >= 0x7FFFFFFFull) return fail(FDM_ERR_INVALID, "point count exceeds 2^31-1");
-    const float* mx = e->zero_copy ? static_cast<const float*>(pinned_alias(s.x)) : nullptr;
+    // (option zero_copy is a point-count BOUND, as in stage_inputs: larger clouds are staged also from pinned memory)
+    const float* mx = (e->zero_copy && s.n <= uint64_t(e->zero_copy)) ? static_cast<const float*>(pinned_alias(s.x)) : nullptr;
     const float* my = mx ? static_cast<const float*>(pinned_alias(s.y)) : nullptr;
     const float* mz = my ? static_cast<const float*>(pinned_alias(s.z)) : nullptr;
     const float* ma = (mz && s.intensity) ? static_cast<const float*>(pinned_alias(s.intensity)) : nullptr;
@@ -1420,7 +1428,7 @@ int fdm_engine_integrate_host_batch(fdm_engine* e, uint32_t count, const fdm_dev
       return fail(FDM_ERR_HIP, "staging a host cloud");
     s.x = ux; s.y = uy; s.z = uz; s.intensity = ua; s.rgb = reinterpret_cast<const uint32_t*>(uc); s.sigma_z2 = uv;
   }
-  e->bstage_busy = need != 0;
+  e->bstage_busy = e->bstage_busy || need != 0;  // (only a drained stream clears it: an earlier call's launches may still read the block)
   if (int rc_batch = fdm_engine_integrate_device_batch(e, count, d.data())) return rc_batch;
   if (!out_last) return FDM_OK;
   int status = FDM_OK;
@@ -1457,6 +1465,61 @@ int fdm_engine_integrate(fdm_engine* e, uint64_t n, const float* x, const float*
   ScanParams P;
   fill_integrate_params(e, P, Tbs, Twb);
   if ((rc = enqueue_scan(e, P, n, dx, dy, dz, da, dc, dv, gather.x ? &gather : nullptr))) return rc;
+  int status = FDM_OK;
+  if ((rc = read_stats(e, out, &status))) return rc;
+  return status;
+}
+
+// FastDEM::integrate on the reference's OWN cloud layout: nanopcl::PointCloud::points() is a contiguous
+// AlignedVector<Vector4f> of {x, y, z, 1} (nanopcl/core/point_cloud.hpp:126-134, types.hpp:19-22).  The 16-byte
+// records are read where they lie when the memory is pinned (once, over PCIe, by the de-interleave launch) and copied
+// to the device first when it is pageable; the optional channels are separate arrays as in the reference.
+int fdm_engine_integrate_points4(fdm_engine* e, uint64_t n, const float* xyz1, const float* intensity,
+                                 const uint32_t* rgb, const float* sigma_z2, const double Tbs[16],
+                                 const double Twb[16], fdm_scan_stats* out) {
+  if (e) { if (int rc_join = join_streams(e)) return rc_join; }
+  if (!e || !Tbs || !Twb) return fail(FDM_ERR_INVALID, "null argument");
+  if (n == 0) {
+    if (out) std::memset(out, 0, sizeof(*out));
+    return FDM_SKIP_EMPTY_CLOUD;
+  }
+  if (!xyz1) return fail(FDM_ERR_INVALID, "null points");
+  if (n >= 0x7FFFFFFFull) return fail(FDM_ERR_INVALID, "point count exceeds 2^31-1");
+  if (reinterpret_cast<uintptr_t>(xyz1) & 15u) return fail(FDM_ERR_INVALID, "points not 16-byte aligned");
+  HIPCK(hipSetDevice(e->device));
+  int rc;
+  if ((rc = ensure_stage(e, n))) return rc;
+  e->stage_rr = (e->stage_rr + 1) % kStageSlots;
+  const size_t cap = e->stage_cap;
+  float* base = e->d_stage + size_t(e->stage_rr) * 6 * cap;
+  const float4* src = static_cast<const float4*>(pinned_alias(xyz1));
+  if (!src) {  // pageable: one copy of the records, then the de-interleave reads HBM
+    if (n > e->aos_cap) {
+      if (int rc_sync = sync_all(e)) return rc_sync;
+      if (e->d_aos) HIPCK(hipFree(e->d_aos));
+      e->aos_cap = n + n / 4 + 1024;
+      HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_aos), e->aos_cap * sizeof(float4)));
+    }
+    HIPCK(hipMemcpyAsync(e->d_aos, xyz1, n * sizeof(float4), hipMemcpyHostToDevice, e->stream));
+    src = e->d_aos;
+  }
+  const int blocks = int(std::min<uint64_t>((n + 255) / 256, 8192));
+  hipLaunchKernelGGL(k_points4_to_soa, dim3(blocks), dim3(256), 0, e->stream, src, size_t(n), base, base + cap, base + cap * 2,
+                     static_cast<float*>(nullptr));  // (the fourth component is the homogeneous 1: not a channel)
+  HIPCK(hipGetLastError());
+  auto up = [&](const void* h, int k) -> int {
+    HIPCK(hipMemcpyAsync(base + cap * k, h, n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    return FDM_OK;
+  };
+  const float* da = nullptr;
+  const uint32_t* dc = nullptr;
+  const float* dv = nullptr;
+  if (intensity) { if ((rc = up(intensity, 3))) return rc; da = base + cap * 3; }
+  if (rgb) { if ((rc = up(rgb, 4))) return rc; dc = reinterpret_cast<const uint32_t*>(base + cap * 4); }
+  if (sigma_z2) { if ((rc = up(sigma_z2, 5))) return rc; dv = base + cap * 5; }
+  ScanParams P;
+  fill_integrate_params(e, P, Tbs, Twb);
+  if ((rc = enqueue_scan(e, P, n, base, base + cap, base + cap * 2, da, dc, dv))) return rc;
   int status = FDM_OK;
   if ((rc = read_stats(e, out, &status))) return rc;
   return status;

@@ -331,7 +331,7 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
   const unsigned seq = e->mseq++;
   const int slot = int(seq % unsigned(kMStates)), par = int(seq & 1u);
   // the crop pass that ran one launch ahead left this batch's pass bits in its state word — if it was for THIS batch
-  const bool pre = e->pre_valid && e->pre_scans == scans && e->pre_count == count && e->pre_seq == seq;
+  const bool pre = e->pre_valid && e->pre_call == e->batch_call && e->pre_scans == scans && e->pre_count == count && e->pre_seq == seq;
   if (e->pre_valid && !pre)  // (bits of a batch that never came: not expected inside one call)
     HIPCK(hipMemsetAsync(e->mstate[slot].flags, 0, sizeof(unsigned) * kLineWords, e->stream));
   e->pre_valid = false;
@@ -385,6 +385,7 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
       std::memcmp(scans[count].T_base_sensor, f.T_base_sensor, 16 * sizeof(double)) == 0) {
     fill_scouts(Cn, next_count, scans + count, e->mstate + int((seq + 1u) % unsigned(kMStates)));
     e->pre_valid = true;
+    e->pre_call = e->batch_call;
     e->pre_scans = scans + count;
     e->pre_count = next_count;
     e->pre_seq = seq + 1u;

@@ -95,8 +95,12 @@ __device__ __forceinline__ void tbin2_flush(const PT& P0, const GeomConst& G, co
     } else {
       if (rare_block && (wl & 1u)) fl_[q] = kRecMinNeg;
       const unsigned gi = b0 + (wl >> 1);
+#ifndef FDM_X_NOSIGMA
       if (P.has_var) var_[q] = I.var[gi];
       else if (P.integrate_mode) var_[q] = sigma_z2(P, I.x[gi], I.y[gi], I.z[gi]);
+#else
+      var_[q] = __uint_as_float(gi);
+#endif
     }
   }
   __syncthreads();  // every record has left the table (the cell words stay: the rare walk probes them)
@@ -191,7 +195,9 @@ __device__ __forceinline__ void tbin2_flush(const PT& P0, const GeomConst& G, co
   }
   __syncthreads();
   unsigned t0_slot = 0u;
+#ifndef FDM_X_NOATOM
   if (wave == 0u && t0_n) t0_slot = atomicAdd(Q.cnt + (size_t(t0_tile) << Q.cnt_shift), 1u);
+#endif
   // (e) the records, grouped by tile, into the block's own region of the pool
 #pragma unroll
   for (int q = 0; q < ROUNDS; ++q) {
@@ -374,8 +380,10 @@ __device__ __forceinline__ void tbin2_body(const PT& P, const GeomConst& G, cons
     unsigned np = 0, ni = 0, ag = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) { np += s_cnt[w] & 0xFFFFu; ni += s_cnt[w] >> 16; ag |= s_any[w]; }
+#ifndef FDM_X_NOFLAGS  // (FDM_X_*: measurement builds only, `make variant`)
     if (np) H.note_pass();
     if (ag) H.note_inside();
+#endif
     bin_part[bid] = (unsigned long long)np | ((unsigned long long)ni << 32);
   }
   FDM_PHASE(2);  // LDS fold done

@@ -150,6 +150,21 @@ class Engine:
             C.byref(st)))
         return rc, st.as_dict()
 
+    def integrate_points4(self, xyz1, T_base_sensor, T_world_base, intensity=None, rgb=None, sigma_z2=None):
+        """The reference's own cloud layout: `xyz1` = n x 4 float32 records {x, y, z, 1} (nanopcl::PointCloud::points()),
+        a C-contiguous HOST array (pinned memory is read in place).  Synchronous; returns (status, stats dict)."""
+        import numpy as np
+        p = xyz1 if isinstance(xyz1, np.ndarray) and xyz1.dtype == np.float32 and xyz1.flags["C_CONTIGUOUS"] \
+            else np.ascontiguousarray(xyz1, dtype=np.float32)
+        assert p.ndim == 2 and p.shape[1] == 4, p.shape
+        a, c, v = _f32(intensity), _u32(rgb), _f32(sigma_z2)
+        tbs, twb = _colmajor16(T_base_sensor), _colmajor16(T_world_base)
+        st = FdmScanStats()
+        rc = _ck(self._lib.fdm_engine_integrate_points4(
+            self._h, p.shape[0], p.ctypes.data if p.shape[0] else None, _ptr(a), _ptr(c), _ptr(v),
+            tbs.ctypes.data_as(C.POINTER(C.c_double)), twb.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st)))
+        return rc, st.as_dict()
+
     def wait_torch(self):
         """Order the engine's stream behind torch's current stream (an event + hipStreamWaitEvent): tensors
         produced by asynchronous torch work (copy_, kernels, NCCL results) are complete before the engine

@@ -172,6 +172,16 @@ int fdm_engine_integrate_device_batch(fdm_engine* e, uint32_t count, const fdm_d
 int fdm_engine_integrate_host_batch(fdm_engine* e, uint32_t count, const fdm_device_scan* host_scans,
                                     fdm_scan_stats* out_last);
 
+/* FastDEM::integrate(cloud, T_base_sensor, T_world_base) on the reference's own point layout — replaces
+ * fastdem/src/fastdem.cpp:122-190 for a caller that holds a nanopcl::PointCloud: `xyz1` = cloud.points().data(), n
+ * contiguous 16-byte {x, y, z, 1} records (nanopcl/core/point_cloud.hpp:126-134, core/types.hpp:19-22), HOST memory,
+ * 16-byte aligned.  Pinned memory (fdm_host_alloc / hipHostMalloc) is read in place, once, over PCIe; pageable memory
+ * is copied first.  intensity / rgb / sigma_z2: the optional channels, separate host arrays of n entries (nullable), as
+ * in fdm_engine_integrate.  Synchronous; status and statistics as fdm_engine_integrate. */
+int fdm_engine_integrate_points4(fdm_engine* e, uint64_t n, const float* xyz1, const float* intensity,
+                                 const uint32_t* rgb, const float* sigma_z2, const double T_base_sensor[16],
+                                 const double T_world_base[16], fdm_scan_stats* out);
+
 /* Same, HOST arrays, enqueue-only; nothing waits.  For a stream of scans from host memory (bag replay,
  * a ROS callback).
  *   PINNED arrays (fdm_host_alloc / hipHostMalloc / hipHostRegister): no copy is queued — the bin kernel
@@ -471,6 +481,16 @@ int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2);
  *   "sync_spin_us" n     : a synchronous call polls the pinned statistics block for up to n microseconds before it
  *                         falls back to a stream wait (default 150; 0 = wait at once)
  *   "tiled" 0/1, "tiled_min" n : large-scan pipeline (per-tile record pools) on/off, its point-count threshold
+ *   "upd_blocks" n, "upd_blocks_alone" n : update blocks (four tile wavefronts each) of a fused large-scan launch
+ *                         (default 768) / of an update launch of its own (2048); every wavefront walks its share of the
+ *                         16 x 16-cell tiles
+ *   "upd_prio" 0/1      : the update wavefronts raise their issue priority (default 1)
+ *   "bin_stagger" n     : fused large-scan launch: start stagger of the first-round bin blocks, n x 512 cycles per
+ *                         resident slot (default 0)
+ *   "cnt_shift" 0..5    : one tile counter per 2^n words of the counter array (default 5 = one per 128 bytes:
+ *                         memory-side atomics on one line queue up); before the first large scan only
+ *   "batch_walk" -1/0/1 : small-scan batches: the chain of moves walked one launch ahead (-1 = for the quantile
+ *                         estimator only)
  *   "batch_ray" 0/1     : raycasting inside the small-scan batches (1); "batch_ray_lds" 0/1: its ray walk on LDS images
  *                         (1) or memory-side atomics with "batch_ray_seg" 1/4/8/16 lanes per ray
  *   "dbg_*"             : measurement-only switches used by scripts/ab_kernels.py */

@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """A/B of engine options on configs[3] (2 M-point scans, fused k_tupdate_tbin), same box, interleaved repetitions.
-usage: c4_ab.py "opt=val,opt=val" "opt=val" ...   ("" = defaults)"""
+usage: c4_ab.py [--lib=path/libfdm_engine_x.so] "opt=val,opt=val" "opt=val" ...   ("" = defaults)"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa
-from fastdem_amd import synth
+from fastdem_amd import capi, synth
+args = sys.argv[1:]
+if args and args[0].startswith("--lib="):  # another build of the engine (make -C fastdem_amd/csrc variant NAME=x)
+    capi.LIB_PATH = args.pop(0)[6:]
 import bench
 
-variants = sys.argv[1:] or [""]
+variants = args or [""]
 wl = synth.lidar128(n_scans=9)
 res = {}
 for rep in range(3):

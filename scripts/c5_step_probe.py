@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where does a one-rank c5 step spend its time?  (bench_global measured 0.44 ms per step in most runs and 0.037 in some:
 none of the per-step host calls probed here — it was ONE 50 ms stall of the first engine call behind the first RCCL
-barrier of the process, whose communicator set-up the barrier only enqueues; FDM_BENCH_TRACE=1 python bench.py --workload c5
+barrier of the process, whose communicator set-up the barrier only enqueues; python bench.py --workload c5 --trace-steps
 shows the per-step host times.  bench.py now warms the communicator and synchronises behind every barrier.)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

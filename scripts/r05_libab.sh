@@ -7,5 +7,5 @@ cd $R
 for N in "$@"; do
   L=$R/fastdem_amd/lib/libfdm_engine${N:+_$N}.so
   echo "== ${N:-shipped}"
-  FDM_ENGINE_LIB=$L timeout 400 python scripts/c4_ab.py "" "overlap=0" 2>/dev/null | tail -1
+  timeout 400 python scripts/c4_ab.py --lib=$L "" "overlap=0" 2>/dev/null | tail -1
 done

@@ -42,10 +42,41 @@ def test_gpus_2_default_workload_prints_replicas_and_the_global_map():
 
 def test_a_failing_global_map_leg_does_not_take_the_replicas_line_with_it():
     """The global-map leg behind the replicas has never run on two devices.  Whatever happens in it — here rank 1 raises
-    at its start (FDM_BENCH_FAIL_GLOBAL) — rank 0 still prints the replicas' line, with the error in `global_map`, and
-    every rank leaves with code 0."""
+    at its start (`--fail-global-rank 1`) — rank 0 still prints the replicas' line, with the error in `global_map`, the
+    top-level `global_map_ok` false, and every rank leaves with code 0."""
     r = run_bench("--gpus", "2", "--backend", "gloo", "--devices", "0,0", "--steps", "4", "--warmup", "2",
-                  "--no-cpu-baseline", "--no-host-legs", "--collective-timeout", "20",
-                  extra_env={"FDM_BENCH_FAIL_GLOBAL": "1"})
+                  "--no-cpu-baseline", "--no-host-legs", "--collective-timeout", "20", "--fail-global-rank", "1")
     assert r["n_gpus"] == 2 and r["value"] > 0 and "replicas" in r["config"]["parallelism"]
-    assert "error" in r["global_map"]
+    assert "error" in r["global_map"] and r["global_map_ok"] is False
+
+
+def test_gpus_8_global_map_plan_and_line_shape():
+    """The command the driver runs on an 8-GPU node, with eight processes on the ONE GPU here (host-staged exchange)
+    and a reduced global map: the 2 x 4 tile plan, eight scans per step, a roofline object — the rank plumbing, the
+    plan, the routing kernels and the exchange loop of the first real 8-GPU run."""
+    r = run_bench("--gpus", "8", "--workload", "c5", "--backend", "gloo", "--devices", "0,0,0,0,0,0,0,0", "--steps", "2",
+                  "--warmup", "1", "--global-size-m", "100", timeout=1500)
+    assert r["n_gpus"] == 8 and r["scaling"] == "weak" and r["value"] > 0
+    assert r["config"]["tile_plan"] == "2x4" and r["config"]["scans_per_step"] == 8
+    assert r["roofline"] and r["roofline"]["achieved"] > 0 and 0 < r["roofline"]["frac"] < 1
+    m = r["rank0_routing_matrix_last_step"]
+    assert m is not None and len(m) == 8  # every source's shares by owner
+
+
+def test_gpus_8_default_workload_replicas_and_global_map():
+    """`bench.py --gpus 8` (the default workload): eight replicas of configs[1] + the global-map leg behind them."""
+    r = run_bench("--gpus", "8", "--backend", "gloo", "--devices", "0,0,0,0,0,0,0,0", "--steps", "4", "--warmup", "2",
+                  "--no-cpu-baseline", "--no-host-legs", "--global-size-m", "100", timeout=1500)
+    assert r["n_gpus"] == 8 and "replicas" in r["config"]["parallelism"] and r["value"] > 0
+    assert r["global_map_ok"] is True
+    g = r["global_map"]
+    assert g["n_gpus"] == 8 and g["config"]["tile_plan"] == "2x4" and g["roofline"]["achieved"] > 0
+
+
+def test_one_rank_of_the_n_rank_path_reproduces_the_default_line():
+    """N = 1 through the launcher-less `--gpus 1` path prints the same figure as the plain command (within 5 %: the
+    driver's `--steps 20 --warmup 5` region is repeated and the median reported)."""
+    a = run_bench("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-host-legs", "--no-large")
+    b = run_bench("--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-host-legs", "--no-large")
+    assert a["n_gpus"] == b["n_gpus"] == 1 and a["repeats"] >= 25 and b["repeats"] >= 25
+    assert abs(a["value"] - b["value"]) / b["value"] < 0.05, (a["value"], b["value"])

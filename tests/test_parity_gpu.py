@@ -701,3 +701,34 @@ def test_first_seen_signed_zero_is_kept_bit_for_bit(gpu, R, n):
             v[::5] = 3.0
         run_both(eng, ref, {"x": x, "y": y, "z": z, "intensity": v}, T(), T(0.05 * k, 0.0))
         assert_layers_bit_identical(eng, ref)
+
+
+def test_points4_host_entry_the_reference_cloud_layout(gpu, R):
+    """fdm_engine_integrate_points4: FastDEM::integrate on nanopcl::PointCloud::points() — n contiguous {x, y, z, 1}
+    records in HOST memory (pageable: copied; pinned: read in place), the optional channels as separate arrays —
+    against the oracle's integrate of the same cloud (fastdem.cpp:122-190, point_cloud.hpp:126-134): status, statistics,
+    cell ids, every layer bit for bit, geometry."""
+    wl = gpu.synth.vlp16(n_scans=4)
+    eng, ref = pair(gpu, R, wl.width, wl.height, wl.resolution, wl.apply_to)
+    keep = []
+    for k in range(4):
+        s = wl.scan(k)
+        n = int(s["x"].size)
+        aos = np.empty((n, 4), dtype=np.float32)
+        aos[:, 0], aos[:, 1], aos[:, 2], aos[:, 3] = s["x"], s["y"], s["z"], 1.0
+        if k % 2:  # pinned: the records are read where they lie
+            h = gpu.host_array(aos.reshape(-1), np.float32)
+            keep.append(h)
+            aos = h.array.reshape(n, 4)
+        rc_e, st_e = eng.integrate_points4(aos, wl.T_base_sensor, wl.pose(k), intensity=s["intensity"])
+        rc_r, st_r = ref.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(k), intensity=s["intensity"])
+        assert (rc_e, st_e) == (rc_r, st_r)
+        assert np.array_equal(eng.last_cell_ids(n), ref.last_cell_ids(n))
+    assert_layers_bit_identical(eng, ref)
+    assert same_geometry(eng.geometry(), ref.geometry())
+    # an empty cloud is skipped like the reference does (fastdem.cpp:125-128); a misaligned pointer is refused
+    rc, _ = eng.integrate_points4(np.empty((0, 4), dtype=np.float32), wl.T_base_sensor, wl.pose(0))
+    assert rc == gpu.capi.FDM_SKIP_EMPTY_CLOUD
+    odd = np.zeros(4 * 8 + 1, dtype=np.float32)[1:].reshape(8, 4)
+    with pytest.raises(gpu.EngineError):
+        eng.integrate_points4(odd, wl.T_base_sensor, wl.pose(0))

@@ -383,9 +383,9 @@ def test_fused_launch_timeline_tool(gpu):
         eng.integrate_device(d["x"], d["y"], d["z"], wl.T_base_sensor, wl.pose(k), intensity=d["intensity"])
     assert eng.last_pipeline() == 1
     ticks, n_upd = eng.debug_timeline()
-    # update blocks (four tile wavefronts each, 16 x 16-cell tiles; at most the option's default of 512) + bin blocks
+    # update blocks (four tile wavefronts each, 16 x 16-cell tiles; at most the option's default of 768) + bin blocks
     tiles = ((eng.rows + 15) // 16) * ((eng.cols + 15) // 16)
-    assert n_upd == min((tiles + 3) // 4, 512) and len(ticks) == n_upd + (wl.n_points + 1023) // 1024
+    assert n_upd == min((tiles + 3) // 4, 768) and len(ticks) == n_upd + (wl.n_points + 1023) // 1024
     assert (ticks[:, 1] >= ticks[:, 0]).all() and ticks[:, 0].min() > 0
     span_us = (int(ticks[:, 1].max()) - int(ticks[:, 0].min())) / 100.0
     assert 1.0 < span_us < 5000.0
