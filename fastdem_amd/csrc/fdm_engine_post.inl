@@ -138,7 +138,13 @@ int fdm_engine_apply_spatial_smoothing(fdm_engine* e, const char* layer, int ker
     hipLaunchKernelGGL(k_median, dim3(cell_blocks(e)), dim3(256), 0, e->stream, e->G, e->d_state,
                        int(e->scan_no & 3), e->d_tmp, lptr(e, *l), lstride(e, *l), kernel_size, min_valid,
                        unsigned(e->ncell));
-  else {
+  else if (median_sel_lds_bytes(kernel_size) <= 160u * 1024u && !(e->dbg_post & 8)) {
+    // selection by bisection on an LDS tile (fdm_post.hpp k_median_sel): every window up to ~175 x 175
+    const unsigned lds = median_sel_lds_bytes(kernel_size);
+    if ((rc = allow_lds(k_median_sel, lds))) return rc;
+    hipLaunchKernelGGL(k_median_sel, dim3(tile3_blocks(e)), dim3(256), lds, e->stream, e->G, e->d_state, int(e->scan_no & 3),
+                       e->d_tmp, lptr(e, *l), lstride(e, *l), kernel_size, min_valid);
+  } else {
     const size_t side = size_t(2 * (kernel_size / 2) + 1);
     unsigned blocks = 0;
     if ((rc = ensure_pool(e, side * side, 256u, &blocks, side * side))) return rc;
@@ -296,7 +302,14 @@ int fdm_engine_apply_feature_extraction(fdm_engine* e, float radius, int min_val
     else launch_tiled(k_features_tiled<16>);
   } else if (pct_ok && need_lo <= 8 && need_hi <= 8) launch_feat(k_features<8>);
   else if (pct_ok && need_lo <= 16 && need_hi <= 16) launch_feat(k_features<16>);
-  else if (reg.size() <= size_t(kMaxRegion)) launch_feat(k_features<0>);
+  else if (reg.size() <= size_t(kMaxRegion) && (e->dbg_post & 8)) launch_feat(k_features<0>);
+  else if (features_sel_lds_bytes(halo, int(reg.size())) <= 160u * 1024u && !(e->dbg_post & 8)) {
+    // any disc, any percentile pair: order statistics by bisection on an LDS tile (fdm_post.hpp k_features_sel)
+    const unsigned lds = features_sel_lds_bytes(halo, int(reg.size()));
+    if ((rc = allow_lds(k_features_sel, lds))) return rc;
+    hipLaunchKernelGGL(k_features_sel, dim3(tile3_blocks(e)), dim3(256), lds, e->stream, e->G, e->d_state, int(e->scan_no & 3),
+                       e->d_region, F, halo, elev_p, O);
+  } else if (reg.size() <= size_t(kMaxRegion)) launch_feat(k_features<0>);
   else {  // any radius the reference accepts (config/postprocess.hpp:45): the sorted heights in the global pool
     unsigned blocks = 0;
     if ((rc = ensure_pool(e, reg.size(), 256u, &blocks, reg.size()))) return rc;

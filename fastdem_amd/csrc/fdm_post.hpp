@@ -19,6 +19,7 @@
 namespace fdm {
 
 constexpr int kMaxRegion = 256;  // entries of a disc / box neighbourhood the kernels accept
+constexpr int kS3R_ = 32, kS3C_ = 8;  // the stencil kernels' block tile: 32 rows (the contiguous axis) x 8 columns
 
 struct RegionEntry { int dr, dc; float dist_sq; float w; };  // w: per-entry weight the host precomputed (fusion)
 
@@ -140,6 +141,60 @@ __global__ __launch_bounds__(256) void k_median_big(const GeomConst G, const Dev
     if (n < min_valid) continue;
     out[ci * out_stride] = win[n / 2];
   }
+}
+
+// Windows beyond kMaxRegion cells, the fast way (round 5): an order statistic does not need a sort.  One block per
+// 32 x 8 cells; the tile and its ring of kernel / 2 cells are staged in LDS ONCE as monotone integer keys (ord(v); a
+// cell outside the stored window or without a finite value is the all-ones key), and every thread finds element
+// n / 2 of its window by BISECTION on the key's 32 bits: per bit one pass over the window counting the keys below the
+// candidate.  33 x k^2 LDS reads per cell instead of ~k^4 / 4 global-memory moves (17 x 17 on the 1200 x 1200 map:
+// 423 ms with the pooled insertion sort).  Among equal values the order is the keys' (-0 before +0: std::nth_element
+// leaves it unspecified, spatial_smoothing.hpp:52-66).
+__device__ __forceinline__ uint32_t post_key(float v) {  // monotone; non-finite -> all ones (never below a candidate)
+  const uint32_t b = __float_as_uint(v);
+  return (b & 0x7FFFFFFFu) >= 0x7F800000u ? 0xFFFFFFFFu : b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float post_unkey(uint32_t u) { return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
+__host__ __device__ constexpr unsigned median_sel_lds_bytes(int kernel) {
+  return unsigned(kS3R_ + 2 * (kernel / 2)) * unsigned(kS3C_ + 2 * (kernel / 2)) * 4u;
+}
+__global__ __launch_bounds__(256) void k_median_sel(const GeomConst G, const DevState* __restrict__ st, int slot,
+                                                    const float* __restrict__ in, float* __restrict__ out,
+                                                    int out_stride, int kernel, int min_valid) {
+  extern __shared__ uint32_t s_keys[];
+  const PostGeom p = post_geom(st, slot, G);
+  const int h = kernel / 2, pitch = kS3R_ + 2 * h, width = kS3C_ + 2 * h;
+  const int tiles_r = (p.rows + kS3R_ - 1) / kS3R_;
+  const int tr = int(blockIdx.x) % tiles_r, tc = int(blockIdx.x) / tiles_r;
+  const int r0 = tr * kS3R_ - h, c0 = tc * kS3C_ - h;
+  for (int k = int(threadIdx.x); k < pitch * width; k += 256) {
+    const int cc = k / pitch, rr = k - cc * pitch;
+    s_keys[k] = post_inside(p, r0 + rr, c0 + cc) ? post_key(in[post_index(p, r0 + rr, c0 + cc)]) : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  const int lrl = int(threadIdx.x) & (kS3R_ - 1), lcl = int(threadIdx.x) >> 5;
+  const int lr = tr * kS3R_ + lrl, lc = tc * kS3C_ + lcl;
+  if (!post_inside(p, lr, lc)) return;
+  const uint32_t* const win = s_keys + lcl * pitch + lrl;  // the window's corner (dr = dc = -h)
+  if (win[h * pitch + h] == 0xFFFFFFFFu) return;          // the centre holds no finite value
+  const int side = 2 * h + 1;
+  auto below = [&](uint32_t t) {  // keys of the window below t
+    int c = 0;
+    for (int dc = 0; dc < side; ++dc) {
+      const uint32_t* const col = win + dc * pitch;
+      for (int dr = 0; dr < side; ++dr) c += col[dr] < t ? 1 : 0;
+    }
+    return c;
+  };
+  const int n = below(0xFFFFFFFFu);  // finite values
+  if (n < min_valid) return;
+  const int r = n / 2;  // nth_element(size / 2)
+  uint32_t key = 0u;
+  for (int b = 31; b >= 0; --b) {
+    const uint32_t t = key | (1u << b);
+    if (below(t) <= r) key = t;  // at most r keys below t: element r is >= t
+  }
+  out[post_index(p, lr, lc) * size_t(out_stride)] = post_unkey(key);
 }
 
 // 3x3 window (the default kernel): the nine values are named registers, missing / non-finite
@@ -800,6 +855,80 @@ __global__ __launch_bounds__(256) void k_features_big(const GeomConst G, const D
     const int hi = static_cast<int>(F.hi_pct * float(count - 1));
     features_store(O, ci, val, normal, trace, zs[lo], zs[hi]);
   }
+}
+
+// Any disc, any percentile pair, without a sort (round 5; replaces the pooled insertion sort of k_features_big wherever
+// the tile fits the LDS): one block per 32 x 8 cells, the tile and its ring of `halo` cells staged in LDS once — as
+// floats for the displacement sums (accumulated in the region's order, as the reference does) and as monotone keys
+// for the two order statistics, which are found by bisection on the keys' bits: per bit ONE pass over the region
+// counts the keys below both candidates.  The region's LDS offsets are a table in LDS (one broadcast read per entry).
+__host__ __device__ constexpr unsigned features_sel_lds_bytes(int halo, int n_entries) {
+  return unsigned(kS3R_ + 2 * halo) * unsigned(kS3C_ + 2 * halo) * 8u + unsigned(n_entries) * 4u;
+}
+__global__ __launch_bounds__(256) void k_features_sel(const GeomConst G, const DevState* __restrict__ st, int slot,
+                                                      const RegionEntry* __restrict__ reg, const FeatureParams F, int halo,
+                                                      const float* __restrict__ elev, const FeatureOut O) {
+  extern __shared__ uint32_t s_feat[];
+  const PostGeom p = post_geom(st, slot, G);
+  const int pitch = kS3R_ + 2 * halo, width = kS3C_ + 2 * halo, cells = pitch * width;
+  float* const s_v = reinterpret_cast<float*>(s_feat);
+  uint32_t* const s_k = s_feat + cells;
+  int* const s_off = reinterpret_cast<int*>(s_feat + 2 * cells);
+  const int tiles_r = (p.rows + kS3R_ - 1) / kS3R_;
+  const int tr = int(blockIdx.x) % tiles_r, tc = int(blockIdx.x) / tiles_r;
+  const int r0 = tr * kS3R_ - halo, c0 = tc * kS3C_ - halo;
+  for (int k = int(threadIdx.x); k < cells; k += 256) {
+    const int cc = k / pitch, rr = k - cc * pitch;
+    const float v = post_inside(p, r0 + rr, c0 + cc) ? elev[post_index(p, r0 + rr, c0 + cc)] : __uint_as_float(0x7FC00000u);
+    s_v[k] = v;
+    s_k[k] = post_key(v);
+  }
+  for (int e = int(threadIdx.x); e < F.n_entries; e += 256) s_off[e] = reg[e].dc * pitch + reg[e].dr;
+  __syncthreads();
+  const int lrl = int(threadIdx.x) & (kS3R_ - 1), lcl = int(threadIdx.x) >> 5;
+  const int lr = tr * kS3R_ + lrl, lc = tc * kS3C_ + lcl;
+  if (!post_inside(p, lr, lc)) return;
+  const int base = (lcl + halo) * pitch + lrl + halo;
+  const float center_z = s_v[base];
+  if (!isfinite(center_z)) return;
+  float sum[3] = {0.f, 0.f, 0.f};
+  float sq[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int count = 0;
+  for (int e = 0; e < F.n_entries; ++e) {
+    const RegionEntry re = reg[e];
+    const float nz = s_v[base + re.dc * pitch + re.dr];
+    if (!isfinite(nz)) continue;  // outside the stored window, or no data
+    const float d[3] = {float(-re.dr) * F.resf, float(-re.dc) * F.resf, nz - center_z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sum[k] += d[k];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) sq[c * 3 + r] += d[r] * d[c];
+    ++count;
+  }
+  if (count < F.min_valid) return;
+  float cov[9], trace;
+  if (!features_cov(sum, sq, count, cov, &trace)) return;
+  float val[3], normal[3];
+  eig3_direct(cov, val, normal);
+  if (val[1] < 1e-8f) return;  // kMinEigenvalue
+  const int lo = static_cast<int>(F.lo_pct * float(count - 1));
+  const int hi = static_cast<int>(F.hi_pct * float(count - 1));
+  uint32_t k_lo = 0u, k_hi = 0u;
+  for (int b = 31; b >= 0; --b) {
+    const uint32_t t_lo = k_lo | (1u << b), t_hi = k_hi | (1u << b);
+    int c_lo = 0, c_hi = 0;
+    for (int e = 0; e < F.n_entries; ++e) {
+      const uint32_t key = s_k[base + s_off[e]];
+      c_lo += key < t_lo ? 1 : 0;
+      c_hi += key < t_hi ? 1 : 0;
+    }
+    if (c_lo <= lo) k_lo = t_lo;
+    if (c_hi <= hi) k_hi = t_hi;
+  }
+  const size_t ci = post_index(p, lr, lc);
+  features_store(O, ci, val, normal, trace, post_unkey(k_lo), post_unkey(k_hi));
 }
 
 // The same stage for dense layers (stride 1) and a region that reaches at most kFeatHaloMax cells: one block per

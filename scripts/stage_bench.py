@@ -141,10 +141,10 @@ for name, fn_gpu, fn_cpu, alg_bytes in (
 # beside them; they exist so that no call the reference accepts is refused ----
 res_cells = eng.rows * eng.cols
 for name, fn_gpu, entries in (
-        ("post_median_17x17 (k_median_big)", lambda: eng.apply_spatial_smoothing("elevation_inpainted", 17, 5), 17 * 17),
+        ("post_median_17x17 (k_median_sel)", lambda: eng.apply_spatial_smoothing("elevation_inpainted", 17, 5), 17 * 17),
         ("post_uncertainty_fusion(r=10 cells: 317 entries, k_fusion_big)",
          lambda: eng.apply_uncertainty_fusion(True, 10.0 * wl.resolution + 1e-4, 0.05, 0.01, 0.99, 3), 317),
-        ("post_feature_extraction(r=10 cells: 317 entries, k_features_big)",
+        ("post_feature_extraction(r=10 cells: 317 entries, k_features_sel)",
          lambda: eng.apply_feature_extraction(10.0 * wl.resolution + 1e-4, 4, 0.05, 0.95), 317)):
     t = timed(fn_gpu, 2)
     print(json.dumps({"stage": name, "workload": a.workload, "cells": res_cells, "entries_per_cell": entries,

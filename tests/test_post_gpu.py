@@ -112,7 +112,8 @@ def test_median_smoothing_parity(gpu, R):
     el[rng.uniform(size=shape) < 0.02] = 50.0  # spikes
     # odd kernels, EVEN kernels (region(Size(k, k)) spans [-k/2, k/2]: the (k + 1)-wide box) and windows beyond 256
     # cells (17 x 17 = 289, 22 -> 23 x 23 = 529: the pooled kernel) — every size the reference accepts
-    for k, mv in ((3, 5), (5, 9), (7, 1), (4, 5), (15, 30), (17, 40), (22, 3)):
+    # (17 and up: k_median_sel, selection by bisection on an LDS tile; 41 x 41 = 1 681 cells needs 48 KB of it)
+    for k, mv in ((3, 5), (5, 9), (7, 1), (4, 5), (15, 30), (17, 40), (22, 3), (41, 200)):
         both((eng, ref), lambda o: (o.set_layer("elevation", el), o.apply_spatial_smoothing("elevation", k, mv)))
         exact(eng, ref, ["elevation"])
     with pytest.raises(gpu.EngineError):
@@ -148,6 +149,21 @@ def test_discs_of_more_than_256_cells(gpu, R):
         both((eng, ref), lambda o: (o.set_layer("elevation", el), o.apply_feature_extraction(0.3, 4, 0.05, 0.95)))
         assert np.isfinite(eng.layer("slope")).sum() > 0.5 * el.size
         exact(eng, ref, ["step", "slope", "roughness", "curvature", "_normal_x", "_normal_y", "_normal_z"])
+    finally:
+        R.set_trig_mode(0)
+
+
+def test_feature_extraction_any_percentile_pair(gpu, R):
+    """Percentiles whose order statistics are not among the 16 smallest / largest heights of the disc take
+    k_features_sel (bisection on the keys of an LDS tile) also for the default radius: `step` bit-exact."""
+    rng = np.random.default_rng(31)
+    eng, ref, shape = rolled_pair(gpu, R, rng, size=20.0, res=0.05)
+    el = terrain(rng, shape, holes=0.2, noise=0.01)
+    R.set_trig_mode(1)
+    try:
+        for lo, hi in ((0.3, 0.7), (0.0, 1.0), (0.5, 0.5)):
+            both((eng, ref), lambda o: (o.set_layer("elevation", el), o.apply_feature_extraction(0.3, 4, lo, hi)))
+            exact(eng, ref, ["step", "slope", "roughness", "curvature", "_normal_x", "_normal_y", "_normal_z"])
     finally:
         R.set_trig_mode(0)
 
