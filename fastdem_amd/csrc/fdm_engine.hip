@@ -191,6 +191,7 @@ struct fdm_engine {
   int upd_blocks = 768;             // option "upd_blocks": update blocks (four tile wavefronts each) of a FUSED launch
   int upd_blocks_alone = 2048;      // option "upd_blocks_alone": ... of an update launch of its own
   int upd_prio = 1;                 // option "upd_prio": update wavefronts run at raised issue priority
+  int tiled_lds_pad = 4096;         // option "tiled_lds_pad": extra dynamic LDS per block of the large-scan bin / fused launches: 4 KB = six blocks per CU instead of seven (configs[3]: 32.3 -> 31.8 us; fewer: slower)
   int cnt_shift = 5;                // option "cnt_shift": one tile counter per 2^cnt_shift words (TilePool::cnt_shift); takes effect before the pools exist
   int bin_stagger = 0;              // option "bin_stagger": start stagger of the fused launch's first-round bin blocks (TileWork::stagger)
   size_t tile_rare_waves = 0;       // update wavefronts the rare-path scratch is sized for

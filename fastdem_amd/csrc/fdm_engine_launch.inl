@@ -167,7 +167,7 @@ int ensure_tile_pool(fdm_engine* e, size_t records, unsigned blocks, bool has_in
 
 int launch_tbin(fdm_engine* e, const ScanParams& P, const ScanInputs& in, const TilePool& Q, int32_t* ids,
                 unsigned bin_blocks, fdm_engine::BinVariant bv) {
-  const unsigned lds = tbin_lds_bytes(bv.has_int, bv.has_col, bv.threads);
+  const unsigned lds = tbin_lds_bytes(bv.has_int, bv.has_col, bv.threads) + unsigned(e->tiled_lds_pad);
   int rc = FDM_OK;
   auto go = [&](auto kern) {
     if ((rc = allow_lds(kern, lds))) return;
@@ -235,7 +235,8 @@ int launch_update_fused(fdm_engine* e, const fdm_engine::PendingUpdate& u, const
       if constexpr (kRec) {
         const unsigned ub = update_blocks(e, true);
         const TileWork K = tile_work(e, ub);
-        const unsigned lds = std::max(tile_lds_bytes(bv.has_int, bv.has_col), tbin_lds_bytes(bv.has_int, bv.has_col, bv.threads));
+        const unsigned lds = std::max(tile_lds_bytes(bv.has_int, bv.has_col), tbin_lds_bytes(bv.has_int, bv.has_col, bv.threads)) +
+                             unsigned(e->tiled_lds_pad);
         int rc = FDM_OK;
         auto go = [&](auto kern) {
           if ((rc = allow_lds(kern, lds))) return;

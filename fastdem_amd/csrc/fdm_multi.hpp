@@ -203,7 +203,10 @@ __device__ __forceinline__ bool mcrops(const MView& V, float& x, float& y, float
 
 // LDS of one block: the bin half's cell table + point staging, or the update half's event exchange.
 constexpr int kEvCap = 512;  // (cell, scan) events of a 256-cell tile exchanged per round (two per thread)
-constexpr int kMPts = 2;                 // points per thread of the bin half: 512-point blocks — half the blocks (every block
+#ifndef FDM_M_PTS
+#define FDM_M_PTS 2
+#endif
+constexpr int kMPts = FDM_M_PTS;                 // points per thread of the bin half: 512-point blocks — half the blocks (every block
 constexpr unsigned kMBlock = 256u * kMPts;  // of a 16-scan batch resident beside the update half) and ~20 % fewer (block, cell) pairs
 struct MBinLds {
   unsigned long long t_key[kMBlock];

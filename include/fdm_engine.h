@@ -487,6 +487,8 @@ int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2);
  *   "upd_prio" 0/1      : the update wavefronts raise their issue priority (default 1)
  *   "bin_stagger" n     : fused large-scan launch: start stagger of the first-round bin blocks, n x 512 cycles per
  *                         resident slot (default 0)
+ *   "tiled_lds_pad" n   : extra dynamic LDS per block of the large-scan launches, bytes (default 4096: six blocks
+ *                         per CU instead of seven)
  *   "cnt_shift" 0..5    : one tile counter per 2^n words of the counter array (default 5 = one per 128 bytes:
  *                         memory-side atomics on one line queue up); before the first large scan only
  *   "batch_walk" -1/0/1 : small-scan batches: the chain of moves walked one launch ahead (-1 = for the quantile
