@@ -469,9 +469,28 @@ int ensure_ids(fdm_engine* e, size_t n) {
   return FDM_OK;
 }
 
+// With cell records the intensity layer lives IN the record (kKalmanIntSlot / kP2IntSlot): a plain array that exists
+// when the records are (re)activated, or is created later, moves there.
+int adopt_intensity(fdm_engine* e) {
+  if (e->rec_kind < 0) return FDM_OK;
+  Layer* l = find_layer(e, "intensity");
+  if (!l || l->field >= 0) return FDM_OK;
+  const int slot = e->rec_kind == 1 ? kP2IntSlot : kKalmanIntSlot;
+  if (int rc = copy_strided(e, e->d_rec + slot, e->rec_floats, l->d, 1)) return rc;
+  if (int rc_sync = sync_all(e)) return rc_sync;
+  HIPCK(hipFree(l->d));
+  l->d = nullptr;
+  l->field = slot;
+  e->layer_ptrs_dirty = true;
+  return FDM_OK;
+}
+
 int ensure_scratch_channels(fdm_engine* e, bool intensity, bool color) {
   int rc;
-  if (intensity && !find_layer(e, "intensity") && (rc = add_layer(e, "intensity", NAN, true))) return rc;
+  if (intensity && !find_layer(e, "intensity")) {
+    if ((rc = add_layer(e, "intensity", NAN, true))) return rc;
+    if ((rc = adopt_intensity(e))) return rc;
+  }
   if (color && !find_layer(e, "color") && (rc = add_layer(e, "color", NAN, true))) return rc;
   return FDM_OK;
 }
@@ -479,6 +498,12 @@ int ensure_scratch_channels(fdm_engine* e, bool intensity, bool color) {
 float* L(fdm_engine* e, const char* n) {
   Layer* l = find_layer(e, n);
   return l ? l->d : nullptr;
+}
+// a layer that may be a record field: pointer to its element 0 and the distance between elements
+float* Lany(fdm_engine* e, const char* n, int* stride) {
+  Layer* l = find_layer(e, n);
+  *stride = l ? lstride(e, *l) : 1;
+  return l ? lptr(e, *l) : nullptr;
 }
 
 // ---- cell records: (de)activate the packed layout for the active estimator ----
@@ -525,7 +550,7 @@ int activate_records(fdm_engine* e, int kind) {
   }
   e->rec_kind = kind;
   e->layer_ptrs_dirty = true;
-  return FDM_OK;
+  return adopt_intensity(e);
 }
 
 // ---- raycasting stage: defined in fdm_engine_ray.inl (same translation unit) ----
@@ -655,7 +680,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   // 31 us against 13.8 us through the per-cell scratch; configs[3], 1444 tiles: 40.7 against 51.3 us).  Measured
   // crossover (128-beam scans of 32 K / 262 K points): 100 tiles 11.9 vs 7.4 / 15.3 vs 13.2 us (scratch wins),
   // 169 tiles 11.8 vs 7.7 / 15.0 vs 19.3, 256 tiles 12.6 vs 15.5 / 15.3 vs 24.4, 625 tiles 13.7 vs 14.4 / 16.6 vs 25.5
-  const size_t kt = e->ncell / kTileCells;
+  const size_t kt = e->ncell / 1024u;  // (the thresholds below were measured in units of 1 024 cells, round 2)
   const bool enough_tiles = e->tiled_forced || kt >= 240 || (kt >= 160 && n >= 100000);
   const bool tiled = e->tiled && e->rec_kind >= 0 && n >= e->tiled_min && aligned && n < 0x7FFF0000ull &&
                      e->bin_variant != 1 && enough_tiles;

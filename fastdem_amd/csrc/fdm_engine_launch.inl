@@ -10,12 +10,14 @@ int with_policy(fdm_engine* e, F&& f) {
   if (e->rec_kind >= 0) {  // cell records
     if (p2mode) {
       P2RecLayers Lr{};
-      Lr.rec = e->d_rec; Lr.obstacle = L(e, "obstacle"); Lr.intensity = L(e, "intensity"); Lr.color = L(e, "color");
+      Lr.rec = e->d_rec; Lr.obstacle = L(e, "obstacle"); Lr.color = L(e, "color");
+      Lr.intensity = Lany(e, "intensity", &Lr.istride);
       Lr.p = p2_params(e->cfg);
       return f(P2RecPolicy{}, Lr);
     }
     KalmanRecLayers Lr{};
-    Lr.rec = e->d_rec; Lr.obstacle = L(e, "obstacle"); Lr.intensity = L(e, "intensity"); Lr.color = L(e, "color");
+    Lr.rec = e->d_rec; Lr.obstacle = L(e, "obstacle"); Lr.color = L(e, "color");
+    Lr.intensity = Lany(e, "intensity", &Lr.istride);
     Lr.min_var = e->cfg.kalman_min_variance; Lr.max_var = e->cfg.kalman_max_variance;
     Lr.q = e->cfg.kalman_process_noise;
     return f(KalmanRecPolicy{}, Lr);

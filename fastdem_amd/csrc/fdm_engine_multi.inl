@@ -26,7 +26,7 @@ uint32_t multi_run(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) 
   if (e->obst_dense_pending || e->last_kind == 1 || e->next_drop_nonfinite) return 0u;
   if (e->dbg_no_atomics || e->dbg_upd) return 0u;
   const fdm_device_scan& f = scans[0];
-  const size_t kt = e->ncell / kTileCells;
+  const size_t kt = e->ncell / 1024u;  // (the thresholds below were measured in units of 1 024 cells, round 2)
   uint32_t run = 0;
   const uint32_t cap = std::min<uint32_t>(count, uint32_t(e->batch_max));
   for (; run < cap; ++run) {

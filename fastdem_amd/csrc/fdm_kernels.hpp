@@ -82,6 +82,7 @@ struct KalmanLayers {
   float *elevation, *elevation_min, *elevation_max, *variance, *n_points, *kalman_p, *sample_mean,
       *sample_m2, *upper, *lower, *obstacle, *intensity, *color;
   float min_var, max_var, q;
+  static constexpr int istride = 1;
 };
 struct P2Layers {
   float *elevation, *elevation_min, *elevation_max, *variance, *n_points, *upper, *lower, *obstacle,
@@ -89,6 +90,7 @@ struct P2Layers {
   float* q[5];
   float* n[5];
   P2Params p;
+  static constexpr int istride = 1;
 };
 
 // Record layout ("cell records"): the estimator state of ONE cell packed into one 64 B (Kalman) or
@@ -103,16 +105,22 @@ constexpr int kP2Rec = 32;
 enum KalmanField { KF_ELEV = 0, KF_MIN, KF_MAX, KF_VAR, KF_N, KF_P, KF_MEAN, KF_M2, KF_UP, KF_LO, KF_COUNT };
 enum P2Field { PF_ELEV = 0, PF_MIN, PF_MAX, PF_VAR, PF_N, PF_Q0, PF_N0 = PF_Q0 + 5, PF_UP = PF_N0 + 5, PF_LO, PF_COUNT };
 
+// (intensity: element o of the layer is intensity[o * istride] — with cell records the running maximum of the
+// intensity is a record field too (slot kKalmanIntSlot / kP2IntSlot: a touched cell's read-modify-write of it rides in
+// the record's line instead of being a scattered access of its own); one array per layer otherwise, istride 1)
 struct KalmanRecLayers {
   float* rec;  // [cells][kKalmanRec]
   float *obstacle, *intensity, *color;
   float min_var, max_var, q;
+  int istride;
 };
 struct P2RecLayers {
   float* rec;  // [cells][kP2Rec]
   float *obstacle, *intensity, *color;
   P2Params p;
+  int istride;
 };
+constexpr int kKalmanIntSlot = 10, kP2IntSlot = 17;  // (behind the last estimator field; cleared with the record)
 
 // Bring one input point into the map frame; returns whether it survived the crops.
 template <class PT>
@@ -914,7 +922,7 @@ __device__ __forceinline__ void update_body(
         POLICY::set_nan(stt);
       } else {
         POLICY::load(L, o, stt);
-        if (P.has_intensity) sint = L.intensity[o];
+        if (P.has_intensity) sint = L.intensity[size_t(o) * L.istride];
       }
       uint32_t rgb = 0u;
       // ---- round 3 (colour channel only): the last point's colour
@@ -937,7 +945,7 @@ __device__ __forceinline__ void update_body(
       if (P.has_intensity) {
         const float obs = (fst & 1u) ? nanv  // first point NaN -> NaN (see Scratch)
                                      : ((imx == 0x80000000u && (zsw.y & 1u)) ? -0.0f : unord(imx));
-        if (isnan(sint) || obs > sint) L.intensity[o] = obs;
+        if (isnan(sint) || obs > sint) L.intensity[size_t(o) * L.istride] = obs;
       }
       if (P.has_color) reinterpret_cast<uint32_t*>(L.color)[o] = rgb & 0x00FFFFFFu;
       S.key[o] = kEmptyKey;  // scratch is clean again for the next scan

@@ -832,7 +832,7 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
   float sint_early = nanv, lo_early = nanv;
   if (RAY && owner) {
     POLICY::load(L, o, rec_early);
-    if (has_int) sint_early = L.intensity[o];
+    if (has_int) sint_early = L.intensity[size_t(o) * L.istride];
     if (U.ray.stamp) lo_early = U.ray.logodds[o];
   }
   const unsigned runmask = RAY ? uni(unsigned(__ballot(v_run))) : 0u;  // scans whose raycasting stage runs (raycasting.cpp:207-220)
@@ -1026,7 +1026,7 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
     }
     if (!RAY && r0 == 0u && owner && tmask) {  // (the record joins the same round trip)
       POLICY::load(L, o, stt);
-      if (has_int) sint = L.intensity[o];
+      if (has_int) sint = L.intensity[size_t(o) * L.istride];
     }
 #pragma unroll
     for (int q = 0; q < kPer; ++q) {
@@ -1140,7 +1140,7 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
       POLICY::store(L, o, stt);
     }
     if (obst_dirty) L.obstacle[o] = obst;
-    if (has_int && (evt || strip_any)) L.intensity[o] = sint;
+    if (has_int && (evt || strip_any)) L.intensity[size_t(o) * L.istride] = sint;
     if (has_col && (evt || strip_any)) reinterpret_cast<uint32_t*>(L.color)[o] = colv;
     if (RAY && U.ray.stamp) {
       if (lo_dirty) U.ray.logodds[o] = lo;
