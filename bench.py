@@ -226,7 +226,12 @@ def measure_kernels(res, k0, steps, tag=None, overlap=1):
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": out[dom]["GBps"] / HBM_PEAK_GBS,
             "traffic": pmc_traffic(tag, real.get(dom, dom)),
             "avg_kernel_us": out[dom]["ms"] * 1e3,
-            "alg_bytes_per_launch": out[dom]["alg_bytes"]}
+            "alg_bytes_per_launch": out[dom]["alg_bytes"],
+            # which terms of SURVEY.md §8d the algorithmic bytes hold (a GLOBAL map has no per-scan whole-layer clear to
+            # count: its fraction is a lower bound and is NOT comparable with a LOCAL map's)
+            "alg_bytes_formula": ("points x %d B + touched cells x %d B" % (res.bytes_per_point(), res.bytes_per_cell())) +
+                                 ("" if res.wl.mode == 1 else " + map cells x 4 B (obstacle layer rewritten per scan)"),
+            "dense_term_included": res.wl.mode != 1}
     return out, roof
 
 
@@ -668,6 +673,8 @@ def main():
                         "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
                         "traffic": pmc_traffic(args.workload, "k_mbatch"), "avg_kernel_us": launch_us,
                         "alg_bytes_per_launch": alg, "scans_per_launch": batch_scans,
+                        "alg_bytes_formula": "%d scans x (%s)" % (batch_scans, roof["alg_bytes_formula"]),
+                        "dense_term_included": roof["dense_term_included"],
                         "measured": "HIP events on the engine stream around the timed region / launches"}
             roof["frac_of_measured_read_bw"] = roof["achieved"] / MEASURED_READ_GBS
             result["roofline"] = roof
@@ -744,6 +751,25 @@ def main():
                 rb["frac_of_measured_read_bw"] = rb["achieved"] / MEASURED_READ_GBS
                 rb["measured_read_bw"] = MEASURED_READ_GBS
                 big_legs = {} if args.no_host_legs else host_legs(big, big.wl, n_warm + n_big + 40, iters=12, stream_iters=40)
+                if not args.no_host_legs:
+                    # the shipped YAML's raycasting switch on (fastdem/config/default.yaml:40-41) at configs[3]: the stage
+                    # runs scan by scan behind each scan's update (scans of this size do not ride the batches)
+                    rayb = Resident(big.wl, local_rank, args.wave_merge, args.overlap)
+                    cfg_b = rayb.eng.cfg
+                    cfg_b.raycast_enabled = 1
+                    rayb.eng.set_config(cfg_b)
+                    wrb, _ = rayb.batch(0, 4)
+                    if rayb.eng.integrate_device_batch(wrb) != 0:
+                        raise RuntimeError("integrate_device_batch (large raycasting leg warm-up) failed")
+                    rayb.eng.sync()
+                    brb, _ = rayb.batch(4, 12)
+                    if rayb.eng.integrate_device_batch_timed(brb) != 0:
+                        raise RuntimeError("integrate_device_batch (large raycasting leg) failed")
+                    ray_b_us = rayb.eng.timer_ms() / 12 * 1e3
+                    big_legs["raycasting_on"] = {"us_per_scan_hip_events": ray_b_us, "scans": 12,
+                                                 "Mpts_per_s": big.wl.n_points / (ray_b_us * 1e-6) / 1e6,
+                                                 "in_batch_launches": False}
+                    del rayb
                 result["large"] = {"workload": big.wl.name, "value": bpts / dtb / 1e6, "steps": n_big,
                                    "device_value": bpts / (big_us * n_big * 1e-6) / 1e6,
                                    "unit": "Mpts/s", "ms_per_step": dtb / n_big * 1e3,

@@ -30,6 +30,7 @@
 #include "fdm_multi.hpp"
 #include "fdm_route.hpp"
 #include "fdm_raycast.hpp"
+#include "fdm_raywedge.hpp"
 #include "fdm_rbatch.hpp"
 #include "fdm_rsort.hpp"
 #include "fdm_egress.hpp"
@@ -159,6 +160,9 @@ struct fdm_engine {
   // scans from this many points up: bucketed ray queue, one lane per ray (option "ray_large_min").  Stage time, shared-
   // ray segments vs this path: 131 K points 0.48 vs 0.52 ms, 262 K 0.78 vs 0.57, 524 K 1.17 vs 0.67, RGB-D 272 K 0.23 vs 0.19
   int ray_large_min = 196608;
+  // large scans: the walk keeps an angular sector's minimum-height image in LDS (option "ray_wedge", fdm_raywedge.hpp;
+  // 0 = one lane per ray on memory-side atomics, k_ray<., 1>)
+  int ray_wedge = 1;
   // update(t) || bin(t+1) in ONE launch (k_update_bin): the update of the last small scan is held back
   // until the next scan arrives (or any other entry point / sync flushes it); the scratch is
   // double-buffered by scan parity.

@@ -79,19 +79,11 @@ int allow_lds(K kern, unsigned bytes) {
 }
 
 // Which tiles the update wavefronts of a launch walk (TileWork, fdm_tiled.hpp): `blocks` update blocks of four
-// wavefronts each.  Runs of consecutive tiles are dealt round robin; a run is one tile while a wavefront owns a
-// handful of tiles (every tile of a dense scan is live, the heavy ones are neighbours) and up to 64 on very large maps
-// (nearly every tile idle: a wavefront looks at 64 counters in one round trip).
+// wavefronts each, tiles dealt round robin.
 TileWork tile_work(const fdm_engine* e, unsigned blocks) {
   TileWork K{};
   K.W = blocks * 4u;
-  const unsigned per_wave = (e->TG.n_tiles + K.W - 1u) / K.W;
-  unsigned rs = 0u;
-  while (rs < 6u && (8u << rs) <= per_wave) ++rs;  // run = the largest power of two <= per_wave / 4, at most 64
-  K.run_shift = rs;
-  const unsigned run = 1u << rs;
-  const unsigned runs = (e->TG.n_tiles + run - 1u) / run;
-  K.T = ((runs + K.W - 1u) / K.W) * run;
+  K.T = (e->TG.n_tiles + K.W - 1u) / K.W;
   K.prio = e->upd_prio ? 1u : 0u;
   K.stagger = unsigned(e->bin_stagger);
   return K;

@@ -218,13 +218,15 @@ RayParams make_ray_params(fdm_engine* e, const fdm_raycast_config& c, const floa
   Q.flag_slot = flag_slot;
   Q.vis_stamp = 3u * unsigned(e->scan_no) + (flag_slot >= 0 ? 3u : 1u);
   Q.dbg = e->dbg_ray;
+  Q.sector_shift = -1;
   return Q;
 }
 
 // processScan + resolveGhostCells on the stream.  voxel: the points are vkeys[1]/vidx[1] runs.
-int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float* dx, const float* dy,
+int enqueue_ray_stage(fdm_engine* e, const RayParams& Q_in, bool voxel, const float* dx, const float* dy,
                       const float* dz, int key_mode) {
   int rc;
+  RayParams Q = Q_in;
   if ((rc = ensure_ray_cells(e))) return rc;
   Layer* elev = find_layer(e, "elevation");
   if (!elev) return FDM_OK;  // raycasting.cpp:213-216
@@ -252,6 +254,10 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float
   // large scans: queue bucketed by (wedge, length class) before the walk (see k_ray_compact)
   const bool large = Q.n >= unsigned(e->ray_large_min);  // one lane per ray, queue bucketed by (wedge, length)
   const bool sort_queue = large && !(e->dbg_ray & 2048);
+  // large scans walk with an angular sector's minimum-height image in LDS (fdm_raywedge.hpp): the queue is ordered
+  // (sector, length class) for it
+  const bool wedge = sort_queue && e->ray_wedge != 0;
+  if (wedge) Q.sector_shift = int(kRwSectorShift);
   uint32_t* ray_key = sort_queue ? reinterpret_cast<uint32_t*>(e->vkeys[0]) : nullptr;       // vkeys hold 2 x vcap uint32
   uint32_t* ray_rank = sort_queue ? reinterpret_cast<uint32_t*>(e->vkeys[0]) + e->vcap : nullptr;
   uint32_t* bin_cnt = sort_queue ? e->ray_bins : nullptr;
@@ -291,7 +297,23 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float
   };
   // small scans are a few hundred wavefronts of dependent round trips: 16 / 8 lanes share a ray
   // (C2: k_ray 60 -> 25 (8) -> 16 us (16)); the point count bounds the ray count from above
-  if (Q.n < (1u << 16) && !large) {
+  if (wedge) {
+    const unsigned H = std::min(unsigned(std::max(e->G.rows, e->G.cols)) + 2u, kRwRowsMax);
+    const unsigned lds = H * kRwCols * unsigned(sizeof(uint32_t));
+    // one workgroup per sector; a sector of a very dense scan is shared by several (each flushes its own window)
+    const unsigned sectors = kRayWedges >> kRwSectorShift;
+    const unsigned parts = std::max(1u, std::min(8u, Q.n / (sectors * 8u * kRwThreads)));
+    const uint32_t* bin_start = e->ray_bins + kRayBins;
+    if (tiled) {
+      if ((rc = allow_lds(k_ray_wedge<true>, lds))) return rc;
+      hipLaunchKernelGGL(k_ray_wedge<true>, dim3(sectors * parts), dim3(kRwThreads), lds, e->stream, Q, e->G, e->d_state,
+                         dx, dy, dz, ray_list, bin_start, e->rc_min, H, parts);
+    } else {
+      if ((rc = allow_lds(k_ray_wedge<false>, lds))) return rc;
+      hipLaunchKernelGGL(k_ray_wedge<false>, dim3(sectors * parts), dim3(kRwThreads), lds, e->stream, Q, e->G, e->d_state,
+                         dx, dy, dz, ray_list, bin_start, e->rc_min, H, parts);
+    }
+  } else if (Q.n < (1u << 16) && !large) {
     tiled ? launch_ray(k_ray<true, 16>, 16u) : launch_ray(k_ray<false, 16>, 16u);
   } else if (!large) {
     tiled ? launch_ray(k_ray<true, 8>, 8u) : launch_ray(k_ray<false, 8>, 8u);

@@ -44,6 +44,7 @@ struct RayParams {
   int flag_slot;        // >= 0: DevFlags slot whose ray_any gates the stage (integrate); -1: ungated
   unsigned vis_stamp;   // DevState::vis_ray value if this is the first frame that runs
   int dbg;              // measurement only: 1 = no atomics in k_ray, 2 = no loads either
+  int sector_shift;     // >= 0: queue ordered (wedge >> sector_shift, length class) for k_ray_wedge (fdm_raywedge.hpp)
 };
 
 // voxel::pack.  float -> int32 outside the int range is UB in C++; the reference's x86 build
@@ -516,7 +517,8 @@ __device__ __forceinline__ void ray_compact_body(const RayParams& Q, const GeomC
           // (measurement override: dbg bits 16..19 = log2(groups) + 1)
           unsigned cpg = kRayGroupClasses;
           if ((Q.dbg >> 16) & 15) cpg = kRayLenClasses >> (((Q.dbg >> 16) & 15) - 1);
-          key[k] = (lk / cpg) * (kRayWedges * cpg) + wedge * cpg + (lk % cpg);
+          key[k] = Q.sector_shift >= 0 ? (wedge >> unsigned(Q.sector_shift)) * kRayLenClasses + lk
+                                       : (lk / cpg) * (kRayWedges * cpg) + wedge * cpg + (lk % cpg);
           rank[k] = atomicAdd(&bin_cnt[key[k]], 1u);
         }
       }

@@ -100,14 +100,14 @@ struct TileAux {           // what the update kernel keeps per tile between scan
   unsigned long long* timeline;  // measurement only (nullable): per block of a fused launch {start, end} in 100 MHz ticks
 };
 
-// Which tiles an update wavefront walks: wavefront w of W, k-th tile = ((k >> run_shift) * W + w) << run_shift | low bits
-// of k — runs of 2^run_shift consecutive tiles dealt round robin.  run_shift 0 on maps whose every tile is live (the
-// heavy tiles around the sensor are neighbours: strided, they spread over all wavefronts); larger on very large maps
-// where nearly every tile is idle and a wavefront reads the counters of 64 tiles in one round trip.
+// Which tiles an update wavefront walks: wavefront w of W, k-th tile = k * W + w — consecutive tiles go to consecutive
+// wavefronts.  The live tiles of a scan are neighbours (on a large GLOBAL map a patch of a few thousand among a quarter
+// of a million): strided, they spread over all wavefronts.  (Runs of 8 consecutive tiles per wavefront on such a map —
+// the tile counters lie one per 128 B, a run coalesces nothing — put configs[4]'s 5 600 live tiles on 700 of the 3 072
+// wavefronts: 176 us per launch against 37.)
 struct TileWork {
   unsigned W;          // update wavefronts of the launch
-  unsigned T;          // tiles per wavefront (a multiple of the run length)
-  unsigned run_shift;
+  unsigned T;          // tiles per wavefront
   unsigned prio;       // 1: the update wavefronts raise their issue priority (option "upd_prio")
   unsigned stagger;    // fused launch: start delay of the first-round bin blocks, in units of 512 cycles per resident slot (option "bin_stagger")
 };
@@ -622,7 +622,6 @@ __device__ __forceinline__ void tupdate_wave(
   TileCtx u;
   make_tile_ctx(P, st, u, w == 0u && lane == 0u);
   if (w >= K.W) return;  // (a surplus wavefront of the grid owns nothing)
-  const unsigned run_mask = (1u << K.run_shift) - 1u;
 #pragma unroll 1
   for (unsigned p0 = 0; p0 < K.T; p0 += 64u) {
     // (kernel arguments re-read per pass, where they are used: see late())
@@ -632,7 +631,7 @@ __device__ __forceinline__ void tupdate_wave(
     const TileGrid& TGp = late<32>(TG, lz);
     const GeomConst& Gp = late<32>(G, lz);
     const unsigned k = p0 + lane;
-    const unsigned tile = (((k >> K.run_shift) * K.W + w) << K.run_shift) | (k & run_mask);
+    const unsigned tile = k * K.W + w;
     const bool valid = k < K.T && tile < TGp.n_tiles;
     unsigned nch = 0u, stamp = 0xFFFFFFFFu;
     if (valid) { nch = Qp.cnt[size_t(tile) << Qp.cnt_shift]; stamp = Ap.stamp[tile]; }

@@ -25,14 +25,15 @@ def R():
 def gpu(request):
     """fastdem_amd with a usable device; loading fails loudly if the HIP library is missing.
     Every GPU test runs twice: with the engine's own choice of pipeline by scan size, and with every
-    scan pushed through the large-scan (per-tile record pool) pipeline — an ENGINE option
-    (`tiled_min` = 1) that every Engine the tests construct receives through `Engine.default_options`;
-    nothing process-wide, nothing the product reads from the environment."""
+    scan pushed through the large-scan pipelines (per-tile record pools: `tiled_min` = 1; raycasting with the ray queue
+    ordered by sector and the walk on an LDS window, fdm_raywedge.hpp: `ray_large_min` = 1) — ENGINE options that
+    every Engine the tests construct receives through `Engine.default_options`; nothing process-wide, nothing the
+    product reads from the environment."""
     import torch
     assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
     import fastdem_amd
     fastdem_amd.capi.load()
     saved = dict(fastdem_amd.Engine.default_options)
-    fastdem_amd.Engine.default_options = {"tiled_min": 1} if request.param == "tiled_all" else {}
+    fastdem_amd.Engine.default_options = {"tiled_min": 1, "ray_large_min": 1} if request.param == "tiled_all" else {}
     yield fastdem_amd
     fastdem_amd.Engine.default_options = saved

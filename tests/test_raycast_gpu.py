@@ -254,6 +254,90 @@ class TestApplyRaycasting:
         assert_layers_equal(eng, ref)
 
 
+class TestSectorWindowWalk:
+    """Large scans walk with an angular sector's minimum-height image in LDS (fdm_raywedge.hpp): option
+    `ray_large_min` = 1 sends scans of any size that way.  The window decides only HOW a visit is stored; these cases
+    put rays on both sides of every decision it takes."""
+
+    def wedge_pair(self, gpu, R, w, h, res, **opts):
+        eng, ref = pair(gpu, R, w, h, res, ray_cfg(rc_log_odds_ghost=0.6, rc_clear_threshold=-1.0))
+        eng.set_option("ray_large_min", 1)
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        return eng, ref
+
+    def test_dense_cloud_all_directions(self, gpu, R):
+        rng = np.random.default_rng(41)
+        eng, ref = self.wedge_pair(gpu, R, 40.0, 40.0, 0.1)
+        elev = rng.uniform(-0.5, 2.5, (eng.rows, eng.cols)).astype(F32)
+        elev[rng.uniform(size=elev.shape) < 0.3] = np.nan
+        both((eng, ref), lambda o: o.set_layer("elevation", elev))
+        for frame in range(2):
+            x, y, z = random_scene(rng, 250_000, 22.0, -0.5, 3.0)  # targets inside and outside the map, some above the sensor
+            both((eng, ref), lambda o: o.apply_raycasting(x, y, z, [0.31, -0.17, 2.0]))
+            assert_layers_equal(eng, ref)
+        assert np.isfinite(eng.layer("raycasting")).sum() > 100_000
+
+    @pytest.mark.parametrize("origin", [[-28.5, 27.9, 2.5], [29.3, 0.04, 1.5], [0.0, -29.95, 3.0]])
+    def test_sensor_at_the_edge_rays_longer_than_the_window(self, gpu, R, origin):
+        """60 m map at 0.05 m (1200 cells): from a corner the rays run up to 1 600 cells — the window has 616 rows,
+        the rest of such a ray goes on with memory-side atomics from the state the window walk left."""
+        rng = np.random.default_rng(42)
+        eng, ref = self.wedge_pair(gpu, R, 60.0, 60.0, 0.05)
+        x, y, z = random_scene(rng, 60_000, 31.0, -1.0, 1.0)
+        both((eng, ref), lambda o: o.apply_raycasting(x, y, z, origin))
+        assert np.isfinite(eng.layer("raycasting")).sum() > 100_000
+        assert_layers_equal(eng, ref)
+
+    @pytest.mark.parametrize("n", [1, 7, 300, 5000])
+    def test_sparse_scans_whose_workgroups_span_wide_angles(self, gpu, R, n):
+        rng = np.random.default_rng(43 + n)
+        eng, ref = self.wedge_pair(gpu, R, 30.0, 30.0, 0.1)
+        x, y, z = random_scene(rng, n, 14.0, -1.0, 1.0)
+        both((eng, ref), lambda o: o.apply_raycasting(x, y, z, [0.0, 0.0, 1.5]))
+        assert_layers_equal(eng, ref)
+
+    def test_one_narrow_beam_and_axis_aligned_rays(self, gpu, R):
+        """Every ray in one direction (all lanes of a workgroup in the same cells), rays exactly along the axes and the
+        diagonals (ties of the DDA at every step), zero-length rays."""
+        rng = np.random.default_rng(44)
+        eng, ref = self.wedge_pair(gpu, R, 30.0, 30.0, 0.1)
+        n = 20_000
+        rad = rng.uniform(0.5, 14.0, n).astype(F32)
+        ang = F32(0.7) + rng.uniform(-0.002, 0.002, n).astype(F32)
+        x, y = (rad * np.cos(ang)).astype(F32), (rad * np.sin(ang)).astype(F32)
+        z = rng.uniform(-1.0, 0.5, n).astype(F32)
+        ax = np.linspace(-14.0, 14.0, 400).astype(F32)
+        zero = np.zeros_like(ax)
+        x = np.concatenate([x, ax, zero, ax, ax, np.full(8, 0.05, F32)])
+        y = np.concatenate([y, zero, ax, ax, -ax, np.full(8, 0.05, F32)])
+        z = np.concatenate([z, zero - 1, zero - 1, zero - 1, zero - 1, np.full(8, 0.0, F32)])
+        for origin in ([0.05, 0.05, 1.5], [0.0, 0.0, 1.5]):
+            both((eng, ref), lambda o: o.apply_raycasting(x, y, z, origin))
+            assert_layers_equal(eng, ref)
+
+    def test_the_window_and_the_memory_side_walk_agree(self, gpu, R):
+        """engine against engine at configs[3]'s density: `ray_wedge` 0 is the round-1..4 walk (one lane per ray on
+        memory-side atomics), `dbg_ray` 64 keeps every ray of the new kernel out of the window."""
+        wl = gpu.synth.lidar128(n_scans=1, n_az=4096)
+        s = wl.scan(0)
+        out = []
+        for opts in ({}, {"ray_wedge": 0}, {"dbg_ray": 64}):
+            def fill(cfg):
+                wl.apply_to(cfg)
+                return ray_cfg()(cfg)
+            eng = gpu.Engine(wl.width, wl.height, wl.resolution, fill(gpu.capi.default_config()))
+            eng.set_option("ray_large_min", 1)
+            for k, v in opts.items():
+                eng.set_option(k, v)
+            eng.integrate(s["x"], s["y"], s["z"], wl.T_base_sensor, wl.pose(0), intensity=s.get("intensity"))
+            out.append({n: eng.layer(n) for n in ("raycasting", "_visibility_logodds", "elevation")})
+        for other in out[1:]:
+            for n, a in out[0].items():
+                assert np.array_equal(a.view(np.uint32), other[n].view(np.uint32)), n
+        assert np.isfinite(out[0]["raycasting"]).sum() > 10_000
+
+
 # ------------------------------------------------- integrate() with raycasting ----
 def run_ray_workload(gpu, R, wl, n_scans, ghosts=None, **rc):
     def fill(cfg):
