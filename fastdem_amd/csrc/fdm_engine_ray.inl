@@ -218,7 +218,7 @@ RayParams make_ray_params(fdm_engine* e, const fdm_raycast_config& c, const floa
   Q.flag_slot = flag_slot;
   Q.vis_stamp = 3u * unsigned(e->scan_no) + (flag_slot >= 0 ? 3u : 1u);
   Q.dbg = e->dbg_ray;
-  Q.sector_shift = -1;
+  Q.by_sector = 0;
   return Q;
 }
 
@@ -257,7 +257,7 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q_in, bool voxel, const fl
   // large scans walk with an angular sector's minimum-height image in LDS (fdm_raywedge.hpp): the queue is ordered
   // (sector, length class) for it
   const bool wedge = sort_queue && e->ray_wedge != 0;
-  if (wedge) Q.sector_shift = int(kRwSectorShift);
+  if (wedge) Q.by_sector = 1;
   uint32_t* ray_key = sort_queue ? reinterpret_cast<uint32_t*>(e->vkeys[0]) : nullptr;       // vkeys hold 2 x vcap uint32
   uint32_t* ray_rank = sort_queue ? reinterpret_cast<uint32_t*>(e->vkeys[0]) + e->vcap : nullptr;
   uint32_t* bin_cnt = sort_queue ? e->ray_bins : nullptr;
@@ -272,10 +272,17 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q_in, bool voxel, const fl
                          dy, dz, static_cast<const uint32_t*>(nullptr), e->rc_cnt, ray_list, ray_key, ray_rank, bin_cnt);
     uint32_t* bin_start = e->ray_bins + kRayBins;
     uint32_t* bin_part = e->ray_bins + 2u * kRayBins;
-    hipLaunchKernelGGL(k_ray_bin_sum, dim3(kRayBins / kRayBinBlock), dim3(256), 0, e->stream, Q, e->G, e->d_state,
-                       bin_cnt, bin_part);
-    hipLaunchKernelGGL(k_ray_bin_scan, dim3(kRayBins / kRayBinBlock), dim3(256), 0, e->stream, Q, e->G, e->d_state,
-                       bin_cnt, bin_part, bin_start);
+    static_assert(kRaySectors * kRaySectorClasses == kRayScan1Threads * kRayScan1Per,
+                  "k_ray_bin_scan1 scans every (sector, length class) bucket");
+    if (wedge) {
+      hipLaunchKernelGGL(k_ray_bin_scan1, dim3(1), dim3(kRayScan1Threads), 0, e->stream, Q, e->G, e->d_state, bin_cnt,
+                         bin_start);
+    } else {
+      hipLaunchKernelGGL(k_ray_bin_sum, dim3(kRayBins / kRayBinBlock), dim3(256), 0, e->stream, Q, e->G, e->d_state,
+                         bin_cnt, bin_part);
+      hipLaunchKernelGGL(k_ray_bin_scan, dim3(kRayBins / kRayBinBlock), dim3(256), 0, e->stream, Q, e->G, e->d_state,
+                         bin_cnt, bin_part, bin_start);
+    }
     hipLaunchKernelGGL(k_ray_scatter, dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, ray_list, ray_key,
                        ray_rank, bin_start, e->vidx[1]);
     ray_list = e->vidx[1];
@@ -301,7 +308,7 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q_in, bool voxel, const fl
     const unsigned H = std::min(unsigned(std::max(e->G.rows, e->G.cols)) + 2u, kRwRowsMax);
     const unsigned lds = H * kRwCols * unsigned(sizeof(uint32_t));
     // one workgroup per sector; a sector of a very dense scan is shared by several (each flushes its own window)
-    const unsigned sectors = kRayWedges >> kRwSectorShift;
+    const unsigned sectors = kRaySectors;
     const unsigned parts = std::max(1u, std::min(8u, Q.n / (sectors * 8u * kRwThreads)));
     const uint32_t* bin_start = e->ray_bins + kRayBins;
     if (tiled) {

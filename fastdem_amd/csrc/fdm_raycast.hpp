@@ -44,7 +44,7 @@ struct RayParams {
   int flag_slot;        // >= 0: DevFlags slot whose ray_any gates the stage (integrate); -1: ungated
   unsigned vis_stamp;   // DevState::vis_ray value if this is the first frame that runs
   int dbg;              // measurement only: 1 = no atomics in k_ray, 2 = no loads either
-  int sector_shift;     // >= 0: queue ordered (wedge >> sector_shift, length class) for k_ray_wedge (fdm_raywedge.hpp)
+  int by_sector;        // 1: queue ordered (sector of equal true angle, coarse length class) for k_ray_wedge (fdm_raywedge.hpp)
 };
 
 // voxel::pack.  float -> int32 outside the int range is UB in C++; the reference's x86 build
@@ -473,6 +473,13 @@ __device__ __forceinline__ unsigned ray_len_key(unsigned cells) {  // group * 32
   return 96u + min(31u, (cells - 480u) / 16u);
 }
 constexpr unsigned kRayBinBlock = 1024u;  // bins per block of the two scan kernels
+// the order k_ray_wedge (fdm_raywedge.hpp) wants: 256 sectors of EQUAL true angle (a spinning LiDAR puts the same number
+// of rays into each — diamond-angle sectors are twice as wide on the diagonals as on the axes) x 32 length classes
+constexpr unsigned kRaySectors = 256u, kRaySectorClasses = 32u;
+__device__ __forceinline__ unsigned ray_sector(float dx, float dy) {
+  const float turn = (atan2f(dy, dx) + 3.14159265f) * (1.0f / 6.28318531f);  // [0, 1]
+  return min(kRaySectors - 1u, unsigned(fmaxf(turn, 0.0f) * float(kRaySectors)));
+}
 
 template <bool VOXEL, int PTS>
 __device__ __forceinline__ void ray_compact_body(const RayParams& Q, const GeomConst& G, const DevGeom& g,
@@ -517,8 +524,9 @@ __device__ __forceinline__ void ray_compact_body(const RayParams& Q, const GeomC
           // (measurement override: dbg bits 16..19 = log2(groups) + 1)
           unsigned cpg = kRayGroupClasses;
           if ((Q.dbg >> 16) & 15) cpg = kRayLenClasses >> (((Q.dbg >> 16) & 15) - 1);
-          key[k] = Q.sector_shift >= 0 ? (wedge >> unsigned(Q.sector_shift)) * kRayLenClasses + lk
-                                       : (lk / cpg) * (kRayWedges * cpg) + wedge * cpg + (lk % cpg);
+          key[k] = (lk / cpg) * (kRayWedges * cpg) + wedge * cpg + (lk % cpg);
+          if (Q.by_sector)  // (which sector a ray lands in decides nothing but speed: atan2f need not be exact)
+            key[k] = ray_sector(dx, dy) * kRaySectorClasses + lk / (kRayLenClasses / kRaySectorClasses);
           rank[k] = atomicAdd(&bin_cnt[key[k]], 1u);
         }
       }
@@ -622,6 +630,49 @@ __global__ __launch_bounds__(256) void k_ray_bin_scan(const RayParams Q, const G
   o.z = o.y + c.y;
   o.w = o.z + c.z;
   reinterpret_cast<uint4*>(bin_start)[blockIdx.x * 256u + threadIdx.x] = o;
+}
+
+// the same in ONE launch for the (sector, length class) order of k_ray_wedge, whose 8 K buckets one workgroup scans:
+// thread t owns buckets [8 t, 8 t + 8)
+constexpr unsigned kRayScan1Threads = 1024u, kRayScan1Per = 8u;
+__global__ __launch_bounds__(kRayScan1Threads) void k_ray_bin_scan1(const RayParams Q, const GeomConst G,
+                                                                    DevState* __restrict__ st,
+                                                                    uint32_t* __restrict__ bin_cnt,
+                                                                    uint32_t* __restrict__ bin_start) {
+  __shared__ unsigned s_w[kRayScan1Threads / 64u];
+  const DevGeom g = st->geom[Q.slot];
+  if (!ray_stage_runs(Q, st, g, G)) return;
+  const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  uint4* const cnt4 = reinterpret_cast<uint4*>(bin_cnt) + threadIdx.x * (kRayScan1Per / 4u);
+  uint4 c[kRayScan1Per / 4u];
+  unsigned mine = 0u;
+#pragma unroll
+  for (unsigned j = 0; j < kRayScan1Per / 4u; ++j) {
+    c[j] = cnt4[j];
+    cnt4[j] = make_uint4(0u, 0u, 0u, 0u);  // (left at zero for the next scan)
+    mine += c[j].x + c[j].y + c[j].z + c[j].w;
+  }
+  unsigned inc = mine;  // inclusive scan over the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned o = __shfl_up(inc, d);
+    if (int(lane) >= d) inc += o;
+  }
+  if (lane == 63u) s_w[w] = inc;
+  __syncthreads();
+  unsigned run = inc - mine;
+  for (unsigned v = 0; v < w; ++v) run += s_w[v];
+  uint4* const out4 = reinterpret_cast<uint4*>(bin_start) + threadIdx.x * (kRayScan1Per / 4u);
+#pragma unroll
+  for (unsigned j = 0; j < kRayScan1Per / 4u; ++j) {
+    uint4 o;
+    o.x = run;
+    o.y = o.x + c[j].x;
+    o.z = o.y + c[j].y;
+    o.w = o.z + c[j].z;
+    run = o.w + c[j].w;
+    out4[j] = o;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_ray_scatter(const RayParams Q, const GeomConst G,

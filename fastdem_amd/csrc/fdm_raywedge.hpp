@@ -3,7 +3,7 @@
 //
 // What k_ray<., 1> (fdm_raycast.hpp) costs at configs[3] is not the DDA (0.18 of its 0.58 ms) but what a visit does:
 // a coherent L2 read, a per-wavefront merge of the lanes standing in one cell and a memory-side atomic per (wavefront,
-// cell) — 4.1 M lowering events for 1.0 M cells.  Here the ray queue is ordered (sector, length class) and a
+// cell) — 4.1 M lowering events for 1.0 M cells.  Here the ray queue is ordered (sector of 1.4 deg, length class) and a
 // workgroup takes ONE sector (a share of one: blockIdx = sector * parts + part) and keeps its footprint in LDS: a
 // visit is a window read and, where that does not settle it, one ds_min_u32 — no memory-side atomic, no merge; the
 // cells a workgroup lowered are flushed once, one memory-side atomicMin each.
@@ -29,7 +29,6 @@ constexpr unsigned kRwCols = 64u;       // window columns
 constexpr unsigned kRwRowsMax = 636u;   // 636 * 64 * 4 B = 159 KB: one workgroup per CU
 constexpr unsigned kRwChunk = 16u;      // visits between two looks at the window's end
 constexpr unsigned kRwRead = 4u;        // visits between two rounds of window reads
-constexpr unsigned kRwSectorShift = 3u;  // queue order: sector = wedge >> 3 (256 sectors)
 
 __device__ __forceinline__ void rw_store(const GeomConst& G, const DevGeom& g, const bool tiled, int r, int c,
                                          uint32_t* __restrict__ rc_min, uint32_t key) {
@@ -85,10 +84,9 @@ __global__ __launch_bounds__(kRwThreads) void k_ray_wedge(const RayParams Q, con
   const unsigned n_rays = st->ray_count;
   if (n_rays == 0u) return;
   // the sector's stretch of the queue (bin_start: first queue position of every (sector, length class) bucket)
-  const unsigned sectors = kRayWedges >> unsigned(Q.sector_shift);
   const unsigned sector = blockIdx.x / parts, part = blockIdx.x - sector * parts;
-  const unsigned q_lo = bin_start[sector * kRayLenClasses];
-  const unsigned q_hi = sector + 1u < sectors ? bin_start[(sector + 1u) * kRayLenClasses] : n_rays;
+  const unsigned q_lo = bin_start[sector * kRaySectorClasses];
+  const unsigned q_hi = sector + 1u < kRaySectors ? bin_start[(sector + 1u) * kRaySectorClasses] : n_rays;
   if (q_lo + part * kRwThreads >= q_hi) return;  // (an empty sector, or a share beyond its rays)
   const DevGeom g = st->geom[Q.slot];
   const float sx = Q.ox, sy = Q.oy, sz = Q.oz;
@@ -104,17 +102,14 @@ __global__ __launch_bounds__(kRwThreads) void k_ray_wedge(const RayParams Q, con
 
   for (unsigned j = threadIdx.x; j < H * (kRwCols / 4u); j += kRwThreads)
     reinterpret_cast<uint4*>(s_win)[j] = make_uint4(kRayEmpty, kRayEmpty, kRayEmpty, kRayEmpty);
-  // the sector's band: major axis, direction and slope of its CENTRE line, from the sector's number alone (the queue's
-  // direction key is a diamond angle a in [0, 4), k_ray_compact: a = p, 2 - p, 4 + p with p = dy / (|dx| + |dy|); grid rows
-  // and columns run against x and y)
+  // the sector's band: major axis, direction and slope of its CENTRE line, from the sector's number alone (ray_sector:
+  // equal angles counted from -pi; grid rows and columns run against x and y)
   bool major_r, band_ok;
   int dir;
   float m0;
   {
-    const float a = (float(sector) + 0.5f) * (4.0f / float(sectors));
-    const float p = a < 1.0f ? a : (a < 3.0f ? 2.0f - a : a - 4.0f);
-    const float cdy = p, cdx = (a >= 1.0f && a < 3.0f) ? -(1.0f - fabsf(p)) : 1.0f - fabsf(p);
-    const float cdr = -cdx, cdc = -cdy;
+    const float ang = (float(sector) + 0.5f) * (6.28318531f / float(kRaySectors)) - 3.14159265f;
+    const float cdr = -cosf(ang), cdc = -sinf(ang);
     major_r = fabsf(cdr) >= fabsf(cdc);
     const float DMr = major_r ? cdr : cdc, DNr = major_r ? cdc : cdr;
     dir = DMr > 0 ? 1 : -1;
@@ -160,7 +155,22 @@ __global__ __launch_bounds__(kRwThreads) void k_ray_wedge(const RayParams Q, con
       // for good.  Inside a chunk there is NO lane-dependent control flow: a ray that has ended keeps stepping with its
       // keys forced to all ones (a minimum with kRayEmpty changes nothing, wherever it lands), which costs one compare,
       // one select and one OR per step — the compiler's masks for a per-lane exit cost thirteen scalar instructions.
-      bool in_win = true;
+      bool in_win = rowoff + (kRwChunk + 1u) * kRowBytes <= row_limit && 1 + int(kRwChunk) <= max_steps;
+      if (in_win) {
+        // the FIRST visit as traceRay writes it: only here can both t_max be zeros of different sign (a sensor on a cell
+        // corner), where `t_max_r < t_max_c ? t_max_r : t_max_c` and a hardware minimum may pick different zeros
+        const bool stepM = decltype(MAJOR_R)::value ? (tM < tN) : !(tN < tM);
+        const float t_exit = stepM ? tM : tN;
+        const float height = sz + ((1.0f < t_exit) ? 1.0f : t_exit) * dz;
+        atomicMin(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(s_win) + (rowoff | (uint32_t(vb) & kColMask))),
+                  ord(height));
+        dead = (t_exit >= 1.0f) ? 0xFFFFFFFFu : 0u;
+        rowoff += stepM ? kRowBytes : 0u;
+        vb += stepM ? 0 : sNb;
+        tM = stepM ? tM + dM : tM;
+        tN = stepM ? tN : tN + dN;
+        s = 1;
+      }
       while (true) {
         in_win = in_win && dead == 0u && rowoff + kRwChunk * kRowBytes <= row_limit && s + int(kRwChunk) <= max_steps;
         if (__ballot(in_win) == 0ull) break;
@@ -174,12 +184,14 @@ __global__ __launch_bounds__(kRwThreads) void k_ray_wedge(const RayParams Q, con
 #pragma unroll
             for (unsigned j = 0; j < kRwRead; ++j) {
               const bool stepM = decltype(MAJOR_R)::value ? (tM < tN) : !(tN < tM);  // traceRay's `t_max_r < t_max_c`
-              const float t_exit = stepM ? tM : tN;  // == std::min(t_max_r, t_max_c): on a tie both hold the same value
-              const float height = sz + ((1.0f < t_exit) ? 1.0f : t_exit) * dz;
+              // min(std::min(t_max_r, t_max_c), 1.0f) in one instruction (behind the first visit no two zeros meet)
+              float t_cl;
+              asm("v_min3_f32 %0, %1, %2, 1.0" : "=v"(t_cl) : "v"(tM), "v"(tN));
+              const float height = sz + t_cl * dz;
               const int hb = __float_as_int(height);
               key[j] = uint32_t(hb ^ ((hb >> 31) | int(0x80000000u))) | dead;  // ord(height)
               at[j] = rowoff | (uint32_t(vb) & kColMask);
-              dead = (t_exit >= 1.0f) ? 0xFFFFFFFFu : dead;  // traceRay leaves the loop behind this visit
+              dead = (t_cl >= 1.0f) ? 0xFFFFFFFFu : dead;  // t_exit >= 1: traceRay leaves the loop behind this visit
               rowoff += stepM ? kRowBytes : 0u;
               vb += stepM ? 0 : sNb;
               tM = stepM ? tM + dM : tM;
@@ -221,14 +233,19 @@ __global__ __launch_bounds__(kRwThreads) void k_ray_wedge(const RayParams Q, con
   }
   __syncthreads();
   // flush: the cell of window word (u, column) is the one within kRwCols / 2 of floor(m0 * u) in that column
-  for (unsigned j = threadIdx.x; j < H * kRwCols && !(Q.dbg & 4096); j += kRwThreads) {  // (dbg 4096, measurement only: no flush)
-    const uint32_t key = s_win[j];
-    if (key == kRayEmpty) continue;
-    const int u = int(j / kRwCols), col = int(j % kRwCols);
+  for (unsigned j = threadIdx.x; j < H * (kRwCols / 4u) && !(Q.dbg & 4096); j += kRwThreads) {  // (dbg 4096, measurement only: no flush)
+    const uint4 q = reinterpret_cast<const uint4*>(s_win)[j];
+    if ((q.x & q.y & q.z & q.w) == kRayEmpty) continue;
+    const int u = int(j / (kRwCols / 4u)), col0 = int(j % (kRwCols / 4u)) * 4;
     const int lo = int(floorf(m0 * float(u))) - int(kRwCols / 2u);
-    const int v = lo + ((col - lo) & int(kRwCols - 1u));
     const int M = dir * u;
-    rw_store(G, g, TILED, major_r ? r0 + M : r0 + v, major_r ? c0 + v : c0 + M, rc_min, key);
+    const uint32_t keys[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (keys[k] == kRayEmpty) continue;
+      const int v = lo + ((col0 + k - lo) & int(kRwCols - 1u));
+      rw_store(G, g, TILED, major_r ? r0 + M : r0 + v, major_r ? c0 + v : c0 + M, rc_min, keys[k]);
+    }
   }
 }
 
