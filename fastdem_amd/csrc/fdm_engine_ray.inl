@@ -66,10 +66,15 @@ int enqueue_radix_sort(fdm_engine* e, unsigned n, unsigned bits) {
     const KEY* kin = reinterpret_cast<const KEY*>(e->vkeys[src]);
     KEY* kout = reinterpret_cast<KEY*>(e->vkeys[src ^ 1]);
     const unsigned shift = unsigned(pass) * 8u;
-    hipLaunchKernelGGL(k_rs_hist<KEY>, dim3(tiles), dim3(256), 0, e->stream, n, kin, shift, tiles, hist);
+    // (the first pass's histogram is k_voxel_keys' and its indices are the positions)
+    if (pass > 0) hipLaunchKernelGGL(k_rs_hist<KEY>, dim3(tiles), dim3(256), 0, e->stream, n, kin, shift, tiles, hist);
     hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(256), 0, e->stream, tiles, hist, total);
-    hipLaunchKernelGGL(k_rs_scatter<KEY>, dim3(tiles), dim3(256), 0, e->stream, n, kin, e->vidx[src], kout,
-                       e->vidx[src ^ 1], shift, tiles, hist, total);
+    if (pass > 0)
+      hipLaunchKernelGGL((k_rs_scatter<KEY, true>), dim3(tiles), dim3(256), 0, e->stream, n, kin, e->vidx[src], kout,
+                         e->vidx[src ^ 1], shift, tiles, hist, total);
+    else
+      hipLaunchKernelGGL((k_rs_scatter<KEY, false>), dim3(tiles), dim3(256), 0, e->stream, n, kin,
+                         static_cast<const uint32_t*>(nullptr), kout, e->vidx[src ^ 1], shift, tiles, hist, total);
   }
   HIPCK(hipGetLastError());
   return FDM_OK;
@@ -178,15 +183,19 @@ int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slo
     // one bit past the fields is enough to keep the dropped points behind every voxel
     const unsigned sort_bits = unsigned(key_bits + 1);
     const int src = voxel_sort_source(sort_bits);
-    hipLaunchKernelGGL(k_voxel_keys<uint32_t>, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, inv, flag_slot, C,
-                       e->d_state, dx, dy, dz, reinterpret_cast<uint32_t*>(e->vkeys[src]), e->vidx[src], e->vsel);
+    static_assert(kVkTile == kRsTile, "k_voxel_keys leaves the first pass's histogram per sort tile");
+    const unsigned tiles = (n + kRsTile - 1u) / kRsTile;
+    hipLaunchKernelGGL(k_voxel_keys<uint32_t>, dim3(tiles), dim3(256), 0, e->stream, n, inv, flag_slot, C, e->d_state,
+                       dx, dy, dz, reinterpret_cast<uint32_t*>(e->vkeys[src]), e->vsel, tiles,
+                       static_cast<uint32_t*>(e->sort_tmp));
     HIPCK(hipGetLastError());
     return enqueue_radix_sort<uint32_t>(e, n, sort_bits);
   }
   const unsigned sort_bits = C.bits > 0 ? unsigned(key_bits + 1) : 64u;
   const int src = voxel_sort_source(sort_bits);
-  hipLaunchKernelGGL(k_voxel_keys<unsigned long long>, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, inv,
-                     flag_slot, C, e->d_state, dx, dy, dz, e->vkeys[src], e->vidx[src], e->vsel);
+  const unsigned tiles64 = (n + kRsTile - 1u) / kRsTile;
+  hipLaunchKernelGGL(k_voxel_keys<unsigned long long>, dim3(tiles64), dim3(256), 0, e->stream, n, inv, flag_slot, C,
+                     e->d_state, dx, dy, dz, e->vkeys[src], e->vsel, tiles64, static_cast<uint32_t*>(e->sort_tmp));
   HIPCK(hipGetLastError());
   return enqueue_radix_sort<unsigned long long>(e, n, sort_bits);
 }

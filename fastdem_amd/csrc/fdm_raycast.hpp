@@ -96,6 +96,10 @@ struct VoxelKeyTraits<uint32_t> {
 
 // (key, index) per point; non-finite points (and points the crops dropped, stored with x = NaN)
 // get the invalid key and therefore sort to the tail (voxel_grid_impl.hpp:50-55).
+// One block per sort tile (kVkTile = fdm_rsort.hpp's kRsTile points, 16 per thread): besides the keys it leaves the
+// FIRST pass's digit histogram of its tile (hist[bin][tile], as k_rs_hist would: one launch and one pass over the keys
+// less), and the point indices are not written at all — the first scatter pass takes "position" for them.
+constexpr unsigned kVkTile = 4096u;
 template <typename KEY>
 __global__ __launch_bounds__(256) void k_voxel_keys(unsigned n, float inv_voxel, int flag_slot,
                                                     const VoxelCompact C, DevState* __restrict__ st,
@@ -103,20 +107,29 @@ __global__ __launch_bounds__(256) void k_voxel_keys(unsigned n, float inv_voxel,
                                                     const float* __restrict__ y,
                                                     const float* __restrict__ z,
                                                     KEY* __restrict__ keys,
-                                                    uint32_t* __restrict__ idx,
-                                                    uint32_t* __restrict__ sel) {
-  const unsigned i = blockIdx.x * 256u + threadIdx.x;
-  bool valid = false;
-  if (i < n) {
-    const float a = x[i], b = y[i], c = z[i];
-    valid = isfinite(a) && isfinite(b) && isfinite(c);
-    KEY k = VoxelKeyTraits<KEY>::invalid;
-    if (valid) k = C.bits > 0 ? voxel_pack_compact<KEY>(a, b, c, inv_voxel, C) : KEY(voxel_pack(a, b, c, inv_voxel));
-    keys[i] = k;
-    idx[i] = i;
-    sel[i] = 0u;  // k_voxel_mark sets the representatives
+                                                    uint32_t* __restrict__ sel,
+                                                    unsigned ntiles, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0u;
+  __syncthreads();
+  bool any = false;
+#pragma unroll 4
+  for (unsigned r = 0; r < kVkTile / 256u; ++r) {
+    const unsigned i = blockIdx.x * kVkTile + r * 256u + threadIdx.x;
+    if (i < n) {
+      const float a = x[i], b = y[i], c = z[i];
+      const bool valid = isfinite(a) && isfinite(b) && isfinite(c);
+      KEY k = VoxelKeyTraits<KEY>::invalid;
+      if (valid) k = C.bits > 0 ? voxel_pack_compact<KEY>(a, b, c, inv_voxel, C) : KEY(voxel_pack(a, b, c, inv_voxel));
+      keys[i] = k;
+      sel[i] = 0u;  // k_voxel_mark sets the representatives
+      atomicAdd(&h[unsigned(k) & 255u], 1u);
+      any = any || valid;
+    }
   }
-  if (flag_slot >= 0 && __ballot(valid) && (threadIdx.x & 63) == 0) st->flags[flag_slot].ray_any = 1u;
+  if (flag_slot >= 0 && __ballot(any) && (threadIdx.x & 63) == 0) st->flags[flag_slot].ray_any = 1u;
+  __syncthreads();
+  hist[size_t(threadIdx.x) * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
 __device__ __forceinline__ bool map_contains(double x, double y, const DevGeom& g, const GeomConst& G) {

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_rs_scan(unsigned ntiles, uint32_t* __re
   if (t == 0) total[blockIdx.x] = s_carry;
 }
 
-template <typename KEY>
+template <typename KEY, bool HAS_IDX>  // HAS_IDX false: the first pass, a pair's index is its position
 __global__ __launch_bounds__(256) void k_rs_scatter(unsigned n, const KEY* __restrict__ keys_in,
                                                     const uint32_t* __restrict__ idx_in, KEY* __restrict__ keys_out,
                                                     uint32_t* __restrict__ idx_out, unsigned shift, unsigned ntiles,
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_rs_scatter(unsigned n, const KEY* __res
     const unsigned i = w_base + unsigned(r) * 64u + lane;
     k_[r] = KEY(0);
     i_[r] = 0u;
-    if (i < n) { k_[r] = keys_in[i]; i_[r] = idx_in[i]; }
+    if (i < n) { k_[r] = keys_in[i]; i_[r] = HAS_IDX ? idx_in[i] : i; }
   }
   // first place of every digit in this tile: exclusive scan of the 256 totals + the tile's prefix
   uint32_t tile_base;
