@@ -51,7 +51,7 @@ constexpr uint32_t kCitMask = (1u << kCitBits) - 1u;
 constexpr uint32_t kNoWinner = 0xFFFFFFFFu;
 constexpr uint32_t kOrdZero = 0x80000000u;  // ord(+0.0f)
 #ifndef FDM_UPD_WAVES
-#define FDM_UPD_WAVES 7  // min waves per SIMD the large-scan kernels are compiled for (<= 72 VGPRs); the LDS allows 7 blocks per CU
+#define FDM_UPD_WAVES 6  // min waves per SIMD the large-scan kernels are compiled for (<= 80 VGPRs): six blocks per CU are what the launch runs with (tiled_lds_pad)
 #endif
 
 // flags beside the cell-in-tile number (8 bits) of a record
