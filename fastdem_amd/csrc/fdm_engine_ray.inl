@@ -46,7 +46,7 @@ int ensure_voxel_buffers(fdm_engine* e, size_t n) {
   }
   HIPCK(hipMalloc(reinterpret_cast<void**>(&e->vsel), e->vcap * sizeof(uint32_t)));
   // the radix sort's histogram: 256 bins x tiles, + the 256 totals (fdm_rsort.hpp)
-  const size_t tiles = (e->vcap + kRsTile - 1) / kRsTile;
+  const size_t tiles = std::max((e->vcap + kRsTile - 1) / kRsTile, (size_t(kRsSmallMax) + kRsTileSmall - 1) / kRsTileSmall);
   e->sort_tmp_bytes = (256u * tiles + 256u) * sizeof(uint32_t);
   HIPCK(hipMalloc(&e->sort_tmp, e->sort_tmp_bytes));
   return FDM_OK;
@@ -56,9 +56,9 @@ int ensure_voxel_buffers(fdm_engine* e, size_t n) {
 // (vkeys[1], vidx[1]).  `src` must be voxel_sort_source(bits): the buffers alternate once per pass.
 int voxel_sort_passes(unsigned bits) { return int((bits + 7u) / 8u); }
 int voxel_sort_source(unsigned bits) { return (voxel_sort_passes(bits) & 1) ? 0 : 1; }
-template <typename KEY>
-int enqueue_radix_sort(fdm_engine* e, unsigned n, unsigned bits) {
-  const unsigned tiles = (n + kRsTile - 1u) / kRsTile;
+template <typename KEY, unsigned TILE>
+int enqueue_radix_sort_t(fdm_engine* e, unsigned n, unsigned bits) {
+  const unsigned tiles = (n + TILE - 1u) / TILE;
   uint32_t* const hist = static_cast<uint32_t*>(e->sort_tmp);
   uint32_t* const total = hist + size_t(256) * tiles;
   int src = voxel_sort_source(bits);
@@ -67,17 +67,35 @@ int enqueue_radix_sort(fdm_engine* e, unsigned n, unsigned bits) {
     KEY* kout = reinterpret_cast<KEY*>(e->vkeys[src ^ 1]);
     const unsigned shift = unsigned(pass) * 8u;
     // (the first pass's histogram is k_voxel_keys' and its indices are the positions)
-    if (pass > 0) hipLaunchKernelGGL(k_rs_hist<KEY>, dim3(tiles), dim3(256), 0, e->stream, n, kin, shift, tiles, hist);
+    if (pass > 0)
+      hipLaunchKernelGGL((k_rs_hist<KEY, TILE>), dim3(tiles), dim3(256), 0, e->stream, n, kin, shift, tiles, hist);
     hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(256), 0, e->stream, tiles, hist, total);
     if (pass > 0)
-      hipLaunchKernelGGL((k_rs_scatter<KEY, true>), dim3(tiles), dim3(256), 0, e->stream, n, kin, e->vidx[src], kout,
-                         e->vidx[src ^ 1], shift, tiles, hist, total);
+      hipLaunchKernelGGL((k_rs_scatter<KEY, true, int(TILE / 256u)>), dim3(tiles), dim3(256), 0, e->stream, n, kin,
+                         e->vidx[src], kout, e->vidx[src ^ 1], shift, tiles, hist, total);
     else
-      hipLaunchKernelGGL((k_rs_scatter<KEY, false>), dim3(tiles), dim3(256), 0, e->stream, n, kin,
+      hipLaunchKernelGGL((k_rs_scatter<KEY, false, int(TILE / 256u)>), dim3(tiles), dim3(256), 0, e->stream, n, kin,
                          static_cast<const uint32_t*>(nullptr), kout, e->vidx[src ^ 1], shift, tiles, hist, total);
   }
   HIPCK(hipGetLastError());
   return FDM_OK;
+}
+template <typename KEY>
+int enqueue_radix_sort(fdm_engine* e, unsigned n, unsigned bits) {
+  return rs_tile(n) == kRsTileSmall ? enqueue_radix_sort_t<KEY, kRsTileSmall>(e, n, bits)
+                                    : enqueue_radix_sort_t<KEY, kRsTile>(e, n, bits);
+}
+template <typename KEY>
+void launch_voxel_keys(fdm_engine* e, unsigned n, float inv, int flag_slot, const VoxelCompact& C, const float* dx,
+                       const float* dy, const float* dz, KEY* keys) {
+  const unsigned tile = rs_tile(n), tiles = (n + tile - 1u) / tile;
+  uint32_t* const hist = static_cast<uint32_t*>(e->sort_tmp);
+  if (tile == kRsTileSmall)
+    hipLaunchKernelGGL((k_voxel_keys<KEY, kRsTileSmall>), dim3(tiles), dim3(256), 0, e->stream, n, inv, flag_slot, C,
+                       e->d_state, dx, dy, dz, keys, e->vsel, tiles, hist);
+  else
+    hipLaunchKernelGGL((k_voxel_keys<KEY, kRsTile>), dim3(tiles), dim3(256), 0, e->stream, n, inv, flag_slot, C,
+                       e->d_state, dx, dy, dz, keys, e->vsel, tiles, hist);
 }
 
 // keys -> stable sort: vkeys[1] / vidx[1] hold the voxel-ordered scan afterwards.
@@ -183,19 +201,13 @@ int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slo
     // one bit past the fields is enough to keep the dropped points behind every voxel
     const unsigned sort_bits = unsigned(key_bits + 1);
     const int src = voxel_sort_source(sort_bits);
-    static_assert(kVkTile == kRsTile, "k_voxel_keys leaves the first pass's histogram per sort tile");
-    const unsigned tiles = (n + kRsTile - 1u) / kRsTile;
-    hipLaunchKernelGGL(k_voxel_keys<uint32_t>, dim3(tiles), dim3(256), 0, e->stream, n, inv, flag_slot, C, e->d_state,
-                       dx, dy, dz, reinterpret_cast<uint32_t*>(e->vkeys[src]), e->vsel, tiles,
-                       static_cast<uint32_t*>(e->sort_tmp));
+    launch_voxel_keys<uint32_t>(e, n, inv, flag_slot, C, dx, dy, dz, reinterpret_cast<uint32_t*>(e->vkeys[src]));
     HIPCK(hipGetLastError());
     return enqueue_radix_sort<uint32_t>(e, n, sort_bits);
   }
   const unsigned sort_bits = C.bits > 0 ? unsigned(key_bits + 1) : 64u;
   const int src = voxel_sort_source(sort_bits);
-  const unsigned tiles64 = (n + kRsTile - 1u) / kRsTile;
-  hipLaunchKernelGGL(k_voxel_keys<unsigned long long>, dim3(tiles64), dim3(256), 0, e->stream, n, inv, flag_slot, C,
-                     e->d_state, dx, dy, dz, e->vkeys[src], e->vsel, tiles64, static_cast<uint32_t*>(e->sort_tmp));
+  launch_voxel_keys<unsigned long long>(e, n, inv, flag_slot, C, dx, dy, dz, e->vkeys[src]);
   HIPCK(hipGetLastError());
   return enqueue_radix_sort<unsigned long long>(e, n, sort_bits);
 }
@@ -271,14 +283,21 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q_in, bool voxel, const fl
   uint32_t* ray_rank = sort_queue ? reinterpret_cast<uint32_t*>(e->vkeys[0]) + e->vcap : nullptr;
   uint32_t* bin_cnt = sort_queue ? e->ray_bins : nullptr;
   if (sort_queue) {
-    constexpr unsigned kPts = 8;
-    const unsigned cblocks = (Q.n + 256u * kPts - 1u) / (256u * kPts);
-    if (voxel)
-      hipLaunchKernelGGL((k_ray_compact<true, kPts>), dim3(cblocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx,
-                         dy, dz, e->vsel, e->rc_cnt, ray_list, ray_key, ray_rank, bin_cnt);
-    else
-      hipLaunchKernelGGL((k_ray_compact<false, kPts>), dim3(cblocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx,
-                         dy, dz, static_cast<const uint32_t*>(nullptr), e->rc_cnt, ray_list, ray_key, ray_rank, bin_cnt);
+    // points per thread of the queue builder: 8 on multi-million-point scans (the queue tail is one same-address
+    // returning atomic per block), 2 below (a 272 K-point scan is 133 blocks of 2 048 points: half the chip)
+    auto compact = [&](auto PTS) {
+      constexpr unsigned kPts = decltype(PTS)::value;
+      const unsigned cblocks = (Q.n + 256u * kPts - 1u) / (256u * kPts);
+      if (voxel)
+        hipLaunchKernelGGL((k_ray_compact<true, int(kPts)>), dim3(cblocks), dim3(256), 0, e->stream, Q, e->G, e->d_state,
+                           dx, dy, dz, e->vsel, e->rc_cnt, ray_list, ray_key, ray_rank, bin_cnt);
+      else
+        hipLaunchKernelGGL((k_ray_compact<false, int(kPts)>), dim3(cblocks), dim3(256), 0, e->stream, Q, e->G, e->d_state,
+                           dx, dy, dz, static_cast<const uint32_t*>(nullptr), e->rc_cnt, ray_list, ray_key, ray_rank,
+                           bin_cnt);
+    };
+    if (Q.n <= kRsSmallMax) compact(std::integral_constant<unsigned, 2>{});
+    else compact(std::integral_constant<unsigned, 8>{});
     uint32_t* bin_start = e->ray_bins + kRayBins;
     uint32_t* bin_part = e->ray_bins + 2u * kRayBins;
     static_assert(kRaySectors * kRaySectorClasses == kRayScan1Threads * kRayScan1Per,
@@ -318,7 +337,8 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q_in, bool voxel, const fl
     const unsigned lds = H * kRwCols * unsigned(sizeof(uint32_t));
     // one workgroup per sector; a sector of a very dense scan is shared by several (each flushes its own window)
     const unsigned sectors = kRaySectors;
-    const unsigned parts = std::max(1u, std::min(8u, Q.n / (sectors * 8u * kRwThreads)));
+    // (mid-size scans are cameras: a 60-degree field of view puts 100 K rays into 43 of the 256 sectors)
+    const unsigned parts = Q.n <= kRsSmallMax ? 4u : std::max(1u, std::min(8u, Q.n / (sectors * 8u * kRwThreads)));
     const uint32_t* bin_start = e->ray_bins + kRayBins;
     if (tiled) {
       if ((rc = allow_lds(k_ray_wedge<true>, lds))) return rc;

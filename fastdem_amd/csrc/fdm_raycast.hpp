@@ -96,11 +96,10 @@ struct VoxelKeyTraits<uint32_t> {
 
 // (key, index) per point; non-finite points (and points the crops dropped, stored with x = NaN)
 // get the invalid key and therefore sort to the tail (voxel_grid_impl.hpp:50-55).
-// One block per sort tile (kVkTile = fdm_rsort.hpp's kRsTile points, 16 per thread): besides the keys it leaves the
+// One block per sort tile (TILE = fdm_rsort.hpp's rs_tile(n) points): besides the keys it leaves the
 // FIRST pass's digit histogram of its tile (hist[bin][tile], as k_rs_hist would: one launch and one pass over the keys
 // less), and the point indices are not written at all — the first scatter pass takes "position" for them.
-constexpr unsigned kVkTile = 4096u;
-template <typename KEY>
+template <typename KEY, unsigned TILE>
 __global__ __launch_bounds__(256) void k_voxel_keys(unsigned n, float inv_voxel, int flag_slot,
                                                     const VoxelCompact C, DevState* __restrict__ st,
                                                     const float* __restrict__ x,
@@ -114,8 +113,8 @@ __global__ __launch_bounds__(256) void k_voxel_keys(unsigned n, float inv_voxel,
   __syncthreads();
   bool any = false;
 #pragma unroll 4
-  for (unsigned r = 0; r < kVkTile / 256u; ++r) {
-    const unsigned i = blockIdx.x * kVkTile + r * 256u + threadIdx.x;
+  for (unsigned r = 0; r < TILE / 256u; ++r) {
+    const unsigned i = blockIdx.x * TILE + r * 256u + threadIdx.x;
     if (i < n) {
       const float a = x[i], b = y[i], c = z[i];
       const bool valid = isfinite(a) && isfinite(b) && isfinite(c);

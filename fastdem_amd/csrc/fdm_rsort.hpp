@@ -4,7 +4,7 @@
 // Reference being served: lib/nanoPCL/include/nanopcl/filters/impl/voxel_grid_impl.hpp:56-63 (sort of the
 // (key, index) array) — the engine needs the STABLE order (ties in point order, see fdm_raycast.hpp).
 //
-// Eight bits per pass, three launches per pass, tiles of 4096 pairs:
+// Eight bits per pass, three launches per pass, tiles of 4096 pairs (1024 for sorts of up to 600 K pairs):
 //   k_rs_hist     per tile: digit histogram (LDS atomics), written bin-major  hist[bin][tile]
 //   k_rs_scan     one block per bin: exclusive prefix over the tiles in place, the bin's total
 //   k_rs_scatter  per tile: bases = scan of the 256 totals (every block, in LDS) + hist[bin][tile]; the tile's pairs stay
@@ -24,18 +24,20 @@
 
 namespace fdm {
 
-constexpr unsigned kRsTile = 4096u;   // pairs per block
-constexpr int kRsRounds = 16;         // per wavefront: 16 x 64 pairs
+constexpr unsigned kRsTile = 4096u;       // pairs per block ...
+constexpr unsigned kRsTileSmall = 1024u;  // ... and for sorts of up to kRsSmallMax pairs (a 272 K-point scan is 67 tiles of 4 096:
+constexpr unsigned kRsSmallMax = 600000u; // a quarter of the chip; 266 of 1 024)
+__host__ __device__ constexpr unsigned rs_tile(unsigned n) { return n <= kRsSmallMax ? kRsTileSmall : kRsTile; }
 
-template <typename KEY>
+template <typename KEY, unsigned TILE>
 __global__ __launch_bounds__(256) void k_rs_hist(unsigned n, const KEY* __restrict__ keys, unsigned shift,
                                                  unsigned ntiles, uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[256];
   h[threadIdx.x] = 0u;
   __syncthreads();
-  const unsigned base = blockIdx.x * kRsTile;
+  const unsigned base = blockIdx.x * TILE;
 #pragma unroll 4
-  for (int r = 0; r < 16; ++r) {
+  for (int r = 0; r < int(TILE / 256u); ++r) {
     const unsigned i = base + unsigned(r) * 256u + threadIdx.x;
     if (i < n) atomicAdd(&h[unsigned(keys[i] >> shift) & 255u], 1u);
   }
@@ -83,7 +85,8 @@ __global__ __launch_bounds__(256) void k_rs_scan(unsigned ntiles, uint32_t* __re
   if (t == 0) total[blockIdx.x] = s_carry;
 }
 
-template <typename KEY, bool HAS_IDX>  // HAS_IDX false: the first pass, a pair's index is its position
+// HAS_IDX false: the first pass, a pair's index is its position.  ROUNDS: 64-pair rounds per wavefront (tile = 256 x ROUNDS)
+template <typename KEY, bool HAS_IDX, int ROUNDS>
 __global__ __launch_bounds__(256) void k_rs_scatter(unsigned n, const KEY* __restrict__ keys_in,
                                                     const uint32_t* __restrict__ idx_in, KEY* __restrict__ keys_out,
                                                     uint32_t* __restrict__ idx_out, unsigned shift, unsigned ntiles,
@@ -92,7 +95,8 @@ __global__ __launch_bounds__(256) void k_rs_scatter(unsigned n, const KEY* __res
   __shared__ uint32_t s_wave[4];
   const unsigned t = threadIdx.x, lane = t & 63u, wave = t >> 6;
   // the pairs of this thread: round r of its wavefront, lane `lane` (issued first)
-  const unsigned w_base = blockIdx.x * kRsTile + wave * 1024u;
+  constexpr int kRsRounds = ROUNDS;
+  const unsigned w_base = blockIdx.x * (256u * unsigned(ROUNDS)) + wave * (64u * unsigned(ROUNDS));
   KEY k_[kRsRounds];
   uint32_t i_[kRsRounds];
 #pragma unroll
