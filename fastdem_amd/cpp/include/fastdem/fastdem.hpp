@@ -10,6 +10,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "fastdem/config/fastdem.hpp"
@@ -19,6 +20,7 @@
 #include "fastdem/postprocess/raycasting.hpp"
 #include "fastdem/sensors/sensor_model.hpp"
 #include "fastdem/transform_interface.hpp"
+#include "nanopcl/point_cloud4.hpp"
 
 namespace fastdem {
 
@@ -128,6 +130,46 @@ class FastDEM {
 
   /// Explicit transforms (fastdem.cpp:122-131).
   bool integrate(const PointCloud& cloud, const Eigen::Isometry3d& T_base_sensor,
+                 const Eigen::Isometry3d& T_world_base) {
+    if (cloud.empty()) {
+      std::fprintf(stderr, "[warn] [FastDEM] Received empty cloud. Skipping...\n");
+      return false;
+    }
+    return integrateImpl(cloud, T_base_sensor, T_world_base);
+  }
+
+  /// The same two calls for a cloud in the REFERENCE's storage layout (nanopcl::PointCloud4: `points()` = contiguous
+  /// {x, y, z, 1} records, nanopcl/core/point_cloud.hpp:126-134): `points().data()` goes to the engine as it is
+  /// (fdm_engine_integrate_points4; pinned records are read in place with 16-byte loads).  Synchronous.
+  bool integrate(std::shared_ptr<nanopcl::PointCloud4> cloud) {
+    if (!calibration_ || !odometry_) {
+      std::fprintf(stderr, "[error] [FastDEM] Transform providers not set. Call setTransformProvider() or "
+                           "setCalibrationProvider()/setOdometryProvider() first, or use integrate(cloud, "
+                           "T_base_sensor, T_world_base) for explicit transforms.\n");
+      return false;
+    }
+    if (!cloud || cloud->empty()) {
+      std::fprintf(stderr, "[warn] [FastDEM] Received empty or null cloud. Skipping...\n");
+      return false;
+    }
+    if (cloud->frameId().empty()) {
+      std::fprintf(stderr, "[error] [FastDEM] Input cloud has no frameId. Skipping...\n");
+      return false;
+    }
+    auto T_base_sensor = calibration_->getExtrinsic(cloud->frameId());
+    if (!T_base_sensor) {
+      std::fprintf(stderr, "[warn] [FastDEM] Calibration not available for '%s'. Skipping...\n", cloud->frameId().c_str());
+      return false;
+    }
+    auto T_world_base = odometry_->getPoseAt(cloud->timestamp());
+    if (!T_world_base) {
+      std::fprintf(stderr, "[warn] [FastDEM] Odometry not available at %llu. Skipping...\n",
+                   static_cast<unsigned long long>(cloud->timestamp()));
+      return false;
+    }
+    return integrateImpl(*cloud, *T_base_sensor, *T_world_base);
+  }
+  bool integrate(const nanopcl::PointCloud4& cloud, const Eigen::Isometry3d& T_base_sensor,
                  const Eigen::Isometry3d& T_world_base) {
     if (cloud.empty()) {
       std::fprintf(stderr, "[warn] [FastDEM] Received empty cloud. Skipping...\n");
@@ -283,10 +325,33 @@ class FastDEM {
     return eff;
   }
   // integrateImpl (fastdem.cpp:133-162): preprocessScan + ElevationMapping::update, on the device
-  bool integrateImpl(const PointCloud& cloud, const Eigen::Isometry3d& T_base_sensor,
+  // (CLOUD: nanopcl::PointCloud — SoA channels — or nanopcl::PointCloud4 — the reference's xyz1 records)
+  int engineIntegrate(const PointCloud& cloud, const float* sigma, const Eigen::Isometry3d& T_base_sensor,
+                      const Eigen::Isometry3d& T_world_base) {
+    return fdm_engine_integrate(map_.engine(), cloud.size(), cloud.xData(), cloud.yData(), cloud.zData(),
+                                cloud.intensityData(), cloud.rgbData(), sigma, T_base_sensor.matrix().data(),
+                                T_world_base.matrix().data(), &last_);
+  }
+  int engineIntegrate(const nanopcl::PointCloud4& cloud, const float* sigma, const Eigen::Isometry3d& T_base_sensor,
+                      const Eigen::Isometry3d& T_world_base) {
+    return fdm_engine_integrate_points4(map_.engine(), cloud.size(), cloud.xyz1Data(), cloud.intensityData(),
+                                        cloud.rgbData(), sigma, T_base_sensor.matrix().data(),
+                                        T_world_base.matrix().data(), &last_);
+  }
+  template <class CLOUD>
+  bool integrateImpl(const CLOUD& cloud, const Eigen::Isometry3d& T_base_sensor,
                      const Eigen::Isometry3d& T_world_base) {
     SensorType bi;
-    if (queued_ && !on_preprocessed_ && !on_rasterized_ && (!sensor_model_ || sensor_model_->builtin(bi))) {
+    if (std::is_same<CLOUD, PointCloud>::value && queued_ && !on_preprocessed_ && !on_rasterized_ &&
+        (!sensor_model_ || sensor_model_->builtin(bi))) {
+      return integrateQueued(cloud, T_base_sensor, T_world_base);
+    }
+    return integrateSync(cloud, T_base_sensor, T_world_base);
+  }
+  bool integrateQueued(const nanopcl::PointCloud4&, const Eigen::Isometry3d&, const Eigen::Isometry3d&) { return false; }  // (never taken)
+  bool integrateQueued(const PointCloud& cloud, const Eigen::Isometry3d& T_base_sensor,
+                       const Eigen::Isometry3d& T_world_base) {
+    {
       map_.flushToDevice();  // (host writes to the map since the last call; nothing to do when there were none)
       if (cfg_dirty_) {      // (the engine takes its parameters when a scan is ENQUEUED: scans already queued keep theirs)
         const fdm_config fq = detail::toEngineConfig(effectiveConfig());
@@ -301,6 +366,10 @@ class FastDEM {
       map_.invalidateHost();
       return true;
     }
+  }
+  template <class CLOUD>
+  bool integrateSync(const CLOUD& cloud, const Eigen::Isometry3d& T_base_sensor,
+                     const Eigen::Isometry3d& T_world_base) {
     drain();
     map_.flushToDevice();
     Config eff = effectiveConfig();
@@ -323,9 +392,7 @@ class FastDEM {
     const fdm_config f = detail::toEngineConfig(eff);
     detail::ck(fdm_engine_set_config(map_.engine(), &f), "fdm_engine_set_config");
     cfg_dirty_ = false;
-    const int rc = fdm_engine_integrate(map_.engine(), cloud.size(), cloud.xData(), cloud.yData(), cloud.zData(),
-                                        cloud.intensityData(), cloud.rgbData(), sigma,
-                                        T_base_sensor.matrix().data(), T_world_base.matrix().data(), &last_);
+    const int rc = engineIntegrate(cloud, sigma, T_base_sensor, T_world_base);
     detail::ck(rc, "fdm_engine_integrate");
     map_.invalidateHost();
     if (rc != FDM_OK) return false;  // FDM_SKIP_ALL_FILTERED == `if (points.empty()) return false`
@@ -340,7 +407,9 @@ class FastDEM {
     detail::ck(fdm_engine_capture(map_.engine(), on_preprocessed_ ? 2 : 0, on_rasterized_ ? 1 : 0),
                "fdm_engine_capture");
   }
-  PointCloud fetch(bool preprocessed, size_t cap, const PointCloud* src = nullptr) {
+  PointCloud fetch(bool preprocessed, size_t cap) { return fetch<PointCloud>(preprocessed, cap, nullptr); }
+  template <class CLOUD>
+  PointCloud fetch(bool preprocessed, size_t cap, const CLOUD* src) {
     std::vector<float> x(cap), y(cap), z(cap);
     uint64_t n = 0;
     if (preprocessed)

@@ -1102,4 +1102,180 @@ TEST(IntegrateBatch, WithRaycastingTheStageOfEveryScanRidesInTheBatch) {
   EXPECT_TRUE(sameMaps(m_one, m_q));
 }
 
+// ---- nanopcl::PointCloud4: the reference's own cloud layout (nanoPCL tests/test_pointcloud.cpp, test_channels.cpp,
+// test_index_range.cpp re-expressed) and FastDEM::integrate on it ----
+TEST(PointCloud4, ConstructorsAddAndTheTwoAccessors) {  // test_pointcloud.cpp:21-85
+  nanopcl::PointCloud4 empty;
+  EXPECT_EQ(empty.size(), 0u);
+  EXPECT_TRUE(empty.empty());
+  nanopcl::PointCloud4 sized(100);
+  EXPECT_EQ(sized.size(), 100u);
+  EXPECT_EQ(sized[99].w(), 1.0f);  // resize() fills with (0, 0, 0, 1)
+  nanopcl::PointCloud4 c;
+  c.add(1.0f, 2.0f, 3.0f);
+  EXPECT_EQ(c.size(), 1u);
+  EXPECT_EQ(c.point(0).x(), 1.0f);
+  EXPECT_EQ(c.point(0).y(), 2.0f);
+  EXPECT_EQ(c.point(0).z(), 3.0f);
+  EXPECT_EQ(c[0].w(), 1.0f);
+  const Eigen::Vector3f p = c.point(0);
+  EXPECT_EQ(p.x(), 1.0f);
+  c.point(0).x() = 10.0f;  // the 3-D view writes into the record
+  EXPECT_EQ(c[0].x(), 10.0f);
+  c[0] = nanopcl::Point4(c[0].x() + 100.0f, c[0].y(), c[0].z(), c[0].w());  // (the "expert" 4-D access)
+  EXPECT_EQ(c.point(0).x(), 110.0f);
+  for (int i = 0; i < 100; ++i) c.add(float(i), float(i), float(i));
+  EXPECT_EQ(c.size(), 101u);
+  EXPECT_EQ(c.point(51).x(), 50.0f);
+}
+TEST(PointCloud4, ResizeReserveClearReset) {  // test_pointcloud.cpp:103-142
+  nanopcl::PointCloud4 c;
+  c.add(1, 2, 3);
+  c.add(4, 5, 6);
+  c.resize(10);
+  EXPECT_EQ(c.size(), 10u);
+  EXPECT_EQ(c.point(0).x(), 1.0f);
+  EXPECT_EQ(c.point(1).x(), 4.0f);
+  nanopcl::PointCloud4 r;
+  r.reserve(1000);
+  EXPECT_TRUE(r.capacity() >= 1000u);
+  EXPECT_EQ(r.size(), 0u);
+  nanopcl::PointCloud4 k;
+  k.add(1, 2, 3, nanopcl::Intensity(0.5f));
+  k.clear();
+  EXPECT_EQ(k.size(), 0u);
+  EXPECT_TRUE(k.hasIntensity());  // clear() keeps the channel structure ...
+  k.add(1, 2, 3, nanopcl::Intensity(0.5f));
+  k.setFrameId("lidar");
+  k.reset();
+  EXPECT_FALSE(k.hasIntensity());  // ... reset() drops it, and the metadata
+  EXPECT_TRUE(k.frameId().empty());
+}
+TEST(PointCloud4, PointsIsOneContiguousArrayOfAligned16ByteRecords) {  // test_pointcloud.cpp:144-160, point_cloud.hpp:126
+  nanopcl::PointCloud4 c;
+  for (int i = 0; i < 33; ++i) c.add(float(i), float(2 * i), float(3 * i));
+  EXPECT_EQ(c.points().size(), 33u);
+  EXPECT_EQ(reinterpret_cast<uintptr_t>(c.points().data()) % 16u, 0u);
+  const float* raw = c.xyz1Data();
+  for (int i = 0; i < 33; ++i) {
+    EXPECT_EQ(raw[4 * i + 0], float(i));
+    EXPECT_EQ(raw[4 * i + 1], float(2 * i));
+    EXPECT_EQ(raw[4 * i + 2], float(3 * i));
+    EXPECT_EQ(raw[4 * i + 3], 1.0f);
+  }
+}
+TEST(PointCloud4, MetadataAndTimestampHelpers) {  // test_pointcloud.cpp:162-189
+  nanopcl::PointCloud4 c;
+  c.setFrameId("os_sensor");
+  EXPECT_EQ(c.frameId(), std::string("os_sensor"));
+  c.setTimestamp(1500000000ull);
+  EXPECT_EQ(c.timestamp(), 1500000000ull);
+  EXPECT_NEAR(nanopcl::toSec(1500000000ull), 1.5, 1e-9);
+  EXPECT_EQ(nanopcl::fromSec(2.5), 2500000000ull);
+}
+TEST(PointCloud4, ChannelsFollowThePoints) {  // test_channels.cpp:21-140
+  nanopcl::PointCloud4 c;
+  EXPECT_FALSE(c.hasIntensity() || c.hasTime() || c.hasRing() || c.hasColor() || c.hasLabel() || c.hasNormal());
+  c.add(1, 2, 3, nanopcl::Intensity(0.5f), nanopcl::Ring(7), nanopcl::Time(0.25f));
+  EXPECT_TRUE(c.hasIntensity() && c.hasRing() && c.hasTime());
+  EXPECT_EQ(c.intensity(0), 0.5f);
+  EXPECT_EQ(c.ring(0), 7);
+  EXPECT_EQ(c.time(0), 0.25f);
+  c.add(4, 5, 6);  // a plain add() keeps the existing channels in step (defaults)
+  EXPECT_EQ(c.intensities().size(), 2u);
+  EXPECT_EQ(c.intensity(1), 0.0f);
+  EXPECT_EQ(c.ring(1), 0);
+  c.resize(5);
+  EXPECT_EQ(c.intensities().size(), 5u);
+  EXPECT_EQ(c.rings().size(), 5u);
+  c.useNormal();  // a channel switched on late is sized to the cloud
+  EXPECT_EQ(c.normals().size(), 5u);
+  c.normal(2) = Eigen::Vector3f(0.0f, 0.0f, 1.0f);
+  EXPECT_EQ(Eigen::Vector3f(c.normal(2)).z(), 1.0f);
+  c.add(7, 8, 9, nanopcl::Color(10, 20, 30), nanopcl::Label(42));
+  EXPECT_EQ(c.color(5).g, 20);
+  EXPECT_EQ(uint32_t(c.label(5)), 42u);
+  EXPECT_EQ(c.color(0).r, 0);  // the earlier points got the default colour
+}
+TEST(PointCloud4, ExtractEraseAndMerge) {  // test_pointcloud.cpp:191-240, test_channels.cpp:157-216
+  nanopcl::PointCloud4 c;
+  c.setFrameId("f");
+  c.setTimestamp(9);
+  for (int i = 0; i < 10; ++i) c.add(float(i), 0, 0, nanopcl::Intensity(float(i) * 0.1f));
+  const nanopcl::PointCloud4 sub = c.extract({1, 3, 5});
+  EXPECT_EQ(sub.size(), 3u);
+  EXPECT_EQ(sub.point(1).x(), 3.0f);
+  EXPECT_TRUE(sub.hasIntensity());
+  EXPECT_FLOAT_EQ(sub.intensity(2), 0.5f);
+  EXPECT_EQ(sub.frameId(), std::string("f"));
+  EXPECT_EQ(sub.timestamp(), 9u);
+  const nanopcl::PointCloud4 run = c.extract(size_t(4), size_t(3));
+  EXPECT_EQ(run.size(), 3u);
+  EXPECT_EQ(run.point(0).x(), 4.0f);
+  c.erase({8, 2, 2, 0});  // order and duplicates do not matter
+  EXPECT_EQ(c.size(), 7u);
+  EXPECT_EQ(c.point(0).x(), 1.0f);
+  EXPECT_EQ(c.point(1).x(), 3.0f);
+  EXPECT_EQ(c.point(6).x(), 9.0f);
+  EXPECT_FLOAT_EQ(c.intensity(6), 0.9f);
+  nanopcl::PointCloud4 a, b;
+  b.add(1, 1, 1, nanopcl::Intensity(0.7f));
+  a += b;  // an empty cloud adopts the other's channels
+  EXPECT_TRUE(a.hasIntensity());
+  EXPECT_EQ(a.intensity(0), 0.7f);
+  nanopcl::PointCloud4 plain;
+  plain.add(2, 2, 2);
+  a += plain;  // a cloud without the channel contributes defaults
+  EXPECT_EQ(a.size(), 2u);
+  EXPECT_EQ(a.intensities().size(), 2u);
+  EXPECT_EQ(a.intensity(1), 0.0f);
+}
+TEST(PointCloud4, IndexRange) {  // test_index_range.cpp:23-175
+  nanopcl::PointCloud4 c(5);
+  size_t sum = 0, count = 0;
+  for (size_t i : c.indices()) { sum += i; ++count; }
+  EXPECT_EQ(count, 5u);
+  EXPECT_EQ(sum, 10u);
+  EXPECT_EQ(c.indices().size(), 5u);
+  constexpr nanopcl::IndexRange r(3);
+  static_assert(r.size() == 3, "constexpr");
+  size_t n_empty = 0;
+  for (size_t i : nanopcl::IndexRange(0)) { (void)i; ++n_empty; }
+  EXPECT_EQ(n_empty, 0u);
+}
+TEST(PointCloud4, IntegrateGivesTheMapOfTheSoACloudBitForBit) {  // fastdem.cpp:122-190 on cloud.points().data()
+  Stream st;
+  ElevationMap m_soa(12.0f, 9.0f, 0.1f, "map"), m_aos(12.0f, 9.0f, 0.1f, "map");
+  FastDEM a(m_soa), b(m_aos);
+  a.setHeightFilter(-1.0f, 2.0f).setRangeFilter(0.0f, 30.0f).setSensorModel(SensorType::LiDAR);
+  b.setHeightFilter(-1.0f, 2.0f).setRangeFilter(0.0f, 30.0f).setSensorModel(SensorType::LiDAR);
+  Eigen::Isometry3d Tbs = Eigen::Isometry3d::Identity();
+  Tbs.translation() = Eigen::Vector3d(0.1, 0.0, 0.4);
+  for (size_t k = 0; k < st.clouds.size(); ++k) {
+    PointCloud& s = st.clouds[k];
+    nanopcl::PointCloud4 q;
+    for (size_t i = 0; i < s.size(); ++i) {
+      const Eigen::Vector3f p = static_cast<const PointCloud&>(s).point(i);
+      if (k % 2) q.add(p.x(), p.y(), p.z(), nanopcl::Intensity(float(i % 17)), nanopcl::Color(uint8_t(i), uint8_t(k), 3));
+      else q.add(p.x(), p.y(), p.z());
+    }
+    if (k % 2) {  // the same channels on the SoA side
+      s.useIntensity();
+      s.useColor();
+      for (size_t i = 0; i < s.size(); ++i) { s.intensity(i) = float(i % 17); s.setColor(i, nanopcl::Color(uint8_t(i), uint8_t(k), 3)); }
+    }
+    const bool ra = a.integrate(s, Tbs, st.poses[k]);
+    const bool rb = b.integrate(q, Tbs, st.poses[k]);
+    EXPECT_EQ(ra, rb);
+    EXPECT_EQ(a.lastStats().n_after_filter, b.lastStats().n_after_filter);
+    EXPECT_EQ(a.lastStats().n_cells_touched, b.lastStats().n_cells_touched);
+  }
+  EXPECT_TRUE(m_soa.exists("intensity") && m_soa.exists("color"));
+  EXPECT_TRUE(sameMaps(m_soa, m_aos));
+  // the online overload: providers + frame id + timestamp, as FastDEM::integrate(shared_ptr) of the reference
+  auto cloud = std::make_shared<nanopcl::PointCloud4>();
+  cloud->add(0.5f, 0.5f, 0.3f);
+  EXPECT_FALSE(b.integrate(cloud));  // no providers
+}
+
 int main(int argc, char** argv) { return mini::run(argc > 1 ? argv[1] : nullptr); }
