@@ -73,5 +73,5 @@ cat $O/ray_bench.jsonl | cut -c1-330
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_ray_batch -o rb -- python3 $R/scripts/ray_batch_run.py 640 > $O/ray_batch_c2.json 2> $O/ray_batch_c2.err)
 # (7) soak of the end-of-round code: engine against engine, bit for bit, every profile
 rm -f $O/soak.jsonl
-for P in small p2 tiled ray rayp2 walk; do timeout 400 python3 scripts/soak_r04.py ${SOAK_S:-75} 5 no $P 2>/dev/null | tail -1 >> $O/soak.jsonl; done
+for P in small p2 tiled ray rayp2 walk rayw; do timeout 400 python3 scripts/soak_r04.py ${SOAK_S:-75} 5 no $P 2>/dev/null | tail -1 >> $O/soak.jsonl; done
 cat $O/soak.jsonl

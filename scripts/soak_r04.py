@@ -25,8 +25,10 @@ profile = sys.argv[4] if len(sys.argv) > 4 else "small"
 # ray   : 16 m map, raycasting on in every call      A = the stage inside the batches (fdm_rbatch.hpp), B = batch_ray 0 (one scan per launch)
 # rayp2 : the same with the P2 estimator + colour
 # walk  : 16 m LOCAL map, Kalman     A = the walker block walks every batch's chain of moves one launch ahead (batch_walk 1), B = batch_walk 0
-SIZE = {"small": 16.0, "tiled": 60.0, "p2": 12.0, "ray": 16.0, "rayp2": 12.0, "walk": 16.0}[profile]
-BIG = {"small": 70000, "tiled": 300000, "p2": 40000, "ray": 70000, "rayp2": 40000, "walk": 30000}[profile]
+# rayw  : 40 m map, raycasting on in every call, scans up to 200 K points     A = every scan's ray walk on the sector window
+#         in LDS (fdm_raywedge.hpp: ray_large_min 1), B = one lane per ray on memory-side atomics (ray_wedge 0)
+SIZE = {"small": 16.0, "tiled": 60.0, "p2": 12.0, "ray": 16.0, "rayp2": 12.0, "walk": 16.0, "rayw": 40.0}[profile]
+BIG = {"small": 70000, "tiled": 300000, "p2": 40000, "ray": 70000, "rayp2": 40000, "walk": 30000, "rayw": 200000}[profile]
 rng = np.random.default_rng(2026)
 
 
@@ -50,7 +52,7 @@ def make(raycast):
         cfg.mode = 1 if profile == "p2" else 0
         cfg.estimation_type = 1
         cfg.sensor_type = 2
-    if profile in ("ray", "rayp2"):  # ghosts get cleared now and then
+    if profile in ("ray", "rayp2", "rayw"):  # ghosts get cleared now and then
         cfg.rc_log_odds_ghost, cfg.rc_clear_threshold, cfg.rc_height_conflict_threshold = 0.9, -0.5, 0.02
     return cfg
 
@@ -83,6 +85,11 @@ if profile == "tiled":
     B.set_option("tiled", 0)
 elif profile in ("ray", "rayp2"):
     B.set_option("batch_ray", 0)
+elif profile == "rayw":
+    for e in (A, B):
+        e.set_option("ray_large_min", 1)
+        e.set_option("batch_ray", 0)
+    B.set_option("ray_wedge", 0)
 elif profile == "walk":
     A.set_option("batch_walk", 1)
     B.set_option("batch_walk", 0)
@@ -97,7 +104,7 @@ if with_oracle:
     rcfg.z_min, rcfg.z_max, rcfg.range_min, rcfg.range_max = -2.0, 4.0, 0.2, 12.0
     if profile in ("p2", "rayp2"):
         rcfg.mode, rcfg.estimation_type, rcfg.sensor_type = (1 if profile == "p2" else 0), 1, 2
-    if profile in ("ray", "rayp2"):
+    if profile in ("ray", "rayp2", "rayw"):
         rcfg.rc_log_odds_ghost, rcfg.rc_clear_threshold, rcfg.rc_height_conflict_threshold = 0.9, -0.5, 0.02
     Rf = R.RefEngine(SIZE, SIZE, 0.1, rcfg)
 t0 = time.perf_counter()
@@ -105,7 +112,7 @@ scans = calls = compares = 0
 px = py = 0.0
 alive = []  # device arrays stay alive until both engines have synchronised (the calls only enqueue)
 while time.perf_counter() - t0 < budget:
-    ray = 1 if profile in ("ray", "rayp2") else int(rng.integers(0, 3) == 0)
+    ray = 1 if profile in ("ray", "rayp2", "rayw") else int(rng.integers(0, 3) == 0)
     for e in (A, B) + ((Rf,) if Rf else ()):
         cfg = e.cfg
         cfg.raycast_enabled = ray
