@@ -116,10 +116,11 @@ class TestVoxelGridAny:
         assert 1000 < sel.size < n
 
     @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, 8191, 8193,
-                                   65535, 65536, 65537, 262143, 262145, 1048577])
+                                   65535, 65536, 65537, 262143, 262145, 599999, 600000, 600001, 1048577])
     def test_sizes_around_the_sort_s_tile_and_wavefront_edges(self, gpu, R, n):
-        """The radix sort walks tiles of 4096 pairs, wavefronts of 1024, rounds of 64: sizes on either side of every
-        edge, many duplicates of a few keys among unique ones (runs that straddle tiles)."""
+        """The radix sort walks tiles of 4096 pairs (1024 up to 600 000 pairs), wavefronts of a quarter tile, rounds of
+        64: sizes on either side of every edge, many duplicates of a few keys among unique ones (runs that straddle
+        tiles)."""
         rng = np.random.default_rng(n)
         x, y, z = (rng.uniform(-30, 30, n).astype(F32) for _ in range(3))
         m = n // 3
