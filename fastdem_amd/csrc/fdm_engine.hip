@@ -144,6 +144,7 @@ struct fdm_engine {
   unsigned long long* vkeys[2] = {nullptr, nullptr};  // voxel keys: unsorted / sorted
   uint32_t* vidx[2] = {nullptr, nullptr};             // point indices: unsorted / sorted
   uint32_t* vsel = nullptr;          // voxel_any output staging
+  uint32_t* ray_blk = nullptr;       // rays queued per block of k_ray_compact (large scans: block-local queue regions)
   size_t vcap = 0;
   void* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
@@ -1327,6 +1328,7 @@ void fdm_engine_destroy(fdm_engine* e) {
     if (e->vidx[k]) (void)hipFree(e->vidx[k]);
   }
   if (e->vsel) (void)hipFree(e->vsel);
+  if (e->ray_blk) (void)hipFree(e->ray_blk);
   if (e->sort_tmp) (void)hipFree(e->sort_tmp);
   if (e->vs_cnt) (void)hipFree(e->vs_cnt);
   if (e->vs_rec) (void)hipFree(e->vs_rec);

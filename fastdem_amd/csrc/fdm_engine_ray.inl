@@ -38,6 +38,7 @@ int ensure_voxel_buffers(fdm_engine* e, size_t n) {
     if (e->vidx[k]) HIPCK(hipFree(e->vidx[k]));
   }
   if (e->vsel) HIPCK(hipFree(e->vsel));
+  if (e->ray_blk) HIPCK(hipFree(e->ray_blk));
   if (e->sort_tmp) HIPCK(hipFree(e->sort_tmp));
   e->vcap = n + n / 4 + 1024;
   for (int k = 0; k < 2; ++k) {
@@ -45,6 +46,7 @@ int ensure_voxel_buffers(fdm_engine* e, size_t n) {
     HIPCK(hipMalloc(reinterpret_cast<void**>(&e->vidx[k]), e->vcap * sizeof(uint32_t)));
   }
   HIPCK(hipMalloc(reinterpret_cast<void**>(&e->vsel), e->vcap * sizeof(uint32_t)));
+  HIPCK(hipMalloc(reinterpret_cast<void**>(&e->ray_blk), (e->vcap / 512u + 2u) * sizeof(uint32_t)));  // (blocks of >= 512 points)
   // the radix sort's histogram: 256 bins x tiles, + the 256 totals (fdm_rsort.hpp)
   const size_t tiles = std::max((e->vcap + kRsTile - 1) / kRsTile, (size_t(kRsSmallMax) + kRsTileSmall - 1) / kRsTileSmall);
   e->sort_tmp_bytes = (256u * tiles + 256u) * sizeof(uint32_t);
@@ -285,16 +287,19 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q_in, bool voxel, const fl
   if (sort_queue) {
     // points per thread of the queue builder: 8 on multi-million-point scans (the queue tail is one same-address
     // returning atomic per block), 2 below (a 272 K-point scan is 133 blocks of 2 048 points: half the chip)
+    unsigned queue_blocks = 0u, queue_block_points = 0u;  // the queue builder's grid: the scatter walks the same block regions
     auto compact = [&](auto PTS) {
       constexpr unsigned kPts = decltype(PTS)::value;
       const unsigned cblocks = (Q.n + 256u * kPts - 1u) / (256u * kPts);
       if (voxel)
         hipLaunchKernelGGL((k_ray_compact<true, int(kPts)>), dim3(cblocks), dim3(256), 0, e->stream, Q, e->G, e->d_state,
-                           dx, dy, dz, e->vsel, e->rc_cnt, ray_list, ray_key, ray_rank, bin_cnt);
+                           dx, dy, dz, e->vsel, e->rc_cnt, ray_list, ray_key, ray_rank, bin_cnt, e->ray_blk);
       else
         hipLaunchKernelGGL((k_ray_compact<false, int(kPts)>), dim3(cblocks), dim3(256), 0, e->stream, Q, e->G, e->d_state,
                            dx, dy, dz, static_cast<const uint32_t*>(nullptr), e->rc_cnt, ray_list, ray_key, ray_rank,
-                           bin_cnt);
+                           bin_cnt, e->ray_blk);
+      queue_blocks = cblocks;
+      queue_block_points = 256u * kPts;
     };
     if (Q.n <= kRsSmallMax) compact(std::integral_constant<unsigned, 2>{});
     else compact(std::integral_constant<unsigned, 8>{});
@@ -311,15 +316,16 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q_in, bool voxel, const fl
       hipLaunchKernelGGL(k_ray_bin_scan, dim3(kRayBins / kRayBinBlock), dim3(256), 0, e->stream, Q, e->G, e->d_state,
                          bin_cnt, bin_part, bin_start);
     }
-    hipLaunchKernelGGL(k_ray_scatter, dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, ray_list, ray_key,
-                       ray_rank, bin_start, e->vidx[1]);
+    hipLaunchKernelGGL(k_ray_scatter, dim3(queue_blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, ray_list, ray_key,
+                       ray_rank, bin_start, e->ray_blk, queue_block_points, e->vidx[1]);
     ray_list = e->vidx[1];
   } else if (voxel) {
     hipLaunchKernelGGL((k_ray_compact<true, 1>), dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx,
-                       dy, dz, e->vsel, e->rc_cnt, ray_list, ray_key, ray_rank, bin_cnt);
+                       dy, dz, e->vsel, e->rc_cnt, ray_list, ray_key, ray_rank, bin_cnt, static_cast<uint32_t*>(nullptr));
   } else {
     hipLaunchKernelGGL((k_ray_compact<false, 1>), dim3(blocks), dim3(256), 0, e->stream, Q, e->G, e->d_state, dx,
-                       dy, dz, static_cast<const uint32_t*>(nullptr), e->rc_cnt, ray_list, ray_key, ray_rank, bin_cnt);
+                       dy, dz, static_cast<const uint32_t*>(nullptr), e->rc_cnt, ray_list, ray_key, ray_rank, bin_cnt,
+                       static_cast<uint32_t*>(nullptr));
   }
   HIPCK(hipGetLastError());
   const bool tiled = e->G.o_rows != e->G.rows || e->G.o_cols != e->G.cols || e->G.s_rows != e->G.rows ||

@@ -504,12 +504,27 @@ __device__ __forceinline__ void ray_compact_body(const RayParams& Q, const GeomC
                                                  uint32_t* __restrict__ ray_key,
                                                  uint32_t* __restrict__ ray_rank,
                                                  uint32_t* __restrict__ bin_cnt,
-                                                 unsigned* __restrict__ ray_count, const unsigned blk) {
+                                                 unsigned* __restrict__ ray_count, uint32_t* __restrict__ blk_cnt,
+                                                 const unsigned blk) {
   __shared__ unsigned s_wave[PTS][4];
   __shared__ unsigned s_base;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   unsigned idx[PTS], key[PTS], rank[PTS];
   unsigned long long mask[PTS];
+  // the block's loads in two round trips (selection flags, then the selected points), whatever PTS is
+  bool take[PTS];
+  float ex_[PTS], ey_[PTS], ez_[PTS];
+#pragma unroll
+  for (int k = 0; k < PTS; ++k) {
+    const unsigned i = (blk * unsigned(PTS) + unsigned(k)) * 256u + threadIdx.x;
+    take[k] = i < Q.n && (!VOXEL || sel[i] != 0u);
+  }
+#pragma unroll
+  for (int k = 0; k < PTS; ++k) {
+    const unsigned i = (blk * unsigned(PTS) + unsigned(k)) * 256u + threadIdx.x;
+    ex_[k] = ey_[k] = ez_[k] = 0.0f;
+    if (take[k]) { ex_[k] = x[i]; ey_[k] = y[i]; ez_[k] = z[i]; }
+  }
 #pragma unroll
   for (int k = 0; k < PTS; ++k) {
     const unsigned i = (blk * unsigned(PTS) + unsigned(k)) * 256u + threadIdx.x;
@@ -517,13 +532,13 @@ __device__ __forceinline__ void ray_compact_body(const RayParams& Q, const GeomC
     key[k] = 0u;
     rank[k] = 0u;
     bool ray = false;
-    if (i < Q.n && (!VOXEL || sel[i] != 0u)) {
-      const float ex = x[i], ey = y[i], ez = z[i];
+    int o = -1;
+    if (take[k]) {
+      const float ex = ex_[k], ey = ey_[k], ez = ez_[k];
       if (VOXEL || (isfinite(ex) && isfinite(ey) && isfinite(ez))) {
         DevCand c;  // observed evidence: the point's own cell (nanoGrid getIndex, fp64)
         c.px = g.px; c.py = g.py; c.sr = g.sr; c.sc = g.sc; c.shr = 0; c.shc = 0;
-        const int o = owned_cell(ex, ey, c, G);
-        if (o >= 0) atomicAdd(&rc_cnt[o], 1u);
+        o = owned_cell(ex, ey, c, G);
         ray = ez < Q.oz;  // upward rays are skipped (raycasting.cpp:168)
         if (ray && bin_cnt) {
           const float dx = ex - Q.ox, dy = ey - Q.oy;
@@ -543,6 +558,18 @@ __device__ __forceinline__ void ray_compact_body(const RayParams& Q, const GeomC
         }
       }
     }
+    // the evidence count: neighbouring lanes are neighbouring points of the scan (the beams of one firing step up a wall
+    // stand in ONE cell), so a run of equal cells is one atomic with the run's length — one memory-side atomic per point
+    // was half of this kernel at configs[3] (1 M atomics, 38 -> 19 us without them)
+    {
+      const int prev = __builtin_amdgcn_update_dpp(-2, o, 0x138, 0xF, 0xF, false);  // wave_shr:1 (lane 0 keeps -2)
+      const unsigned long long edge = __ballot(o != prev);                          // a run starts here (lane 0 always)
+      if (o >= 0 && o != prev && !(Q.dbg & 128)) {  // (dbg 128, measurement only: no evidence count)
+        const unsigned long long later = lane == 63 ? 0ull : (edge >> (lane + 1));
+        const unsigned run = later ? unsigned(__ffsll((long long)later)) : 64u - unsigned(lane);
+        atomicAdd(&rc_cnt[o], run);
+      }
+    }
     mask[k] = __ballot(ray);
     if (lane == 0) s_wave[k][w] = unsigned(__popcll(mask[k]));
   }
@@ -551,7 +578,14 @@ __device__ __forceinline__ void ray_compact_body(const RayParams& Q, const GeomC
     unsigned tot = 0u;
 #pragma unroll
     for (int k = 0; k < PTS; ++k) tot += s_wave[k][0] + s_wave[k][1] + s_wave[k][2] + s_wave[k][3];
-    s_base = tot ? atomicAdd(ray_count, tot) : 0u;
+    // large scans (blk_cnt != nullptr): the block's rays go to the block's OWN region of the queue, [blk * points per
+    // block, ...), and k_ray_scatter walks the regions — the queue tail was one same-address returning atomic per block
+    if (blk_cnt) {
+      blk_cnt[blk] = tot;
+      s_base = blk * unsigned(PTS) * 256u;
+    } else {
+      s_base = tot ? atomicAdd(ray_count, tot) : 0u;
+    }
   }
   __syncthreads();
   unsigned off = s_base;
@@ -580,13 +614,14 @@ __global__ __launch_bounds__(256) void k_ray_compact(const RayParams Q, const Ge
                                                      uint32_t* __restrict__ ray_list,
                                                      uint32_t* __restrict__ ray_key,
                                                      uint32_t* __restrict__ ray_rank,
-                                                     uint32_t* __restrict__ bin_cnt) {
+                                                     uint32_t* __restrict__ bin_cnt,
+                                                     uint32_t* __restrict__ blk_cnt) {
   const DevGeom g = st->geom[Q.slot];
   if (!ray_stage_runs(Q, st, g, G)) return;
   if (blockIdx.x == 0 && threadIdx.x == 0 && st->vis_ray == 0u)
     st->vis_ray = Q.vis_stamp;  // the three layers become visible (raycasting.cpp:223-226)
   ray_compact_body<VOXEL, PTS>(Q, G, g, x, y, z, sel, rc_cnt, ray_list, ray_key, ray_rank, bin_cnt, &st->ray_count,
-                               blockIdx.x);
+                               bin_cnt ? blk_cnt : nullptr, blockIdx.x);
 }
 
 // bucket counts -> offsets, in two launches of kRayBins / kRayBinBlock blocks: per-block sums, then every block
@@ -642,6 +677,7 @@ __global__ __launch_bounds__(256) void k_ray_bin_scan(const RayParams Q, const G
   o.z = o.y + c.y;
   o.w = o.z + c.z;
   reinterpret_cast<uint4*>(bin_start)[blockIdx.x * 256u + threadIdx.x] = o;
+  if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 255u) st->ray_count = o.w + c.w;  // (the queue's length)
 }
 
 // the same in ONE launch for the (sector, length class) order of k_ray_wedge, whose 8 K buckets one workgroup scans:
@@ -685,6 +721,7 @@ __global__ __launch_bounds__(kRayScan1Threads) void k_ray_bin_scan1(const RayPar
     run = o.w + c[j].w;
     out4[j] = o;
   }
+  if (threadIdx.x == kRayScan1Threads - 1u) st->ray_count = run;  // (the queue's length: the sum of all buckets)
 }
 
 __global__ __launch_bounds__(256) void k_ray_scatter(const RayParams Q, const GeomConst G,
@@ -693,12 +730,16 @@ __global__ __launch_bounds__(256) void k_ray_scatter(const RayParams Q, const Ge
                                                      const uint32_t* __restrict__ ray_key,
                                                      const uint32_t* __restrict__ ray_rank,
                                                      const uint32_t* __restrict__ bin_start,
+                                                     const uint32_t* __restrict__ blk_cnt, const unsigned block_points,
                                                      uint32_t* __restrict__ ray_sorted) {
   const DevGeom g = st->geom[Q.slot];
   if (!ray_stage_runs(Q, st, g, G)) return;
-  const unsigned q = blockIdx.x * 256u + threadIdx.x;
-  if (q >= st->ray_count) return;
-  ray_sorted[bin_start[ray_key[q]] + ray_rank[q]] = ray_list[q];
+  // block b of the queue builder left blk_cnt[b] rays at the start of its region
+  const unsigned cnt = blk_cnt[blockIdx.x], base = blockIdx.x * block_points;
+  for (unsigned j = threadIdx.x; j < cnt; j += 256u) {
+    const unsigned q = base + j;
+    ray_sorted[bin_start[ray_key[q]] + ray_rank[q]] = ray_list[q];
+  }
 }
 
 // Minimum over the 64 lanes with DPP row operations (VALU rate; a __shfl butterfly is six trips through
