@@ -493,6 +493,10 @@ int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2);
  *                         memory-side atomics on one line queue up); before the first large scan only
  *   "batch_walk" -1/0/1 : small-scan batches: the chain of moves walked one launch ahead (-1 = for the quantile
  *                         estimator only)
+ *   "ray_large_min" n   : raycasting of scans from n points up takes the large-scan path (default 196608): ray queue
+ *                         ordered by (angular sector, length class)
+ *   "ray_wedge" 0/1     : ... and walks it with the sector's minimum-height window in LDS (fdm_raywedge.hpp, default 1;
+ *                         0 = one lane per ray on memory-side atomics)
  *   "batch_ray" 0/1     : raycasting inside the small-scan batches (1); "batch_ray_lds" 0/1: its ray walk on LDS images
  *                         (1) or memory-side atomics with "batch_ray_seg" 1/4/8/16 lanes per ray
  *   "dbg_*"             : measurement-only switches used by scripts/ab_kernels.py */
