@@ -15,6 +15,8 @@ echo "== C++ mirror host-only code under ASan/UBSan =="
 make -s -C $R/fastdem_amd/cpp asan
 FDM_CONFIG_DIR=$R/fastdem_amd/config ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=halt_on_error=1 \
   $R/fastdem_amd/cpp/build/fdm_cpp_tests_asan ConfigLoad.
+echo "== nanopcl::PointCloud4 (host-only groups) under ASan/UBSan =="
+for G in ConstructorsAdd ResizeReserve PointsIsOne MetadataAnd ChannelsFollow ExtractErase IndexRange; do ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=halt_on_error=1 $R/fastdem_amd/cpp/build/fdm_cpp_tests_asan PointCloud4.$G | tail -1; done
 echo "== libfdm_halo host code (tile plan, route plan) under ASan/UBSan =="
 make -s -C $R/fastdem_amd/csrc asan
 LD_PRELOAD="$ASAN_LIB $(gcc -print-file-name=libstdc++.so.6)" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
