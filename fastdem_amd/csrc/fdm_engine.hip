@@ -133,6 +133,11 @@ struct fdm_engine {
   bool cap_cov = false;                   // ... the preprocessed cloud with its 3x3 covariance channel
   float* d_cap = nullptr;            // 4 channels x cap_cap points
   size_t cap_cap = 0;
+  // the preprocessed cloud of a scan whose raycasting stage is HELD BACK with its update (option "ray_hold"): by scan
+  // parity — the next scan's bin half writes its own while the stage of this one has not run yet; 3 channels x rcap_cap
+  float* d_rcap[2] = {nullptr, nullptr};
+  size_t rcap_cap = 0;
+  int ray_hold = 1;
   float* d_ras = nullptr;            // ncell
   bool saved_want_ids = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -186,6 +191,11 @@ struct fdm_engine {
     TilePool Q;             // tiled pipeline: the record pool of the scan's parity
     TileAux A;
     unsigned upd_blocks = 0;
+    // the scan's raycasting stage (fastdem.cpp:152-159), which runs right behind this update wherever that is launched
+    bool ray = false;
+    RayParams RQ;
+    const float *ray_x = nullptr, *ray_y = nullptr, *ray_z = nullptr;  // the scan's preprocessed cloud (d_rcap[parity])
+    double ray_box[6] = {0, 0, 0, 0, 0, 0};
   } pend;
   // ---- tiled pipeline state (allocated when the first large scan arrives) ----
   bool borrow_inputs = false;       // option "borrow_inputs": a held-back update gathers from the CALLER's device arrays
@@ -292,10 +302,13 @@ namespace {
 // Launch the held-back update kernel, if any.  Called at the top of every entry point that is not
 // the next scan of the chain, and before anything that syncs or reallocates.
 int launch_update_alone(fdm_engine* e, const fdm_engine::PendingUpdate& u);
+// The raycasting stage of the scan whose update was just launched (fdm_engine_ray.inl).
+int run_held_ray_stage(fdm_engine* e, fdm_engine::PendingUpdate& u);
 int join_streams(fdm_engine* e) {
   if (e->chain) {
     e->chain = false;
     if (int rc = launch_update_alone(e, e->pend)) return rc;
+    if (int rc = run_held_ray_stage(e, e->pend)) return rc;
   }
   return FDM_OK;
 }
@@ -653,7 +666,20 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     if (dvar) { e->S.wt_var = const_cast<float*>(gather->var); e->S.wt_src_var = dvar; }
     if (drgb) { e->S.wt_rgb = const_cast<uint32_t*>(gather->rgb); e->S.wt_src_rgb = drgb; }
   }
-  if ((e->cap_pre || ray_on) && n) {
+  // (a scan with raycasting and nothing else optional is held back like a plain one: its stage runs behind its update)
+  const bool ray_held = ray_on && e->ray_hold && e->overlap && e->key2[1] && !e->cap_pre && !e->cap_ras;
+  if (ray_held && n) {
+    if (n > e->rcap_cap) {
+      if (int rc_sync = sync_all(e)) return rc_sync;
+      for (float*& p : e->d_rcap) { if (p) HIPCK(hipFree(p)); p = nullptr; }
+      e->rcap_cap = n + n / 4 + 1024;
+      for (float*& p : e->d_rcap) HIPCK(hipMalloc(reinterpret_cast<void**>(&p), e->rcap_cap * 3 * sizeof(float)));
+    }
+    float* const base = e->d_rcap[e->scan_no & 1];
+    e->S.cap_x = base;
+    e->S.cap_y = base + e->rcap_cap;
+    e->S.cap_z = base + 2 * e->rcap_cap;
+  } else if ((e->cap_pre || ray_on) && n) {
     if (n > e->cap_cap) {
       if (int rc_sync = sync_all(e)) return rc_sync;
       if (e->d_cap) HIPCK(hipFree(e->d_cap));
@@ -696,7 +722,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     e->S.aux = e->aux2[parity];
     e->S.zs = e->zs2[parity];
   }
-  const bool plain = e->overlap && e->key2[1] && !ray_on && !e->cap_pre &&
+  const bool plain = e->overlap && e->key2[1] && (!ray_on || ray_held) && !e->cap_pre &&
                      !e->cap_ras && !e->obst_dense_pending;
   // A held-back update of the scratch pipeline gathers the winning points AFTER this call has returned and
   // the next scan has been enqueued.  Device arrays handed to the enqueue-only entry points are therefore
@@ -794,6 +820,9 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   }
   HIPCK(hipGetLastError());
   if (e->profile) HIPCK(hipEventRecord(e->ev[1], e->stream));
+  // the previous scan's raycasting stage, if it was held back with the update that has just left in the fused launch:
+  // behind that update, ahead of everything of this scan but its bin half (which reads no layer)
+  if (fuse_now && (rc = run_held_ray_stage(e, e->pend))) return rc;
 
   if (e->obst_dense_pending) {
     const int blocks = int(std::min<size_t>((e->ncell + 255) / 256, 4096));
@@ -833,21 +862,16 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     HIPCK(hipEventRecord(e->ev[3], e->stream));  // back-to-back pair: the event-to-event overhead
   }
   e->ray_timed = false;
+  u.ray = false;
   if (ray_on) {  // step 3 of integrateImpl (fastdem.cpp:152-159) on the map this scan just updated
-    if (e->profile) HIPCK(hipEventRecord(e->ev_ray[0], e->stream));
     const float origin[3] = {P.ray_ox, P.ray_oy, P.ray_oz};
-    double box[6];
-    ray_box_of(e, P, box);
-    int key_mode = 0;
-    if ((rc = enqueue_voxel_sort(e, P.n, static_cast<float>(e->G.res), P.slot, e->S.cap_x, e->S.cap_y,
-                                 e->S.cap_z, box, &key_mode)))
-      return rc;
-    const RayParams Q = make_ray_params(e, ray_config_of(e->cfg), origin, P.n, (P.slot + 1) & 3, P.slot);
-    if ((rc = enqueue_ray_stage(e, Q, true, e->S.cap_x, e->S.cap_y, e->S.cap_z, key_mode))) return rc;
-    if (e->profile) {
-      HIPCK(hipEventRecord(e->ev_ray[1], e->stream));
-      e->ray_timed = true;
-    }
+    u.RQ = make_ray_params(e, ray_config_of(e->cfg), origin, P.n, (P.slot + 1) & 3, P.slot);
+    u.ray_x = e->S.cap_x; u.ray_y = e->S.cap_y; u.ray_z = e->S.cap_z;
+    ray_box_of(e, P, u.ray_box);
+    u.ray = true;
+    // held back with the update (plain): it runs behind it — in the next scan's launch sequence or at the next flush;
+    // otherwise now, the update has just been launched
+    if (!plain && (rc = run_held_ray_stage(e, u))) return rc;
   }
   e->scan_no++;
   e->last_batch_n = 0;
@@ -1304,6 +1328,7 @@ void fdm_engine_destroy(fdm_engine* e) {
   if (e->d_aos) (void)hipFree(e->d_aos);
   if (e->d_cell_ids) (void)hipFree(e->d_cell_ids);
   if (e->d_cap) (void)hipFree(e->d_cap);
+  for (float* p : e->d_rcap) if (p) (void)hipFree(p);
   if (e->d_ras) (void)hipFree(e->d_ras);
   for (auto& ev : e->ev)
     if (ev) (void)hipEventDestroy(ev);

@@ -441,6 +441,7 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
     N.ray.clear_thr = c.clear_threshold; N.ray.conflict_thr = c.height_conflict_threshold;
   }
   e->pend.multi = true;
+  e->pend.ray = false;
   e->pend.ch = ch;
   e->pend.tiled = false;
   e->chain = true;

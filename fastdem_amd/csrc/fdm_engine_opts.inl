@@ -264,6 +264,11 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
     e->ray_large_min = value < 1 ? 1 : value;
     return FDM_OK;
   }
+  if (std::strcmp(key, "ray_hold") == 0) {
+    if (int rc = join_streams(e)) return rc;
+    e->ray_hold = value != 0;
+    return FDM_OK;
+  }
   if (std::strcmp(key, "ray_wedge") == 0) {
     e->ray_wedge = value != 0;
     return FDM_OK;

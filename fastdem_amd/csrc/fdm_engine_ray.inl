@@ -371,6 +371,25 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q_in, bool voxel, const fl
   return FDM_OK;
 }
 
+// The raycasting stage of a scan of integrate(), on the map its update — launched just before — leaves: voxel filter
+// of the scan's preprocessed cloud, processScan, resolveGhostCells.  Everything it needs was fixed when the scan was
+// enqueued (PendingUpdate::RQ, the cloud of the scan's parity): it may run after the NEXT scan's bin half.
+int run_held_ray_stage(fdm_engine* e, fdm_engine::PendingUpdate& u) {
+  if (!u.ray) return FDM_OK;
+  u.ray = false;
+  int rc;
+  if (e->profile) HIPCK(hipEventRecord(e->ev_ray[0], e->stream));
+  int key_mode = 0;
+  if ((rc = enqueue_voxel_sort(e, u.RQ.n, static_cast<float>(e->G.res), u.RQ.flag_slot, u.ray_x, u.ray_y, u.ray_z,
+                               u.ray_box, &key_mode)))
+    return rc;
+  if ((rc = enqueue_ray_stage(e, u.RQ, true, u.ray_x, u.ray_y, u.ray_z, key_mode))) return rc;
+  if (e->profile) {
+    HIPCK(hipEventRecord(e->ev_ray[1], e->stream));
+    e->ray_timed = true;
+  }
+  return FDM_OK;
+}
 
 }  // namespace
 

@@ -497,6 +497,9 @@ int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2);
  *                         ordered by (angular sector, length class)
  *   "ray_wedge" 0/1     : ... and walks it with the sector's minimum-height window in LDS (fdm_raywedge.hpp, default 1;
  *                         0 = one lane per ray on memory-side atomics)
+ *   "ray_hold" 0/1      : a scan's raycasting stage is held back together with its map update and runs right behind it —
+ *                         in the next scan's launch sequence (the update then shares a launch with that scan's bin half) or
+ *                         at the next flush (default 1; 0 = update and stage at once, the round-1..4 order)
  *   "batch_ray" 0/1     : raycasting inside the small-scan batches (1); "batch_ray_lds" 0/1: its ray walk on LDS images
  *                         (1) or memory-side atomics with "batch_ray_seg" 1/4/8/16 lanes per ray
  *   "dbg_*"             : measurement-only switches used by scripts/ab_kernels.py */
