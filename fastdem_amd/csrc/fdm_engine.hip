@@ -672,7 +672,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     if (n > e->rcap_cap) {
       if (int rc_sync = sync_all(e)) return rc_sync;
       for (float*& p : e->d_rcap) { if (p) HIPCK(hipFree(p)); p = nullptr; }
-      e->rcap_cap = n + n / 4 + 1024;
+      e->rcap_cap = (n + n / 4 + 1024 + 63) & ~size_t(63);  // (a multiple of 64 points: every channel starts 16-byte aligned)
       for (float*& p : e->d_rcap) HIPCK(hipMalloc(reinterpret_cast<void**>(&p), e->rcap_cap * 3 * sizeof(float)));
     }
     float* const base = e->d_rcap[e->scan_no & 1];
@@ -683,7 +683,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     if (n > e->cap_cap) {
       if (int rc_sync = sync_all(e)) return rc_sync;
       if (e->d_cap) HIPCK(hipFree(e->d_cap));
-      e->cap_cap = n + n / 4 + 1024;
+      e->cap_cap = (n + n / 4 + 1024 + 63) & ~size_t(63);  // (a multiple of 64 points: every channel starts 16-byte aligned)
       HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_cap), e->cap_cap * 13 * sizeof(float)));  // x y z var + 9 cov
     }
     e->S.cap_x = e->d_cap;

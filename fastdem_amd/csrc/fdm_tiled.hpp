@@ -225,12 +225,25 @@ __device__ __forceinline__ void tbin_prep(const PT& P, const Scratch& S, const u
     }
     const bool exists = live && (!drop_nf || (isfinite(xs[j]) && isfinite(ys[j]) && isfinite(zs[j])));
     pass[j] = preprocess_point(P, xs[j], ys[j], zs[j]) && exists;
-    if (cap_x && live) {
-      cap_x[i0 + j] = (S.cap_drop_nan && !pass[j]) ? __uint_as_float(0x7FC00000u) : xs[j];
-      S.cap_y[i0 + j] = ys[j]; S.cap_z[i0 + j] = zs[j];
-      if (cap_var) cap_var[i0 + j] = cvar;
-    }
+    if (cap_var && live) cap_var[i0 + j] = cvar;
     n_pass += pass[j] ? 1u : 0u;
+  }
+  // the preprocessed cloud (scan callbacks, the raycasting stage's input): the thread's four points per channel in ONE
+  // 16-byte store (the channels start on 16-byte boundaries: the engine rounds their pitch) — as four 4-byte stores per
+  // channel the capture was a quarter of the launch's write requests
+  if (cap_x) {
+    float cx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cx[j] = (S.cap_drop_nan && !pass[j]) ? __uint_as_float(0x7FC00000u) : xs[j];
+    if (i0 + 3u < P.n) {
+      *reinterpret_cast<float4*>(cap_x + i0) = make_float4(cx[0], cx[1], cx[2], cx[3]);
+      *reinterpret_cast<float4*>(S.cap_y + i0) = make_float4(ys[0], ys[1], ys[2], ys[3]);
+      *reinterpret_cast<float4*>(S.cap_z + i0) = make_float4(zs[0], zs[1], zs[2], zs[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i0 + unsigned(j) < P.n) { cap_x[i0 + j] = cx[j]; S.cap_y[i0 + j] = ys[j]; S.cap_z[i0 + j] = zs[j]; }
+    }
   }
 }
 template <bool HAS_INT, int THREADS, bool LEAN, bool SIDE, class PT>
