@@ -197,6 +197,15 @@ int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* 
     hipLaunchKernelGGL(k_fusion_net32, dim3(fblocks), dim3(kFusionThreads), 0, e->stream, e->G, e->d_state,
                        int(e->scan_no & 3), e->d_region, F, e->d_tmp, e->d_tmp2, lptr(e, *up), lstride(e, *up),
                        lptr(e, *lo), lstride(e, *lo), unsigned(e->ncell));
+  } else if (int(reg.size()) <= kFusionWaveMax && !(e->dbg_post & 16)) {  // one wavefront per cell, the samples sorted in LDS
+    unsigned n_pad = 64u;
+    while (n_pad < reg.size()) n_pad <<= 1;
+    const unsigned lds = fusion_wave_lds_bytes(n_pad);
+    if ((rc = allow_lds(k_fusion_wave, lds))) return rc;
+    const unsigned wblocks = unsigned(std::min<size_t>((e->ncell + 1) / 2, 8192));
+    hipLaunchKernelGGL(k_fusion_wave, dim3(wblocks), dim3(kFusionWaveThreads), lds, e->stream, e->G, e->d_state,
+                       int(e->scan_no & 3), e->d_region, F, n_pad, e->d_tmp, e->d_tmp2, lptr(e, *up), lstride(e, *up),
+                       lptr(e, *lo), lstride(e, *lo), unsigned(e->ncell));
   } else if (int(reg.size()) <= kFusionLdsEntries) {  // sample lists in LDS
     const size_t lds = size_t(4) * reg.size() * kFusionThreads * sizeof(float);
     static bool raised = false;

@@ -411,7 +411,129 @@ __global__ __launch_bounds__(kFusionThreads) void k_fusion(const GeomConst G, co
   }
 }
 
-// discs of more than kMaxRegion cells: the four lists in the global pool (see k_median_big)
+// Discs of more than 32 cells: ONE WAVEFRONT per cell, the samples sorted in LDS.  The insertion sorts of k_fusion /
+// k_fusion_big keep a list per THREAD (O(n^2) moves through LDS, scratch or a global pool: 134 ms for a 317-cell disc on
+// the 1200 x 1200 map); here a wavefront gathers the disc once (lane = entry), sorts 64-bit keys ord(value) << 32 | entry
+// — ties in entry order, which is what the reference's insertion into a sorted list leaves — with a bitonic network
+// in wave-private LDS, lays the weights out in sorted order and walks SimpleWeightedECDF::quantile's two sequential sums
+// (uncertainty_fusion.cpp:63-91: the float sums are in sorted order) with the values handed from lane to lane.
+// N: the entry count padded to a power of two (<= kFusionWaveMax); LDS per wavefront = 24 N bytes.
+constexpr int kFusionWaveMax = 1024;
+constexpr unsigned kFusionWaveThreads = 128u;  // two wavefronts per block
+__host__ __device__ constexpr unsigned fusion_wave_lds_bytes(unsigned n_pad) { return 2u * 24u * n_pad; }
+// (LDS that only one wavefront touches needs no s_barrier: its DS instructions execute in order; this keeps the compiler
+// from moving accesses of different lanes across the point)
+__device__ __forceinline__ void fusion_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ float fusion_wave_quantile(const unsigned long long* __restrict__ key, const float* __restrict__ ws,
+                                                      const float* __restrict__ val, const unsigned n, const float p,
+                                                      const unsigned lane) {
+  const float nanv = __uint_as_float(0x7FC00000u);
+  if (n == 0u) return nanv;
+  if (n == 1u) return val[uint32_t(key[0])];
+  // total, then the cumulative sum up to the first sample that reaches p * total — every lane walks the same chain
+  float total = 0.0f;
+  for (unsigned c = 0; c < n; c += 64u) {
+    const float mine = c + lane < n ? ws[c + lane] : 0.0f;
+    const unsigned m = min(64u, n - c);
+    for (unsigned l = 0; l < m; ++l) total += __uint_as_float(unsigned(__builtin_amdgcn_readlane(int(__float_as_uint(mine)), int(l))));
+  }
+  if (total <= 0.0f) return nanv;
+  const float target = p * total;
+  float cumulative = 0.0f;
+  for (unsigned c = 0; c < n; c += 64u) {
+    const float mine = c + lane < n ? ws[c + lane] : 0.0f;
+    const unsigned m = min(64u, n - c);
+    for (unsigned l = 0; l < m; ++l) {
+      cumulative += __uint_as_float(unsigned(__builtin_amdgcn_readlane(int(__float_as_uint(mine)), int(l))));
+      if (cumulative >= target) return val[uint32_t(key[c + l])];
+    }
+  }
+  return val[uint32_t(key[n - 1u])];
+}
+__global__ __launch_bounds__(kFusionWaveThreads) void k_fusion_wave(const GeomConst G, const DevState* __restrict__ st,
+                                                                    int slot, const RegionEntry* __restrict__ reg,
+                                                                    const FusionParams F, const unsigned n_pad,
+                                                                    const float* __restrict__ up_in,
+                                                                    const float* __restrict__ lo_in,
+                                                                    float* __restrict__ up_out, int up_stride,
+                                                                    float* __restrict__ lo_out, int lo_stride,
+                                                                    unsigned ncell) {
+  extern __shared__ unsigned char s_fw[];
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  unsigned long long* const key = reinterpret_cast<unsigned long long*>(s_fw + size_t(wave) * 24u * n_pad);
+  float* const s_w = reinterpret_cast<float*>(key + n_pad);  // weight by entry
+  float* const s_ws = s_w + n_pad;                            // weight by sorted position
+  float* const s_lo = s_ws + n_pad;                           // the entries' lower / upper values
+  float* const s_up = s_lo + n_pad;
+  const PostGeom p = post_geom(st, slot, G);
+  const unsigned waves = gridDim.x * (kFusionWaveThreads / 64u);
+  for (unsigned t = blockIdx.x * (kFusionWaveThreads / 64u) + wave; t < ncell; t += waves) {  // (wave-uniform)
+    const int lc = int(t / unsigned(p.rows)), lr = int(t - unsigned(lc) * unsigned(p.rows));
+    const size_t ci = post_index(p, lr, lc);
+    if (!isfinite(up_in[ci]) || !isfinite(lo_in[ci])) continue;
+    fusion_wave_sync();  // (the previous cell's readers are done with the arrays)
+    unsigned n = 0u, valid = 0u;
+    for (unsigned e = lane; e < n_pad; e += 64u) {
+      bool ok = false, take = false;
+      float nu_v = 0.0f, nl_v = 0.0f, weight = 0.0f;
+      if (e < unsigned(F.n_entries)) {
+        const RegionEntry re = reg[e];
+        if (post_inside(p, lr + re.dr, lc + re.dc)) {
+          const size_t ni = post_index(p, lr + re.dr, lc + re.dc);
+          nu_v = up_in[ni]; nl_v = lo_in[ni];
+          if (isfinite(nu_v) && isfinite(nl_v)) {
+            ok = true;
+            weight = re.w * (1.0f / ((nu_v - nl_v) + 1e-4f));
+            take = weight > 1e-6f;  // SimpleWeightedECDF::add; the values are finite here
+          }
+        }
+      }
+      s_w[e] = take ? weight : 0.0f;
+      s_lo[e] = nl_v;
+      s_up[e] = nu_v;
+      // (sorted behind every sample)
+      key[e] = take ? (((unsigned long long)ord(nl_v == 0.0f ? 0.0f : nl_v) << 32) | e) : ~0ull;
+      n += unsigned(__popcll(__ballot(take)));
+      valid += unsigned(__popcll(__ballot(ok)));
+    }
+    if (int(valid) < F.min_valid) continue;
+    float q[2];
+#pragma unroll 1
+    for (int list = 0; list < 2; ++list) {
+      if (list == 1) {  // the upper list: the same entries keyed by their upper value
+        fusion_wave_sync();
+        for (unsigned e = lane; e < n_pad; e += 64u)
+          key[e] = s_w[e] != 0.0f ? (((unsigned long long)ord(s_up[e] == 0.0f ? 0.0f : s_up[e]) << 32) | e) : ~0ull;
+      }
+      // bitonic sort, ascending
+      for (unsigned k = 2u; k <= n_pad; k <<= 1) {
+        for (unsigned j = k >> 1; j > 0u; j >>= 1) {
+          fusion_wave_sync();
+          for (unsigned i = lane; i < n_pad / 2u; i += 64u) {
+            const unsigned a = ((i & ~(j - 1u)) << 1) | (i & (j - 1u)), b = a | j;
+            const unsigned long long x = key[a], y = key[b];
+            const bool asc = (a & k) == 0u;
+            if ((x > y) == asc) { key[a] = y; key[b] = x; }
+          }
+        }
+      }
+      fusion_wave_sync();
+      for (unsigned pos = lane; pos < n; pos += 64u) s_ws[pos] = s_w[uint32_t(key[pos])];
+      fusion_wave_sync();
+      q[list] = fusion_wave_quantile(key, s_ws, list == 0 ? s_lo : s_up, n, list == 0 ? F.q_lower : F.q_upper, lane);
+    }
+    if (lane == 0u && isfinite(q[0]) && isfinite(q[1])) {
+      up_out[ci * up_stride] = q[1];
+      lo_out[ci * lo_stride] = q[0];
+    }
+  }
+}
+
+// discs of more than kFusionWaveMax cells: the four lists in the global pool (see k_median_big)
 __global__ __launch_bounds__(kFusionThreads) void k_fusion_big(const GeomConst G, const DevState* __restrict__ st,
                                                                int slot, const RegionEntry* __restrict__ reg,
                                                                const FusionParams F, const float* __restrict__ up_in,

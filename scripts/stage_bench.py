@@ -137,12 +137,12 @@ for name, fn_gpu, fn_cpu, alg_bytes in (
                       "algorithmic_MB": round(alg_bytes / 1e6, 2), "GBps": round(alg_bytes / t / 1e9, 1),
                       "cpu_oracle_ms": round(t_cpu * 1e3, 2), "speedup": round(t_cpu / t, 1)}))
 
-# ---- the pooled slow paths (neighbourhoods of more than 256 cells: k_median_big / k_fusion_big / k_features_big), no CPU
+# ---- the big neighbourhoods (k_median_sel / k_fusion_wave / k_features_sel; beyond the LDS: the pooled k_*_big), no CPU
 # beside them; they exist so that no call the reference accepts is refused ----
 res_cells = eng.rows * eng.cols
 for name, fn_gpu, entries in (
         ("post_median_17x17 (k_median_sel)", lambda: eng.apply_spatial_smoothing("elevation_inpainted", 17, 5), 17 * 17),
-        ("post_uncertainty_fusion(r=10 cells: 317 entries, k_fusion_big)",
+        ("post_uncertainty_fusion(r=10 cells: 317 entries, k_fusion_wave)",
          lambda: eng.apply_uncertainty_fusion(True, 10.0 * wl.resolution + 1e-4, 0.05, 0.01, 0.99, 3), 317),
         ("post_feature_extraction(r=10 cells: 317 entries, k_features_sel)",
          lambda: eng.apply_feature_extraction(10.0 * wl.resolution + 1e-4, 4, 0.05, 0.95), 317)):
