@@ -596,13 +596,15 @@ template <bool UPPER, bool TILED = false>
 __device__ __forceinline__ float fusion_list32(const PostGeom& p, int lr, int lc, const RegionEntry* __restrict__ reg,
                                                const FusionParams& F, const float* __restrict__ up_in,
                                                const float* __restrict__ lo_in, float (*s_w)[kFusionThreads],
-                                               int& valid) {
+                                               int& valid, uint32_t& taken) {
   constexpr unsigned long long kNone = ~0ull;  // sorts behind every sample
   int n = 0;
-  valid = 0;
 #define FDM_DECL(e) unsigned long long a##e = kNone;
   FDM_E32(FDM_DECL)
 #undef FDM_DECL
+  if (!UPPER) {  // the first list decides which entries count (bit e of `taken`) and leaves their weights in LDS
+    valid = 0;
+    taken = 0u;
 #define FDM_GATHER(e)                                                                         \
   if (e < F.n_entries) {                                                                       \
     const RegionEntry re = reg[e];                                                             \
@@ -612,17 +614,29 @@ __device__ __forceinline__ float fusion_list32(const PostGeom& p, int lr, int lc
       if (isfinite(nu_v) && isfinite(nl_v)) {                                                  \
         const float weight = re.w * (1.0f / ((nu_v - nl_v) + 1e-4f));                          \
         if (weight > 1e-6f) {                                                                  \
-          if (!UPPER) s_w[e][threadIdx.x] = weight;                                            \
-          const float v = UPPER ? nu_v : nl_v;                                                 \
-          a##e = ((unsigned long long)ord(v == 0.0f ? 0.0f : v) << 32) | unsigned(e);          \
+          s_w[e][threadIdx.x] = weight;                                                        \
+          a##e = ((unsigned long long)ord(nl_v == 0.0f ? 0.0f : nl_v) << 32) | unsigned(e);    \
+          taken |= 1u << e;                                                                    \
           ++n;                                                                                 \
         }                                                                                      \
         ++valid;                                                                               \
       }                                                                                        \
     }                                                                                          \
   }
-  FDM_E32(FDM_GATHER)
+    FDM_E32(FDM_GATHER)
 #undef FDM_GATHER
+  } else {  // the second list: the same entries keyed by their upper value — no test, no weight to work out again
+    n = __popc(taken);
+#define FDM_GATHER_U(e)                                                                       \
+  if ((taken >> e) & 1u) {                                                                     \
+    const RegionEntry re = reg[e];                                                             \
+    const size_t ni = TILED ? size_t(lr + re.dc * lc + re.dr) : post_index(p, lr + re.dr, lc + re.dc); \
+    const float nu_v = up_in[ni];                                                              \
+    a##e = ((unsigned long long)ord(nu_v == 0.0f ? 0.0f : nu_v) << 32) | unsigned(e);          \
+  }
+    FDM_E32(FDM_GATHER_U)
+#undef FDM_GATHER_U
+  }
   if (valid < F.min_valid) return __uint_as_float(0x7FC00000u);
 #define FDM_CE(i, j) { const bool sw = a##i > a##j; const unsigned long long lo_ = sw ? a##j : a##i; a##j = sw ? a##i : a##j; a##i = lo_; }
   FDM_NET32(FDM_CE)
@@ -663,9 +677,10 @@ __global__ __launch_bounds__(kFusionThreads) void k_fusion_net32(const GeomConst
   const size_t ci = post_index(p, lr, lc);
   if (!isfinite(up_in[ci]) || !isfinite(lo_in[ci])) return;
   int valid = 0;
-  const float lower = fusion_list32<false>(p, lr, lc, reg, F, up_in, lo_in, s_w, valid);
+  uint32_t taken = 0u;
+  const float lower = fusion_list32<false>(p, lr, lc, reg, F, up_in, lo_in, s_w, valid, taken);
   if (valid < F.min_valid) return;
-  const float upper = fusion_list32<true>(p, lr, lc, reg, F, up_in, lo_in, s_w, valid);
+  const float upper = fusion_list32<true>(p, lr, lc, reg, F, up_in, lo_in, s_w, valid, taken);
   if (isfinite(lower) && isfinite(upper)) {
     up_out[ci * up_stride] = upper;
     lo_out[ci * lo_stride] = lower;
@@ -706,9 +721,10 @@ __global__ __launch_bounds__(kFusionThreads) void k_fusion_net32_tiled(const Geo
   if (!isfinite(s_up[base]) || !isfinite(s_lo[base])) return;
   const size_t ci = post_index(p, lr, lc);
   int valid = 0;
-  const float lower = fusion_list32<false, true>(p, base, pitch, reg, F, s_up, s_lo, s_w, valid);
+  uint32_t taken = 0u;
+  const float lower = fusion_list32<false, true>(p, base, pitch, reg, F, s_up, s_lo, s_w, valid, taken);
   if (valid < F.min_valid) return;
-  const float upper = fusion_list32<true, true>(p, base, pitch, reg, F, s_up, s_lo, s_w, valid);
+  const float upper = fusion_list32<true, true>(p, base, pitch, reg, F, s_up, s_lo, s_w, valid, taken);
   if (isfinite(lower) && isfinite(upper)) {
     up_out[ci * up_stride] = upper;
     lo_out[ci * lo_stride] = lower;
