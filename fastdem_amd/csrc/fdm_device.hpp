@@ -78,7 +78,13 @@ struct DevState {
   unsigned ray_count;  // rays queued by k_ray_compact for k_ray; k_ray_resolve puts it back to 0
   unsigned vis_col, vis_ray;
   unsigned fault;      // a device-side invariant failed: reported once by the next sync / statistics read-back as FDM_ERR_HIP.
-  unsigned pad_f[3];   // (Nothing sets it since round 4: no kernel of the engine waits for another block any more.)
+                       // (Nothing sets it since round 4: no kernel of the engine waits for another block any more.)
+  // The whole-layer obstacle clear a scan owes when something other than its own pipeline's books may hold obstacle
+  // cells (a pipeline switch, a host write of the layer): `dense_owed` is the host's sequence number of the latest such
+  // event, `dense_paid` the number the last scan that OBSERVED a cell cleared for (k_obstacle_dense_clear /
+  // k_obstacle_dense_paid) — a scan that observes nothing clears nothing, like the reference, and the debt stays.
+  unsigned dense_owed, dense_paid;
+  unsigned pad_f;
 };
 
 struct GeomConst {

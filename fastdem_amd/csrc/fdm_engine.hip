@@ -122,7 +122,11 @@ struct fdm_engine {
   std::vector<unsigned long long> h_bin_part;
   unsigned n_tiles = 0;
   std::vector<uint32_t> h_upd_part;
-  bool obst_dense_pending = false;  // host wrote the obstacle layer: next scan clears it densely
+  bool obst_dense_pending = false;  // host wrote the obstacle layer / the pipeline changed: the next scan that observes a
+                                    // cell clears it densely — which scan that is only the device knows (DevState::
+                                    // dense_owed / dense_paid); the flag falls at the first sync behind it
+  bool obst_owe_armed = false;      // ... the device has been told about the current debt
+  unsigned obst_owe_seq = 0;
   bool estimator_ready = false;     // ElevationMapping ctor ran (ensureLayers + obstacle layer)
   bool use_records = true;          // pack the active estimator's state into cell records
   float* d_rec = nullptr;           // [ncell][rec_floats]
@@ -316,6 +320,11 @@ int sync_all(fdm_engine* e) {
   if (int rc = join_streams(e)) return rc;
   HIPCK(hipStreamSynchronize(e->stream));
   e->bstage_busy = false;  // (the stream has drained: nothing reads the host-batch staging block any more)
+  if (e->obst_dense_pending && e->obst_owe_armed) {  // has a scan that observed a cell paid the obstacle layer's debt?
+    unsigned w[2] = {0u, 1u};
+    HIPCK(hipMemcpy(w, &e->d_state->dense_owed, sizeof(w), hipMemcpyDeviceToHost));
+    if (w[0] == w[1]) e->obst_dense_pending = false;
+  }
   return FDM_OK;
 }
 // DevState::fault after the stream has drained: a batch launch whose in-kernel wait for the scans ahead ran out of
@@ -715,8 +724,16 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   const bool enough_tiles = e->tiled_forced || kt >= 240 || (kt >= 160 && n >= 100000);
   const bool tiled = e->tiled && e->rec_kind >= 0 && n >= e->tiled_min && aligned && n < 0x7FFF0000ull &&
                      e->bin_variant != 1 && enough_tiles;
-  if (e->last_kind >= 0 && e->last_kind != int(tiled)) e->obst_dense_pending = true;  // the pipelines keep
-  e->last_kind = int(tiled);                                // separate books on which tiles hold obstacle cells
+  if (e->last_kind >= 0 && e->last_kind != int(tiled)) {  // the pipelines keep separate books on which tiles hold
+    e->obst_dense_pending = true;                         // obstacle cells
+    e->obst_owe_armed = false;
+  }
+  e->last_kind = int(tiled);
+  if (e->obst_dense_pending && !e->obst_owe_armed) {  // (a new debt: also one a host write of the layer left)
+    hipLaunchKernelGGL(k_obstacle_dense_owe, dim3(1), dim3(1), 0, e->stream, e->d_state, ++e->obst_owe_seq);
+    HIPCK(hipGetLastError());
+    e->obst_owe_armed = true;
+  }
   if (e->key2[1]) {  // the scratch set of this scan's parity
     e->S.key = e->key2[parity];
     e->S.aux = e->aux2[parity];
@@ -825,11 +842,12 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   if (fuse_now && (rc = run_held_ray_stage(e, e->pend))) return rc;
 
   if (e->obst_dense_pending) {
+    // (every scan enqueued while the flag stands tries: the first one that observed a cell clears and pays)
     const int blocks = int(std::min<size_t>((e->ncell + 255) / 256, 4096));
     hipLaunchKernelGGL(k_obstacle_dense_clear, dim3(blocks), dim3(256), 0, e->stream, P, e->d_state,
                        L(e, "obstacle"), e->ncell);
+    hipLaunchKernelGGL(k_obstacle_dense_paid, dim3(1), dim3(1), 0, e->stream, P, e->d_state);
     HIPCK(hipGetLastError());
-    e->obst_dense_pending = false;
   }
   // this scan's update: held back (the next scan's launch or a flush carries it) or launched now
   fdm_engine::PendingUpdate& u = e->pend;

@@ -86,7 +86,7 @@ int fdm_engine_layer_add(fdm_engine* e, const char* name, float value) {
   if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return rc_join; } }
   if (!e || !name) return fail(FDM_ERR_INVALID, "null argument");
   HIPCK(hipSetDevice(e->device));
-  if (std::strcmp(name, "obstacle") == 0) e->obst_dense_pending = true;
+  if (std::strcmp(name, "obstacle") == 0) { e->obst_dense_pending = true; e->obst_owe_armed = false; }
   if (int rc = resolve_pending(e)) return rc;  // keeps getLayers() in the reference's creation order
   return add_layer(e, name, value, false);
 }
@@ -120,7 +120,7 @@ int fdm_engine_layer_upload(fdm_engine* e, const char* name, const float* host, 
     l = find_layer(e, name);
   }
   l->pending = false;
-  if (std::strcmp(name, "obstacle") == 0) e->obst_dense_pending = true;
+  if (std::strcmp(name, "obstacle") == 0) { e->obst_dense_pending = true; e->obst_owe_armed = false; }
   if (l->field >= 0) {
     if (int rc = ensure_tmp(e)) return rc;
     HIPCK(hipMemcpyAsync(e->d_tmp, host, e->ncell * sizeof(float), hipMemcpyHostToDevice, e->stream));

@@ -304,6 +304,7 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
   if (std::strcmp(key, "dense") == 0) {  // force stamp-gated (0) or dense (1) update sweeps
     e->S.dense = value != 0;
     e->obst_dense_pending = true;  // stamps were not maintained while dense
+    e->obst_owe_armed = false;
     return FDM_OK;
   }
   if (std::strcmp(key, "dbg_upd") == 0) {

@@ -152,7 +152,7 @@ int fdm_engine_apply_spatial_smoothing(fdm_engine* e, const char* layer, int ker
                        e->d_tmp, lptr(e, *l), lstride(e, *l), kernel_size, min_valid, unsigned(e->ncell), e->d_post_pool);
   }
   HIPCK(hipGetLastError());
-  if (std::strcmp(layer, "obstacle") == 0) e->obst_dense_pending = true;
+  if (std::strcmp(layer, "obstacle") == 0) { e->obst_dense_pending = true; e->obst_owe_armed = false; }
   return FDM_OK;
 }
 

@@ -1161,12 +1161,18 @@ __global__ __launch_bounds__(256) void k_update_bin(
 // the scan observed a cell.
 __global__ void k_obstacle_dense_clear(const ScanParams P, DevState* __restrict__ st,
                                        float* __restrict__ obstacle, size_t n) {
-  if (st->flags[P.slot].any_inside == 0u) return;
+  if (st->flags[P.slot].any_inside == 0u || st->dense_paid == st->dense_owed) return;  // (nothing observed | nothing owed)
   size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t stride = size_t(gridDim.x) * blockDim.x;
   const float nanv = __uint_as_float(0x7FC00000u);
   for (; i < n; i += stride) obstacle[i] = nanv;
 }
+
+// ... and behind it (one thread): the scan that observed a cell has paid the debt
+__global__ void k_obstacle_dense_paid(const ScanParams P, DevState* __restrict__ st) {
+  if (st->flags[P.slot].any_inside != 0u) st->dense_paid = st->dense_owed;
+}
+__global__ void k_obstacle_dense_owe(DevState* __restrict__ st, unsigned seq) { st->dense_owed = seq; }
 
 // ---- small utility kernels (a layer is a strided view: stride 1 or the record size) ----
 __global__ void k_fill(float* __restrict__ p, float v, size_t n, int es) {

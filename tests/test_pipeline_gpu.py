@@ -173,6 +173,38 @@ def test_chain_mixes_small_and_large_scans(gpu, R):
     assert_layers_equal(eng, ref)
 
 
+@pytest.mark.parametrize("first", ["tiled", "scratch"])
+def test_pipeline_switch_on_a_scan_that_observes_nothing(gpu, R, first):
+    """The two pipelines keep separate books on which tiles hold obstacle cells, so the first UPDATING scan behind a switch
+    clears the layer as a whole (the reference's `map_.clear(obstacle)`, elevation_mapping.cpp:144-146).  If the scan AT
+    the switch observes nothing — every point filtered — the reference clears nothing and the debt passes on to the next
+    scan that does.  Found by a 240-s soak in round 5: 1 stale obstacle cell after 352 K scans."""
+    small = gpu.synth.vlp16(n_scans=4)
+    eng, ref = pair(gpu, R, 60.0, 60.0, 0.1, small.apply_to)   # 600 x 600: scans of >= 2 048 points take the record pools
+    rng = np.random.default_rng(5)
+
+    def cloud(n, lift=0.0, x0=0.0):
+        x = rng.uniform(-8, 8, n).astype(F32) + F32(x0)
+        y = rng.uniform(-8, 8, n).astype(F32)
+        z = (rng.uniform(-0.5, 0.5, n) + lift).astype(F32)
+        return {"x": x, "y": y, "z": z, "intensity": rng.uniform(0, 1, n).astype(F32), "rgb": None}
+
+    big, little = 6000, 900  # (tiled_min is 2 048 points)
+    a, b = (big, little) if first == "tiled" else (little, big)
+    # pipeline A observes (obstacle cells around x = -4), the switch to B happens on a scan that is filtered away as a
+    # whole (z far above z_max), then B observes somewhere else, twice
+    seq = [cloud(a, x0=-4.0), cloud(a, x0=-4.0), cloud(b, lift=50.0), cloud(b, x0=4.0), cloud(b, x0=4.0)]
+    Tbs = small.T_base_sensor
+    keep = []
+    for k, s in enumerate(seq):
+        d = dev(s)
+        keep.append(d)
+        enqueue(eng, d, Tbs, small.pose(0))
+        ref_step(ref, s, Tbs, small.pose(0))
+    assert_layers_equal(eng, ref)
+    assert np.isfinite(eng.layer("obstacle")).sum() > 0
+
+
 def test_p2_and_per_layer_storage_in_a_chain(gpu, R):
     wl = gpu.synth.vlp16(n_scans=8)
 
