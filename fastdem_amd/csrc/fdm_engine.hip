@@ -316,15 +316,19 @@ int join_streams(fdm_engine* e) {
   }
   return FDM_OK;
 }
+// Has a scan that observed a cell paid the obstacle layer's debt?  k_obstacle_dense_paid leaves the number it paid for
+// in pinned host memory: no stream wait — an enqueue-only caller gets its fused / batch launches back a scan or two
+// after the switch, not at its next sync.  (A number read early only means one more scan tries; a number read is
+// final: a new debt takes a new number.)
+void poll_dense_paid(fdm_engine* e) {
+  if (!e->obst_dense_pending || !e->obst_owe_armed || !e->h_stats) return;
+  if (__atomic_load_n(&e->h_stats->dense_paid, __ATOMIC_ACQUIRE) == e->obst_owe_seq) e->obst_dense_pending = false;
+}
 int sync_all(fdm_engine* e) {
   if (int rc = join_streams(e)) return rc;
   HIPCK(hipStreamSynchronize(e->stream));
   e->bstage_busy = false;  // (the stream has drained: nothing reads the host-batch staging block any more)
-  if (e->obst_dense_pending && e->obst_owe_armed) {  // has a scan that observed a cell paid the obstacle layer's debt?
-    unsigned w[2] = {0u, 1u};
-    HIPCK(hipMemcpy(w, &e->d_state->dense_owed, sizeof(w), hipMemcpyDeviceToHost));
-    if (w[0] == w[1]) e->obst_dense_pending = false;
-  }
+  poll_dense_paid(e);
   return FDM_OK;
 }
 // DevState::fault after the stream has drained: a batch launch whose in-kernel wait for the scans ahead ran out of
@@ -639,6 +643,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   if (n >= 0xFFFFFFFEull) return fail(FDM_ERR_INVALID, "point count exceeds 2^32-2");
   if (n >= 0x7FFFFFFFull) return fail(FDM_ERR_INVALID, "point count exceeds 2^31-1");
   int rc;
+  poll_dense_paid(e);
   P.n = uint32_t(n);
   P.scan_no = uint32_t(e->scan_no);
   P.slot = int(e->scan_no & 3);
@@ -846,7 +851,7 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     const int blocks = int(std::min<size_t>((e->ncell + 255) / 256, 4096));
     hipLaunchKernelGGL(k_obstacle_dense_clear, dim3(blocks), dim3(256), 0, e->stream, P, e->d_state,
                        L(e, "obstacle"), e->ncell);
-    hipLaunchKernelGGL(k_obstacle_dense_paid, dim3(1), dim3(1), 0, e->stream, P, e->d_state);
+    hipLaunchKernelGGL(k_obstacle_dense_paid, dim3(1), dim3(1), 0, e->stream, P, e->d_state, e->h_stats_dev);
     HIPCK(hipGetLastError());
   }
   // this scan's update: held back (the next scan's launch or a flush carries it) or launched now
@@ -1090,6 +1095,7 @@ int read_stats(fdm_engine* e, fdm_scan_stats* out, int* status) {
     else if (np == 0) *status = FDM_SKIP_ALL_FILTERED;
   }
   if (out) *out = s;
+  poll_dense_paid(e);  // (the stream has drained)
   if (e->profile) {
     (void)hipEventElapsedTime(&e->last_ms[0], e->ev[0], e->ev[1]);
     (void)hipEventElapsedTime(&e->last_ms[1], e->ev[1], e->ev[2]);

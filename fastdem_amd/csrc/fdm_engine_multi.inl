@@ -23,6 +23,7 @@ uint32_t multi_run(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) 
     if (!e->batch_ray || !e->voxel_small || !voxel_size_ok(static_cast<float>(e->G.res))) return 0u;
     if (e->G.o_rows != e->G.rows || e->G.o_cols != e->G.cols || e->G.s_rows != e->G.rows || e->G.s_cols != e->G.cols) return 0u;
   }
+  poll_dense_paid(e);
   if (e->obst_dense_pending || e->last_kind == 1 || e->next_drop_nonfinite) return 0u;
   if (e->dbg_no_atomics || e->dbg_upd) return 0u;
   const fdm_device_scan& f = scans[0];

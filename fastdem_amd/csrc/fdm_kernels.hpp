@@ -1053,6 +1053,8 @@ struct StatsOut {  // pinned host memory, written by the last block
   int shr, shc;
   unsigned fault, pad;     // DevState::fault
   unsigned long long seq;  // written last (system scope): the host polls it instead of sleeping in a stream wait
+  unsigned dense_paid;     // DevState::dense_paid as of the last k_obstacle_dense_paid (the host reads it without a sync)
+  unsigned pad2;
 };
 __global__ __launch_bounds__(256) void k_collect_stats(const unsigned long long* __restrict__ bin_part,
                                                        unsigned n_bin, const uint32_t* __restrict__ upd_part,
@@ -1169,8 +1171,13 @@ __global__ void k_obstacle_dense_clear(const ScanParams P, DevState* __restrict_
 }
 
 // ... and behind it (one thread): the scan that observed a cell has paid the debt
-__global__ void k_obstacle_dense_paid(const ScanParams P, DevState* __restrict__ st) {
-  if (st->flags[P.slot].any_inside != 0u) st->dense_paid = st->dense_owed;
+// (the paid number is also left in the pinned statistics block: enqueue-only callers learn that the debt is gone
+// without a stream wait — until then every scan is "not plain": no fused launch, no batch launch)
+__global__ void k_obstacle_dense_paid(const ScanParams P, DevState* __restrict__ st, StatsOut* __restrict__ out) {
+  if (st->flags[P.slot].any_inside != 0u) {
+    st->dense_paid = st->dense_owed;
+    __hip_atomic_store(&out->dense_paid, st->dense_owed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 __global__ void k_obstacle_dense_owe(DevState* __restrict__ st, unsigned seq) { st->dense_owed = seq; }
 
