@@ -419,12 +419,10 @@ __device__ __forceinline__ void tupdate_tile(
   const unsigned long long* const row = Q.desc + size_t(tile) * Q.stride;
 
   bool rare_tile = false;  // wave-uniform
-  // (dbg_upd 4 / 8: measurement only — tiles of >= 24 / 48 chunks are not folded: what the heavy tiles cost a launch)
-  const unsigned n_fold = (((P0.dbg_upd & 4) && n_chunks >= 24u) || ((P0.dbg_upd & 8) && n_chunks >= 48u)) ? 0u : n_chunks;
-  if (n_fold) {
+  if (n_chunks) {
     // the first 64 descriptors leave at once; the image is initialised in their shadow
     unsigned long long d_first = 0ull;
-    if (lane < n_fold) d_first = row[lane];
+    if (lane < n_chunks) d_first = row[lane];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const unsigned k = lane + unsigned(q) * 64u;
@@ -440,10 +438,10 @@ __device__ __forceinline__ void tupdate_tile(
 #pragma unroll 1
     for (int step = 0; step < 2; ++step) {
 #pragma unroll 1
-      for (unsigned c0 = 0; c0 < n_fold; c0 += 64u) {
+      for (unsigned c0 = 0; c0 < n_chunks; c0 += 64u) {
         unsigned long long d = 0ull;
         if (c0 == 0u) d = d_first;
-        else if (c0 + lane < n_fold) d = row[c0 + lane];
+        else if (c0 + lane < n_chunks) d = row[c0 + lane];
         const unsigned cnt = unsigned(d >> 32);
         const unsigned inc = wave_scan_incl(cnt);
         const unsigned total = uni(unsigned(__builtin_amdgcn_readlane(int(inc), 63)));
@@ -521,7 +519,7 @@ __device__ __forceinline__ void tupdate_tile(
   // vacates (NaN in EVERY layer, touched or not) and the obstacle clear of the untouched cells.  Then the touched ones,
   // compacted into a list so that each is one lane's only cell and all their record / sigma loads are ONE round trip.
   // (tr, tc: the tile's row / column in the tile grid; `strips`: a vacated strip crosses the tile) ----
-  const bool fold = n_fold != 0u && u.do_update;
+  const bool fold = n_chunks != 0u && u.do_update;
   unsigned n_touched = 0;  // wave-uniform
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
