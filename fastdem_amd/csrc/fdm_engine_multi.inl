@@ -25,7 +25,7 @@ uint32_t multi_run(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) 
   }
   poll_dense_paid(e);
   if (e->obst_dense_pending || e->last_kind == 1 || e->next_drop_nonfinite) return 0u;
-  if (e->dbg_no_atomics || e->dbg_upd) return 0u;
+  if (e->dbg_no_atomics || e->dbg_upd || e->move_clear_basic) return 0u;
   const fdm_device_scan& f = scans[0];
   const size_t kt = e->ncell / 1024u;  // (the thresholds below were measured in units of 1 024 cells, round 2)
   uint32_t run = 0;

@@ -215,6 +215,11 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
     e->bin_stagger = value;
     return FDM_OK;
   }
+  if (std::strcmp(key, "move_clear_basic") == 0) {  // which layers GridMap::move()'s strips clear (see fdm_engine::move_clear_basic)
+    if (int rc_sync = sync_all(e)) return rc_sync;
+    e->move_clear_basic = value != 0;
+    return FDM_OK;
+  }
   if (std::strcmp(key, "cnt_shift") == 0) {
     if (value < 0 || value > 5) return fail(FDM_ERR_INVALID, "cnt_shift: 0 .. 5");
     if (e->pool[0].cnt) return fail(FDM_ERR_INVALID, "cnt_shift: the record pools exist already");

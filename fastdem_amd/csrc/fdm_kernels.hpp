@@ -701,6 +701,11 @@ struct KalmanPolicy {  // one array per layer
     t.s.x = t.s.P = t.s.count = t.s.mean = t.s.var = t.s.m2 = t.smin = t.smax = nanv;
   }
   static __device__ __forceinline__ void clear_cell(const Layers&, unsigned) {}
+  // (move_basic: a vacated strip clears the three basic layers only)
+  static __device__ __forceinline__ void set_nan_basic(State& t) { t.s.x = t.smin = t.smax = __uint_as_float(0x7FC00000u); }
+  static __device__ __forceinline__ void clear_cell_basic(const Layers& L, unsigned o) {
+    L.elevation[o] = L.elevation_min[o] = L.elevation_max[o] = __uint_as_float(0x7FC00000u);
+  }
   static __device__ __forceinline__ void update(const Layers& L, unsigned o, State& t, float min_z,
                                                 float var, float max_z) {
     kalman_step(t.s, min_z, var, L.min_var, L.max_var, L.q);
@@ -736,6 +741,11 @@ struct KalmanRecPolicy {  // cell records
     float4* r = reinterpret_cast<float4*>(L.rec + size_t(o) * kKalmanRec);
     const float4 n4 = make_float4(nanv, nanv, nanv, nanv);
     r[0] = n4; r[1] = n4; r[2] = n4;
+  }
+  static __device__ __forceinline__ void set_nan_basic(State& t) { t.s.x = t.smin = t.smax = __uint_as_float(0x7FC00000u); }
+  static __device__ __forceinline__ void clear_cell_basic(const Layers& L, unsigned o) {
+    float* r = L.rec + size_t(o) * kKalmanRec;  // fields 0, 1, 2 = elevation, elevation_min, elevation_max
+    r[0] = r[1] = r[2] = __uint_as_float(0x7FC00000u);
   }
   static __device__ __forceinline__ void update(const Layers& L, unsigned o, State& t, float min_z,
                                                 float var, float max_z) {
@@ -785,6 +795,10 @@ struct P2Policy {  // one array per layer
     for (int k = 0; k < 5; ++k) t.s.q[k] = t.s.n[k] = nanv;
   }
   static __device__ __forceinline__ void clear_cell(const Layers&, unsigned) {}
+  static __device__ __forceinline__ void set_nan_basic(State& t) { t.smin = t.smax = __uint_as_float(0x7FC00000u); }
+  static __device__ __forceinline__ void clear_cell_basic(const Layers& L, unsigned o) {
+    L.elevation[o] = L.elevation_min[o] = L.elevation_max[o] = __uint_as_float(0x7FC00000u);
+  }
   static __device__ __forceinline__ void update(const Layers& L, unsigned o, State& t, float min_z,
                                                 float /*var*/, float max_z) {
     p2_step(t.s, min_z, L.p);
@@ -826,6 +840,11 @@ struct P2RecPolicy {  // cell records
     float4* r = reinterpret_cast<float4*>(L.rec + size_t(o) * kP2Rec);
     const float4 n4 = make_float4(nanv, nanv, nanv, nanv);
     r[0] = n4; r[1] = n4; r[2] = n4; r[3] = n4; r[4] = n4;
+  }
+  static __device__ __forceinline__ void set_nan_basic(State& t) { t.s.elevation = t.smin = t.smax = __uint_as_float(0x7FC00000u); }
+  static __device__ __forceinline__ void clear_cell_basic(const Layers& L, unsigned o) {
+    float* r = L.rec + size_t(o) * kP2Rec;  // fields 0, 1, 2 = elevation, elevation_min, elevation_max
+    r[0] = r[1] = r[2] = __uint_as_float(0x7FC00000u);
   }
   static __device__ __forceinline__ void update(const Layers& L, unsigned o, State& t, float min_z,
                                                 float /*var*/, float max_z) {
@@ -880,12 +899,16 @@ __device__ __forceinline__ void update_body(
   if (valid && (u.cur || u.obst_tile || u.strips) && P.dbg_upd != 1) {
     if (!S.dense && u.cur) key = S.key[o];
     bool in_strip = false;
+    // (a move of >= the map's size on an axis is clearAll() in either reading of move())
+    const bool basic = P.move_basic && abs(u.C.shr) < G.rows && abs(u.C.shc) < G.cols;
     if (u.strips) {
       const int r = int(o % unsigned(G.s_rows)) + G.s_r0;
       const int col = int(o / unsigned(G.s_rows)) + G.s_c0;
       in_strip = in_cleared_strip(r, u.E.sr, u.C.shr, G.rows) ||
                  in_cleared_strip(col, u.E.sc, u.C.shc, G.cols);
-      if (in_strip) {
+      if (in_strip && basic) {
+        POLICY::clear_cell_basic(L, o);  // (option "move_clear_basic": the three basic layers only)
+      } else if (in_strip) {
         // NaN in EVERY layer (GridMap::move).  Pointers are fetched 8 at a time so the loop costs
         // ceil(n/8) round trips, not one per layer.
         for (int l0 = 0; l0 < n_layers; l0 += 8) {
@@ -902,7 +925,7 @@ __device__ __forceinline__ void update_body(
     touched = u.cur && key != kEmptyKey && P.dbg_upd != 3;  // dbg_upd: measurement-only switches
     if (!touched) {
       // map_.clear(obstacle) (elevation_mapping.cpp:144-146) for the cells it can matter for
-      if (u.obst_tile && !in_strip) L.obstacle[o] = nanv;
+      if (u.obst_tile && (!in_strip || basic)) L.obstacle[o] = nanv;
     } else {
       // ---- round 2: every load the update needs, issued before any is used ----
       const uint32_t idx = uint32_t(key);
@@ -918,11 +941,12 @@ __device__ __forceinline__ void update_body(
       const uint32_t zm = ax.x, imx = ax.y, fst = ax.z, lst = ax.w;
       float sint = nanv;
       typename POLICY::State stt;
-      if (in_strip) {
+      if (in_strip && !basic) {
         POLICY::set_nan(stt);
       } else {
         POLICY::load(L, o, stt);
         if (P.has_intensity) sint = L.intensity[size_t(o) * L.istride];
+        if (in_strip) POLICY::set_nan_basic(stt);
       }
       uint32_t rgb = 0u;
       // ---- round 3 (colour channel only): the last point's colour

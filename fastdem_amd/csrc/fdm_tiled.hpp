@@ -520,6 +520,8 @@ __device__ __forceinline__ void tupdate_tile(
   // compacted into a list so that each is one lane's only cell and all their record / sigma loads are ONE round trip.
   // (tr, tc: the tile's row / column in the tile grid; `strips`: a vacated strip crosses the tile) ----
   const bool fold = n_chunks != 0u && u.do_update;
+  // (a move of >= the map's size on an axis is clearAll() in either reading of move())
+  const bool basic = P.move_basic && abs(u.shr) < G.rows && abs(u.shc) < G.cols;
   unsigned n_touched = 0;  // wave-uniform
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -535,7 +537,9 @@ __device__ __forceinline__ void tupdate_tile(
     bool in_strip = false;
     if (strips) {
       in_strip = in_cleared_strip(sr + G.s_r0, u.e_sr, u.shr, G.rows) || in_cleared_strip(sc + G.s_c0, u.e_sc, u.shc, G.cols);
-      if (in_strip) {
+      if (in_strip && basic) {
+        POLICY::clear_cell_basic(L, o);  // (option "move_clear_basic": the three basic layers only)
+      } else if (in_strip) {
         for (int l0 = 0; l0 < n_layers; l0 += 8) {
           float* p[8];
 #pragma unroll
@@ -576,11 +580,12 @@ __device__ __forceinline__ void tupdate_tile(
       if (has_col) rgb = Q.cold[s_last[lc] - 1u].rgb;
       typename POLICY::State stt;
       float sint = nanv;
-      if (strip) {
+      if (strip && !basic) {
         POLICY::set_nan(stt);
       } else {
         POLICY::load(L, o, stt);
         if (has_int && !(P.dbg_upd & 2)) sint = L.intensity[size_t(o) * L.istride];
+        if (strip) POLICY::set_nan_basic(stt);
       }
       const float min_z = wl != kNoWinner ? signed_value(uint32_t(key >> 32), wl & 1u) : kFltMax;
       const float max_z = zm ? signed_value(zm, zsw & 1u) : -kFltMax;

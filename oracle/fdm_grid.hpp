@@ -187,11 +187,18 @@ class Grid {
   }
 
  private:
-  // axis 0: rows [index, index+n) of every layer; axis 1: cols.
-  // (basicLayers is empty for ElevationMap, so clearRows/clearCols hit all layers.)
+  // axis 0: rows [index, index+n) of the cleared layers; axis 1: cols.
+  // WHICH layers: grid_map_core's clearRows / clearCols take `basicLayers_` when that list is not empty, every layer
+  // otherwise.  ASSUMED (default, "all"): basicLayers is empty for ElevationMap.  The reference hints the other way —
+  // it constructs nanogrid::GridMap({elevation, elevation_min, elevation_max}) (elevation_map.hpp:101-103) and its test
+  // file speaks of "basicLayers = {elevation}" (tests/test_elevation_map.cpp:91) — and nanoGrid is not on disk to
+  // settle it, so the other reading is a switch (setMoveClearBasic; the engine: option "move_clear_basic"): the strips
+  // of a move shorter than the map then clear those three layers only (a move of >= the map's size is clearAll()
+  // either way).  scripts/conformance/probe.cpp prints what the real library does.
   void clearStrip(int axis, int index, int n) {
     const int R = size_[0], C = size_[1];
     for (auto& kv : data_) {
+      if (move_clear_basic_ && kv.first != "elevation" && kv.first != "elevation_min" && kv.first != "elevation_max") continue;
       float* d = kv.second.data();
       if (axis == 0) {
         for (int c = 0; c < C; ++c)
@@ -203,6 +210,12 @@ class Grid {
     }
   }
 
+ public:
+  void setMoveClearBasic(bool on) { move_clear_basic_ = on; }
+  bool moveClearBasic() const { return move_clear_basic_; }
+
+ private:
+  bool move_clear_basic_ = false;
   std::vector<std::string> names_;
   std::unordered_map<std::string, std::vector<float>> data_;
   int size_[2] = {0, 0};

@@ -101,6 +101,9 @@ uint64_t fdmref_last_rasterized(void* e, uint64_t cap, float* x, float* y, float
  * n_cleared}.  voxel tie order: 1 = by original index (default; what the engine reproduces),
  * 0 = std::sort on the key exactly as the reference. */
 void fdmref_set_voxel_stable(void* e, int on);
+/* GridMap::move(): 1 = the vacated strips clear the basic layers {elevation, elevation_min, elevation_max} only
+ * (fdm_grid.hpp clearStrip; default 0 = every layer) */
+void fdmref_set_move_clear_basic(void* e, int on);
 void fdmref_last_ray_stats(void* e, uint32_t* stats5);
 /* applyRaycasting(map, scan, sensor_origin, cfg) on a map-frame cloud (raycasting.cpp:204-249) */
 int fdmref_apply_raycasting(void* e, uint64_t n, const float* x, const float* y, const float* z,

@@ -301,6 +301,7 @@ void fdmref_eig3(const float* cov9, float* val3, float* vec9) {
 }
 
 void fdmref_set_voxel_stable(void* e, int on) { E(e)->voxel_stable = on != 0; }
+void fdmref_set_move_clear_basic(void* e, int on) { E(e)->map().setMoveClearBasic(on != 0); }
 static void copyRay(const RayStats& r, uint32_t* s5) {
   if (!s5) return;
   s5[0] = r.n_rays; s5[1] = r.n_observed; s5[2] = r.n_ray_cells; s5[3] = r.n_conflicts; s5[4] = r.n_cleared;

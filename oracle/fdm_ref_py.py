@@ -144,6 +144,7 @@ def load(native=False):
     lib.fdmref_pack_cloud.argtypes = [P, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, P, C.c_uint64,
                                       C.POINTER(C.c_uint32), C.c_char_p, C.c_uint64]
     lib.fdmref_set_voxel_stable.argtypes = [P, C.c_int]
+    lib.fdmref_set_move_clear_basic.argtypes = [P, C.c_int]
     lib.fdmref_last_ray_stats.argtypes = [P, P]
     lib.fdmref_apply_raycasting.restype = C.c_int
     lib.fdmref_apply_raycasting.argtypes = [P, C.c_uint64, P, P, P, P, P]
@@ -374,6 +375,10 @@ class RefEngine:
 
     def set_voxel_stable(self, on=True):
         self._lib.fdmref_set_voxel_stable(self._h, int(on))
+
+    def set_move_clear_basic(self, on=True):
+        """GridMap::move(): the strips clear {elevation, elevation_min, elevation_max} only (fdm_grid.hpp clearStrip)."""
+        self._lib.fdmref_set_move_clear_basic(self._h, int(on))
 
     def last_ray_stats(self):
         s = np.zeros(5, dtype=np.uint32)

@@ -110,3 +110,26 @@ def test_move_wraparound_two_regions(R):
     cleared = np.isnan(lay).all(axis=1)
     assert set(np.nonzero(cleared)[0]) == set(range(14, 20)) | set(range(0, 8))
     assert e.geometry().start_row == (8 - 14) % 20
+
+
+def test_move_clear_scope_switch():
+    """fdm_grid.hpp clearStrip: the default clears every layer in the strips move() vacates; with the switch only the
+    basic layers {elevation, elevation_min, elevation_max} (grid_map_core's clearRows / clearCols with a non-empty
+    basicLayers list; elevation_map.hpp:101-103 passes exactly these three to the GridMap constructor).  A move of >= the
+    map's size is clearAll() in both readings."""
+    import fdm_ref_py as R
+    for basic in (0, 1):
+        e = R.RefEngine(2.0, 2.0, 0.1)   # 20 x 20
+        e.set_move_clear_basic(basic)
+        for name in ("elevation", "elevation_min", "elevation_max", "variance", "user"):
+            if not e.exists(name):
+                e.add(name, 1.0)
+            e.set_layer(name, np.full((20, 20), 1.0, dtype=np.float32))
+        e.move(0.3, 0.0)                 # three rows vacated
+        for name in ("elevation", "elevation_min", "elevation_max"):
+            assert np.isnan(e.layer(name)).sum() == 3 * 20, (basic, name)
+        for name in ("variance", "user"):
+            assert np.isnan(e.layer(name)).sum() == (0 if basic else 3 * 20), (basic, name)
+        e.move(5.0, 0.0)                 # beyond the map: clearAll()
+        for name in ("elevation", "variance", "user"):
+            assert np.isnan(e.layer(name)).all(), (basic, name)
