@@ -177,6 +177,7 @@ PROTOTYPES = {
     "fdm_engine_layer_upload": (C.c_int, [_P, C.c_char_p, _P, C.c_int32, C.c_int32]),
     "fdm_engine_layer_device_ptr": (_P, [_P, C.c_char_p]),
     "fdm_engine_clear": (C.c_int, [_P, C.c_char_p]),
+    "fdm_engine_layer_copy": (C.c_int, [_P, _P, C.c_char_p]),
     "fdm_engine_region_pack": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.POINTER(C.c_char_p), C.c_int, _P]),
     "fdm_engine_region_unpack": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

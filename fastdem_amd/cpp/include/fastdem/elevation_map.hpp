@@ -50,6 +50,8 @@ class ElevationMap : public nanogrid::GridMap {
   }
   ElevationMap(ElevationMap&&) = default;
   ElevationMap& operator=(ElevationMap&&) = default;
+  ElevationMap(const ElevationMap&) = default;             // a deep copy, device to device (nanogrid::GridMap::copyFrom)
+  ElevationMap& operator=(const ElevationMap&) = default;
 
   /// float arguments are promoted to double exactly like the reference (elevation_map.hpp:112-116).
   void setGeometry(float width, float height, float resolution) {
@@ -83,9 +85,10 @@ class ElevationMap : public nanogrid::GridMap {
     snap.setPosition(getPosition());
     snap.setStartIndex(getStartIndex());
     snap.setTimestamp(getTimestamp());
+    const_cast<ElevationMap*>(this)->flushToDevice();
     for (const auto& name : layers) {
       if (!exists(name)) continue;
-      snap.add(name, get(name));
+      ck(fdm_engine_layer_copy(snap.eng_, eng_, name.c_str()), "layer_copy");  // device to device
     }
     return snap;
   }

@@ -4,11 +4,20 @@
 //   device -> host : on the first get()/at() after a device-side change (one download per layer)
 //   host -> device : non-const access marks the layer host-dirty; FastDEM::integrate() /
 //                    ElevationMapping::update() upload dirty layers before launching kernels.
-// A Matrix& obtained BEFORE an integrate() is a snapshot; call get() again afterwards.
+// A `Matrix&` keeps its ADDRESS for the life of the map (the reference hands out references that stay live across
+// integrate(): estimators bind raw pointers, kalman_estimation.hpp:85-95, callers hold references): the host copy of a
+// layer is refreshed IN PLACE at the first host access — get() / at() of ANY layer, by anyone — after the device
+// changed the map, so a reference held across an integrate() reads fresh data from then on.  What it cannot do is
+// refresh on a bare dereference; a reference dereferenced between the device-side change and the next get() / at()
+// would read the old values — builds without NDEBUG (or with FDM_MIRROR_GUARD) throw std::logic_error there instead.
+// GridMap is copyable (a deep copy, device to device): snapshot() by value, the ROS node's copy under a shared lock
+// (elevation_map.hpp:95-99, ros1/src/fastdem_ros_node.cpp:192-199).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -36,22 +45,45 @@ class Matrix {
  public:
   Matrix() = default;
   Matrix(int r, int c, float v = NAN) : r_(r), c_(c), d_(size_t(r) * size_t(c), v) {}
+  // a copy is a value of its own (it watches no map); assigning INTO a layer's host copy keeps that copy's watch
+  Matrix(const Matrix& o) : r_(o.r_), c_(o.c_), d_((o.guard(), o.d_)) {}
+  Matrix(Matrix&& o) noexcept : r_(o.r_), c_(o.c_), d_(std::move(o.d_)) { o.r_ = o.c_ = 0; }
+  Matrix& operator=(const Matrix& o) {
+    if (this != &o) { o.guard(); guard(); r_ = o.r_; c_ = o.c_; d_ = o.d_; }
+    return *this;
+  }
+  Matrix& operator=(Matrix&& o) noexcept {
+    if (this != &o) { r_ = o.r_; c_ = o.c_; d_ = std::move(o.d_); o.r_ = o.c_ = 0; }
+    return *this;
+  }
   int rows() const { return r_; }
   int cols() const { return c_; }
   size_t size() const { return d_.size(); }
-  float* data() { return d_.data(); }
-  const float* data() const { return d_.data(); }
-  float& operator()(int i, int j) { return d_[size_t(j) * r_ + i]; }
-  float operator()(int i, int j) const { return d_[size_t(j) * r_ + i]; }
+  float* data() { guard(); return d_.data(); }
+  const float* data() const { guard(); return d_.data(); }
+  float& operator()(int i, int j) { guard(); return d_[size_t(j) * r_ + i]; }
+  float operator()(int i, int j) const { guard(); return d_[size_t(j) * r_ + i]; }
   float& operator()(const Index& i) { return (*this)(i(0), i(1)); }
   float operator()(const Index& i) const { return (*this)(i(0), i(1)); }
-  void setConstant(float v) { std::fill(d_.begin(), d_.end(), v); }
-  bool allNaN() const { for (float v : d_) if (!std::isnan(v)) return false; return true; }
-  size_t countFinite() const { size_t n = 0; for (float v : d_) n += std::isfinite(v) ? 1 : 0; return n; }
+  void setConstant(float v) { guard(); std::fill(d_.begin(), d_.end(), v); }
+  // (a layer's host copy: GridMap sets the flag when the device changes the map and clears it when it has refreshed the
+  // copy in place; an access in between reads stale data — debug builds refuse)
+  void watch(const bool* stale) { stale_ = stale; }
+  float* raw() { return d_.data(); }
+  bool allNaN() const { guard(); for (float v : d_) if (!std::isnan(v)) return false; return true; }
+  size_t countFinite() const { guard(); size_t n = 0; for (float v : d_) n += std::isfinite(v) ? 1 : 0; return n; }
 
  private:
+  void guard() const {
+#if !defined(NDEBUG) || defined(FDM_MIRROR_GUARD)
+    if (stale_ && *stale_)
+      throw std::logic_error("nanogrid::Matrix: a reference obtained before integrate() / move() was dereferenced before the "
+                             "next GridMap::get() / at(): it would read the map as it was (call get() again)");
+#endif
+  }
   int r_ = 0, c_ = 0;
   std::vector<float> d_;
+  const bool* stale_ = nullptr;
 };
 
 // nanogrid::colorVectorToValue: 0x00RRGGBB bit-cast to float (bridge/ros/impl.hpp:20-21)
@@ -70,8 +102,13 @@ class GridMap {
  public:
   GridMap() = default;
   explicit GridMap(const std::vector<std::string>& layers) : initial_layers_(layers) {}
-  GridMap(const GridMap&) = delete;
-  GridMap& operator=(const GridMap&) = delete;
+  // a deep copy: an engine of its own, every layer copied device to device (host writes of `o` that have not reached
+  // the device yet go there first)
+  GridMap(const GridMap& o) { copyFrom(o); }
+  GridMap& operator=(const GridMap& o) {
+    if (this != &o) copyFrom(o);
+    return *this;
+  }
   GridMap(GridMap&& o) noexcept { *this = std::move(o); }
   GridMap& operator=(GridMap&& o) noexcept {
     if (this != &o) {
@@ -80,7 +117,7 @@ class GridMap {
       rows_ = o.rows_; cols_ = o.cols_; res_ = o.res_; length_ = o.length_;
       frame_id_ = std::move(o.frame_id_); timestamp_ = o.timestamp_;
       mirror_ = std::move(o.mirror_); initial_layers_ = std::move(o.initial_layers_);
-      pending_pos_ = o.pending_pos_;
+      pending_pos_ = o.pending_pos_; move_clear_basic_ = o.move_clear_basic_; device_ = o.device_;
     }
     return *this;
   }
@@ -100,6 +137,14 @@ class GridMap {
     mirror_.clear();
     for (const auto& n : initial_layers_)
       if (!exists(n)) add(n);
+    if (move_clear_basic_) setMoveClearBasic(true);
+  }
+  // Which layers move() clears in the strips it vacates: every layer (default, what this repo assumes of nanoGrid) or
+  // the basic layers {elevation, elevation_min, elevation_max} only — the other reading (scripts/conformance/probe.cpp
+  // tells which one the real library implements)
+  void setMoveClearBasic(bool on) {
+    move_clear_basic_ = on;
+    if (eng_) ck(fdm_engine_set_option(eng_, "move_clear_basic", on ? 1 : 0), "set_option(move_clear_basic)");
   }
   bool hasEngine() const { return eng_ != nullptr; }
   fdm_engine* engine() const { return eng_; }
@@ -169,13 +214,13 @@ class GridMap {
   void add(const std::string& n, float value = NAN) {
     need();
     ck(fdm_engine_layer_add(eng_, n.c_str(), value), "layer_add");
-    mirror_.erase(n);
+    outdated(n);
   }
   void add(const std::string& n, const Matrix& m) {
     need();
     if (m.rows() != rows_ || m.cols() != cols_) throw std::invalid_argument("layer shape mismatch");
     ck(fdm_engine_layer_upload(eng_, n.c_str(), m.data(), rows_, cols_), "layer_upload");
-    mirror_.erase(n);
+    outdated(n);
   }
   Matrix& get(const std::string& n) {
     Mirror& m = fetch(n);
@@ -198,39 +243,83 @@ class GridMap {
   void clear(const std::string& n) {
     need();
     ck(fdm_engine_clear(eng_, n.c_str()), "clear");
-    mirror_.erase(n);
+    outdated(n);
   }
   void clearAll() {
     if (!eng_) return;
     ck(fdm_engine_clear(eng_, nullptr), "clearAll");
-    mirror_.clear();
+    invalidateHost();
   }
 
   // ---- coherence hooks used by FastDEM / ElevationMapping ----
   void flushToDevice() {
     if (!eng_) return;
     for (auto& kv : mirror_)
-      if (kv.second.dirty) {
-        ck(fdm_engine_layer_upload(eng_, kv.first.c_str(), kv.second.host.data(), rows_, cols_), "layer_upload");
-        kv.second.dirty = false;
+      if (kv.second->dirty && !kv.second->stale) {
+        ck(fdm_engine_layer_upload(eng_, kv.first.c_str(), kv.second->host.raw(), rows_, cols_), "layer_upload");
+        kv.second->dirty = false;
       }
   }
-  void invalidateHost() { mirror_.clear(); }
+  // the device changed the map: every host copy is out of date until the next host access refreshes it in place
+  void invalidateHost() {
+    for (auto& kv : mirror_) { kv.second->stale = true; kv.second->dirty = false; }
+    any_stale_ = !mirror_.empty();
+  }
 
  protected:
   struct Mirror {
     Matrix host;
     bool dirty = false;
+    bool stale = false;   // the device holds newer data (Matrix::guard watches this flag)
   };
+  void outdated(const std::string& n) {
+    auto it = mirror_.find(n);
+    if (it != mirror_.end()) { it->second->stale = true; it->second->dirty = false; any_stale_ = true; }
+  }
+  // the first host access after a device-side change refreshes EVERY host copy in place (a layer that no longer exists
+  // reads as NaN): whoever holds a Matrix& of any layer reads fresh data from here on
+  void refresh() {
+    if (!any_stale_) return;
+    for (auto& kv : mirror_) {
+      Mirror& m = *kv.second;
+      if (!m.stale) continue;
+      if (exists(kv.first)) ck(fdm_engine_layer_download(eng_, kv.first.c_str(), m.host.raw(), rows_, cols_), "layer_download");
+      else std::fill(m.host.raw(), m.host.raw() + m.host.size(), NAN);
+      m.stale = false;
+    }
+    any_stale_ = false;
+  }
   Mirror& fetch(const std::string& n) {
     need();
+    refresh();
     auto it = mirror_.find(n);
-    if (it != mirror_.end()) return it->second;
+    if (it != mirror_.end()) {
+      if (!exists(n)) throw std::out_of_range("GridMap::get(): no layer '" + n + "'");
+      return *it->second;
+    }
     if (!exists(n)) throw std::out_of_range("GridMap::get(): no layer '" + n + "'");
-    Mirror m;
-    m.host = Matrix(rows_, cols_);
-    ck(fdm_engine_layer_download(eng_, n.c_str(), m.host.data(), rows_, cols_), "layer_download");
-    return mirror_.emplace(n, std::move(m)).first->second;
+    std::unique_ptr<Mirror> m(new Mirror);
+    m->host = Matrix(rows_, cols_);
+    ck(fdm_engine_layer_download(eng_, n.c_str(), m->host.raw(), rows_, cols_), "layer_download");
+    m->host.watch(&m->stale);
+    return *mirror_.emplace(n, std::move(m)).first->second;
+  }
+  void copyFrom(const GridMap& o) {
+    release();
+    rows_ = cols_ = 0;
+    frame_id_ = o.frame_id_; timestamp_ = o.timestamp_; initial_layers_ = o.initial_layers_;
+    pending_pos_ = o.pending_pos_; device_ = o.device_; move_clear_basic_ = o.move_clear_basic_;
+    if (!o.eng_) return;
+    const_cast<GridMap&>(o).flushToDevice();
+    const fdm_geometry g = o.geom();
+    fdm_geometry mine{};
+    mine.length_x = g.length_x; mine.length_y = g.length_y; mine.resolution = g.resolution;
+    mine.position_x = g.position_x; mine.position_y = g.position_y;
+    ck(fdm_engine_create_map(&mine, nullptr, device_, &eng_), "fdm_engine_create_map");
+    rows_ = o.rows_; cols_ = o.cols_; res_ = o.res_; length_ = o.length_;
+    ck(fdm_engine_set_start_index(eng_, g.start_row, g.start_col), "set_start_index");
+    if (move_clear_basic_) ck(fdm_engine_set_option(eng_, "move_clear_basic", 1), "set_option(move_clear_basic)");
+    for (const auto& n : o.getLayers()) ck(fdm_engine_layer_copy(eng_, o.eng_, n.c_str()), "layer_copy");
   }
   fdm_geometry geom() const {
     fdm_geometry g{};
@@ -259,7 +348,10 @@ class GridMap {
   uint64_t timestamp_ = 0;
   std::vector<std::string> initial_layers_;
   Position pending_pos_{0.0, 0.0};
-  mutable std::unordered_map<std::string, Mirror> mirror_;
+  bool move_clear_basic_ = false;
+  bool any_stale_ = false;
+  // (heap nodes: a Matrix& — and the flag its guard watches — keep their address when the map is moved or rehashed)
+  mutable std::unordered_map<std::string, std::unique_ptr<Mirror>> mirror_;
 };
 
 }  // namespace nanogrid

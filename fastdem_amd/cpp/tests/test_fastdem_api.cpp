@@ -1279,3 +1279,94 @@ TEST(PointCloud4, IntegrateGivesTheMapOfTheSoACloudBitForBit) {  // fastdem.cpp:
 }
 
 int main(int argc, char** argv) { return mini::run(argc > 1 ? argv[1] : nullptr); }
+
+// ---------------------------------------------------------------- the mirror's reference and copy semantics ----
+// The reference hands out Matrix& that stay live across integrate() (estimators bind raw pointers,
+// kalman_estimation.hpp:85-95) and its map is copyable (snapshot() by value, elevation_map.hpp:95-99; the ROS node copies
+// it under a shared lock, ros1/src/fastdem_ros_node.cpp:192-199).
+TEST(MirrorSemantics, AHeldReferenceKeepsItsAddressAndIsRefreshedInPlace) {
+  Fixture f;
+  FastDEM mapper(f.map);
+  mapper.setHeightFilter(-2.0f, 5.0f).setRangeFilter(0.0f, 20.0f).setSensorModel(SensorType::Constant);
+  auto& elev = f.map.get(layer::elevation);           // obtained BEFORE the scan
+  const float* const address = elev.data();
+  EXPECT_EQ(elev.countFinite(), size_t(0));
+  ASSERT_TRUE(mapper.integrate(makeGroundCloud(1.0f), f.T_base_sensor, f.T_world_base));
+  // (debug builds: the reference is stale until the next host access of the map ...)
+  EXPECT_THROW((void)elev.countFinite(), std::logic_error);
+  // ... of ANY layer, by anyone: every host copy is refreshed in place
+  EXPECT_TRUE(f.map.exists(layer::variance));
+  (void)f.map.get(layer::variance);
+  EXPECT_EQ(elev.data(), address);
+  EXPECT_GT(elev.countFinite(), size_t(0));
+  nanogrid::Index c;
+  ASSERT_TRUE(f.map.getIndex(nanogrid::Position(0.0, 0.0), c));
+  EXPECT_NEAR(elev(c), 1.0f, 0.1f);
+  // a second scan, a write through a FRESH reference, a third scan that sees it
+  ASSERT_TRUE(mapper.integrate(makeGroundCloud(1.2f), f.T_base_sensor, f.T_world_base));
+  auto& again = f.map.get(layer::elevation);
+  EXPECT_EQ(&again, &elev);
+  again(c) = 7.0f;
+  ASSERT_TRUE(mapper.integrate(makeGroundCloud(1.2f), f.T_base_sensor, f.T_world_base));
+  EXPECT_GT(f.map.at(layer::elevation, c), 1.25f);     // (the estimator started from 7, not from ~1.1)
+  // a copy of a layer's matrix is a value of its own
+  nanogrid::Matrix value = f.map.get(layer::elevation);
+  ASSERT_TRUE(mapper.integrate(makeGroundCloud(1.2f), f.T_base_sensor, f.T_world_base));
+  EXPECT_NO_THROW((void)value.countFinite());
+}
+
+TEST(MirrorSemantics, TheMapIsCopyableADeepCopy) {
+  Fixture f;
+  FastDEM mapper(f.map);
+  mapper.setHeightFilter(-2.0f, 5.0f).setRangeFilter(0.0f, 20.0f).setSensorModel(SensorType::Constant);
+  ASSERT_TRUE(mapper.integrate(makeGroundCloud(1.0f), f.T_base_sensor, f.T_world_base));
+  f.map.setFrameId("map");
+  f.map.setTimestamp(42);
+  nanogrid::Index c;
+  ASSERT_TRUE(f.map.getIndex(nanogrid::Position(0.3, -0.3), c));
+  f.map.at(layer::elevation, c) = 3.5f;                // (a host write that has not reached the device yet)
+  ElevationMap copy = f.map;                           // copy constructor
+  EXPECT_TRUE(copy.isInitialized());
+  EXPECT_EQ(copy.getFrameId(), std::string("map"));
+  EXPECT_EQ(copy.getTimestamp(), uint64_t(42));
+  EXPECT_EQ(copy.getLayers().size(), f.map.getLayers().size());
+  EXPECT_EQ(copy.getStartIndex()(0), f.map.getStartIndex()(0));
+  EXPECT_FLOAT_EQ(copy.at(layer::elevation, c), 3.5f);
+  for (const auto& name : f.map.getLayers()) {
+    const auto& a = f.map.get(name);
+    const auto& b = copy.get(name);
+    bool same = true;
+    for (size_t k = 0; k < a.size(); ++k) {
+      const float x = a.data()[k], y = b.data()[k];
+      same = same && ((std::isnan(x) && std::isnan(y)) || x == y);
+    }
+    EXPECT_TRUE(same);
+  }
+  // the two maps live their own lives
+  ASSERT_TRUE(mapper.integrate(makeGroundCloud(2.0f), f.T_base_sensor, f.T_world_base));
+  EXPECT_FLOAT_EQ(copy.at(layer::elevation, c), 3.5f);
+  copy.clearAll();
+  EXPECT_TRUE(copy.isEmpty());
+  EXPECT_FALSE(f.map.isEmpty());
+  ElevationMap assigned;
+  assigned = f.map;                                    // copy assignment
+  EXPECT_FALSE(assigned.isEmpty());
+  // the ROS node's pattern (fastdem_ros_node.cpp:192-199): a snapshot by value of a few layers
+  const ElevationMap snap = f.map.snapshot({layer::elevation, layer::variance});
+  EXPECT_EQ(snap.getLayers().size(), size_t(4));  // (elevation_min / _max come with the constructor)
+}
+
+TEST(MirrorSemantics, MoveClearScopeSwitch) {   // which layers move()'s strips clear
+  for (int basic = 0; basic < 2; ++basic) {
+    ElevationMap m;
+    m.setGeometry(2.0f, 2.0f, 0.1f);
+    m.setMoveClearBasic(basic != 0);
+    m.add("user", 1.0f);
+    m.get(layer::elevation).setConstant(1.0f);
+    m.move(nanogrid::Position(0.3, 0.0));              // three rows vacated
+    EXPECT_EQ(m.get(layer::elevation).countFinite(), size_t(20 * 20 - 3 * 20));
+    EXPECT_EQ(m.get("user").countFinite(), size_t(basic ? 20 * 20 : 20 * 20 - 3 * 20));
+    m.move(nanogrid::Position(9.0, 0.0));              // beyond the map: clearAll() in both readings
+    EXPECT_EQ(m.get("user").countFinite(), size_t(0));
+  }
+}

@@ -122,7 +122,7 @@ struct ScanParams {
   int force_inside;    // 1: "some point of the scan landed in the map" holds whatever this engine's points say (a
                        //    routed slice of a larger scan: the fact is global, fdm_engine_integrate_points4_device)
   int move_basic;      // 1: the strips a move shorter than the map vacates clear the basic layers {elevation, elevation_min,
-};                     //    elevation_max} only (option "move_clear_basic": the other reading of nanoGrid's move(), oracle/fdm_grid.hpp)
+};                     //    elevation_max} only (option "move_clear_basic": the other reading of nanoGrid's move())
 
 // ---- helpers ----
 // uniform value that came out of LDS / a ballot: tell the compiler (everything derived from it — tile number,

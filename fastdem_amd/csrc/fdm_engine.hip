@@ -209,7 +209,7 @@ struct fdm_engine {
   bool tiled_forced = false;        // tiled_min was set by hand (option "tiled_min"): no map-size condition
   int upd_blocks = 768;             // option "upd_blocks": update blocks (four tile wavefronts each) of a FUSED launch
   int upd_blocks_alone = 2048;      // option "upd_blocks_alone": ... of an update launch of its own
-  int move_clear_basic = 0;         // option "move_clear_basic": GridMap::move()'s strips clear {elevation, elevation_min, elevation_max} only (the other reading of nanoGrid, oracle/fdm_grid.hpp clearStrip); such an engine takes no batch launches
+  int move_clear_basic = 0;         // option "move_clear_basic": GridMap::move()'s strips clear {elevation, elevation_min, elevation_max} only (the other reading of nanoGrid: DESIGN.md §6); such an engine takes no batch launches
   int upd_prio = 1;                 // option "upd_prio": update wavefronts run at raised issue priority
   int tiled_lds_pad = 4096;         // option "tiled_lds_pad": extra dynamic LDS per block of the large-scan bin / fused launches: 4 KB = six blocks per CU instead of seven (configs[3]: 32.3 -> 31.8 us; fewer: slower)
   int cnt_shift = 5;                // option "cnt_shift": one tile counter per 2^cnt_shift words (TilePool::cnt_shift); takes effect before the pools exist

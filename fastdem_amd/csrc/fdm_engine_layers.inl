@@ -132,6 +132,33 @@ int fdm_engine_layer_upload(fdm_engine* e, const char* name, const float* host, 
   return FDM_OK;
 }
 
+// A copy of a map (ElevationMap's copy constructor, snapshot(): elevation_map.hpp:95-99; the ROS node copies the map under
+// a shared lock, ros1/src/fastdem_ros_node.cpp:192-199): layer `name` of `src` into the layer of the same name of `dst`
+// (created if missing), device to device — no host staging.  Same device, same stored window.
+int fdm_engine_layer_copy(fdm_engine* dst, fdm_engine* src, const char* name) {
+  if (!dst || !src || !name) return fail(FDM_ERR_INVALID, "null argument");
+  if (dst == src) return FDM_OK;
+  if (int rc = join_streams(src)) return rc;
+  if (int rc = join_streams(dst)) return rc;
+  if (dst->device != src->device) return fail(FDM_ERR_INVALID, "layer_copy: engines on different devices");
+  if (dst->G.s_rows != src->G.s_rows || dst->G.s_cols != src->G.s_cols) return fail(FDM_ERR_INVALID, "layer_copy: shape mismatch");
+  HIPCK(hipSetDevice(dst->device));
+  if (int rc = resolve_pending(src)) return rc;
+  Layer* ls = find_layer(src, name);
+  if (!ls || ls->pending) return fail(FDM_ERR_NO_LAYER, std::string("no layer ") + name);
+  if (int rc = sync_all(src)) return rc;  // (the source map is current; its stream has drained)
+  Layer* ld = find_layer(dst, name);
+  if (!ld) {
+    if (int rc = add_layer(dst, name, NAN, false)) return rc;
+    ld = find_layer(dst, name);
+    ls = find_layer(src, name);
+  }
+  ld->pending = false;
+  if (std::strcmp(name, "obstacle") == 0) { dst->obst_dense_pending = true; dst->obst_owe_armed = false; }
+  if (int rc = copy_strided(dst, lptr(dst, *ld), lstride(dst, *ld), lptr(src, *ls), lstride(src, *ls))) return rc;
+  return sync_all(dst);
+}
+
 float* fdm_engine_layer_device_ptr(fdm_engine* e, const char* name) {
   if (e) { if (int rc_join = join_streams(e)) { (void)rc_join; return nullptr; } }
   if (!e || !name) return nullptr;

@@ -383,6 +383,10 @@ class Engine:
         _ck(self._lib.fdm_engine_layer_upload(self._h, name.encode(), _ptr(a), self.s_rows,
                                               self.s_cols))
 
+    def copy_layer_from(self, other, name):
+        """Layer `name` of another engine (same device, same window) into this one, device to device."""
+        _ck(self._lib.fdm_engine_layer_copy(self._h, other._h, name.encode()))
+
     def layer_device_ptr(self, name):
         return self._lib.fdm_engine_layer_device_ptr(self._h, name.encode())
 

@@ -253,6 +253,10 @@ int fdm_engine_layer_upload(fdm_engine* e, const char* name, const float* host, 
 float* fdm_engine_layer_device_ptr(fdm_engine* e, const char* name); /* NULL if absent or if the layer is
                                                                       a field of the packed cell records */
 int fdm_engine_clear(fdm_engine* e, const char* name /* NULL = clearAll */);
+/* Copy of a map, layer by layer, device to device (ElevationMap's copy constructor / snapshot(), elevation_map.hpp:95-99;
+ * the ROS node's copy under a shared lock, ros1/src/fastdem_ros_node.cpp:192-199): layer `name` of `src` into `dst`
+ * (created there if missing).  Both engines on one device with the same stored window. */
+int fdm_engine_layer_copy(fdm_engine* dst, fdm_engine* src, const char* name);
 
 /* Halo exchange support for spatial tiling: pack the rectangle [r0,r0+nr) x [c0,c0+nc)
  * (storage-local indices) of `n_layers` named layers into a contiguous device buffer

@@ -62,3 +62,38 @@ def test_cpp_multi_gpu_loops_with_a_one_rank_rccl_communicator():
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "halo loop: ok" in r.stdout
+
+
+def test_conformance_expected_is_current():
+    """scripts/conformance/expected.json + vectors.inc are what make_expected.py generates from the oracle today."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts", "conformance"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import make_expected as M
+    exp = json.load(open(os.path.join(ROOT, "scripts", "conformance", "expected.json")))
+    assert exp["index"] == M.expect_index() and exp["colors"] == M.expect_colors() and exp["regions"] == M.expect_regions()
+    assert exp["move_all"] == M.expect_move(0) and exp["move_basic"] == M.expect_move(1) and exp["move_all"] != exp["move_basic"]
+    assert exp["pre"] == M.expect_pre()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("basic", [0, 1])
+def test_conformance_probe_through_the_mirror(basic, tmp_path):
+    """The maintainer-side probe (scripts/conformance/probe.cpp) compiled against THIS repo's C++ mirror and run on the
+    engine: index arithmetic, move() — in both readings of which layers it clears —, the packed colour, the preprocessed
+    cloud incl. R Sigma R^T and every layer of the map after two scans per sensor model and estimator must be what the
+    oracle put into expected.json.  (What the probe prints about the REAL libraries is the maintainer's to run:
+    INTEGRATION.md §C.)"""
+    exe = os.path.join(ROOT, "fastdem_amd", "cpp", "build", "fdm_probe_mirror")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "fastdem_amd", "cpp")])
+    r = subprocess.run([exe] + (["--move-clear-basic"] if basic else []), capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = tmp_path / "probe.txt"
+    out.write_text(r.stdout)
+    c = subprocess.run(["python3", os.path.join(ROOT, "scripts", "conformance", "check.py"), str(out), "--skip", "regions"],
+                       capture_output=True, text=True, timeout=120)
+    print(c.stdout)
+    assert c.returncode == 0, c.stdout + c.stderr
+    assert ("BASIC layers only" in c.stdout) == bool(basic)
