@@ -456,6 +456,46 @@ def host_legs(res, wl, k, iters=50, stream_iters=200):
     return out
 
 
+def rank_identity(args, rank, world, device):
+    """Who ran this line — so that the first run on N devices certifies itself: per rank the device it
+    computed on (index, PCI bus id, UUID, name) and host; `rccl_ranks` = the size RCCL ITSELF reports for a communicator
+    built over the job's ranks (ncclCommCount on fastdem_amd.halo.make_comm's communicator — the one libfdm_halo's
+    collectives use), `rccl_allreduce_sum` = a device all-reduce of ones through torch's process group (== N iff every
+    rank's GPU took part), `distinct_devices` = distinct UUIDs over the ranks.  Collective: every rank calls it."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    p = torch.cuda.get_device_properties(device)
+    me = {"rank": rank, "device": int(device), "name": p.name, "uuid": str(getattr(p, "uuid", "")),
+          "pci_bus_id": f"{getattr(p, 'pci_domain_id', 0):04x}:{getattr(p, 'pci_bus_id', 0):02x}:{getattr(p, 'pci_device_id', 0):02x}",
+          "cus": int(p.multi_processor_count), "host": socket.gethostname()}
+    out = {"backend": args.backend if world > 1 or dist.is_initialized() else "none", "world_size": world}
+    ranks = [me]
+    if dist.is_initialized():
+        box = [None] * world
+        dist.all_gather_object(box, me)
+        ranks = box
+        if args.backend == "nccl":
+            ones = torch.ones(1, dtype=torch.int32, device=f"cuda:{device}")
+            dist.all_reduce(ones)
+            out["rccl_allreduce_sum"] = int(ones.item())
+            try:
+                import ctypes as C
+                from fastdem_amd import halo
+                comm = halo.make_comm(rank, world, dist)
+                n = C.c_int(-1)
+                nccl = halo._rccl()
+                nccl.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+                rc = nccl.ncclCommCount(comm, C.byref(n))
+                out["rccl_ranks"] = int(n.value) if rc == 0 else f"ncclCommCount failed: {rc}"
+                halo.destroy_comm(comm)
+            except Exception as e:  # (the line is printed whatever happens here)
+                out["rccl_ranks"] = f"unavailable: {type(e).__name__}: {e}"
+    out["distinct_devices"] = len({(r["host"], r["uuid"] or r["pci_bus_id"]) for r in ranks})
+    out["ranks"] = ranks
+    return out
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks here — one process per GPU through
     torch.distributed.run, rendezvous on 127.0.0.1 — BEFORE this process has touched the GPU (it never does: it only
@@ -793,10 +833,15 @@ def main():
         if rank == 0:
             result["global_map"] = g
             result["global_map_ok"] = bool(g) and "error" not in g
+    try:
+        ident = rank_identity(args, rank, world, local_rank)
+    except Exception as e:  # (never in the way of the line)
+        ident = {"error": f"{type(e).__name__}: {e}"}
     if world > 1 or routed:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        result["ranks"] = ident
         print(json.dumps(result))
 
 

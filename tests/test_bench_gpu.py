@@ -32,12 +32,23 @@ def test_gpus_2_global_map_unwrapped():
     assert r["roofline"] and r["roofline"]["achieved"] > 0 and 0 < r["roofline"]["frac"] < 1
 
 
+def test_one_rank_rccl_line_certifies_its_communicator():
+    """`--workload c5` with ONE rank runs its collectives over RCCL (a 1-rank communicator): the line says what RCCL saw."""
+    r = run_bench("--workload", "c5", "--steps", "3", "--warmup", "1", "--global-size-m", "100")
+    who = r["ranks"]
+    assert who["backend"] == "nccl" and who["rccl_ranks"] == 1 and who["rccl_allreduce_sum"] == 1, who
+
+
 def test_gpus_2_default_workload_prints_replicas_and_the_global_map():
     r = run_bench("--gpus", "2", "--backend", "gloo", "--devices", "0,0", "--steps", "4", "--warmup", "2",
                   "--no-cpu-baseline", "--no-host-legs")
     assert r["n_gpus"] == 2 and "replicas" in r["config"]["parallelism"]
     g = r["global_map"]
     assert g["n_gpus"] == 2 and g["roofline"]["achieved"] > 0 and g["value"] > 0
+    # who ran the line: two ranks, both on the ONE device of this box (an 8-GPU run must read distinct_devices 8)
+    who = r["ranks"]
+    assert who["world_size"] == 2 and [x["rank"] for x in who["ranks"]] == [0, 1] and who["distinct_devices"] == 1
+    assert all(x["cus"] == 256 and x["uuid"] for x in who["ranks"])
 
 
 def test_a_failing_global_map_leg_does_not_take_the_replicas_line_with_it():
@@ -79,4 +90,5 @@ def test_one_rank_of_the_n_rank_path_reproduces_the_default_line():
     a = run_bench("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-host-legs", "--no-large")
     b = run_bench("--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-host-legs", "--no-large")
     assert a["n_gpus"] == b["n_gpus"] == 1 and a["repeats"] >= 25 and b["repeats"] >= 25
+    assert b["ranks"]["world_size"] == 1 and b["ranks"]["distinct_devices"] == 1 and b["ranks"]["ranks"][0]["cus"] == 256
     assert abs(a["value"] - b["value"]) / b["value"] < 0.05, (a["value"], b["value"])
