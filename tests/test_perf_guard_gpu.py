@@ -1,18 +1,45 @@
-"""Performance guards (GPU): device-side time per scan of every BASELINE config against a GENEROUS ceiling — about
-1.5 x what profiles/r05 holds.  Not a benchmark (bench.py is): a tripwire for an order-of-magnitude slip that no parity
-test sees.  Round 5 shipped the reason for it: a tile-walk change left every layer bit-identical and configs[4] at
-176 us per scan instead of 36, and only the end-of-round evidence pass noticed."""
+"""Performance guards (GPU): device-side time per scan of every BASELINE config, with and without raycasting, against a
+ceiling of 1.2 x what profiles/r06/perf_guard.json holds (best of five there and here) — scaled by how this box's
+device-to-device copy bandwidth compares with the box the figures were taken on, and only on the device they were taken
+on (256 CUs).  Not a benchmark (bench.py is): a tripwire for a slip that no parity test sees.  Round 5 shipped the
+reason for it: a tile-walk change left every layer bit-identical and configs[4] at 176 us per scan instead of 36, and
+only the end-of-round evidence pass noticed; and ADVICE r05: a pipeline state that quietly costs an enqueue-only stream
+its batch launches is invisible to guards that sync between regions — the last test here does not."""
+import json
 import os
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+MEASURED = json.load(open(os.path.join(ROOT, "profiles", "r06", "perf_guard.json")))
+MARGIN = 1.2
 
 
-def device_us_per_scan(gpu, wl, warm, timed, raycast=0, **options):
+def box_scale():
+    """>= 1: how much slower this box copies device memory than the box of profiles/r06/perf_guard.json (a shared or
+    down-clocked GPU must not fail the suite); skips on another device altogether."""
+    import torch
+    p = torch.cuda.get_device_properties(0)
+    if p.multi_processor_count != MEASURED["cus"]:
+        pytest.skip(f"the figures were taken on a {MEASURED['cus']}-CU device; this one has {p.multi_processor_count}")
+    a = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+    b = torch.empty_like(a)
+    best = float("inf")
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return max(1.0, best / MEASURED["copy_256MiB_ms"]), best
+
+
+def device_us_per_scan(gpu, wl, warm, timed, raycast=0, reps=5, **options):
     import bench
     res = bench.Resident(wl, 0)
     for k, v in options.items():
@@ -25,39 +52,73 @@ def device_us_per_scan(gpu, wl, warm, timed, raycast=0, **options):
     assert res.eng.integrate_device_batch(w) == 0
     res.eng.sync()
     best = float("inf")
-    for rep in range(3):  # (the best of three: a noisy neighbour must not fail the suite)
+    for rep in range(reps):  # (the best of five: a noisy neighbour must not fail the suite)
         b, _ = res.batch(warm + rep * timed, timed)
         assert res.eng.integrate_device_batch_timed(b) == 0
         best = min(best, res.eng.timer_ms() / timed * 1e3)
     return best
 
 
-# (workload, scans, ceiling in us per scan, measured in profiles/r05)
-CASES = [
-    ("c2", dict(n_scans=16), 160, 2.0, "1.05"),
-    ("c3", dict(n_scans=8), 96, 8.0, "4.8"),
-    ("c4", dict(n_scans=4), 40, 48.0, "31"),
-    ("c5", dict(n_scans=4), 40, 55.0, "36"),
-]
+CASES = [("c2", dict(n_scans=16), 160), ("c3", dict(n_scans=8), 96), ("c4", dict(n_scans=4), 40), ("c5", dict(n_scans=4), 40)]
+RAY_CASES = [("c2", dict(n_scans=16), 96), ("c3", dict(n_scans=4), 16), ("c4", dict(n_scans=3), 8)]
 
 
-@pytest.mark.parametrize("name,kw,timed,ceiling,measured", CASES, ids=[c[0] for c in CASES])
-def test_integrate_stays_within_reach_of_the_measured_time(gpu, name, kw, timed, ceiling, measured):
+def check(name, us, key):
+    scale, copy_ms = box_scale()
+    measured = MEASURED[key][name]
+    ceiling = MARGIN * scale * measured
+    assert us < ceiling, (f"{name} ({key}): {us:.2f} us per scan on the device; profiles/r06/perf_guard.json: {measured:.2f}, "
+                          f"ceiling {ceiling:.2f} (x {MARGIN} x box scale {scale:.2f}: 256 MiB copy {copy_ms:.3f} ms here)")
+
+
+@pytest.mark.parametrize("name,kw,timed", CASES, ids=[c[0] for c in CASES])
+def test_integrate_stays_within_reach_of_the_measured_time(gpu, name, kw, timed):
     if gpu.Engine.default_options:
         pytest.skip("the engine's own pipeline choice only (the other fixture variant forces slower paths on purpose)")
-    wl = gpu.synth.make(name, **kw)
-    us = device_us_per_scan(gpu, wl, 32, timed)
-    assert us < ceiling, f"{name}: {us:.1f} us per scan on the device (profiles/r05: {measured}; ceiling {ceiling})"
+    check(name, device_us_per_scan(gpu, gpu.synth.make(name, **kw), 32, timed), "integrate_us")
 
 
-@pytest.mark.parametrize("name,kw,timed,ceiling,measured", [
-    ("c2", dict(n_scans=16), 96, 16.0, "9.3"),
-    ("c3", dict(n_scans=4), 16, 170.0, "100"),
-    ("c4", dict(n_scans=3), 8, 520.0, "350"),
-], ids=["c2", "c3", "c4"])
-def test_raycasting_stays_within_reach_of_the_measured_time(gpu, name, kw, timed, ceiling, measured):
+@pytest.mark.parametrize("name,kw,timed", RAY_CASES, ids=[c[0] for c in RAY_CASES])
+def test_raycasting_stays_within_reach_of_the_measured_time(gpu, name, kw, timed):
     if gpu.Engine.default_options:
         pytest.skip("the engine's own pipeline choice only")
-    wl = gpu.synth.make(name, **kw)
-    us = device_us_per_scan(gpu, wl, 8, timed, raycast=1)
-    assert us < ceiling, f"{name} with raycasting: {us:.1f} us per scan (profiles/r05: {measured}; ceiling {ceiling})"
+    check(name, device_us_per_scan(gpu, gpu.synth.make(name, **kw), 8, timed, raycast=1), "raycast_us")
+
+
+def test_an_enqueue_only_stream_gets_its_batch_launches_back_behind_a_host_write(gpu):
+    """A host write of the obstacle layer (or a pipeline switch) leaves a whole-layer clear owed; until a scan that observed
+    a cell has paid it every scan is "not plain": no fused launch, no batch launch, two extra launches per scan.  The
+    host learns that the debt is paid from pinned memory, WITHOUT a sync — an enqueue-only caller must be
+    back in batch launches a few scans later, and at the usual time per scan."""
+    if gpu.Engine.default_options:
+        pytest.skip("the engine's own pipeline choice only")
+    import bench
+    wl = gpu.synth.make("c2", n_scans=16)
+    res = bench.Resident(wl, 0)
+    w, _ = res.batch(0, 32)
+    assert res.eng.integrate_device_batch(w) == 0
+    res.eng.sync()
+    a = res.eng.layer("obstacle")
+    a[3, :] = np.float32(0.5)
+    res.eng.set_layer("obstacle", a)          # the debt
+    before = sum(res.eng.batch_launches())
+    keep = []
+    for rep in range(6):                      # enqueue-only calls, no sync in between
+        b, _ = res.batch(32 + rep * 64, 64)
+        keep.append(b)
+        assert res.eng.integrate_device_batch(b) == 0
+    assert sum(res.eng.batch_launches()) > before, "no batch launch behind the host write: the debt never fell without a sync"
+    b, _ = res.batch(500, 160)
+    assert res.eng.integrate_device_batch_timed(b) == 0
+    check("c2", res.eng.timer_ms() / 160 * 1e3, "integrate_us")
+
+
+if __name__ == "__main__":   # python tests/test_perf_guard_gpu.py > profiles/rNN/perf_guard.json  (on the GPU box)
+    import torch
+    import fastdem_amd as gpu
+    MEASURED = {"cus": torch.cuda.get_device_properties(0).multi_processor_count, "copy_256MiB_ms": 1e9}
+    out = {"device": torch.cuda.get_device_properties(0).name, "cus": MEASURED["cus"]}
+    out["copy_256MiB_ms"] = round(box_scale()[1], 4)
+    out["integrate_us"] = {n: round(device_us_per_scan(gpu, gpu.synth.make(n, **kw), 32, t), 3) for n, kw, t in CASES}
+    out["raycast_us"] = {n: round(device_us_per_scan(gpu, gpu.synth.make(n, **kw), 8, t, raycast=1), 3) for n, kw, t in RAY_CASES}
+    print(json.dumps(out))
