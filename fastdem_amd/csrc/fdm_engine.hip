@@ -1602,7 +1602,14 @@ int fdm_engine_integrate_points4(fdm_engine* e, uint64_t n, const float* xyz1, c
   if (sigma_z2) { if ((rc = up(sigma_z2, 5))) return rc; dv = base + cap * 5; }
   ScanParams P;
   fill_integrate_params(e, P, Tbs, Twb);
-  if ((rc = enqueue_scan(e, P, n, base, base + cap, base + cap * 2, da, dc, dv))) return rc;
+  // (the channels already sit in the engine's own staging slot, which stays valid until read_stats below has flushed the
+  // held-back update: the update gathers from the slot itself — without this a plain non-tiled scan took a SECOND slot
+  // and had the bin kernel write x / y / z through to it, 12 B per point for nothing: ADVICE r05)
+  const bool borrow = e->borrow_inputs;
+  e->borrow_inputs = true;
+  rc = enqueue_scan(e, P, n, base, base + cap, base + cap * 2, da, dc, dv);
+  e->borrow_inputs = borrow;
+  if (rc) return rc;
   int status = FDM_OK;
   if ((rc = read_stats(e, out, &status))) return rc;
   return status;

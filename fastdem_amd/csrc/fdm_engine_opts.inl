@@ -265,7 +265,11 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
     e->dbg_post = value;
     return FDM_OK;
   }
+  // (the ray options are read when a scan's raycasting stage is LAUNCHED; under ray_hold the previous scan's stage may
+  // still be pending: it leaves first, so that a switch never lands in the scan before it — results are the same either
+  // way, A/B timings are attributed to the right scan: ADVICE r05)
   if (std::strcmp(key, "ray_large_min") == 0) {
+    if (int rc = join_streams(e)) return rc;
     e->ray_large_min = value < 1 ? 1 : value;
     return FDM_OK;
   }
@@ -275,10 +279,12 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
     return FDM_OK;
   }
   if (std::strcmp(key, "ray_wedge") == 0) {
+    if (int rc = join_streams(e)) return rc;
     e->ray_wedge = value != 0;
     return FDM_OK;
   }
   if (std::strcmp(key, "dbg_ray") == 0) {
+    if (int rc = join_streams(e)) return rc;
     e->dbg_ray = value;
     return FDM_OK;
   }
