@@ -228,7 +228,10 @@ struct fdm_engine {
   int last_do_move = 0, last_gate = 0;
   // ---- batch pipeline (fdm_multi.hpp): up to kMaxBatch small scans per launch, allocated by the first batch ----
   int batch = 1;                     // option "batch": fdm_engine_integrate_device_batch groups eligible scans
-  int batch_max = kMaxBatch;         // option "batch_max": scans per launch (2 .. kMaxBatch)
+  int batch_max = 0;                 // option "batch_max": scans per launch (2 .. kMaxBatch = 32); 0 = automatic: 32 with the quantile
+                                     // estimator, 16 with Kalman — measured (profiles/r06/batch_max.txt): configs[2] (P2, 272 K-point
+                                     // scans) 52.8 -> 56.9 G pts/s at 32, configs[1] (Kalman, 28.8 K-point scans) 27.0 -> 26.2: that
+                                     // launch is within ~2 x of its instruction-issue floor, a second round of blocks only adds its time
   int batch_fuse = 1;                // option "batch_fuse": hold a batch's update back for the next batch's bin launch
   unsigned long long* mkey[2] = {nullptr, nullptr};  // [kMaxBatch][ncell] per batch parity
   uint4* maux[2] = {nullptr, nullptr};

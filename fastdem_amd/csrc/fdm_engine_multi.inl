@@ -2,7 +2,7 @@
 // fdm_engine_integrate_device_batch call may leave as one batch, the per-batch scratch sets, and the launches.
 // Part of fdm_engine.hip's translation unit (inside its anonymous namespace): do not compile on its own.
 
-// Maps up to this many cells take batches: the kMaxBatch scratch sets of both parities cost 1 KB per cell.
+// Maps up to this many cells take batches: the kMaxBatch scratch sets of both parities cost 2 KB per cell.
 constexpr size_t kBatchMaxCells = size_t(1) << 18;
 
 // A 4x4 whose last row is exactly (0 0 0 1) — what Isometry3d::matrix() always is.
@@ -29,7 +29,8 @@ uint32_t multi_run(fdm_engine* e, uint32_t count, const fdm_device_scan* scans) 
   const fdm_device_scan& f = scans[0];
   const size_t kt = e->ncell / 1024u;  // (the thresholds below were measured in units of 1 024 cells, round 2)
   uint32_t run = 0;
-  const uint32_t cap = std::min<uint32_t>(count, uint32_t(e->batch_max));
+  const uint32_t batch_max = e->batch_max > 0 ? uint32_t(e->batch_max) : (e->cfg.estimation_type == 1 ? uint32_t(kMaxBatch) : 16u);
+  const uint32_t cap = std::min<uint32_t>(count, batch_max);
   for (; run < cap; ++run) {
     const fdm_device_scan& s = scans[run];
     if (s.n == 0 || !s.x || !s.y || !s.z) break;
@@ -83,7 +84,7 @@ int ensure_multi(fdm_engine* e, size_t max_n, size_t blocks) {
     for (int k = 0; k < 2 && ok; ++k)
       ok = alloc(e->mkey[k], slots * sizeof(unsigned long long)) && alloc(e->maux[k], slots * sizeof(uint4)) &&
            alloc(e->mzs[k], slots * sizeof(uint2));
-    ok = ok && alloc(e->mupd_part, ((e->ncell + kUpdCells - 1u) / kUpdCells) * sizeof(uint32_t));
+    ok = ok && alloc(e->mupd_part, ((e->ncell + 31u) / 32u) * sizeof(uint32_t));  // (32 cells per update block at least: upd_cells_per_block)
     if (!ok) {
       (void)hipGetLastError();
       release();
@@ -217,9 +218,11 @@ int with_channels(int ch, F&& f) {
 
 // One k_mbatch launch: [ update U | bin B | crop Cn ], any of which may be empty (count == 0).
 int launch_mbatch(fdm_engine* e, int ch, const MUpd& U, const MBin& B, const MCrop& Cn, const MCommon& K) {
-  static_assert(sizeof(MUpd) + sizeof(MBin) + sizeof(MCrop) + sizeof(MCommon) + sizeof(GeomConst) + 160 <= 4096,
-                "k_mbatch: kernel arguments beyond 4 KB");
-  const unsigned ub = U.count ? unsigned((e->ncell + kUpdCells - 1u) / kUpdCells) : 0u;
+  // (7.2 KB of kernel arguments with 32 scans per batch: the AQL kernarg segment has no 4 KB limit — scripts/ubench/
+  // kernarg_big.hip passes 8 KB by value on this stack, checked on the box in round 6)
+  static_assert(sizeof(MUpd) + sizeof(MBin) + sizeof(MCrop) + sizeof(MCommon) + sizeof(GeomConst) + 160 <= 8192,
+                "k_mbatch: kernel arguments beyond 8 KB");
+  const unsigned ub = U.count ? unsigned((e->ncell + upd_cells_per_block(U.count) - 1u) / upd_cells_per_block(U.count)) : 0u;
   // rows as wide as the widest scan; the update's blocks fill as many leading rows as they need
   unsigned gx = 0u;
   for (unsigned k = 0; k < B.count; ++k) gx = std::max(gx, (B.n[k] + kMBlock - 1u) / kMBlock);
@@ -454,7 +457,7 @@ int enqueue_multi(fdm_engine* e, uint32_t count, const fdm_device_scan* scans, u
   e->last_kind = 0;
   e->last_bin_blocks = blocks - B.first_block[count - 1u];
   e->last_bin_part = B.bin_part + B.first_block[count - 1u];
-  e->last_upd_tiles = unsigned((e->ncell + kUpdCells - 1u) / kUpdCells);
+  e->last_upd_tiles = unsigned((e->ncell + upd_cells_per_block(count) - 1u) / upd_cells_per_block(count));
   e->last_upd_part = e->mupd_part;
   e->ray_timed = false;
   e->scan_no += count;

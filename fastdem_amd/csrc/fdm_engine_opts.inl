@@ -206,7 +206,7 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
     return FDM_OK;
   }
   if (std::strcmp(key, "batch_max") == 0) {
-    if (value < 2 || value > kMaxBatch) return fail(FDM_ERR_INVALID, "batch_max: 2 .. 16 scans per launch");
+    if (value != 0 && (value < 2 || value > kMaxBatch)) return fail(FDM_ERR_INVALID, "batch_max: 0 (automatic) or 2 .. 32 scans per launch");
     e->batch_max = value;
     return FDM_OK;
   }

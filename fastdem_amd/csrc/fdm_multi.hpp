@@ -51,7 +51,14 @@
 
 namespace fdm {
 
-constexpr int kMaxBatch = 16;            // scans per launch (one bit per scan in 16-bit halves of a state word)
+constexpr int kMaxBatch = 32;            // scans per launch (one bit per scan in 32-bit state words).  Round 6: 16 -> 32 — a
+                                         // 16-scan VLP-16 batch is LESS than one round of blocks on the chip and pays the launch's
+                                         // fixed costs (3.4 us queue floor, the first round trip of 1 264 blocks at once) in full
+constexpr int kScansPerThread = 4;   // update half: a thread looks after four scans of its cell, so a cell takes four threads in
+                                     // a batch of up to 16 scans (64 cells per block) and eight beyond (32 cells per block):
+                                     // MUpd::tpc — at most 1 024 (cell, scan) events per block = two rounds of the exchange either way
+// the n lowest bits (n <= 32: a shift by 32 is not a shift)
+__host__ __device__ constexpr unsigned lowbits(unsigned n) { return n >= 32u ? 0xFFFFFFFFu : (1u << n) - 1u; }
 constexpr int kLineWords = 32;           // a 128-byte line of 32-bit words
 #ifndef FDM_MB_WAVES
 #define FDM_MB_WAVES 6  // waves per SIMD k_mbatch is compiled for (<= 80 VGPRs; the LDS allows 6 blocks per CU): every block of a 16-scan VLP-16 batch resident at once
@@ -63,7 +70,7 @@ constexpr int kMStates = 4;              // ring of batch states: update b-1 | b
 struct MState {
   DevGeom E[kMaxBatch];        // geometry before scan k (written by the scan's first bin block)
   DevCand C[kMaxBatch];        // geometry after its move + the index shift
-  unsigned flags[kLineWords];  // [0]: bit 16 + k = scan k has a surviving point (scouts); [1]: bit 31 = PE / PC below are valid, bits 0..15 = the pass bits they assume
+  unsigned flags[kLineWords];  // [0]: bit k = scan k has a surviving point (scouts); [1]: the pass bits PE / PC below assume; [2]: != 0 = PE / PC are valid
   unsigned inside[kMaxBatch];  // some point of scan k landed in the map (elevation_mapping.cpp:118)
   unsigned pad[16];
   DevGeom PE[kMaxBatch];       // the chain of moves walked ONE LAUNCH AHEAD by the walker block (mwalk_body): geometry before
@@ -113,10 +120,10 @@ struct MBin {     // bin half: batch b
 // minimum ray height per cell — and the update half resolves them cell by cell, each scan's behind that scan's
 // observation (resolveGhostCells, raycasting.cpp:175-202).
 struct RState {   // device bookkeeping of a batch's ray launches (one per engine: they run between the launch that bins the batch and the one that updates it)
-  unsigned any[16];        // == the batch's stamp: the voxel-filtered scan k is not empty (raycasting.cpp:207-209)
-  unsigned origin_in[16];  // the sensor origin lies in the map after scan k's move (raycasting.cpp:217-220)
-  unsigned qcount[16][4];  // queued downward rays of scan k, by the quadrant they leave the sensor's cell into
-  unsigned total[16];      // valid points of scan k (VoxelSmall::total)
+  unsigned any[kMaxBatch];        // == the batch's stamp: the voxel-filtered scan k is not empty (raycasting.cpp:207-209)
+  unsigned origin_in[kMaxBatch];  // the sensor origin lies in the map after scan k's move (raycasting.cpp:217-220)
+  unsigned qcount[kMaxBatch][4];  // queued downward rays of scan k, by the quadrant they leave the sensor's cell into
+  unsigned total[kMaxBatch];      // valid points of scan k (VoxelSmall::total)
 };
 struct MRay {
   const RState* rs;
@@ -218,7 +225,9 @@ struct MBinLds {
 };
 struct MEvent { uint32_t idx; uint16_t cell, k; };  // winner's point index | cell in tile | scan
 struct MObs { float min_z, var, max_z, iobs; };
-constexpr unsigned kUpdCells = 64u;
+constexpr unsigned kUpdCells = 64u;   // cells per update block at most (MUpd::tpc == 4; 32 with eight threads per cell)
+__host__ __device__ constexpr unsigned upd_threads_per_cell(unsigned count) { return count > 16u ? 8u : 4u; }
+__host__ __device__ constexpr unsigned upd_cells_per_block(unsigned count) { return 256u / upd_threads_per_cell(count); }
 constexpr uint32_t kMRayEmpty = 0xFFFFFFFFu;  // (= kRayEmpty, fdm_raycast.hpp)
 template <bool COL, bool RAY>
 struct MUpdLds {
@@ -260,7 +269,7 @@ __device__ __forceinline__ void mcrop_body(const MCrop& Cn, const MCommon& K, co
       }
     }
     if (__syncthreads_or(pass ? 1 : 0)) {
-      if (threadIdx.x == 0) atomicOr(&Cn.ms->flags[0], 0x10000u << k);  // (<= kMScout per scan)
+      if (threadIdx.x == 0) atomicOr(&Cn.ms->flags[0], 1u << k);  // (<= kMScout per scan)
       return;
     }
   }
@@ -290,7 +299,7 @@ __device__ __forceinline__ DevGeom mbatch_start(const MState* __restrict__ prev,
   if (!prev) return st->geom[scan_no0 & 3u];
   const unsigned pk = prev_count - 1u;
   DevGeom g = prev->E[pk];
-  if (K.do_move && (!K.gate_on_filter || ((prev->flags[0] >> (16u + pk)) & 1u) != 0u)) {
+  if (K.do_move && (!K.gate_on_filter || ((prev->flags[0] >> pk) & 1u) != 0u)) {
     const DevCand c = prev->C[pk];
     g.px = c.px; g.py = c.py; g.sr = c.sr; g.sc = c.sc;
   }
@@ -362,11 +371,12 @@ __device__ __forceinline__ void mwalk_body(const MBin& B, const MCrop& Cn, const
   const unsigned lane = threadIdx.x & 63u;
   DevGeom g;
   if (B.count) {  // behind the batch this launch bins: its own chain as pre-walked if its scouts agreed, else walked here
-    const unsigned act = K.gate_on_filter ? (uni(B.ms->flags[0]) >> 16) : 0xFFFFu, pre = uni(B.ms->flags[1]);
+    const unsigned act = K.gate_on_filter ? uni(B.ms->flags[0]) : 0xFFFFFFFFu, pre = uni(B.ms->flags[1]);
+    const bool pre_valid = uni(B.ms->flags[2]) != 0u;
     const unsigned last = B.count - 1u;
     DevGeom e_l;
     DevCand c_l;
-    if ((pre >> 31) != 0u && ((pre ^ act) & ((1u << last) - 1u)) == 0u) {
+    if (pre_valid && ((pre ^ act) & lowbits(last)) == 0u) {
       e_l = B.ms->PE[last];
       c_l = B.ms->PC[last];
     } else {
@@ -380,8 +390,8 @@ __device__ __forceinline__ void mwalk_body(const MBin& B, const MCrop& Cn, const
   }
   DevGeom e_l;
   DevCand c_l;
-  mwalk_batch(g, Cn.count, Cn.robot_x, Cn.robot_y, 0xFFFFu, K, G, Cn.ms, e_l, c_l);
-  if (lane == 0u) Cn.ms->flags[1] = 0x80000000u | ((1u << Cn.count) - 1u);
+  mwalk_batch(g, Cn.count, Cn.robot_x, Cn.robot_y, 0xFFFFFFFFu, K, G, Cn.ms, e_l, c_l);
+  if (lane == 0u) { Cn.ms->flags[1] = lowbits(Cn.count); Cn.ms->flags[2] = 1u; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -409,7 +419,7 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
   double pose_x = 0.0, pose_y = 0.0;
   DevGeom g_start, g_pre;
   DevCand c_prev, c_pre;
-  unsigned f_prev = 0u, w_pre = 0u;
+  unsigned f_prev = 0u, w_pre = 0u, w_valid = 0u;
   g_start.px = g_start.py = 0.0; g_start.sr = g_start.sc = 0; g_start.pad0 = g_start.pad1 = 0;
   c_prev.px = c_prev.py = 0.0; c_prev.sr = c_prev.sc = c_prev.shr = c_prev.shc = 0;
   g_pre = g_start;
@@ -417,6 +427,7 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
   if (threadIdx.x < 64u) {
     // (the chain as the walker block of the previous launch left it: used if the scouts confirmed what it assumed)
     w_pre = ms->flags[1];
+    w_valid = ms->flags[2];
     g_pre = ms->PE[k];
     c_pre = ms->PC[k];
     if (lane <= k) { pose_x = B.robot_x[lane]; pose_y = B.robot_y[lane]; }
@@ -472,8 +483,8 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
     return __hiloint2double(hi, lo);
   };
   auto chain = [&](unsigned passmask) {  // (every lane of the first wavefront, uniformly)
-    if (K.do_move && K.walk && K.dbg != 2 && K.dbg != 3 && (uni(w_pre) >> 31) != 0u &&
-        ((uni(w_pre) ^ passmask) & ((1u << k) - 1u)) == 0u) {  // pre-walked (mwalk_body): nothing to walk
+    if (K.do_move && K.walk && K.dbg != 2 && K.dbg != 3 && uni(w_valid) != 0u &&
+        ((uni(w_pre) ^ passmask) & lowbits(k)) == 0u) {  // pre-walked (mwalk_body): nothing to walk
       if (threadIdx.x == 0) {
         S.s_cand = c_pre;
         if (lb == 0u) { ms->E[k] = g_pre; ms->C[k] = c_pre; }
@@ -483,7 +494,7 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
     DevGeom g = g_start;
     if (B.prev) {  // what the update of the previous batch (the other half of this launch) is about to commit
       const unsigned pk = B.prev_count - 1u;
-      if (K.do_move && (!K.gate_on_filter || ((f_prev >> (16u + pk)) & 1u) != 0u)) {
+      if (K.do_move && (!K.gate_on_filter || ((f_prev >> pk) & 1u) != 0u)) {
         g.px = c_prev.px; g.py = c_prev.py; g.sr = c_prev.sr; g.sc = c_prev.sc;
       }
     }
@@ -517,7 +528,7 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
           dy = static_cast<int>(t + 0.5 * (t > 0 ? 1 : -1));
         }
       };
-      unsigned m = K.dbg == 2 ? 0u : ((K.gate_on_filter ? passmask : 0xFFFFu) & ((1u << k) - 1u));  // the moves ahead of scan k
+      unsigned m = K.dbg == 2 ? 0u : ((K.gate_on_filter ? passmask : 0xFFFFFFFFu) & lowbits(k));  // the moves ahead of scan k
       bool unwrapped = false;
       while (m) {  // (a scan that returned before its move is not in the mask)
         const unsigned j = unsigned(__ffs(int(m))) - 1u;
@@ -570,7 +581,7 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
   // or a small launch of their own ahead of a call's first batch — left it in the state word.  The walk runs in the
   // shadow of the point loads; nothing is published, nothing is polled)
   const bool gated = K.do_move && K.gate_on_filter;
-  if (threadIdx.x < 64u) chain((gated && k > 0u) ? uni(ms->flags[0] >> 16) : 0xFFFFu);
+  if (threadIdx.x < 64u) chain((gated && k > 0u) ? uni(ms->flags[0]) : 0xFFFFFFFFu);
 
 #if FDM_MB_PHASES == 2
   FDM_PHASE(2);
@@ -787,18 +798,19 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
   constexpr bool has_int = (CH & 1) != 0, has_col = (CH & 2) != 0;
   const float nanv = __uint_as_float(0x7FC00000u);
   const unsigned lt = threadIdx.x, lane = lt & 63u, wave = lt >> 6;
-  const unsigned cq = lt & 3u, cl = lt >> 2;
-  const unsigned o = bid * kUpdCells + cl;
+  const unsigned count = U.count;
+  const unsigned tpc = upd_threads_per_cell(count), cpb = 256u / tpc;   // threads per cell, cells per block (block-uniform)
+  const unsigned cq = lt & (tpc - 1u), cl = tpc == 8u ? lt >> 3 : lt >> 2;
+  const unsigned o = bid * cpb + cl;
   const bool valid = o < ncell;
   const bool owner = valid && cq == 0u;  // the thread that applies the cell's events
-  const unsigned count = U.count;
   MState* const ms = U.ms;
 
   // ---- round trip 1: the thread's four keys, the per-scan geometry (lane j holds scan j's) ----
-  unsigned long long kk[4];
+  unsigned long long kk[kScansPerThread];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const unsigned k = cq * 4u + unsigned(j);
+  for (int j = 0; j < kScansPerThread; ++j) {
+    const unsigned k = cq * unsigned(kScansPerThread) + unsigned(j);
     kk[j] = kEmptyKey;
     if (k < count && valid) kk[j] = U.key[size_t(k) * ncell + o];
   }
@@ -813,11 +825,11 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
   }
   // raycasting: the thread's four (evidence count, min ray height) pairs join round trip 1 (the images of a scan whose
   // stage did not run are clean: no events)
-  uint32_t rc_[4], rh_[4];
+  uint32_t rc_[kScansPerThread], rh_[kScansPerThread];
   if (RAY) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned k = cq * 4u + unsigned(j);
+    for (int j = 0; j < kScansPerThread; ++j) {
+      const unsigned k = cq * unsigned(kScansPerThread) + unsigned(j);
       rc_[j] = 0u; rh_[j] = kMRayEmpty;
       if (U.ray.stamp && k < count && valid) {
         rc_[j] = U.ray.rc_cnt[size_t(k) * ncell + o];
@@ -836,7 +848,7 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
     if (U.ray.stamp) lo_early = U.ray.logodds[o];
   }
   const unsigned runmask = RAY ? uni(unsigned(__ballot(v_run))) : 0u;  // scans whose raycasting stage runs (raycasting.cpp:207-220)
-  const unsigned passbits = uni(ms->flags[0]) >> 16;
+  const unsigned passbits = uni(ms->flags[0]);
   const bool v_applied = lane < count && U.do_move && (!U.gate_on_filter || ((passbits >> lane) & 1u) != 0u);
   const unsigned umask = uni(unsigned(__ballot(lane < count && v_in != 0u)));                     // scans that observed a cell
   unsigned stripmask = uni(unsigned(__ballot(v_applied && (v_shr != 0 || v_shc != 0))));         // scans whose move vacated cells
@@ -865,22 +877,23 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
   }
   if (bid == 0 && lt >= 64u && lt < 64u + unsigned(kMaxBatch)) {  // re-arm the state of the batch after next
     U.rearm->inside[lt - 64u] = 0u;
-    if (lt == 64u) { U.rearm->flags[0] = 0u; U.rearm->flags[1] = 0u; }
+    if (lt == 64u) { U.rearm->flags[0] = 0u; U.rearm->flags[1] = 0u; U.rearm->flags[2] = 0u; }
   }
 
   unsigned nib = 0u;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) nib |= (kk[j] != kEmptyKey) ? (1u << j) : 0u;
+  for (int j = 0; j < kScansPerThread; ++j) nib |= (kk[j] != kEmptyKey) ? (1u << j) : 0u;
   FDM_PHASE(0);  // round trip 1 (keys, geometry) back
-  unsigned tmask = nib << (4u * cq);  // the cell's scans, all four threads of the cell
+  unsigned tmask = nib << (unsigned(kScansPerThread) * cq);  // the cell's scans, all four threads of the cell
   tmask |= unsigned(__shfl_xor(int(tmask), 1));
   tmask |= unsigned(__shfl_xor(int(tmask), 2));
+  if (tpc == 8u) tmask |= unsigned(__shfl_xor(int(tmask), 4));
   unsigned rmask = 0u;  // the cell's ray events: scans whose stage left evidence or a ray height in it
   if (RAY) {
     unsigned rb = 0u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned k = cq * 4u + unsigned(j);
+    for (int j = 0; j < kScansPerThread; ++j) {
+      const unsigned k = cq * unsigned(kScansPerThread) + unsigned(j);
       if (rc_[j] != 0u || rh_[j] != kMRayEmpty) {
         rb |= 1u << j;
         if (rc_[j] != 0u) U.ray.rc_cnt[size_t(k) * ncell + o] = 0u;  // the images are clean again for the next batch
@@ -889,9 +902,10 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
       S.rcnt[k * kUpdCells + cl] = rc_[j];
       S.rmin[k * kUpdCells + cl] = rh_[j];
     }
-    rmask = rb << (4u * cq);
+    rmask = rb << (unsigned(kScansPerThread) * cq);
     rmask |= unsigned(__shfl_xor(int(rmask), 1));
     rmask |= unsigned(__shfl_xor(int(rmask), 2));
+    if (tpc == 8u) rmask |= unsigned(__shfl_xor(int(rmask), 4));
   }
   // which scans' moves vacated THIS cell
   unsigned smask = 0u;
@@ -988,13 +1002,13 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
     {  // every thread lists its (at most four) events of this round
       unsigned e = base;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < kScansPerThread; ++j) {
         if ((nib >> j) & 1u) {
           if (e >= r0 && e < r1) {
             MEvent ev;
             ev.idx = uint32_t(kk[j]);
             ev.cell = uint16_t(cl);
-            ev.k = uint16_t(cq * 4u + unsigned(j));
+            ev.k = uint16_t(cq * unsigned(kScansPerThread) + unsigned(j));
             S.ev[e - r0] = ev;
           }
           ++e;
@@ -1018,7 +1032,7 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
       ev_[q].idx = kNoIdx; ev_[q].cell = 0; ev_[q].k = 0;
       if (r0 + j < r1) {
         ev_[q] = S.ev[j];
-        const size_t oc = size_t(ev_[q].k) * ncell + (bid * kUpdCells + ev_[q].cell);
+        const size_t oc = size_t(ev_[q].k) * ncell + (bid * cpb + ev_[q].cell);
         if (ev_[q].idx != kNoIdx) ob_[q] = U.obs[size_t(ev_[q].k) * U.obs_stride + ev_[q].idx];
         ax_[q] = U.aux[oc];
         zs_[q] = U.zs[oc];
@@ -1043,7 +1057,7 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
       if (has_int) ob.iobs = (fst & 1u) ? nanv : ((imx == 0x80000000u && (zs_[q].y & 1u)) ? -0.0f : unord(imx));
       S.ob[j] = ob;
       FDM_PHASE(1);  // round trip 2 (observations, record) back
-      const size_t oc = size_t(ev_[q].k) * ncell + (bid * kUpdCells + ev_[q].cell);
+      const size_t oc = size_t(ev_[q].k) * ncell + (bid * cpb + ev_[q].cell);
       U.key[oc] = kEmptyKey;  // the scratch is clean again for the batch after next
       U.aux[oc] = make_uint4(0u, 0u, kNoIdx, 0u);
       if ((zs_[q].x & zs_[q].y) != 0xFFFFFFFFu) U.zs[oc] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
@@ -1057,7 +1071,7 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
         const MObs ob = S.ob[e_next - r0];
         const uint32_t rgb = has_col ? S.rgb[e_next - r0] : 0u;
         ++e_next;
-        const unsigned upto = (2u << k) - 1u, from = (1u << lastp1) - 1u;  // scans lastp1 .. k
+        const unsigned upto = lowbits(k + 1u), from = lowbits(lastp1);  // scans lastp1 .. k
         if (smask & upto & ~from) {  // vacated since the last event: NaN in every layer (GridMap::move)
           POLICY::set_nan(stt);
           sint = nanv;
@@ -1077,7 +1091,7 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
       while (m | rm) {
         const unsigned k = unsigned(__ffs(int(m | rm))) - 1u, bit = 1u << k;
         if ((m & bit) && e_next >= r1) break;  // (its observation arrives with the next round)
-        const unsigned upto = (2u << k) - 1u, from = (1u << lastp1) - 1u;  // scans lastp1 .. k
+        const unsigned upto = lowbits(k + 1u), from = lowbits(lastp1);  // scans lastp1 .. k
         if (smask & upto & ~from) wipe();  // vacated since the last event: NaN in every layer (GridMap::move)
         if (m & bit) {
           m &= ~bit;
@@ -1106,7 +1120,7 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
     while (rm) {
       const unsigned k = unsigned(__ffs(int(rm))) - 1u;
       rm &= rm - 1u;
-      const unsigned upto = (2u << k) - 1u, from = (1u << lastp1) - 1u;
+      const unsigned upto = lowbits(k + 1u), from = lowbits(lastp1);
       if (smask & upto & ~from) wipe();
       resolve(k);
       lastp1 = k + 1u;
@@ -1115,14 +1129,14 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
   FDM_PHASE(2);  // events applied
   // the scans after the cell's last event
   if (owner) {
-    const unsigned all = (1u << count) - 1u, from = (1u << lastp1) - 1u;
+    const unsigned all = lowbits(count), from = lowbits(lastp1);
     const unsigned tail = all & ~from;
     if (smask & tail) {
       strip_any = true; st_dirty = false; sint = nanv; colv = 0x7FC00000u; obst = nanv; obst_dirty = true;
       if (RAY) { lo = nanv; lo_dirty = false; ghost_one = false; ray_val = nanv; }
     }
     // map_.clear(obstacle) by every scan that observed a cell (elevation_mapping.cpp:144-146), behind the cell's last observation
-    const unsigned tail_u = RAY ? (all & ~((1u << lastu1) - 1u)) : tail;
+    const unsigned tail_u = RAY ? (all & ~lowbits(lastu1)) : tail;
     if (umask & tail_u) { obst = nanv; obst_dirty = true; }
     if (strip_any) {
       for (int l0 = 0; l0 < n_layers; l0 += 8) {
@@ -1152,7 +1166,7 @@ __device__ __forceinline__ void mupdate_body(const MUpd& U, const GeomConst& G, 
   const unsigned long long mt = __ballot(owner && ((tmask >> (count - 1u)) & 1u) != 0u);
   if (lane == 0u) S.s_t[wave] = unsigned(__popcll(mt));
   __syncthreads();
-  if (lt == 0 && bid * kUpdCells < ncell) U.upd_part[bid] = S.s_t[0] + S.s_t[1] + S.s_t[2] + S.s_t[3];
+  if (lt == 0 && bid * cpb < ncell) U.upd_part[bid] = S.s_t[0] + S.s_t[1] + S.s_t[2] + S.s_t[3];
 }
 
 // [ update of batch b-1 | bin of batch b | crop pass of batch b+1 ] — any of the three may be empty.

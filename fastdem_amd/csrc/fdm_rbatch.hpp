@@ -60,7 +60,7 @@ __device__ __forceinline__ VoxelSmall rb_voxel(const RBatch& R, const unsigned k
 // map geometry after scan k's move (what the bin half binned the scan against)
 __device__ __forceinline__ DevGeom rb_geom(const RBatch& R, const unsigned k) {
   DevGeom g = R.ms->E[k];
-  if (R.do_move && (!R.gate_on_filter || ((R.ms->flags[0] >> (16u + k)) & 1u) != 0u)) {
+  if (R.do_move && (!R.gate_on_filter || ((R.ms->flags[0] >> k) & 1u) != 0u)) {
     const DevCand c = R.ms->C[k];
     g.px = c.px; g.py = c.py; g.sr = c.sr; g.sc = c.sc;
   }

@@ -8,6 +8,10 @@ import numpy as np  # noqa: E402
 import bench  # noqa: E402
 from fastdem_amd import synth  # noqa: E402
 
+BM = 32  # scans per launch (kMaxBatch; batch_max=N on the command line)
+for kv in sys.argv[1:]:
+    if kv.startswith("batch_max="):
+        BM = int(kv.split("=")[1])
 wl = synth.make("c2", n_scans=8)
 res = bench.Resident(wl, 0)
 res.eng.set_option("dbg_timeline", 1)
@@ -18,14 +22,13 @@ for kv in sys.argv[1:]:
         res.eng.set_config(cfg)
         continue
     res.eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
-for kk in range(400):
+for kk in range(30 * BM):
     res.pose(kk)
-arr, _ = res.batch(0, 160)
+arr, _ = res.batch(0, 10 * BM)
 assert res.eng.integrate_device_batch(arr) == 0
 res.eng.sync()
-arr, _ = res.batch(160, 64)  # 4 batches: the timeline holds the LAST launch with a bin half (update 2 | bin 3 | no crop)
-arr2, _ = res.batch(160, 80)
-assert res.eng.integrate_device_batch(arr2) == 0   # 5 batches; last bin launch = update 3 | bin 4
+arr2, _ = res.batch(10 * BM, 5 * BM)
+assert res.eng.integrate_device_batch(arr2) == 0   # 5 batches; the timeline holds the LAST launch with a bin half: update 3 | bin 4
 t, gx = res.eng.debug_timeline()   # rows of gx blocks: row 0 update tiles, then one row per scan (bin), then crop rows
 t = t.astype(np.int64)
 live = t[:, 1] > 0
@@ -44,8 +47,8 @@ nu = (22500 + 63) // 64
 ur = (nu + gx - 1) // gx
 upd_idx = np.arange(0, nu)
 out["update"] = {"n": int(nu), "start": q(s[upd_idx]), "end": q(e[upd_idx]), "dur": q(d[upd_idx])}
-out["bin"] = role(list(range(ur, ur + 16)), nb)
-out["crop"] = role(list(range(ur + 16, nrow)), nb)
+out["bin"] = role(list(range(ur, ur + BM)), nb)
+out["crop"] = role(list(range(ur + BM, nrow)), nb)
 out["bin_by_scan"] = [{"k": k, "start50": round(float(np.median(s[(ur + k) * gx:(ur + k) * gx + nb])), 2),
-                       "end50": round(float(np.median(e[(ur + k) * gx:(ur + k) * gx + nb])), 2)} for k in range(16)]
+                       "end50": round(float(np.median(e[(ur + k) * gx:(ur + k) * gx + nb])), 2)} for k in range(BM)]
 print(json.dumps(out))

@@ -133,7 +133,7 @@ def test_vlp16_stream_in_batches_equals_the_reference_scan_by_scan(gpu, R):
     check_batch(gpu, R, eng, ref, [wl.scan(k) for k in range(40, 51)], wl.T_base_sensor, [wl.pose(k) for k in range(40, 51)])
 
 
-@pytest.mark.parametrize("batch_max", [2, 3, 16])
+@pytest.mark.parametrize("batch_max", [2, 3, 16, 17, 32])
 def test_moves_that_wrap_clear_everything_and_come_back(gpu, R, batch_max):
     """Ragged small clouds under a pose sequence built to stress GridMap::move inside a batch: multi-cell shifts in
     both directions and on both axes, a jump larger than the map (everything cleared), a return to the old place,

@@ -100,7 +100,7 @@ def test_first_scans_of_a_fresh_engine_in_a_batch(gpu, R):
     assert "raycasting" in eng.layers() and "_visibility_logodds" in eng.layers()
 
 
-@pytest.mark.parametrize("batch_max", [2, 5, 16])
+@pytest.mark.parametrize("batch_max", [2, 5, 16, 32])
 def test_moves_strips_and_ghosts_inside_a_batch(gpu, R, batch_max):
     """Ragged small clouds under a pose sequence that stresses GridMap::move inside a batch (multi-cell shifts, a jump
     beyond the map, wrap-arounds) with aggressive ghost removal: cells are cleared by clearAt, vacated by strips and

@@ -163,6 +163,8 @@ def test_thousands_of_scans_against_the_oracle(gpu, R, seed):
         eng.set_option("tiled_min", TILED_MIN)
         eng.set_option("ray_large_min", RAY_LARGE_MIN)
     eng.set_option("voxel_small_max", VOXEL_SMALL_MAX)
+    if seed == 31:
+        eng.set_option("batch_max", 32)   # (Kalman takes 16 scans per launch by default: the 32-scan layout of the update half here too)
     g = Gen(seed)
     rng = g.rng
     Tbs = T(0.0, 0.0, 1.2)
