@@ -211,7 +211,9 @@ struct fdm_engine {
   int upd_blocks_alone = 2048;      // option "upd_blocks_alone": ... of an update launch of its own
   int move_clear_basic = 0;         // option "move_clear_basic": GridMap::move()'s strips clear {elevation, elevation_min, elevation_max} only (the other reading of nanoGrid: DESIGN.md §6); such an engine takes no batch launches
   int upd_prio = 1;                 // option "upd_prio": update wavefronts run at raised issue priority
-  int tiled_lds_pad = 4096;         // option "tiled_lds_pad": extra dynamic LDS per block of the large-scan bin / fused launches: 4 KB = six blocks per CU instead of seven (configs[3]: 32.3 -> 31.8 us; fewer: slower)
+  int tiled_lds_pad = -1;           // option "tiled_lds_pad": extra dynamic LDS per block of the large-scan bin / fused launches; -1 = as much as
+                                    // makes it SIX blocks per CU (seven: configs[3] 32.3 -> 31.8 us at six; five — what the fixed 4 KB of round 5
+                                    // came to for a scan with an intensity channel, 29.7 KB per block — 31.4 -> 30.3 us at six, profiles/r06/probe_l.json)
   int cnt_shift = 5;                // option "cnt_shift": one tile counter per 2^cnt_shift words (TilePool::cnt_shift); takes effect before the pools exist
   int bin_stagger = 0;              // option "bin_stagger": start stagger of the fused launch's first-round bin blocks (TileWork::stagger)
   size_t tile_rare_waves = 0;       // update wavefronts the rare-path scratch is sized for

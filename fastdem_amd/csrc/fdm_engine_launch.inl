@@ -159,9 +159,15 @@ int ensure_tile_pool(fdm_engine* e, size_t records, unsigned blocks, bool has_in
   return FDM_OK;
 }
 
+// dynamic LDS of a large-scan launch that needs `lds` bytes: padded so that six blocks share a CU's 160 KB, not seven
+unsigned tiled_lds_padded(const fdm_engine* e, unsigned lds) {
+  if (e->tiled_lds_pad >= 0) return lds + unsigned(e->tiled_lds_pad);
+  constexpr unsigned kSeven = 163840u / 7u;  // at most this much: seven blocks fit
+  return lds <= kSeven ? kSeven + 16u : lds;
+}
 int launch_tbin(fdm_engine* e, const ScanParams& P, const ScanInputs& in, const TilePool& Q, int32_t* ids,
                 unsigned bin_blocks, fdm_engine::BinVariant bv) {
-  const unsigned lds = tbin_lds_bytes(bv.has_int, bv.has_col, bv.threads) + unsigned(e->tiled_lds_pad);
+  const unsigned lds = tiled_lds_padded(e, tbin_lds_bytes(bv.has_int, bv.has_col, bv.threads));
   int rc = FDM_OK;
   auto go = [&](auto kern) {
     if ((rc = allow_lds(kern, lds))) return;
@@ -229,8 +235,7 @@ int launch_update_fused(fdm_engine* e, const fdm_engine::PendingUpdate& u, const
       if constexpr (kRec) {
         const unsigned ub = update_blocks(e, true);
         const TileWork K = tile_work(e, ub);
-        const unsigned lds = std::max(tile_lds_bytes(bv.has_int, bv.has_col), tbin_lds_bytes(bv.has_int, bv.has_col, bv.threads)) +
-                             unsigned(e->tiled_lds_pad);
+        const unsigned lds = tiled_lds_padded(e, std::max(tile_lds_bytes(bv.has_int, bv.has_col), tbin_lds_bytes(bv.has_int, bv.has_col, bv.threads)));
         int rc = FDM_OK;
         auto go = [&](auto kern) {
           if ((rc = allow_lds(kern, lds))) return;

@@ -227,7 +227,7 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
     return FDM_OK;
   }
   if (std::strcmp(key, "tiled_lds_pad") == 0) {
-    if (value < 0 || value > 120 * 1024) return fail(FDM_ERR_INVALID, "tiled_lds_pad: 0 .. 122880 bytes");
+    if (value < -1 || value > 120 * 1024) return fail(FDM_ERR_INVALID, "tiled_lds_pad: -1 (automatic) or 0 .. 122880 bytes");
     e->tiled_lds_pad = value;
     return FDM_OK;
   }
