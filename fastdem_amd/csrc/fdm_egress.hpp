@@ -72,7 +72,7 @@ __device__ __forceinline__ unsigned long long pack_total(const PackParams& Q, co
 }
 
 // valid cells per block of 256 consecutive visits
-__global__ __launch_bounds__(256) void k_pack_count(const PackParams Q, const GeomConst G,
+inline __global__ __launch_bounds__(256) void k_pack_count(const PackParams Q, const GeomConst G,
                                                     const DevState* __restrict__ st, const PackLayers L,
                                                     uint32_t* __restrict__ counts) {
   __shared__ unsigned s_w[4];
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_pack_count(const PackParams Q, const Ge
 
 // in-place exclusive scan of the block counts (one block, carries across 1024-entry chunks);
 // counts[n] receives the total
-__global__ __launch_bounds__(1024) void k_pack_scan(uint32_t* __restrict__ counts, unsigned n) {
+inline __global__ __launch_bounds__(1024) void k_pack_scan(uint32_t* __restrict__ counts, unsigned n) {
   __shared__ unsigned s_wave[16];
   __shared__ unsigned s_carry;
   if (threadIdx.x == 0) s_carry = 0u;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(1024) void k_pack_scan(uint32_t* __restrict__ count
   if (threadIdx.x == 0) counts[n] = s_carry;
 }
 
-__global__ __launch_bounds__(256) void k_pack_write(const PackParams Q, const GeomConst G,
+inline __global__ __launch_bounds__(256) void k_pack_write(const PackParams Q, const GeomConst G,
                                                     const DevState* __restrict__ st, const PackLayers L,
                                                     const uint32_t* __restrict__ offsets,
                                                     float* __restrict__ out) {

@@ -5,315 +5,22 @@
 // k_update on the engine's stream.  No per-point or per-cell work ever runs on the CPU and
 // there is NO CPU fallback: without a HIP device fdm_engine_create fails with
 // FDM_ERR_NO_DEVICE.
-#include "../../include/fdm_engine.h"
-#include "../../include/fdm_engine_debug.h"
+// (One of the library's three translation units: fdm_engine_host.hpp.)
+#include "fdm_engine_host.hpp"
 
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <cstdint>
-#include <cstdlib>
-#include <cstring>
-#include <limits>
-#include <mutex>
-#include <string>
-#include <type_traits>
-#include <unordered_map>
-#include <vector>
-
-
-#include "fdm_kernels.hpp"
-#include "fdm_tiled.hpp"
-#include "fdm_multi.hpp"
-#include "fdm_route.hpp"
-#include "fdm_raycast.hpp"
-#include "fdm_raywedge.hpp"
-#include "fdm_rbatch.hpp"
-#include "fdm_rsort.hpp"
-#include "fdm_egress.hpp"
-#include "fdm_ingest.hpp"
-#include "fdm_post.hpp"
-
-using namespace fdm;
-
-namespace {
-
+namespace fdmh {
 thread_local std::string g_err;
-
 int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
+}  // namespace fdmh
 
-#define HIPCK(expr)                                                                        \
-  do {                                                                                     \
-    hipError_t _e = (expr);                                                                \
-    if (_e != hipSuccess)                                                                  \
-      return fail(FDM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));         \
-  } while (0)
-
-struct Layer {
-  std::string name;
-  float* d = nullptr;    // own array (stride 1), or nullptr when the layer is a record field
-  int field = -1;        // index inside the cell record, -1 = own array
-  bool pending = false;  // allocated, but not yet visible (lazy intensity / colour layers)
-};
-
-// field order inside the cell records (KalmanField / P2Field in fdm_kernels.hpp)
-const char* const kKalmanFields[KF_COUNT] = {"elevation", "elevation_min", "elevation_max", "variance",
-                                             "n_points", "_kalman_p", "_sample_mean", "_sample_m2",
-                                             "upper_bound", "lower_bound"};
-const char* const kP2Fields[PF_COUNT] = {"elevation", "elevation_min", "elevation_max", "variance",
-                                         "n_points", "_p2_q0", "_p2_q1", "_p2_q2", "_p2_q3", "_p2_q4",
-                                         "_p2_n0", "_p2_n1", "_p2_n2", "_p2_n3", "_p2_n4",
-                                         "upper_bound", "lower_bound"};
-
-}  // namespace
-
-struct fdm_engine {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = true;
-  fdm_config cfg{};
-  GeomConst G{};
-  size_t ncell = 0;
-  std::vector<Layer> layers;
-  float** d_layer_ptrs = nullptr;  // device array of every layer pointer (strip clears)
-  int n_layer_ptrs = 0;
-  bool layer_ptrs_dirty = true;
-  Scratch S{};
-  DevState* d_state = nullptr;
-  DevState* h_state = nullptr;  // pinned mirror for read-backs
-  StatsOut* h_stats = nullptr;  // pinned + device-mapped: k_collect_stats writes here
-  StatsOut* h_stats_dev = nullptr;  // the device's alias of h_stats
-  unsigned long long stats_seq = 0; // sequence number of the last statistics launch (StatsOut::seq)
-  int sync_spin_us = 150;           // read_stats polls the pinned block this long before a stream wait (option)
-  StatsAcc* d_stats_acc = nullptr;
-  uint64_t scan_no = 0;
-  bool have_scan = false;
-  uint32_t last_n = 0;        // points of the last scan as enqueued (array length of the captures / cell ids)
-  uint32_t last_n_input = 0;  // ... as the reference counts them (cloud.size(): finite points of a PointCloud2)
-  int next_drop_nonfinite = 0;  // set by fdm_engine_integrate_cloud2 for the scan it enqueues
-  unsigned ingest_blocks = 0; // > 0: the last scan came through k_ingest_soa; its finite count is still on the device
-  int last_was_integrate = 0;
-  // staging for the host-pointer entry points
-  float* d_stage = nullptr;
-  float4* d_aos = nullptr;  // fdm_engine_integrate_points4 on pageable memory: the cloud's {x, y, z, 1} records
-  size_t aos_cap = 0;
-  size_t stage_cap = 0;  // in points
-  int stage_rr = 0;      // rotating staging block
-  int32_t* d_cell_ids = nullptr;
-  size_t ids_cap = 0;
-  bool want_ids = false;
-  bool profile = false;
-  bool wave_merge = true;
-  int bin_table = 1;                 // k_bin: per-block LDS cell table (option "bin_table")
-  // fdm_engine_integrate_async: scans of up to this many points whose arrays are PINNED host memory
-  // are read in place by the bin kernel (0 = always stage with copy commands; option "zero_copy")
-  int zero_copy = 1 << 30;
-  int dbg_no_atomics = 0;
-  int dbg_upd = 0;
-  int bin_variant = 0;  // 0 = by scan size, 4 = k_bin4 (LDS-staged), 1 = k_bin (one point/thread)
-  size_t bin_part_cap = 0;   // blocks
-  unsigned last_bin_blocks = 0;
-  std::vector<unsigned long long> h_bin_part;
-  unsigned n_tiles = 0;
-  std::vector<uint32_t> h_upd_part;
-  bool obst_dense_pending = false;  // host wrote the obstacle layer / the pipeline changed: the next scan that observes a
-                                    // cell clears it densely — which scan that is only the device knows (DevState::
-                                    // dense_owed / dense_paid); the flag falls at the first sync behind it
-  bool obst_owe_armed = false;      // ... the device has been told about the current debt
-  unsigned obst_owe_seq = 0;
-  bool estimator_ready = false;     // ElevationMapping ctor ran (ensureLayers + obstacle layer)
-  bool use_records = true;          // pack the active estimator's state into cell records
-  float* d_rec = nullptr;           // [ncell][rec_floats]
-  int rec_kind = -1;                // -1 none, 0 Kalman, 1 P2
-  int rec_floats = 0;
-  float* d_tmp = nullptr;           // ncell floats: contiguous staging for strided layer transfers
-  bool cap_pre = false, cap_ras = false;  // scan-callback captures
-  bool cap_cov = false;                   // ... the preprocessed cloud with its 3x3 covariance channel
-  float* d_cap = nullptr;            // 4 channels x cap_cap points
-  size_t cap_cap = 0;
-  // the preprocessed cloud of a scan whose raycasting stage is HELD BACK with its update (option "ray_hold"): by scan
-  // parity — the next scan's bin half writes its own while the stage of this one has not run yet; 3 channels x rcap_cap
-  float* d_rcap[2] = {nullptr, nullptr};
-  size_t rcap_cap = 0;
-  int ray_hold = 1;
-  float* d_ras = nullptr;            // ncell
-  bool saved_want_ids = false;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  float last_ms[3] = {0.f, 0.f, 0.f};
-  // raycasting stage (fdm_raycast.hpp)
-  uint32_t* rc_cnt = nullptr;        // [ncell] ray-scan points observed in the cell this frame
-  uint32_t* rc_min = nullptr;        // [ncell] ord(min ray height), kRayEmpty = not traversed
-  uint32_t* ray_bins = nullptr;      // large scans: ray-queue bucket counts | offsets | block sums (fdm_raycast.hpp)
-  unsigned long long* vkeys[2] = {nullptr, nullptr};  // voxel keys: unsorted / sorted
-  uint32_t* vidx[2] = {nullptr, nullptr};             // point indices: unsorted / sorted
-  uint32_t* vsel = nullptr;          // voxel_any output staging
-  uint32_t* ray_blk = nullptr;       // rays queued per block of k_ray_compact (large scans: block-local queue regions)
-  size_t vcap = 0;
-  void* sort_tmp = nullptr;
-  size_t sort_tmp_bytes = 0;
-  int voxel_small = 1;               // option "voxel_small": scans of <= 64 K points take the sort-free voxel filter
-  uint32_t* vs_cnt = nullptr;        // fine | coarse bucket counters | valid points of k_vs_*
-  uint4* vs_rec = nullptr;           // {key, point, bucket start, bucket size} by position
-  size_t vs_rec_cap = 0;
-  int voxel_small_max = 1 << 16;     // option "voxel_small_max": largest scan that takes it
-  VoxelSmall vs{};                   // the last small-scan filter's parameters (k_vs_mark runs from enqueue_ray_stage)
-  hipEvent_t ev_ray[2] = {nullptr, nullptr};
-  hipEvent_t ev_timer[2] = {nullptr, nullptr};  // fdm_engine_timer_start / _stop
-  bool ray_timed = false;
-  int dbg_ray = 0;
-  // scans from this many points up: bucketed ray queue, one lane per ray (option "ray_large_min").  Stage time, shared-
-  // ray segments vs this path: 131 K points 0.48 vs 0.52 ms, 262 K 0.78 vs 0.57, 524 K 1.17 vs 0.67, RGB-D 272 K 0.23 vs 0.19
-  int ray_large_min = 196608;
-  // large scans: the walk keeps an angular sector's minimum-height image in LDS (option "ray_wedge", fdm_raywedge.hpp;
-  // 0 = one lane per ray on memory-side atomics, k_ray<., 1>)
-  int ray_wedge = 1;
-  // update(t) || bin(t+1) in ONE launch (k_update_bin): the update of the last small scan is held back
-  // until the next scan arrives (or any other entry point / sync flushes it); the scratch is
-  // double-buffered by scan parity.
-  unsigned long long* key2[2] = {nullptr, nullptr};  // scratch of even / odd scans ([0] == the original allocation)
-  uint4* aux2[2] = {nullptr, nullptr};
-  uint2* zs2[2] = {nullptr, nullptr};
-  bool overlap = true;          // option "overlap"
-  bool chain = false;           // an update is held back: the next bin derives its geometry from the previous slot
-  struct BinVariant { bool bin4, has_int, has_col, wave_merge; unsigned threads; int lean; };  // lean: see bin4_body
-  // the held-back update (plain data: the layer set cannot change while it is pending, every entry
-  // point that could change it flushes first)
-  struct PendingUpdate {
-    bool multi = false;     // a whole batch (fdm_multi.hpp): MU / ch are what matters
-    MUpd MU;
-    int ch = 0;
-    bool tiled = false;     // large-scan pipeline (fdm_tiled.hpp) or the per-cell scratch one
-    ScanParams P;
-    Scratch S;              // scratch pipeline: the key / aux set of the scan's parity, captures
-    ScanInputs in;          // scratch pipeline: where the winning points are gathered from
-    TilePool Q;             // tiled pipeline: the record pool of the scan's parity
-    TileAux A;
-    unsigned upd_blocks = 0;
-    // the scan's raycasting stage (fastdem.cpp:152-159), which runs right behind this update wherever that is launched
-    bool ray = false;
-    RayParams RQ;
-    const float *ray_x = nullptr, *ray_y = nullptr, *ray_z = nullptr;  // the scan's preprocessed cloud (d_rcap[parity])
-    double ray_box[6] = {0, 0, 0, 0, 0, 0};
-  } pend;
-  // ---- tiled pipeline state (allocated when the first large scan arrives) ----
-  bool borrow_inputs = false;       // option "borrow_inputs": a held-back update gathers from the CALLER's device arrays
-  int tiled = 1;                    // option "tiled": large scans go through per-tile record pools
-  unsigned tiled_min = 2048;        // ... from this many points up (on a map of >= 512 tiles the pipeline wins at every
-                                    // size measured: 2 K points 13.1 vs 14.6 us, 32 K 16.6 vs 20.5, 262 K 18.9 vs 34.3)
-  bool tiled_forced = false;        // tiled_min was set by hand (option "tiled_min"): no map-size condition
-  int upd_blocks = 768;             // option "upd_blocks": update blocks (four tile wavefronts each) of a FUSED launch
-  int upd_blocks_alone = 2048;      // option "upd_blocks_alone": ... of an update launch of its own
-  int move_clear_basic = 0;         // option "move_clear_basic": GridMap::move()'s strips clear {elevation, elevation_min, elevation_max} only (the other reading of nanoGrid: DESIGN.md §6); such an engine takes no batch launches
-  int upd_prio = 1;                 // option "upd_prio": update wavefronts run at raised issue priority
-  int tiled_lds_pad = -1;           // option "tiled_lds_pad": extra dynamic LDS per block of the large-scan bin / fused launches; -1 = as much as
-                                    // makes it SIX blocks per CU (seven: configs[3] 32.3 -> 31.8 us at six; five — what the fixed 4 KB of round 5
-                                    // came to for a scan with an intensity channel, 29.7 KB per block — 31.4 -> 30.3 us at six, profiles/r06/probe_l.json)
-  int cnt_shift = 5;                // option "cnt_shift": one tile counter per 2^cnt_shift words (TilePool::cnt_shift); takes effect before the pools exist
-  int bin_stagger = 0;              // option "bin_stagger": start stagger of the fused launch's first-round bin blocks (TileWork::stagger)
-  size_t tile_rare_waves = 0;       // update wavefronts the rare-path scratch is sized for
-  TileGrid TG{};
-  TilePool pool[2] = {};            // by scan parity
-  size_t pool_cap = 0;              // records per pool
-  unsigned desc_stride = 0;
-  uint32_t* tile_stamp32 = nullptr;
-  uint32_t* upd_part32 = nullptr;
-  uint32_t* tile_rare = nullptr;    // the update's rare-path scratch, 3 KB per update wavefront
-  unsigned last_upd_tiles = 0;      // length of the per-tile statistics of the last scan
-  uint32_t* last_upd_part = nullptr;
-  int last_kind = -1;               // pipeline of the last scan (0 scratch, 1 tiled)
-  int last_do_move = 0, last_gate = 0;
-  // ---- batch pipeline (fdm_multi.hpp): up to kMaxBatch small scans per launch, allocated by the first batch ----
-  int batch = 1;                     // option "batch": fdm_engine_integrate_device_batch groups eligible scans
-  int batch_max = 0;                 // option "batch_max": scans per launch (2 .. kMaxBatch = 32); 0 = automatic: 32 with the quantile
-                                     // estimator, 16 with Kalman — measured (profiles/r06/batch_max.txt): configs[2] (P2, 272 K-point
-                                     // scans) 52.8 -> 56.9 G pts/s at 32, configs[1] (Kalman, 28.8 K-point scans) 27.0 -> 26.2: that
-                                     // launch is within ~2 x of its instruction-issue floor, a second round of blocks only adds its time
-  int batch_fuse = 1;                // option "batch_fuse": hold a batch's update back for the next batch's bin launch
-  unsigned long long* mkey[2] = {nullptr, nullptr};  // [kMaxBatch][ncell] per batch parity
-  uint4* maux[2] = {nullptr, nullptr};
-  uint2* mzs[2] = {nullptr, nullptr};
-  float2* mobs[2] = {nullptr, nullptr};              // [kMaxBatch][mobs_stride]
-  uint32_t* mcobs[2] = {nullptr, nullptr};
-  size_t mobs_stride = 0;
-  unsigned long long* mbin_part[2] = {nullptr, nullptr};
-  size_t mbin_cap = 0;
-  uint32_t* mupd_part = nullptr;     // [update blocks] touched cells of a batch's last scan
-  MState* mstate = nullptr;          // [kMStates] ring, slot = batch number % kMStates
-  unsigned mseq = 0;                 // batches enqueued so far
-  int last_batch_n = 0;              // scans of the batch launch the last scan left in (0: it took the single-scan path)
-  uint64_t n_mbatch = 0;             // batch launches since creation (fdm_engine_debug_batch_launches)
-  bool fault_watch = false;          // a launch that can raise DevState::fault was enqueued since it was last read (none can since round 4)
-  int dbg_batch = 0;                 // measurement only (option "dbg_batch")
-  int batch_crop = 1;                // option "batch_crop": evaluate the next batch's crops one launch ahead
-  int batch_walk = -1;               // option "batch_walk": the chain of moves walked one launch ahead (fdm_multi.hpp mwalk_body): -1 = for the quantile estimator only, 0 off, 1 on
-  unsigned long long batch_call = 0; // calls of fdm_engine_integrate_device_batch so far: a look-ahead is only ever honoured inside the call that made it
-  unsigned long long pre_call = 0;
-  bool pre_valid = false;            // the last launch carried the crop pass of the batch (pre_scans, pre_count) = number pre_seq
-  const fdm_device_scan* pre_scans = nullptr;
-  uint32_t pre_count = 0;
-  unsigned pre_seq = 0;
-  const unsigned long long* last_bin_part = nullptr;  // per-block statistics of the last scan (either pipeline)
-  // ---- raycasting inside the small-scan batches (fdm_rbatch.hpp) ----
-  int batch_ray = 1;                 // option "batch_ray": 0 = an engine with raycasting on takes the single-scan path
-  int batch_ray_seg = 4;             // option "batch_ray_seg": lanes per ray of k_rb_ray (1, 4, 8, 16)
-  int batch_ray_lds = 1;             // option "batch_ray_lds": 0 = always the global-atomic walk (k_rb_ray)
-  int batch_ray_parts = 0;           // option "batch_ray_parts": workgroups per quadrant and scan of k_rb_ray_lds (0 = fill the chip)
-  int batch_ray_words = 0;           // option "batch_ray_words": LDS image words of k_rb_ray_lds (0 = twice a centred sensor's quadrant)
-  unsigned rb_lds_words = 0;         // dynamic LDS k_rb_ray_lds may use, in 32-bit words (0: not asked yet)
-  RState* rb_state = nullptr;
-  float* rb_cap = nullptr;           // [3][kMaxBatch][rb_stride] preprocessed clouds of the batch being binned
-  uint32_t* rb_u32 = nullptr;        // keys | place | sel | ray_list, [kMaxBatch][rb_stride] each
-  uint4* rb_rec = nullptr;           // [kMaxBatch][rb_stride]
-  uint32_t* rb_counters = nullptr;   // fine [kMaxBatch][2^18] | coarse [kMaxBatch][kVsCoarse]
-  uint32_t* rb_img = nullptr;        // rc_cnt [kMaxBatch][ncell] | rc_min [kMaxBatch][ncell]
-  size_t rb_stride = 0;
-  unsigned rb_seq = 0;               // stamp of the last batch's ray launches (RState::any)
-  float* d_bstage = nullptr;         // fdm_engine_integrate_host_batch: pageable clouds of a call, staged back to back
-  size_t bstage_cap = 0;             // floats
-  bool bstage_busy = false;          // launches of the previous call may still be reading it
-  // scan routing (fdm_route.hpp)
-  uint8_t* d_route_owner = nullptr;  // [route_cap] owner rank of every point of the slice
-  uint32_t* d_route_cnt = nullptr;   // [route_blocks_cap][world + 2] block counts -> offsets | [kMaxRanks] bases at the end
-  size_t route_cap = 0, route_blocks_cap = 0;
-  // stencil post-processing (fdm_post.hpp)
-  RegionEntry* d_region = nullptr;   // region_cap entries
-  size_t region_cap = 0;
-  float* d_post_pool = nullptr;      // per-thread lists of the big-neighbourhood stencil kernels
-  size_t post_pool_bytes = 0;
-  FeatEntry* d_feat_tab = nullptr;   // kMaxRegion entries: the region as k_features_tiled reads it
-  int dbg_post = 0;                  // measurement only: 1 = untiled feature kernel
-  unsigned long long* d_timeline = nullptr;  // measurement only: {start, end} ticks per block of the last fused launch
-  unsigned timeline_cap = 0;         // blocks the buffer holds
-  unsigned timeline_blocks = 0, timeline_upd = 0;  // grid of the last fused launch, its update blocks
-  unsigned timeline_bin = 0;         // ... its bin blocks (batch launches: the rest are crop blocks)
-  float* d_tmp2 = nullptr;           // second ncell staging array (fusion works on two layers)
-  // ingest (fdm_ingest.hpp)
-  uint8_t* d_blob = nullptr;         // raw message bytes
-  size_t blob_cap = 0;
-  float* d_in = nullptr;             // 5 channels x in_cap: x y z intensity rgb
-  size_t in_cap = 0;
-  uint64_t in_n = 0;
-  bool in_has_int = false, in_has_rgb = false;
-  // egress (fdm_egress.hpp)
-  uint32_t* pack_counts = nullptr;   // per-block valid counts / offsets (+1 for the total)
-  size_t pack_counts_cap = 0;
-  float* d_pack = nullptr;           // packed records
-  size_t pack_cap = 0;               // in floats
-};
-
-namespace {
+namespace fdmh {
 
 // Launch the held-back update kernel, if any.  Called at the top of every entry point that is not
 // the next scan of the chain, and before anything that syncs or reallocates.
-int launch_update_alone(fdm_engine* e, const fdm_engine::PendingUpdate& u);
 // The raycasting stage of the scan whose update was just launched (fdm_engine_ray.inl).
-int run_held_ray_stage(fdm_engine* e, fdm_engine::PendingUpdate& u);
 int join_streams(fdm_engine* e) {
   if (e->chain) {
     e->chain = false;
@@ -360,7 +67,7 @@ Layer* find_layer(fdm_engine* e, const char* name) {
 float* lptr(fdm_engine* e, const Layer& l) { return l.field >= 0 ? e->d_rec + l.field : l.d; }
 int lstride(fdm_engine* e, const Layer& l) { return l.field >= 0 ? e->rec_floats : 1; }
 
-int fill_async(fdm_engine* e, float* p, float v, size_t n, int stride = 1) {
+int fill_async(fdm_engine* e, float* p, float v, size_t n, int stride) {
   if (n == 0) return FDM_OK;
   const int blocks = int(std::min<size_t>((n + 255) / 256, 4096));
   hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, e->stream, p, v, n, stride);
@@ -378,7 +85,7 @@ int ensure_tmp(fdm_engine* e) {
   return FDM_OK;
 }
 
-int add_layer(fdm_engine* e, const char* name, float value, bool pending = false) {
+int add_layer(fdm_engine* e, const char* name, float value, bool pending) {
   if (Layer* l = find_layer(e, name)) {  // GridMap::add on an existing layer overwrites it
     l->pending = l->pending && pending;
     return fill_async(e, lptr(e, *l), value, e->ncell, lstride(e, *l));
@@ -401,8 +108,6 @@ int ensure_layer(fdm_engine* e, const char* name, float value) {
   return add_layer(e, name, value);
 }
 
-const char* kP2Q[5] = {"_p2_q0", "_p2_q1", "_p2_q2", "_p2_q3", "_p2_q4"};
-const char* kP2N[5] = {"_p2_n0", "_p2_n1", "_p2_n2", "_p2_n3", "_p2_n4"};
 
 int activate_records(fdm_engine* e, int kind);
 
@@ -590,19 +295,6 @@ int activate_records(fdm_engine* e, int kind) {
   return adopt_intensity(e);
 }
 
-// ---- raycasting stage: defined in fdm_engine_ray.inl (same translation unit) ----
-bool voxel_size_ok(float v);
-int ensure_ray_layers(fdm_engine* e);
-VoxelCompact voxel_compact_of(float voxel_size, const double* box);
-void ray_box_of(const fdm_engine* e, const ScanParams& P, double box[6]);
-int enqueue_voxel_sort(fdm_engine* e, unsigned n, float voxel_size, int flag_slot, const float* dx,
-                       const float* dy, const float* dz, const double* box, int* key_mode);
-fdm_raycast_config ray_config_of(const fdm_config& c);
-RayParams make_ray_params(fdm_engine* e, const fdm_raycast_config& c, const float* origin, unsigned n,
-                          int slot, int flag_slot);
-int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float* dx, const float* dy,
-                      const float* dz, int key_mode = 0);
-
 // ---- launch helpers -------------------------------------------------------------------------
 P2Params p2_params(const fdm_config& c) {  // P2Quantile ctor (quantile_estimation.hpp:84-95): clamp, then monotone dn
   P2Params p2{};
@@ -635,7 +327,6 @@ void sensor_params(const fdm_config& cfg, int& type, float* sp) {
   }
 }
 
-constexpr int kStageSlots = 3;  // rotating staging blocks (see ensure_stage)
 int ensure_stage(fdm_engine* e, size_t n);
 
 // One scan = k_bin + k_update on the stream.  All pointers are device pointers.
@@ -645,7 +336,7 @@ int ensure_stage(fdm_engine* e, size_t n);
 // queued.  Null: the update gathers from dx..dvar themselves.
 int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, const float* dy,
                  const float* dz, const float* dint, const uint32_t* drgb, const float* dvar,
-                 const ScanInputs* gather = nullptr) {
+                 const ScanInputs* gather) {
   if (n >= 0xFFFFFFFEull) return fail(FDM_ERR_INVALID, "point count exceeds 2^32-2");
   if (n >= 0x7FFFFFFFull) return fail(FDM_ERR_INVALID, "point count exceeds 2^31-1");
   int rc;
@@ -951,7 +642,6 @@ void fill_update_params(fdm_engine* e, ScanParams& P, double rx, double ry, bool
   P.gate_on_filter = 0;
 }
 
-#include "fdm_engine_multi.inl"  // the batch pipeline's host side: eligibility, buffers, enqueue_multi
 
 // Staging for host-array entry points: kStageSlots rotating blocks of 6 channels.  A block is reused
 // three scans later, when the update that gathers from it (held back by at most one scan) has long
@@ -988,7 +678,7 @@ const void* pinned_alias(const void* p) {
 int stage_inputs(fdm_engine* e, uint64_t n, const float* x, const float* y, const float* z,
                  const float* a, const uint32_t* rgb, const float* v, const float** dx,
                  const float** dy, const float** dz, const float** da, const uint32_t** drgb,
-                 const float** dv, ScanInputs* gather = nullptr) {
+                 const float** dv, ScanInputs* gather) {
   int rc;
   if ((rc = ensure_stage(e, n))) return rc;
   e->stage_rr = (e->stage_rr + 1) % kStageSlots;
@@ -1110,7 +800,7 @@ int read_stats(fdm_engine* e, fdm_scan_stats* out, int* status) {
   return FDM_OK;
 }
 
-}  // namespace
+}  // namespace fdmh
 
 extern "C" {
 
@@ -1789,7 +1479,8 @@ int fdm_engine_update(fdm_engine* e, uint64_t n, const float* x, const float* y,
 }
 
 // ---- pinned host pool (fdm_host_alloc) ----
-namespace {
+extern "C++" {
+namespace fdmh {
 struct HostPool {
   static constexpr int kMinShift = 12, kMaxShift = 30;  // 4 KiB .. 1 GiB classes; larger blocks are not pooled
   std::mutex mu;
@@ -1809,7 +1500,8 @@ const void* host_pool_alias(const void* p) {
   auto al = hp.alias.find(p);
   return al == hp.alias.end() ? nullptr : al->second;
 }
-}  // namespace
+}  // namespace fdmh
+}  // extern "C++"
 
 void* fdm_host_alloc(uint64_t bytes) {
   HostPool& hp = *host_pool();
@@ -2007,8 +1699,5 @@ int fdm_engine_last_stats(fdm_engine* e, fdm_scan_stats* out) {
 
 }  // extern "C"
 
-// The stages either side of the hot path, same translation unit (they share the engine struct and
-// the helpers above): raycasting, stencil post-processing, PointCloud2 ingest / map egress.
-#include "fdm_engine_ray.inl"
-#include "fdm_engine_post.inl"
-#include "fdm_engine_io.inl"
+// The stages either side of the hot path are translation units of their own: fdm_engine_ray.hip (raycasting),
+// fdm_engine_post.hip (stencil post-processing, PointCloud2 ingest / map egress).

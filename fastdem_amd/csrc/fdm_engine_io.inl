@@ -1,5 +1,5 @@
 // fdm_engine_io.inl — host side of PointCloud2 ingest (fdm_ingest.hpp) and map egress (fdm_egress.hpp).
-// Part of fdm_engine.hip's translation unit (included at its end): do not compile on its own.
+// Part of fdm_engine_post.hip (one of the library's three translation units, fdm_engine_host.hpp).
 
 namespace {
 // fdm_cloud2_layout -> IngestLayout; L.aligned covers the record layout only (the caller adds the blob's address)

@@ -1,6 +1,6 @@
 // fdm_engine_multi.inl — host side of the batch pipeline (fdm_multi.hpp): which scans of a
 // fdm_engine_integrate_device_batch call may leave as one batch, the per-batch scratch sets, and the launches.
-// Part of fdm_engine.hip's translation unit (inside its anonymous namespace): do not compile on its own.
+// The body of fdm_engine_multi.hip (inside namespace fdmh): do not compile on its own.
 
 // Maps up to this many cells take batches: the kMaxBatch scratch sets of both parities cost 2 KB per cell.
 constexpr size_t kBatchMaxCells = size_t(1) << 18;

@@ -1,5 +1,5 @@
 // fdm_engine_post.inl — host side of the stencil post-processing stages (kernels: fdm_post.hpp).
-// Part of fdm_engine.hip's translation unit (included at its end): do not compile on its own.
+// Part of fdm_engine_post.hip (one of the library's three translation units, fdm_engine_host.hpp).
 
 extern "C" {
 

@@ -1,8 +1,8 @@
 // fdm_engine_ray.inl — host side of the raycasting stage (kernels: fdm_raycast.hpp): voxel sort, ray
 // queue, resolve; entry points fdm_engine_apply_raycasting*, fdm_engine_voxel_any, fdm_engine_last_ray_ms.
-// Part of fdm_engine.hip's translation unit (included at its end): do not compile on its own.
+// The body of fdm_engine_ray.hip (one of the library's three translation units, fdm_engine_host.hpp).
 
-namespace {
+namespace fdmh {
 
 // ---- raycasting stage (fdm_raycast.hpp) ----
 bool voxel_size_ok(float v) { return v >= 0.001f && v <= 100.0f; }  // voxel_grid_impl.hpp:31-33
@@ -391,7 +391,7 @@ int run_held_ray_stage(fdm_engine* e, fdm_engine::PendingUpdate& u) {
   return FDM_OK;
 }
 
-}  // namespace
+}  // namespace fdmh
 
 extern "C" {
 

@@ -46,7 +46,7 @@ __device__ __forceinline__ IngestPoint ingest_xyz(const uint8_t* __restrict__ bl
   return p;
 }
 
-__global__ __launch_bounds__(256) void k_ingest_count(const uint8_t* __restrict__ blob, const IngestLayout L,
+inline __global__ __launch_bounds__(256) void k_ingest_count(const uint8_t* __restrict__ blob, const IngestLayout L,
                                                       unsigned long long n, uint32_t* __restrict__ counts) {
   __shared__ unsigned s_w[4];
   const unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_ingest_count(const uint8_t* __restrict_
   if (threadIdx.x == 0) counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-__global__ __launch_bounds__(256) void k_ingest_write(const uint8_t* __restrict__ blob, const IngestLayout L,
+inline __global__ __launch_bounds__(256) void k_ingest_write(const uint8_t* __restrict__ blob, const IngestLayout L,
                                                       unsigned long long n,
                                                       const uint32_t* __restrict__ offsets,
                                                       float* __restrict__ ox, float* __restrict__ oy,
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_ingest_write(const uint8_t* __restrict_
 // drop_nonfinite) — an order-preserving compaction changes no min / first / last decision, only
 // the indices — so the host needs neither the kept count nor a sync before it can size the scan's
 // launch.  counts[block] = finite points of the block (summed by k_collect_stats for n_input).
-__global__ __launch_bounds__(256) void k_ingest_soa(const uint8_t* __restrict__ blob, const IngestLayout L,
+inline __global__ __launch_bounds__(256) void k_ingest_soa(const uint8_t* __restrict__ blob, const IngestLayout L,
                                                     unsigned long long n, uint32_t* __restrict__ counts,
                                                     float* __restrict__ ox, float* __restrict__ oy,
                                                     float* __restrict__ oz, float* __restrict__ oint,

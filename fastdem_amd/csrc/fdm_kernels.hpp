@@ -1080,7 +1080,7 @@ struct StatsOut {  // pinned host memory, written by the last block
   unsigned dense_paid;     // DevState::dense_paid as of the last k_obstacle_dense_paid (the host reads it without a sync)
   unsigned pad2;
 };
-__global__ __launch_bounds__(256) void k_collect_stats(const unsigned long long* __restrict__ bin_part,
+inline __global__ __launch_bounds__(256) void k_collect_stats(const unsigned long long* __restrict__ bin_part,
                                                        unsigned n_bin, const uint32_t* __restrict__ upd_part,
                                                        unsigned n_tiles, const uint32_t* __restrict__ ingest_part,
                                                        unsigned n_ingest, const DevState* __restrict__ st, int slot,
@@ -1185,7 +1185,7 @@ __global__ __launch_bounds__(256) void k_update_bin(
 // The host wrote the obstacle layer (upload / add): the touched-cell lists no longer bound the
 // non-NaN cells, so this scan falls back to the reference's whole-layer clear — still only if
 // the scan observed a cell.
-__global__ void k_obstacle_dense_clear(const ScanParams P, DevState* __restrict__ st,
+inline __global__ void k_obstacle_dense_clear(const ScanParams P, DevState* __restrict__ st,
                                        float* __restrict__ obstacle, size_t n) {
   if (st->flags[P.slot].any_inside == 0u || st->dense_paid == st->dense_owed) return;  // (nothing observed | nothing owed)
   size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -1197,44 +1197,44 @@ __global__ void k_obstacle_dense_clear(const ScanParams P, DevState* __restrict_
 // ... and behind it (one thread): the scan that observed a cell has paid the debt
 // (the paid number is also left in the pinned statistics block: enqueue-only callers learn that the debt is gone
 // without a stream wait — until then every scan is "not plain": no fused launch, no batch launch)
-__global__ void k_obstacle_dense_paid(const ScanParams P, DevState* __restrict__ st, StatsOut* __restrict__ out) {
+inline __global__ void k_obstacle_dense_paid(const ScanParams P, DevState* __restrict__ st, StatsOut* __restrict__ out) {
   if (st->flags[P.slot].any_inside != 0u) {
     st->dense_paid = st->dense_owed;
     __hip_atomic_store(&out->dense_paid, st->dense_owed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
-__global__ void k_obstacle_dense_owe(DevState* __restrict__ st, unsigned seq) { st->dense_owed = seq; }
+inline __global__ void k_obstacle_dense_owe(DevState* __restrict__ st, unsigned seq) { st->dense_owed = seq; }
 
 // ---- small utility kernels (a layer is a strided view: stride 1 or the record size) ----
-__global__ void k_fill(float* __restrict__ p, float v, size_t n, int es) {
+inline __global__ void k_fill(float* __restrict__ p, float v, size_t n, int es) {
   size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t stride = size_t(gridDim.x) * blockDim.x;
   for (; i < n; i += stride) p[i * size_t(es)] = v;
 }
 // dst[i*ds] = src[i*ss]  (gather a record field into a contiguous array and back)
-__global__ void k_copy_strided(float* __restrict__ dst, int ds, const float* __restrict__ src, int ss,
+inline __global__ void k_copy_strided(float* __restrict__ dst, int ds, const float* __restrict__ src, int ss,
                                size_t n) {
   size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t stride = size_t(gridDim.x) * blockDim.x;
   for (; i < n; i += stride) dst[i * size_t(ds)] = src[i * size_t(ss)];
 }
-__global__ void k_fill_aux(uint4* __restrict__ p, size_t n) {
+inline __global__ void k_fill_aux(uint4* __restrict__ p, size_t n) {
   size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t stride = size_t(gridDim.x) * blockDim.x;
   for (; i < n; i += stride) p[i] = make_uint4(0u, 0u, kNoIdx, 0u);
 }
-__global__ void k_fill_u64(unsigned long long* __restrict__ p, unsigned long long v, size_t n) {
+inline __global__ void k_fill_u64(unsigned long long* __restrict__ p, unsigned long long v, size_t n) {
   size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t stride = size_t(gridDim.x) * blockDim.x;
   for (; i < n; i += stride) p[i] = v;
 }
-__global__ void k_fill_u32(uint32_t* __restrict__ p, uint32_t v, size_t n) {
+inline __global__ void k_fill_u32(uint32_t* __restrict__ p, uint32_t v, size_t n) {
   size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t stride = size_t(gridDim.x) * blockDim.x;
   for (; i < n; i += stride) p[i] = v;
 }
 // rectangle <-> contiguous buffer (halo exchange); thread = (row within rect), blockIdx.y = col
-__global__ void k_region_copy(float* __restrict__ layer, int es, float* __restrict__ buf, int s_rows,
+inline __global__ void k_region_copy(float* __restrict__ layer, int es, float* __restrict__ buf, int s_rows,
                               int r0, int c0, int nr, int nc, int to_buf) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int c = blockIdx.y;
@@ -1255,7 +1255,7 @@ struct RegionArgs {
   int es[kRegionLayers];
   int n_rects, n_layers, s_rows, to_buf;
 };
-__global__ void k_regions_copy(const RegionArgs A, float* __restrict__ buf) {
+inline __global__ void k_regions_copy(const RegionArgs A, float* __restrict__ buf) {
   const int q = blockIdx.y / A.n_layers, l = blockIdx.y % A.n_layers;
   const int nr = A.nr[q], nc = A.nc[q];
   const size_t cells = size_t(nr) * size_t(nc);

@@ -722,7 +722,11 @@ __device__ __forceinline__ void mbin_body(const MBin& B, const MCommon& K, const
       }
     }
     if (commit) {
+#ifdef FDM_X_MHASH  // (measurement build, profiles/r06/batch_max.txt: a multiplicative hash instead of cell mod 512)
+      uint32_t hh = (uint32_t(cell) * 2654435761u) >> 23;
+#else
       uint32_t hh = uint32_t(cell) & (kMBlock - 1u);
+#endif
       while (true) {
         const uint32_t prev = atomicCAS(&S.t_cell[hh], kEmptyCell, uint32_t(cell));
         if (prev == kEmptyCell || prev == uint32_t(cell)) break;

@@ -50,7 +50,7 @@ __device__ __forceinline__ bool post_inside(const PostGeom& p, int lr, int lc) {
 }
 
 // ---- inpainting: one pass (inpainting.cpp:41-64); the caller ping-pongs two buffers ----
-__global__ __launch_bounds__(256) void k_inpaint_pass(const GeomConst G, const DevState* __restrict__ st, int slot,
+inline __global__ __launch_bounds__(256) void k_inpaint_pass(const GeomConst G, const DevState* __restrict__ st, int slot,
                                                       const float* __restrict__ in, int in_stride,
                                                       float* __restrict__ out, int out_stride,
                                                       int min_valid, unsigned ncell) {
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_inpaint_pass(const GeomConst G, const D
 }
 
 // ---- spatial median smoothing (spatial_smoothing.hpp:52-66); `in` is a private copy ----
-__global__ __launch_bounds__(256) void k_median(const GeomConst G, const DevState* __restrict__ st, int slot,
+inline __global__ __launch_bounds__(256) void k_median(const GeomConst G, const DevState* __restrict__ st, int slot,
                                                 const float* __restrict__ in, float* __restrict__ out,
                                                 int out_stride, int kernel, int min_valid, unsigned ncell) {
   const unsigned t = blockIdx.x * 256u + threadIdx.x;
@@ -116,7 +116,7 @@ struct PoolList {
   unsigned pitch;
   __device__ __forceinline__ float& operator[](int k) const { return base[size_t(k) * pitch]; }
 };
-__global__ __launch_bounds__(256) void k_median_big(const GeomConst G, const DevState* __restrict__ st, int slot,
+inline __global__ __launch_bounds__(256) void k_median_big(const GeomConst G, const DevState* __restrict__ st, int slot,
                                                     const float* __restrict__ in, float* __restrict__ out,
                                                     int out_stride, int kernel, int min_valid, unsigned ncell,
                                                     float* __restrict__ pool) {
@@ -158,7 +158,7 @@ __device__ __forceinline__ float post_unkey(uint32_t u) { return __uint_as_float
 __host__ __device__ constexpr unsigned median_sel_lds_bytes(int kernel) {
   return unsigned(kS3R_ + 2 * (kernel / 2)) * unsigned(kS3C_ + 2 * (kernel / 2)) * 4u;
 }
-__global__ __launch_bounds__(256) void k_median_sel(const GeomConst G, const DevState* __restrict__ st, int slot,
+inline __global__ __launch_bounds__(256) void k_median_sel(const GeomConst G, const DevState* __restrict__ st, int slot,
                                                     const float* __restrict__ in, float* __restrict__ out,
                                                     int out_stride, int kernel, int min_valid) {
   extern __shared__ uint32_t s_keys[];
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_median_sel(const GeomConst G, const Dev
 // 3x3 window (the default kernel): the nine values are named registers, missing / non-finite
 // neighbours are +inf, a 25-step sorting network (verified on all 512 0-1 inputs) orders them and
 // element n/2 of the n finite ones is the median — no window in scratch memory, no dependent loop.
-__global__ __launch_bounds__(256) void k_median3(const GeomConst G, const DevState* __restrict__ st, int slot,
+inline __global__ __launch_bounds__(256) void k_median3(const GeomConst G, const DevState* __restrict__ st, int slot,
                                                  const float* __restrict__ in, float* __restrict__ out,
                                                  int out_stride, int min_valid, unsigned ncell) {
   const unsigned t = blockIdx.x * 256u + threadIdx.x;
@@ -245,7 +245,7 @@ __device__ __forceinline__ void stage_tile3(const PostGeom& p, const float* __re
   }
   __syncthreads();
 }
-__global__ __launch_bounds__(256) void k_inpaint_pass_tiled(const GeomConst G, const DevState* __restrict__ st, int slot,
+inline __global__ __launch_bounds__(256) void k_inpaint_pass_tiled(const GeomConst G, const DevState* __restrict__ st, int slot,
                                                             const float* __restrict__ in, int in_stride,
                                                             float* __restrict__ out, int out_stride, int min_valid) {
   __shared__ float s_t[kS3Pitch * kS3Width];
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_inpaint_pass_tiled(const GeomConst G, c
   }
   out[post_index(p, lr, lc) * size_t(out_stride)] = v;
 }
-__global__ __launch_bounds__(256) void k_median3_tiled(const GeomConst G, const DevState* __restrict__ st, int slot,
+inline __global__ __launch_bounds__(256) void k_median3_tiled(const GeomConst G, const DevState* __restrict__ st, int slot,
                                                        const float* __restrict__ in, float* __restrict__ out,
                                                        int out_stride, int min_valid) {
   __shared__ float s_t[kS3Pitch * kS3Width];
@@ -454,7 +454,7 @@ __device__ __forceinline__ float fusion_wave_quantile(const unsigned long long* 
   }
   return val[uint32_t(key[n - 1u])];
 }
-__global__ __launch_bounds__(kFusionWaveThreads) void k_fusion_wave(const GeomConst G, const DevState* __restrict__ st,
+inline __global__ __launch_bounds__(kFusionWaveThreads) void k_fusion_wave(const GeomConst G, const DevState* __restrict__ st,
                                                                     int slot, const RegionEntry* __restrict__ reg,
                                                                     const FusionParams F, const unsigned n_pad,
                                                                     const float* __restrict__ up_in,
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(kFusionWaveThreads) void k_fusion_wave(const GeomCo
 }
 
 // discs of more than kFusionWaveMax cells: the four lists in the global pool (see k_median_big)
-__global__ __launch_bounds__(kFusionThreads) void k_fusion_big(const GeomConst G, const DevState* __restrict__ st,
+inline __global__ __launch_bounds__(kFusionThreads) void k_fusion_big(const GeomConst G, const DevState* __restrict__ st,
                                                                int slot, const RegionEntry* __restrict__ reg,
                                                                const FusionParams F, const float* __restrict__ up_in,
                                                                const float* __restrict__ lo_in,
@@ -662,7 +662,7 @@ __device__ __forceinline__ float fusion_list32(const PostGeom& p, int lr, int lc
   return q;
 }
 
-__global__ __launch_bounds__(kFusionThreads) void k_fusion_net32(const GeomConst G, const DevState* __restrict__ st,
+inline __global__ __launch_bounds__(kFusionThreads) void k_fusion_net32(const GeomConst G, const DevState* __restrict__ st,
                                                                  int slot, const RegionEntry* __restrict__ reg,
                                                                  const FusionParams F, const float* __restrict__ up_in,
                                                                  const float* __restrict__ lo_in,
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(kFusionThreads) void k_fusion_net32(const GeomConst
 // `halo` cells (NaN outside the stored window, so "outside" and "no data" are one test).  The two passes (lower
 // list, then upper) re-read LDS instead of L2, and a neighbour costs no 64-bit index arithmetic.
 constexpr int kFusTileR = 32, kFusTileC = kFusionThreads / kFusTileR, kFusHaloMax = 8;
-__global__ __launch_bounds__(kFusionThreads) void k_fusion_net32_tiled(const GeomConst G, const DevState* __restrict__ st,
+inline __global__ __launch_bounds__(kFusionThreads) void k_fusion_net32_tiled(const GeomConst G, const DevState* __restrict__ st,
                                                                        int slot, const RegionEntry* __restrict__ reg,
                                                                        const FusionParams F, int halo,
                                                                        const float* __restrict__ up_in,
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(256) void k_features(const GeomConst G, const DevSt
 }
 
 // discs of more than kMaxRegion cells, any percentile pair: the sorted heights in the global pool (see k_median_big)
-__global__ __launch_bounds__(256) void k_features_big(const GeomConst G, const DevState* __restrict__ st, int slot,
+inline __global__ __launch_bounds__(256) void k_features_big(const GeomConst G, const DevState* __restrict__ st, int slot,
                                                       const RegionEntry* __restrict__ reg, const FeatureParams F,
                                                       const float* __restrict__ elev, int elev_stride,
                                                       const FeatureOut O, unsigned ncell, float* __restrict__ pool) {
@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(256) void k_features_big(const GeomConst G, const D
 __host__ __device__ constexpr unsigned features_sel_lds_bytes(int halo, int n_entries) {
   return unsigned(kS3R_ + 2 * halo) * unsigned(kS3C_ + 2 * halo) * 8u + unsigned(n_entries) * 4u;
 }
-__global__ __launch_bounds__(256) void k_features_sel(const GeomConst G, const DevState* __restrict__ st, int slot,
+inline __global__ __launch_bounds__(256) void k_features_sel(const GeomConst G, const DevState* __restrict__ st, int slot,
                                                       const RegionEntry* __restrict__ reg, const FeatureParams F, int halo,
                                                       const float* __restrict__ elev, const FeatureOut O) {
   extern __shared__ uint32_t s_feat[];

@@ -307,7 +307,7 @@ __device__ __forceinline__ void vs_count_body(unsigned n, float inv_voxel, const
   }
   if (any_word && __ballot(valid) && (threadIdx.x & 63) == 0) *any_word = any_val;
 }
-__global__ __launch_bounds__(256) void k_vs_count(unsigned n, float inv_voxel, int flag_slot, const VoxelCompact C,
+inline __global__ __launch_bounds__(256) void k_vs_count(unsigned n, float inv_voxel, int flag_slot, const VoxelCompact C,
                                                   const VoxelSmall V, DevState* __restrict__ st,
                                                   const float* __restrict__ x, const float* __restrict__ y,
                                                   const float* __restrict__ z, uint32_t* __restrict__ keys,
@@ -362,7 +362,7 @@ __device__ __forceinline__ void vs_scatter_body(unsigned n, const VoxelSmall& V,
   }
   V.rec[s + V.place[i]] = make_uint4(k, i, s, m);
 }
-__global__ __launch_bounds__(256) void k_vs_scatter(unsigned n, const VoxelSmall V, const uint32_t* __restrict__ keys) {
+inline __global__ __launch_bounds__(256) void k_vs_scatter(unsigned n, const VoxelSmall V, const uint32_t* __restrict__ keys) {
   vs_scatter_body(n, V, keys, blockIdx.x);
 }
 
@@ -446,7 +446,7 @@ __device__ __forceinline__ void vs_mark_body(const VoxelSmall& V, uint32_t* __re
     V.coarse[f >> 5] = 0u;
   }
 }
-__global__ __launch_bounds__(256) void k_vs_mark(const VoxelSmall V, uint32_t* __restrict__ sel) {
+inline __global__ __launch_bounds__(256) void k_vs_mark(const VoxelSmall V, uint32_t* __restrict__ sel) {
   vs_mark_body(V, sel, blockIdx.x);
 }
 
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256) void k_ray_compact(const RayParams Q, const Ge
 // bucket counts -> offsets, in two launches of kRayBins / kRayBinBlock blocks: per-block sums, then every block
 // adds up the sums in front of it and scans its own kRayBinBlock counts (4 per thread).  The counts are left
 // at zero for the next scan.
-__global__ __launch_bounds__(256) void k_ray_bin_sum(const RayParams Q, const GeomConst G,
+inline __global__ __launch_bounds__(256) void k_ray_bin_sum(const RayParams Q, const GeomConst G,
                                                      DevState* __restrict__ st,
                                                      const uint32_t* __restrict__ bin_cnt,
                                                      uint32_t* __restrict__ bin_part) {
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256) void k_ray_bin_sum(const RayParams Q, const Ge
   if (threadIdx.x == 0) bin_part[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-__global__ __launch_bounds__(256) void k_ray_bin_scan(const RayParams Q, const GeomConst G,
+inline __global__ __launch_bounds__(256) void k_ray_bin_scan(const RayParams Q, const GeomConst G,
                                                       DevState* __restrict__ st,
                                                       uint32_t* __restrict__ bin_cnt,
                                                       const uint32_t* __restrict__ bin_part,
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(256) void k_ray_bin_scan(const RayParams Q, const G
 // the same in ONE launch for the (sector, length class) order of k_ray_wedge, whose 8 K buckets one workgroup scans:
 // thread t owns buckets [8 t, 8 t + 8)
 constexpr unsigned kRayScan1Threads = 1024u, kRayScan1Per = 8u;
-__global__ __launch_bounds__(kRayScan1Threads) void k_ray_bin_scan1(const RayParams Q, const GeomConst G,
+inline __global__ __launch_bounds__(kRayScan1Threads) void k_ray_bin_scan1(const RayParams Q, const GeomConst G,
                                                                     DevState* __restrict__ st,
                                                                     uint32_t* __restrict__ bin_cnt,
                                                                     uint32_t* __restrict__ bin_start) {
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(kRayScan1Threads) void k_ray_bin_scan1(const RayPar
   if (threadIdx.x == kRayScan1Threads - 1u) st->ray_count = run;  // (the queue's length: the sum of all buckets)
 }
 
-__global__ __launch_bounds__(256) void k_ray_scatter(const RayParams Q, const GeomConst G,
+inline __global__ __launch_bounds__(256) void k_ray_scatter(const RayParams Q, const GeomConst G,
                                                      DevState* __restrict__ st,
                                                      const uint32_t* __restrict__ ray_list,
                                                      const uint32_t* __restrict__ ray_key,
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(256) void k_ray(const RayParams Q, const GeomConst 
 
 // voxelGrid(ANY) on its own (fdm_engine_voxel_any): sel[i] = picked point index if sorted position
 // i heads a run, else kNoIdx.  Output order of the filter == ascending i.
-__global__ __launch_bounds__(256) void k_voxel_select(unsigned n,
+inline __global__ __launch_bounds__(256) void k_voxel_select(unsigned n,
                                                       const unsigned long long* __restrict__ keys,
                                                       const uint32_t* __restrict__ idx,
                                                       uint32_t* __restrict__ sel) {
@@ -962,7 +962,7 @@ struct RayLayers {
 
 // One thread per stored cell: fold the observed evidence, publish the frame's min ray height,
 // resolve the ghost decision (raycasting.cpp:175-202), and leave the two scratch arrays clean.
-__global__ __launch_bounds__(256) void k_ray_resolve(const RayParams Q, const GeomConst G,
+inline __global__ __launch_bounds__(256) void k_ray_resolve(const RayParams Q, const GeomConst G,
                                                      DevState* __restrict__ st, const RayLayers L,
                                                      float* const* __restrict__ layer_ptrs,
                                                      int n_layer_ptrs, uint32_t* __restrict__ rc_cnt,

@@ -80,7 +80,7 @@ __device__ __forceinline__ bool rb_runs(const RBatch& R, const unsigned k) {  //
   return R.rs->any[k] == R.stamp && R.rs->origin_in[k] != 0u;
 }
 
-__global__ __launch_bounds__(256) void k_rb_count(const RBatch R, const GeomConst G) {
+inline __global__ __launch_bounds__(256) void k_rb_count(const RBatch R, const GeomConst G) {
   const unsigned k = blockIdx.y;
   if (blockIdx.x * 256u >= R.n[k]) return;
   if (blockIdx.x == 0u && threadIdx.x == 0u) {  // (read by the launches behind this one)
@@ -93,13 +93,13 @@ __global__ __launch_bounds__(256) void k_rb_count(const RBatch R, const GeomCons
                 R.keys + at, R.sel + at, &R.rs->any[k], R.stamp, blockIdx.x);
 }
 
-__global__ __launch_bounds__(256) void k_rb_scatter(const RBatch R) {
+inline __global__ __launch_bounds__(256) void k_rb_scatter(const RBatch R) {
   const unsigned k = blockIdx.y;
   if (blockIdx.x * 256u >= R.n[k]) return;
   vs_scatter_body(R.n[k], rb_voxel(R, k), R.keys + size_t(k) * R.stride, blockIdx.x);
 }
 
-__global__ __launch_bounds__(256) void k_rb_mark(const RBatch R) {
+inline __global__ __launch_bounds__(256) void k_rb_mark(const RBatch R) {
   const unsigned k = blockIdx.y;
   if (blockIdx.x * 256u >= R.n[k]) return;
   vs_mark_body(rb_voxel(R, k), R.sel + size_t(k) * R.stride, blockIdx.x);
@@ -131,7 +131,7 @@ __device__ __forceinline__ unsigned ray_quadrant(const RayFrame& F, float res, f
 
 // processScan's first half for scan blockIdx.y (as k_ray_compact): observed evidence counted, the downward rays queued —
 // in FOUR queues, by quadrant (k_rb_ray_lds keeps a quadrant's min-height image in LDS)
-__global__ __launch_bounds__(256) void k_rb_compact(const RBatch R, const GeomConst G) {
+inline __global__ __launch_bounds__(256) void k_rb_compact(const RBatch R, const GeomConst G) {
   __shared__ unsigned s_cnt[4][4];  // [wavefront][quadrant]
   __shared__ unsigned s_base[4];
   const unsigned k = blockIdx.y;
@@ -203,7 +203,7 @@ constexpr unsigned kRbRayThreads = 1024u;
 #define FDM_RB_STEPS 4
 #endif
 constexpr int kRbSteps = FDM_RB_STEPS;  // cells a ray walks between two rounds of LDS reads
-__global__ __launch_bounds__(kRbRayThreads) void k_rb_ray_lds(const RBatch R, const GeomConst G, const unsigned parts,
+inline __global__ __launch_bounds__(kRbRayThreads) void k_rb_ray_lds(const RBatch R, const GeomConst G, const unsigned parts,
                                                               const unsigned lds_words) {
   extern __shared__ uint32_t s_img[];
   const unsigned k = blockIdx.y, q = blockIdx.x / parts, part = blockIdx.x - q * parts;

@@ -37,7 +37,7 @@ __device__ __forceinline__ unsigned route_owner(const RoutePlan& R, int r, int c
 }
 
 // cnt layout: [blocks][world + 2] — per owner, then surviving points, then points inside the map
-__global__ __launch_bounds__(256) void k_route_count(const ScanParams P, const GeomConst G, const RoutePlan R,
+inline __global__ __launch_bounds__(256) void k_route_count(const ScanParams P, const GeomConst G, const RoutePlan R,
                                                      const DevState* __restrict__ st, const float* __restrict__ px,
                                                      const float* __restrict__ py, const float* __restrict__ pz,
                                                      uint8_t* __restrict__ owner_out, uint32_t* __restrict__ cnt) {
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_route_count(const ScanParams P, const G
 // one 1024-thread block per column of cnt (world + 2 columns): exclusive scan over the scan's blocks, eight
 // consecutive entries per thread and pass so that their loads are in flight together (one wavefront walking the
 // column entry by entry spent 100 us of dependent load latency on a 2 M-point slice)
-__global__ __launch_bounds__(1024) void k_route_scan(uint32_t* __restrict__ cnt, unsigned blocks, int world,
+inline __global__ __launch_bounds__(1024) void k_route_scan(uint32_t* __restrict__ cnt, unsigned blocks, int world,
                                                       uint32_t* __restrict__ totals /* [world + 2] */) {
   __shared__ unsigned s_w[16];
   __shared__ unsigned s_run;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(1024) void k_route_scan(uint32_t* __restrict__ cnt,
 }
 // the owners' shares in the send buffer start where the shares of the lower ranks end
 // (soa: every share is padded to a multiple of four points, so that each of its four channels starts 16-byte aligned)
-__global__ void k_route_base(const uint32_t* __restrict__ totals, int world, uint32_t* __restrict__ base, int soa) {
+inline __global__ void k_route_base(const uint32_t* __restrict__ totals, int world, uint32_t* __restrict__ base, int soa) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     unsigned acc = 0;
     for (int d = 0; d < world; ++d) { base[d] = acc; acc += soa ? ((totals[d] + 3u) & ~3u) : totals[d]; }
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void k_route_scatter(unsigned n, int world, co
 }
 
 // received points {x, y, z, intensity} -> the SoA channels the bin kernels read
-__global__ void k_points4_to_soa(const float4* __restrict__ pts, size_t n, float* __restrict__ x, float* __restrict__ y,
+inline __global__ void k_points4_to_soa(const float4* __restrict__ pts, size_t n, float* __restrict__ x, float* __restrict__ y,
                                  float* __restrict__ z, float* __restrict__ a) {
   size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t stride = size_t(gridDim.x) * blockDim.x;

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_rs_hist(unsigned n, const KEY* __restri
 }
 
 // block d: hist[d][0 .. ntiles) -> exclusive prefix in place, total[d]
-__global__ __launch_bounds__(256) void k_rs_scan(unsigned ntiles, uint32_t* __restrict__ hist, uint32_t* __restrict__ total) {
+inline __global__ __launch_bounds__(256) void k_rs_scan(unsigned ntiles, uint32_t* __restrict__ hist, uint32_t* __restrict__ total) {
   __shared__ uint32_t s_wave[4];
   __shared__ uint32_t s_carry;
   uint32_t* const row = hist + size_t(blockIdx.x) * ntiles;

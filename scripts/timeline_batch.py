@@ -8,7 +8,7 @@ import numpy as np  # noqa: E402
 import bench  # noqa: E402
 from fastdem_amd import synth  # noqa: E402
 
-BM = 32  # scans per launch (kMaxBatch; batch_max=N on the command line)
+BM = 16  # scans per launch (the engine's default for Kalman; batch_max=N on the command line, up to kMaxBatch = 32)
 for kv in sys.argv[1:]:
     if kv.startswith("batch_max="):
         BM = int(kv.split("=")[1])
@@ -43,7 +43,8 @@ def role(rows, width):
     idx = np.concatenate([np.arange(r * gx, r * gx + width) for r in rows]) if rows else np.array([], dtype=int)
     idx = idx[live[idx]] if len(idx) else idx
     return {"n": int(len(idx)), "start": q(s[idx]), "end": q(e[idx]), "dur": q(d[idx])}
-nu = (22500 + 63) // 64
+cpb = 64 if BM <= 16 else 32   # cells per update block (fdm_multi.hpp upd_cells_per_block)
+nu = (22500 + cpb - 1) // cpb
 ur = (nu + gx - 1) // gx
 upd_idx = np.arange(0, nu)
 out["update"] = {"n": int(nu), "start": q(s[upd_idx]), "end": q(e[upd_idx]), "dur": q(d[upd_idx])}
