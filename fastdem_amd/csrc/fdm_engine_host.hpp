@@ -217,6 +217,8 @@ struct fdm_engine {
                                     // makes it SIX blocks per CU (seven: configs[3] 32.3 -> 31.8 us at six; five — what the fixed 4 KB of round 5
                                     // came to for a scan with an intensity channel, 29.7 KB per block — 31.4 -> 30.3 us at six, profiles/r06/probe_l.json)
   int cnt_shift = 5;                // option "cnt_shift": one tile counter per 2^cnt_shift words (TilePool::cnt_shift); takes effect before the pools exist
+  int bin_delay = 0;                // option "bin_delay": see TileWork::delay (measurement: profiles/r06/probe_delay.json)
+  int bin_delay_blocks = 1024;      // option "bin_delay_blocks"
   int bin_stagger = 0;              // option "bin_stagger": start stagger of the fused launch's first-round bin blocks (TileWork::stagger)
   size_t tile_rare_waves = 0;       // update wavefronts the rare-path scratch is sized for
   TileGrid TG{};

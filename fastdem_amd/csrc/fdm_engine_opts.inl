@@ -210,6 +210,11 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
     e->batch_max = value;
     return FDM_OK;
   }
+  if (std::strcmp(key, "bin_delay") == 0 || std::strcmp(key, "bin_delay_blocks") == 0) {
+    if (value < 0 || value > 65535) return fail(FDM_ERR_INVALID, "bin_delay: 0 .. 65535");
+    if (key[9] == '_') e->bin_delay_blocks = value; else e->bin_delay = value;
+    return FDM_OK;
+  }
   if (std::strcmp(key, "bin_stagger") == 0) {
     if (value < 0 || value > 64) return fail(FDM_ERR_INVALID, "bin_stagger: 0 .. 64");
     e->bin_stagger = value;

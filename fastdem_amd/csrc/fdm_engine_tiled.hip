@@ -13,6 +13,8 @@ TileWork tile_work(const fdm_engine* e, unsigned blocks) {
   K.T = (e->TG.n_tiles + K.W - 1u) / K.W;
   K.prio = e->upd_prio ? 1u : 0u;
   K.stagger = unsigned(e->bin_stagger);
+  K.delay = unsigned(e->bin_delay);
+  K.delay_blocks = unsigned(e->bin_delay_blocks);
   return K;
 }
 // update blocks of a launch: alone, enough to fill the chip; beside a bin half (fused launch), few — the bin blocks are

@@ -110,6 +110,8 @@ struct TileWork {
   unsigned T;          // tiles per wavefront
   unsigned prio;       // 1: the update wavefronts raise their issue priority (option "upd_prio")
   unsigned stagger;    // fused launch: start delay of the first-round bin blocks, in units of 512 cycles per resident slot (option "bin_stagger")
+  unsigned delay;      // fused launch: the first `delay_blocks` bin blocks wait this many units of 512 cycles before their first load
+  unsigned delay_blocks;  //            (option "bin_delay": the update wavefronts' first round trip goes ahead of 12 MB of point loads)
 };
 
 // value of a canonicalised ord word; `neg`: the first zero seen was -0 (only looked at for a zero)
@@ -716,6 +718,8 @@ __global__ __launch_bounds__(THREADS, FDM_UPD_WAVES) void k_tupdate_tbin(
       const unsigned slot = (bb >> 8) & 7u;
       for (unsigned i = 0; i < slot * K.stagger && bb < 2048u; ++i) __builtin_amdgcn_s_sleep(8);
     }
+    if (K.delay && bb < K.delay_blocks)
+      for (unsigned i = 0; i < K.delay; ++i) __builtin_amdgcn_s_sleep(8);
     TbinRing H(Pb, st);
     tbin2_body<HAS_INT, HAS_COL, LEAN>(Pb, G, TG, H, Ib, Sb, Sb.bin_part, Qb, cell_ids, dyn_lds, bb);
   }

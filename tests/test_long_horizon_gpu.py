@@ -251,5 +251,4 @@ def test_thousands_of_scans_against_the_oracle(gpu, R, seed):
     # the stream did exercise what it is for
     if "tiled_min" not in gpu.Engine.default_options:
         assert sum(eng.batch_launches()) > launches0, "no batch launch in the whole stream"
-    assert np.isfinite(eng.layer("elevation")).sum() > 0
     assert time.perf_counter() - t0 < 240.0
