@@ -523,15 +523,29 @@ __device__ __forceinline__ void p2_step(P2State& s, float x, const P2Params& p) 
     for (int k = 0; k < 5; ++k) q[k] = (ic == k) ? x : q[k];
     count += 1.0f;
     if (count >= 5.0f) {
-      // std::sort on 5 elements == stable insertion sort (libstdc++ __insertion_sort)
+      // std::sort on 5 elements IS libstdc++'s __insertion_sort (quantile_estimation.hpp:150; no introsort loop below 16
+      // elements), restated step for step: an element smaller than the FIRST goes to the front without a look at the
+      // ones in between, any other one walks down until the first neighbour it is not smaller than — and stops there.
+      // For five finite values that is any sort.  It is not when a marker is NaN — a cell whose n_points another
+      // estimator advanced (setEstimatorType at run time, fastdem.cpp:34-38: the layers are shared) skips a slot, and
+      // `NaN < x` is false both ways: rounds 1-5 ran adjacent swaps all the way down instead and left the NaN (and with it
+      // every later quantile of the cell) somewhere else than the reference does.  Found by the round-6 oracle soak
+      // (scripts/soak_oracle.py, seed 1098 after 784 K scans; profiles/r06/soak_oracle.txt).
 #pragma unroll
       for (int i = 1; i < 5; ++i) {
+        const float val = q[i];
+        if (val < q[0]) {  // std::move_backward(first, i, i + 1); *first = val
 #pragma unroll
-        for (int j = i; j > 0; --j) {
-          const float a = q[j - 1], b = q[j];
-          const bool sw = b < a;
-          q[j - 1] = sw ? b : a;
-          q[j] = sw ? a : b;
+          for (int j = i; j > 0; --j) q[j] = q[j - 1];
+          q[0] = val;
+        } else {           // __unguarded_linear_insert
+          bool moving = true;
+#pragma unroll
+          for (int j = i; j > 0; --j) {
+            const bool shift = moving && (val < q[j - 1]);
+            q[j] = shift ? q[j - 1] : (moving ? val : q[j]);
+            moving = shift;
+          }
         }
       }
 #pragma unroll

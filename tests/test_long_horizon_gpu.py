@@ -151,6 +151,8 @@ def compare(eng, ref, what, names=None):
 
 
 N_SCANS = {2026: 12000, 7: 6000, 31: 6000}
+TRACE = None   # scripts/soak_oracle_repro.py: a list that takes one record per call (what the call looked like)
+HOOK = None    # ... and a callable(call number, eng, ref, scans, poses, Tbs) -> True if it integrated the call's scans itself
 
 
 @pytest.mark.parametrize("seed", sorted(N_SCANS))
@@ -189,10 +191,16 @@ def test_thousands_of_scans_against_the_oracle(gpu, R, seed):
             o.set_config(c)
         if int(rng.integers(0, 4)) == 0:
             host_event(rng, eng, ref)
+            if TRACE is not None:
+                TRACE.append({"host_event_before_call": calls + 1})
         count = int(rng.integers(1, 40))
         scans = [g.cloud(g.size(), colour) for _ in range(count)]
         poses = [g.pose() for _ in range(count)]
         how = int(rng.integers(0, 8))
+        if HOOK is not None and HOOK(calls + 1, eng, ref, scans, poses, Tbs):
+            done += count
+            calls += 1
+            continue
         # ---- the oracle, scan by scan ----
         rc_r = st_r = None
         for s, Twb in zip(scans, poses):
@@ -238,6 +246,9 @@ def test_thousands_of_scans_against_the_oracle(gpu, R, seed):
             assert eng.integrate_device_batch(b.arr) == 0
         done += count
         calls += 1
+        if TRACE is not None:
+            TRACE.append({"call": calls, "done": done, "ray": ray, "how": how, "count": count, "estimator": int(eng.cfg.estimation_type),
+                          "colour": bool(colour), "sizes": [int(s_["x"].size) for s_ in scans]})
         # behind EVERY call: the two layers a dropped clear or a missed strip shows in first (a stale cell lives only until
         # the next pipeline switch or host write wipes it: a compare every 50 scans walks past most of them)
         compare(eng, ref, f"after {done} scans ({calls} calls, seed {seed})",

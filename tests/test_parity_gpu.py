@@ -732,3 +732,44 @@ def test_points4_host_entry_the_reference_cloud_layout(gpu, R):
     odd = np.zeros(4 * 8 + 1, dtype=np.float32)[1:].reshape(8, 4)
     with pytest.raises(gpu.EngineError):
         eng.integrate_points4(odd, wl.T_base_sensor, wl.pose(0))
+
+
+@pytest.mark.parametrize("first", ["kalman", "p2"])
+def test_p2_markers_sorted_as_libstdcxx_does_when_one_is_nan(gpu, R, first):
+    """P2Quantile::updateP2 sorts its five markers with std::sort when the fifth sample arrives (quantile_estimation.hpp:150) —
+    libstdc++'s insertion sort below 16 elements.  The estimators share `n_points` (fastdem.cpp:34-38: setEstimatorType at
+    run time keeps the other estimator's layers): samples a Kalman estimator counted make P2 skip marker slots, and the
+    fifth sample then sorts an array that holds NaN — where `NaN < x` is false both ways and the result is whatever the
+    insertion sort's exact sequence of comparisons leaves.  Rounds 1-5 sorted with adjacent swaps carried all the way down:
+    the same for finite values, another permutation with a NaN among them (every later quantile of the cell differed).
+    Found by scripts/soak_oracle.py after 784 K scans (profiles/r06/soak_oracle.txt)."""
+    def fill(c):
+        c.z_min, c.z_max, c.range_min, c.range_max = -3.0, 3.0, 0.0, 30.0
+        c.mode = 1                       # GLOBAL: the cells stay where they are
+        c.estimation_type = 0 if first == "kalman" else 1
+    eng, ref = pair(gpu, R, 8.0, 8.0, 0.1, fill)
+    rng = np.random.default_rng(17)
+    n = 1500
+    x = rng.uniform(-3.5, 3.5, n).astype(F32)
+    y = rng.uniform(-3.5, 3.5, n).astype(F32)
+    Tbs = np.eye(4)
+
+    def scan(z0):
+        return {"x": x, "y": y, "z": (z0 + 0.3 * rng.standard_normal(n)).astype(F32), "intensity": None, "rgb": None}
+
+    def switch(est):
+        for o in (eng, ref):
+            c = o.cfg
+            c.estimation_type = est
+            o.set_config(c)
+
+    plan = ([("k", 2), ("p", 3), ("k", 1), ("p", 4)] if first == "kalman" else [("p", 1), ("k", 2), ("p", 4), ("k", 1), ("p", 3)])
+    for est, scans in plan:
+        switch(0 if est == "k" else 1)
+        for _ in range(scans):
+            run_both(eng, ref, scan(-0.2), Tbs, Tbs, check_ids=False)
+    assert_layers_bit_identical(eng, ref)
+    # the case is there: cells past their fifth sample that hold a NaN marker beside finite ones
+    q = np.stack([eng.layer(f"_p2_q{k}") for k in range(5)])
+    mixed = (eng.layer("n_points") >= 5) & np.isnan(q).any(axis=0) & np.isfinite(q).any(axis=0)
+    assert mixed.sum() > 100, int(mixed.sum())
