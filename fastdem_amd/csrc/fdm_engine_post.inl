@@ -186,8 +186,21 @@ int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* 
   const unsigned fblocks = unsigned((e->ncell + kFusionThreads - 1) / kFusionThreads);
   int halo = 0;
   for (const RegionEntry& r : reg) halo = std::max(halo, std::max(std::abs(r.dr), std::abs(r.dc)));
-  if (reg.size() <= 32 && halo <= kFusHaloMax && !(e->dbg_ray & 1024) && !(e->dbg_post & 2)) {
-    // samples sorted in registers (the default radius: 29 cells), neighbourhood staged in LDS
+  const auto q_ok = [](float q) { return q >= 1e-6f && q <= 1.0f; };  // (k_fusion_f64_tiled's walk: a positive target within the total)
+  if (reg.size() <= 32 && halo <= kFusHaloMax && !(e->dbg_ray & 1024) && !(e->dbg_post & (2 | 32)) && q_ok(F.q_lower) &&
+      q_ok(F.q_upper)) {
+    // samples as doubles sorted by v_min_f64 / v_max_f64 (the default radius: 29 cells), neighbourhood staged in LDS
+    const unsigned tblocks = unsigned((e->G.s_rows + kFusTileR - 1) / kFusTileR) *
+                             unsigned((e->G.s_cols + kFusTileC - 1) / kFusTileC);
+    auto launch_f64 = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(tblocks), dim3(kFusionThreads), 0, e->stream, e->G, e->d_state, int(e->scan_no & 3),
+                         e->d_region, F, halo, e->d_tmp, e->d_tmp2, lptr(e, *up), lstride(e, *up), lptr(e, *lo),
+                         lstride(e, *lo));
+    };
+    if (reg.size() <= 29) launch_f64(k_fusion_f64_tiled<29>);
+    else launch_f64(k_fusion_f64_tiled<32>);
+  } else if (reg.size() <= 32 && halo <= kFusHaloMax && !(e->dbg_ray & 1024) && !(e->dbg_post & 2)) {
+    // samples as 64-bit integers sorted in registers, neighbourhood staged in LDS (round 2; any quantile)
     const unsigned tblocks = unsigned((e->G.s_rows + kFusTileR - 1) / kFusTileR) *
                              unsigned((e->G.s_cols + kFusTileC - 1) / kFusTileC);
     hipLaunchKernelGGL(k_fusion_net32_tiled, dim3(tblocks), dim3(kFusionThreads), 0, e->stream, e->G, e->d_state,
@@ -307,7 +320,11 @@ int fdm_engine_apply_feature_extraction(fdm_engine* e, float radius, int min_val
       hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, e->stream, e->G, e->d_state, int(e->scan_no & 3),
                          e->d_feat_tab, F, halo, elev_p, O);
     };
-    if (need_lo <= 8 && need_hi <= 8) launch_tiled(k_features_tiled<8>);  // defaults: 6 from the bottom, 7 from the top
+    if (e->dbg_post & 64) {  // (measurement: the two-instruction insertion chains of round 2)
+      if (need_lo <= 8 && need_hi <= 8) launch_tiled(k_features_tiled<8, 8, false>);
+      else launch_tiled(k_features_tiled<16, 16, false>);
+    } else if (need_lo <= 6 && need_hi <= 7) launch_tiled(k_features_tiled<6, 7>);  // the defaults: 6 from the bottom, 7 from the top
+    else if (need_lo <= 8 && need_hi <= 8) launch_tiled(k_features_tiled<8>);
     else launch_tiled(k_features_tiled<16>);
   } else if (pct_ok && need_lo <= 8 && need_hi <= 8) launch_feat(k_features<8>);
   else if (pct_ok && need_lo <= 16 && need_hi <= 16) launch_feat(k_features<16>);

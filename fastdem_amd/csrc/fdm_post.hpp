@@ -730,6 +730,147 @@ inline __global__ __launch_bounds__(kFusionThreads) void k_fusion_net32_tiled(co
     lo_out[ci * lo_stride] = lower;
   }
 }
+// Round 6: the same stage with each sample as a POSITIVE DOUBLE of one fixed exponent (2^33): mantissa bits 50..19 hold
+// ord(value), bits 13..9 the entry index, so that v_min_f64 / v_max_f64 order samples by (value, entry) and a
+// compare-exchange is TWO instructions (the 64-bit integer version: v_cmp_u64 + four v_cndmask + two wait states).
+// Every entry of the region is a sample in both lists — one whose weight does not count (no data, or weight <= 1e-6)
+// has the weight 0.0 in its LDS slot: x + 0.0f == x for the sums of positive weights the reference forms, and the
+// quantile can only stop at a sample that moved the cumulative sum (the host sends quantiles outside [1e-6, 1] to
+// k_fusion_net32_tiled).  So the gather has no branches, the upper list needs no tests at all, and the walk over
+// the sorted samples is branch-free: pass one replaces each sample by {ord(value), weight} and sums the total,
+// pass two keeps the value of the first sample whose cumulative weight reaches the target.  N = 29 (the default
+// disc) drops the twenty compare-exchanges of Batcher's 32-network that would only touch its three padding slots.
+__device__ __forceinline__ double vmin_f64(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vmax_f64(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+constexpr uint32_t kFusEShift = 9u, kFusEMask = 31u << kFusEShift;  // s_w[e][t]: byte offset e * 512 + t * 4
+static_assert(kFusionThreads * 4 == 1 << kFusEShift, "the entry field of a sample is the byte offset of its weight row");
+__device__ __forceinline__ double fusion_sample(float v, uint32_t e) {
+  const uint32_t i = ord(v + 0.0f);  // -0 -> +0: the reference's `<` calls them equal
+  return __hiloint2double(int(__builtin_amdgcn_alignbit(0x840u, i, 13)), int((i << 19) | (e << kFusEShift)));
+}
+__device__ __forceinline__ double fusion_pad(uint32_t e) {  // behind every value, weight slot e (0.0)
+  return __hiloint2double(int(0x4207FFFFu), int(0xFFF80000u | (e << kFusEShift)));
+}
+template <int N, bool UPPER>
+__device__ __forceinline__ float fusion_list_f64(int base, int pitch, const RegionEntry* __restrict__ reg,
+                                                 const FusionParams& F, const float* __restrict__ s_up,
+                                                 const float* __restrict__ s_lo, float (*s_w)[kFusionThreads],
+                                                 int& valid, bool& any) {
+  const uint32_t t4 = threadIdx.x * 4u;
+#define FDM_DECL(e) double d##e = 0.0;
+  FDM_E32(FDM_DECL)
+#undef FDM_DECL
+  if (!UPPER) {
+    valid = 0;
+    any = false;
+#define FDM_GATHER(e)                                                                    \
+  if (e < N) {                                                                            \
+    if (e < F.n_entries) {                                                                \
+      const RegionEntry re = reg[e];                                                      \
+      const int ni = base + re.dc * pitch + re.dr;                                        \
+      const float nu_v = s_up[ni], nl_v = s_lo[ni];                                       \
+      const bool fin = isfinite(nu_v) && isfinite(nl_v);                                  \
+      const float weight = re.w * (1.0f / ((nu_v - nl_v) + 1e-4f));                       \
+      const bool tk = fin && weight > 1e-6f;                                              \
+      s_w[e][threadIdx.x] = tk ? weight : 0.0f;                                           \
+      any = any || tk;                                                                    \
+      valid += fin ? 1 : 0;                                                               \
+      d##e = fusion_sample(nl_v, e);                                                      \
+    } else {                                                                              \
+      s_w[e][threadIdx.x] = 0.0f;                                                         \
+      d##e = fusion_pad(e);                                                               \
+    }                                                                                     \
+  }
+    FDM_E32(FDM_GATHER)
+#undef FDM_GATHER
+    if (valid < F.min_valid) return __uint_as_float(0x7FC00000u);
+  } else {
+#define FDM_GATHER_U(e)                                                                  \
+  if (e < N) {                                                                            \
+    if (e < F.n_entries) {                                                                \
+      const RegionEntry re = reg[e];                                                      \
+      d##e = fusion_sample(s_up[base + re.dc * pitch + re.dr], e);                        \
+    } else {                                                                              \
+      d##e = fusion_pad(e);                                                               \
+    }                                                                                     \
+  }
+    FDM_E32(FDM_GATHER_U)
+#undef FDM_GATHER_U
+  }
+#define FDM_CE(i, j) if (j < N) { const double lo_ = vmin_f64(d##i, d##j); d##j = vmax_f64(d##i, d##j); d##i = lo_; }
+  FDM_NET32(FDM_CE)
+#undef FDM_CE
+  // SimpleWeightedECDF::quantile (uncertainty_fusion.cpp:63-91): total and cumulative sums in sorted order
+  float total = 0.0f;
+#define FDM_W1(k)                                                                                          \
+  uint32_t v##k = 0u;                                                                                      \
+  float w##k = 0.0f;                                                                                       \
+  if (k < N) {                                                                                             \
+    const uint32_t lo_ = uint32_t(__double2loint(d##k)), hi_ = uint32_t(__double2hiint(d##k));            \
+    v##k = __builtin_amdgcn_alignbit(hi_, lo_, 19);                                                        \
+    w##k = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(&s_w[0][0]) + ((lo_ & kFusEMask) | t4)); \
+    total += w##k;                                                                                         \
+  }
+  FDM_E32(FDM_W1)
+#undef FDM_W1
+  const float target = (UPPER ? F.q_upper : F.q_lower) * total;
+  float cum = 0.0f;
+  uint32_t qi = v0;
+#define FDM_W2(k) if (k < N) { qi = cum >= target ? qi : v##k; cum += w##k; }
+  FDM_E32(FDM_W2)
+#undef FDM_W2
+  return any ? unord(qi) : __uint_as_float(0x7FC00000u);
+}
+
+template <int N>
+__global__ __launch_bounds__(kFusionThreads) void k_fusion_f64_tiled(const GeomConst G, const DevState* __restrict__ st,
+                                                                     int slot, const RegionEntry* __restrict__ reg,
+                                                                     const FusionParams F, int halo,
+                                                                     const float* __restrict__ up_in,
+                                                                     const float* __restrict__ lo_in,
+                                                                     float* __restrict__ up_out, int up_stride,
+                                                                     float* __restrict__ lo_out, int lo_stride) {
+  __shared__ float s_w[32][kFusionThreads];
+  __shared__ float s_up[(kFusTileR + 2 * kFusHaloMax) * (kFusTileC + 2 * kFusHaloMax)];
+  __shared__ float s_lo[(kFusTileR + 2 * kFusHaloMax) * (kFusTileC + 2 * kFusHaloMax)];
+  const PostGeom p = post_geom(st, slot, G);
+  const int tiles_r = (p.rows + kFusTileR - 1) / kFusTileR;
+  const int tr = int(blockIdx.x) % tiles_r, tc = int(blockIdx.x) / tiles_r;
+  const int pitch = kFusTileR + 2 * halo, width = kFusTileC + 2 * halo;
+  const int r0 = tr * kFusTileR - halo, c0 = tc * kFusTileC - halo;
+  const float nanv = __uint_as_float(0x7FC00000u);
+  for (int k = int(threadIdx.x); k < pitch * width; k += kFusionThreads) {
+    const int cc = k / pitch, rr = k - cc * pitch;
+    const bool in = post_inside(p, r0 + rr, c0 + cc);
+    const size_t gi = in ? post_index(p, r0 + rr, c0 + cc) : 0;
+    s_up[k] = in ? up_in[gi] : nanv;
+    s_lo[k] = in ? lo_in[gi] : nanv;
+  }
+  __syncthreads();
+  const int lrl = int(threadIdx.x) & (kFusTileR - 1), lcl = int(threadIdx.x) / kFusTileR;
+  const int lr = tr * kFusTileR + lrl, lc = tc * kFusTileC + lcl;
+  if (!post_inside(p, lr, lc)) return;
+  const int base = (lcl + halo) * pitch + lrl + halo;
+  if (!isfinite(s_up[base]) || !isfinite(s_lo[base])) return;
+  int valid = 0;
+  bool any = false;
+  const float lower = fusion_list_f64<N, false>(base, pitch, reg, F, s_up, s_lo, s_w, valid, any);
+  if (valid < F.min_valid) return;
+  const float upper = fusion_list_f64<N, true>(base, pitch, reg, F, s_up, s_lo, s_w, valid, any);
+  if (isfinite(lower) && isfinite(upper)) {
+    const size_t ci = post_index(p, lr, lc);
+    up_out[ci * up_stride] = upper;
+    lo_out[ci * lo_stride] = lower;
+  }
+}
 #undef FDM_E32
 
 // ---- Eigen::SelfAdjointEigenSolver<Matrix3f>::computeDirect (Eigen 3.4, 3x3 closed form) ----
@@ -1090,6 +1231,14 @@ __device__ __forceinline__ float vmax_f32(float a, float b) {
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// Inserting a into an ascending list s that keeps its K smallest: new s[j] = max(s[j-1], min(a, s[j])) = the MEDIAN of
+// {s[j-1], a, s[j]} because s[j-1] <= s[j] — one v_med3_f32 per slot, every slot from the OLD list (no chain of
+// dependent min / max pairs: round 6, half the instructions of the two-instruction step).
+__device__ __forceinline__ float vmed3_f32(float a, float b, float c) {
+  float r;
+  asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 constexpr int kFeatTileR = 32, kFeatTileC = 8, kFeatHaloMax = 16;
 struct FeatEntry { int off; float d0, d1, p00, p01, p11; int pad0, pad1; };  // 32 B: one s_load_dwordx8
 
@@ -1099,7 +1248,7 @@ __device__ __forceinline__ void pin_sgpr(const FeatEntry& f) {
   asm volatile("" ::"s"(f.off), "s"(f.d0), "s"(f.d1), "s"(f.p00), "s"(f.p01), "s"(f.p11));
 }
 
-template <int TOPK>
+template <int KLO, int KHI = KLO, bool MED3 = true>
 __global__ __launch_bounds__(256) void k_features_tiled(const GeomConst G, const DevState* __restrict__ st, int slot,
                                                         const FeatEntry* __restrict__ tab, const FeatureParams F,
                                                         int halo, const float* __restrict__ elev,
@@ -1126,9 +1275,11 @@ __global__ __launch_bounds__(256) void k_features_tiled(const GeomConst G, const
   const size_t ci = post_index(p, lr, lc);
   float sum[3] = {0.f, 0.f, 0.f};
   float s00 = 0.f, s01 = 0.f, s11 = 0.f, s02 = 0.f, s12 = 0.f, s22 = 0.f;
-  float small[TOPK], large[TOPK];
+  float small[KLO], large[KHI];
 #pragma unroll
-  for (int j = 0; j < TOPK; ++j) { small[j] = 3.402823466e+38f; large[j] = -3.402823466e+38f; }
+  for (int j = 0; j < KLO; ++j) small[j] = 3.402823466e+38f;
+#pragma unroll
+  for (int j = 0; j < KHI; ++j) large[j] = -3.402823466e+38f;
   int count = 0;
   auto visit = [&](const FeatEntry& fe, float nz) {
     if (!isfinite(nz)) return;
@@ -1142,14 +1293,27 @@ __global__ __launch_bounds__(256) void k_features_tiled(const GeomConst G, const
     s02 += fe.d0 * d2;
     s12 += fe.d1 * d2;
     s22 += d2 * d2;
-    float a = nz, b = nz;
+    if (MED3) {  // small[] ascending, large[] descending; slot j from the old slots j - 1 and j
 #pragma unroll
-    for (int j = 0; j < TOPK; ++j) {  // small[] ascending, large[] descending
-      const float lo_j = small[j], hi_j = large[j];
-      small[j] = vmin_f32(a, lo_j);
-      a = vmax_f32(a, lo_j);
-      large[j] = vmax_f32(b, hi_j);
-      b = vmin_f32(b, hi_j);
+      for (int j = KLO - 1; j > 0; --j) small[j] = vmed3_f32(small[j - 1], nz, small[j]);
+      small[0] = vmin_f32(nz, small[0]);
+#pragma unroll
+      for (int j = KHI - 1; j > 0; --j) large[j] = vmed3_f32(large[j - 1], nz, large[j]);
+      large[0] = vmax_f32(nz, large[0]);
+    } else {
+      float a = nz, b = nz;
+#pragma unroll
+      for (int j = 0; j < KLO; ++j) {
+        const float lo_j = small[j];
+        small[j] = vmin_f32(a, lo_j);
+        a = vmax_f32(a, lo_j);
+      }
+#pragma unroll
+      for (int j = 0; j < KHI; ++j) {
+        const float hi_j = large[j];
+        large[j] = vmax_f32(b, hi_j);
+        b = vmin_f32(b, hi_j);
+      }
     }
     ++count;
   };
@@ -1175,10 +1339,9 @@ __global__ __launch_bounds__(256) void k_features_tiled(const GeomConst G, const
   const int from_top = count - 1 - static_cast<int>(F.hi_pct * float(count - 1));
   float z_lo = small[0], z_hi = large[0];
 #pragma unroll
-  for (int j = 1; j < TOPK; ++j) {
-    z_lo = lo == j ? small[j] : z_lo;
-    z_hi = from_top == j ? large[j] : z_hi;
-  }
+  for (int j = 1; j < KLO; ++j) z_lo = lo == j ? small[j] : z_lo;
+#pragma unroll
+  for (int j = 1; j < KHI; ++j) z_hi = from_top == j ? large[j] : z_hi;
   features_store(O, ci, val, normal, trace, z_lo, z_hi);
 }
 

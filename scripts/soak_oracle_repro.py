@@ -18,6 +18,8 @@ opts = {}
 for a in sys.argv[3:]:
     if a == "tiled_all":
         opts.update({"tiled_min": 1, "ray_large_min": 1})
+    elif a == "extra":
+        pass
     elif "=" in a:
         opts[a.split("=")[0]] = int(a.split("=")[1])
 if seed % 2 and "batch_max" not in opts:
@@ -27,6 +29,10 @@ gpu.capi.load()
 R.load()
 T.N_SCANS[seed] = per
 T.TRACE = []
+if "extra" in sys.argv[3:]:   # (the soak's extra operations between the calls: the same generator)
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import soak_oracle
+    soak_oracle.install_extra(seed)
 state = {}
 orig = T.compare
 
@@ -64,7 +70,13 @@ if "--at" in sys.argv:
                               "engine": {n: ce[n] for n in ce if n.startswith("_p2_q") or n in ("n_points", "elevation")},
                               "oracle": {n: cr[n] for n in cr if n.startswith("_p2_q") or n in ("n_points", "elevation")}}))
         return True
-    T.HOOK = hook
+    prev_hook = T.HOOK
+
+    def both_hooks(call, eng, ref, scans, poses, Tbs):
+        if prev_hook is not None:
+            prev_hook(call, eng, ref, scans, poses, Tbs)
+        return hook(call, eng, ref, scans, poses, Tbs)
+    T.HOOK = both_hooks
 try:
     T.test_thousands_of_scans_against_the_oracle(gpu, R, seed)
     print(json.dumps({"seed": seed, "ok": True, "calls": len(T.TRACE)}))
