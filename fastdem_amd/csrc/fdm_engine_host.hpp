@@ -291,6 +291,8 @@ struct fdm_engine {
   float* d_post_pool = nullptr;      // per-thread lists of the big-neighbourhood stencil kernels
   size_t post_pool_bytes = 0;
   FeatEntry* d_feat_tab = nullptr;   // kMaxRegion entries: the region as k_features_tiled reads it
+  std::vector<RegionEntry> h_region; // what d_region holds (upload_region skips an identical table)
+  std::vector<FeatEntry> h_feat_tab; // what d_feat_tab holds
   int dbg_post = 0;                  // measurement only: 1 = untiled feature kernel, 32 = fusion with integer samples, 64 = features with min / max chains
   unsigned long long* d_timeline = nullptr;  // measurement only: {start, end} ticks per block of the last fused launch
   unsigned timeline_cap = 0;         // blocks the buffer holds

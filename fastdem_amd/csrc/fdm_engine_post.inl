@@ -25,8 +25,15 @@ int upload_region(fdm_engine* e, const std::vector<RegionEntry>& reg) {
     e->region_cap = std::max<size_t>(size_t(kMaxRegion), reg.size() + reg.size() / 4);
     HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_region), e->region_cap * sizeof(RegionEntry)));
   }
+  // the table of the last call stays on the device: a stage called again with the same parameters (the usual case: once
+  // per published map) uploads nothing and waits for nothing
+  if (e->h_region.size() == reg.size() && !reg.empty() &&
+      std::memcmp(e->h_region.data(), reg.data(), reg.size() * sizeof(RegionEntry)) == 0)
+    return FDM_OK;
+  e->h_region.clear();
   HIPCK(hipMemcpyAsync(e->d_region, reg.data(), reg.size() * sizeof(RegionEntry), hipMemcpyHostToDevice, e->stream));
   if (int rc_sync = sync_all(e)) return rc_sync;  // `reg` is a host temporary
+  e->h_region = reg;
   return FDM_OK;
 }
 void region_disc(const fdm_engine* e, float radius, std::vector<RegionEntry>& reg) {
@@ -175,8 +182,15 @@ int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* 
   }
   if ((rc = upload_region(e, reg))) return rc;
   if ((rc = ensure_tmp(e)) || (rc = ensure_tmp2(e))) return rc;
-  if ((rc = copy_strided(e, e->d_tmp, 1, lptr(e, *up), lstride(e, *up)))) return rc;
-  if ((rc = copy_strided(e, e->d_tmp2, 1, lptr(e, *lo), lstride(e, *lo)))) return rc;
+  if (lstride(e, *up) == lstride(e, *lo)) {  // fields of the same cell records (or two dense layers): one pass
+    const int blocks = int(std::min<size_t>((e->ncell + 255) / 256, 4096));
+    hipLaunchKernelGGL(k_copy_strided2, dim3(blocks), dim3(256), 0, e->stream, e->d_tmp, e->d_tmp2, lptr(e, *up), lptr(e, *lo),
+                       lstride(e, *up), e->ncell);
+    HIPCK(hipGetLastError());
+  } else {
+    if ((rc = copy_strided(e, e->d_tmp, 1, lptr(e, *up), lstride(e, *up)))) return rc;
+    if ((rc = copy_strided(e, e->d_tmp2, 1, lptr(e, *lo), lstride(e, *lo)))) return rc;
+  }
   FusionParams F{};
   F.inv_2s2 = 1.0f / (2.0f * cfg->spatial_sigma * cfg->spatial_sigma);
   F.q_lower = cfg->quantile_lower;
@@ -193,12 +207,13 @@ int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* 
     const unsigned tblocks = unsigned((e->G.s_rows + kFusTileR - 1) / kFusTileR) *
                              unsigned((e->G.s_cols + kFusTileC - 1) / kFusTileC);
     auto launch_f64 = [&](auto kern) {
-      hipLaunchKernelGGL(kern, dim3(tblocks), dim3(kFusionThreads), 0, e->stream, e->G, e->d_state, int(e->scan_no & 3),
-                         e->d_region, F, halo, e->d_tmp, e->d_tmp2, lptr(e, *up), lstride(e, *up), lptr(e, *lo),
-                         lstride(e, *lo));
+      hipLaunchKernelGGL(kern, dim3(tblocks), dim3(kFusionThreads), fusion_f64_lds_bytes(halo), e->stream, e->G, e->d_state,
+                         int(e->scan_no & 3), e->d_region, F, halo, e->d_tmp, e->d_tmp2, lptr(e, *up), lstride(e, *up),
+                         lptr(e, *lo), lstride(e, *lo));
     };
-    if (reg.size() <= 29) launch_f64(k_fusion_f64_tiled<29>);
-    else launch_f64(k_fusion_f64_tiled<32>);
+    if (reg.size() == 29 && !(e->dbg_post & 128)) launch_f64(k_fusion_f64_tiled<29, true>);  // the default disc: three cells of radius
+    else if (reg.size() <= 29) launch_f64(k_fusion_f64_tiled<29, false>);
+    else launch_f64(k_fusion_f64_tiled<32, false>);
   } else if (reg.size() <= 32 && halo <= kFusHaloMax && !(e->dbg_ray & 1024) && !(e->dbg_post & 2)) {
     // samples as 64-bit integers sorted in registers, neighbourhood staged in LDS (round 2; any quantile)
     const unsigned tblocks = unsigned((e->G.s_rows + kFusTileR - 1) / kFusTileR) *
@@ -276,11 +291,17 @@ int fdm_engine_apply_feature_extraction(fdm_engine* e, float radius, int min_val
       t.p00 = t.d0 * t.d0;
       t.p01 = t.d0 * t.d1;
       t.p11 = t.d1 * t.d1;
-      t.pad0 = t.pad1 = 0;
+      t.one = 1.0f;
+      t.pad = 0;
     }
     if (!e->d_feat_tab) HIPCK(hipMalloc(reinterpret_cast<void**>(&e->d_feat_tab), kMaxRegion * sizeof(FeatEntry)));
-    if (!tab.empty())
-      HIPCK(hipMemcpyAsync(e->d_feat_tab, tab.data(), tab.size() * sizeof(FeatEntry), hipMemcpyHostToDevice, e->stream));
+    const bool same_tab = e->h_feat_tab.size() == tab.size() &&
+                          std::memcmp(e->h_feat_tab.data(), tab.data(), tab.size() * sizeof(FeatEntry)) == 0;
+    if (!tab.empty() && !same_tab) {
+      if (int rc_sync = sync_all(e)) return rc_sync;  // (a kernel of an earlier call may still read the old table)
+      HIPCK(hipMemcpy(e->d_feat_tab, tab.data(), tab.size() * sizeof(FeatEntry), hipMemcpyHostToDevice));
+      e->h_feat_tab = tab;
+    }
   }
   if ((rc = upload_region(e, reg))) return rc;
   Layer* elev = find_layer(e, "elevation");

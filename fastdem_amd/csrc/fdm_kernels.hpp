@@ -1218,6 +1218,17 @@ inline __global__ void k_copy_strided(float* __restrict__ dst, int ds, const flo
   const size_t stride = size_t(gridDim.x) * blockDim.x;
   for (; i < n; i += stride) dst[i * size_t(ds)] = src[i * size_t(ss)];
 }
+// two fields of the same records in one pass (a record's line is fetched once): uncertainty fusion's private copies
+inline __global__ void k_copy_strided2(float* __restrict__ dst0, float* __restrict__ dst1, const float* __restrict__ src0,
+                                       const float* __restrict__ src1, int ss, size_t n) {
+  size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const size_t stride = size_t(gridDim.x) * blockDim.x;
+  for (; i < n; i += stride) {
+    const float a = src0[i * size_t(ss)], b = src1[i * size_t(ss)];
+    dst0[i] = a;
+    dst1[i] = b;
+  }
+}
 inline __global__ void k_fill_aux(uint4* __restrict__ p, size_t n) {
   size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t stride = size_t(gridDim.x) * blockDim.x;

@@ -311,6 +311,32 @@ inline __global__ __launch_bounds__(256) void k_median3_tiled(const GeomConst G,
   out[post_index(p, lr, lc) * size_t(out_stride)] = m == 0 ? w0 : (m == 1 ? w1 : (m == 2 ? w2 : (m == 3 ? w3 : w4)));
 }
 
+// The stencil kernels work only for cells that hold data, and a map is rings and patches: with thread = cell a
+// wavefront runs its ~3 000 instructions for whichever of its 64 cells are there (configs[3] after 12 scans: half).
+// compact_cells hands the block's cells that pass `live` to consecutive threads in cell order (ballot + popcount, two
+// barriers); the others get -1.  Every thread of the block must call it.
+template <int THREADS, class LIVE>
+__device__ __forceinline__ int compact_cells(LIVE live) {
+  static_assert(THREADS % 64 == 0 && THREADS <= 512, "whole wavefronts");
+  __shared__ uint16_t s_cell[THREADS];
+  __shared__ int s_live[THREADS / 64];
+  const int t = int(threadIdx.x), w = t >> 6;
+  const bool mine = live(t);
+  const unsigned long long bal = __ballot(mine);
+  if ((t & 63) == 0) s_live[w] = __popcll(bal);
+  __syncthreads();
+  int before = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < THREADS / 64; ++k) {
+    const int n = s_live[k];
+    before += k < w ? n : 0;
+    total += n;
+  }
+  if (mine) s_cell[before + __popcll(bal & ((1ull << (t & 63)) - 1ull))] = uint16_t(t);
+  __syncthreads();
+  return t < total ? int(s_cell[t]) : -1;
+}
+
 // ---- uncertainty fusion (uncertainty_fusion.cpp:135-181); upper/lower are private copies ----
 struct FusionParams {
   float inv_2s2, q_lower, q_upper;
@@ -759,11 +785,10 @@ __device__ __forceinline__ double fusion_sample(float v, uint32_t e) {
 __device__ __forceinline__ double fusion_pad(uint32_t e) {  // behind every value, weight slot e (0.0)
   return __hiloint2double(int(0x4207FFFFu), int(0xFFF80000u | (e << kFusEShift)));
 }
-template <int N, bool UPPER>
+template <int N, bool FULL, bool UPPER>
 __device__ __forceinline__ float fusion_list_f64(int base, int pitch, const RegionEntry* __restrict__ reg,
-                                                 const FusionParams& F, const float* __restrict__ s_up,
-                                                 const float* __restrict__ s_lo, float (*s_w)[kFusionThreads],
-                                                 int& valid, bool& any) {
+                                                 const FusionParams& F, const float2* __restrict__ s_ul,
+                                                 float (*s_w)[kFusionThreads], int& valid, bool& any) {
   const uint32_t t4 = threadIdx.x * 4u;
 #define FDM_DECL(e) double d##e = 0.0;
   FDM_E32(FDM_DECL)
@@ -773,17 +798,16 @@ __device__ __forceinline__ float fusion_list_f64(int base, int pitch, const Regi
     any = false;
 #define FDM_GATHER(e)                                                                    \
   if (e < N) {                                                                            \
-    if (e < F.n_entries) {                                                                \
+    if (FULL || e < F.n_entries) {                                                        \
       const RegionEntry re = reg[e];                                                      \
-      const int ni = base + re.dc * pitch + re.dr;                                        \
-      const float nu_v = s_up[ni], nl_v = s_lo[ni];                                       \
-      const bool fin = isfinite(nu_v) && isfinite(nl_v);                                  \
-      const float weight = re.w * (1.0f / ((nu_v - nl_v) + 1e-4f));                       \
+      const float2 ul = s_ul[base + re.dc * pitch + re.dr];                               \
+      const bool fin = isfinite(ul.x) && isfinite(ul.y);                                  \
+      const float weight = re.w * (1.0f / ((ul.x - ul.y) + 1e-4f));                       \
       const bool tk = fin && weight > 1e-6f;                                              \
       s_w[e][threadIdx.x] = tk ? weight : 0.0f;                                           \
       any = any || tk;                                                                    \
       valid += fin ? 1 : 0;                                                               \
-      d##e = fusion_sample(nl_v, e);                                                      \
+      d##e = fusion_sample(ul.y, e);                                                      \
     } else {                                                                              \
       s_w[e][threadIdx.x] = 0.0f;                                                         \
       d##e = fusion_pad(e);                                                               \
@@ -795,9 +819,9 @@ __device__ __forceinline__ float fusion_list_f64(int base, int pitch, const Regi
   } else {
 #define FDM_GATHER_U(e)                                                                  \
   if (e < N) {                                                                            \
-    if (e < F.n_entries) {                                                                \
+    if (FULL || e < F.n_entries) {                                                        \
       const RegionEntry re = reg[e];                                                      \
-      d##e = fusion_sample(s_up[base + re.dc * pitch + re.dr], e);                        \
+      d##e = fusion_sample(s_ul[base + re.dc * pitch + re.dr].x, e);                      \
     } else {                                                                              \
       d##e = fusion_pad(e);                                                               \
     }                                                                                     \
@@ -830,17 +854,21 @@ __device__ __forceinline__ float fusion_list_f64(int base, int pitch, const Regi
   return any ? unord(qi) : __uint_as_float(0x7FC00000u);
 }
 
-template <int N>
-__global__ __launch_bounds__(kFusionThreads) void k_fusion_f64_tiled(const GeomConst G, const DevState* __restrict__ st,
+// one block per 32 x 4 cells; dynamic LDS: the tile of {upper, lower} pairs with its ring of `halo` cells (NaN outside
+// the stored window) — fusion_f64_lds_bytes(halo); FULL: the region has exactly N entries
+__host__ __device__ constexpr unsigned fusion_f64_lds_bytes(int halo) {
+  return unsigned(kFusTileR + 2 * halo) * unsigned(kFusTileC + 2 * halo) * 8u;
+}
+template <int N, bool FULL>
+__global__ __launch_bounds__(kFusionThreads, 4) void k_fusion_f64_tiled(const GeomConst G, const DevState* __restrict__ st,
                                                                      int slot, const RegionEntry* __restrict__ reg,
                                                                      const FusionParams F, int halo,
                                                                      const float* __restrict__ up_in,
                                                                      const float* __restrict__ lo_in,
                                                                      float* __restrict__ up_out, int up_stride,
                                                                      float* __restrict__ lo_out, int lo_stride) {
-  __shared__ float s_w[32][kFusionThreads];
-  __shared__ float s_up[(kFusTileR + 2 * kFusHaloMax) * (kFusTileC + 2 * kFusHaloMax)];
-  __shared__ float s_lo[(kFusTileR + 2 * kFusHaloMax) * (kFusTileC + 2 * kFusHaloMax)];
+  __shared__ float s_w[N][kFusionThreads];
+  extern __shared__ float2 s_ul[];
   const PostGeom p = post_geom(st, slot, G);
   const int tiles_r = (p.rows + kFusTileR - 1) / kFusTileR;
   const int tr = int(blockIdx.x) % tiles_r, tc = int(blockIdx.x) / tiles_r;
@@ -851,20 +879,23 @@ __global__ __launch_bounds__(kFusionThreads) void k_fusion_f64_tiled(const GeomC
     const int cc = k / pitch, rr = k - cc * pitch;
     const bool in = post_inside(p, r0 + rr, c0 + cc);
     const size_t gi = in ? post_index(p, r0 + rr, c0 + cc) : 0;
-    s_up[k] = in ? up_in[gi] : nanv;
-    s_lo[k] = in ? lo_in[gi] : nanv;
+    s_ul[k] = make_float2(in ? up_in[gi] : nanv, in ? lo_in[gi] : nanv);
   }
   __syncthreads();
-  const int lrl = int(threadIdx.x) & (kFusTileR - 1), lcl = int(threadIdx.x) / kFusTileR;
+  const int cell = compact_cells<kFusionThreads>([&](int t) {
+    const int rr = t & (kFusTileR - 1), cc = t / kFusTileR;
+    const float2 ul = s_ul[(cc + halo) * pitch + rr + halo];
+    return post_inside(p, tr * kFusTileR + rr, tc * kFusTileC + cc) && isfinite(ul.x) && isfinite(ul.y);
+  });
+  if (cell < 0) return;
+  const int lrl = cell & (kFusTileR - 1), lcl = cell / kFusTileR;
   const int lr = tr * kFusTileR + lrl, lc = tc * kFusTileC + lcl;
-  if (!post_inside(p, lr, lc)) return;
   const int base = (lcl + halo) * pitch + lrl + halo;
-  if (!isfinite(s_up[base]) || !isfinite(s_lo[base])) return;
   int valid = 0;
   bool any = false;
-  const float lower = fusion_list_f64<N, false>(base, pitch, reg, F, s_up, s_lo, s_w, valid, any);
+  const float lower = fusion_list_f64<N, FULL, false>(base, pitch, reg, F, s_ul, s_w, valid, any);
   if (valid < F.min_valid) return;
-  const float upper = fusion_list_f64<N, true>(base, pitch, reg, F, s_up, s_lo, s_w, valid, any);
+  const float upper = fusion_list_f64<N, FULL, true>(base, pitch, reg, F, s_ul, s_w, valid, any);
   if (isfinite(lower) && isfinite(upper)) {
     const size_t ci = post_index(p, lr, lc);
     up_out[ci * up_stride] = upper;
@@ -937,8 +968,10 @@ __device__ __forceinline__ void eig3_direct(const float* cov, float* val, float*
   q = fmaxf(q, 0.0f);
   const float rho = sqrtf(a_over_3);
   const float theta = static_cast<float>(atan2(static_cast<double>(sqrtf(q)), static_cast<double>(half_b))) * s_inv3;
-  const float cos_theta = static_cast<float>(cos(static_cast<double>(theta)));
-  const float sin_theta = static_cast<float>(sin(static_cast<double>(theta)));
+  double sin_d, cos_d;  // one argument reduction for the pair (the same doubles sin() and cos() return)
+  sincos(static_cast<double>(theta), &sin_d, &cos_d);
+  const float cos_theta = static_cast<float>(cos_d);
+  const float sin_theta = static_cast<float>(sin_d);
   float ev[3];
   ev[0] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
   ev[1] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
@@ -1240,12 +1273,16 @@ __device__ __forceinline__ float vmed3_f32(float a, float b, float c) {
   return r;
 }
 constexpr int kFeatTileR = 32, kFeatTileC = 8, kFeatHaloMax = 16;
-struct FeatEntry { int off; float d0, d1, p00, p01, p11; int pad0, pad1; };  // 32 B: one s_load_dwordx8
+
+// 32 B: one s_load_dwordx8; {d0, d1}, {p00, p01}, {p11, 1.0f} are even-aligned scalar pairs — the second operand of one
+// v_pk_add_f32 each (`one` counts the finite neighbours in the lane beside s11: exact far beyond any region's size)
+struct FeatEntry { float d0, d1, p00, p01, p11, one; int off, pad; };
+typedef float feat_v2f __attribute__((ext_vector_type(2)));
 
 // keeps a table row's scalar loads where they are written (the compiler otherwise sinks them into the branch that
 // uses them, one dependent scalar-cache round trip per neighbour)
 __device__ __forceinline__ void pin_sgpr(const FeatEntry& f) {
-  asm volatile("" ::"s"(f.off), "s"(f.d0), "s"(f.d1), "s"(f.p00), "s"(f.p01), "s"(f.p11));
+  asm volatile("" ::"s"(f.off), "s"(f.d0), "s"(f.d1), "s"(f.p00), "s"(f.p01), "s"(f.p11), "s"(f.one));
 }
 
 template <int KLO, int KHI = KLO, bool MED3 = true>
@@ -1266,33 +1303,35 @@ __global__ __launch_bounds__(256) void k_features_tiled(const GeomConst G, const
     s_z[k] = post_inside(p, lr, lc) ? elev[post_index(p, lr, lc)] : nanv;
   }
   __syncthreads();
-  const int lrl = int(threadIdx.x) & (kFeatTileR - 1), lcl = int(threadIdx.x) >> 5;
+  const int cell = compact_cells<256>([&](int t) {  // (round 6) cells with data take consecutive threads: full wavefronts
+    const int rr = t & (kFeatTileR - 1), cc = t >> 5;
+    return post_inside(p, tr * kFeatTileR + rr, tc * kFeatTileC + cc) && isfinite(s_z[(cc + halo) * pitch + rr + halo]);
+  });
+  if (cell < 0) return;
+  const int lrl = cell & (kFeatTileR - 1), lcl = cell >> 5;
   const int lr = tr * kFeatTileR + lrl, lc = tc * kFeatTileC + lcl;
-  if (!post_inside(p, lr, lc)) return;
   const int base = (lcl + halo) * pitch + lrl + halo;
   const float center_z = s_z[base];
-  if (!isfinite(center_z)) return;
   const size_t ci = post_index(p, lr, lc);
-  float sum[3] = {0.f, 0.f, 0.f};
-  float s00 = 0.f, s01 = 0.f, s11 = 0.f, s02 = 0.f, s12 = 0.f, s22 = 0.f;
+  // nine running sums + the count as five register pairs: every pair one v_pk_add_f32 per neighbour
+  feat_v2f a01 = {0.f, 0.f};   // sum[0], sum[1]
+  feat_v2f b01 = {0.f, 0.f};   // s00, s01
+  feat_v2f c11 = {0.f, 0.f};   // s11, count
+  feat_v2f m02 = {0.f, 0.f};   // s02, s12
+  feat_v2f z22 = {0.f, 0.f};   // sum[2], s22
   float small[KLO], large[KHI];
 #pragma unroll
   for (int j = 0; j < KLO; ++j) small[j] = 3.402823466e+38f;
 #pragma unroll
   for (int j = 0; j < KHI; ++j) large[j] = -3.402823466e+38f;
-  int count = 0;
   auto visit = [&](const FeatEntry& fe, float nz) {
     if (!isfinite(nz)) return;
     const float d2 = nz - center_z;
-    sum[0] += fe.d0;
-    sum[1] += fe.d1;
-    sum[2] += d2;
-    s00 += fe.p00;
-    s01 += fe.p01;
-    s11 += fe.p11;
-    s02 += fe.d0 * d2;
-    s12 += fe.d1 * d2;
-    s22 += d2 * d2;
+    a01 += feat_v2f{fe.d0, fe.d1};
+    b01 += feat_v2f{fe.p00, fe.p01};
+    c11 += feat_v2f{fe.p11, fe.one};
+    m02 += feat_v2f{fe.d0, fe.d1} * feat_v2f{d2, d2};
+    z22 += feat_v2f{d2, d2 * d2};
     if (MED3) {  // small[] ascending, large[] descending; slot j from the old slots j - 1 and j
 #pragma unroll
       for (int j = KLO - 1; j > 0; --j) small[j] = vmed3_f32(small[j - 1], nz, small[j]);
@@ -1315,7 +1354,6 @@ __global__ __launch_bounds__(256) void k_features_tiled(const GeomConst G, const
         b = vmin_f32(b, hi_j);
       }
     }
-    ++count;
   };
   int e = 0;
   for (; e + 4 <= F.n_entries; e += 4) {  // four entries' scalar loads and LDS reads in flight together
@@ -1328,7 +1366,10 @@ __global__ __launch_bounds__(256) void k_features_tiled(const GeomConst G, const
     const FeatEntry fe = tab[e];
     visit(fe, s_z[base + fe.off]);
   }
+  const int count = int(c11.y);
   if (count < F.min_valid) return;
+  const float sum[3] = {a01.x, a01.y, z22.x};
+  const float s00 = b01.x, s01 = b01.y, s11 = c11.x, s02 = m02.x, s12 = m02.y, s22 = z22.y;
   const float sq[9] = {s00, s01, s02, s01, s11, s12, s02, s12, s22};  // d[r] * d[c] is the same float either way round
   float cov[9], trace;
   if (!features_cov(sum, sq, count, cov, &trace)) return;

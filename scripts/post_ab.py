@@ -41,7 +41,7 @@ def restore():
 
 
 out = {}
-for tag, opt in (("fusion_f64", 0), ("fusion_u64", 32)):
+for tag, opt in (("fusion_f64", 0), ("fusion_f64_branches", 128), ("fusion_u64", 32)):
     eng.set_option("dbg_post", opt)
     restore()
     eng.apply_uncertainty_fusion(True, 0.15, 0.05, 0.01, 0.99, 3)
