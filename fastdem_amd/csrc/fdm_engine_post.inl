@@ -201,8 +201,8 @@ int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* 
   int halo = 0;
   for (const RegionEntry& r : reg) halo = std::max(halo, std::max(std::abs(r.dr), std::abs(r.dc)));
   const auto q_ok = [](float q) { return q >= 1e-6f && q <= 1.0f; };  // (k_fusion_f64_tiled's walk: a positive target within the total)
-  if (reg.size() <= 32 && halo <= kFusHaloMax && !(e->dbg_ray & 1024) && !(e->dbg_post & (2 | 32)) && q_ok(F.q_lower) &&
-      q_ok(F.q_upper)) {
+  if (reg.size() <= 29 && halo <= kFusHaloMax && !(e->dbg_ray & 1024) && !(e->dbg_post & (2 | 32)) && q_ok(F.q_lower) &&
+      q_ok(F.q_upper)) {  // (a disc of a radius has 1, 5, 9, 13, 21, 25, 29, 37 .. cells: nothing between 29 and 32)
     // samples as doubles sorted by v_min_f64 / v_max_f64 (the default radius: 29 cells), neighbourhood staged in LDS
     const unsigned tblocks = unsigned((e->G.s_rows + kFusTileR - 1) / kFusTileR) *
                              unsigned((e->G.s_cols + kFusTileC - 1) / kFusTileC);
@@ -212,8 +212,7 @@ int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* 
                          lptr(e, *lo), lstride(e, *lo));
     };
     if (reg.size() == 29 && !(e->dbg_post & 128)) launch_f64(k_fusion_f64_tiled<29, true>);  // the default disc: three cells of radius
-    else if (reg.size() <= 29) launch_f64(k_fusion_f64_tiled<29, false>);
-    else launch_f64(k_fusion_f64_tiled<32, false>);
+    else launch_f64(k_fusion_f64_tiled<29, false>);
   } else if (reg.size() <= 32 && halo <= kFusHaloMax && !(e->dbg_ray & 1024) && !(e->dbg_post & 2)) {
     // samples as 64-bit integers sorted in registers, neighbourhood staged in LDS (round 2; any quantile)
     const unsigned tblocks = unsigned((e->G.s_rows + kFusTileR - 1) / kFusTileR) *
@@ -322,7 +321,10 @@ int fdm_engine_apply_feature_extraction(fdm_engine* e, float radius, int min_val
   // is its own cache line — a dense copy of the layer first (C4: 0.82 -> see LABNOTES.md, rounds 1-3 §7)
   const float* elev_p = lptr(e, *elev);
   int elev_s = lstride(e, *elev);
-  if (elev_s != 1) {
+  // (the LDS-tiled kernel stages its tile straight from the records: every cell is fetched ~3.4 times, from the L2, behind
+  //  other blocks' arithmetic — the copy was 17 of the call's 127 us at configs[3]; dbg_post 256: copy first, as before)
+  const bool tiled_ok = pct_ok && need_lo <= 16 && need_hi <= 16 && !tab.empty() && !(e->dbg_post & 1);
+  if (elev_s != 1 && (!tiled_ok || (e->dbg_post & 256))) {
     if ((rc = ensure_tmp(e))) return rc;
     if ((rc = copy_strided(e, e->d_tmp, 1, elev_p, elev_s))) return rc;
     elev_p = e->d_tmp;
@@ -333,13 +335,12 @@ int fdm_engine_apply_feature_extraction(fdm_engine* e, float radius, int min_val
                        e->d_region, F, elev_p, elev_s, O, unsigned(e->ncell));
   };
   // dense layer + a region of bounded reach: LDS-tiled kernel fed from a pre-digested region table (fdm_post.hpp)
-  const bool tiled_ok = pct_ok && need_lo <= 16 && need_hi <= 16 && !tab.empty() && !(e->dbg_post & 1);
   if (tiled_ok) {
     const int rows = e->G.s_rows, cols = e->G.s_cols;
     const unsigned blocks = unsigned((rows + kFeatTileR - 1) / kFeatTileR) * unsigned((cols + kFeatTileC - 1) / kFeatTileC);
     auto launch_tiled = [&](auto kern) {
-      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, e->stream, e->G, e->d_state, int(e->scan_no & 3),
-                         e->d_feat_tab, F, halo, elev_p, O);
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(kFeatThreads), 0, e->stream, e->G, e->d_state, int(e->scan_no & 3),
+                         e->d_feat_tab, F, halo, elev_p, elev_s, O);
     };
     if (e->dbg_post & 64) {  // (measurement: the two-instruction insertion chains of round 2)
       if (need_lo <= 8 && need_hi <= 8) launch_tiled(k_features_tiled<8, 8, false>);

@@ -1272,7 +1272,7 @@ __device__ __forceinline__ float vmed3_f32(float a, float b, float c) {
   asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
-constexpr int kFeatTileR = 32, kFeatTileC = 8, kFeatHaloMax = 16;
+constexpr int kFeatTileR = 32, kFeatTileC = 16, kFeatHaloMax = 16, kFeatThreads = kFeatTileR * kFeatTileC;  // (32 x 16 cells: 2.4 cells staged per cell at the default radius, 3.4 with 32 x 8)
 
 // 32 B: one s_load_dwordx8; {d0, d1}, {p00, p01}, {p11, 1.0f} are even-aligned scalar pairs — the second operand of one
 // v_pk_add_f32 each (`one` counts the finite neighbours in the lane beside s11: exact far beyond any region's size)
@@ -1286,9 +1286,9 @@ __device__ __forceinline__ void pin_sgpr(const FeatEntry& f) {
 }
 
 template <int KLO, int KHI = KLO, bool MED3 = true>
-__global__ __launch_bounds__(256) void k_features_tiled(const GeomConst G, const DevState* __restrict__ st, int slot,
+__global__ __launch_bounds__(kFeatThreads) void k_features_tiled(const GeomConst G, const DevState* __restrict__ st, int slot,
                                                         const FeatEntry* __restrict__ tab, const FeatureParams F,
-                                                        int halo, const float* __restrict__ elev,
+                                                        int halo, const float* __restrict__ elev, int elev_stride,
                                                         const FeatureOut O) {
   __shared__ float s_z[(kFeatTileR + 2 * kFeatHaloMax) * (kFeatTileC + 2 * kFeatHaloMax)];
   const PostGeom p = post_geom(st, slot, G);
@@ -1297,13 +1297,13 @@ __global__ __launch_bounds__(256) void k_features_tiled(const GeomConst G, const
   const int pitch = kFeatTileR + 2 * halo, width = kFeatTileC + 2 * halo;
   const int r0 = tr * kFeatTileR - halo, c0 = tc * kFeatTileC - halo;
   const float nanv = __uint_as_float(0x7FC00000u);
-  for (int k = int(threadIdx.x); k < pitch * width; k += 256) {
+  for (int k = int(threadIdx.x); k < pitch * width; k += kFeatThreads) {
     const int cc = k / pitch, rr = k - cc * pitch;
     const int lr = r0 + rr, lc = c0 + cc;
-    s_z[k] = post_inside(p, lr, lc) ? elev[post_index(p, lr, lc)] : nanv;
+    s_z[k] = post_inside(p, lr, lc) ? elev[post_index(p, lr, lc) * size_t(elev_stride)] : nanv;
   }
   __syncthreads();
-  const int cell = compact_cells<256>([&](int t) {  // (round 6) cells with data take consecutive threads: full wavefronts
+  const int cell = compact_cells<kFeatThreads>([&](int t) {  // (round 6) cells with data take consecutive threads: full wavefronts
     const int rr = t & (kFeatTileR - 1), cc = t >> 5;
     return post_inside(p, tr * kFeatTileR + rr, tc * kFeatTileC + cc) && isfinite(s_z[(cc + halo) * pitch + rr + halo]);
   });

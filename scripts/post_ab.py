@@ -52,7 +52,7 @@ for tag, opt in (("fusion_f64", 0), ("fusion_f64_branches", 128), ("fusion_u64",
 same = all(np.array_equal(out["fusion_f64"][n].view(np.uint32), out["fusion_u64"][n].view(np.uint32)) for n in saved)
 print(json.dumps({"fusion_layers_identical": bool(same)}))
 FEAT = ("step", "slope", "roughness", "curvature", "_normal_x", "_normal_y", "_normal_z")
-for tag, opt in (("features_med3", 0), ("features_minmax", 64)):
+for tag, opt in (("features_med3", 0), ("features_med3_copy_first", 256), ("features_minmax", 64)):
     eng.set_option("dbg_post", opt)
     restore()
     eng.apply_feature_extraction(0.3, 4, 0.05, 0.95)

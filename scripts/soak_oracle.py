@@ -20,9 +20,12 @@ F32 = np.float32
 
 def install_extra(seed):
     rng = np.random.default_rng(900000 + seed)
+    LAST = {}
 
     def hook(call, eng, ref, scans, poses, Tbs):
         pick = int(rng.integers(0, 12))
+        if T.TRACE is not None:
+            T.TRACE.append({"extra_before_call": call, "pick": pick})
         if pick == 0:      # an explicit move (GridMap::move through the C ABI), a few cells or many
             g = ref.geometry()
             x, y = g.position_x + float(rng.uniform(-2.0, 2.0)), g.position_y + float(rng.uniform(-2.0, 2.0))
@@ -41,15 +44,28 @@ def install_extra(seed):
             sr = ref.update(x, y, z, robot, z_var=var, intensity=a)
             assert se == sr, (se, sr)
         elif pick == 2 and ref.exists("elevation"):
+            a = (int(rng.integers(1, 4)), int(rng.integers(1, 4)), bool(rng.integers(0, 2)))
+            LAST["args"] = list(a)
             for o in (eng, ref):
-                o.apply_inpainting(int(rng.integers(1, 4)), int(rng.integers(1, 4)), bool(rng.integers(0, 2)))
+                o.apply_inpainting(*a)
         elif pick == 3 and ref.exists("elevation"):
             k = int(rng.choice([3, 5]))
+            a = ("elevation", k, int(rng.integers(1, 6)))
+            LAST["args"] = list(a)
             for o in (eng, ref):
-                o.apply_spatial_smoothing("elevation", k, int(rng.integers(1, 6)))
+                o.apply_spatial_smoothing(*a)
         elif pick == 4 and ref.exists("upper_bound"):
             for o in (eng, ref):
                 o.apply_uncertainty_fusion(True, 0.15, 0.05, 0.01, 0.99, 3)
+        if T.TRACE is not None and pick <= 4:   # (the replay, scripts/soak_oracle_repro.py: every layer right behind the operation)
+            T.TRACE[-1]["args"] = LAST.get("args")
+            mode = os.environ.get("EXTRA_CHECK", "compare")
+            if mode == "compare":
+                T.compare(eng, ref, f"behind extra operation {pick} before call {call}", None)
+            elif mode == "sync":
+                eng.sync()
+            elif mode == "geometry":
+                eng.geometry()
         return False
     T.HOOK = hook
 

@@ -132,6 +132,59 @@ def test_uncertainty_fusion_parity(gpu, R):
     assert not np.array_equal(eng.layer("upper_bound"), el + half, equal_nan=True)
 
 
+def test_uncertainty_fusion_small_discs_ties_and_quantile_edges(gpu, R):
+    """The double-sample kernel (k_fusion_f64_tiled, discs of up to 29 cells) at every disc size below the default, with
+    what its branch-free walk must get right: entries without data or with a weight <= 1e-6 (they stay in the sorted list
+    with the weight 0.0), ties in value (entry order), -0.0 / +0.0, min_valid gating, and quantiles at and beyond the
+    ends of the range it takes (0 and > 1 go to the integer-sample kernel) — all bit for bit against the oracle."""
+    rng = np.random.default_rng(41)
+    eng, ref, shape = rolled_pair(gpu, R, rng, size=12.0, res=0.05)
+    el = terrain(rng, shape, holes=0.35)
+    half = np.abs(rng.normal(0.05, 0.03, shape)).astype(F32) + F32(0.005)
+    up, lo = el + half, el - half
+    # plateaus of equal bounds (ties keep the entry order), signed zeros, and pairs so far apart that the weight is <= 1e-6
+    up[20:60, 20:60] = np.where(np.isfinite(up[20:60, 20:60]), F32(0.25), up[20:60, 20:60])
+    lo[20:60, 20:60] = np.where(np.isfinite(lo[20:60, 20:60]), F32(-0.125), lo[20:60, 20:60])
+    z = rng.uniform(size=shape) < 0.05
+    lo[z & np.isfinite(lo)] = F32(-0.0)
+    z2 = rng.uniform(size=shape) < 0.05
+    up[z2 & np.isfinite(up) & (lo <= 0)] = F32(0.0)
+    far = rng.uniform(size=shape) < 0.05
+    up[far & np.isfinite(up)] = F32(3.0e6)   # 1 / (range + 1e-4) * w_spatial <= 1e-6: counted as valid, never sampled
+    inv = rng.uniform(size=shape) < 0.02
+    up[inv & np.isfinite(up)] = F32(-5.0)    # upper below lower: a negative range, a negative (or huge) weight
+    cases = []
+    for radius in (0.049, 0.05, 0.0708, 0.1, 0.112, 0.1415, 0.15):   # 1, 5, 9, 13, 21, 25, 29 cells
+        cases.append((True, radius, 0.05, 0.01, 0.99, 3))
+    cases += [(True, 0.15, 0.05, 1e-6, 1.0, 1), (True, 0.15, 0.05, 0.0, 1.0, 3), (True, 0.15, 0.05, 0.5, 0.5, 29),
+              (True, 0.15, 0.05, 0.25, 1.5, 3), (True, 0.1, 0.02, 0.01, 0.99, 14), (True, 0.15, 0.3, 0.999, 0.001, 2)]
+    for cfgv in cases:
+        both((eng, ref), lambda o: (o.set_layer("upper_bound", up), o.set_layer("lower_bound", lo),
+                                    o.apply_uncertainty_fusion(*cfgv)))
+        exact(eng, ref, ["upper_bound", "lower_bound"])
+    # the same call twice in a row: the second one finds its region table on the device
+    both((eng, ref), lambda o: (o.apply_uncertainty_fusion(*cases[6]), o.apply_uncertainty_fusion(*cases[6])))
+    exact(eng, ref, ["upper_bound", "lower_bound"])
+
+
+def test_feature_extraction_order_statistic_slots(gpu, R):
+    """k_features_tiled keeps exactly the order statistics the percentiles can ask for: 6 / 7 slots (the defaults on the
+    default disc), 8 / 8 and 16 / 16 — one v_med3_f32 per slot; `step` and the PCA layers bit for bit on all three."""
+    rng = np.random.default_rng(43)
+    eng, ref, shape = rolled_pair(gpu, R, rng, size=15.0, res=0.05)
+    el = terrain(rng, shape, holes=0.3, noise=0.01)
+    el[rng.uniform(size=shape) < 0.03] = F32(0.0)
+    el[rng.uniform(size=shape) < 0.02] = F32(-0.0)
+    R.set_trig_mode(1)
+    try:
+        for radius, lo, hi in ((0.3, 0.05, 0.95), (0.3, 0.06, 0.94), (0.3, 0.13, 0.87), (0.2, 0.05, 0.95), (0.3, 0.0, 0.95),
+                               (0.3, 0.05, 0.95)):
+            both((eng, ref), lambda o: (o.set_layer("elevation", el), o.apply_feature_extraction(radius, 4, lo, hi)))
+            exact(eng, ref, ["step", "slope", "roughness", "curvature", "_normal_x", "_normal_y", "_normal_z"])
+    finally:
+        R.set_trig_mode(0)
+
+
 def test_discs_of_more_than_256_cells(gpu, R):
     """config/postprocess.hpp:35,45 put no bound on the radii: 0.3 m on a 0.02 m map is a disc of 709 cells, 0.15 m
     one of 177.  The big-neighbourhood kernels (per-cell lists in a global pool) against the oracle: fusion bit-exact;
