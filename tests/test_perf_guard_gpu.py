@@ -85,6 +85,48 @@ def test_raycasting_stays_within_reach_of_the_measured_time(gpu, name, kw, timed
     check(name, device_us_per_scan(gpu, gpu.synth.make(name, **kw), 8, timed, raycast=1), "raycast_us")
 
 
+def stage_ms(gpu, reps=5, iters=20):
+    """Wall time per call [ms] of the default-radius stencil stages on the configs[3] map after 12 scans (the calls only
+    enqueue; a sync on both sides of `iters` of them), best of `reps`."""
+    import time
+    import bench
+    wl = gpu.synth.make("c4", n_scans=4)
+    res = bench.Resident(wl, 0)
+    for k in range(12):
+        res.step(k)
+    eng = res.eng
+    eng.sync()
+    out = {}
+    for name, fn in (("fusion_c4", lambda: eng.apply_uncertainty_fusion(True, 0.15, 0.05, 0.01, 0.99, 3)),
+                     ("features_c4", lambda: eng.apply_feature_extraction(0.3, 4, 0.05, 0.95))):
+        fn()
+        best = float("inf")
+        for _ in range(reps):
+            eng.sync()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                fn()
+            eng.sync()
+            best = min(best, (time.perf_counter() - t0) / iters * 1e3)
+        out[name] = best
+    return out
+
+
+def test_stencil_stages_stay_within_reach_of_the_measured_time(gpu):
+    """Uncertainty fusion and feature extraction at their default radii (round 6: 0.219 -> 0.090 ms and 0.254 -> 0.121 ms
+    on the 1200 x 1200 map; the kernels are bound by instruction issue, so a slip is a compiler or a code change)."""
+    if gpu.Engine.default_options:
+        pytest.skip("the engine's own pipeline choice only")
+    if "stage_ms" not in MEASURED:
+        pytest.skip("profiles/r06/perf_guard.json holds no stage times")
+    got = stage_ms(gpu)
+    scale, copy_ms = box_scale()
+    for name, ms in got.items():
+        ceiling = MARGIN * scale * MEASURED["stage_ms"][name]
+        assert ms < ceiling, (f"{name}: {ms:.4f} ms per call; profiles/r06/perf_guard.json: {MEASURED['stage_ms'][name]:.4f}, "
+                              f"ceiling {ceiling:.4f} (x {MARGIN} x box scale {scale:.2f}: 256 MiB copy {copy_ms:.3f} ms here)")
+
+
 def test_an_enqueue_only_stream_gets_its_batch_launches_back_behind_a_host_write(gpu):
     """A host write of the obstacle layer (or a pipeline switch) leaves a whole-layer clear owed; until a scan that observed
     a cell has paid it every scan is "not plain": no fused launch, no batch launch, two extra launches per scan.  The
@@ -121,4 +163,5 @@ if __name__ == "__main__":   # python tests/test_perf_guard_gpu.py > profiles/rN
     out["copy_256MiB_ms"] = round(box_scale()[1], 4)
     out["integrate_us"] = {n: round(device_us_per_scan(gpu, gpu.synth.make(n, **kw), 32, t), 3) for n, kw, t in CASES}
     out["raycast_us"] = {n: round(device_us_per_scan(gpu, gpu.synth.make(n, **kw), 8, t, raycast=1), 3) for n, kw, t in RAY_CASES}
+    out["stage_ms"] = {n: round(v, 4) for n, v in stage_ms(gpu).items()}
     print(json.dumps(out))
