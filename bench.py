@@ -810,6 +810,24 @@ def main():
                                                  "Mpts_per_s": big.wl.n_points / (ray_b_us * 1e-6) / 1e6,
                                                  "in_batch_launches": False}
                     del rayb
+                if not args.no_host_legs:
+                    # the default-radius stencil stages on the map the scans above left: wall time per
+                    # call (the calls only enqueue; a sync on both sides of 20 of them), best of three
+                    def stage_ms(fn):
+                        fn()
+                        best = float("inf")
+                        for _ in range(3):
+                            big.eng.sync()
+                            ts = time.perf_counter()
+                            for _ in range(20):
+                                fn()
+                            big.eng.sync()
+                            best = min(best, (time.perf_counter() - ts) / 20 * 1e3)
+                        return best
+                    big_legs["stencils_ms_per_call"] = {
+                        "uncertainty_fusion_r0.15": stage_ms(lambda: big.eng.apply_uncertainty_fusion(True, 0.15, 0.05, 0.01, 0.99, 3)),
+                        "feature_extraction_r0.3": stage_ms(lambda: big.eng.apply_feature_extraction(0.3, 4, 0.05, 0.95)),
+                        "cells": int(big.eng.rows * big.eng.cols)}
                 result["large"] = {"workload": big.wl.name, "value": bpts / dtb / 1e6, "steps": n_big,
                                    "device_value": bpts / (big_us * n_big * 1e-6) / 1e6,
                                    "unit": "Mpts/s", "ms_per_step": dtb / n_big * 1e3,

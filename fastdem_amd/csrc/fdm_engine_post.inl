@@ -211,7 +211,15 @@ int fdm_engine_apply_uncertainty_fusion(fdm_engine* e, const fdm_fusion_config* 
                          int(e->scan_no & 3), e->d_region, F, halo, e->d_tmp, e->d_tmp2, lptr(e, *up), lstride(e, *up),
                          lptr(e, *lo), lstride(e, *lo));
     };
-    if (reg.size() == 29 && !(e->dbg_post & 128)) launch_f64(k_fusion_f64_tiled<29, true>);  // the default disc: three cells of radius
+    // one instantiation per disc size there is below 30 cells (the sorting network shrinks with it: 171 exchanges for 29
+    // samples, 19 for the 9 of the shipped 0.15 m on a 0.1 m map); dbg_post 128: the 29-slot kernel with branches
+    const size_t nreg = (e->dbg_post & 128) ? 0 : reg.size();
+    if (nreg == 29) launch_f64(k_fusion_f64_tiled<29, true>);
+    else if (nreg == 25) launch_f64(k_fusion_f64_tiled<25, true>);
+    else if (nreg == 21) launch_f64(k_fusion_f64_tiled<21, true>);
+    else if (nreg == 13) launch_f64(k_fusion_f64_tiled<13, true>);
+    else if (nreg == 9) launch_f64(k_fusion_f64_tiled<9, true>);
+    else if (nreg == 5) launch_f64(k_fusion_f64_tiled<5, true>);
     else launch_f64(k_fusion_f64_tiled<29, false>);
   } else if (reg.size() <= 32 && halo <= kFusHaloMax && !(e->dbg_ray & 1024) && !(e->dbg_post & 2)) {
     // samples as 64-bit integers sorted in registers, neighbourhood staged in LDS (round 2; any quantile)
@@ -345,7 +353,9 @@ int fdm_engine_apply_feature_extraction(fdm_engine* e, float radius, int min_val
     if (e->dbg_post & 64) {  // (measurement: the two-instruction insertion chains of round 2)
       if (need_lo <= 8 && need_hi <= 8) launch_tiled(k_features_tiled<8, 8, false>);
       else launch_tiled(k_features_tiled<16, 16, false>);
-    } else if (need_lo <= 6 && need_hi <= 7) launch_tiled(k_features_tiled<6, 7>);  // the defaults: 6 from the bottom, 7 from the top
+    } else if (need_lo <= 2 && need_hi <= 3) launch_tiled(k_features_tiled<2, 3>);  // the defaults on a 29-cell disc (0.3 m on a 0.1 m map)
+    else if (need_lo <= 4 && need_hi <= 4) launch_tiled(k_features_tiled<4, 4>);
+    else if (need_lo <= 6 && need_hi <= 7) launch_tiled(k_features_tiled<6, 7>);  // the defaults on a 113-cell disc: 6 from the bottom, 7 from the top
     else if (need_lo <= 8 && need_hi <= 8) launch_tiled(k_features_tiled<8>);
     else launch_tiled(k_features_tiled<16>);
   } else if (pct_ok && need_lo <= 8 && need_hi <= 8) launch_feat(k_features<8>);

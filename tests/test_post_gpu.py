@@ -168,8 +168,8 @@ def test_uncertainty_fusion_small_discs_ties_and_quantile_edges(gpu, R):
 
 
 def test_feature_extraction_order_statistic_slots(gpu, R):
-    """k_features_tiled keeps exactly the order statistics the percentiles can ask for: 6 / 7 slots (the defaults on the
-    default disc), 8 / 8 and 16 / 16 — one v_med3_f32 per slot; `step` and the PCA layers bit for bit on all three."""
+    """k_features_tiled keeps exactly the order statistics the percentiles can ask for: 2 / 3, 4 / 4, 6 / 7 (the defaults on
+    discs of 29 / 49 / 113 cells), 8 / 8 and 16 / 16 slots — one v_med3_f32 per slot; `step` and the PCA layers bit for bit."""
     rng = np.random.default_rng(43)
     eng, ref, shape = rolled_pair(gpu, R, rng, size=15.0, res=0.05)
     el = terrain(rng, shape, holes=0.3, noise=0.01)
@@ -177,8 +177,9 @@ def test_feature_extraction_order_statistic_slots(gpu, R):
     el[rng.uniform(size=shape) < 0.02] = F32(-0.0)
     R.set_trig_mode(1)
     try:
+        # slots: 6 / 7, 8 / 8, 16 / 16, 4 / 4 (49-cell disc), 6 / 7, 2 / 3 (29-cell disc: the defaults on a 0.1 m map), 2 / 3 (13 cells)
         for radius, lo, hi in ((0.3, 0.05, 0.95), (0.3, 0.06, 0.94), (0.3, 0.13, 0.87), (0.2, 0.05, 0.95), (0.3, 0.0, 0.95),
-                               (0.3, 0.05, 0.95)):
+                               (0.15, 0.05, 0.95), (0.1, 0.05, 0.95), (0.3, 0.05, 0.95)):
             both((eng, ref), lambda o: (o.set_layer("elevation", el), o.apply_feature_extraction(radius, 4, lo, hi)))
             exact(eng, ref, ["step", "slope", "roughness", "curvature", "_normal_x", "_normal_y", "_normal_z"])
     finally:
