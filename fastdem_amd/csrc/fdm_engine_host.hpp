@@ -175,6 +175,7 @@ struct fdm_engine {
   // large scans: the walk keeps an angular sector's minimum-height image in LDS (option "ray_wedge", fdm_raywedge.hpp;
   // 0 = one lane per ray on memory-side atomics, k_ray<., 1>)
   int ray_wedge = 1;
+  int ray_wedge_parts = 0;           // option "ray_wedge_parts": workgroups per sector (0 = by the scan's size)
   // update(t) || bin(t+1) in ONE launch (k_update_bin): the update of the last small scan is held back
   // until the next scan arrives (or any other entry point / sync flushes it); the scratch is
   // double-buffered by scan parity.

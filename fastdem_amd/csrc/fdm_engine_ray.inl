@@ -345,17 +345,19 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q_in, bool voxel, const fl
     const unsigned sectors = kRaySectors;
     // (a camera's 60-degree field of view puts its rays into 43 of the 256 sectors; four workgroups per sector for
     // scans of that size measured 22 us against 18: every one initialises and flushes a window of its own)
-    const unsigned parts = std::max(1u, std::min(8u, Q.n / (sectors * 8u * kRwThreads)));
+    const unsigned parts = e->ray_wedge_parts > 0 ? unsigned(e->ray_wedge_parts)
+                                                  : std::max(1u, std::min(8u, Q.n / (sectors * 8u * kRwThreads)));
     const uint32_t* bin_start = e->ray_bins + kRayBins;
-    if (tiled) {
-      if ((rc = allow_lds(k_ray_wedge<true>, lds))) return rc;
-      hipLaunchKernelGGL(k_ray_wedge<true>, dim3(sectors * parts), dim3(kRwThreads), lds, e->stream, Q, e->G, e->d_state,
-                         dx, dy, dz, ray_list, bin_start, e->rc_min, H, parts);
-    } else {
-      if ((rc = allow_lds(k_ray_wedge<false>, lds))) return rc;
-      hipLaunchKernelGGL(k_ray_wedge<false>, dim3(sectors * parts), dim3(kRwThreads), lds, e->stream, Q, e->G, e->d_state,
-                         dx, dy, dz, ray_list, bin_start, e->rc_min, H, parts);
-    }
+    auto launch_wedge = [&](auto kern) -> int {
+      if (int rc_lds = allow_lds(kern, lds)) return rc_lds;
+      hipLaunchKernelGGL(kern, dim3(sectors * parts), dim3(kRwThreads), lds, e->stream, Q, e->G, e->d_state, dx, dy, dz,
+                         ray_list, bin_start, e->rc_min, H, parts);
+      return FDM_OK;
+    };
+    const bool fwin = !(e->dbg_ray & 32768);  // (dbg 32768, measurement only: the integer window of round 5)
+    if (tiled) rc = fwin ? launch_wedge(k_ray_wedge<true, true>) : launch_wedge(k_ray_wedge<true, false>);
+    else rc = fwin ? launch_wedge(k_ray_wedge<false, true>) : launch_wedge(k_ray_wedge<false, false>);
+    if (rc) return rc;
   } else if (Q.n < (1u << 16) && !large) {
     tiled ? launch_ray(k_ray<true, 16>, 16u) : launch_ray(k_ray<false, 16>, 16u);
   } else if (!large) {

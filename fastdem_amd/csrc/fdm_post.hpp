@@ -764,8 +764,9 @@ inline __global__ __launch_bounds__(kFusionThreads) void k_fusion_net32_tiled(co
 // quantile can only stop at a sample that moved the cumulative sum (the host sends quantiles outside [1e-6, 1] to
 // k_fusion_net32_tiled).  So the gather has no branches, the upper list needs no tests at all, and the walk over
 // the sorted samples is branch-free: pass one replaces each sample by {ord(value), weight} and sums the total,
-// pass two keeps the value of the first sample whose cumulative weight reaches the target.  N = 29 (the default
-// disc) drops the twenty compare-exchanges of Batcher's 32-network that would only touch its three padding slots.
+// pass two keeps the value of the first sample whose cumulative weight reaches the target.  N = the disc's size (5, 9,
+// 13, 21, 25 or 29 cells: there is no disc of 30 .. 32): only the compare-exchanges of Batcher's 32-network between
+// slots below N are kept — slots from N on would hold padding that never moves (171 exchanges for 29, 26 for 9).
 __device__ __forceinline__ double vmin_f64(double a, double b) {
   double r;
   asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));

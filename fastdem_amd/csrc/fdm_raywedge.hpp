@@ -71,7 +71,21 @@ __device__ __forceinline__ RwRay rw_setup(float ex, float ey, float origin_x, fl
   return R;
 }
 
-template <bool TILED>
+// FWIN (round 6): the window holds the heights as FLOATS (+inf = not visited) and a visit that lowers a cell is a
+// ds_min_f32 — no ord() per visit (three instructions of twenty), and a ray that has ended walks on with dz = NaN: its
+// heights are NaN, `NaN < seen` is false, nothing is stored.  ord() is taken once per lowered cell, at the flush.
+// (Among equal heights the integer window preferred -0 to +0 and this one keeps the first: the reference keeps the
+// first too, raycasting.cpp:131 `height < cur_min`.)
+// The window starts at LDS address 0 (the kernel has no static LDS; checked once per block): its words are addressed by
+// their byte offset alone — through the generic `s_win` pointer every access paid one more add for a base that is zero.
+typedef __attribute__((address_space(3))) float rw_lds_f32;
+__device__ __forceinline__ void rw_fmin(uint32_t byte_off, float h) {
+  (void)__hip_atomic_fetch_min(reinterpret_cast<rw_lds_f32*>(uintptr_t(byte_off)), h, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ float rw_read(uint32_t byte_off) { return *reinterpret_cast<rw_lds_f32*>(uintptr_t(byte_off)); }
+constexpr uint32_t kRwEmptyF = 0x7F800000u;  // +inf
+template <bool TILED, bool FWIN = true>
 __global__ __launch_bounds__(kRwThreads) void k_ray_wedge(const RayParams Q, const GeomConst G,
                                                           DevState* __restrict__ st,
                                                           const float* __restrict__ x, const float* __restrict__ y,
@@ -83,6 +97,7 @@ __global__ __launch_bounds__(kRwThreads) void k_ray_wedge(const RayParams Q, con
   extern __shared__ uint32_t s_win[];  // [H][kRwCols] (the window starts at LDS address 0)
   const unsigned n_rays = st->ray_count;
   if (n_rays == 0u) return;
+  if (FWIN && uint32_t(uintptr_t((__attribute__((address_space(3))) uint32_t*)s_win)) != 0u) __builtin_trap();
   // the sector's stretch of the queue (bin_start: first queue position of every (sector, length class) bucket)
   const unsigned sector = blockIdx.x / parts, part = blockIdx.x - sector * parts;
   const unsigned q_lo = bin_start[sector * kRaySectorClasses];
@@ -101,7 +116,8 @@ __global__ __launch_bounds__(kRwThreads) void k_ray_wedge(const RayParams Q, con
   constexpr uint32_t kColMask = (kRwCols - 1u) * 4u, kRowBytes = kRwCols * 4u;
 
   for (unsigned j = threadIdx.x; j < H * (kRwCols / 4u); j += kRwThreads)
-    reinterpret_cast<uint4*>(s_win)[j] = make_uint4(kRayEmpty, kRayEmpty, kRayEmpty, kRayEmpty);
+    reinterpret_cast<uint4*>(s_win)[j] = FWIN ? make_uint4(kRwEmptyF, kRwEmptyF, kRwEmptyF, kRwEmptyF)
+                                              : make_uint4(kRayEmpty, kRayEmpty, kRayEmpty, kRayEmpty);
   // the sector's band: major axis, direction and slope of its CENTRE line, from the sector's number alone (ray_sector:
   // equal angles counted from -pi; grid rows and columns run against x and y)
   bool major_r, band_ok;
@@ -149,6 +165,8 @@ __global__ __launch_bounds__(kRwThreads) void k_ray_wedge(const RayParams Q, con
     const int sNb = sN * 4;
     int s = 0;
     uint32_t dead = 0u;
+    float dzw = dz;  // FWIN: NaN once the ray has ended
+    const bool no_min = (Q.dbg & 65536) != 0;  // (dbg 65536, measurement only: the window is read, never lowered)
     auto walk_window = [&](auto MAJOR_R) {
       // kRwChunk visits between two looks at the window's end: u grows by at most one per step, so a lane with
       // kRwChunk rows (and steps) to spare cannot leave its rows inside a chunk; one without them leaves the window
@@ -162,9 +180,13 @@ __global__ __launch_bounds__(kRwThreads) void k_ray_wedge(const RayParams Q, con
         const bool stepM = decltype(MAJOR_R)::value ? (tM < tN) : !(tN < tM);
         const float t_exit = stepM ? tM : tN;
         const float height = sz + ((1.0f < t_exit) ? 1.0f : t_exit) * dz;
-        atomicMin(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(s_win) + (rowoff | (uint32_t(vb) & kColMask))),
-                  ord(height));
+        if (FWIN)
+          rw_fmin(rowoff | (uint32_t(vb) & kColMask), height);
+        else
+          atomicMin(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(s_win) + (rowoff | (uint32_t(vb) & kColMask))),
+                    ord(height));
         dead = (t_exit >= 1.0f) ? 0xFFFFFFFFu : 0u;
+        dzw = (t_exit >= 1.0f) ? __uint_as_float(0x7FC00000u) : dz;
         rowoff += stepM ? kRowBytes : 0u;
         vb += stepM ? 0 : sNb;
         tM = stepM ? tM + dM : tM;
@@ -172,12 +194,41 @@ __global__ __launch_bounds__(kRwThreads) void k_ray_wedge(const RayParams Q, con
         s = 1;
       }
       while (true) {
+        if (FWIN) dead = (dzw != dzw) ? 0xFFFFFFFFu : 0u;
         in_win = in_win && dead == 0u && rowoff + kRwChunk * kRowBytes <= row_limit && s + int(kRwChunk) <= max_steps;
         if (__ballot(in_win) == 0ull) break;
         if (in_win) {
           s += int(kRwChunk);
 #pragma unroll 1
-          for (unsigned k = 0; k < kRwChunk; k += kRwRead) {
+          for (unsigned k = 0; FWIN && k < kRwChunk; k += kRwRead) {
+            uint32_t at[kRwRead];
+            float hk[kRwRead], seen[kRwRead];
+#pragma unroll
+            for (unsigned j = 0; j < kRwRead; ++j) {
+              const bool stepM = decltype(MAJOR_R)::value ? (tM < tN) : !(tN < tM);  // traceRay's `t_max_r < t_max_c`
+              float t_cl;
+              asm("v_min3_f32 %0, %1, %2, 1.0" : "=v"(t_cl) : "v"(tM), "v"(tN));
+              hk[j] = sz + t_cl * dzw;
+              at[j] = rowoff | (uint32_t(vb) & kColMask);
+              dzw = (t_cl >= 1.0f) ? __uint_as_float(0x7FC00000u) : dzw;  // t_exit >= 1: traceRay leaves the loop behind this visit
+              rowoff += stepM ? kRowBytes : 0u;
+              vb += stepM ? 0 : sNb;
+              // the axis that steps takes its delta, the other one + 0.0f (t >= 0: the same float): one v_pk_add_f32
+              typedef float rw_v2f __attribute__((ext_vector_type(2)));
+              rw_v2f t2 = {tM, tN};
+              t2 += rw_v2f{stepM ? dM : 0.0f, stepM ? 0.0f : dN};
+              tM = t2.x;
+              tN = t2.y;
+            }
+#pragma unroll
+            for (unsigned j = 0; j < kRwRead; ++j)
+              seen[j] = rw_read(at[j]);
+#pragma unroll
+            for (unsigned j = 0; j < kRwRead; ++j)
+              if (hk[j] < seen[j] && !no_min) rw_fmin(at[j], hk[j]);
+          }
+#pragma unroll 1
+          for (unsigned k = 0; !FWIN && k < kRwChunk; k += kRwRead) {
             // kRwRead steps walked in registers, their window words read together (lanes reading one word share the
             // read), then a ds_min only where the read did not settle the visit
             uint32_t at[kRwRead], key[kRwRead], seen[kRwRead];
@@ -212,7 +263,7 @@ __global__ __launch_bounds__(kRwThreads) void k_ray_wedge(const RayParams Q, con
     if (alive) {
       if (major_r) walk_window(std::true_type{}); else walk_window(std::false_type{});
     }
-    if (dead) alive = false;
+    if (FWIN ? (dzw != dzw) : (dead != 0u)) alive = false;
     if (alive && !(Q.dbg & 8192)) {  // (dbg 8192, measurement only: no walk outside the window)
       // outside its rows of the window (or never in it): memory-side atomics, one per visit
       const int u = int(rowoff / kRowBytes) * sM, v = vb / 4;
@@ -235,16 +286,18 @@ __global__ __launch_bounds__(kRwThreads) void k_ray_wedge(const RayParams Q, con
   // flush: the cell of window word (u, column) is the one within kRwCols / 2 of floor(m0 * u) in that column
   for (unsigned j = threadIdx.x; j < H * (kRwCols / 4u) && !(Q.dbg & 4096); j += kRwThreads) {  // (dbg 4096, measurement only: no flush)
     const uint4 q = reinterpret_cast<const uint4*>(s_win)[j];
-    if ((q.x & q.y & q.z & q.w) == kRayEmpty) continue;
+    constexpr uint32_t kEmpty = FWIN ? kRwEmptyF : kRayEmpty;
+    if (q.x == kEmpty && q.y == kEmpty && q.z == kEmpty && q.w == kEmpty) continue;
     const int u = int(j / (kRwCols / 4u)), col0 = int(j % (kRwCols / 4u)) * 4;
     const int lo = int(floorf(m0 * float(u))) - int(kRwCols / 2u);
     const int M = dir * u;
     const uint32_t keys[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (keys[k] == kRayEmpty) continue;
+      if (keys[k] == kEmpty) continue;
       const int v = lo + ((col0 + k - lo) & int(kRwCols - 1u));
-      rw_store(G, g, TILED, major_r ? r0 + M : r0 + v, major_r ? c0 + v : c0 + M, rc_min, keys[k]);
+      rw_store(G, g, TILED, major_r ? r0 + M : r0 + v, major_r ? c0 + v : c0 + M, rc_min,
+               FWIN ? ord(__uint_as_float(keys[k])) : keys[k]);
     }
   }
 }
