@@ -501,6 +501,7 @@ int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2);
  *                         ordered by (angular sector, length class)
  *   "ray_wedge" 0/1     : ... and walks it with the sector's minimum-height window in LDS (fdm_raywedge.hpp, default 1;
  *                         0 = one lane per ray on memory-side atomics)
+ *   "ray_wedge_parts" n : workgroups per sector of that walk (0 = by the scan's size, the default; 1 .. 16: measurement)
  *   "ray_hold" 0/1      : a scan's raycasting stage is held back together with its map update and runs right behind it —
  *                         in the next scan's launch sequence (the update then shares a launch with that scan's bin half) or
  *                         at the next flush (default 1; 0 = update and stage at once, the round-1..4 order)
