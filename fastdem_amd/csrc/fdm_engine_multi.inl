@@ -172,7 +172,9 @@ int launch_rbatch(fdm_engine* e, const RBatch& R) {
   // spare for a sensor off the centre; else one lane (or SEG lanes) per ray on global atomics.
   if (e->rb_lds_words == 0u) {  // (once per engine: the largest dynamic LDS a workgroup of this kernel may ask for)
     e->rb_lds_words = 16384u;   // 64 KB without asking
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_rb_ray_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_rb_ray_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            128 * 1024) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rb_ray_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             128 * 1024) == hipSuccess)
       e->rb_lds_words = 32768u;
     else
@@ -186,8 +188,12 @@ int launch_rbatch(fdm_engine* e, const RBatch& R) {
     // larger quadrant takes the kernel's global-atomic loop — or for the whole map when that is less)
     const unsigned words = unsigned(std::min<size_t>({size_t(e->rb_lds_words), size_t(e->G.rows) * size_t(e->G.cols),
                                                       e->batch_ray_words > 0 ? size_t(e->batch_ray_words) : quadrant * 2}));
-    hipLaunchKernelGGL(k_rb_ray_lds, dim3(4u * parts, R.count), dim3(kRbRayThreads), words * sizeof(uint32_t), e->stream,
-                       R, e->G, parts, words);
+    if (e->dbg_ray & (1 << 20))  // (dbg_ray 1048576, measurement only: the integer image of round 4)
+      hipLaunchKernelGGL(k_rb_ray_lds<false>, dim3(4u * parts, R.count), dim3(kRbRayThreads), words * sizeof(uint32_t),
+                         e->stream, R, e->G, parts, words);
+    else
+      hipLaunchKernelGGL(k_rb_ray_lds<true>, dim3(4u * parts, R.count), dim3(kRbRayThreads), words * sizeof(uint32_t),
+                         e->stream, R, e->G, parts, words);
   } else {
     // upper bound of a scan's queue: every point a ray, padded to whole wavefronts per segment
     auto rays = [&](auto seg) {

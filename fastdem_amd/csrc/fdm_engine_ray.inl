@@ -354,7 +354,7 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q_in, bool voxel, const fl
                          ray_list, bin_start, e->rc_min, H, parts);
       return FDM_OK;
     };
-    const bool fwin = !(e->dbg_ray & 32768);  // (dbg 32768, measurement only: the integer window of round 5)
+    const bool fwin = !(e->dbg_ray & (1 << 20));  // (dbg_ray 1048576, measurement only: the integer window of round 5)
     if (tiled) rc = fwin ? launch_wedge(k_ray_wedge<true, true>) : launch_wedge(k_ray_wedge<true, false>);
     else rc = fwin ? launch_wedge(k_ray_wedge<false, true>) : launch_wedge(k_ray_wedge<false, false>);
     if (rc) return rc;

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kRwThreads) void k_ray_wedge(const RayParams Q, con
     int s = 0;
     uint32_t dead = 0u;
     float dzw = dz;  // FWIN: NaN once the ray has ended
-    const bool no_min = (Q.dbg & 65536) != 0;  // (dbg 65536, measurement only: the window is read, never lowered)
+    const bool no_min = (Q.dbg & (1 << 21)) != 0;  // (dbg_ray 2097152, measurement only: the window is read, never lowered)
     auto walk_window = [&](auto MAJOR_R) {
       // kRwChunk visits between two looks at the window's end: u grows by at most one per step, so a lane with
       // kRwChunk rows (and steps) to spare cannot leave its rows inside a chunk; one without them leaves the window
