@@ -310,7 +310,6 @@ int fdm_engine_apply_feature_extraction(fdm_engine* e, float radius, int min_val
       e->h_feat_tab = tab;
     }
   }
-  if ((rc = upload_region(e, reg))) return rc;
   Layer* elev = find_layer(e, "elevation");
   F.lo_pct = lo_pct;
   F.hi_pct = hi_pct;
@@ -332,6 +331,9 @@ int fdm_engine_apply_feature_extraction(fdm_engine* e, float radius, int min_val
   // (the LDS-tiled kernel stages its tile straight from the records: every cell is fetched ~3.4 times, from the L2, behind
   //  other blocks' arithmetic — the copy was 17 of the call's 127 us at configs[3]; dbg_post 256: copy first, as before)
   const bool tiled_ok = pct_ok && need_lo <= 16 && need_hi <= 16 && !tab.empty() && !(e->dbg_post & 1);
+  // (the tiled kernel reads its own table only: the plain region — which the fusion stage of the same publish cycle keeps
+  //  on the device with its weights — is left alone, and neither stage uploads anything from the second cycle on)
+  if (!tiled_ok && (rc = upload_region(e, reg))) return rc;
   if (elev_s != 1 && (!tiled_ok || (e->dbg_post & 256))) {
     if ((rc = ensure_tmp(e))) return rc;
     if ((rc = copy_strided(e, e->d_tmp, 1, elev_p, elev_s))) return rc;

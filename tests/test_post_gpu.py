@@ -182,6 +182,15 @@ def test_feature_extraction_order_statistic_slots(gpu, R):
                                (0.15, 0.05, 0.95), (0.1, 0.05, 0.95), (0.3, 0.05, 0.95)):
             both((eng, ref), lambda o: (o.set_layer("elevation", el), o.apply_feature_extraction(radius, 4, lo, hi)))
             exact(eng, ref, ["step", "slope", "roughness", "curvature", "_normal_x", "_normal_y", "_normal_z"])
+        # a publish cycle runs fusion and feature extraction one after the other, again and again: each keeps its table on
+        # the device, neither disturbs the other's (and a changed parameter still uploads)
+        half = np.abs(rng.normal(0.05, 0.03, shape)).astype(F32) + F32(0.005)
+        both((eng, ref), lambda o: (o.set_layer("upper_bound", el + half), o.set_layer("lower_bound", el - half)))
+        for cycle in range(3):
+            radius = 0.3 if cycle < 2 else 0.25
+            both((eng, ref), lambda o: (o.apply_uncertainty_fusion(True, 0.15, 0.05, 0.01, 0.99, 3),
+                                        o.apply_feature_extraction(radius, 4, 0.05, 0.95)))
+            exact(eng, ref, ["upper_bound", "lower_bound", "step", "slope", "roughness", "curvature", "_normal_z"])
     finally:
         R.set_trig_mode(0)
 
