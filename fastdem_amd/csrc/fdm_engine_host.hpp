@@ -236,7 +236,8 @@ struct fdm_engine {
   // ---- batch pipeline (fdm_multi.hpp): up to kMaxBatch small scans per launch, allocated by the first batch ----
   int batch = 1;                     // option "batch": fdm_engine_integrate_device_batch groups eligible scans
   int batch_max = 0;                 // option "batch_max": scans per launch (2 .. kMaxBatch = 32); 0 = automatic: 32 with the quantile
-                                     // estimator, 16 with Kalman — measured (profiles/r06/batch_max.txt): configs[2] (P2, 272 K-point
+                                     // estimator or with raycasting on (configs[1] with it: 9.25 -> 7.78 us per scan), 16 with Kalman
+                                     // alone — measured (profiles/r06/batch_max.txt): configs[2] (P2, 272 K-point
                                      // scans) 52.8 -> 56.9 G pts/s at 32, configs[1] (Kalman, 28.8 K-point scans) 27.0 -> 26.2: that
                                      // launch is within ~2 x of its instruction-issue floor, a second round of blocks only adds its time
   int batch_fuse = 1;                // option "batch_fuse": hold a batch's update back for the next batch's bin launch

@@ -153,7 +153,7 @@ int fdm_engine_integrate_device(fdm_engine* e, uint64_t n, const float* d_x, con
  * raycast_enabled (fastdem.cpp:152-159) the stage of every scan rides in the batch as well — voxel filter, ray walks,
  * ghost resolution, each scan's behind that scan's map update (fdm_rbatch.hpp; scans of <= 64 K points on an untiled
  * engine; 9.3 us instead of 60 us per VLP-16 scan).  Scans that do not qualify take the single-scan path in place.
- * Options "batch" 0/1, "batch_max" 0 (automatic: 32 with the quantile estimator, 16 with Kalman) or 2..32, "batch_ray" 0/1. */
+ * Options "batch" 0/1, "batch_max" 0 (automatic: 32 with the quantile estimator or with raycasting on, 16 with Kalman alone) or 2..32, "batch_ray" 0/1. */
 typedef struct fdm_device_scan {
   uint64_t n;
   const float *x, *y, *z, *intensity; /* device pointers; intensity nullable */
