@@ -84,7 +84,7 @@ struct DevState {
   // event, `dense_paid` the number the last scan that OBSERVED a cell cleared for (k_obstacle_dense_clear /
   // k_obstacle_dense_paid) — a scan that observes nothing clears nothing, like the reference, and the debt stays.
   unsigned dense_owed, dense_paid;
-  unsigned pad_f;
+  unsigned ray_count_b;  // the same counter for a raycasting stage of the second context (RayParams::ctx 1: two stages in flight)
 };
 
 struct GeomConst {

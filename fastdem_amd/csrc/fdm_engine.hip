@@ -40,6 +40,8 @@ void poll_dense_paid(fdm_engine* e) {
 int sync_all(fdm_engine* e) {
   if (int rc = join_streams(e)) return rc;
   HIPCK(hipStreamSynchronize(e->stream));
+  for (hipStream_t rs : e->ray_stream)  // (every early stage part has its resolve on the main stream behind it by now: idle)
+    if (rs) HIPCK(hipStreamSynchronize(rs));
   e->bstage_busy = false;  // (the stream has drained: nothing reads the host-batch staging block any more)
   poll_dense_paid(e);
   return FDM_OK;
@@ -540,6 +542,13 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
   }
   HIPCK(hipGetLastError());
   if (e->profile) HIPCK(hipEventRecord(e->ev[1], e->stream));
+  // (option "ray_overlap": this scan's stage may start as soon as its bin half has run — marked HERE, ahead of the wait for
+  //  the previous scan's stage that run_held_ray_stage is about to put on this stream)
+  e->ray_bin_marked = false;
+  if (ray_held && e->ray_overlap && e->ray_stream[0]) {
+    HIPCK(hipEventRecord(e->ev_ray_bin, e->stream));
+    e->ray_bin_marked = true;
+  }
   // the previous scan's raycasting stage, if it was held back with the update that has just left in the fused launch:
   // behind that update, ahead of everything of this scan but its bin half (which reads no layer)
   if (fuse_now && (rc = run_held_ray_stage(e, e->pend))) return rc;
@@ -590,9 +599,12 @@ int enqueue_scan(fdm_engine* e, ScanParams& P, uint64_t n, const float* dx, cons
     u.ray_x = e->S.cap_x; u.ray_y = e->S.cap_y; u.ray_z = e->S.cap_z;
     ray_box_of(e, P, u.ray_box);
     u.ray = true;
+    u.ray_pre = 0;
     // held back with the update (plain): it runs behind it — in the next scan's launch sequence or at the next flush;
     // otherwise now, the update has just been launched
     if (!plain && (rc = run_held_ray_stage(e, u))) return rc;
+    // (option "ray_overlap": what the stage can do before the update leaves at once, on a stream of its own)
+    if (plain && (rc = start_ray_stage_early(e, u, P))) return rc;
   }
   e->scan_no++;
   e->last_batch_n = 0;
@@ -1078,6 +1090,16 @@ void fdm_engine_destroy(fdm_engine* e) {
   if (e->sort_tmp) (void)hipFree(e->sort_tmp);
   if (e->vs_cnt) (void)hipFree(e->vs_cnt);
   if (e->vs_rec) (void)hipFree(e->vs_rec);
+  {  // the second set of the raycasting stage's buffers, its streams and events (option "ray_overlap")
+    fdm_engine::RayBank& b = e->ray_bank1;
+    for (void* p : {static_cast<void*>(b.rc_cnt), static_cast<void*>(b.rc_min), static_cast<void*>(b.ray_bins),
+                    static_cast<void*>(b.vkeys[0]), static_cast<void*>(b.vkeys[1]), static_cast<void*>(b.vidx[0]),
+                    static_cast<void*>(b.vidx[1]), static_cast<void*>(b.vsel), static_cast<void*>(b.ray_blk), b.sort_tmp})
+      if (p) (void)hipFree(p);
+    for (hipStream_t rs : e->ray_stream) if (rs) (void)hipStreamDestroy(rs);
+    for (hipEvent_t ev : {e->ev_ray_pre[0], e->ev_ray_pre[1], e->ev_ray_res[0], e->ev_ray_res[1], e->ev_ray_bin})
+      if (ev) (void)hipEventDestroy(ev);
+  }
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -1242,7 +1264,10 @@ int fdm_engine_integrate(fdm_engine* e, uint64_t n, const float* x, const float*
   if (rc) return rc;
   ScanParams P;
   fill_integrate_params(e, P, Tbs, Twb);
-  if ((rc = enqueue_scan(e, P, n, dx, dy, dz, da, dc, dv, gather.x ? &gather : nullptr))) return rc;
+  e->sync_call = true;  // (the flush follows at once: the scan's raycasting stage may start beside its update, "ray_overlap")
+  rc = enqueue_scan(e, P, n, dx, dy, dz, da, dc, dv, gather.x ? &gather : nullptr);
+  e->sync_call = false;
+  if (rc) return rc;
   int status = FDM_OK;
   if ((rc = read_stats(e, out, &status))) return rc;
   return status;
@@ -1302,7 +1327,9 @@ int fdm_engine_integrate_points4(fdm_engine* e, uint64_t n, const float* xyz1, c
   // and had the bin kernel write x / y / z through to it, 12 B per point for nothing: ADVICE r05)
   const bool borrow = e->borrow_inputs;
   e->borrow_inputs = true;
+  e->sync_call = true;
   rc = enqueue_scan(e, P, n, base, base + cap, base + cap * 2, da, dc, dv);
+  e->sync_call = false;
   e->borrow_inputs = borrow;
   if (rc) return rc;
   int status = FDM_OK;

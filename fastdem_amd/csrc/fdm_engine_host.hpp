@@ -176,6 +176,30 @@ struct fdm_engine {
   // 0 = one lane per ray on memory-side atomics, k_ray<., 1>)
   int ray_wedge = 1;
   int ray_wedge_parts = 0;           // option "ray_wedge_parts": workgroups per sector (0 = by the scan's size)
+  // two stages in flight (option "ray_overlap", fdm_engine_ray.inl): the map-independent part of a large scan's stage
+  // (voxel filter, queue, walk) leaves on a stream of its own as soon as the scan's bin half has been launched, by scan
+  // parity; k_ray_resolve stays behind the scan's update on the main stream
+  int ray_overlap = 0;               // option "ray_overlap": 0 = off (default), 1 = whenever possible, -1 = for synchronous calls (whose update
+                                     // then runs beside the stage's first part) and scans of >= 1 M points.  Measured in a process of its
+                                     // own (scripts/ray_overlap_ab.py): configs[3] streamed 336 -> 290 us per scan, synchronous integrate()
+                                     // 0.344 -> 0.311 ms, configs[2] synchronous 0.106 -> 0.092 ms; a STREAM of 272 K-point scans is bound
+                                     // by the host's launches and pays for the events: 95 -> 125 us.  OFF by default because the gain
+                                     // depends on the process: HIP maps streams onto four hardware queues, and in a process that has used
+                                     // more than that (bench.py by the time of its large raycasting leg) the three streams of a stage
+                                     // share queues and the events serialise them: 339 -> 365 us (profiles/r06/ray_overlap_ab.txt)
+  bool sync_call = false;            // a synchronous entry point is running (its flush follows the enqueue at once)
+  struct RayBank {                   // the second set of the stage's buffers (ray_bank_swap)
+    uint32_t *rc_cnt = nullptr, *rc_min = nullptr, *ray_bins = nullptr;
+    unsigned long long* vkeys[2] = {nullptr, nullptr};
+    uint32_t* vidx[2] = {nullptr, nullptr};
+    uint32_t *vsel = nullptr, *ray_blk = nullptr;
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0, vcap = 0;
+  } ray_bank1;
+  hipStream_t ray_stream[2] = {nullptr, nullptr};
+  hipEvent_t ev_ray_pre[2] = {nullptr, nullptr}, ev_ray_res[2] = {nullptr, nullptr}, ev_ray_bin = nullptr;
+  bool ray_res_pending[2] = {false, false};  // ev_ray_res[k] has been recorded since the bank was last used
+  bool ray_bin_marked = false;       // ev_ray_bin was recorded behind the current scan's bin half (enqueue_scan)
   // update(t) || bin(t+1) in ONE launch (k_update_bin): the update of the last small scan is held back
   // until the next scan arrives (or any other entry point / sync flushes it); the scratch is
   // double-buffered by scan parity.
@@ -200,6 +224,8 @@ struct fdm_engine {
     unsigned upd_blocks = 0;
     // the scan's raycasting stage (fastdem.cpp:152-159), which runs right behind this update wherever that is launched
     bool ray = false;
+    int ray_pre = 0;        // 1 + context if the stage's first part already left on a ray stream (ray_overlap)
+    int ray_key_mode = 0;   // ... and what enqueue_voxel_sort left in the buffers
     RayParams RQ;
     const float *ray_x = nullptr, *ray_y = nullptr, *ray_z = nullptr;  // the scan's preprocessed cloud (d_rcap[parity])
     double ray_box[6] = {0, 0, 0, 0, 0, 0};
@@ -354,8 +380,9 @@ fdm_raycast_config ray_config_of(const fdm_config& c);
 RayParams make_ray_params(fdm_engine* e, const fdm_raycast_config& c, const float* origin, unsigned n,
                           int slot, int flag_slot);
 int enqueue_ray_stage(fdm_engine* e, const RayParams& Q, bool voxel, const float* dx, const float* dy,
-                      const float* dz, int key_mode = 0);
+                      const float* dz, int key_mode = 0, int phase = 3);  // phase: 1 = everything but k_ray_resolve, 2 = k_ray_resolve, 3 = both
 int run_held_ray_stage(fdm_engine* e, fdm_engine::PendingUpdate& u);
+int start_ray_stage_early(fdm_engine* e, fdm_engine::PendingUpdate& u, const ScanParams& P);
 // the large-scan pipeline (fdm_engine_tiled.hip)
 int ensure_tile_aux(fdm_engine* e);
 int ensure_tile_pool(fdm_engine* e, size_t records, unsigned blocks, bool has_int, bool has_col);

@@ -154,7 +154,10 @@ int fdm_engine_integrate_cloud2(fdm_engine* e, const void* data, int on_device, 
   ScanParams P;
   fill_integrate_params(e, P, Tbs, Twb);
   e->next_drop_nonfinite = 1;
-  if ((rc = enqueue_scan(e, P, n_points, base, base + cap, base + cap * 2, di, dc, nullptr))) return rc;
+  e->sync_call = true;
+  rc = enqueue_scan(e, P, n_points, base, base + cap, base + cap * 2, di, dc, nullptr);
+  e->sync_call = false;
+  if (rc) return rc;
   e->ingest_blocks = blocks;  // read_stats sums the finite counts with the scan's other statistics
   int status = FDM_OK;
   if ((rc = read_stats(e, out, &status))) return rc;

@@ -288,6 +288,12 @@ int fdm_engine_set_option(fdm_engine* e, const char* key, int value) {
     e->ray_wedge = value != 0;
     return FDM_OK;
   }
+  if (std::strcmp(key, "ray_overlap") == 0) {  // two raycasting stages of large scans in flight (fdm_engine_ray.inl)
+    if (value < -1 || value > 1) return fail(FDM_ERR_INVALID, "ray_overlap: -1 (automatic), 0, 1");
+    if (int rc = sync_all(e)) return rc;
+    e->ray_overlap = value;
+    return FDM_OK;
+  }
   if (std::strcmp(key, "ray_wedge_parts") == 0) {  // workgroups per sector of k_ray_wedge (0 = by the scan's size)
     if (value < 0 || value > 16) return fail(FDM_ERR_INVALID, "ray_wedge_parts: 0 .. 16");
     if (int rc = join_streams(e)) return rc;

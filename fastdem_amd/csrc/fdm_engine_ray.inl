@@ -242,17 +242,64 @@ RayParams make_ray_params(fdm_engine* e, const fdm_raycast_config& c, const floa
   Q.vis_stamp = 3u * unsigned(e->scan_no) + (flag_slot >= 0 ? 3u : 1u);
   Q.dbg = e->dbg_ray;
   Q.by_sector = 0;
+  Q.ctx = 0;
+  Q.pre_slot = -1;
+  Q.pre_do_move = Q.pre_gate = 0;
   return Q;
+}
+
+// ---- two raycasting stages in flight (option "ray_overlap", large scans held back with their update) ----
+// The stage's buffers live in the engine's members; a second set is swapped in and out around the launches of a stage
+// of the other context (bank 1), so that every helper keeps working on "the" members.
+void ray_bank_swap(fdm_engine* e) {
+  fdm_engine::RayBank& b = e->ray_bank1;
+  std::swap(e->rc_cnt, b.rc_cnt); std::swap(e->rc_min, b.rc_min); std::swap(e->ray_bins, b.ray_bins);
+  std::swap(e->vkeys[0], b.vkeys[0]); std::swap(e->vkeys[1], b.vkeys[1]);
+  std::swap(e->vidx[0], b.vidx[0]); std::swap(e->vidx[1], b.vidx[1]);
+  std::swap(e->vsel, b.vsel); std::swap(e->ray_blk, b.ray_blk);
+  std::swap(e->sort_tmp, b.sort_tmp); std::swap(e->sort_tmp_bytes, b.sort_tmp_bytes);
+  std::swap(e->vcap, b.vcap);
+}
+struct RayBankScope {  // bank `ctx` is the live one inside the scope
+  fdm_engine* e;
+  bool swapped;
+  RayBankScope(fdm_engine* e_, int ctx) : e(e_), swapped(ctx == 1) { if (swapped) ray_bank_swap(e); }
+  ~RayBankScope() { if (swapped) ray_bank_swap(e); }
+};
+int ensure_ray_streams(fdm_engine* e) {
+  if (e->ray_stream[0]) return FDM_OK;
+  for (int k = 0; k < 2; ++k) {
+    HIPCK(hipStreamCreateWithFlags(&e->ray_stream[k], hipStreamNonBlocking));
+    HIPCK(hipEventCreateWithFlags(&e->ev_ray_pre[k], hipEventDisableTiming));
+    HIPCK(hipEventCreateWithFlags(&e->ev_ray_res[k], hipEventDisableTiming));
+  }
+  HIPCK(hipEventCreateWithFlags(&e->ev_ray_bin, hipEventDisableTiming));
+  return FDM_OK;
 }
 
 // processScan + resolveGhostCells on the stream.  voxel: the points are vkeys[1]/vidx[1] runs.
 int enqueue_ray_stage(fdm_engine* e, const RayParams& Q_in, bool voxel, const float* dx, const float* dy,
-                      const float* dz, int key_mode) {
+                      const float* dz, int key_mode, int phase) {
   int rc;
   RayParams Q = Q_in;
   if ((rc = ensure_ray_cells(e))) return rc;
   Layer* elev = find_layer(e, "elevation");
   if (!elev) return FDM_OK;  // raycasting.cpp:213-216
+  if (phase == 2) {  // (the first part left earlier, on a ray stream: start_ray_stage_early)
+    RayLayers L{};
+    L.elevation = lptr(e, *elev);
+    L.elevation_stride = lstride(e, *elev);
+    L.logodds = find_layer(e, "_visibility_logodds")->d;
+    L.ray_min = find_layer(e, "raycasting")->d;
+    L.ghost = find_layer(e, "ghost_removal")->d;
+    L.rec = e->d_rec;
+    L.rec_floats = e->rec_floats;
+    hipLaunchKernelGGL(k_ray_resolve, dim3(unsigned((e->ncell + 255) / 256)), dim3(256), 0, e->stream, Q,
+                       e->G, e->d_state, L, e->d_layer_ptrs, e->n_layer_ptrs, e->rc_cnt, e->rc_min,
+                       unsigned(e->ncell));
+    HIPCK(hipGetLastError());
+    return FDM_OK;
+  }
   RayLayers L{};
   L.elevation = lptr(e, *elev);
   L.elevation_stride = lstride(e, *elev);
@@ -366,6 +413,7 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q_in, bool voxel, const fl
     tiled ? launch_ray(k_ray<true, 1>, 1u) : launch_ray(k_ray<false, 1>, 1u);
   }
   HIPCK(hipGetLastError());
+  if (phase == 1) return FDM_OK;
   hipLaunchKernelGGL(k_ray_resolve, dim3(unsigned((e->ncell + 255) / 256)), dim3(256), 0, e->stream, Q,
                      e->G, e->d_state, L, e->d_layer_ptrs, e->n_layer_ptrs, e->rc_cnt, e->rc_min,
                      unsigned(e->ncell));
@@ -376,10 +424,73 @@ int enqueue_ray_stage(fdm_engine* e, const RayParams& Q_in, bool voxel, const fl
 // The raycasting stage of a scan of integrate(), on the map its update — launched just before — leaves: voxel filter
 // of the scan's preprocessed cloud, processScan, resolveGhostCells.  Everything it needs was fixed when the scan was
 // enqueued (PendingUpdate::RQ, the cloud of the scan's parity): it may run after the NEXT scan's bin half.
+// Option "ray_overlap": the part of a large scan's stage that needs the scan and the map GEOMETRY only — voxel filter,
+// ray queue, walk — is launched when the scan's bin half has been, on the ray stream of the scan's parity, with the
+// geometry derived as the update will commit it (RayParams::pre_slot).  Stages of consecutive scans then run beside
+// each other (and beside the fused launches of the main stream); k_ray_resolve stays where it was: behind the scan's
+// update, ahead of the next one, on the main stream, which waits for the early part there.
+int start_ray_stage_early(fdm_engine* e, fdm_engine::PendingUpdate& u, const ScanParams& P) {
+  u.ray_pre = 0;
+  const bool want = e->ray_overlap > 0 || (e->ray_overlap < 0 && (e->sync_call || u.RQ.n >= 1000000u));
+  if (!want || !u.ray || u.RQ.n < unsigned(e->ray_large_min) || e->profile || !e->ray_wedge) return FDM_OK;
+  if (e->voxel_small && u.RQ.n <= unsigned(e->voxel_small_max)) return FDM_OK;  // (the sort-free filter keeps state of its own)
+  if (!find_layer(e, "elevation")) return FDM_OK;
+  int rc;
+  if ((rc = ensure_ray_streams(e))) return rc;
+  const int ctx = int(P.scan_no & 1u);
+  bool fresh = false;
+  {  // allocations (they may drain the streams and, with them, flush this very scan: then the stage has run) before anything is enqueued
+    RayBankScope bank(e, ctx);
+    fresh = e->rc_cnt == nullptr || u.RQ.n > e->vcap;
+    if ((rc = ensure_ray_cells(e)) || (rc = ensure_voxel_buffers(e, u.RQ.n))) return rc;
+  }
+  if (!u.ray || !e->chain) return FDM_OK;
+  hipStream_t rs = e->ray_stream[ctx];
+  // the scan's bin half (and everything before it): marked right behind that launch (enqueue_scan) — a mark taken here
+  // would also wait for the previous scan's stage, whose resolve has been put on the main stream since
+  if (fresh || !e->ray_bin_marked) HIPCK(hipEventRecord(e->ev_ray_bin, e->stream));
+  HIPCK(hipStreamWaitEvent(rs, e->ev_ray_bin, 0));
+  if (e->ray_res_pending[ctx]) HIPCK(hipStreamWaitEvent(rs, e->ev_ray_res[ctx], 0));  // the bank's previous stage has been resolved
+  RayParams Q = u.RQ;
+  Q.ctx = ctx;
+  Q.pre_slot = P.slot;
+  Q.pre_do_move = P.do_move;
+  Q.pre_gate = P.gate_on_filter;
+  hipStream_t main_stream = e->stream;
+  int key_mode = 0;
+  {
+    RayBankScope bank(e, ctx);
+    e->stream = rs;
+    rc = enqueue_voxel_sort(e, Q.n, static_cast<float>(e->G.res), Q.flag_slot, u.ray_x, u.ray_y, u.ray_z, u.ray_box, &key_mode);
+    if (!rc) rc = enqueue_ray_stage(e, Q, true, u.ray_x, u.ray_y, u.ray_z, key_mode, 1);
+    e->stream = main_stream;
+  }
+  if (rc) return rc;
+  HIPCK(hipEventRecord(e->ev_ray_pre[ctx], rs));
+  u.RQ = Q;
+  u.ray_pre = 1 + ctx;
+  u.ray_key_mode = key_mode;
+  return FDM_OK;
+}
+
 int run_held_ray_stage(fdm_engine* e, fdm_engine::PendingUpdate& u) {
   if (!u.ray) return FDM_OK;
   u.ray = false;
   int rc;
+  if (u.ray_pre) {  // the first part is on its way (start_ray_stage_early): wait for it here, resolve
+    const int ctx = u.ray_pre - 1;
+    u.ray_pre = 0;
+    HIPCK(hipStreamWaitEvent(e->stream, e->ev_ray_pre[ctx], 0));
+    {
+      RayBankScope bank(e, ctx);
+      rc = enqueue_ray_stage(e, u.RQ, true, u.ray_x, u.ray_y, u.ray_z, u.ray_key_mode, 2);
+    }
+    if (rc) return rc;
+    HIPCK(hipEventRecord(e->ev_ray_res[ctx], e->stream));
+    e->ray_res_pending[ctx] = true;
+    e->ray_timed = false;
+    return FDM_OK;
+  }
   if (e->profile) HIPCK(hipEventRecord(e->ev_ray[0], e->stream));
   int key_mode = 0;
   if ((rc = enqueue_voxel_sort(e, u.RQ.n, static_cast<float>(e->G.res), u.RQ.flag_slot, u.ray_x, u.ray_y, u.ray_z,

@@ -45,7 +45,25 @@ struct RayParams {
   unsigned vis_stamp;   // DevState::vis_ray value if this is the first frame that runs
   int dbg;              // measurement only: 1 = no atomics in k_ray, 2 = no loads either
   int by_sector;        // 1: queue ordered (sector of equal true angle, coarse length class) for k_ray_wedge (fdm_raywedge.hpp)
+  // Two stages in flight (option "ray_overlap"): everything of a stage but k_ray_resolve may run BEFORE the scan's update,
+  // beside the next scans' launches.  The geometry it runs on is then derived as the update will commit it (make_ctx):
+  // geom[pre_slot], moved to cand[pre_slot] iff pre_do_move and (not pre_gate or flags[pre_slot].any_pass).
+  int ctx;              // which of the two queue counters (DevState::ray_count / ray_count_b) and buffer sets
+  int pre_slot;         // >= 0: derive the geometry from this ring slot (the scan's own); -1: geom[slot] is there
+  int pre_do_move, pre_gate;
 };
+__device__ __forceinline__ DevGeom ray_geom(const DevState* __restrict__ st, const RayParams& Q) {
+  if (Q.pre_slot < 0) return st->geom[Q.slot];
+  DevGeom g = st->geom[Q.pre_slot];
+  if (Q.pre_do_move && (!Q.pre_gate || st->flags[Q.pre_slot].any_pass != 0u)) {
+    const DevCand c = st->cand[Q.pre_slot];
+    g.px = c.px; g.py = c.py; g.sr = c.sr; g.sc = c.sc;
+  }
+  return g;
+}
+__device__ __forceinline__ unsigned* ray_counter(DevState* __restrict__ st, const RayParams& Q) {
+  return Q.ctx ? &st->ray_count_b : &st->ray_count;
+}
 
 // voxel::pack.  float -> int32 outside the int range is UB in C++; the reference's x86 build
 // (cvttss2si) produces INT_MIN for both signs, restated here explicitly.
@@ -616,11 +634,11 @@ __global__ __launch_bounds__(256) void k_ray_compact(const RayParams Q, const Ge
                                                      uint32_t* __restrict__ ray_rank,
                                                      uint32_t* __restrict__ bin_cnt,
                                                      uint32_t* __restrict__ blk_cnt) {
-  const DevGeom g = st->geom[Q.slot];
+  const DevGeom g = ray_geom(st, Q);
   if (!ray_stage_runs(Q, st, g, G)) return;
   if (blockIdx.x == 0 && threadIdx.x == 0 && st->vis_ray == 0u)
     st->vis_ray = Q.vis_stamp;  // the three layers become visible (raycasting.cpp:223-226)
-  ray_compact_body<VOXEL, PTS>(Q, G, g, x, y, z, sel, rc_cnt, ray_list, ray_key, ray_rank, bin_cnt, &st->ray_count,
+  ray_compact_body<VOXEL, PTS>(Q, G, g, x, y, z, sel, rc_cnt, ray_list, ray_key, ray_rank, bin_cnt, ray_counter(st, Q),
                                bin_cnt ? blk_cnt : nullptr, blockIdx.x);
 }
 
@@ -632,7 +650,7 @@ inline __global__ __launch_bounds__(256) void k_ray_bin_sum(const RayParams Q, c
                                                      const uint32_t* __restrict__ bin_cnt,
                                                      uint32_t* __restrict__ bin_part) {
   __shared__ unsigned s_w[4];
-  const DevGeom g = st->geom[Q.slot];
+  const DevGeom g = ray_geom(st, Q);
   if (!ray_stage_runs(Q, st, g, G)) return;
   const uint4 c = reinterpret_cast<const uint4*>(bin_cnt)[blockIdx.x * 256u + threadIdx.x];
   unsigned v = c.x + c.y + c.z + c.w;
@@ -649,7 +667,7 @@ inline __global__ __launch_bounds__(256) void k_ray_bin_scan(const RayParams Q, 
                                                       const uint32_t* __restrict__ bin_part,
                                                       uint32_t* __restrict__ bin_start) {
   __shared__ unsigned s_w[4], s_p[4];
-  const DevGeom g = st->geom[Q.slot];
+  const DevGeom g = ray_geom(st, Q);
   if (!ray_stage_runs(Q, st, g, G)) return;
   static_assert(kRayBins / kRayBinBlock == 256u, "one partial sum per thread");
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -677,7 +695,7 @@ inline __global__ __launch_bounds__(256) void k_ray_bin_scan(const RayParams Q, 
   o.z = o.y + c.y;
   o.w = o.z + c.z;
   reinterpret_cast<uint4*>(bin_start)[blockIdx.x * 256u + threadIdx.x] = o;
-  if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 255u) st->ray_count = o.w + c.w;  // (the queue's length)
+  if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 255u) *ray_counter(st, Q) = o.w + c.w;  // (the queue's length)
 }
 
 // the same in ONE launch for the (sector, length class) order of k_ray_wedge, whose 8 K buckets one workgroup scans:
@@ -688,7 +706,7 @@ inline __global__ __launch_bounds__(kRayScan1Threads) void k_ray_bin_scan1(const
                                                                     uint32_t* __restrict__ bin_cnt,
                                                                     uint32_t* __restrict__ bin_start) {
   __shared__ unsigned s_w[kRayScan1Threads / 64u];
-  const DevGeom g = st->geom[Q.slot];
+  const DevGeom g = ray_geom(st, Q);
   if (!ray_stage_runs(Q, st, g, G)) return;
   const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
   uint4* const cnt4 = reinterpret_cast<uint4*>(bin_cnt) + threadIdx.x * (kRayScan1Per / 4u);
@@ -721,7 +739,7 @@ inline __global__ __launch_bounds__(kRayScan1Threads) void k_ray_bin_scan1(const
     run = o.w + c[j].w;
     out4[j] = o;
   }
-  if (threadIdx.x == kRayScan1Threads - 1u) st->ray_count = run;  // (the queue's length: the sum of all buckets)
+  if (threadIdx.x == kRayScan1Threads - 1u) *ray_counter(st, Q) = run;  // (the queue's length: the sum of all buckets)
 }
 
 inline __global__ __launch_bounds__(256) void k_ray_scatter(const RayParams Q, const GeomConst G,
@@ -732,7 +750,7 @@ inline __global__ __launch_bounds__(256) void k_ray_scatter(const RayParams Q, c
                                                      const uint32_t* __restrict__ bin_start,
                                                      const uint32_t* __restrict__ blk_cnt, const unsigned block_points,
                                                      uint32_t* __restrict__ ray_sorted) {
-  const DevGeom g = st->geom[Q.slot];
+  const DevGeom g = ray_geom(st, Q);
   if (!ray_stage_runs(Q, st, g, G)) return;
   // block b of the queue builder left blk_cnt[b] rays at the start of its region
   const unsigned cnt = blk_cnt[blockIdx.x], base = blockIdx.x * block_points;
@@ -933,8 +951,8 @@ __global__ __launch_bounds__(256) void k_ray(const RayParams Q, const GeomConst 
                                              const float* __restrict__ z,
                                              const uint32_t* __restrict__ ray_list,
                                              uint32_t* __restrict__ rc_min) {
-  const unsigned n_rays = st->ray_count;
-  const DevGeom g = st->geom[Q.slot];
+  const unsigned n_rays = *ray_counter(st, Q);
+  const DevGeom g = ray_geom(st, Q);
   ray_walk_body<TILED, SEG>(Q, G, g, n_rays, x, y, z, ray_list, rc_min, blockIdx.x * 256u + threadIdx.x);
 }
 
@@ -970,7 +988,7 @@ inline __global__ __launch_bounds__(256) void k_ray_resolve(const RayParams Q, c
   const DevGeom g = st->geom[Q.slot];
   if (!ray_stage_runs(Q, st, g, G)) return;
   const unsigned o = blockIdx.x * 256u + threadIdx.x;
-  if (o == 0) st->ray_count = 0u;  // the queue is consumed
+  if (o == 0) *ray_counter(st, Q) = 0u;  // the queue is consumed
   if (o >= ncell) return;
   const float nanv = __uint_as_float(0x7FC00000u);
   const uint32_t cnt = rc_cnt[o];

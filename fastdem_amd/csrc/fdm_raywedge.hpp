@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kRwThreads) void k_ray_wedge(const RayParams Q, con
                                                           uint32_t* __restrict__ rc_min, const unsigned H,
                                                           const unsigned parts) {
   extern __shared__ uint32_t s_win[];  // [H][kRwCols] (the window starts at LDS address 0)
-  const unsigned n_rays = st->ray_count;
+  const unsigned n_rays = *ray_counter(st, Q);
   if (n_rays == 0u) return;
   if (FWIN && uint32_t(uintptr_t((__attribute__((address_space(3))) uint32_t*)s_win)) != 0u) __builtin_trap();
   // the sector's stretch of the queue (bin_start: first queue position of every (sector, length class) bucket)
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kRwThreads) void k_ray_wedge(const RayParams Q, con
   const unsigned q_lo = bin_start[sector * kRaySectorClasses];
   const unsigned q_hi = sector + 1u < kRaySectors ? bin_start[(sector + 1u) * kRaySectorClasses] : n_rays;
   if (q_lo + part * kRwThreads >= q_hi) return;  // (an empty sector, or a share beyond its rays)
-  const DevGeom g = st->geom[Q.slot];
+  const DevGeom g = ray_geom(st, Q);
   const float sx = Q.ox, sy = Q.oy, sz = Q.oz;
   const float res = Q.resolution;
   const int nrows = G.rows, ncols = G.cols;

@@ -73,6 +73,7 @@ __device__ __forceinline__ RayParams rb_params(const RBatch& R, const unsigned k
   Q.resolution = R.resolution;
   Q.n = R.n[k];
   Q.slot = 0; Q.flag_slot = -1; Q.vis_stamp = 0u;
+  Q.pre_slot = -1;
   Q.dbg = R.dbg;
   return Q;
 }

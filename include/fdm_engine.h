@@ -501,6 +501,10 @@ int fdm_engine_last_kernel_ms(fdm_engine* e, float* ms2);
  *                         ordered by (angular sector, length class)
  *   "ray_wedge" 0/1     : ... and walks it with the sector's minimum-height window in LDS (fdm_raywedge.hpp, default 1;
  *                         0 = one lane per ray on memory-side atomics)
+ *   "ray_overlap" -1/0/1: the stage's map-independent part (voxel filter, queue, walk) of a large scan leaves on a stream of its
+ *                         own as soon as the scan's bin half has run, its resolve stays behind the scan's update (0, default:
+ *                         never; 1 whenever possible; -1 for synchronous calls and scans of >= 1 M points).  Worth 10-14 % in a
+ *                         process with few active streams, a loss in one with many
  *   "ray_wedge_parts" n : workgroups per sector of that walk (0 = by the scan's size, the default; 1 .. 16: measurement)
  *   "ray_hold" 0/1      : a scan's raycasting stage is held back together with its map update and runs right behind it —
  *                         in the next scan's launch sequence (the update then shares a launch with that scan's bin half) or

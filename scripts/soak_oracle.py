@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Long soak of the engine against the ORACLE: the generator of tests/test_long_horizon_gpu.py, more seeds, more scans.
     python scripts/soak_oracle.py [seconds] [first seed] [scans per seed] [tiled_all] [extra]
+`key=value`: engine options for every engine (e.g. ray_overlap=1 voxel_small=0: two raycasting stages in flight for every scan).
 `extra`: between the calls, with a generator of its own, also GridMap::move() explicitly, ElevationMapping::update() directly
 (no transforms, no crops; with and without a per-point variance channel), inpainting, median smoothing and uncertainty fusion
 (they write layers the next scans and compares see).
@@ -85,6 +86,7 @@ def main():
     while time.perf_counter() - t0 < budget:
         T.N_SCANS[seed] = per
         base = {"tiled_min": 1, "ray_large_min": 1} if out["variant"] == "tiled_all" else {}
+        base.update({a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[4:] if "=" in a})   # (e.g. ray_overlap=1 voxel_small=0)
         gpu.Engine.default_options = dict(base, batch_max=32) if seed % 2 else base   # (every other seed: 32 scans per launch also with Kalman)
         if EXTRA:
             install_extra(seed)

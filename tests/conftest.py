@@ -35,5 +35,9 @@ def gpu(request):
     fastdem_amd.capi.load()
     saved = dict(fastdem_amd.Engine.default_options)
     fastdem_amd.Engine.default_options = {"tiled_min": 1, "ray_large_min": 1} if request.param == "tiled_all" else {}
+    # (test campaigns of a switch that is off by default, e.g. FDM_TEST_EXTRA_OPTIONS="ray_overlap=1,voxel_small=0": read by
+    #  the TEST harness, handed to the engines as options like the variant's own)
+    for kv in filter(None, os.environ.get("FDM_TEST_EXTRA_OPTIONS", "").split(",")):
+        fastdem_amd.Engine.default_options[kv.split("=")[0]] = int(kv.split("=")[1])
     yield fastdem_amd
     fastdem_amd.Engine.default_options = saved

@@ -467,6 +467,55 @@ class TestIntegrateWithRaycasting:
         wl = gpu.synth.lidar128(n_scans=2, order=order)
         run_ray_workload(gpu, R, wl, 2, ghosts=plant_ghost_block, rc_log_odds_ghost=1.2)
 
+    @pytest.mark.parametrize("overlap", [1, 0, -1])
+    def test_two_stages_in_flight(self, gpu, R, overlap):
+        """Option ray_overlap: voxel filter, queue and walk of a large scan leave on a stream of their own as soon as the
+        scan's bin half has run — on the geometry its update WILL commit (moves, a scan that moves nothing because every
+        point is filtered) — while k_ray_resolve stays behind the update; stages of consecutive scans overlap by scan
+        parity.  Streams of enqueue-only calls, synchronous calls in between, a flush in the middle of the stream, scans
+        whose sizes differ (the buffers of either parity grow at different times): every layer equals the oracle's."""
+        def fill(cfg):
+            cfg.z_min, cfg.z_max, cfg.range_min, cfg.range_max = -2.0, 4.0, 0.2, 14.0
+            return ray_cfg(rc_log_odds_ghost=0.8, rc_clear_threshold=-1.0)(cfg)
+        eng, ref = pair(gpu, R, 24.0, 24.0, 0.1, fill)
+        eng.set_option("ray_overlap", overlap)
+        eng.set_option("ray_large_min", 1)      # every scan takes the large path ...
+        eng.set_option("voxel_small", 0)        # ... and the sort (the sort-free filter never overlaps)
+        rng = np.random.default_rng(101 + overlap)
+        Tbs = np.eye(4)
+        Tbs[2, 3] = 1.1
+        sizes = (30000, 1200, 52000, 52000, 7, 40000, 90000, 90000, 3000, 61000, 61000, 20000)
+        scans, poses = [], []
+        for k, n in enumerate(sizes):
+            x = rng.uniform(-11.0, 11.0, n).astype(F32)
+            y = rng.uniform(-11.0, 11.0, n).astype(F32)
+            z = (rng.uniform(-1.0, 0.5, n) - 1.1).astype(F32)
+            if k == 4:
+                z[:] = 50.0   # everything filtered: no move, no stage
+            if k % 3 == 1:    # a ghost block for the stage to find
+                x[: n // 10] = F32(3.0) + rng.uniform(0, 0.5, n // 10).astype(F32)
+                y[: n // 10] = F32(-2.0) + rng.uniform(0, 0.5, n // 10).astype(F32)
+                z[: n // 10] = F32(0.9 - 1.1)
+            T = np.eye(4)
+            T[0, 3], T[1, 3] = 0.37 * k, -0.23 * k   # LOCAL map: a move of a few cells with every scan
+            scans.append({"x": x, "y": y, "z": z, "intensity": rng.uniform(0, 1, n).astype(F32), "rgb": None})
+            poses.append(T)
+        for s_, T in zip(scans, poses):
+            ref.integrate(s_["x"], s_["y"], s_["z"], Tbs, T, intensity=s_["intensity"])
+        from test_batch_gpu import DeviceBatch
+        b = DeviceBatch(gpu, scans[:5], Tbs, poses[:5])
+        assert eng.integrate_device_batch(b.arr) == 0                      # a stream of enqueue-only scans
+        eng.integrate(scans[5]["x"], scans[5]["y"], scans[5]["z"], Tbs, poses[5], intensity=scans[5]["intensity"])  # synchronous
+        b2 = DeviceBatch(gpu, scans[6:9], Tbs, poses[6:9])
+        assert eng.integrate_device_batch(b2.arr) == 0
+        eng.sync()                                                          # a flush with a stage in flight
+        b3 = DeviceBatch(gpu, scans[9:], Tbs, poses[9:])
+        for k in range(len(scans) - 9):                                     # one enqueue-only call per scan
+            one = (gpu.capi.FdmDeviceScan * 1)(b3.arr[k])
+            assert eng.integrate_device_batch(one) == 0
+        assert_layers_equal(eng, ref)
+        assert ref.last_ray_stats()["n_rays"] > 1000
+
     def test_per_layer_storage(self, gpu, R):
         wl = gpu.synth.vlp16(n_scans=4)
 
